@@ -1,0 +1,371 @@
+// mnav_eval.h -- per-vertex evaluation rules and band controller of the wavefront engine.
+//
+// Shared between the HIP kernels (mnav_kernels.hip) and the CPU schedule model that the
+// test-suite uses to check the *schedule* against the sequential oracle (oracle/
+// schedule_model.cpp, test infrastructure).  No HIP intrinsics in here; atomics and list
+// pushes are injected by the caller.
+//
+// Engine in one paragraph: both reference planners are ordered wavefronts
+// driven by a priority queue (dijkstra_mesh_planner.cpp:287-348, cvp_mesh_planner.cpp:747-886).
+// We replace the queue by distance *bands*: all vertices whose pop time falls in
+// [thr_fixed, thr) are settled together by iterating a per-vertex GATHER rule to its fixed
+// point, then the band advances.  The gather rule recomputes a vertex from scratch out of the
+// state of its neighbours and reproduces what the sequential loop would have done to that
+// vertex: for Dijkstra a min over expanded neighbours (order-free), for CVP a replay of the
+// incident-face updates in the order in which their triggering vertices pop.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MNAV_HD __host__ __device__ __forceinline__
+#else
+#define MNAV_HD inline
+#endif
+
+namespace mnav {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// MBF GetPath result codes, dijkstra_mesh_planner.h:72-85
+enum : uint32_t { kSuccess = 0, kCanceled = 51, kInvalidStart = 52, kInvalidGoal = 53, kNoPathFound = 54,
+                  kInternalError = 59 };
+
+enum : uint32_t { kPlannerDijkstra = 0, kPlannerCvp = 1 };
+
+// One directed CSR entry of the SSSP gather graph: row v holds {u, w(u,v)} for every
+// neighbour u.  w is +inf when u may never act as a source for v (v invalid, or
+// vertex_costs[u] > cost_limit: dijkstra_mesh_planner.cpp:302,328).
+struct Nbr { uint32_t u; float w; };
+
+// One incident-face corner of vertex v3 (CVP).  (v1,v2,v3) is the cyclic rotation of the
+// face with v3 last (cvp_mesh_planner.cpp:811,834,857); a=w(v2,v3), b=w(v1,v3), c=w(v1,v2)
+// (cvp_mesh_planner.cpp:380-390).  v1 == kNone marks a face that must be skipped because one
+// of its vertices is invalid (cvp_mesh_planner.cpp:785).
+struct Corner { uint32_t v1, v2; float a, b, c; uint32_t face; };
+
+MNAV_HD float u2f(uint32_t u) { union { uint32_t u; float f; } x; x.u = u; return x.f; }
+MNAV_HD uint32_t f2u(float f) { union { uint32_t u; float f; } x; x.f = f; return x.u; }
+MNAV_HD float inf_f() { return u2f(0x7f800000u); }
+MNAV_HD float next_up(float x) { return (x >= 0.0f) ? u2f(f2u(x) + 1u) : u2f(f2u(x) - 1u); }  // finite x
+
+// ---------------------------------------------------------------------------------------
+// CVP triangle update, cvp_mesh_planner.cpp:369-556, on plain numbers.  float64 arithmetic,
+// float32 result, no FMA contraction (build with -ffp-contract=off).
+// ---------------------------------------------------------------------------------------
+struct CvpUpd { float u3; float dir; int sel; bool ok; };  // sel: 1 -> pred=v1, 2 -> pred=v2
+
+MNAV_HD CvpUpd cvp_update(float u1f, float u2f_, float u3f, float af, float bf, float cf)
+{
+  CvpUpd r; r.ok = false; r.u3 = u3f; r.dir = 0.0f; r.sel = 0;
+  const double u1 = u1f, u2 = u2f_, u3 = u3f;              // :376-378
+  const double c = cf, c_sq = c * c;                        // :381-382
+  const double b = bf, b_sq = b * b;                        // :385-386
+  const double a = af, a_sq = a * a;                        // :389-390
+  const double u1_sq = u1 * u1, u2_sq = u2 * u2;            // :392-393
+  const double sx = (c_sq + u1_sq - u2_sq) / (2 * c);       // :395
+  const double sy = -sqrt(fmax(u1_sq - sx * sx, 0.0));      // :396
+  const double p = (b_sq + c_sq - a_sq) / (2 * c);          // :398
+  const double hc = sqrt(fmax(b_sq - p * p, 0.0));          // :399
+  const double dy = hc - sy, dx = p - sx;                   // :401-402
+  const double u3tmp_sq = dx * dx + dy * dy;                // :404
+  double u3tmp = sqrt(u3tmp_sq);                            // :405
+  if (!(u3tmp < u3)) return r;                              // :411
+  const double t0a = (a_sq + b_sq - c_sq) / (2 * a * b);            // :413
+  const double t1a = (u3tmp_sq + b_sq - u1_sq) / (2 * u3tmp * b);   // :414
+  const double t2a = (a_sq + u3tmp_sq - u2_sq) / (2 * a * u3tmp);   // :415
+  int fallback = 0;                                         // 1 -> u1+b, 2 -> u2+a
+  if (fabs(t1a) > 1) fallback = 1;                          // :418
+  else if (fabs(t2a) > 1) fallback = 2;                     // :437
+  else {
+    const double theta0 = acos(t0a), theta1 = acos(t1a), theta2 = acos(t2a);  // :456-458
+    if (theta1 < theta0 && theta2 < theta0) {               // :493
+      r.ok = true; r.u3 = (float)u3tmp;                     // :497
+      if (theta1 < theta2) { r.sel = 1; r.dir = (float)theta1; }     // :498-501
+      else { r.sel = 2; r.dir = (float)(-theta2); }                  // :507-510
+      return r;
+    }
+    fallback = (theta1 < theta2) ? 1 : 2;                   // :518 / :536
+  }
+  u3tmp = (fallback == 1) ? (u1 + b) : (u2 + a);            // :420,439,520,538
+  if (u3tmp < u3) { r.ok = true; r.u3 = (float)u3tmp; r.sel = fallback; r.dir = 0.0f; }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-plan control block.  Two copies ping-pong between consecutive steps (step j reads
+// slot (j-1)&1 and block 0 writes slot j&1); three counter blocks rotate (step j counts
+// into j%3, reads (j-1)%3, clears (j+1)%3).  See DESIGN.md §3.3.
+// ---------------------------------------------------------------------------------------
+struct Ctl {
+  int32_t it;          // index of the step that produced this block (-1 = initial state)
+  uint32_t n;          // entries in the work list that step `it` processes
+  float thr;           // band upper bound: pop times < thr are settled by this band
+  float thr_fixed;     // pop times < thr_fixed are final (bands completed so far)
+  float goal_dist;     // +inf until armed (dijkstra :296 / cvp :769)
+  uint32_t armed;
+  uint32_t done;
+  uint32_t band_new;   // 1 on the first step of a band
+  uint32_t bands;      // statistics
+  uint32_t overflow;   // work-list overflow (never with capacity V; reported as internal error)
+  uint32_t repair;     // this step is the post-arming repair sweep over all vertices
+  uint32_t pad;
+};
+
+struct Cnt {
+  uint32_t n_next;     // entries pushed to the next work list
+  uint32_t changed;    // in-band vertices whose (dist, pop time) changed this step
+  uint32_t minkey;     // min pop time (float bits) over retained out-of-band entries
+  uint32_t evals;      // statistics: vertex evaluations
+};
+
+// Constant per-plan parameters + state pointers.  All pointers address the plan's own slices.
+struct Plan {
+  uint32_t planner;        // kPlannerDijkstra / kPlannerCvp
+  uint32_t V;
+  // shared read-only mesh data
+  const uint32_t* row_ptr; // V+1 (Dijkstra gather CSR)
+  const Nbr* nbr;          // 2E
+  const uint32_t* crn_ptr; // V+1 (CVP corners)
+  const Corner* crn;       // 3F
+  const uint8_t* blocked;  // V: CVP free-vertex gate (cost >= limit || invalid), cvp :760,802,825,848
+  // per-plan state
+  float* dist;             // V  potential
+  float* tpop;             // V  pop time (CVP only; Dijkstra aliases dist)
+  uint32_t* pred;          // V
+  float* dirn;             // V  (CVP)
+  uint32_t* cutf;          // V  (CVP)
+  uint32_t* stamp;         // V  work-list dedup
+  uint32_t* list[2];       // work lists, capacity `cap`
+  uint32_t cap;
+  Ctl* ctl;                // [2]
+  Cnt* cnt;                // [3]
+  // parameters
+  float delta;             // band width
+  double offset;           // goal_dist_offset
+  uint32_t seed[3];        // wave seed vertices (Dijkstra: seed[0], others kNone)
+  uint32_t seed_expands[3];// seed passes the cost/invalid cut-offs (cvp :757,760)
+  uint32_t target[3];      // robot vertex / robot-face vertices
+  uint32_t target_expands[3];
+  uint32_t max_steps;
+};
+
+MNAV_HD bool is_seed(const Plan& P, uint32_t v) { return v == P.seed[0] || v == P.seed[1] || v == P.seed[2]; }
+
+// --- arming of goal_dist once the robot vertex / robot face is settled -----------------------
+// Dijkstra: goal_dist = dist[target] + offset when the target pops (dijkstra :293-297).
+// CVP: when a robot-face vertex pops that passes the cut-offs while all three are fixed
+// (cvp :757-771); seeds are fixed from the start (cvp :726).
+MNAV_HD void try_arm(const Plan& P, Ctl& q)
+{
+  if (P.planner == kPlannerDijkstra) {
+    const uint32_t t = P.target[0];
+    if (t == kNone) return;
+    const float d = P.dist[t];
+    if (d < q.thr_fixed) { q.goal_dist = (float)((double)d + P.offset); q.armed = 1; }
+    return;
+  }
+  float t_all = -inf_f();
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t g = P.target[k];
+    if (g == kNone) return;
+    if (is_seed(P, g)) continue;                 // fixed from the start
+    const float tp = P.tpop[g];
+    if (!(tp < q.thr_fixed)) return;             // not all fixed yet
+    t_all = fmaxf(t_all, tp);
+  }
+  float best_t = inf_f(); float best_d = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    const uint32_t g = P.target[k];
+    if (!P.target_expands[k]) continue;
+    const float tp = P.tpop[g];
+    if (!(tp < q.thr_fixed)) continue;           // has not popped yet
+    if (tp >= t_all && tp < best_t) { best_t = tp; best_d = P.dist[g]; }
+  }
+  if (best_t < inf_f()) { q.goal_dist = (float)((double)best_d + P.offset); q.armed = 1; }
+}
+
+// Band controller: pure function of the previous control block and the previous step's counters.
+//
+// goal_dist is only known once the robot vertex/face is settled, and the band that settles it
+// may already have let vertices beyond goal_dist act as sources.  Everything at or below
+// goal_dist is unaffected by that (sources only feed larger values), so arming is followed by
+// one REPAIR step that re-evaluates every vertex above goal_dist under the final cut-off and
+// rebuilds the work list (process_repair below).
+MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
+{
+  Ctl q = p;
+  q.it = p.it + 1;
+  q.repair = 0;
+  if (p.done) { q.n = 0; return q; }
+  q.n = c.n_next;
+  if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
+  const bool out_of_steps = (uint32_t)q.it >= P.max_steps;
+  if (c.changed > 0 && !out_of_steps) { q.band_new = 0; return q; }  // band still moving
+  q.thr_fixed = p.thr;
+  if (!p.repair) q.bands = p.bands + 1;
+  if (!q.armed && !out_of_steps) {
+    try_arm(P, q);
+    if (q.armed) { q.repair = 1; q.band_new = 0; return q; }
+  }
+  const float m = u2f(c.minkey);
+  if (c.n_next == 0 || !(m < inf_f()) || out_of_steps) { q.done = 1; q.n = 0; return q; }
+  if (q.armed && m > q.goal_dist) { q.done = 1; q.n = 0; return q; }   // nothing left that may expand
+  float thr = m + P.delta;
+  if (!(thr > m)) thr = next_up(m);
+  q.thr = thr;
+  q.band_new = 1;
+  return q;
+}
+
+// ---------------------------------------------------------------------------------------
+// Gather rules
+// ---------------------------------------------------------------------------------------
+struct Eval { float d; float t; uint32_t pred; float dir; uint32_t cut; };
+
+// Dijkstra: dist[v] = min over neighbours u that expand (popped: dist[u] < thr; not cut off:
+// dist[u] <= goal_dist, dijkstra :299; cost cut-off folded into w) of dist[u] + w(u,v), the very
+// float add of dijkstra :331.  Predecessor = first-popped neighbour attaining the minimum
+// (strict '<' at :332): argmin (sum, dist[u], u) -- DESIGN.md "tie rule".
+MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
+{
+  Eval e; e.d = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  float best_du = inf_f();
+  const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
+  for (uint32_t i = beg; i < end; ++i) {
+    const Nbr nb = P.nbr[i];
+    const float du = P.dist[nb.u];
+    if (!(du < c.thr) || du > c.goal_dist) continue;
+    const float s = du + nb.w;
+    if (s < e.d || (s == e.d && s < inf_f() && (du < best_du || (du == best_du && nb.u < e.pred)))) {
+      e.d = s; best_du = du; e.pred = nb.u;
+    }
+  }
+  if (!(e.d < inf_f())) e.pred = v;
+  e.t = e.d;
+  return e;
+}
+
+// CVP: replay of the incident-face updates of vertex v in the order their trigger vertices
+// pop.  Face f=(x,y -> v) fires when a support s in {x,y} pops (pop time tpop[s] < thr), passes
+// the cut-offs (cvp :754-760) and the other support is already fixed (seed, or popped no later
+// than s).  It is applied to v only while v is still free, i.e. while the fire time is below
+// v's own pop time max(key, time of its last applied update).  Faces fired by the same pop are
+// applied in ascending face id (cvp :778 loop order; CONVENTION for getFacesOfVertex).
+MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
+{
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
+  float last_tf = -inf_f();
+  for (;;) {
+    // next fire time strictly after last_tf
+    float tf_min = inf_f();
+    for (uint32_t i = beg; i < end; ++i) {
+      const Corner k = P.crn[i];
+      if (k.v1 == kNone) continue;
+      const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
+      const float t1 = P.tpop[k.v1], t2 = P.tpop[k.v2];
+      if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) continue;      // both supports fixed by this band
+      const float fix1 = s1 ? -inf_f() : t1, fix2 = s2 ? -inf_f() : t2;
+      float tf = inf_f();
+      bool ex1 = true, ex2 = true;
+      if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
+      if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+      if (t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && fix2 <= t1) tf = t1;
+      if (t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && fix1 <= t2) tf = fminf(tf, t2);
+      if (tf > last_tf && tf < tf_min) tf_min = tf;
+    }
+    if (!(tf_min < inf_f())) break;
+    if (!(tf_min < e.t)) break;                    // v pops before this group fires
+    // apply every face of the group in ascending face id
+    bool any = false;
+    for (uint32_t i = beg; i < end; ++i) {
+      const Corner k = P.crn[i];
+      if (k.v1 == kNone) continue;
+      const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
+      const float t1 = P.tpop[k.v1], t2 = P.tpop[k.v2];
+      if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) continue;
+      const float fix1 = s1 ? -inf_f() : t1, fix2 = s2 ? -inf_f() : t2;
+      float tf = inf_f();
+      bool ex1 = true, ex2 = true;
+      if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
+      if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+      if (t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && fix2 <= t1) tf = t1;
+      if (t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && fix1 <= t2) tf = fminf(tf, t2);
+      if (tf != tf_min) continue;
+      const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
+      if (u.ok) {
+        e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = k.face;
+        any = true;
+      }
+    }
+    if (any) e.t = fmaxf(e.d, tf_min);
+    last_tf = tf_min;
+  }
+  if (!(e.d < inf_f())) { e.pred = v; e.t = inf_f(); }
+  return e;
+}
+
+// ---------------------------------------------------------------------------------------
+// One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list),
+// note_changed(), note_min(float), note_eval().
+// ---------------------------------------------------------------------------------------
+template <class Ops>
+MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
+{
+  if (is_seed(P, v)) return;                                     // seeds are fixed from the start
+  const bool cvp = (P.planner == kPlannerCvp);
+  const float old_t = cvp ? P.tpop[v] : P.dist[v];
+  if (old_t < c.thr_fixed) return;                               // settled by an earlier band
+  if (cvp && P.blocked[v]) return;                               // never updated (cvp :802,825,848)
+  ops.note_eval();
+  const Eval e = cvp ? eval_cvp(P, c, v) : eval_dijkstra(P, c, v);
+  const float old_d = P.dist[v];
+  bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t));
+  if (cvp) changed = changed || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
+  else changed = changed || (e.pred != P.pred[v]);
+  if (changed) {
+    P.dist[v] = e.d; P.pred[v] = e.pred;
+    if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+  }
+  const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
+  if ((changed && (was_in || now_in)) || (now_in && c.band_new)) {
+    // v is (or was) usable by its neighbours and moved, or only just entered the band:
+    // the neighbours must look again, and the band cannot complete in this step.
+    ops.note_changed();
+    if (cvp) {
+      for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) {
+        const Corner k = P.crn[i];
+        if (k.v1 == kNone) continue;
+        ops.push(k.v1); ops.push(k.v2);
+      }
+    } else {
+      for (uint32_t i = P.row_ptr[v]; i < P.row_ptr[v + 1]; ++i) ops.push(P.nbr[i].u);
+    }
+  }
+  if (!now_in && e.t < inf_f()) {
+    ops.push(v);                                                 // keyed, waits for its band
+    ops.note_min(e.t);
+  }
+}
+
+// Repair sweep entry (one per vertex, step with ctl.repair == 1): see controller().
+template <class Ops>
+MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
+{
+  if (is_seed(P, v)) return;
+  const bool cvp = (P.planner == kPlannerCvp);
+  float d = P.dist[v];
+  if (!(d < inf_f())) return;
+  float t = cvp ? P.tpop[v] : d;
+  if (d > c.goal_dist) {
+    ops.note_eval();
+    const Eval e = cvp ? eval_cvp(P, c, v) : eval_dijkstra(P, c, v);
+    P.dist[v] = e.d; P.pred[v] = e.pred;
+    if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+    d = e.d; t = e.t;
+  }
+  if (t >= c.thr && t < inf_f()) { ops.push(v); ops.note_min(t); }
+}
+
+}  // namespace mnav

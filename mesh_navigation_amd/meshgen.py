@@ -1,0 +1,129 @@
+"""Seeded synthetic terrain meshes (SURVEY.md §8d / BASELINE.md inputs).
+
+The reference loads its meshes from HDF5/assimp files (mesh_map/src/mesh_map.cpp:149-452,
+out of scope); these generators stand in for that loader and fix the id conventions
+the rest of the repo relies on:
+
+* vertex id  = row-major grid index  ``j * N + i``  (x = column i, y = row j);
+* face ids   = cell-major, two triangles per cell split along the same diagonal,
+  counter-clockwise seen from +z: ``(v00, v10, v11)`` then ``(v00, v11, v01)``;
+* undirected edge ids = order of first appearance while iterating faces and, inside
+  a face, the sides (v0,v1), (v1,v2), (v2,v0) -- identical to oracle/mnav_oracle.c
+  ``mo_mesh_create`` (cross-checked in tests/test_meshgen.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class TerrainMesh:
+    N: int
+    h: float
+    xyz: np.ndarray        # (V,3) float32
+    faces: np.ndarray      # (F,3) uint32
+    edges: np.ndarray      # (E,2) uint32, reference edge ids
+    face_edges: np.ndarray # (F,3) uint32, edge between face vertex k and (k+1)%3
+
+    @property
+    def V(self) -> int:
+        return int(self.xyz.shape[0])
+
+    @property
+    def F(self) -> int:
+        return int(self.faces.shape[0])
+
+    @property
+    def E(self) -> int:
+        return int(self.edges.shape[0])
+
+    def vertex_at(self, fi: float, fj: float) -> int:
+        """Vertex id at fractional grid position (fi, fj) in [0,1]^2."""
+        i = min(self.N - 1, max(0, int(round(fi * (self.N - 1)))))
+        j = min(self.N - 1, max(0, int(round(fj * (self.N - 1)))))
+        return j * self.N + i
+
+
+def grid_faces(N: int) -> np.ndarray:
+    i, j = np.meshgrid(np.arange(N - 1, dtype=np.int64), np.arange(N - 1, dtype=np.int64))
+    v00 = (j * N + i).ravel()
+    v10 = v00 + 1
+    v01 = v00 + N
+    v11 = v01 + 1
+    t1 = np.stack([v00, v10, v11], axis=1)
+    t2 = np.stack([v00, v11, v01], axis=1)
+    faces = np.empty((2 * (N - 1) * (N - 1), 3), dtype=np.uint32)
+    faces[0::2] = t1
+    faces[1::2] = t2
+    return faces
+
+
+def edges_from_faces(faces: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Undirected edges in order of first appearance + per-face side -> edge id."""
+    f = faces.astype(np.int64)
+    a = f[:, [0, 1, 2]].ravel()          # face-major, sides (0,1),(1,2),(2,0)
+    b = f[:, [1, 2, 0]].ravel()
+    lo = np.minimum(a, b)
+    hi = np.maximum(a, b)
+    key = (lo << 32) | hi
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")          # unique-key index -> rank by first appearance
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    face_edges = rank[inv].reshape(-1, 3).astype(np.uint32)
+    fa = first[order]
+    edges = np.stack([a[fa], b[fa]], axis=1).astype(np.uint32)   # oriented as first seen
+    return edges, face_edges
+
+
+def terrain(N: int, h: float = 0.1, seed: int = 0, amplitude: float = 2.0,
+            base_freq: float = 1.0 / 50.0, jitter: float = 0.2, octaves: int = 5) -> TerrainMesh:
+    """Terrain(N, h, seed) of SURVEY.md §8d: jittered grid, 5-octave sin*cos heights."""
+    rng = np.random.default_rng(seed)
+    jx = rng.uniform(-jitter * h, jitter * h, size=(N, N))
+    jy = rng.uniform(-jitter * h, jitter * h, size=(N, N))
+    phi = rng.uniform(0.0, 2.0 * np.pi, size=octaves)
+    psi = rng.uniform(0.0, 2.0 * np.pi, size=octaves)
+    i, j = np.meshgrid(np.arange(N, dtype=np.float64), np.arange(N, dtype=np.float64))
+    x = i * h + jx
+    y = j * h + jy
+    z = np.zeros_like(x)
+    for k in range(1, octaves + 1):
+        z += (amplitude / 2.0 ** k) * np.sin(2.0 * np.pi * base_freq * 2.0 ** k * x + phi[k - 1]) \
+             * np.cos(2.0 * np.pi * base_freq * 2.0 ** k * y + psi[k - 1])
+    xyz = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1).astype(np.float32)
+    faces = grid_faces(N)
+    edges, face_edges = edges_from_faces(faces)
+    return TerrainMesh(N=N, h=h, xyz=xyz, faces=faces, edges=edges, face_edges=face_edges)
+
+
+def flat_grid(N: int, h: float = 1.0) -> TerrainMesh:
+    """Un-jittered flat grid (tie-stress / analytic tests)."""
+    i, j = np.meshgrid(np.arange(N, dtype=np.float64), np.arange(N, dtype=np.float64))
+    xyz = np.stack([(i * h).ravel(), (j * h).ravel(), np.zeros(N * N)], axis=1).astype(np.float32)
+    faces = grid_faces(N)
+    edges, face_edges = edges_from_faces(faces)
+    return TerrainMesh(N=N, h=h, xyz=xyz, faces=faces, edges=edges, face_edges=face_edges)
+
+
+def edge_lengths(mesh: TerrainMesh) -> np.ndarray:
+    """float32 Euclidean edge lengths with the oracle's operation order
+    (dx*dx + dy*dy + dz*dz in float32, then sqrt)."""
+    p = mesh.xyz[mesh.edges[:, 0]]
+    q = mesh.xyz[mesh.edges[:, 1]]
+    d = (p - q).astype(np.float32)
+    s = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+    s = (s + d[:, 2] * d[:, 2]).astype(np.float32)
+    return np.sqrt(s, dtype=np.float32)
+
+
+# Benchmark / parity configurations of BASELINE.md (C1..C5)
+CONFIGS = {
+    "C1": dict(N=224, seed=1),
+    "C2": dict(N=1000, seed=2),
+    "C3": dict(N=1000, seed=3),
+    "C4": dict(N=3163, seed=4),
+    "C5": dict(N=1000, seed=2),
+}
