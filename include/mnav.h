@@ -1,0 +1,146 @@
+/*
+ * mnav.h -- C ABI of the MI355X-native wavefront planner (libmnav.so).
+ *
+ * The reference has no C ABI: its boundary is the C++ pure-virtual plugin class
+ * mbf_mesh_core::MeshPlanner (mbf_mesh_core/include/mbf_mesh_core/mesh_planner.h:50-92)
+ * loaded through pluginlib.  This header is what a MeshPlanner implementation binds
+ * instead of running the priority-queue loops itself; INTEGRATION.md shows the
+ * adapter (mesh_navigation_amd/csrc/adapter/) that keeps makePlan / cancel /
+ * initialize unchanged on top of it.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer it
+ * passes; the context owns all device memory; one plan call in flight per
+ * context (the reference reuses potential_/predecessors_ members the same way,
+ * dijkstra_mesh_planner.h:189-197).  Vertex / face / edge ids are the
+ * reference's handles' idx() values.  All plan functions return the MBF GetPath
+ * result codes of dijkstra_mesh_planner.h:72-85.  The library never computes on
+ * the CPU: without a usable GPU mnav_create() fails (returns NULL).
+ */
+#ifndef MNAV_H
+#define MNAV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNAV_SUCCESS 0u         /* mbf_msgs GetPath::Result::SUCCESS        */
+#define MNAV_CANCELED 51u       /* ...::CANCELED                            */
+#define MNAV_INVALID_START 52u  /* ...::INVALID_START                       */
+#define MNAV_INVALID_GOAL 53u   /* ...::INVALID_GOAL                        */
+#define MNAV_NO_PATH_FOUND 54u  /* ...::NO_PATH_FOUND                       */
+#define MNAV_INTERNAL_ERROR 59u /* ...::INTERNAL_ERROR (device/runtime failure) */
+#define MNAV_NONE 0xFFFFFFFFu
+
+typedef struct mnav_ctx mnav_ctx;
+
+/* Per-call statistics (the phases the reference logs, dijkstra_mesh_planner.cpp:391-394,
+ * cvp_mesh_planner.cpp:956-960).  Times are HIP-event milliseconds on the context stream. */
+typedef struct mnav_stats {
+  uint32_t steps;          /* wavefront step-kernel launches that did work       */
+  uint32_t launches;       /* step launches enqueued (incl. overshoot no-ops)    */
+  uint32_t bands;          /* distance bands completed                           */
+  uint32_t armed;          /* goal_dist was armed                                */
+  float goal_dist;         /* armed value or +inf                                */
+  uint32_t n_plans;        /* plans in the call (batch size)                     */
+  uint64_t evals;          /* vertex evaluations (all plans)                     */
+  uint64_t settled;        /* vertices with a finite potential (all plans)       */
+  float ms_init;           /* state initialisation                               */
+  float ms_propagation;    /* wavefront propagation (all step launches)          */
+  float ms_vector_map;     /* computeVectorMap                                   */
+  float ms_path;           /* predecessor walk                                   */
+  float ms_download;       /* device -> host copies of requested outputs         */
+  float ms_total;          /* whole call                                         */
+} mnav_stats;
+
+/* -- life cycle -------------------------------------------------------------------------- */
+/* Replaces: plugin construction + MeshPlanner::initialize(name, mesh_map, node),
+ * mesh_planner.h:88 (dijkstra_mesh_planner.cpp:142-169, cvp_mesh_planner.cpp:148-186). */
+mnav_ctx* mnav_create(int device);
+void mnav_destroy(mnav_ctx* ctx);
+/* Text of the last failure on this context ("" if none); valid until the next call. */
+const char* mnav_last_error(const mnav_ctx* ctx);
+
+/* Upload the half-edge mesh once (MeshMap::mesh(), mesh_map.h:276-279) as flat arrays:
+ * xyz V*3, face_vtx F*3 (reference face order), edge_vtx E*2 (reference edge ids),
+ * vertex_normals V*3 (MeshMap::vertexNormals(), mesh_map.h:326-337; may be NULL if CVP
+ * vector maps are never requested).  Returns 0 on success, <0 on error. */
+int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const float* xyz,
+                     const uint32_t* face_vtx, const uint32_t* edge_vtx,
+                     const float* vertex_normals);
+
+/* Upload the inputs the planners re-read on every plan (dijkstra_mesh_planner.cpp:214,
+ * cvp_mesh_planner.cpp:245): vertex_costs V (MeshMap::vertexCosts(), mesh_map.h:292-295),
+ * edge_weights E (MeshMap::edgeWeights(), mesh_map.h:342-345), invalid V bytes
+ * (MeshMap::invalid, mesh_map.h:447; NULL = none). */
+int mnav_upload_costs(mnav_ctx* ctx, const float* vertex_costs, const float* edge_weights,
+                      const uint8_t* invalid);
+
+/* Device version of MeshMap::computeEdgeWeights (mesh_map/src/mesh_map.cpp:517-561): uploads
+ * vertex_costs V and edge_distances E and derives the edge weights on the GPU with the
+ * reference's mixed float/double arithmetic.  edge_weights_out (E, may be NULL) receives them. */
+int mnav_compute_edge_weights(mnav_ctx* ctx, const float* vertex_costs, const float* edge_distances,
+                              double edge_cost_factor, const uint8_t* invalid,
+                              float* edge_weights_out);
+
+/* -- planning ---------------------------------------------------------------------------- */
+/* Replaces DijkstraMeshPlanner::dijkstra (7-arg) + computeVectorMap,
+ * dijkstra_mesh_planner.cpp:217-398, :189-209.  seed_vertex = wave seed (navigation goal),
+ * target_vertex = robot vertex (both already resolved by MeshMap::getNearestVertexHandle,
+ * :235-236).  Outputs (any may be NULL): dist_out V (potential_), pred_out V
+ * (predecessors_), vecmap_out V*3 (vector_map_, zero rows where the reference has no entry),
+ * path_out/path_len: the vertex path in dijkstra()'s list order (seed first ... pred[target]),
+ * at most path_cap entries are written, *path_len is the full length. */
+uint32_t mnav_plan_dijkstra(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex,
+                            double goal_dist_offset, double cost_limit, float* dist_out,
+                            uint32_t* pred_out, uint32_t* path_out, uint32_t path_cap,
+                            uint32_t* path_len, float* vecmap_out);
+
+/* Replaces CVPMeshPlanner::waveFrontPropagation up to and including computeVectorMap,
+ * cvp_mesh_planner.cpp:651-918, :204-239 (the vector-field back-tracking :920-951 stays on
+ * the host, see the adapter).  seed_pos = exact wave seed position (navigation goal),
+ * seed_face / target_face = containing faces (MeshMap::getContainingFace, :673-674).
+ * Outputs (any may be NULL): dist_out V, pred_out V, direction_out V (direction_),
+ * cutface_out V (cutting_faces_, MNAV_NONE = no entry), vecmap_out V*3.  Entries of
+ * direction/cutface/vecmap for vertices the wave did not update are 0 / MNAV_NONE / 0
+ * (the reference leaves stale values of earlier plans there, cvp_mesh_planner.cpp:179). */
+uint32_t mnav_plan_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_face,
+                       uint32_t target_face, double goal_dist_offset, double cost_limit,
+                       float* dist_out, uint32_t* pred_out, float* direction_out,
+                       uint32_t* cutface_out, float* vecmap_out);
+
+/* n independent Dijkstra plans on the same mesh in one sweep (BASELINE config 5: concurrent
+ * goals).  seeds/targets: n each.  codes_out n.  dist_out/pred_out: n*V or NULL.
+ * path_out: n*path_cap or NULL, path_len n. */
+uint32_t mnav_plan_dijkstra_batch(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds,
+                                  const uint32_t* targets, double goal_dist_offset,
+                                  double cost_limit, uint32_t* codes_out, float* dist_out,
+                                  uint32_t* pred_out, uint32_t* path_out, uint32_t path_cap,
+                                  uint32_t* path_len);
+
+/* Replaces MeshPlanner::cancel(), mesh_planner.h:80 (dijkstra_mesh_planner.cpp:136-140):
+ * async-signal/thread safe, only sets a flag that the running plan polls between step
+ * batches; the plan then returns MNAV_CANCELED.  The flag is cleared when a plan starts
+ * (dijkstra_mesh_planner.cpp:238). */
+void mnav_cancel(mnav_ctx* ctx);
+
+/* -- introspection / tuning -------------------------------------------------------------- */
+int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out);
+/* Band width of the wavefront engine in potential units; <= 0 selects the default
+ * (3 x mean finite edge weight, recomputed on every cost upload). */
+int mnav_set_band_width(mnav_ctx* ctx, float delta);
+/* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (default), 1 = the
+ * distance-band gather steps that the CVP planner uses.  Both give identical results. */
+int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
+/* Device pointers of the last plan's resident outputs (slot = plan index in a batch):
+ * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available. */
+const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what);
+/* Algorithmic bytes of the last call per SURVEY.md §8(d): SSSP 24*V' + 24*E', CVP 32*V' + 68*F'
+ * with V' = settled vertices and E'/F' their incident edges/faces scaled from the full mesh. */
+uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNAV_H */

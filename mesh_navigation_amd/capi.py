@@ -1,0 +1,241 @@
+"""ctypes binding of the C ABI in include/mnav.h (libmnav.so).
+
+Plumbing only: numpy arrays in, numpy arrays out.  There is no CPU fallback -- if the HIP
+library is missing or no GPU is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import build as _build
+
+NONE = 0xFFFFFFFF
+SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 0, 51, 52, 53, 54, 59
+
+# every symbol include/mnav.h declares
+SYMBOLS = [
+    "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_upload_mesh", "mnav_upload_costs",
+    "mnav_compute_edge_weights", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch",
+    "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
+    "mnav_algorithmic_bytes",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [("steps", C.c_uint32), ("launches", C.c_uint32), ("bands", C.c_uint32), ("armed", C.c_uint32),
+                ("goal_dist", C.c_float), ("n_plans", C.c_uint32), ("evals", C.c_uint64), ("settled", C.c_uint64),
+                ("ms_init", C.c_float), ("ms_propagation", C.c_float), ("ms_vector_map", C.c_float),
+                ("ms_path", C.c_float), ("ms_download", C.c_float), ("ms_total", C.c_float)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load libmnav.so (building it in-tree if the sources are newer).  Raises if unavailable."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _build.LIB
+    if path is None and not os.path.exists(p):
+        _build.build_lib()
+    if not os.path.exists(p):
+        raise RuntimeError(f"HIP library {p} is missing -- run `python -m mesh_navigation_amd.build`")
+    L = C.CDLL(p)
+    vp, u32, f64 = C.c_void_p, C.c_uint32, C.c_double
+    L.mnav_create.restype = vp
+    L.mnav_create.argtypes = [C.c_int]
+    L.mnav_destroy.argtypes = [vp]
+    L.mnav_last_error.restype = C.c_char_p
+    L.mnav_last_error.argtypes = [vp]
+    L.mnav_upload_mesh.restype = C.c_int
+    L.mnav_upload_mesh.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp]
+    L.mnav_upload_costs.restype = C.c_int
+    L.mnav_upload_costs.argtypes = [vp, vp, vp, vp]
+    L.mnav_compute_edge_weights.restype = C.c_int
+    L.mnav_compute_edge_weights.argtypes = [vp, vp, vp, f64, vp, vp]
+    L.mnav_plan_dijkstra.restype = u32
+    L.mnav_plan_dijkstra.argtypes = [vp, u32, u32, f64, f64, vp, vp, vp, u32, C.POINTER(u32), vp]
+    L.mnav_plan_cvp.restype = u32
+    L.mnav_plan_cvp.argtypes = [vp, vp, u32, u32, f64, f64, vp, vp, vp, vp, vp]
+    L.mnav_plan_dijkstra_batch.restype = u32
+    L.mnav_plan_dijkstra_batch.argtypes = [vp, u32, vp, vp, f64, f64, vp, vp, vp, vp, u32, vp]
+    L.mnav_cancel.argtypes = [vp]
+    L.mnav_get_stats.restype = C.c_int
+    L.mnav_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.mnav_set_band_width.restype = C.c_int
+    L.mnav_set_band_width.argtypes = [vp, C.c_float]
+    L.mnav_set_dijkstra_engine.restype = C.c_int
+    L.mnav_set_dijkstra_engine.argtypes = [vp, C.c_int]
+    L.mnav_device_output.restype = vp
+    L.mnav_device_output.argtypes = [vp, u32, C.c_int]
+    L.mnav_algorithmic_bytes.restype = C.c_uint64
+    L.mnav_algorithmic_bytes.argtypes = [vp]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+@dataclass
+class DijkstraOut:
+    code: int
+    dist: np.ndarray | None
+    pred: np.ndarray | None
+    path: np.ndarray          # dijkstra() list order: seed first ... pred[target]
+    vecmap: np.ndarray | None
+    stats: dict
+
+
+@dataclass
+class CvpOut:
+    code: int
+    dist: np.ndarray | None
+    pred: np.ndarray | None
+    direction: np.ndarray | None
+    cutface: np.ndarray | None
+    vecmap: np.ndarray | None
+    stats: dict
+
+
+class MnavContext:
+    """One device context = one planner instance's device state (mnav_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        self._h = self._L.mnav_create(int(device))
+        if not self._h:
+            raise RuntimeError("mnav_create failed: no usable MI355X/HIP device (there is no CPU fallback)")
+        self.V = self.F = self.E = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mnav_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _err(self) -> str:
+        return (self._L.mnav_last_error(self._h) or b"").decode()
+
+    def upload_mesh(self, xyz, faces, edges, vertex_normals=None):
+        xyz, faces, edges = _f32(xyz), _u32(faces), _u32(edges)
+        vn = None if vertex_normals is None else _f32(vertex_normals)
+        self.V, self.F, self.E = xyz.shape[0], faces.shape[0], edges.shape[0]
+        rc = self._L.mnav_upload_mesh(self._h, self.V, self.F, self.E, _p(xyz), _p(faces), _p(edges), _p(vn))
+        if rc != 0:
+            raise RuntimeError(f"mnav_upload_mesh failed ({rc}): {self._err()}")
+
+    def upload_costs(self, vertex_costs, edge_weights, invalid=None):
+        vc, w = _f32(vertex_costs), _f32(edge_weights)
+        inv = None if invalid is None else np.ascontiguousarray(invalid, dtype=np.uint8)
+        rc = self._L.mnav_upload_costs(self._h, _p(vc), _p(w), _p(inv))
+        if rc != 0:
+            raise RuntimeError(f"mnav_upload_costs failed ({rc}): {self._err()}")
+
+    def compute_edge_weights(self, vertex_costs, edge_distances, edge_cost_factor: float, invalid=None) -> np.ndarray:
+        vc, ed = _f32(vertex_costs), _f32(edge_distances)
+        inv = None if invalid is None else np.ascontiguousarray(invalid, dtype=np.uint8)
+        out = np.empty(self.E, dtype=np.float32)
+        rc = self._L.mnav_compute_edge_weights(self._h, _p(vc), _p(ed), float(edge_cost_factor), _p(inv), _p(out))
+        if rc != 0:
+            raise RuntimeError(f"mnav_compute_edge_weights failed ({rc}): {self._err()}")
+        return out
+
+    def set_band_width(self, delta: float):
+        self._L.mnav_set_band_width(self._h, float(delta))
+
+    def set_dijkstra_engine(self, engine: str):
+        """'tiled' (default) or 'band'."""
+        self._L.mnav_set_dijkstra_engine(self._h, 1 if engine == "band" else 0)
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._L.mnav_get_stats(self._h, C.byref(s))
+        d = s.as_dict()
+        d["algorithmic_bytes"] = int(self._L.mnav_algorithmic_bytes(self._h))
+        return d
+
+    def cancel(self):
+        self._L.mnav_cancel(self._h)
+
+    def device_output(self, slot: int, what: int) -> int:
+        return int(self._L.mnav_device_output(self._h, slot, what) or 0)
+
+    def plan_dijkstra(self, seed_vertex: int, target_vertex: int, goal_dist_offset: float = 0.3,
+                      cost_limit: float = 1.0, want_fields: bool = True, want_vecmap: bool = False) -> DijkstraOut:
+        V = self.V
+        dist = np.empty(V, np.float32) if want_fields else None
+        pred = np.empty(V, np.uint32) if want_fields else None
+        vm = np.empty((V, 3), np.float32) if want_vecmap else None
+        path = np.empty(max(V, 1), np.uint32)
+        n = C.c_uint32(0)
+        code = self._L.mnav_plan_dijkstra(self._h, int(seed_vertex) & 0xFFFFFFFF, int(target_vertex) & 0xFFFFFFFF,
+                                          float(goal_dist_offset), float(cost_limit), _p(dist), _p(pred), _p(path),
+                                          path.shape[0], C.byref(n), _p(vm))
+        if code == INTERNAL_ERROR:
+            raise RuntimeError(f"mnav_plan_dijkstra internal error: {self._err()}")
+        return DijkstraOut(code, dist, pred, path[: n.value].copy(), vm, self.stats())
+
+    def plan_dijkstra_batch(self, seeds, targets, goal_dist_offset: float = 0.3, cost_limit: float = 1.0,
+                            want_fields: bool = False, path_cap: int | None = None):
+        seeds, targets = _u32(seeds), _u32(targets)
+        n = seeds.shape[0]
+        V = self.V
+        cap = int(path_cap if path_cap is not None else V)
+        codes = np.empty(n, np.uint32)
+        dist = np.empty((n, V), np.float32) if want_fields else None
+        pred = np.empty((n, V), np.uint32) if want_fields else None
+        paths = np.empty((n, max(cap, 1)), np.uint32)
+        lens = np.zeros(n, np.uint32)
+        rc = self._L.mnav_plan_dijkstra_batch(self._h, n, _p(seeds), _p(targets), float(goal_dist_offset),
+                                              float(cost_limit), _p(codes), _p(dist), _p(pred), _p(paths), cap, _p(lens))
+        if rc == INTERNAL_ERROR:
+            raise RuntimeError(f"mnav_plan_dijkstra_batch internal error: {self._err()}")
+        return dict(rc=rc, codes=codes, dist=dist, pred=pred,
+                    paths=[paths[i, : min(int(lens[i]), cap)].copy() for i in range(n)], path_len=lens,
+                    stats=self.stats())
+
+    def plan_cvp(self, seed_pos, seed_face: int, target_face: int, goal_dist_offset: float = 0.3,
+                 cost_limit: float = 1.0, want_fields: bool = True, want_vecmap: bool = True) -> CvpOut:
+        V = self.V
+        sp = _f32(seed_pos)
+        dist = np.empty(V, np.float32) if want_fields else None
+        pred = np.empty(V, np.uint32) if want_fields else None
+        dirn = np.empty(V, np.float32) if want_fields else None
+        cutf = np.empty(V, np.uint32) if want_fields else None
+        vm = np.empty((V, 3), np.float32) if want_vecmap else None
+        code = self._L.mnav_plan_cvp(self._h, _p(sp), int(seed_face) & 0xFFFFFFFF, int(target_face) & 0xFFFFFFFF,
+                                     float(goal_dist_offset), float(cost_limit), _p(dist), _p(pred), _p(dirn),
+                                     _p(cutf), _p(vm))
+        if code == INTERNAL_ERROR:
+            raise RuntimeError(f"mnav_plan_cvp internal error: {self._err()}")
+        return CvpOut(code, dist, pred, dirn, cutf, vm, self.stats())

@@ -1,0 +1,1833 @@
+// mnav.hip -- MI355X (gfx950) wavefront planner: HIP kernels + the C ABI of include/mnav.h.
+//
+// Hot path replaced (reference file:line):
+//   DijkstraMeshPlanner::dijkstra       dijkstra_mesh_planner/src/dijkstra_mesh_planner.cpp:217-398
+//   DijkstraMeshPlanner::computeVectorMap                                            :189-209
+//   CVPMeshPlanner::waveFrontPropagation cvp_mesh_planner/src/cvp_mesh_planner.cpp:651-918
+//   CVPMeshPlanner::waveFrontUpdate                                                  :369-556
+//   CVPMeshPlanner::computeVectorMap                                                 :204-239
+//   MeshMap::computeEdgeWeights          mesh_map/src/mesh_map.cpp:517-561
+//
+// Design: the priority-queue loops become distance bands settled by a gather
+// rule iterated to its fixed point (mnav_eval.h).  One step = one launch of k_step over the
+// current work list of every plan in the batch; steps are enqueued back-to-back from a
+// hipGraph with no host round trip, all loop control (band advance, goal_dist arming,
+// termination) is recomputed by every workgroup from the previous step's counters.
+// Memory-bound irregular gather work: no MFMA, coalescing via CSR rows + 24-byte corner
+// records, wave-aggregated atomics for the work lists.
+//
+// This file never computes a plan on the CPU: every entry point fails when no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mnav.h"
+#include "mnav_build.h"
+#include "mnav_eval.h"
+
+using namespace mnav;
+
+namespace {
+
+// Pointers that reach a kernel through a struct in memory are generic to the compiler: it emits
+// flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) around every LDS access.  Device-memory arrays are
+// therefore re-typed as address_space(1) before use (global_load, waits only on vmcnt).
+#define MNAV_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ MNAV_GLOBAL T* as_global(T* p) { return (MNAV_GLOBAL T*)p; }
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte copy unit
+
+constexpr int kBlock = 256;   // streaming kernels (init, vector map, input preparation)
+constexpr int kChunk = 96;  // step launches per graph replay; multiple of 6 (slot parities)
+
+// ---------------------------------------------------------------------------------------------
+// Step kernel.  One wave (64 lanes) per workgroup, 8 lanes cooperate on one work-list entry:
+// the lanes of a group fetch the CSR row / the corner records of the vertex in parallel, the
+// gather rule of mnav_eval.h is then evaluated with in-group shuffles, and list pushes are
+// aggregated per wave (one atomicAdd per wave and push round).  The serial rules in mnav_eval.h
+// (eval_dijkstra / eval_cvp / process_entry) are the specification; this is the same arithmetic
+// spread over lanes, and tests compare both against the oracle.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWave = 64;
+constexpr int kGroup = 8;                 // lanes per work-list entry
+constexpr int kGroupsPerWave = kWave / kGroup;
+
+struct StepCtx {
+  const Plan* P;
+  Cnt* cnt;
+  uint32_t* next;
+  uint32_t sv;          // dedup stamp of this step
+  float lmin;
+  uint32_t levals;
+  bool lchanged;
+};
+
+// dedup'd, wave-aggregated append of v to the next work list (all lanes of the wave that reach
+// this point take part; `want` selects the lanes that actually push)
+__device__ __forceinline__ void push_agg(StepCtx& S, bool want, uint32_t v)
+{
+  bool ok = false;
+  if (want) {
+    if (S.P->stamp[v] != S.sv) ok = atomicExch(&S.P->stamp[v], S.sv) != S.sv;
+  }
+  const unsigned long long m = __ballot(ok);
+  if (m == 0ull) return;
+  const int leader = __ffsll((long long)m) - 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&S.cnt->n_next, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (ok) {
+    const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (idx < S.P->cap) S.next[idx] = v;
+  }
+}
+
+template <class T>
+__device__ __forceinline__ T gshfl(T x, int src) { return __shfl(x, src, kGroup); }
+
+// --- Dijkstra gather over 8 lanes (spec: mnav_eval.h::eval_dijkstra) ---------------------------
+__device__ __forceinline__ Eval group_eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v, int sub)
+{
+  float best_s = inf_f(), best_du = inf_f();
+  uint32_t best_u = v;
+  const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
+  for (uint32_t i = beg + sub; i < end; i += kGroup) {
+    const Nbr nb = P.nbr[i];
+    const float du = P.dist[nb.u];
+    if (!(du < c.thr) || du > c.goal_dist) continue;
+    const float s = du + nb.w;                                    // dijkstra :331
+    if (s < best_s || (s == best_s && s < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) {
+      best_s = s; best_du = du; best_u = nb.u;
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < kGroup; o <<= 1) {
+    const float os = __shfl_xor(best_s, o, kGroup), odu = __shfl_xor(best_du, o, kGroup);
+    const uint32_t ou = __shfl_xor(best_u, o, kGroup);
+    if (os < best_s || (os == best_s && os < inf_f() && (odu < best_du || (odu == best_du && ou < best_u)))) {
+      best_s = os; best_du = odu; best_u = ou;
+    }
+  }
+  Eval e; e.d = best_s; e.t = best_s; e.pred = (best_s < inf_f()) ? best_u : v; e.dir = 0.0f; e.cut = kNone;
+  return e;
+}
+
+// --- CVP replay over 8 lanes (spec: mnav_eval.h::eval_cvp) ------------------------------------
+struct CornerItem { float tf; CvpCand k; uint32_t v1, v2, face; };
+
+__device__ __forceinline__ float corner_fire_time(const Plan& P, const Ctl& c, const Corner& k)
+{
+  if (k.v1 == kNone) return inf_f();
+  const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
+  const float t1 = P.tpop[k.v1], t2 = P.tpop[k.v2];
+  if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return inf_f();
+  const float fix1 = s1 ? -inf_f() : t1, fix2 = s2 ? -inf_f() : t2;
+  bool ex1 = true, ex2 = true;
+  if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
+  if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+  float tf = inf_f();
+  if (t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && fix2 <= t1) tf = t1;
+  if (t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && fix1 <= t2) tf = fminf(tf, t2);
+  return tf;
+}
+
+__device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint32_t v, int sub)
+{
+  const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
+  if (end - beg > 2 * kGroup) return eval_cvp(P, c, v);           // rare high-valence vertex: serial rule
+  CornerItem it[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t i = beg + sub + r * kGroup;
+    it[r].tf = inf_f(); it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone;
+    it[r].k.u3tmp = 0.0; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = 0; it[r].k.kind = 0;
+    if (i < end) {
+      const Corner k = P.crn[i];
+      it[r].tf = corner_fire_time(P, c, k);
+      if (it[r].tf < inf_f()) {
+        it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
+        it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = k.face;
+      }
+    }
+  }
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  float last_tf = -inf_f();
+  const int gbase = (threadIdx.x & (kWave - 1)) & ~(kGroup - 1);
+  for (;;) {
+    float m = inf_f();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) if (it[r].tf > last_tf && it[r].tf < m) m = it[r].tf;
+#pragma unroll
+    for (int o = 1; o < kGroup; o <<= 1) m = fminf(m, __shfl_xor(m, o, kGroup));
+    if (!(m < inf_f())) break;
+    if (!(m < e.t)) break;                                         // v pops before this group fires
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                                  // ascending corner index = ascending face id
+      unsigned gm = (unsigned)((__ballot(it[r].tf == m) >> gbase) & 0xFFull);
+      while (gm) {
+        const int src = __ffs((int)gm) - 1;
+        gm &= gm - 1;
+        CvpCand k;
+        k.u3tmp = gshfl(it[r].k.u3tmp, src); k.cand = gshfl(it[r].k.cand, src); k.dir = gshfl(it[r].k.dir, src);
+        k.sel = gshfl(it[r].k.sel, src); k.kind = gshfl(it[r].k.kind, src);
+        int sel = 0; float dir = 0.0f;
+        if (cvp_apply(k, e.d, sel, dir)) {
+          const uint32_t v1 = gshfl(it[r].v1, src), v2 = gshfl(it[r].v2, src);
+          e.pred = (sel == 1) ? v1 : v2; e.dir = dir; e.cut = gshfl(it[r].face, src);
+          any = true;
+        }
+      }
+    }
+    if (any) e.t = fmaxf(e.d, m);
+    last_tf = m;
+  }
+  if (!(e.d < inf_f())) { e.pred = v; e.t = inf_f(); }
+  return e;
+}
+
+template <uint32_t PLANNER>
+__device__ __forceinline__ Eval group_eval(const Plan& P, const Ctl& c, uint32_t v, int sub)
+{
+  if constexpr (PLANNER == kPlannerCvp) return group_eval_cvp(P, c, v, sub);
+  else return group_eval_dijkstra(P, c, v, sub);
+}
+
+// push the neighbourhood of v (spec: process_entry)
+template <uint32_t PLANNER>
+__device__ __forceinline__ void group_push_neighbours(StepCtx& S, const Plan& P, uint32_t v, int sub, bool want)
+{
+  if constexpr (PLANNER == kPlannerCvp) {
+    const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
+    const uint32_t rounds = want ? (end - beg + kGroup - 1) / kGroup : 0;
+    // every lane of the wave must reach push_agg the same number of times -> wave-max of rounds
+    uint32_t wr = rounds;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wr = max(wr, (uint32_t)__shfl_xor((int)wr, o));
+    for (uint32_t r = 0; r < wr; ++r) {
+      const uint32_t i = beg + sub + r * kGroup;
+      uint32_t a = kNone, b = kNone;
+      if (want && i < end) { const Corner k = P.crn[i]; if (k.v1 != kNone) { a = k.v1; b = k.v2; } }
+      push_agg(S, a != kNone, a);
+      push_agg(S, b != kNone, b);
+    }
+  } else {
+    const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
+    const uint32_t rounds = want ? (end - beg + kGroup - 1) / kGroup : 0;
+    uint32_t wr = rounds;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wr = max(wr, (uint32_t)__shfl_xor((int)wr, o));
+    for (uint32_t r = 0; r < wr; ++r) {
+      const uint32_t i = beg + sub + r * kGroup;
+      const bool w = want && i < end;
+      const uint32_t u = w ? P.nbr[i].u : kNone;
+      push_agg(S, w, u);
+    }
+  }
+}
+
+// one work-list entry per 8-lane group; `active` = this group has an entry (inactive groups only
+// take part in the wave-wide pushes).  Spec: mnav_eval.h::process_entry / process_repair.
+template <uint32_t PLANNER, bool REPAIR>
+__device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const Ctl& c, bool active, uint32_t v, int sub)
+{
+  constexpr bool cvp = (PLANNER == kPlannerCvp);
+  bool push_nb = false, retain = false;
+  float t_new = inf_f();
+  if (active && !is_seed(P, v)) {
+    const float old_d = P.dist[v];
+    const float old_t = cvp ? P.tpop[v] : old_d;
+    bool go;
+    if (REPAIR) go = (old_d < inf_f());
+    else go = !(old_t < c.thr_fixed) && !(cvp && P.blocked[v]);
+    if (go) {
+      if (!REPAIR || old_d > c.goal_dist) {
+        if (sub == 0) ++S.levals;
+        const Eval e = group_eval<PLANNER>(P, c, v, sub);
+        bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != P.pred[v]);
+        if (cvp) changed = changed || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
+        if ((changed || REPAIR) && sub == 0) {
+          P.dist[v] = e.d; P.pred[v] = e.pred;
+          if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+        }
+        t_new = e.t;
+        if (!REPAIR) {
+          const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
+          push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
+          retain = !now_in && e.t < inf_f();
+        }
+      } else {
+        t_new = old_t;
+      }
+      if (REPAIR) retain = (t_new >= c.thr) && (t_new < inf_f());
+    }
+  }
+  if (push_nb && sub == 0) S.lchanged = true;
+  group_push_neighbours<PLANNER>(S, P, v, sub, push_nb);
+  push_agg(S, retain && sub == 0, v);
+  if (retain && sub == 0) S.lmin = fminf(S.lmin, t_new);
+}
+
+__device__ __forceinline__ float wave_min(float x)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fminf(x, __shfl_xor(x, o));
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+// grid = (waves per plan, plans).  slot j (0..5) selects the ping-pong control block (j&1) and
+// the counter block (j%3).
+template <uint32_t PLANNER>
+__global__ __launch_bounds__(kWave) void k_step(const Plan* __restrict__ plans, int j)
+{
+  const Plan& P = plans[blockIdx.y];
+  const int lane = threadIdx.x;
+  __shared__ Ctl s_ctl;
+  if (lane == 0) {
+    const Ctl prev = P.ctl[(j + 1) & 1];
+    const Cnt cprev = P.cnt[(j + 2) % 3];
+    const Ctl cur = controller(P, prev, cprev);
+    s_ctl = cur;
+    if (blockIdx.x == 0) {
+      P.ctl[j & 1] = cur;
+      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
+      P.cnt[(j + 1) % 3] = z;
+    }
+  }
+  __syncthreads();
+  const Ctl cur = s_ctl;
+  if (cur.done) return;
+  Cnt* cnt = &P.cnt[j % 3];
+  StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false };
+  const int sub = lane & (kGroup - 1), grp = lane >> 3;
+  const uint32_t ngroups = gridDim.x * kGroupsPerWave;
+  const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
+  if (cur.repair) {
+    const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint32_t v = g0 + r * ngroups;
+      group_process<PLANNER, true>(S, P, cur, v < P.V, v < P.V ? v : 0u, sub);
+    }
+  } else {
+    const uint32_t* list = P.list[cur.it & 1];
+    const uint32_t rounds = (cur.n + ngroups - 1) / ngroups;
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint32_t i = g0 + r * ngroups;
+      const bool active = i < cur.n;
+      const uint32_t v = active ? list[i] : 0u;
+      group_process<PLANNER, false>(S, P, cur, active, v, sub);
+    }
+  }
+  const float wmin = wave_min(S.lmin);
+  const uint32_t wev = wave_sum(S.levals);
+  const bool wch = __any(S.lchanged);
+  if (lane == 0) {
+    if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
+    if (wev) atomicAdd(&cnt->evals, wev);
+    if (wch) atomicOr(&cnt->changed, 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiled label-correcting SSSP (Dijkstra planner).  The final float32 distances of the reference
+// loop (dijkstra :287-348) are the unique fixed point of d[v] = min_u fl(d[u] + w(u,v)) over
+// expanding sources u, so any relaxation schedule reproduces them bit for bit.  Schedule used
+// here: the mesh is cut into Morton tiles of <= tile_size vertices (mnav_build.h).  One
+// workgroup stages a tile's push graph, its distances and its halo in LDS and relaxes to the
+// local fixed point with LDS-only sweeps over an active queue (ds_min on the float bits, 8 lanes
+// per active vertex), restricted to sources below the current band threshold `thr`; it then
+// writes the owned distances back and leaves a wake-up value (the smallest source value still
+// to be propagated) for itself and for the tiles owning halo vertices it undercut.  One launch
+// = one round over all tiles whose wake-up value lies below thr; thr advances by `band` when
+// nothing below it is left.  Sources above the running bound dist[target] + offset are never
+// relaxed (goal_dist cut-off, dijkstra :293-300); the exact cut-off semantics and the
+// predecessors are then produced by one gather pass (k_dij_finalize).
+// ---------------------------------------------------------------------------------------------
+struct TCtl { int32_t it; uint32_t done; float thr; float thr_prev; uint32_t acts; uint32_t sweeps; uint32_t pad[2]; };
+struct TCnt { uint32_t minpend; uint32_t acts; uint32_t sweeps; uint32_t pad; };
+
+struct TilePlan {
+  uint32_t V, ntiles;
+  const uint32_t *vptr, *verts, *hptr, *halo_verts, *halo_tile, *eptr, *rptr;
+  const uint16_t* rowptr;
+  const uint2* cw;         // per local edge {target, push weight bits}; tiles padded to 4 entries
+  float* dist;
+  uint32_t* pend[2];       // per-tile wake-up value (float bits), ping-pong by round parity
+  float* tlast;            // per-tile threshold of its last solve
+  TCtl* ctl;               // [2]
+  TCnt* cnt;               // [3]
+  uint32_t seed, target;
+  double offset;
+  float band;
+  uint32_t max_rounds;
+  uint32_t max_nv, max_nh, max_ne;
+};
+
+constexpr int kTileBlock = 256;
+constexpr int kTileVpt = 8;              // owned vertices per thread: tile_size <= 2048
+constexpr int kTileTodo = 64;            // tiles one workgroup takes per round
+constexpr uint32_t kInfBits = 0x7f800000u;
+
+__host__ __device__ inline uint32_t pad_to(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+
+__host__ __device__ inline size_t tile_lds_bytes(uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
+{
+  const uint32_t nl = max_nv + max_nh;
+  return 8 * (size_t)pad_to(max_ne, 2) + 4 * (size_t)pad_to(nl, 4) + 4 * (size_t)pad_to(max_nv, 4) +
+         4 * (size_t)pad_to(max_nh, 4) + 2 * (size_t)pad_to(nl + 1, 8) + 2 * 2 * (size_t)pad_to(nl, 8);
+}
+
+#ifdef MNAV_TILE_TIMING
+__device__ unsigned long long g_tile_timing[4096 * 8];
+__device__ unsigned int g_tile_timing_n;
+#define TT_STAMP(k) do { if (tid == 0) tt[k] = clock64(); } while (0)
+#else
+#define TT_STAMP(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __restrict__ plans, int j)
+{
+#ifdef MNAV_TILE_TIMING
+  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+  const TilePlan& P = plans[blockIdx.y];
+  const int tid = threadIdx.x;
+  TT_STAMP(0);
+  __shared__ TCtl s_ctl;
+  __shared__ float s_bound;
+  __shared__ uint32_t s_todo[kTileTodo];
+  __shared__ uint32_t s_ntodo;
+  __shared__ uint32_t s_hdr[kTileTodo][8];
+  __shared__ uint32_t s_nq[3];
+  __shared__ uint32_t s_left;
+  if (tid == 0) {
+    const TCtl prev = P.ctl[(j + 1) & 1];
+    const TCnt cprev = P.cnt[(j + 2) % 3];
+    TCtl cur = prev;
+    cur.it = prev.it + 1;
+    cur.acts = prev.acts + cprev.acts;
+    cur.sweeps = prev.sweeps + cprev.sweeps;
+    const float m = u2f(cprev.minpend);
+    const float dt = P.dist[P.target];
+    const float bound = (float)((double)dt + P.offset);            // >= the final goal_dist (dijkstra :296)
+    cur.done = (prev.done || !(m < inf_f()) || m > bound || (uint32_t)cur.it >= P.max_rounds) ? 1u : 0u;
+    if (!cur.done && !(m < prev.thr)) {                             // band exhausted: advance
+      cur.thr_prev = prev.thr;
+      float thr = m + P.band;
+      if (!(thr > m)) thr = next_up(m);
+      cur.thr = thr;
+    }
+    s_ctl = cur; s_bound = bound; s_ntodo = 0;
+    if (blockIdx.x == 0) {
+      P.ctl[j & 1] = cur;
+      TCnt z; z.minpend = kInfBits; z.acts = 0; z.sweeps = 0; z.pad = 0;
+      P.cnt[(j + 1) % 3] = z;
+    }
+  }
+  __syncthreads();
+  const TCtl cur = s_ctl;
+  if (cur.done) return;
+  TT_STAMP(1);
+  const float bound = s_bound, thr = cur.thr;
+  TCnt* cnt = &P.cnt[j % 3];
+  MNAV_GLOBAL uint32_t* pc = as_global(P.pend[cur.it & 1]);
+  MNAV_GLOBAL uint32_t* pn = as_global(P.pend[(cur.it + 1) & 1]);
+  MNAV_GLOBAL const uint32_t* g_vptr = as_global(P.vptr);
+  MNAV_GLOBAL const uint32_t* g_hptr = as_global(P.hptr);
+  MNAV_GLOBAL const uint32_t* g_eptr = as_global(P.eptr);
+  MNAV_GLOBAL const uint32_t* g_rptr = as_global(P.rptr);
+  MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
+  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
+  MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
+  MNAV_GLOBAL float* g_dist = as_global(P.dist);
+  MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
+
+  // every tile is looked at by exactly one thread of one workgroup per round
+  uint32_t carry_min = kInfBits;
+  for (uint32_t t = blockIdx.x + (uint32_t)tid * gridDim.x; t < P.ntiles; t += gridDim.x * kTileBlock) {
+    const uint32_t pb = pc[t];
+    if (pb == kInfBits) continue;
+    pc[t] = kInfBits;
+    const float p = u2f(pb);
+    if (!(p <= bound)) continue;                                    // can never propagate any more
+    bool take = false;
+    if (p < thr) {
+      const uint32_t k = atomicAdd(&s_ntodo, 1u);
+      if (k < (uint32_t)kTileTodo) {
+        s_todo[k] = t; take = true;                                 // ... and fetches the tile header
+        s_hdr[k][0] = g_vptr[t]; s_hdr[k][1] = g_vptr[t + 1]; s_hdr[k][2] = g_hptr[t]; s_hdr[k][3] = g_hptr[t + 1];
+        s_hdr[k][4] = g_eptr[t]; s_hdr[k][5] = g_eptr[t + 1]; s_hdr[k][6] = g_rptr[t]; s_hdr[k][7] = f2u(g_tlast[t]);
+      }
+    }
+    if (!take) { atomicMin((uint32_t*)&pn[t], pb); carry_min = min(carry_min, pb); }   // carry the wake-up over
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) carry_min = min(carry_min, (uint32_t)__shfl_xor((int)carry_min, o));
+  if ((tid & 63) == 0 && carry_min != kInfBits) atomicMin(&cnt->minpend, carry_min);
+  __syncthreads();
+  const uint32_t ntodo = min(s_ntodo, (uint32_t)kTileTodo);
+  if (ntodo == 0) return;
+  TT_STAMP(2);
+  TT_STAMP(3);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t nlmax = P.max_nv + P.max_nh;
+  uint2* lcw = reinterpret_cast<uint2*>(smem);                                    // {target, weight bits}
+  uint32_t* ldu = reinterpret_cast<uint32_t*>(lcw + pad_to(P.max_ne, 2));         // distances (float bits)
+  uint32_t* inq = ldu + pad_to(nlmax, 4);                                         // queue stamps (owned)
+  uint32_t* lh0 = inq + pad_to(P.max_nv, 4);                                      // halo values as loaded
+  uint16_t* lrow = reinterpret_cast<uint16_t*>(lh0 + pad_to(P.max_nh, 4));
+  uint16_t* q0 = lrow + pad_to(nlmax + 1, 8);
+  uint16_t* q1 = q0 + pad_to(nlmax, 8);
+  const int sub = tid & (kGroup - 1);
+
+  for (uint32_t ti = 0; ti < ntodo; ++ti) {
+    const uint32_t t = s_todo[ti];
+    const uint32_t v0 = s_hdr[ti][0], nv = s_hdr[ti][1] - v0;
+    const uint32_t h0 = s_hdr[ti][2], nh = s_hdr[ti][3] - h0;
+    const uint32_t e0 = s_hdr[ti][4], ne = s_hdr[ti][5] - e0;
+    const uint32_t r0 = s_hdr[ti][6];
+    const uint32_t nl = nv + nh;
+    const float tl = u2f(s_hdr[ti][7]);
+    if (tid == 0) { s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0; s_left = kInfBits; }
+    __syncthreads();
+    // stage: all index / bulk loads in flight at once (16-byte vectors), then the distance gathers
+    uint32_t gi[kTileVpt];
+#pragma unroll
+    for (int k = 0; k < kTileVpt; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
+    uint32_t hi[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
+    {
+      MNAV_GLOBAL const u32x4* src = (MNAV_GLOBAL const u32x4*)(P.cw + e0);      // e0, ne multiples of 4 entries
+      u32x4* dst = reinterpret_cast<u32x4*>(lcw);
+      const uint32_t n16 = ne / 2;
+      uint32_t base = tid;
+      for (; base + 7 * kTileBlock < n16; base += 8 * kTileBlock) {              // 8 x 16 B in flight per thread
+        const u32x4 a0 = src[base], a1 = src[base + kTileBlock], a2 = src[base + 2 * kTileBlock], a3 = src[base + 3 * kTileBlock];
+        const u32x4 a4 = src[base + 4 * kTileBlock], a5 = src[base + 5 * kTileBlock], a6 = src[base + 6 * kTileBlock], a7 = src[base + 7 * kTileBlock];
+        dst[base] = a0; dst[base + kTileBlock] = a1; dst[base + 2 * kTileBlock] = a2; dst[base + 3 * kTileBlock] = a3;
+        dst[base + 4 * kTileBlock] = a4; dst[base + 5 * kTileBlock] = a5; dst[base + 6 * kTileBlock] = a6; dst[base + 7 * kTileBlock] = a7;
+      }
+      for (; base < n16; base += kTileBlock) dst[base] = src[base];
+      MNAV_GLOBAL const u32x4* rs = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);   // r0 multiple of 8 entries
+      u32x4* rd = reinterpret_cast<u32x4*>(lrow);
+      const uint32_t nr16 = (nl + 1 + 7) / 8;
+      for (uint32_t i = tid; i < nr16; i += kTileBlock) rd[i] = rs[i];
+    }
+    uint32_t orig[kTileVpt];
+#pragma unroll
+    for (int k = 0; k < kTileVpt; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      orig[k] = 0u;
+      if (i < nv) {
+        const float d = g_dist[gi[k]];
+        orig[k] = f2u(d); ldu[i] = orig[k]; inq[i] = 0u;
+        if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;   // owned sources in [tlast, thr)
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      if (i < nh) { const float d = g_dist[hi[k]]; ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i); }
+    }
+    for (uint32_t i = tid + 2 * kTileBlock; i < nh; i += kTileBlock) {
+      const float d = g_dist[g_halo_verts[h0 + i]];
+      ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
+    }
+    __syncthreads();
+    TT_STAMP(4);
+    // sweeps over the active queue: 8 lanes per active vertex push along its row with ds_min
+    // on the float bits; improved owned targets enter the next queue (stamp-dedup'd), lowered
+    // halo copies are turned into wake-ups for their owners after the sweeps
+    uint32_t sweep = 0;
+    for (;;) {
+      const uint32_t nq = s_nq[sweep % 3];
+      if (nq == 0) break;
+      if (tid == 0) s_nq[(sweep + 2) % 3] = 0;
+      const uint16_t* qa = (sweep & 1) ? q1 : q0;
+      uint16_t* qb = (sweep & 1) ? q0 : q1;
+      uint32_t* nqb = &s_nq[(sweep + 1) % 3];
+      const uint32_t stamp = sweep + 1;
+      for (uint32_t idx = (uint32_t)tid >> 3; idx < nq; idx += kTileBlock / kGroup) {
+        const uint32_t x = qa[idx];
+        const uint32_t dib = ldu[x];
+        const uint32_t eb = lrow[x], ee = lrow[x + 1];              // issued together with ldu[x]
+        const float di = u2f(dib);
+        if (!(di < thr) || !(di <= bound)) continue;
+        for (uint32_t e = eb + sub; e < ee; e += kGroup) {
+          const uint2 cw = lcw[e];
+          const uint32_t ndb = f2u(di + u2f(cw.y));                 // the float add of dijkstra :331
+          const uint32_t old = atomicMin(&ldu[cw.x], ndb);
+          if (ndb < old && cw.x < nv && atomicMax(&inq[cw.x], stamp) < stamp) qb[atomicAdd(nqb, 1u)] = (uint16_t)cw.x;
+        }
+      }
+      ++sweep;
+      __syncthreads();
+    }
+    TT_STAMP(5);
+    // wake the owners of the halo vertices we undercut (value = the candidate we found for them)
+    uint32_t left = kInfBits, own_left = kInfBits;
+    for (uint32_t i = tid; i < nh; i += kTileBlock) {
+      const uint32_t b = ldu[nv + i];
+      if (b < lh0[i]) { atomicMin((uint32_t*)&pn[g_halo_tile[h0 + i]], b); left = min(left, b); }
+    }
+    // write back what moved; remember the smallest owned value that still has to propagate
+#pragma unroll
+    for (int k = 0; k < kTileVpt; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      if (i < nv) {
+        const uint32_t db = ldu[i];
+        if (db != orig[k]) g_dist[gi[k]] = u2f(db);
+        const float d = u2f(db);
+        if (!(d < thr) && d <= bound) { if (db < left) left = db; own_left = min(own_left, db); }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      left = min(left, (uint32_t)__shfl_xor((int)left, o));
+      own_left = min(own_left, (uint32_t)__shfl_xor((int)own_left, o));
+    }
+    if ((tid & 63) == 0) {
+      if (left != kInfBits) atomicMin(&s_left, left);
+      if (own_left != kInfBits) atomicMin((uint32_t*)&pn[t], own_left);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      g_tlast[t] = thr;
+      const uint32_t l = s_left;                                   // own left-overs and halo wake-ups
+      if (l != kInfBits) atomicMin(&cnt->minpend, l);
+      atomicAdd(&cnt->acts, 1u); atomicAdd(&cnt->sweeps, sweep);
+    }
+    __syncthreads();
+#ifdef MNAV_TILE_TIMING
+    if (tid == 0 && ti == 0) {
+      tt[6] = clock64(); tt[7] = ((unsigned long long)cur.it << 32) | sweep;
+      const unsigned int k = atomicAdd(&g_tile_timing_n, 1u);
+      if (k < 4096) for (int q = 0; q < 8; ++q) g_tile_timing[k * 8 + q] = tt[q];
+    }
+#endif
+  }
+}
+
+// per-plan initialisation of the tile state (dist/pred are set by k_init)
+__global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile)
+{
+  const TilePlan& P = plans[blockIdx.y];
+  const uint32_t stride = gridDim.x * kBlock;
+  const uint32_t st = vert_tile[P.seed];
+  for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) {
+    P.pend[0][t] = (t == st) ? 0u : kInfBits;                       // the seed's tile wakes at 0
+    P.pend[1][t] = kInfBits;
+    P.tlast[t] = -inf_f();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.dist[P.seed] = 0.0f;                                          // dijkstra :276
+    TCtl c0; memset(&c0, 0, sizeof(c0));
+    c0.it = -1; c0.done = 0; c0.thr = -inf_f(); c0.thr_prev = -inf_f();
+    P.ctl[0] = c0; P.ctl[1] = c0;
+    TCnt ci; ci.minpend = 0u; ci.acts = 0; ci.sweeps = 0; ci.pad = 0;
+    P.cnt[2] = ci;
+    TCnt z; z.minpend = kInfBits; z.acts = 0; z.sweeps = 0; z.pad = 0;
+    P.cnt[0] = z; P.cnt[1] = z;
+  }
+}
+
+// per-tile weights from the (cost-limit folded) gather CSR
+__global__ __launch_bounds__(kBlock) void k_tile_weights(uint32_t n, const uint32_t* __restrict__ src, const uint16_t* __restrict__ col,
+                                                         const Nbr* __restrict__ nbr, uint2* __restrict__ cw)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) cw[i] = make_uint2((uint32_t)col[i], (src[i] == kNone) ? kInfBits : f2u(nbr[src[i]].w));
+}
+
+// Exact cut-off semantics + predecessors in one gather pass over all vertices (8 lanes per
+// vertex).  After the tile rounds every vertex with dist <= goal_dist holds its final value.
+// A vertex above goal_dist keeps, in the reference, the tentative value it got from expanded
+// (dist <= goal_dist) neighbours only, or +inf -- exactly eval_dijkstra with thr = +inf.
+// pred = first-popped neighbour attaining the minimum (DESIGN.md tie rule).
+__global__ __launch_bounds__(kBlock) void k_dij_finalize(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans,
+                                                         uint32_t* __restrict__ mismatch)
+{
+  const Plan& P = plans[blockIdx.y];
+  const TilePlan& T = tplans[blockIdx.y];
+  const uint32_t target = P.target[0], seed = P.seed[0];
+  const float dt = P.dist[target];
+  Ctl c; memset(&c, 0, sizeof(c));
+  c.thr = inf_f(); c.thr_fixed = -inf_f();
+  c.armed = (dt < inf_f()) ? 1u : 0u;
+  c.goal_dist = c.armed ? (float)((double)dt + P.offset) : inf_f();  // dijkstra :296
+  const int sub = threadIdx.x & (kGroup - 1);
+  const uint32_t ngroups = gridDim.x * (kBlock / kGroup);
+  for (uint32_t v = blockIdx.x * (kBlock / kGroup) + (threadIdx.x >> 3); v < P.V; v += ngroups) {
+    if (v == seed) continue;
+    // NB: vertices the rounds never reached are evaluated too -- a wake-up above the bound is
+    // dropped by the rounds, yet its target still owes a tentative value to an expanded source.
+    const float old = P.dist[v];
+    const Eval e = group_eval_dijkstra(P, c, v, sub);
+    if (sub == 0) {
+      P.pred[v] = e.pred;
+      if (old > c.goal_dist) P.dist[v] = e.d;
+      else if (f2u(e.d) != f2u(old)) atomicAdd(mismatch, 1u);      // fixed point violated: internal error
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const TCtl a = T.ctl[0], b = T.ctl[1];
+    const TCtl last = (a.it > b.it) ? a : b;
+    Ctl r; memset(&r, 0, sizeof(r));
+    r.it = last.it; r.done = last.done; r.armed = c.armed; r.goal_dist = c.goal_dist; r.bands = last.sweeps;
+    r.evals = last.acts; r.thr = inf_f(); r.thr_fixed = inf_f();
+    P.ctl[0] = r; P.ctl[1] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan state initialisation (dijkstra :266-270, cvp :710-714) and seeding (:272-277, :719-728)
+// ---------------------------------------------------------------------------------------------
+template <uint32_t PLANNER>
+__global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
+{
+  const Plan& P = plans[blockIdx.y];
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
+    P.dist[v] = inf_f();
+    P.pred[v] = v;
+    P.stamp[v] = 0u;
+    if (PLANNER == kPlannerCvp) { P.tpop[v] = inf_f(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; }
+  }
+}
+
+template <uint32_t PLANNER>
+__global__ void k_seed(const Plan* __restrict__ plans)
+{
+  const Plan& P = plans[blockIdx.x];
+  if (threadIdx.x != 0) return;
+  constexpr int ns = (PLANNER == kPlannerCvp) ? 3 : 1;
+  float m0 = inf_f();
+  for (int k = 0; k < ns; ++k) {
+    const uint32_t s = P.seed[k];
+    P.dist[s] = P.seed_d[k];
+    if (PLANNER == kPlannerCvp) { P.tpop[s] = P.seed_d[k]; P.cutf[s] = P.seed_face; }
+    m0 = fminf(m0, P.seed_d[k]);
+  }
+  uint32_t n = 0;
+  uint32_t* l0 = P.list[0];
+  for (int k = 0; k < ns; ++k) {
+    const uint32_t s = P.seed[k];
+    if (PLANNER == kPlannerCvp) {
+      for (uint32_t i = P.crn_ptr[s]; i < P.crn_ptr[s + 1]; ++i) {
+        const Corner c = P.crn[i];
+        if (c.v1 == kNone) continue;
+        if (P.stamp[c.v1] != 0xFFFFFFFFu) { P.stamp[c.v1] = 0xFFFFFFFFu; if (n < P.cap) l0[n] = c.v1; ++n; }
+        if (P.stamp[c.v2] != 0xFFFFFFFFu) { P.stamp[c.v2] = 0xFFFFFFFFu; if (n < P.cap) l0[n] = c.v2; ++n; }
+      }
+    } else {
+      for (uint32_t i = P.row_ptr[s]; i < P.row_ptr[s + 1]; ++i) {
+        const uint32_t u = P.nbr[i].u;
+        if (P.stamp[u] != 0xFFFFFFFFu) { P.stamp[u] = 0xFFFFFFFFu; if (n < P.cap) l0[n] = u; ++n; }
+      }
+    }
+  }
+  Ctl c0; memset(&c0, 0, sizeof(c0));
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.thr = m0 + P.delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
+  c0.band_new = 1;
+  P.ctl[1] = c0;
+  P.ctl[0] = c0;
+  Cnt ci; ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u; ci.evals = 0;
+  P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"
+  Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
+  P.cnt[0] = z; P.cnt[1] = z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// result assembly: code + vertex path (dijkstra :358-373) / reachability (cvp :902-918), stats
+// ---------------------------------------------------------------------------------------------
+struct PlanResult {
+  uint32_t code;
+  uint32_t path_len;
+  uint32_t steps, bands, armed, overflow;
+  float goal_dist;
+  uint32_t pad;
+  unsigned long long settled;
+  unsigned long long evals;
+};
+
+template <uint32_t PLANNER>
+__global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict__ res,
+                         uint32_t* __restrict__ paths, uint32_t path_stride)
+{
+  const Plan& P = plans[blockIdx.x];
+  if (threadIdx.x != 0) return;
+  PlanResult& R = res[blockIdx.x];
+  const Ctl a = P.ctl[0], b = P.ctl[1];
+  const Ctl last = (a.it > b.it) ? a : b;
+  R.steps = (uint32_t)(last.it < 0 ? 0 : last.it);
+  R.bands = last.bands; R.armed = last.armed; R.overflow = last.overflow; R.goal_dist = last.goal_dist;
+  R.evals = last.evals;
+  R.path_len = 0;
+  uint32_t code = kSuccess;
+  if (last.overflow || !last.done) code = kInternalError;
+  else if (PLANNER == kPlannerDijkstra) {
+    const uint32_t seed = P.seed[0], target = P.target[0];
+    if (P.pred[target] == target) code = kNoPathFound;             // dijkstra :358
+    else {
+      uint32_t* path = paths + (size_t)blockIdx.x * path_stride;   // written target-side first
+      uint32_t n = 0, v = target;
+      while (v != seed && n < path_stride) { v = P.pred[v]; path[n++] = v; }   // :369-373
+      if (v != seed) code = kInternalError;
+      R.path_len = n;
+    }
+  } else {
+    bool any = false;
+    for (int k = 0; k < 3; ++k) any = any || (P.pred[P.target[k]] != P.target[k]);   // cvp :904-911
+    if (!any && !(P.target[0] == P.seed[0] && P.target[1] == P.seed[1] && P.target[2] == P.seed[2]))
+      code = kNoPathFound;                                                           // :912-918
+  }
+  R.code = code;
+}
+
+__global__ __launch_bounds__(kBlock) void k_count(const Plan* __restrict__ plans, PlanResult* __restrict__ res)
+{
+  const Plan& P = plans[blockIdx.y];
+  uint32_t c = 0;
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) c += (P.dist[v] < inf_f()) ? 1u : 0u;
+  c = wave_sum(c);
+  __shared__ uint32_t s_c[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int k = 0; k < kBlock / 64; ++k) tot += s_c[k];
+    if (tot) atomicAdd(&res[blockIdx.y].settled, (unsigned long long)tot);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector maps: dijkstra :189-209, cvp :204-239
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store3(float* p, float x, float y, float z) { p[0] = x; p[1] = y; p[2] = z; }
+
+__global__ __launch_bounds__(kBlock) void k_vecmap_dijkstra(const Plan* __restrict__ plans, const float* __restrict__ xyz,
+                                                            float* const* __restrict__ vecmaps)
+{
+  const Plan& P = plans[blockIdx.y];
+  float* vm = vecmaps[blockIdx.y];
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
+    const uint32_t p = P.pred[v];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (p != v) {                                               // :197
+      x = xyz[3 * (size_t)p] - xyz[3 * (size_t)v];              // :204
+      y = xyz[3 * (size_t)p + 1] - xyz[3 * (size_t)v + 1];
+      z = xyz[3 * (size_t)p + 2] - xyz[3 * (size_t)v + 2];
+      const float len = sqrtf(x * x + y * y + z * z);           // normalized(), :206
+      x = x / len; y = y / len; z = z / len;
+    }
+    store3(vm + 3 * (size_t)v, x, y, z);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vecmap_cvp(const Plan* __restrict__ plans, const float* __restrict__ xyz,
+                                                       const float* __restrict__ nrm, float* const* __restrict__ vecmaps,
+                                                       const float* __restrict__ seed_pos)
+{
+  const Plan& P = plans[blockIdx.y];
+  float* vm = vecmaps[blockIdx.y];
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
+    const uint32_t p = P.pred[v];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (is_seed(P, v)) {                                        // cvp :722-724 (un-normalised diff)
+      x = seed_pos[0] - xyz[3 * (size_t)v]; y = seed_pos[1] - xyz[3 * (size_t)v + 1]; z = seed_pos[2] - xyz[3 * (size_t)v + 2];
+    } else if (p != v && P.cutf[v] != kNone) {                  // :218, :222-225
+      const float dx = xyz[3 * (size_t)p] - xyz[3 * (size_t)v];
+      const float dy = xyz[3 * (size_t)p + 1] - xyz[3 * (size_t)v + 1];
+      const float dz = xyz[3 * (size_t)p + 2] - xyz[3 * (size_t)v + 2];
+      const float nx = nrm[3 * (size_t)v], ny = nrm[3 * (size_t)v + 1], nz = nrm[3 * (size_t)v + 2];
+      // rotated(normal, direction) :234 -- Rodrigues (CONVENTION, lvr2 un-vendored; see oracle)
+      const float ang = P.dirn[v];
+      const float c = cosf(ang), s = sinf(ang);
+      const float cx = ny * dz - nz * dy, cy = nz * dx - nx * dz, cz = nx * dy - ny * dx;
+      const float ndv = nx * dx + ny * dy + nz * dz;
+      const float k = ndv * (1.0f - c);
+      x = dx * c + cx * s + nx * k; y = dy * c + cy * s + ny * k; z = dz * c + cz * s + nz * k;
+      const float len = sqrtf(x * x + y * y + z * z);           // :236
+      x = x / len; y = y / len; z = z / len;
+    }
+    store3(vm + 3 * (size_t)v, x, y, z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// input preparation
+// ---------------------------------------------------------------------------------------------
+// MeshMap::computeEdgeWeights, mesh_map.cpp:517-561 (exact promotion order, no contraction)
+__global__ __launch_bounds__(kBlock) void k_edge_weights(uint32_t E, const uint32_t* __restrict__ edge_vtx,
+                                                         const float* __restrict__ edge_dist, const float* __restrict__ cost,
+                                                         double factor, float* __restrict__ w)
+{
+  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const float c1 = cost[edge_vtx[2 * (size_t)e]], c2 = cost[edge_vtx[2 * (size_t)e + 1]];   // :528-529
+  if (isinf(c1) || isinf(c2)) { w[e] = inf_f(); return; }                                    // :538-542
+  const float vd = edge_dist[e];                                                             // :548
+  const float edge_cost = (float)((double)(vd * (c1 + c2)) / 2.0);                           // :550
+  w[e] = (float)((double)vd + factor * (double)edge_cost);                                   // :552
+}
+
+// gather CSR for Dijkstra: {u, w(u,v)}; w=+inf when v is invalid (:328) or u is over the cost
+// limit (:302, u would be popped but never expanded)
+__global__ __launch_bounds__(kBlock) void k_build_nbr(uint32_t V, const uint32_t* __restrict__ row_ptr,
+                                                      const uint32_t* __restrict__ nbr_u, const uint32_t* __restrict__ nbr_e,
+                                                      const float* __restrict__ w, const float* __restrict__ cost,
+                                                      const uint8_t* __restrict__ invalid, double cost_limit, Nbr* __restrict__ out)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const bool vinv = invalid[v] != 0;
+  for (uint32_t i = row_ptr[v]; i < row_ptr[v + 1]; ++i) {
+    const uint32_t u = nbr_u[i];
+    float ww = w[nbr_e[i]];
+    if (vinv || (double)cost[u] > cost_limit) ww = inf_f();
+    Nbr n; n.u = u; n.w = ww;
+    out[i] = n;
+  }
+}
+
+struct CornerIdx { uint32_t v1, v2, ea, eb, ec, face; };
+
+__global__ __launch_bounds__(kBlock) void k_build_crn(uint32_t V, const uint32_t* __restrict__ crn_ptr,
+                                                      const CornerIdx* __restrict__ idx, const float* __restrict__ w,
+                                                      const float* __restrict__ cost, const uint8_t* __restrict__ invalid,
+                                                      double cost_limit, Corner* __restrict__ out, uint8_t* __restrict__ blocked)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const bool vinv = invalid[v] != 0;
+  blocked[v] = ((double)cost[v] >= cost_limit || vinv) ? 1 : 0;      // cvp :802,825,848 / :785
+  for (uint32_t i = crn_ptr[v]; i < crn_ptr[v + 1]; ++i) {
+    const CornerIdx k = idx[i];
+    Corner c;
+    c.v1 = (vinv || invalid[k.v1] || invalid[k.v2]) ? kNone : k.v1;   // cvp :785
+    c.v2 = k.v2; c.a = w[k.ea]; c.b = w[k.eb]; c.c = w[k.ec]; c.face = k.face;
+    out[i] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Slot {
+  float *dist = nullptr, *tpop = nullptr, *dirn = nullptr, *vecmap = nullptr;
+  uint32_t *pred = nullptr, *cutf = nullptr, *stamp = nullptr, *list0 = nullptr, *list1 = nullptr;
+  Ctl* ctl = nullptr;
+  Cnt* cnt = nullptr;
+  bool cvp_ready = false;
+  // tiled engine
+  uint32_t *tpend0 = nullptr, *tpend1 = nullptr;
+  float* tlast = nullptr;
+  TCtl* tctl = nullptr;
+  TCnt* tcnt = nullptr;
+  bool tile_ready = false;
+};
+
+}  // namespace
+
+struct mnav_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::atomic<int> cancel{ 0 };
+  // host copies needed for seeding
+  uint32_t V = 0, F = 0, E = 0;
+  std::vector<float> h_xyz;
+  std::vector<uint32_t> h_faces;
+  bool have_mesh = false, have_costs = false, have_normals = false;
+  // device mesh
+  uint32_t *d_row_ptr = nullptr, *d_nbr_u = nullptr, *d_nbr_e = nullptr, *d_crn_ptr = nullptr, *d_edge_vtx = nullptr;
+  CornerIdx* d_crn_idx = nullptr;
+  float *d_xyz = nullptr, *d_nrm = nullptr, *d_cost = nullptr, *d_w = nullptr, *d_edge_dist = nullptr;
+  uint8_t* d_invalid = nullptr;
+  // materialised per cost_limit
+  Nbr* d_nbr = nullptr; double nbr_limit = NAN; bool nbr_valid = false;
+  Corner* d_crn = nullptr; uint8_t* d_blocked = nullptr; double crn_limit = NAN; bool crn_valid = false;
+  // plans
+  std::vector<Slot> slots;
+  Plan* d_plans = nullptr; uint32_t plans_cap = 0;
+  PlanResult* d_res = nullptr; PlanResult* h_res = nullptr;
+  float** d_vecptrs = nullptr;
+  uint32_t* d_paths = nullptr; uint32_t paths_cap = 0;
+  Ctl* h_ctl = nullptr;       // pinned, 2 per plan
+  float* d_seed_pos = nullptr;
+  std::map<uint64_t, hipGraphExec_t> graphs;
+  // tiled SSSP engine
+  int dij_engine = 0;          // 0 tiled, 1 band
+  uint32_t tile_size = 1024;
+  float tile_band_user = 0.f, tile_band_auto = 1.f;
+  uint32_t* d_t_rptr = nullptr;
+  HostTiles tiles_meta;        // only the small per-tile vectors are kept (vert_tile, sizes)
+  uint32_t *d_t_vptr = nullptr, *d_t_verts = nullptr, *d_t_hptr = nullptr, *d_t_halo_verts = nullptr, *d_t_halo_tile = nullptr,
+           *d_t_eptr = nullptr, *d_t_src = nullptr, *d_vert_tile = nullptr, *d_mismatch = nullptr;
+  uint16_t *d_t_rowptr = nullptr, *d_t_col = nullptr;
+  uint2* d_t_cw = nullptr; bool tw_valid = false; uint32_t t_nnz = 0;
+  TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
+  TCtl* h_tctl = nullptr;
+  size_t tile_lds = 0;
+  bool use_graph = true;
+  float delta_user = 0.f, delta_auto = 0.f;
+  uint32_t last_planner = 0, last_n = 0;
+  mnav_stats stats{};
+  uint64_t algo_bytes = 0;
+  hipEvent_t ev[8]{};
+};
+
+namespace {
+
+#define HIPCHK(call)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+      return -1;                                                                                   \
+    }                                                                                              \
+  } while (0)
+
+template <class T>
+int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
+{
+  if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+  HIPCHK(hipMalloc((void**)dptr, sizeof(T) * (n ? n : 1)));
+  if (n && host) HIPCHK(hipMemcpyAsync(*dptr, host, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+void free_slot(Slot& s)
+{
+  (void)hipFree(s.dist); (void)hipFree(s.tpop); (void)hipFree(s.dirn); (void)hipFree(s.vecmap);
+  (void)hipFree(s.pred); (void)hipFree(s.cutf); (void)hipFree(s.stamp); (void)hipFree(s.list0); (void)hipFree(s.list1);
+  (void)hipFree(s.ctl); (void)hipFree(s.cnt);
+  (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tctl); (void)hipFree(s.tcnt);
+  s = Slot{};
+}
+
+void drop_graphs(mnav_ctx* ctx)
+{
+  for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+  ctx->graphs.clear();
+}
+
+int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
+{
+  const size_t V = ctx->V ? ctx->V : 1;
+  while (ctx->slots.size() < n) {
+    Slot s;
+    HIPCHK(hipMalloc((void**)&s.dist, 4 * V)); HIPCHK(hipMalloc((void**)&s.pred, 4 * V));
+    HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.list0, 4 * V));
+    HIPCHK(hipMalloc((void**)&s.list1, 4 * V)); HIPCHK(hipMalloc((void**)&s.vecmap, 12 * V));
+    HIPCHK(hipMalloc((void**)&s.ctl, 2 * sizeof(Ctl))); HIPCHK(hipMalloc((void**)&s.cnt, 3 * sizeof(Cnt)));
+    ctx->slots.push_back(s);
+  }
+  if (cvp)
+    for (uint32_t i = 0; i < n; ++i) {
+      Slot& s = ctx->slots[i];
+      if (!s.cvp_ready) {
+        HIPCHK(hipMalloc((void**)&s.tpop, 4 * V)); HIPCHK(hipMalloc((void**)&s.dirn, 4 * V));
+        HIPCHK(hipMalloc((void**)&s.cutf, 4 * V));
+        s.cvp_ready = true;
+      }
+    }
+  if (ctx->plans_cap < n) {
+    if (ctx->d_plans) (void)hipFree(ctx->d_plans);
+    if (ctx->d_res) (void)hipFree(ctx->d_res);
+    if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+    if (ctx->d_vecptrs) (void)hipFree(ctx->d_vecptrs);
+    ctx->d_plans = nullptr; ctx->d_res = nullptr; ctx->h_res = nullptr; ctx->h_ctl = nullptr; ctx->d_vecptrs = nullptr;
+    drop_graphs(ctx);   // graphs captured the old d_plans pointer
+    HIPCHK(hipMalloc((void**)&ctx->d_plans, sizeof(Plan) * n));
+    HIPCHK(hipMalloc((void**)&ctx->d_res, sizeof(PlanResult) * n));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_res, sizeof(PlanResult) * n, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_ctl, sizeof(Ctl) * 2 * n, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void**)&ctx->d_vecptrs, sizeof(float*) * n));
+    ctx->plans_cap = n;
+  }
+  return 0;
+}
+
+int ensure_paths(mnav_ctx* ctx, uint32_t n)
+{
+  if (ctx->paths_cap < n) {
+    if (ctx->d_paths) (void)hipFree(ctx->d_paths);
+    ctx->d_paths = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_paths, sizeof(uint32_t) * (size_t)n * (ctx->V ? ctx->V : 1)));
+    ctx->paths_cap = n;
+  }
+  return 0;
+}
+
+uint32_t blocks_per_plan(const mnav_ctx* ctx)
+{
+  // the work list of a planar mesh is O(sqrt(V)) long; 8 entries per wave and round
+  const double want = 12.0 * std::sqrt((double)ctx->V) / kGroupsPerWave;
+  uint32_t g = (uint32_t)std::ceil(want);
+  if (const char* e = getenv("MNAV_BLOCKS_PER_PLAN")) g = (uint32_t)atoi(e);
+  if (g < 4) g = 4;
+  if (g > 4096) g = 4096;
+  return g;
+}
+
+template <uint32_t PLANNER>
+int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count)
+{
+  for (int j = 0; j < count; ++j) {
+    hipLaunchKernelGGL(k_step<PLANNER>, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <uint32_t PLANNER>
+int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G)
+{
+  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, kChunk);
+  const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)n << 32) | G;
+  auto it = ctx->graphs.find(key);
+  if (it == ctx->graphs.end()) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = launch_steps<PLANNER>(ctx, n, G, kChunk);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = ctx->graphs.emplace(key, ge).first;
+  }
+  HIPCHK(hipGraphLaunch(it->second, ctx->stream));
+  return 0;
+}
+
+int materialize(mnav_ctx* ctx, bool cvp, double cost_limit)
+{
+  const uint32_t V = ctx->V;
+  const uint32_t gb = (V + kBlock - 1) / kBlock;
+  if (!cvp) {
+    if (ctx->nbr_valid && ctx->nbr_limit == cost_limit) return 0;
+    if (!ctx->d_nbr) HIPCHK(hipMalloc((void**)&ctx->d_nbr, sizeof(Nbr) * (size_t)(ctx->E ? 2 * (size_t)ctx->E : 1)));
+    hipLaunchKernelGGL(k_build_nbr, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, V, ctx->d_row_ptr, ctx->d_nbr_u,
+                       ctx->d_nbr_e, ctx->d_w, ctx->d_cost, ctx->d_invalid, cost_limit, ctx->d_nbr);
+    HIPCHK(hipGetLastError());
+    ctx->nbr_limit = cost_limit; ctx->nbr_valid = true; ctx->tw_valid = false;
+  } else {
+    if (ctx->crn_valid && ctx->crn_limit == cost_limit) return 0;
+    if (!ctx->d_crn) HIPCHK(hipMalloc((void**)&ctx->d_crn, sizeof(Corner) * (size_t)(ctx->F ? 3 * (size_t)ctx->F : 1)));
+    if (!ctx->d_blocked) HIPCHK(hipMalloc((void**)&ctx->d_blocked, V ? V : 1));
+    hipLaunchKernelGGL(k_build_crn, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, V, ctx->d_crn_ptr, ctx->d_crn_idx,
+                       ctx->d_w, ctx->d_cost, ctx->d_invalid, cost_limit, ctx->d_crn, ctx->d_blocked);
+    HIPCHK(hipGetLastError());
+    ctx->crn_limit = cost_limit; ctx->crn_valid = true;
+  }
+  return 0;
+}
+
+struct PlanIn {
+  uint32_t seed[3], target[3];
+  float seed_d[3];
+  uint32_t seed_face;
+  uint32_t seed_expands[3], target_expands[3];
+};
+
+// Runs n plans of one planner to completion on the device.  Returns 0, -1 (error) or 1 (cancelled).
+template <uint32_t PLANNER>
+int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, bool want_path)
+{
+  constexpr bool cvp = PLANNER == kPlannerCvp;
+  if (ensure_slots(ctx, n, cvp)) return -1;
+  if (want_path && ensure_paths(ctx, n)) return -1;
+  const float delta = ctx->delta_user > 0.f ? ctx->delta_user : ctx->delta_auto;
+  std::vector<Plan> hp(n);
+  std::vector<float*> vecs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Slot& s = ctx->slots[i];
+    Plan& P = hp[i];
+    memset(&P, 0, sizeof(P));
+    P.planner = PLANNER; P.V = ctx->V;
+    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+    P.dist = s.dist; P.tpop = cvp ? s.tpop : s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.delta = delta; P.offset = offset; P.max_steps = 0x7FFFFFF0u;
+    for (int k = 0; k < 3; ++k) {
+      P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = in[i].seed_d[k];
+      P.seed_expands[k] = in[i].seed_expands[k]; P.target_expands[k] = in[i].target_expands[k];
+    }
+    P.seed_face = in[i].seed_face;
+    vecs[i] = s.vecmap;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
+
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<PLANNER>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  hipLaunchKernelGGL(k_seed<PLANNER>, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+
+  const uint32_t G = blocks_per_plan(ctx);
+  uint32_t launches = 0;
+  int rc = 0;
+  for (;;) {
+    if (run_chunk<PLANNER>(ctx, n, G)) return -1;
+    launches += kChunk;
+    for (uint32_t i = 0; i < n; ++i)
+      HIPCHK(hipMemcpyAsync(ctx->h_ctl + 2 * i, ctx->slots[i].ctl, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bool all_done = true;
+    for (uint32_t i = 0; i < n; ++i) {
+      const Ctl& a = ctx->h_ctl[2 * i];
+      const Ctl& b = ctx->h_ctl[2 * i + 1];
+      const Ctl& last = a.it > b.it ? a : b;
+      if (!last.done) all_done = false;
+    }
+    if (all_done) break;
+    if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
+  }
+  ctx->stats.launches = launches;
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  return rc;
+}
+
+int ensure_tile_state(mnav_ctx* ctx, uint32_t n)
+{
+  const size_t nt = ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    Slot& s = ctx->slots[i];
+    if (!s.tile_ready) {
+      HIPCHK(hipMalloc((void**)&s.tpend0, 4 * nt)); HIPCHK(hipMalloc((void**)&s.tpend1, 4 * nt));
+      HIPCHK(hipMalloc((void**)&s.tlast, 4 * nt)); HIPCHK(hipMalloc((void**)&s.tctl, 2 * sizeof(TCtl)));
+      HIPCHK(hipMalloc((void**)&s.tcnt, 3 * sizeof(TCnt)));
+      s.tile_ready = true;
+    }
+  }
+  if (ctx->tplans_cap < n) {
+    if (ctx->d_tplans) (void)hipFree(ctx->d_tplans);
+    if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
+    ctx->d_tplans = nullptr; ctx->h_tctl = nullptr;
+    drop_graphs(ctx);
+    HIPCHK(hipMalloc((void**)&ctx->d_tplans, sizeof(TilePlan) * n));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_tctl, sizeof(TCtl) * 2 * n, hipHostMallocDefault));
+    ctx->tplans_cap = n;
+  }
+  if (!ctx->d_mismatch) HIPCHK(hipMalloc((void**)&ctx->d_mismatch, 4));
+  return 0;
+}
+
+int tile_weights(mnav_ctx* ctx)
+{
+  if (ctx->tw_valid) return 0;
+  const uint32_t n = ctx->t_nnz;
+  const uint32_t gb = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_tile_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, n, ctx->d_t_src, ctx->d_t_col, ctx->d_nbr, ctx->d_t_cw);
+  HIPCHK(hipGetLastError());
+  ctx->tw_valid = true;
+  return 0;
+}
+
+constexpr int kTileChunk = 24;   // rounds per graph replay (multiple of 6)
+
+int launch_tile_rounds(mnav_ctx* ctx, uint32_t n, uint32_t G, int count)
+{
+  for (int j = 0; j < count; ++j)
+    hipLaunchKernelGGL(k_tile_round, dim3(G, n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, j % 6);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int run_tile_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G)
+{
+  if (!ctx->use_graph) return launch_tile_rounds(ctx, n, G, kTileChunk);
+  const uint64_t key = (7ull << 60) | ((uint64_t)n << 32) | G;
+  auto it = ctx->graphs.find(key);
+  if (it == ctx->graphs.end()) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = launch_tile_rounds(ctx, n, G, kTileChunk);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = ctx->graphs.emplace(key, ge).first;
+  }
+  HIPCHK(hipGraphLaunch(it->second, ctx->stream));
+  return 0;
+}
+
+// Dijkstra through the tiled engine.  Returns 0, -1 (error) or 1 (cancelled).
+int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
+{
+  if (ensure_slots(ctx, n, false)) return -1;
+  if (ensure_paths(ctx, n)) return -1;
+  if (ensure_tile_state(ctx, n)) return -1;
+  if (tile_weights(ctx)) return -1;
+  const HostTiles& M = ctx->tiles_meta;
+  std::vector<Plan> hp(n);
+  std::vector<TilePlan> tp(n);
+  std::vector<float*> vecs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Slot& s = ctx->slots[i];
+    Plan& P = hp[i];
+    memset(&P, 0, sizeof(P));
+    P.planner = kPlannerDijkstra; P.V = ctx->V;
+    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+    P.dist = s.dist; P.tpop = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u;
+    for (int k = 0; k < 3; ++k) {
+      P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1;
+    }
+    P.seed_face = kNone;
+    vecs[i] = s.vecmap;
+    TilePlan& T = tp[i];
+    memset(&T, 0, sizeof(T));
+    T.V = ctx->V; T.ntiles = M.ntiles;
+    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.cw = ctx->d_t_cw;
+    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
+    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset; T.max_rounds = 0x7FFFFFF0u;
+    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
+    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
+
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  {
+    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
+    if (gt < 1) gt = 1;
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+
+  // active tiles form a ring along the wavefront: O(sqrt(ntiles)); every workgroup scans a
+  // strided share of the tile table, so any grid size is correct
+  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)M.ntiles)) + 8;
+  if (const char* e = getenv("MNAV_TILE_BLOCKS")) G = (uint32_t)atoi(e);
+  if (G > M.ntiles) G = M.ntiles;
+  if (G < 1) G = 1;
+  uint32_t launches = 0;
+  int rc = 0;
+  for (;;) {
+    if (run_tile_chunk(ctx, n, G)) return -1;
+    launches += kTileChunk;
+    for (uint32_t i = 0; i < n; ++i)
+      HIPCHK(hipMemcpyAsync(ctx->h_tctl + 2 * i, ctx->slots[i].tctl, 2 * sizeof(TCtl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bool all_done = true;
+    for (uint32_t i = 0; i < n; ++i) {
+      const TCtl& a = ctx->h_tctl[2 * i];
+      const TCtl& b = ctx->h_tctl[2 * i + 1];
+      const TCtl& last = a.it > b.it ? a : b;
+      if (!last.done) all_done = false;
+    }
+    if (all_done) break;
+    if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
+  }
+  ctx->stats.launches = launches;
+  if (rc == 0) {
+    uint32_t gf = (ctx->V + (kBlock / kGroup) - 1) / (kBlock / kGroup);
+    if (gf > 8192) gf = 8192;
+    if (gf < 1) gf = 1;
+    hipLaunchKernelGGL(k_dij_finalize, dim3(gf, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_mismatch);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  return rc;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+  return ms;
+}
+
+void finish_stats(mnav_ctx* ctx, uint32_t n, bool cvp)
+{
+  mnav_stats& st = ctx->stats;
+  st.n_plans = n;
+  st.steps = 0; st.bands = 0; st.armed = 0; st.goal_dist = INFINITY; st.settled = 0; st.evals = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const PlanResult& r = ctx->h_res[i];
+    if (r.steps > st.steps) st.steps = r.steps;
+    if (r.bands > st.bands) st.bands = r.bands;
+    st.armed += r.armed;
+    if (i == 0) st.goal_dist = r.goal_dist;
+    st.settled += r.settled;
+    st.evals += r.evals;
+  }
+  st.ms_init = ev_ms(ctx->ev[1], ctx->ev[2]);
+  st.ms_propagation = ev_ms(ctx->ev[2], ctx->ev[3]);
+  st.ms_path = ev_ms(ctx->ev[3], ctx->ev[4]);
+  st.ms_vector_map = ev_ms(ctx->ev[4], ctx->ev[5]);
+  st.ms_download = ev_ms(ctx->ev[5], ctx->ev[6]);
+  st.ms_total = ev_ms(ctx->ev[0], ctx->ev[6]);
+  // early-exit variant = settled vertices and their incident edges / faces
+  const double V = ctx->V ? ctx->V : 1;
+  const double frac = (double)st.settled / V;   // summed over plans
+  if (!cvp) ctx->algo_bytes = (uint64_t)(24.0 * st.settled + 24.0 * frac * ctx->E);
+  else ctx->algo_bytes = (uint64_t)(32.0 * st.settled + 68.0 * frac * ctx->F);
+}
+
+int check_ready(mnav_ctx* ctx)
+{
+  if (!ctx) return -1;
+  if (!ctx->have_mesh) { ctx->err = "mnav_upload_mesh has not been called"; return -1; }
+  if (!ctx->have_costs) { ctx->err = "mnav_upload_costs has not been called"; return -1; }
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+mnav_ctx* mnav_create(int device)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  mnav_ctx* ctx = new mnav_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  for (auto& e : ctx->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete ctx; return nullptr; }
+  if (hipMalloc((void**)&ctx->d_seed_pos, 3 * sizeof(float)) != hipSuccess) { delete ctx; return nullptr; }
+  if (const char* e = getenv("MNAV_NO_GRAPH")) ctx->use_graph = !(atoi(e) != 0);
+  if (const char* e = getenv("MNAV_DIJKSTRA_ENGINE")) ctx->dij_engine = (strcmp(e, "band") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+  return ctx;
+}
+
+void mnav_destroy(mnav_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  drop_graphs(ctx);
+  for (auto& s : ctx->slots) free_slot(s);
+  (void)hipFree(ctx->d_row_ptr); (void)hipFree(ctx->d_nbr_u); (void)hipFree(ctx->d_nbr_e); (void)hipFree(ctx->d_crn_ptr);
+  (void)hipFree(ctx->d_edge_vtx); (void)hipFree(ctx->d_crn_idx); (void)hipFree(ctx->d_xyz); (void)hipFree(ctx->d_nrm);
+  (void)hipFree(ctx->d_cost); (void)hipFree(ctx->d_w); (void)hipFree(ctx->d_edge_dist); (void)hipFree(ctx->d_invalid);
+  (void)hipFree(ctx->d_nbr); (void)hipFree(ctx->d_crn); (void)hipFree(ctx->d_blocked); (void)hipFree(ctx->d_plans);
+  (void)hipFree(ctx->d_res); (void)hipFree(ctx->d_vecptrs); (void)hipFree(ctx->d_paths); (void)hipFree(ctx->d_seed_pos);
+  (void)hipFree(ctx->d_t_vptr); (void)hipFree(ctx->d_t_verts); (void)hipFree(ctx->d_t_hptr); (void)hipFree(ctx->d_t_halo_verts);
+  (void)hipFree(ctx->d_t_halo_tile); (void)hipFree(ctx->d_t_eptr); (void)hipFree(ctx->d_t_src); (void)hipFree(ctx->d_vert_tile);
+  (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_cw);
+  (void)hipFree(ctx->d_tplans);
+  if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
+  if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+  if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+  for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* mnav_last_error(const mnav_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const float* xyz, const uint32_t* face_vtx,
+                     const uint32_t* edge_vtx, const float* vertex_normals)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if ((V && !xyz) || (F && !face_vtx) || (E && !edge_vtx)) { ctx->err = "null mesh array"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  HostTopology t;
+  try { t = build_topology(V, F, E, face_vtx, edge_vtx); }
+  catch (const std::exception& ex) { ctx->err = ex.what(); return -2; }
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& s : ctx->slots) free_slot(s);
+  ctx->slots.clear();
+  drop_graphs(ctx);
+  (void)hipFree(ctx->d_paths); ctx->d_paths = nullptr; ctx->paths_cap = 0;
+  (void)hipFree(ctx->d_nbr); ctx->d_nbr = nullptr; (void)hipFree(ctx->d_crn); ctx->d_crn = nullptr;
+  (void)hipFree(ctx->d_blocked); ctx->d_blocked = nullptr;
+  (void)hipFree(ctx->d_cost); ctx->d_cost = nullptr; (void)hipFree(ctx->d_w); ctx->d_w = nullptr;
+  (void)hipFree(ctx->d_invalid); ctx->d_invalid = nullptr; (void)hipFree(ctx->d_edge_dist); ctx->d_edge_dist = nullptr;
+  ctx->nbr_valid = ctx->crn_valid = false; ctx->have_costs = false;
+  ctx->V = V; ctx->F = F; ctx->E = E;
+  ctx->h_xyz.assign(xyz, xyz + 3 * (size_t)V);
+  ctx->h_faces.assign(face_vtx, face_vtx + 3 * (size_t)F);
+  if (dev_upload(ctx, &ctx->d_row_ptr, t.row_ptr.data(), t.row_ptr.size())) return -1;
+  if (dev_upload(ctx, &ctx->d_nbr_u, t.nbr_u.data(), t.nbr_u.size())) return -1;
+  if (dev_upload(ctx, &ctx->d_nbr_e, t.nbr_e.data(), t.nbr_e.size())) return -1;
+  if (dev_upload(ctx, &ctx->d_crn_ptr, t.crn_ptr.data(), t.crn_ptr.size())) return -1;
+  if (dev_upload(ctx, &ctx->d_edge_vtx, edge_vtx, 2 * (size_t)E)) return -1;
+  std::vector<CornerIdx> ci(t.crn_v1.size());
+  for (size_t i = 0; i < ci.size(); ++i) ci[i] = CornerIdx{ t.crn_v1[i], t.crn_v2[i], t.crn_ea[i], t.crn_eb[i], t.crn_ec[i], t.crn_face[i] };
+  if (dev_upload(ctx, &ctx->d_crn_idx, ci.data(), ci.size())) return -1;
+  if (dev_upload(ctx, &ctx->d_xyz, xyz, 3 * (size_t)V)) return -1;
+  ctx->have_normals = vertex_normals != nullptr;
+  if (dev_upload(ctx, &ctx->d_nrm, vertex_normals, vertex_normals ? 3 * (size_t)V : 0)) return -1;
+  // LDS tiles of the SSSP engine
+  {
+    if (const char* e = getenv("MNAV_TILE_SIZE")) ctx->tile_size = (uint32_t)atoi(e);
+    if (ctx->tile_size < 64) ctx->tile_size = 64;
+    if (ctx->tile_size > (uint32_t)(kTileBlock * kTileVpt)) ctx->tile_size = kTileBlock * kTileVpt;
+    HostTiles T;
+    for (;;) {
+      try { T = build_tiles(t, xyz, ctx->tile_size); }
+      catch (const std::exception& ex) { ctx->err = ex.what(); return -2; }
+      ctx->tile_lds = tile_lds_bytes(T.max_nv, T.max_nh, T.max_ne);
+      if (ctx->tile_lds <= 150 * 1024 || ctx->tile_size <= 64) break;
+      ctx->tile_size /= 2;                       // irregular mesh: shrink until a tile fits the 160 KiB LDS
+    }
+    if (ctx->tile_lds > 160 * 1024) { ctx->err = "mesh valence too high for the LDS tile engine"; return -2; }
+    if (ctx->tile_lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)k_tile_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+    (void)hipFree(ctx->d_t_cw); ctx->d_t_cw = nullptr; ctx->tw_valid = false;
+    ctx->t_nnz = (uint32_t)T.col.size();
+    if (dev_upload(ctx, &ctx->d_t_vptr, T.vptr.data(), T.vptr.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_verts, T.verts.data(), T.verts.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_hptr, T.hptr.data(), T.hptr.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_halo_verts, T.halo_verts.data(), T.halo_verts.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_halo_tile, T.halo_tile.data(), T.halo_tile.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_eptr, T.eptr.data(), T.eptr.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_rptr, T.rptr.data(), T.rptr.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_rowptr, T.rowptr.data(), T.rowptr.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_col, T.col.data(), T.col.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_src, T.src.data(), T.src.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_vert_tile, T.vert_tile.data(), T.vert_tile.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_cw, (const uint2*)nullptr, T.col.size())) return -1;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // keep only the sizes on the host
+    T.verts.clear(); T.verts.shrink_to_fit(); T.halo_verts.clear(); T.halo_verts.shrink_to_fit();
+    T.halo_tile.clear(); T.halo_tile.shrink_to_fit(); T.rowptr.clear(); T.rowptr.shrink_to_fit();
+    T.col.clear(); T.col.shrink_to_fit(); T.src.clear(); T.src.shrink_to_fit(); T.vert_tile.clear(); T.vert_tile.shrink_to_fit();
+    ctx->tiles_meta = std::move(T);
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope
+  ctx->have_mesh = true;
+  return 0;
+}
+
+static void auto_delta(mnav_ctx* ctx, const float* w, uint32_t E)
+{
+  double s = 0; uint64_t c = 0;
+  for (uint32_t e = 0; e < E; ++e) if (std::isfinite(w[e])) { s += w[e]; ++c; }
+  ctx->delta_auto = c ? (float)(3.0 * s / (double)c) : 1.0f;
+  if (!(ctx->delta_auto > 0.f)) ctx->delta_auto = 1.0f;
+  // tile band ~ the potential difference across one tile (sqrt(tile_size) mean edges)
+  ctx->tile_band_auto = (ctx->delta_auto / 3.0f) * std::sqrt((float)ctx->tile_size);
+  if (const char* e = getenv("MNAV_TILE_BAND")) ctx->tile_band_user = (float)atof(e);
+}
+
+int mnav_upload_costs(mnav_ctx* ctx, const float* vertex_costs, const float* edge_weights, const uint8_t* invalid)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!ctx->have_mesh) { ctx->err = "mnav_upload_mesh has not been called"; return -1; }
+  if ((ctx->V && !vertex_costs) || (ctx->E && !edge_weights)) { ctx->err = "null cost array"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  if (dev_upload(ctx, &ctx->d_cost, vertex_costs, ctx->V)) return -1;
+  if (dev_upload(ctx, &ctx->d_w, edge_weights, ctx->E)) return -1;
+  std::vector<uint8_t> zero;
+  if (!invalid) { zero.assign(ctx->V ? ctx->V : 1, 0); invalid = zero.data(); }
+  if (dev_upload(ctx, &ctx->d_invalid, invalid, ctx->V)) return -1;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  auto_delta(ctx, edge_weights, ctx->E);
+  ctx->nbr_valid = ctx->crn_valid = false;
+  ctx->have_costs = true;
+  return 0;
+}
+
+int mnav_compute_edge_weights(mnav_ctx* ctx, const float* vertex_costs, const float* edge_distances, double edge_cost_factor,
+                              const uint8_t* invalid, float* edge_weights_out)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!ctx->have_mesh) { ctx->err = "mnav_upload_mesh has not been called"; return -1; }
+  if ((ctx->V && !vertex_costs) || (ctx->E && !edge_distances)) { ctx->err = "null cost array"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  if (dev_upload(ctx, &ctx->d_cost, vertex_costs, ctx->V)) return -1;
+  if (dev_upload(ctx, &ctx->d_edge_dist, edge_distances, ctx->E)) return -1;
+  if (dev_upload(ctx, &ctx->d_w, (const float*)nullptr, ctx->E)) return -1;
+  std::vector<uint8_t> zero;
+  if (!invalid) { zero.assign(ctx->V ? ctx->V : 1, 0); invalid = zero.data(); }
+  if (dev_upload(ctx, &ctx->d_invalid, invalid, ctx->V)) return -1;
+  const uint32_t gb = (ctx->E + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_edge_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, ctx->E, ctx->d_edge_vtx, ctx->d_edge_dist,
+                     ctx->d_cost, edge_cost_factor, ctx->d_w);
+  HIPCHK(hipGetLastError());
+  std::vector<float> w(ctx->E ? ctx->E : 1);
+  HIPCHK(hipMemcpyAsync(w.data(), ctx->d_w, sizeof(float) * ctx->E, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (edge_weights_out) memcpy(edge_weights_out, w.data(), sizeof(float) * ctx->E);
+  auto_delta(ctx, w.data(), ctx->E);
+  ctx->nbr_valid = ctx->crn_valid = false;
+  ctx->have_costs = true;
+  return 0;
+}
+
+static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, const uint32_t* targets, double offset,
+                              double cost_limit, uint32_t* codes_out, float* dist_out, uint32_t* pred_out, uint32_t* path_out,
+                              uint32_t path_cap, uint32_t* path_len, float* vecmap_out, bool want_vecmap)
+{
+  if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
+  ctx->err.clear();
+  ctx->cancel.store(0);                                               // dijkstra :238
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
+  const uint32_t V = ctx->V;
+  uint32_t worst = MNAV_SUCCESS;
+  // id checks stand in for the optional-handle tests of dijkstra :240-243
+  std::vector<PlanIn> in; std::vector<uint32_t> map;   // map: device plan -> caller index
+  std::vector<uint32_t> codes(n, MNAV_SUCCESS);
+  std::vector<uint8_t> cleared(n, 0);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (path_len) path_len[i] = 0;
+    if (seeds[i] >= V) { codes[i] = MNAV_INVALID_START; continue; }
+    if (targets[i] >= V) { codes[i] = MNAV_INVALID_GOAL; continue; }
+    if (seeds[i] == targets[i]) { cleared[i] = 1; continue; }   // :252-255 SUCCESS right after clearing the maps
+    PlanIn p{};
+    for (int k = 0; k < 3; ++k) { p.seed[k] = kNone; p.target[k] = kNone; p.seed_d[k] = 0.f; p.seed_expands[k] = 1; p.target_expands[k] = 1; }
+    p.seed[0] = seeds[i]; p.target[0] = targets[i]; p.seed_face = kNone;
+    in.push_back(p); map.push_back(i);
+  }
+  (void)hipEventRecord(ctx->ev[0], ctx->stream);
+  const uint32_t m = (uint32_t)in.size();
+  ctx->last_planner = kPlannerDijkstra; ctx->last_n = m;
+  if (m) {
+    if (materialize(ctx, false, cost_limit)) return MNAV_INTERNAL_ERROR;
+    const bool want_path = true;
+    const int rc = (ctx->dij_engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
+                                          : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
+    if (rc < 0) return MNAV_INTERNAL_ERROR;
+    if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
+    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
+    const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
+    hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
+    (void)hipEventRecord(ctx->ev[4], ctx->stream);
+    if (want_vecmap)
+      hipLaunchKernelGGL(k_vecmap_dijkstra, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_xyz, ctx->d_vecptrs);
+    (void)hipEventRecord(ctx->ev[5], ctx->stream);
+    if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
+    if (ctx->dij_engine == 0) {
+      uint32_t mism = 0;
+      if (hipMemcpy(&mism, ctx->d_mismatch, 4, hipMemcpyDeviceToHost) != hipSuccess || mism != 0) {
+        ctx->err = "tiled SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)";
+        return MNAV_INTERNAL_ERROR;
+      }
+    }
+    std::vector<uint32_t> tmp;
+    for (uint32_t k = 0; k < m; ++k) {
+      const uint32_t i = map[k];
+      const PlanResult& r = ctx->h_res[k];
+      codes[i] = r.code;
+      if (r.code == MNAV_SUCCESS) {
+        if (path_len) path_len[i] = r.path_len;
+        if (path_out && path_cap) {
+          tmp.resize(r.path_len);
+          if (r.path_len && hipMemcpy(tmp.data(), ctx->d_paths + (size_t)k * V, sizeof(uint32_t) * r.path_len, hipMemcpyDeviceToHost) != hipSuccess)
+            { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
+          // device order: pred[target] ... seed ; reference list order: seed ... pred[target]
+          uint32_t* dst = path_out + (size_t)i * path_cap;
+          for (uint32_t q = 0; q < r.path_len && q < path_cap; ++q) dst[q] = tmp[r.path_len - 1 - q];
+        }
+      }
+      if (dist_out && hipMemcpyAsync(dist_out + (size_t)i * V, ctx->slots[k].dist, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        { ctx->err = "dist download failed"; return MNAV_INTERNAL_ERROR; }
+      if (pred_out && hipMemcpyAsync(pred_out + (size_t)i * V, ctx->slots[k].pred, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        { ctx->err = "pred download failed"; return MNAV_INTERNAL_ERROR; }
+      if (vecmap_out && want_vecmap && hipMemcpyAsync(vecmap_out + (size_t)i * 3 * V, ctx->slots[k].vecmap, 12 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        { ctx->err = "vecmap download failed"; return MNAV_INTERNAL_ERROR; }
+    }
+    (void)hipEventRecord(ctx->ev[6], ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "sync failed"; return MNAV_INTERNAL_ERROR; }
+    finish_stats(ctx, m, false);
+  }
+  // plans rejected before reaching the device: the reference has cleared its maps by then
+  for (uint32_t i = 0; i < n; ++i) {
+    if (codes[i] == MNAV_INVALID_START || codes[i] == MNAV_INVALID_GOAL || cleared[i]) {
+      if (dist_out) for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)i * V + v] = INFINITY;
+      if (pred_out) for (uint32_t v = 0; v < V; ++v) pred_out[(size_t)i * V + v] = v;
+    }
+    if (codes_out) codes_out[i] = codes[i];
+    if (codes[i] != MNAV_SUCCESS && worst == MNAV_SUCCESS) worst = codes[i];
+  }
+  return worst;
+}
+
+uint32_t mnav_plan_dijkstra(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit,
+                            float* dist_out, uint32_t* pred_out, uint32_t* path_out, uint32_t path_cap, uint32_t* path_len,
+                            float* vecmap_out)
+{
+  if (!ctx) return MNAV_INTERNAL_ERROR;
+  uint32_t code = MNAV_INTERNAL_ERROR;
+  uint32_t len = 0;
+  const uint32_t rc = dijkstra_impl(ctx, 1, &seed_vertex, &target_vertex, goal_dist_offset, cost_limit, &code, dist_out, pred_out,
+                                    path_out, path_cap, &len, vecmap_out, true);
+  if (path_len) *path_len = len;
+  return rc == MNAV_INTERNAL_ERROR || rc == MNAV_CANCELED ? rc : code;
+}
+
+uint32_t mnav_plan_dijkstra_batch(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, const uint32_t* targets, double goal_dist_offset,
+                                  double cost_limit, uint32_t* codes_out, float* dist_out, uint32_t* pred_out, uint32_t* path_out,
+                                  uint32_t path_cap, uint32_t* path_len)
+{
+  if (!ctx) return MNAV_INTERNAL_ERROR;
+  if (n == 0) return MNAV_SUCCESS;
+  if (!seeds || !targets) { ctx->err = "null seeds/targets"; return MNAV_INTERNAL_ERROR; }
+  return dijkstra_impl(ctx, n, seeds, targets, goal_dist_offset, cost_limit, codes_out, dist_out, pred_out, path_out, path_cap,
+                       path_len, nullptr, false);
+}
+
+uint32_t mnav_plan_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_face, uint32_t target_face, double goal_dist_offset,
+                       double cost_limit, float* dist_out, uint32_t* pred_out, float* direction_out, uint32_t* cutface_out,
+                       float* vecmap_out)
+{
+  if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
+  ctx->err.clear();
+  ctx->cancel.store(0);                                               // cvp :679
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
+  const uint32_t V = ctx->V;
+  if (seed_face >= ctx->F || !seed_pos) return MNAV_INVALID_START;   // cvp :681-685
+  if (target_face >= ctx->F) return MNAV_INVALID_GOAL;                // cvp :686-690
+  if (!ctx->have_normals) { ctx->err = "vertex normals were not uploaded"; return MNAV_INTERNAL_ERROR; }
+  (void)hipEventRecord(ctx->ev[0], ctx->stream);
+  if (materialize(ctx, true, cost_limit)) return MNAV_INTERNAL_ERROR;
+  // the cut-off flags of the seed / robot-face vertices need cost + invalid on the host: fetch 6 values
+  PlanIn p{};
+  float costs[6]; uint8_t inv[6];
+  for (int k = 0; k < 3; ++k) {
+    p.seed[k] = ctx->h_faces[3 * (size_t)seed_face + k];
+    p.target[k] = ctx->h_faces[3 * (size_t)target_face + k];
+  }
+  for (int k = 0; k < 3; ++k) {
+    if (hipMemcpyAsync(&costs[k], ctx->d_cost + p.seed[k], 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&costs[3 + k], ctx->d_cost + p.target[k], 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&inv[k], ctx->d_invalid + p.seed[k], 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(&inv[3 + k], ctx->d_invalid + p.target[k], 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      { ctx->err = "cost fetch failed"; return MNAV_INTERNAL_ERROR; }
+  }
+  if (hipMemcpyAsync(ctx->d_seed_pos, seed_pos, 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "seed upload failed"; return MNAV_INTERNAL_ERROR; }
+  for (int k = 0; k < 3; ++k) {
+    // cvp :721-723  diff = start - vertex; dist = diff.length()  (float arithmetic)
+    const float dx = seed_pos[0] - ctx->h_xyz[3 * (size_t)p.seed[k]];
+    const float dy = seed_pos[1] - ctx->h_xyz[3 * (size_t)p.seed[k] + 1];
+    const float dz = seed_pos[2] - ctx->h_xyz[3 * (size_t)p.seed[k] + 2];
+    const float l2 = dx * dx + dy * dy + dz * dz;
+    p.seed_d[k] = sqrtf(l2);
+    p.seed_expands[k] = (!((double)costs[k] >= cost_limit) && !inv[k]) ? 1u : 0u;           // cvp :757,760
+    p.target_expands[k] = (!((double)costs[3 + k] >= cost_limit) && !inv[3 + k]) ? 1u : 0u;
+  }
+  p.seed_face = seed_face;
+  std::vector<PlanIn> in{ p };
+  ctx->last_planner = kPlannerCvp; ctx->last_n = 1;
+  const int rc = run_plans<kPlannerCvp>(ctx, 1, in, goal_dist_offset, false);
+  if (rc < 0) return MNAV_INTERNAL_ERROR;
+  if (rc == 1) return MNAV_CANCELED;                                  // cvp :888-892
+  hipLaunchKernelGGL(k_finish<kPlannerCvp>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, (uint32_t*)nullptr, 0u);
+  const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
+  hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
+  (void)hipEventRecord(ctx->ev[4], ctx->stream);
+  hipLaunchKernelGGL(k_vecmap_cvp, dim3(gc ? gc : 1, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_xyz, ctx->d_nrm,
+                     ctx->d_vecptrs, ctx->d_seed_pos);                // cvp :897
+  (void)hipEventRecord(ctx->ev[5], ctx->stream);
+  Slot& s = ctx->slots[0];
+  bool ok = hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  if (ok && dist_out) ok = hipMemcpyAsync(dist_out, s.dist, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  if (ok && pred_out) ok = hipMemcpyAsync(pred_out, s.pred, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  if (ok && direction_out) ok = hipMemcpyAsync(direction_out, s.dirn, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  if (ok && cutface_out) ok = hipMemcpyAsync(cutface_out, s.cutf, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  if (ok && vecmap_out) ok = hipMemcpyAsync(vecmap_out, s.vecmap, 12 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  (void)hipEventRecord(ctx->ev[6], ctx->stream);
+  if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "output download failed"; return MNAV_INTERNAL_ERROR; }
+  finish_stats(ctx, 1, true);
+  return ctx->h_res[0].code;
+}
+
+void mnav_cancel(mnav_ctx* ctx) { if (ctx) ctx->cancel.store(1, std::memory_order_relaxed); }
+
+int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out)
+{
+  if (!ctx || !out) return -1;
+  *out = ctx->stats;
+  return 0;
+}
+
+int mnav_set_band_width(mnav_ctx* ctx, float delta)
+{
+  if (!ctx) return -1;
+  ctx->delta_user = delta > 0.f ? delta : 0.f;
+  return 0;
+}
+
+int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
+{
+  if (!ctx || engine < 0 || engine > 1) return -1;
+  ctx->dij_engine = engine;
+  return 0;
+}
+
+const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
+{
+  if (!ctx || slot >= ctx->slots.size()) return nullptr;
+  const Slot& s = ctx->slots[slot];
+  switch (what) {
+    case 0: return s.dist;
+    case 1: return s.pred;
+    case 2: return s.dirn;
+    case 3: return s.cutf;
+    case 4: return s.vecmap;
+    default: return nullptr;
+  }
+}
+
+uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx) { return ctx ? ctx->algo_bytes : 0; }
+
+#ifdef MNAV_TILE_TIMING
+int mnav_debug_tile_timing(unsigned long long* out, unsigned int cap)
+{
+  unsigned int n = 0;
+  (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_tile_timing_n), sizeof(n));
+  if (n > 4096) n = 4096;
+  if (n > cap) n = cap;
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_timing), sizeof(unsigned long long) * 8 * n);
+  unsigned int z = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_timing_n), &z, sizeof(z));
+  return (int)n;
+}
+#endif
+
+}  // extern "C"

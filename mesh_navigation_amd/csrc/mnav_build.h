@@ -6,8 +6,10 @@
 // reference walks on every pop (getEdgesOfVertex :305-308, getFacesOfVertex cvp :775-776,
 // getEdgeBetween cvp :380-390) become flat CSR arrays.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <numeric>
 #include <stdexcept>
 #include <vector>
 
@@ -156,6 +158,142 @@ inline void materialize_host(const HostTopology& t, const float* edge_weights, c
   blocked.resize(t.V);
   for (uint32_t v = 0; v < t.V; ++v)
     blocked[v] = ((double)vertex_costs[v] >= cost_limit || (invalid && invalid[v])) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tiles for the label-correcting SSSP engine (mnav.hip: k_tile_round).  Vertices are sorted
+// along a Morton curve of their quantised positions and cut into chunks of <= tile_size
+// vertices.  A tile's local graph is PUSH oriented: local vertex x (owned vertices first, then
+// the halo = neighbours owned by other tiles) lists the local vertices y it can relax, with the
+// weight w(x -> y) taken from row y of the global gather CSR (entry `src`).  Owned vertices list
+// all their neighbours (owned and halo), halo vertices only their owned neighbours.
+// ---------------------------------------------------------------------------------------------
+struct HostTiles {
+  uint32_t ntiles = 0, tile_size = 0;
+  uint32_t max_nv = 0, max_nh = 0, max_ne = 0;
+  std::vector<uint32_t> vptr;        // ntiles+1 -> verts
+  std::vector<uint32_t> verts;       // V   vertex ids grouped by tile
+  std::vector<uint32_t> hptr;        // ntiles+1 -> halo_verts / halo_tile
+  std::vector<uint32_t> halo_verts;  // vertex ids of the halo
+  std::vector<uint32_t> halo_tile;   // owning tile of each halo vertex
+  std::vector<uint32_t> eptr;        // ntiles+1 -> col / src (each tile padded to a multiple of 4 entries)
+  std::vector<uint32_t> rptr;        // ntiles+1 -> rowptr (nv+nh+1 entries per tile, padded to a multiple of 8)
+  std::vector<uint16_t> rowptr;      // local row pointers
+  std::vector<uint16_t> col;         // tile-local target index: < nv owned, else nv + halo index
+  std::vector<uint32_t> src;         // position of w(x -> y) in the global gather CSR; kNone on padding
+  std::vector<uint32_t> vert_tile;   // V   tile of a vertex
+};
+
+namespace detail {
+inline uint64_t spread3(uint64_t x)   // 21 bits -> every third bit
+{
+  x &= 0x1fffffULL;
+  x = (x | x << 32) & 0x1f00000000ffffULL;
+  x = (x | x << 16) & 0x1f0000ff0000ffULL;
+  x = (x | x << 8) & 0x100f00f00f00f00fULL;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+  x = (x | x << 2) & 0x1249249249249249ULL;
+  return x;
+}
+}  // namespace detail
+
+inline HostTiles build_tiles(const HostTopology& t, const float* xyz, uint32_t tile_size)
+{
+  HostTiles T;
+  const uint32_t V = t.V;
+  T.tile_size = tile_size;
+  // Morton order of quantised positions (isotropic scale: the largest extent maps to 2^21)
+  float lo[3] = { 0, 0, 0 }, hi[3] = { 0, 0, 0 };
+  for (uint32_t v = 0; v < V; ++v)
+    for (int k = 0; k < 3; ++k) {
+      const float x = xyz[3 * size_t(v) + k];
+      if (v == 0 || x < lo[k]) lo[k] = x;
+      if (v == 0 || x > hi[k]) hi[k] = x;
+    }
+  float ext = 0;
+  for (int k = 0; k < 3; ++k) ext = std::max(ext, hi[k] - lo[k]);
+  const double scale = ext > 0 ? 2097151.0 / ext : 0.0;
+  std::vector<uint64_t> key(V);
+  for (uint32_t v = 0; v < V; ++v) {
+    uint64_t q[3];
+    for (int k = 0; k < 3; ++k) {
+      double f = (double(xyz[3 * size_t(v) + k]) - lo[k]) * scale;
+      if (!(f >= 0)) f = 0;
+      if (f > 2097151.0) f = 2097151.0;
+      q[k] = (uint64_t)f;
+    }
+    key[v] = detail::spread3(q[0]) | (detail::spread3(q[1]) << 1) | (detail::spread3(q[2]) << 2);
+  }
+  T.verts.resize(V);
+  std::iota(T.verts.begin(), T.verts.end(), 0u);
+  std::sort(T.verts.begin(), T.verts.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+
+  // chunk: <= tile_size vertices and < 60000 directed entries per tile (16-bit local row pointers)
+  T.vert_tile.assign(V, 0);
+  T.vptr.push_back(0);
+  {
+    uint32_t nv = 0; uint64_t ne = 0;
+    for (uint32_t i = 0; i < V; ++i) {
+      const uint32_t v = T.verts[i];
+      const uint32_t deg = t.row_ptr[v + 1] - t.row_ptr[v];
+      if (nv > 0 && (nv >= tile_size || ne + deg >= 60000)) { T.vptr.push_back(i); nv = 0; ne = 0; }
+      T.vert_tile[v] = uint32_t(T.vptr.size() - 1);
+      ++nv; ne += deg;
+    }
+    T.vptr.push_back(V);
+  }
+  T.ntiles = uint32_t(T.vptr.size() - 1);
+  if (V == 0) { T.ntiles = 0; T.vptr.assign(1, 0); }
+
+  // position of source x inside row y of the gather CSR
+  auto pos_in_row = [&](uint32_t y, uint32_t x) -> uint32_t {
+    for (uint32_t k = t.row_ptr[y]; k < t.row_ptr[y + 1]; ++k) if (t.nbr_u[k] == x) return k;
+    return kNone;
+  };
+  std::vector<uint32_t> local(V, kNone);     // vertex -> local index inside the tile being built
+  T.hptr.assign(1, 0); T.eptr.assign(1, 0); T.rptr.assign(1, 0);
+  std::vector<uint32_t> halo;
+  for (uint32_t tl = 0; tl < T.ntiles; ++tl) {
+    const uint32_t b = T.vptr[tl], e = T.vptr[tl + 1], nv = e - b;
+    for (uint32_t i = b; i < e; ++i) local[T.verts[i]] = i - b;
+    halo.clear();
+    for (uint32_t i = b; i < e; ++i) {
+      const uint32_t v = T.verts[i];
+      for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
+        const uint32_t u = t.nbr_u[k];
+        if (local[u] == kNone) { local[u] = nv + uint32_t(halo.size()); halo.push_back(u); }
+      }
+    }
+    const uint32_t nh = uint32_t(halo.size());
+    if (nv + nh > 0xFFFFu) throw std::invalid_argument("tile too large for 16-bit local indices");
+    uint32_t ne = 0;
+    for (uint32_t x = 0; x < nv + nh; ++x) {
+      const uint32_t gx = x < nv ? T.verts[b + x] : halo[x - nv];
+      T.rowptr.push_back(uint16_t(ne));
+      for (uint32_t k = t.row_ptr[gx]; k < t.row_ptr[gx + 1]; ++k) {
+        const uint32_t gy = t.nbr_u[k];
+        const uint32_t ly = local[gy];
+        if (ly == kNone) continue;                 // halo vertex: neighbour outside the tile
+        if (x >= nv && ly >= nv) continue;         // halo -> halo is not this tile's business
+        T.col.push_back(uint16_t(ly));
+        T.src.push_back(pos_in_row(gy, gx));
+        ++ne;
+      }
+    }
+    if (ne > 0xFFFFu) throw std::invalid_argument("tile too large for 16-bit local row pointers");
+    T.rowptr.push_back(uint16_t(ne));
+    while (T.rowptr.size() % 8) T.rowptr.push_back(uint16_t(ne));
+    while (T.col.size() % 4) { T.col.push_back(0); T.src.push_back(kNone); }
+    for (uint32_t h = 0; h < nh; ++h) { T.halo_verts.push_back(halo[h]); T.halo_tile.push_back(T.vert_tile[halo[h]]); local[halo[h]] = kNone; }
+    for (uint32_t i = b; i < e; ++i) local[T.verts[i]] = kNone;
+    T.hptr.push_back(uint32_t(T.halo_verts.size()));
+    T.eptr.push_back(uint32_t(T.col.size()));
+    T.rptr.push_back(uint32_t(T.rowptr.size()));
+    T.max_nv = std::max(T.max_nv, nv);
+    T.max_nh = std::max(T.max_nh, nh);
+    T.max_ne = std::max(T.max_ne, uint32_t(T.col.size()) - T.eptr[tl]);   // padded entry count (staged as is)
+  }
+  return T;
 }
 
 }  // namespace mnav

@@ -55,10 +55,15 @@ MNAV_HD float next_up(float x) { return (x >= 0.0f) ? u2f(f2u(x) + 1u) : u2f(f2u
 // ---------------------------------------------------------------------------------------
 struct CvpUpd { float u3; float dir; int sel; bool ok; };  // sel: 1 -> pred=v1, 2 -> pred=v2
 
-MNAV_HD CvpUpd cvp_update(float u1f, float u2f_, float u3f, float af, float bf, float cf)
+// The update splits into a part that does not depend on the current value u3 of the free vertex
+// (candidate) and two strict '<' gates against u3 (apply).  kind: 1 = planar solution u3tmp is
+// accepted as is (:493-517), 2 = edge fall-back u1+b / u2+a (:418-454, :518-553).
+struct CvpCand { double u3tmp; double cand; float dir; int sel; int kind; };
+
+MNAV_HD CvpCand cvp_candidate(float u1f, float u2f_, float af, float bf, float cf)
 {
-  CvpUpd r; r.ok = false; r.u3 = u3f; r.dir = 0.0f; r.sel = 0;
-  const double u1 = u1f, u2 = u2f_, u3 = u3f;              // :376-378
+  CvpCand r;
+  const double u1 = u1f, u2 = u2f_;                         // :376-377
   const double c = cf, c_sq = c * c;                        // :381-382
   const double b = bf, b_sq = b * b;                        // :385-386
   const double a = af, a_sq = a * a;                        // :389-390
@@ -69,8 +74,8 @@ MNAV_HD CvpUpd cvp_update(float u1f, float u2f_, float u3f, float af, float bf, 
   const double hc = sqrt(fmax(b_sq - p * p, 0.0));          // :399
   const double dy = hc - sy, dx = p - sx;                   // :401-402
   const double u3tmp_sq = dx * dx + dy * dy;                // :404
-  double u3tmp = sqrt(u3tmp_sq);                            // :405
-  if (!(u3tmp < u3)) return r;                              // :411
+  const double u3tmp = sqrt(u3tmp_sq);                      // :405
+  r.u3tmp = u3tmp; r.cand = u3tmp; r.dir = 0.0f; r.sel = 0; r.kind = 1;
   const double t0a = (a_sq + b_sq - c_sq) / (2 * a * b);            // :413
   const double t1a = (u3tmp_sq + b_sq - u1_sq) / (2 * u3tmp * b);   // :414
   const double t2a = (a_sq + u3tmp_sq - u2_sq) / (2 * a * u3tmp);   // :415
@@ -80,15 +85,31 @@ MNAV_HD CvpUpd cvp_update(float u1f, float u2f_, float u3f, float af, float bf, 
   else {
     const double theta0 = acos(t0a), theta1 = acos(t1a), theta2 = acos(t2a);  // :456-458
     if (theta1 < theta0 && theta2 < theta0) {               // :493
-      r.ok = true; r.u3 = (float)u3tmp;                     // :497
       if (theta1 < theta2) { r.sel = 1; r.dir = (float)theta1; }     // :498-501
       else { r.sel = 2; r.dir = (float)(-theta2); }                  // :507-510
       return r;
     }
     fallback = (theta1 < theta2) ? 1 : 2;                   // :518 / :536
   }
-  u3tmp = (fallback == 1) ? (u1 + b) : (u2 + a);            // :420,439,520,538
-  if (u3tmp < u3) { r.ok = true; r.u3 = (float)u3tmp; r.sel = fallback; r.dir = 0.0f; }
+  r.kind = 2; r.sel = fallback;
+  r.cand = (fallback == 1) ? (u1 + b) : (u2 + a);           // :420,439,520,538
+  return r;
+}
+
+// Gates of :411 and :421,440,521,539 against the current value; returns the reference's bool.
+MNAV_HD bool cvp_apply(const CvpCand& k, float& u3, int& sel, float& dir)
+{
+  if (!(k.u3tmp < (double)u3)) return false;                // :411
+  if (k.kind == 2 && !(k.cand < (double)u3)) return false;  // :421,440,521,539
+  u3 = (float)k.cand; sel = k.sel; dir = k.dir;             // :430,449,497,526,544
+  return true;
+}
+
+MNAV_HD CvpUpd cvp_update(float u1f, float u2f_, float u3f, float af, float bf, float cf)
+{
+  CvpUpd r; r.u3 = u3f; r.dir = 0.0f; r.sel = 0;
+  const CvpCand k = cvp_candidate(u1f, u2f_, af, bf, cf);
+  r.ok = cvp_apply(k, r.u3, r.sel, r.dir);
   return r;
 }
 
@@ -109,7 +130,7 @@ struct Ctl {
   uint32_t bands;      // statistics
   uint32_t overflow;   // work-list overflow (never with capacity V; reported as internal error)
   uint32_t repair;     // this step is the post-arming repair sweep over all vertices
-  uint32_t pad;
+  uint32_t evals;      // statistics: vertex evaluations so far
 };
 
 struct Cnt {
@@ -145,6 +166,8 @@ struct Plan {
   double offset;           // goal_dist_offset
   uint32_t seed[3];        // wave seed vertices (Dijkstra: seed[0], others kNone)
   uint32_t seed_expands[3];// seed passes the cost/invalid cut-offs (cvp :757,760)
+  float seed_d[3];         // initial potential of the seeds (Dijkstra 0; CVP Euclidean, cvp :721-723)
+  uint32_t seed_face;      // CVP: cutting face of the seeds (cvp :725)
   uint32_t target[3];      // robot vertex / robot-face vertices
   uint32_t target_expands[3];
   uint32_t max_steps;
@@ -197,6 +220,7 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
   Ctl q = p;
   q.it = p.it + 1;
   q.repair = 0;
+  q.evals = p.evals + c.evals;
   if (p.done) { q.n = 0; return q; }
   q.n = c.n_next;
   if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
@@ -310,16 +334,17 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 // One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list),
 // note_changed(), note_min(float), note_eval().
 // ---------------------------------------------------------------------------------------
-template <class Ops>
+template <uint32_t PLANNER, class Ops>
 MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 {
   if (is_seed(P, v)) return;                                     // seeds are fixed from the start
-  const bool cvp = (P.planner == kPlannerCvp);
+  constexpr bool cvp = (PLANNER == kPlannerCvp);
   const float old_t = cvp ? P.tpop[v] : P.dist[v];
   if (old_t < c.thr_fixed) return;                               // settled by an earlier band
   if (cvp && P.blocked[v]) return;                               // never updated (cvp :802,825,848)
   ops.note_eval();
-  const Eval e = cvp ? eval_cvp(P, c, v) : eval_dijkstra(P, c, v);
+  Eval e;
+  if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
   const float old_d = P.dist[v];
   bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t));
   if (cvp) changed = changed || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
@@ -350,17 +375,18 @@ MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 }
 
 // Repair sweep entry (one per vertex, step with ctl.repair == 1): see controller().
-template <class Ops>
+template <uint32_t PLANNER, class Ops>
 MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 {
   if (is_seed(P, v)) return;
-  const bool cvp = (P.planner == kPlannerCvp);
+  constexpr bool cvp = (PLANNER == kPlannerCvp);
   float d = P.dist[v];
   if (!(d < inf_f())) return;
   float t = cvp ? P.tpop[v] : d;
   if (d > c.goal_dist) {
     ops.note_eval();
-    const Eval e = cvp ? eval_cvp(P, c, v) : eval_dijkstra(P, c, v);
+    Eval e;
+    if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
     P.dist[v] = e.d; P.pred[v] = e.pred;
     if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
     d = e.d; t = e.t;

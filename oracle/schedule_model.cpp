@@ -127,7 +127,10 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1) };
     const uint32_t* list = P.list[j & 1];
     if (cur.repair) {
-      for (uint32_t v = 0; v < V; ++v) process_repair(P, cur, v, ops);
+      for (uint32_t v = 0; v < V; ++v) {
+        if (planner == kPlannerCvp) process_repair<kPlannerCvp>(P, cur, v, ops);
+        else process_repair<kPlannerDijkstra>(P, cur, v, ops);
+      }
     } else {
       perm.resize(cur.n);
       for (uint32_t i = 0; i < cur.n; ++i) perm[i] = i;
@@ -137,7 +140,10 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
           rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
           std::swap(perm[i - 1], perm[rng % i]);
         }
-      for (uint32_t i = 0; i < cur.n; ++i) process_entry(P, cur, list[perm[i]], ops);
+      for (uint32_t i = 0; i < cur.n; ++i) {
+        if (planner == kPlannerCvp) process_entry<kPlannerCvp>(P, cur, list[perm[i]], ops);
+        else process_entry<kPlannerDijkstra>(P, cur, list[perm[i]], ops);
+      }
     }
     evals += cc.evals;
   }

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_factory():
+    """Factory for device contexts; GPU tests fail loudly (no skip) when the HIP path is unusable."""
+    from mesh_navigation_amd import capi
+
+    made = []
+
+    def make():
+        ctx = capi.MnavContext(0)
+        made.append(ctx)
+        return ctx
+
+    yield make
+    for c in made:
+        c.close()
