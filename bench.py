@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""bench.py -- plans/sec of the MI355X wavefront planner on BASELINE config C2.
+
+One "step" = one batch of B independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex
+synthetic terrain (N=1000, h=0.1 m, seed 2, edge_cost_factor 0, reference default
+cut-offs goal_dist_offset 0.3 / cost_limit 1.0), B goal vertices drawn per step, common robot
+vertex (the concurrent-goals shape of BASELINE config 5).  Mesh and costs are resident in HBM
+before the timed region; each plan returns its vertex-index path, the V-sized fields stay on the
+device.  For N > 1 every rank (one per GPU) runs its own batches on its own replica of the mesh:
+the path shards by plan, there is no data-path collective (weak scaling).
+
+Prints ONE JSON line (see the task contract).  `value` = plans/s of the whole job.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "64")))
+    ap.add_argument("--grid", type=int, default=int(os.environ.get("MNAV_BENCH_N", "1000")))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from mesh_navigation_amd import capi, meshgen
+
+    N, B = args.grid, args.batch
+    mesh = meshgen.terrain(N, 0.1, 2)
+    edge_w = meshgen.edge_lengths(mesh)                  # edge_cost_factor 0 -> weights == edge distances
+    costs = np.zeros(mesh.V, np.float32)
+    ctx = capi.MnavContext(local_rank)
+    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
+    ctx.upload_costs(costs, edge_w)
+    robot = mesh.vertex_at(0.9, 0.9)
+    rng = np.random.default_rng(5 + 1000 * rank)
+
+    def batch_goals():
+        g = rng.choice(mesh.V, size=B, replace=False).astype(np.uint32)
+        return g, np.full(B, robot, np.uint32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    first = None
+    for _ in range(max(args.warmup, 0)):
+        g, t = batch_goals()
+        r = ctx.plan_dijkstra_batch(g, t, want_fields=False, path_cap=16384)
+        if first is None:
+            first = (g, t, r)
+    prop_ms = launches = algo = 0.0
+    settled = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g, t = batch_goals()
+        r = ctx.plan_dijkstra_batch(g, t, want_fields=False, path_cap=16384)
+        assert (r["codes"] == 0).all(), r["codes"]
+        st = r["stats"]
+        prop_ms += st["ms_propagation"]; launches += st["launches"]; algo += st["algorithmic_bytes"]
+        settled += st["settled"]
+        if first is None:
+            first = (g, t, r)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # single-plan latency (ms/makePlan, device part) -- rank 0 only, outside the timed region
+    single_ms = None
+    if rank == 0:
+        lat = []
+        for k in range(5):
+            o = ctx.plan_dijkstra(int(first[0][k % B]), robot, want_fields=False)
+            lat.append(o.stats["ms_total"])
+        single_ms = float(np.median(lat))
+
+    out = None
+    if rank == 0:
+        total_plans = world * B * args.steps
+        ms_step = elapsed / args.steps * 1e3
+        # roofline of the dominant kernel (k_tile_round): algorithmic bytes per launch (SURVEY.md
+        # §8d: 24 B per settled vertex + 24 B per incident edge, summed over the batch) divided by
+        # the average launch duration from the HIP events the library records on its own stream
+        # around the propagation phase (all k_tile_round launches + the finalize gather).
+        per_launch_bytes = algo / max(launches, 1)
+        per_launch_s = prop_ms * 1e-3 / max(launches, 1)
+        achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        out = {
+            "metric": "plans/sec (Dijkstra makePlan device path, 1M-vertex mesh)",
+            "value": total_plans / elapsed,
+            "unit": "plans/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C2: delta-stepping SSSP (tiled label-correcting), {N}x{N} terrain = {mesh.V} vertices, "
+                                   f"uniform edge costs, batch of {B} goals per step per GPU, goal_dist_offset 0.3",
+                       "vertices": mesh.V, "edges": mesh.E, "batch_per_gpu": B,
+                       "parallelism": f"{world} independent replicas (plans sharded by rank)"},
+            "ms_per_makeplan_single": single_ms,
+            "ms_per_plan_in_batch": ms_step / B,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_tile_round", "launches_per_step": launches / args.steps,
+                         "algorithmic_bytes_per_step": algo / args.steps,
+                         "avg_launch_us": per_launch_s * 1e6,
+                         "settled_vertices_per_plan": settled / max(args.steps * B, 1)},
+        }
+        if not args.no_cpu and world >= 1:
+            out["cpu_baseline"] = cpu_baseline(mesh, edge_w, costs, first, B)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(mesh, edge_w, costs, first, B):
+    """The oracle (C restatement of dijkstra_mesh_planner.cpp:217-398, -O3, one thread) timed on this
+    box's host cores on the plans of the first batch; also checks the GPU paths of that batch."""
+    from oracle import oracle as O
+    om = O.OracleMesh(mesh.xyz, mesh.faces)
+    g, t, r = first
+    n = min(B, 64)
+    t_sum = 0.0
+    ok = True
+    tw = time.perf_counter()
+    for k in range(n):
+        ref = om.dijkstra(edge_w, costs, int(g[k]), int(t[k]))
+        t_sum += ref.stats["t_init_ms"] + ref.stats["t_propagation_ms"] + ref.stats["t_backtrack_ms"]
+        ok = ok and ref.code == int(r["codes"][k]) and np.array_equal(ref.path, r["paths"][k])
+    wall = time.perf_counter() - tw
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} plans of the first batch, oracle Dijkstra single thread, {wall:.1f} s wall",
+            "ms_per_plan": t_sum / n, "host_cpu": model, "host_cores_available": os.cpu_count(),
+            "gpu_paths_match_oracle": bool(ok)}
+
+
+if __name__ == "__main__":
+    main()

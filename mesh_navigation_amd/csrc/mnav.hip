@@ -117,28 +117,12 @@ __device__ __forceinline__ Eval group_eval_dijkstra(const Plan& P, const Ctl& c,
       best_s = os; best_du = odu; best_u = ou;
     }
   }
-  Eval e; e.d = best_s; e.t = best_s; e.pred = (best_s < inf_f()) ? best_u : v; e.dir = 0.0f; e.cut = kNone;
+  Eval e; e.d = best_s; e.t = best_s; e.key = 0; e.pred = (best_s < inf_f()) ? best_u : v; e.dir = 0.0f; e.cut = kNone;
   return e;
 }
 
 // --- CVP replay over 8 lanes (spec: mnav_eval.h::eval_cvp) ------------------------------------
-struct CornerItem { float tf; CvpCand k; uint32_t v1, v2, face; };
-
-__device__ __forceinline__ float corner_fire_time(const Plan& P, const Ctl& c, const Corner& k)
-{
-  if (k.v1 == kNone) return inf_f();
-  const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
-  const float t1 = P.tpop[k.v1], t2 = P.tpop[k.v2];
-  if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return inf_f();
-  const float fix1 = s1 ? -inf_f() : t1, fix2 = s2 ? -inf_f() : t2;
-  bool ex1 = true, ex2 = true;
-  if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
-  if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
-  float tf = inf_f();
-  if (t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && fix2 <= t1) tf = t1;
-  if (t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && fix1 <= t2) tf = fminf(tf, t2);
-  return tf;
-}
+struct CornerItem { PopKey fk; bool valid; CvpCand k; uint32_t v1, v2, face; };
 
 __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint32_t v, int sub)
 {
@@ -148,32 +132,35 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const uint32_t i = beg + sub + r * kGroup;
-    it[r].tf = inf_f(); it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone;
+    it[r].fk = key_inf(); it[r].valid = false; it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone;
     it[r].k.u3tmp = 0.0; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = 0; it[r].k.kind = 0;
     if (i < end) {
       const Corner k = P.crn[i];
-      it[r].tf = corner_fire_time(P, c, k);
-      if (it[r].tf < inf_f()) {
+      const Fire f = corner_fire(P, c, k);
+      if (f.trig != kNone) {
+        it[r].valid = true; it[r].fk = f.key;
         it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
         it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = k.face;
       }
     }
   }
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
-  float last_tf = -inf_f();
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  constexpr PopKey kNoKey = ~0ull;
+  PopKey last = 0;
+  bool first = true;
   const int gbase = (threadIdx.x & (kWave - 1)) & ~(kGroup - 1);
   for (;;) {
-    float m = inf_f();
+    PopKey m = kNoKey;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) if (it[r].tf > last_tf && it[r].tf < m) m = it[r].tf;
+    for (int r = 0; r < 2; ++r) if (it[r].valid && (first || it[r].fk > last) && it[r].fk < m) m = it[r].fk;
 #pragma unroll
-    for (int o = 1; o < kGroup; o <<= 1) m = fminf(m, __shfl_xor(m, o, kGroup));
-    if (!(m < inf_f())) break;
-    if (!(m < e.t)) break;                                         // v pops before this group fires
+    for (int o = 1; o < kGroup; o <<= 1) { const PopKey om = __shfl_xor(m, o, kGroup); m = om < m ? om : m; }
+    if (m == kNoKey) break;
+    if (!(m < e.key)) break;                                       // v pops before this trigger
     bool any = false;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {                                  // ascending corner index = ascending face id
-      unsigned gm = (unsigned)((__ballot(it[r].tf == m) >> gbase) & 0xFFull);
+      unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].fk == m) >> gbase) & 0xFFull);
       while (gm) {
         const int src = __ffs((int)gm) - 1;
         gm &= gm - 1;
@@ -188,10 +175,14 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
         }
       }
     }
-    if (any) e.t = fmaxf(e.d, m);
-    last_tf = m;
+    if (any) {
+      const PopKey own = make_key(e.d, v, 0), after = key_after(m);
+      e.key = own > after ? own : after;
+    }
+    last = m; first = false;
   }
-  if (!(e.d < inf_f())) { e.pred = v; e.t = inf_f(); }
+  if (!(e.d < inf_f())) { e.pred = v; e.key = key_inf(); }
+  e.t = key_time(e.key);
   return e;
 }
 
@@ -245,7 +236,9 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
   float t_new = inf_f();
   if (active && !is_seed(P, v)) {
     const float old_d = P.dist[v];
-    const float old_t = cvp ? P.tpop[v] : old_d;
+    PopKey old_key = 0;
+    if constexpr (cvp) old_key = P.tkey[v];
+    const float old_t = cvp ? key_time(old_key) : old_d;
     bool go;
     if (REPAIR) go = (old_d < inf_f());
     else go = !(old_t < c.thr_fixed) && !(cvp && P.blocked[v]);
@@ -254,10 +247,10 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
         if (sub == 0) ++S.levals;
         const Eval e = group_eval<PLANNER>(P, c, v, sub);
         bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != P.pred[v]);
-        if (cvp) changed = changed || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
+        if (cvp) changed = changed || (e.key != old_key) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
         if ((changed || REPAIR) && sub == 0) {
           P.dist[v] = e.d; P.pred[v] = e.pred;
-          if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+          if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
         }
         t_new = e.t;
         if (!REPAIR) {
@@ -708,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
     P.dist[v] = inf_f();
     P.pred[v] = v;
     P.stamp[v] = 0u;
-    if (PLANNER == kPlannerCvp) { P.tpop[v] = inf_f(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; }
+    if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; }
   }
 }
 
@@ -722,7 +715,7 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   for (int k = 0; k < ns; ++k) {
     const uint32_t s = P.seed[k];
     P.dist[s] = P.seed_d[k];
-    if (PLANNER == kPlannerCvp) { P.tpop[s] = P.seed_d[k]; P.cutf[s] = P.seed_face; }
+    if (PLANNER == kPlannerCvp) { P.tkey[s] = make_key(P.seed_d[k], s, 0); P.cutf[s] = P.seed_face; }
     m0 = fminf(m0, P.seed_d[k]);
   }
   uint32_t n = 0;
@@ -746,7 +739,7 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   Ctl c0; memset(&c0, 0, sizeof(c0));
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = m0 + P.delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
-  c0.band_new = 1;
+  c0.band_new = 1; c0.width = P.delta;
   P.ctl[1] = c0;
   P.ctl[0] = c0;
   Cnt ci; ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u; ci.evals = 0;
@@ -935,7 +928,8 @@ __global__ __launch_bounds__(kBlock) void k_build_crn(uint32_t V, const uint32_t
 // host side
 // ---------------------------------------------------------------------------------------------
 struct Slot {
-  float *dist = nullptr, *tpop = nullptr, *dirn = nullptr, *vecmap = nullptr;
+  float *dist = nullptr, *dirn = nullptr, *vecmap = nullptr;
+  PopKey* tkey = nullptr;
   uint32_t *pred = nullptr, *cutf = nullptr, *stamp = nullptr, *list0 = nullptr, *list1 = nullptr;
   Ctl* ctl = nullptr;
   Cnt* cnt = nullptr;
@@ -979,6 +973,8 @@ struct mnav_ctx {
   std::map<uint64_t, hipGraphExec_t> graphs;
   // tiled SSSP engine
   int dij_engine = 0;          // 0 tiled, 1 band
+  uint32_t max_steps = 1u << 20;   // per plan; set from the mesh size at upload (a wavefront needs O(diameter) steps)
+  double max_wall_s = 120.0;   // host-side guard: a plan that takes longer is abandoned with an error
   uint32_t tile_size = 1024;
   float tile_band_user = 0.f, tile_band_auto = 1.f;
   uint32_t* d_t_rptr = nullptr;
@@ -1020,7 +1016,7 @@ int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
 
 void free_slot(Slot& s)
 {
-  (void)hipFree(s.dist); (void)hipFree(s.tpop); (void)hipFree(s.dirn); (void)hipFree(s.vecmap);
+  (void)hipFree(s.dist); (void)hipFree(s.tkey); (void)hipFree(s.dirn); (void)hipFree(s.vecmap);
   (void)hipFree(s.pred); (void)hipFree(s.cutf); (void)hipFree(s.stamp); (void)hipFree(s.list0); (void)hipFree(s.list1);
   (void)hipFree(s.ctl); (void)hipFree(s.cnt);
   (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tctl); (void)hipFree(s.tcnt);
@@ -1048,7 +1044,7 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
     for (uint32_t i = 0; i < n; ++i) {
       Slot& s = ctx->slots[i];
       if (!s.cvp_ready) {
-        HIPCHK(hipMalloc((void**)&s.tpop, 4 * V)); HIPCHK(hipMalloc((void**)&s.dirn, 4 * V));
+        HIPCHK(hipMalloc((void**)&s.tkey, 8 * V)); HIPCHK(hipMalloc((void**)&s.dirn, 4 * V));
         HIPCHK(hipMalloc((void**)&s.cutf, 4 * V));
         s.cvp_ready = true;
       }
@@ -1170,9 +1166,9 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     memset(&P, 0, sizeof(P));
     P.planner = PLANNER; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tpop = cvp ? s.tpop : s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.dist = s.dist; P.tkey = cvp ? s.tkey : nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = delta; P.offset = offset; P.max_steps = 0x7FFFFFF0u;
+    P.delta = delta; P.offset = offset; P.max_steps = ctx->max_steps;
     for (int k = 0; k < 3; ++k) {
       P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = in[i].seed_d[k];
       P.seed_expands[k] = in[i].seed_expands[k]; P.target_expands[k] = in[i].target_expands[k];
@@ -1196,7 +1192,11 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   const uint32_t G = blocks_per_plan(ctx);
   uint32_t launches = 0;
   int rc = 0;
+  const auto t_start = std::chrono::steady_clock::now();
   for (;;) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
+      ctx->err = "wavefront steps exceeded the wall-clock guard"; return -1;
+    }
     if (run_chunk<PLANNER>(ctx, n, G)) return -1;
     launches += kChunk;
     for (uint32_t i = 0; i < n; ++i)
@@ -1300,7 +1300,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     memset(&P, 0, sizeof(P));
     P.planner = kPlannerDijkstra; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tpop = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u;
     for (int k = 0; k < 3; ++k) {
@@ -1314,7 +1314,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
     T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.cw = ctx->d_t_cw;
     T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset; T.max_rounds = 0x7FFFFFF0u;
+    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset; T.max_rounds = ctx->max_steps;
     T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
     T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
@@ -1345,7 +1345,11 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   if (G < 1) G = 1;
   uint32_t launches = 0;
   int rc = 0;
+  const auto t_start = std::chrono::steady_clock::now();
   for (;;) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
+      ctx->err = "tile rounds exceeded the wall-clock guard"; return -1;
+    }
     if (run_tile_chunk(ctx, n, G)) return -1;
     launches += kTileChunk;
     for (uint32_t i = 0; i < n; ++i)
@@ -1485,6 +1489,13 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   (void)hipFree(ctx->d_invalid); ctx->d_invalid = nullptr; (void)hipFree(ctx->d_edge_dist); ctx->d_edge_dist = nullptr;
   ctx->nbr_valid = ctx->crn_valid = false; ctx->have_costs = false;
   ctx->V = V; ctx->F = F; ctx->E = E;
+  {
+    // a planar wavefront needs a few steps per hop of the mesh diameter ~ sqrt(V); generous cap
+    const double cap = 400.0 * std::sqrt((double)V) + 20000.0;
+    ctx->max_steps = cap > 2.0e9 ? 2000000000u : (uint32_t)cap;
+    if (const char* e = getenv("MNAV_MAX_STEPS")) ctx->max_steps = (uint32_t)atoll(e);
+    if (const char* e = getenv("MNAV_MAX_WALL_S")) ctx->max_wall_s = atof(e);
+  }
   ctx->h_xyz.assign(xyz, xyz + 3 * (size_t)V);
   ctx->h_faces.assign(face_vtx, face_vtx + 3 * (size_t)F);
   if (dev_upload(ctx, &ctx->d_row_ptr, t.row_ptr.data(), t.row_ptr.size())) return -1;
@@ -1723,6 +1734,7 @@ uint32_t mnav_plan_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_fac
   if (seed_face >= ctx->F || !seed_pos) return MNAV_INVALID_START;   // cvp :681-685
   if (target_face >= ctx->F) return MNAV_INVALID_GOAL;                // cvp :686-690
   if (!ctx->have_normals) { ctx->err = "vertex normals were not uploaded"; return MNAV_INTERNAL_ERROR; }
+  if (V > (1u << kKeyIdBits)) { ctx->err = "CVP pop keys hold 26-bit vertex ids: mesh too large"; return MNAV_INTERNAL_ERROR; }
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   if (materialize(ctx, true, cost_limit)) return MNAV_INTERNAL_ERROR;
   // the cut-off flags of the seed / robot-face vertices need cost + invalid on the host: fetch 6 values

@@ -49,6 +49,30 @@ MNAV_HD uint32_t f2u(float f) { union { uint32_t u; float f; } x; x.f = f; retur
 MNAV_HD float inf_f() { return u2f(0x7f800000u); }
 MNAV_HD float next_up(float x) { return (x >= 0.0f) ? u2f(f2u(x) + 1u) : u2f(f2u(x) - 1u); }  // finite x
 
+// Total order of pops.  Among equal heap keys the smaller vertex id pops first (the tie rule fixed
+// for the un-vendored lvr2::Meap, see DESIGN.md "tie rule"); a vertex whose key was
+// set BELOW the current pop front by a face update (non-causal update on an obtuse / cost-inflated
+// triangle) pops right after the vertex whose pop fired that face, and so on down a chain of such
+// updates.  Both are captured by a 64-bit pop key compared as an integer:
+//     [ float bits of the pop time : 32 | tie id : 26 | chain depth : 6 ]
+// (d, v, 0) for an ordinary vertex; (time, tie id, depth + 1) of its trigger for a non-causal one.
+// A dependent therefore always has a strictly larger key than its trigger, which keeps the
+// gather iteration well-founded (no mutually supporting vertices).  Limits: V <= 2^26 for CVP.
+typedef unsigned long long PopKey;
+constexpr uint32_t kKeyIdBits = 26, kKeyDepthBits = 6, kKeyDepthMax = (1u << kKeyDepthBits) - 1u;
+MNAV_HD PopKey make_key(float t, uint32_t id, uint32_t depth)
+{
+  return ((PopKey)f2u(t) << 32) | ((PopKey)(id & ((1u << kKeyIdBits) - 1u)) << kKeyDepthBits) | (PopKey)depth;
+}
+MNAV_HD PopKey key_after(PopKey trigger)
+{
+  const uint32_t d = (uint32_t)(trigger & kKeyDepthMax);
+  return (trigger & ~(PopKey)kKeyDepthMax) | (PopKey)(d < kKeyDepthMax ? d + 1u : kKeyDepthMax);
+}
+MNAV_HD float key_time(PopKey k) { return u2f((uint32_t)(k >> 32)); }
+MNAV_HD PopKey key_inf() { return make_key(inf_f(), 0, 0); }
+
+
 // ---------------------------------------------------------------------------------------
 // CVP triangle update, cvp_mesh_planner.cpp:369-556, on plain numbers.  float64 arithmetic,
 // float32 result, no FMA contraction (build with -ffp-contract=off).
@@ -129,8 +153,12 @@ struct Ctl {
   uint32_t band_new;   // 1 on the first step of a band
   uint32_t bands;      // statistics
   uint32_t overflow;   // work-list overflow (never with capacity V; reported as internal error)
-  uint32_t repair;     // this step is the post-arming repair sweep over all vertices
+  uint32_t repair;     // 1: post-arming repair sweep over all vertices, 2: work-list rebuild after a band shrink
   uint32_t evals;      // statistics: vertex evaluations so far
+  uint32_t band_steps; // steps spent in the current band
+  float width;         // current band width (<= Plan.delta; shrinks when a band does not converge)
+  uint32_t shrinks;    // statistics: band shrinks
+  uint32_t pad;
 };
 
 struct Cnt {
@@ -152,7 +180,7 @@ struct Plan {
   const uint8_t* blocked;  // V: CVP free-vertex gate (cost >= limit || invalid), cvp :760,802,825,848
   // per-plan state
   float* dist;             // V  potential
-  float* tpop;             // V  pop time (CVP only; Dijkstra aliases dist)
+  PopKey* tkey;            // V  pop key (CVP only)
   uint32_t* pred;          // V
   float* dirn;             // V  (CVP)
   uint32_t* cutf;          // V  (CVP)
@@ -188,24 +216,24 @@ MNAV_HD void try_arm(const Plan& P, Ctl& q)
     if (d < q.thr_fixed) { q.goal_dist = (float)((double)d + P.offset); q.armed = 1; }
     return;
   }
-  float t_all = -inf_f();
+  PopKey k_all = 0; bool have_all = false;         // pop key of the last goal vertex to get fixed
   for (int k = 0; k < 3; ++k) {
     const uint32_t g = P.target[k];
     if (g == kNone) return;
     if (is_seed(P, g)) continue;                 // fixed from the start
-    const float tp = P.tpop[g];
-    if (!(tp < q.thr_fixed)) return;             // not all fixed yet
-    t_all = fmaxf(t_all, tp);
+    const PopKey kg = P.tkey[g];
+    if (!(key_time(kg) < q.thr_fixed)) return;   // not all fixed yet
+    if (!have_all || kg > k_all) { k_all = kg; have_all = true; }
   }
-  float best_t = inf_f(); float best_d = 0.0f;
+  PopKey best_k = 0; float best_d = 0.0f; uint32_t best_i = kNone;
   for (int k = 0; k < 3; ++k) {
     const uint32_t g = P.target[k];
     if (!P.target_expands[k]) continue;
-    const float tp = P.tpop[g];
-    if (!(tp < q.thr_fixed)) continue;           // has not popped yet
-    if (tp >= t_all && tp < best_t) { best_t = tp; best_d = P.dist[g]; }
+    const PopKey kg = P.tkey[g];
+    if (!(key_time(kg) < q.thr_fixed)) continue; // has not popped yet
+    if ((!have_all || kg >= k_all) && (best_i == kNone || kg < best_k)) { best_k = kg; best_d = P.dist[g]; best_i = g; }
   }
-  if (best_t < inf_f()) { q.goal_dist = (float)((double)best_d + P.offset); q.armed = 1; }
+  if (best_i != kNone) { q.goal_dist = (float)((double)best_d + P.offset); q.armed = 1; }
 }
 
 // Band controller: pure function of the previous control block and the previous step's counters.
@@ -215,6 +243,8 @@ MNAV_HD void try_arm(const Plan& P, Ctl& q)
 // goal_dist is unaffected by that (sources only feed larger values), so arming is followed by
 // one REPAIR step that re-evaluates every vertex above goal_dist under the final cut-off and
 // rebuilds the work list (process_repair below).
+constexpr uint32_t kBandStepLimit = 64;   // a band that is still moving after this many steps is cut down
+
 MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
 {
   Ctl q = p;
@@ -225,17 +255,37 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
   q.n = c.n_next;
   if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
   const bool out_of_steps = (uint32_t)q.it >= P.max_steps;
-  if (c.changed > 0 && !out_of_steps) { q.band_new = 0; return q; }  // band still moving
+  if (c.changed > 0 && !out_of_steps) {
+    q.band_new = 0;
+    q.band_steps = p.band_steps + 1;
+    if (P.planner == kPlannerCvp && q.band_steps >= kBandStepLimit && p.thr > next_up(p.thr_fixed > 0.0f ? p.thr_fixed : 0.0f)) {
+      // Not converging: on triangles that grossly violate the triangle inequality the in-band
+      // vertices can support each other in a cycle.  Cut the band down from the bottom (at the
+      // width of a single key the replay is exactly the sequential loop) and rebuild the work
+      // list with a full scan; the width recovers over the following bands.
+      const float lo = p.thr_fixed > 0.0f ? p.thr_fixed : 0.0f;
+      q.width = p.width * 0.25f;
+      float thr = lo + q.width;
+      if (!(thr > lo)) thr = next_up(lo);
+      if (thr > p.thr) thr = p.thr;
+      q.thr = thr;
+      q.repair = 2; q.band_new = 1; q.band_steps = 0; q.shrinks = p.shrinks + 1;
+    }
+    return q;                                                          // band still moving
+  }
   q.thr_fixed = p.thr;
+  q.band_steps = 0;
   if (!p.repair) q.bands = p.bands + 1;
   if (!q.armed && !out_of_steps) {
     try_arm(P, q);
     if (q.armed) { q.repair = 1; q.band_new = 0; return q; }
   }
   const float m = u2f(c.minkey);
-  if (c.n_next == 0 || !(m < inf_f()) || out_of_steps) { q.done = 1; q.n = 0; return q; }
+  if (out_of_steps) { q.overflow = 2; q.done = 1; q.n = 0; return q; }   // did not converge: reported as an error
+  if (c.n_next == 0 || !(m < inf_f())) { q.done = 1; q.n = 0; return q; }
   if (q.armed && m > q.goal_dist) { q.done = 1; q.n = 0; return q; }   // nothing left that may expand
-  float thr = m + P.delta;
+  q.width = fminf(P.delta, p.width * 2.0f);
+  float thr = m + q.width;
   if (!(thr > m)) thr = next_up(m);
   q.thr = thr;
   q.band_new = 1;
@@ -245,7 +295,7 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
 // ---------------------------------------------------------------------------------------
 // Gather rules
 // ---------------------------------------------------------------------------------------
-struct Eval { float d; float t; uint32_t pred; float dir; uint32_t cut; };
+struct Eval { float d; float t; PopKey key; uint32_t pred; float dir; uint32_t cut; };
 
 // Dijkstra: dist[v] = min over neighbours u that expand (popped: dist[u] < thr; not cut off:
 // dist[u] <= goal_dist, dijkstra :299; cost cut-off folded into w) of dist[u] + w(u,v), the very
@@ -253,7 +303,7 @@ struct Eval { float d; float t; uint32_t pred; float dir; uint32_t cut; };
 // (strict '<' at :332): argmin (sum, dist[u], u) -- DESIGN.md "tie rule".
 MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
 {
-  Eval e; e.d = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  Eval e; e.d = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.key = 0;
   float best_du = inf_f();
   const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
   for (uint32_t i = beg; i < end; ++i) {
@@ -270,63 +320,69 @@ MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
   return e;
 }
 
+// Fire event of face (v1,v2 -> v): the pop of a support that passes the cut-offs (cvp :754-760)
+// while the other support is already fixed (seed, or popped earlier).  Returns the pop key of the
+// earliest such pop; trig == kNone when the face cannot fire in this band.
+struct Fire { PopKey key; uint32_t trig; };
+
+MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
+{
+  Fire f; f.key = key_inf(); f.trig = kNone;
+  if (k.v1 == kNone) return f;
+  const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
+  const PopKey k1 = P.tkey[k.v1], k2 = P.tkey[k.v2];
+  const float t1 = key_time(k1), t2 = key_time(k2);
+  if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return f;         // both supports fixed by this band
+  bool ex1 = true, ex2 = true;
+  if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
+  if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+  const bool trig1 = t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && (s2 || k2 <= k1);
+  const bool trig2 = t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && (s1 || k1 <= k2);
+  if (trig1) { f.key = k1; f.trig = k.v1; }
+  if (trig2 && (!trig1 || k2 < k1)) { f.key = k2; f.trig = k.v2; }
+  return f;
+}
+
 // CVP: replay of the incident-face updates of vertex v in the order their trigger vertices
-// pop.  Face f=(x,y -> v) fires when a support s in {x,y} pops (pop time tpop[s] < thr), passes
-// the cut-offs (cvp :754-760) and the other support is already fixed (seed, or popped no later
-// than s).  It is applied to v only while v is still free, i.e. while the fire time is below
-// v's own pop time max(key, time of its last applied update).  Faces fired by the same pop are
-// applied in ascending face id (cvp :778 loop order; CONVENTION for getFacesOfVertex).
+// pop.  A face is applied to v only while v is still free, i.e. while the trigger pops before v
+// itself would.  Faces fired by the same pop are applied in ascending face id (cvp :778 loop
+// order; CONVENTION for getFacesOfVertex).
 MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 {
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
-  float last_tf = -inf_f();
+  PopKey last = 0;
+  bool first = true;
   for (;;) {
-    // next fire time strictly after last_tf
-    float tf_min = inf_f();
+    // next trigger pop strictly after the last one
+    PopKey m = key_inf(); bool have = false;
     for (uint32_t i = beg; i < end; ++i) {
-      const Corner k = P.crn[i];
-      if (k.v1 == kNone) continue;
-      const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
-      const float t1 = P.tpop[k.v1], t2 = P.tpop[k.v2];
-      if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) continue;      // both supports fixed by this band
-      const float fix1 = s1 ? -inf_f() : t1, fix2 = s2 ? -inf_f() : t2;
-      float tf = inf_f();
-      bool ex1 = true, ex2 = true;
-      if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
-      if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
-      if (t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && fix2 <= t1) tf = t1;
-      if (t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && fix1 <= t2) tf = fminf(tf, t2);
-      if (tf > last_tf && tf < tf_min) tf_min = tf;
+      const Fire f = corner_fire(P, c, P.crn[i]);
+      if (f.trig == kNone) continue;
+      if (!first && !(f.key > last)) continue;
+      if (!have || f.key < m) { m = f.key; have = true; }
     }
-    if (!(tf_min < inf_f())) break;
-    if (!(tf_min < e.t)) break;                    // v pops before this group fires
-    // apply every face of the group in ascending face id
+    if (!have) break;
+    if (!(m < e.key)) break;                              // v pops before this trigger
     bool any = false;
-    for (uint32_t i = beg; i < end; ++i) {
+    for (uint32_t i = beg; i < end; ++i) {                // faces of this pop, ascending face id
       const Corner k = P.crn[i];
-      if (k.v1 == kNone) continue;
-      const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
-      const float t1 = P.tpop[k.v1], t2 = P.tpop[k.v2];
-      if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) continue;
-      const float fix1 = s1 ? -inf_f() : t1, fix2 = s2 ? -inf_f() : t2;
-      float tf = inf_f();
-      bool ex1 = true, ex2 = true;
-      if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
-      if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
-      if (t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && fix2 <= t1) tf = t1;
-      if (t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && fix1 <= t2) tf = fminf(tf, t2);
-      if (tf != tf_min) continue;
+      const Fire f = corner_fire(P, c, k);
+      if (f.trig == kNone || f.key != m) continue;
       const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
       if (u.ok) {
         e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = k.face;
         any = true;
       }
     }
-    if (any) e.t = fmaxf(e.d, tf_min);
-    last_tf = tf_min;
+    if (any) {
+      const PopKey own = make_key(e.d, v, 0), after = key_after(m);  // ordinary pop vs right after the trigger
+      e.key = own > after ? own : after;
+    }
+    last = m; first = false;
   }
-  if (!(e.d < inf_f())) { e.pred = v; e.t = inf_f(); }
+  if (!(e.d < inf_f())) { e.pred = v; e.key = key_inf(); }
+  e.t = key_time(e.key);
   return e;
 }
 
@@ -334,12 +390,17 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 // One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list),
 // note_changed(), note_min(float), note_eval().
 // ---------------------------------------------------------------------------------------
+// R = state the rule reads, W = state it writes.  The kernels use R == W (in-place, racy but
+// monotone towards the fixed point); the CPU model can also run it Jacobi-style on a snapshot to
+// emulate the worst interleaving of concurrently evaluated neighbours.
 template <uint32_t PLANNER, class Ops>
-MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
+MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32_t v, Ops& ops)
 {
   if (is_seed(P, v)) return;                                     // seeds are fixed from the start
   constexpr bool cvp = (PLANNER == kPlannerCvp);
-  const float old_t = cvp ? P.tpop[v] : P.dist[v];
+  PopKey old_key = 0;
+  if constexpr (cvp) old_key = P.tkey[v];
+  const float old_t = cvp ? key_time(old_key) : P.dist[v];
   if (old_t < c.thr_fixed) return;                               // settled by an earlier band
   if (cvp && P.blocked[v]) return;                               // never updated (cvp :802,825,848)
   ops.note_eval();
@@ -347,11 +408,11 @@ MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
   if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
   const float old_d = P.dist[v];
   bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t));
-  if (cvp) changed = changed || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
+  if (cvp) changed = changed || (e.key != old_key) || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
   else changed = changed || (e.pred != P.pred[v]);
   if (changed) {
-    P.dist[v] = e.d; P.pred[v] = e.pred;
-    if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+    W.dist[v] = e.d; W.pred[v] = e.pred;
+    if constexpr (cvp) { W.tkey[v] = e.key; W.dirn[v] = e.dir; W.cutf[v] = e.cut; }
   }
   const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
   if ((changed && (was_in || now_in)) || (now_in && c.band_new)) {
@@ -374,6 +435,9 @@ MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
   }
 }
 
+template <uint32_t PLANNER, class Ops>
+MNAV_HD void process_entry(const Plan& P, const Ctl& c, uint32_t v, Ops& ops) { process_entry_rw<PLANNER>(P, P, c, v, ops); }
+
 // Repair sweep entry (one per vertex, step with ctl.repair == 1): see controller().
 template <uint32_t PLANNER, class Ops>
 MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
@@ -382,16 +446,26 @@ MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
   constexpr bool cvp = (PLANNER == kPlannerCvp);
   float d = P.dist[v];
   if (!(d < inf_f())) return;
-  float t = cvp ? P.tpop[v] : d;
+  float t = d;
+  if constexpr (cvp) t = key_time(P.tkey[v]);
   if (d > c.goal_dist) {
     ops.note_eval();
     Eval e;
     if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
     P.dist[v] = e.d; P.pred[v] = e.pred;
-    if (cvp) { P.tpop[v] = e.t; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+    if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
     d = e.d; t = e.t;
   }
   if (t >= c.thr && t < inf_f()) { ops.push(v); ops.note_min(t); }
+}
+
+// Work-list rebuild after a band shrink (step with ctl.repair == 2): every keyed vertex that is
+// not settled yet is re-evaluated under the narrower band and re-enters the list.
+template <uint32_t PLANNER, class Ops>
+MNAV_HD void process_rebuild(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
+{
+  if (!(P.dist[v] < inf_f())) return;
+  process_entry<PLANNER>(P, c, v, ops);      // c.band_new == 1: in-band vertices wake their neighbours
 }
 
 }  // namespace mnav

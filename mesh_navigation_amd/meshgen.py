@@ -8,8 +8,8 @@ the rest of the repo relies on:
 * face ids   = cell-major, two triangles per cell split along the same diagonal,
   counter-clockwise seen from +z: ``(v00, v10, v11)`` then ``(v00, v11, v01)``;
 * undirected edge ids = order of first appearance while iterating faces and, inside
-  a face, the sides (v0,v1), (v1,v2), (v2,v0) -- identical to oracle/mnav_oracle.c
-  ``mo_mesh_create`` (cross-checked in tests/test_meshgen.py).
+  a face, the sides (v0,v1), (v1,v2), (v2,v0) -- the same convention the CPU checker uses
+  (cross-checked in tests/test_meshgen.py).
 """
 from __future__ import annotations
 

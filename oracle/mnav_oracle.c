@@ -15,6 +15,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -244,9 +245,11 @@ void mo_steepness(const mo_mesh* m, const float* vertex_normals, double threshol
 
 /* ------------------------------------------------------------------------- */
 /* lvr2::Meap<VertexHandle,float> emulation.  CONVENTION (lvr2 un-vendored):  */
-/* array binary min-heap + key->position index; insert() = insert-or-update;  */
-/* strict '<' in both sift directions; popMin moves the last element to the   */
-/* root and sifts down, preferring the left child on equal children.          */
+/* array binary min-heap + key->position index; insert() = insert-or-update.  */
+/* Which of several entries with EQUAL value popMin() returns is an internal  */
+/* of lvr2 that the reference does not pin; we fix it: among equal values the */
+/* smaller vertex id pops first, i.e. the heap is ordered by (value, id).     */
+/* The device path implements the same total order (DESIGN.md "tie rule").    */
 /* ------------------------------------------------------------------------- */
 struct mo_meap {
   uint32_t n, cap;
@@ -275,11 +278,15 @@ static void meap_swap(mo_meap* h, uint32_t i, uint32_t j)
   h->keys[i] = kj; h->vals[i] = vj; h->pos[kj] = i;
   h->keys[j] = ki; h->vals[j] = vi; h->pos[ki] = j;
 }
+static int meap_lt(const mo_meap* h, uint32_t i, uint32_t j)
+{
+  return h->vals[i] < h->vals[j] || (h->vals[i] == h->vals[j] && h->keys[i] < h->keys[j]);
+}
 static void meap_up(mo_meap* h, uint32_t i)
 {
   while (i > 0) {
     const uint32_t p = (i - 1) / 2;
-    if (!(h->vals[i] < h->vals[p])) break;
+    if (!meap_lt(h, i, p)) break;
     meap_swap(h, i, p);
     i = p;
   }
@@ -288,12 +295,12 @@ static void meap_down(mo_meap* h, uint32_t i)
 {
   for (;;) {
     const uint32_t l = 2 * i + 1, r = 2 * i + 2;
-    const int lsm = l < h->n && h->vals[l] < h->vals[i];
-    const int rsm = r < h->n && h->vals[r] < h->vals[i];
+    const int lsm = l < h->n && meap_lt(h, l, i);
+    const int rsm = r < h->n && meap_lt(h, r, i);
     if (!lsm && !rsm) break;
     uint32_t c;
     if (r >= h->n) c = l;
-    else c = h->vals[l] < h->vals[r] ? l : r;
+    else c = meap_lt(h, l, r) ? l : r;
     meap_swap(h, i, c);
     i = c;
   }
@@ -562,6 +569,7 @@ uint32_t mo_cvp_propagate(const mo_mesh* m, const float* edge_weights, const flo
     if (distances[cur] > goal_dist) continue;                 /* :754 */
     if ((double)vertex_costs[cur] >= cost_limit) continue;    /* :757 */
     if (invalid && invalid[cur]) continue;                    /* :760 */
+    if (getenv("MO_DEBUG") && (cur == g0 || cur == g1 || cur == g2)) fprintf(stderr, "pop goal vertex %u d=%.9g fixed=%d%d%d goal_dist=%g\n", cur, distances[cur], fixed[g0], fixed[g1], fixed[g2], goal_dist);
     if (cur == g0 || cur == g1 || cur == g2) {                /* :763 */
       if (goal_dist == INFINITY && fixed[g0] && fixed[g1] && fixed[g2])   /* :765-766 */
         goal_dist = (float)((double)distances[cur] + goal_dist_offset);   /* :769 */

@@ -363,13 +363,13 @@ def model_lib():
         vp, u32 = C.c_void_p, C.c_uint32
         L.sm_run.restype = u32
         L.sm_run.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, vp, C.c_double, C.c_double,
-                             C.c_float, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+                             C.c_float, C.c_int, u32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
         _model = L
     return _model
 
 
 def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_v, seed_d, seed_face,
-                   target_v, offset=0.3, cost_limit=1.0, delta=0.3, order=0, invalid=None):
+                   target_v, offset=0.3, cost_limit=1.0, delta=0.3, order=0, invalid=None, max_steps=0):
     faces, edges = _u32(faces), _u32(edges)
     w, vc = _f32(edge_weights), _f32(vertex_costs)
     V, F, E = vc.shape[0], faces.shape[0], edges.shape[0]
@@ -381,10 +381,10 @@ def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_
     pred = np.empty(V, np.uint32)
     dirn = np.zeros(V, np.float32)
     cutf = np.full(V, NONE, np.uint32)
-    stats = np.zeros(4, np.uint64)
+    stats = np.zeros(5, np.uint64)
     gd = C.c_float(0)
     code = model_lib().sm_run(planner, V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(sv), _p(sd),
                               int(seed_face), _p(tv), float(offset), float(cost_limit), float(delta), int(order),
-                              _p(dist), _p(pred), _p(dirn), _p(cutf), _p(stats), C.byref(gd))
+                              int(max_steps), _p(dist), _p(pred), _p(dirn), _p(cutf), _p(stats), C.byref(gd))
     return dict(code=code, dist=dist, pred=pred, direction=dirn, cutface=cutf, steps=int(stats[0]),
-                bands=int(stats[1]), evals=int(stats[2]), armed=int(stats[3]), goal_dist=gd.value)
+                bands=int(stats[1]), evals=int(stats[2]), armed=int(stats[3]), shrinks=int(stats[4]), goal_dist=gd.value)

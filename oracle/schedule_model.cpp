@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -33,21 +35,22 @@ struct HostOps {
 
 extern "C" {
 
-// order: 0 = list order, 1 = reversed list order, 2 = pseudo-random permutation per step.
+// order: 0 = list order, 1 = reversed list order, 2 = pseudo-random permutation per step,
+// 3 = Jacobi: every entry of a step reads the state as it was at the start of the step.
 // seeds: Dijkstra -> seed_v[0]; CVP -> 3 seed-face vertices with seed_d[] Euclidean distances.
 // stats_out[0]=steps, [1]=bands, [2]=evals, [3]=armed, goal_dist_out.
 uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx,
                 const uint32_t* edge_vtx, const float* edge_weights, const float* vertex_costs,
                 const uint8_t* invalid, const uint32_t seed_v[3], const float seed_d[3],
                 uint32_t seed_face, const uint32_t target_v[3], double offset, double cost_limit,
-                float delta, int order, float* dist, uint32_t* pred, float* dirn, uint32_t* cutf,
+                float delta, int order, uint32_t max_steps, float* dist, uint32_t* pred, float* dirn, uint32_t* cutf,
                 uint64_t* stats_out, float* goal_dist_out)
 {
   HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
 
-  std::vector<float> tpop(V, inf_f());
+  std::vector<PopKey> tkey(V, key_inf());
   std::vector<uint32_t> stamp(V, 0), l0(V), l1(V);
   Ctl ctl[2]; Cnt cnt[3];
   std::memset(ctl, 0, sizeof(ctl)); std::memset(cnt, 0, sizeof(cnt));
@@ -56,11 +59,11 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   P.planner = planner; P.V = V;
   P.row_ptr = topo.row_ptr.data(); P.nbr = nbr.data();
   P.crn_ptr = topo.crn_ptr.data(); P.crn = crn.data(); P.blocked = blocked.data();
-  P.dist = dist; P.tpop = (planner == kPlannerCvp) ? tpop.data() : dist;
+  P.dist = dist; P.tkey = tkey.data();
   P.pred = pred; P.dirn = dirn; P.cutf = cutf; P.stamp = stamp.data();
   P.list[0] = l0.data(); P.list[1] = l1.data(); P.cap = V;
   P.ctl = ctl; P.cnt = cnt;
-  P.delta = delta; P.offset = offset; P.max_steps = 100000000u;
+  P.delta = delta; P.offset = offset; P.max_steps = max_steps ? max_steps : 100000000u;
   for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.seed_expands[k] = 0; P.target[k] = kNone; P.target_expands[k] = 0; }
 
   for (uint32_t v = 0; v < V; ++v) { dist[v] = inf_f(); pred[v] = v; }
@@ -73,7 +76,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     const uint32_t s = seed_v[k];
     P.seed[k] = s;
     const float d = (planner == kPlannerCvp) ? seed_d[k] : 0.0f;
-    dist[s] = d; P.tpop[s] = d;
+    dist[s] = d; P.tkey[s] = make_key(d, s, 0);
     if (planner == kPlannerCvp) {
       cutf[s] = seed_face;
       P.seed_expands[k] = !((double)vertex_costs[s] >= cost_limit) && !(invalid && invalid[s]);  // cvp :757,760
@@ -109,7 +112,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   Ctl& c0 = ctl[1];
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = m0 + delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
-  c0.band_new = 1;
+  c0.band_new = 1; c0.width = delta;
 
   uint64_t evals = 0, rng = 88172645463325252ull;
   int j = 0;
@@ -122,11 +125,18 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     ctl[j & 1] = cur;
     Cnt& cnext = cnt[(j + 1) % 3];
     cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0;
+    if (getenv("SM_DEBUG") && j >= atoi(getenv("SM_DEBUG")) && j < atoi(getenv("SM_DEBUG")) + 140)
+      fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
     if (cur.done) break;
     Cnt& cc = cnt[j % 3];
     HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1) };
     const uint32_t* list = P.list[j & 1];
-    if (cur.repair) {
+    if (cur.repair == 2) {
+      for (uint32_t v = 0; v < V; ++v) {
+        if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
+        else process_rebuild<kPlannerDijkstra>(P, cur, v, ops);
+      }
+    } else if (cur.repair) {
       for (uint32_t v = 0; v < V; ++v) {
         if (planner == kPlannerCvp) process_repair<kPlannerCvp>(P, cur, v, ops);
         else process_repair<kPlannerDijkstra>(P, cur, v, ops);
@@ -140,6 +150,19 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
           rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
           std::swap(perm[i - 1], perm[rng % i]);
         }
+      if (order == 3) {
+        // snapshot of everything the rules read
+        std::vector<float> sd(dist, dist + V), sdir; std::vector<uint32_t> sp(pred, pred + V), scut;
+        std::vector<PopKey> sk(tkey);
+        if (planner == kPlannerCvp) { sdir.assign(dirn, dirn + V); scut.assign(cutf, cutf + V); }
+        Plan R = P;
+        R.dist = sd.data(); R.pred = sp.data(); R.tkey = sk.data();
+        if (planner == kPlannerCvp) { R.dirn = sdir.data(); R.cutf = scut.data(); }
+        for (uint32_t i = 0; i < cur.n; ++i) {
+          if (planner == kPlannerCvp) process_entry_rw<kPlannerCvp>(R, P, cur, list[i], ops);
+          else process_entry_rw<kPlannerDijkstra>(R, P, cur, list[i], ops);
+        }
+      } else
       for (uint32_t i = 0; i < cur.n; ++i) {
         if (planner == kPlannerCvp) process_entry<kPlannerCvp>(P, cur, list[perm[i]], ops);
         else process_entry<kPlannerDijkstra>(P, cur, list[perm[i]], ops);
@@ -147,9 +170,9 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     }
     evals += cc.evals;
   }
-  if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; }
+  if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks; }
   if (goal_dist_out) *goal_dist_out = cur.goal_dist;
-  return cur.overflow ? kInternalError : kSuccess;
+  return cur.overflow ? kInternalError : kSuccess;   // overflow == 2: step cap hit (no convergence)
 }
 
 }  // extern "C"

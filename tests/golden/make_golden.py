@@ -1,0 +1,76 @@
+"""Regenerates tests/golden/*.npz from the CPU oracle (python tests/golden/make_golden.py).
+
+The reference has no golden vectors for either planner and cannot be built/imported here
+(SURVEY.md §8c), so these are FROZEN ORACLE OUTPUTS: they pin the oracle against silent drift and
+give the GPU box fixtures that do not depend on anything outside the repository.  Parity with the
+reference itself stays "unpinned" (DESIGN.md)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from mesh_navigation_amd import meshgen  # noqa: E402
+from tests.common import Case, layered_costs  # noqa: E402
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def seed_target(case, fs=(0.1, 0.1), ft=(0.9, 0.9), free=None):
+    m = case.mesh
+    if free is None:
+        return m.vertex_at(*fs), m.vertex_at(*ft)
+    def near(f):
+        v = m.vertex_at(*f)
+        return int(free[((m.xyz[free, :2] - m.xyz[v, :2]) ** 2).sum(1).argmin()])
+    return near(fs), near(ft)
+
+
+def plan_record(case, seed, target, prefix, out):
+    m = case.mesh
+    r = case.om.dijkstra(case.weights, case.costs, seed, target)
+    off = np.array([0.03, 0.02, 0.0], np.float32)
+    sp, tp = m.xyz[seed] + off, m.xyz[target] + off
+    sf, _ = case.om.containing_face(sp)
+    tf, _ = case.om.containing_face(tp)
+    c = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    code, ppos, pface = case.om.cvp_backtrack(c.vecmap, c.has_vec, sp, sf, tp, tf)
+    out.update({
+        prefix + "seed_target": np.array([seed, target], np.uint32),
+        prefix + "dij_code": np.array([r.code], np.uint32), prefix + "dij_goal_dist": np.array([r.stats["goal_dist"]], np.float32),
+        prefix + "dij_path": r.path, prefix + "dij_dist_sha": np.array(sha(r.dist)), prefix + "dij_pred_sha": np.array(sha(r.pred)),
+        prefix + "dij_dist_sample": r.dist[:: max(1, m.V // 512)].copy(),
+        prefix + "cvp_faces": np.array([sf, tf], np.uint32), prefix + "cvp_seed_pos": sp, prefix + "cvp_target_pos": tp,
+        prefix + "cvp_code": np.array([c.code], np.uint32), prefix + "cvp_goal_dist": np.array([c.stats["goal_dist"]], np.float32),
+        prefix + "cvp_dist_sha": np.array(sha(c.dist)), prefix + "cvp_pred_sha": np.array(sha(c.pred)),
+        prefix + "cvp_dist_sample": c.dist[:: max(1, m.V // 512)].copy(),
+        prefix + "cvp_path_code": np.array([code], np.uint32), prefix + "cvp_path_pos": ppos, prefix + "cvp_path_face": pface,
+    })
+    return r, c
+
+
+def main():
+    out = {}
+    # G1: BASELINE config C1 (224x224 terrain, seed 1, zero costs)
+    c1 = Case(meshgen.terrain(224, 0.1, 1))
+    plan_record(c1, *seed_target(c1), "c1_", out)
+    # G2: small terrain with the config-3 cost stack, full arrays
+    base = Case(meshgen.terrain(40, 0.1, 3, amplitude=0.8))
+    costs, parts = layered_costs(base, "avg")
+    g2 = Case(base.mesh, costs, 1.0)
+    free = np.where(costs < 0.5)[0]
+    s, t = seed_target(g2, (0.15, 0.15), (0.85, 0.85), free)
+    r, c = plan_record(g2, s, t, "g2_", out)
+    out.update({"g2_costs": costs, "g2_weights": g2.weights, "g2_dij_dist": r.dist, "g2_dij_pred": r.pred,
+                "g2_cvp_dist": c.dist, "g2_cvp_pred": c.pred, "g2_cvp_direction": c.direction, "g2_cvp_cutface": c.cutface,
+                "g2_steepness": parts["steepness"], "g2_inflation": parts["inflation"]})
+    np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
+    print("wrote", os.path.join(HERE, "planner_golden.npz"), os.path.getsize(os.path.join(HERE, "planner_golden.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""GPU parity at BASELINE's full single-GPU size (config C2 / C3 shape: 1M-vertex terrain)."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from tests.common import Case, layered_costs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2(gpu_ctx_factory):
+    case = Case(meshgen.terrain(1000, 0.1, 2))
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    return case, ctx
+
+
+@pytest.mark.parametrize("engine", ["tiled", "band"])
+def test_dijkstra_c2_bit_exact(c2, engine):
+    case, ctx = c2
+    ctx.set_dijkstra_engine(engine)
+    m = case.mesh
+    s, t = m.vertex_at(0.1, 0.1), m.vertex_at(0.9, 0.9)
+    ref = case.om.dijkstra(case.weights, case.costs, s, t)
+    out = ctx.plan_dijkstra(s, t)
+    assert out.code == ref.code == 0
+    assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(out.path, ref.path)
+    # predecessors: the device uses the documented (dist[u], u) tie rule, the oracle the emulated
+    # Meap order; on jittered terrain they coincide (DESIGN.md "tie rule")
+    assert np.array_equal(out.pred, ref.pred)
+    ctx.set_dijkstra_engine("tiled")
+
+
+def test_dijkstra_c2_full_field_properties(c2):
+    case, ctx = c2
+    m = case.mesh
+    s, t = m.vertex_at(0.5, 0.5), m.vertex_at(0.02, 0.97)
+    out = ctx.plan_dijkstra(s, t, goal_dist_offset=float("inf"))
+    d, e, w = out.dist, m.edges, case.weights
+    assert d[s] == 0 and np.isfinite(d).all()
+    assert (d[e[:, 0]] <= d[e[:, 1]] + w).all() and (d[e[:, 1]] <= d[e[:, 0]] + w).all()   # relaxation fixed point
+    nz = np.arange(m.V) != s
+    assert (d[out.pred[nz]] < d[nz]).all()                                                # descent along pred
+    assert out.stats["algorithmic_bytes"] == 24 * m.V + 24 * m.E
+
+
+def test_cvp_c2(c2):
+    case, ctx = c2
+    m = case.mesh
+    s, t = m.vertex_at(0.1, 0.1), m.vertex_at(0.9, 0.9)
+    sp = m.xyz[s] + np.array([0.03, 0.02, 0.0], np.float32)
+    tp = m.xyz[t] + np.array([0.03, 0.02, 0.0], np.float32)
+    sf, _ = case.om.containing_face(sp)
+    tf, _ = case.om.containing_face(tp)
+    ref = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    out = ctx.plan_cvp(sp, sf, tf)
+    assert out.code == ref.code == 0
+    fin = np.isfinite(ref.dist)
+    assert np.array_equal(np.isfinite(out.dist), fin)
+    rel = np.abs(out.dist[fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
+    assert rel.max() <= 1e-5
+    assert (out.pred != ref.pred).mean() < 1e-4
+
+
+def test_cvp_c3_layered_costs_1m(gpu_ctx_factory):
+    """BASELINE config 3: 1M vertices, Inflation + Steepness costs (Avg), edge_cost_factor 1."""
+    base = Case(meshgen.terrain(1000, 0.1, 3, amplitude=0.8))
+    costs, parts = layered_costs(base, "avg")
+    case = Case(base.mesh, costs, 1.0)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    m = case.mesh
+    free = np.where(costs < 0.5)[0]
+    def near(fi, fj):
+        v = m.vertex_at(fi, fj)
+        return int(free[((m.xyz[free, :2] - m.xyz[v, :2]) ** 2).sum(1).argmin()])
+    s, t = near(0.1, 0.1), near(0.9, 0.9)
+    sp = m.xyz[s] + np.array([0.02, 0.01, 0], np.float32)
+    tp = m.xyz[t] + np.array([0.02, 0.01, 0], np.float32)
+    sf, _ = case.om.containing_face(sp)
+    tf, _ = case.om.containing_face(tp)
+    ref = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    out = ctx.plan_cvp(sp, sf, tf)
+    assert out.code == ref.code == 0
+    fin = np.isfinite(ref.dist)
+    assert np.array_equal(np.isfinite(out.dist), fin)
+    rel = np.abs(out.dist[fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
+    assert rel.max() <= 1e-5
+    refd = case.om.dijkstra(case.weights, case.costs, s, t)
+    outd = ctx.plan_dijkstra(s, t)
+    assert np.array_equal(outd.dist.view(np.uint32), refd.dist.view(np.uint32)) and np.array_equal(outd.path, refd.path)

@@ -1,0 +1,173 @@
+"""Known-answer tests that pin the CPU oracle.
+
+REFERENCE-DERIVED assertions replay the only numeric known answers the reference holds
+(mesh_layers/test/inflation_layer_test.cpp:38-100) and closed forms of the reference arithmetic;
+CONVENTION-DERIVED ones pin the choices we had to make because lvr2 is not vendored (heap order,
+circulator order).  The planners themselves have no reference tests: parity is unpinned.
+"""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from oracle import oracle as O
+
+
+def triangle_mesh():
+    # genTriangle(), inflation_layer_test.cpp:7-23: legs of 0.5
+    xyz = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0]], np.float32)
+    faces = np.array([[0, 1, 2]], np.uint32)
+    return O.OracleMesh(xyz, faces)
+
+
+def test_reference_inflation_wave_front_update():
+    """REFERENCE-DERIVED: inflation_layer_test.cpp:38-80 (test_wave_front_update)."""
+    om = triangle_mesh()
+    w = om.edge_distances()                      # calcEdgeWeights(): Euclidean lengths, :26-36
+    edges = om.edges()
+    e01 = [i for i, e in enumerate(edges) if set(e) == {0, 1}][0]
+    dist = np.full(3, np.inf, np.float32)
+    dist[0] = 0.0
+    dist[1] = w[e01]                              # :60-62
+    vec = np.zeros((3, 3), np.float32)
+    assert om.inflation_wavefront_update(dist, vec, 5.0, w, 0, 1, 2) is True       # :66-75 EXPECT_TRUE
+    assert dist[2] == np.float32(0.5)                                               # :79 EXPECT_FLOAT_EQ
+    cfg = O.InflationCfg(0.5, 1.5, 1.0, 0.9, 1.0)                                   # :41-45
+    assert O.inflation_fading(cfg, float(dist[2])) == pytest.approx(0.9, rel=1e-6)  # :82
+
+
+def test_reference_inflation_fading():
+    """REFERENCE-DERIVED: inflation_layer_test.cpp:83-100 (test_fading)."""
+    cfg = O.InflationCfg(0.5, 1.5, 1.0, 0.9, 1.0)
+    assert O.inflation_fading(cfg, 0.2) == pytest.approx(0.9, rel=1e-6)
+    assert 0.0 < O.inflation_fading(cfg, 0.6) < 0.9
+    assert O.inflation_fading(cfg, 2.0) == 0.0
+    assert O.inflation_fading(cfg, 0.0) == pytest.approx(1.0)     # lethality, inflation_layer.cpp:338
+
+
+def test_cvp_update_same_triangle():
+    """REFERENCE-DERIVED arithmetic: CVP's waveFrontUpdate (cvp_mesh_planner.cpp:369-556) on the
+    Inflation test triangle: sx=0, sy=0, p=0, hc=0.5 -> u3 == 0.5 exactly."""
+    c, b, a = 0.5, 0.5, float(np.float32(np.sqrt(np.float32(0.5))))
+    ok, u3, sel, direction = O.cvp_update_scalar(0.0, 0.5, np.inf, a, b, c)
+    assert ok and u3 == 0.5
+    assert sel in (1, 2)
+    # no update when the candidate is not smaller than the current value (:411 strict '<')
+    ok2, _, _, _ = O.cvp_update_scalar(0.0, 0.5, 0.5, a, b, c)
+    assert not ok2
+
+
+def test_cvp_update_flat_wave_is_euclidean():
+    """Closed form: a point source at v1 (u1=0) makes u3 = |v1 v3| = b for any triangle where the
+    ray stays inside the unfolding (:395-405)."""
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        p = rng.uniform(-1, 1, size=(3, 2))
+        c = np.linalg.norm(p[0] - p[1]); b = np.linalg.norm(p[0] - p[2]); a = np.linalg.norm(p[1] - p[2])
+        ok, u3, sel, d = O.cvp_update_scalar(0.0, np.float32(c), np.inf, np.float32(a), np.float32(b), np.float32(c))
+        assert ok
+        assert u3 <= np.float32(b) * (1 + 1e-6) + 1e-7          # never longer than the edge fallback u1 + b
+
+
+def test_edge_weight_formula_mixed_precision():
+    """REFERENCE-DERIVED: mesh_map.cpp:548-552 promotion order (float mul/add, double divide and
+    weighted sum, float store), inf costs -> inf weight (:538-542)."""
+    m = meshgen.terrain(12, 0.1, 5)
+    om = O.OracleMesh(m.xyz, m.faces)
+    ed = om.edge_distances()
+    rng = np.random.default_rng(1)
+    costs = rng.uniform(0, 1.5, m.V).astype(np.float32)
+    costs[3] = np.inf
+    for factor in (0.0, 1.0, 0.37):
+        w = om.edge_weights(ed, costs, factor)
+        e = m.edges
+        c1, c2 = costs[e[:, 0]], costs[e[:, 1]]
+        s = (c1 + c2).astype(np.float32)
+        edge_cost = ((ed * s).astype(np.float32).astype(np.float64) / 2.0).astype(np.float32)
+        exp = (ed.astype(np.float64) + factor * edge_cost.astype(np.float64)).astype(np.float32)
+        exp[np.isinf(c1) | np.isinf(c2)] = np.inf
+        assert np.array_equal(w.view(np.uint32), exp.view(np.uint32))
+    assert np.array_equal(om.edge_weights(ed, np.zeros(m.V, np.float32), 0.0), ed)   # default factor 0 (:105)
+
+
+def test_meap_is_a_min_queue_with_upsert():
+    """CONVENTION-DERIVED: lvr2::Meap stand-in -- insert() updates an existing key."""
+    L = O.lib()
+    import ctypes as C
+    h = L.mo_meap_create(16)
+    for k, v in ((3, 5.0), (1, 2.0), (7, 9.0), (3, 1.0), (2, 2.0)):
+        L.mo_meap_insert(h, k, v)
+    out = []
+    while not L.mo_meap_empty(h):
+        val = C.c_float()
+        out.append((L.mo_meap_pop_min(h, C.byref(val)), val.value))
+    L.mo_meap_destroy(h)
+    assert [v for _, v in out] == [1.0, 2.0, 2.0, 9.0]
+    assert out[0][0] == 3 and {out[1][0], out[2][0]} == {1, 2}
+
+
+def test_dijkstra_unit_grid_closed_form():
+    """Closed form on an un-jittered flat grid with unit spacing: with the (v00,v11) diagonals the
+    graph distance from the corner (0,0) to (i,j) is max(i,j) + (sqrt2 - 1) * min(i,j)."""
+    N = 9
+    m = meshgen.flat_grid(N, 1.0)
+    om = O.OracleMesh(m.xyz, m.faces)
+    w = om.edge_distances()
+    r = om.dijkstra(w, np.zeros(m.V, np.float32), 0, N * N - 1, goal_dist_offset=np.inf)
+    assert r.code == 0
+    i, j = np.meshgrid(np.arange(N), np.arange(N))
+    exp = np.maximum(i, j) + (np.sqrt(2.0) - 1.0) * np.minimum(i, j)
+    assert np.allclose(r.dist.reshape(N, N), exp, rtol=1e-6)
+    assert len(r.path) == N - 1 and r.path[0] == 0            # seed first, pred[target] last
+
+
+def test_dijkstra_return_codes_and_cutoffs():
+    m = meshgen.terrain(16, 0.1, 3)
+    om = O.OracleMesh(m.xyz, m.faces)
+    w = om.edge_distances()
+    costs = np.zeros(m.V, np.float32)
+    r = om.dijkstra(w, costs, 5, 5)
+    assert r.code == 0 and len(r.path) == 0                   # dijkstra :252-255
+    # a wall of cost > cost_limit vertices separates seed and target -> NO_PATH_FOUND (:358)
+    costs2 = costs.copy()
+    costs2[8 * 16: 9 * 16] = 2.0
+    r2 = om.dijkstra(w, costs2, 0, 16 * 16 - 1)
+    assert r2.code == O.NO_PATH_FOUND
+    assert np.isfinite(r2.dist[8 * 16: 9 * 16]).all()         # reached but never expanded (:302)
+    assert np.isinf(r2.dist[9 * 16:]).all()
+    # early exit: nothing beyond goal_dist is expanded
+    r3 = om.dijkstra(w, costs, 0, 17, goal_dist_offset=0.05)
+    far = r3.dist[np.isfinite(r3.dist)]
+    assert far.max() <= r3.stats["goal_dist"] + w.max() + 1e-6
+
+
+def test_cvp_flat_plane_matches_euclidean_distance():
+    """Analytic check: on a flat zero-cost mesh the CVP potential is the Euclidean
+    distance to the seed wherever the straight ray is reachable through the triangle fan."""
+    N = 41
+    m = meshgen.flat_grid(N, 0.1)
+    om = O.OracleMesh(m.xyz, m.faces)
+    w = om.edge_distances()
+    vn = om.vertex_normals()
+    c = (N // 2) * N + N // 2
+    sp = m.xyz[c] + np.array([0.03, 0.02, 0.0], np.float32)
+    sf, _ = om.containing_face(sp)
+    tf, _ = om.containing_face(m.xyz[N + 1] + np.array([0.03, 0.02, 0], np.float32))
+    r = om.cvp(w, np.zeros(m.V, np.float32), vn, sp, sf, tf, goal_dist_offset=np.inf)
+    assert r.code == 0
+    eu = np.linalg.norm(m.xyz - sp, axis=1)
+    assert np.isfinite(r.dist).all()
+    err = np.abs(r.dist - eu)
+    assert err.max() < 1e-2 and np.median(err) < 1e-3       # first-order accurate fan unfolding
+    assert (r.dist >= eu - 1e-5).all()                        # a geodesic is never shorter than the chord
+
+
+def test_seed_lookup_and_pose():
+    m = meshgen.flat_grid(5, 1.0)
+    om = O.OracleMesh(m.xyz, m.faces)
+    assert om.nearest_vertex([2.1, 1.9, 0.3]) == 2 * 5 + 2
+    f, bary = om.containing_face(np.array([2.3, 2.1, 0.0], np.float32))
+    assert f != O.NONE and abs(bary.sum() - 1) < 1e-5
+    pose, length = O.pose_from_position([0, 0, 0], [1, 0, 0], [0, 0, 1])
+    assert length == 1.0 and np.allclose(pose, [0, 0, 0, 0, 0, 0, 1])      # identity orientation
+    pose, _ = O.pose_from_position([0, 0, 0], [0, 2, 0], [0, 0, 1])
+    assert np.allclose(pose[3:], [0, 0, np.sqrt(0.5), np.sqrt(0.5)])       # +90 deg about z

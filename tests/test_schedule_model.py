@@ -1,0 +1,187 @@
+"""CPU check of the DEVICE SCHEDULE: the band/gather rules and band controller the HIP kernels run
+(mesh_navigation_amd/csrc/mnav_eval.h), executed serially by oracle/schedule_model.cpp, must
+reproduce the sequential priority-queue planners of the oracle on the same inputs."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from oracle import oracle as O
+from tests.common import Case, layered_costs
+
+
+def run_dijkstra(case, seed, target, **kw):
+    off = kw.pop("offset", 0.3)
+    lim = kw.pop("cost_limit", 1.0)
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target, goal_dist_offset=off, cost_limit=lim,
+                           invalid=case.invalid)
+    mod = O.schedule_model(0, case.mesh.faces, case.mesh.edges, case.weights, case.costs, [seed], [0.0], 0, [target],
+                           offset=off, cost_limit=lim, invalid=case.invalid, **kw)
+    return ref, mod
+
+
+def run_cvp(case, sp, tp, **kw):
+    off = kw.pop("offset", 0.3)
+    lim = kw.pop("cost_limit", 1.0)
+    sf, _ = case.om.containing_face(sp)
+    tf, _ = case.om.containing_face(tp)
+    ref = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf, goal_dist_offset=off, cost_limit=lim,
+                      invalid=case.invalid)
+    sv = case.mesh.faces[sf]
+    mod = O.schedule_model(1, case.mesh.faces, case.mesh.edges, case.weights, case.costs, sv, ref.dist[sv], sf,
+                           case.mesh.faces[tf], offset=off, cost_limit=lim, invalid=case.invalid, **kw)
+    return ref, mod
+
+
+@pytest.mark.parametrize("delta", [0.07, 0.3, 2.0])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_dijkstra_schedule_bit_exact(delta, order):
+    case = Case(meshgen.terrain(64, 0.1, 11))
+    m = case.mesh
+    ref, mod = run_dijkstra(case, m.vertex_at(0.2, 0.1), m.vertex_at(0.8, 0.9), delta=delta, order=order)
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+    assert mod["goal_dist"] == ref.stats["goal_dist"]
+
+
+@pytest.mark.parametrize("offset", [0.0, 0.01, 0.3, 5.0, np.inf])
+def test_dijkstra_goal_dist_offsets(offset):
+    """goal_dist arming + the post-arming repair sweep reproduce the cut-off of dijkstra :293-300."""
+    case = Case(meshgen.terrain(48, 0.1, 12))
+    m = case.mesh
+    ref, mod = run_dijkstra(case, m.vertex_at(0.5, 0.5), m.vertex_at(0.7, 0.6), offset=offset, delta=0.4)
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+
+
+def test_dijkstra_cost_limit_invalid_and_unreachable():
+    mesh = meshgen.terrain(40, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)          # ~1/6 of the vertices over the limit
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    case = Case(mesh, costs, 1.0, invalid)
+    seed, target = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    case.invalid[[seed, target]] = 0
+    case.costs[[seed, target]] = 0
+    ref, mod = run_dijkstra(case, seed, target, delta=0.3)
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+    # wall -> unreachable target
+    costs2 = np.zeros(mesh.V, np.float32)
+    costs2[20 * 40: 21 * 40] = 5.0
+    case2 = Case(mesh, costs2, 0.0)
+    ref2, mod2 = run_dijkstra(case2, seed, target, delta=0.3)
+    assert ref2.code == O.NO_PATH_FOUND and mod2["pred"][target] == target
+    assert np.array_equal(mod2["dist"].view(np.uint32), ref2.dist.view(np.uint32))
+
+
+def test_dijkstra_unit_grid_ties():
+    """Tie stress (SURVEY.md §8d C2 variant): un-jittered grid, all weights exactly representable.
+    Distances are schedule independent; predecessors follow the documented (dist[u], u) rule: the
+    neighbour that pops first under the (value, vertex id) heap order wins (strict '<' at :332)."""
+    m = meshgen.flat_grid(24, 1.0)
+    case = Case(m)
+    ones = np.ones(m.E, np.float32)
+    ref = case.om.dijkstra(ones, case.costs, 0, m.V - 1, goal_dist_offset=np.inf)
+    mod = O.schedule_model(0, m.faces, m.edges, ones, case.costs, [0], [0.0], 0, [m.V - 1], offset=np.inf, delta=1.5)
+    assert np.array_equal(mod["dist"], ref.dist)
+    rule = case.om.dijkstra_pred_rule(ones, case.costs, 0, np.inf, 1.0, ref.dist)
+    assert np.array_equal(mod["pred"], rule)
+    # with the heap tie rule fixed to (value, vertex id) the queue-driven loop picks the same tree
+    assert np.array_equal(ref.pred, rule)
+    # both predecessor fields are shortest-path trees of the same potential
+    for pred in (mod["pred"], ref.pred):
+        v = m.V - 1
+        hops = 0
+        while v != 0:
+            assert ref.dist[pred[v]] + 1.0 == ref.dist[v]
+            v = pred[v]; hops += 1
+        assert hops == int(ref.dist[m.V - 1])
+
+
+@pytest.mark.parametrize("delta", [0.05, 0.3, 1.5])
+@pytest.mark.parametrize("order", [0, 2])
+def test_cvp_schedule_matches_oracle(delta, order):
+    case = Case(meshgen.terrain(56, 0.1, 14))
+    m = case.mesh
+    sp = m.xyz[m.vertex_at(0.2, 0.2)] + np.array([0.03, 0.02, 0], np.float32)
+    tp = m.xyz[m.vertex_at(0.85, 0.8)] + np.array([0.01, 0.04, 0], np.float32)
+    ref, mod = run_cvp(case, sp, tp, delta=delta, order=order)
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+    upd = ref.pred != np.arange(m.V)
+    assert np.array_equal(mod["cutface"][upd], ref.cutface[upd])
+    assert np.array_equal(mod["direction"][upd], ref.direction[upd])
+    assert mod["goal_dist"] == ref.stats["goal_dist"]
+
+
+def test_cvp_layered_costs_config3():
+    """BASELINE config 3 shape at test size: Steepness + Inflation costs (Avg combination),
+    edge_cost_factor 1 -> cost-inflated, partly obtuse 'weighted' triangles and blocked vertices."""
+    base = Case(meshgen.terrain(72, 0.1, 3, amplitude=0.8))
+    costs, parts = layered_costs(base, "avg")
+    assert 0.0 < parts["lethal"].mean() < 0.2
+    case = Case(base.mesh, costs, 1.0)
+    m = case.mesh
+    free = np.where(costs < 0.5)[0]
+    def near(fi, fj):
+        v = m.vertex_at(fi, fj)
+        return int(free[((m.xyz[free, :2] - m.xyz[v, :2]) ** 2).sum(1).argmin()])
+    s, t = near(0.15, 0.15), near(0.85, 0.85)
+    sp = m.xyz[s] + np.array([0.02, 0.01, 0], np.float32)
+    tp = m.xyz[t] + np.array([0.02, 0.01, 0], np.float32)
+    for off in (0.3, np.inf):
+        ref, mod = run_cvp(case, sp, tp, offset=off, delta=0.3)
+        fin = np.isfinite(ref.dist)
+        assert np.array_equal(np.isfinite(mod["dist"]), fin)
+        rel = np.abs(mod["dist"][fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
+        assert rel.max() <= 1e-5                                   # north_star tolerance
+        assert (mod["pred"] != ref.pred).mean() < 1e-3
+    # and Dijkstra on the same cost-inflated weights
+    refd, modd = run_dijkstra(case, s, t, delta=0.3)
+    assert np.array_equal(modd["dist"].view(np.uint32), refd.dist.view(np.uint32))
+
+
+def test_cvp_seed_face_equals_target_face_and_blocked_seed():
+    case = Case(meshgen.terrain(24, 0.1, 15))
+    m = case.mesh
+    sp = m.xyz[m.vertex_at(0.5, 0.5)] + np.array([0.03, 0.02, 0], np.float32)
+    ref, mod = run_cvp(case, sp, sp.copy(), delta=0.3)               # robot in the goal's face
+    assert ref.code == 0
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    # one seed vertex at/above the cost limit: it is fixed but never expands (cvp :757)
+    sf, _ = case.om.containing_face(sp)
+    costs = np.zeros(m.V, np.float32)
+    costs[m.faces[sf][0]] = 1.0
+    case2 = Case(m, costs, 0.0)
+    tp = m.xyz[m.vertex_at(0.9, 0.1)] + np.array([0.03, 0.02, 0], np.float32)
+    ref2, mod2 = run_cvp(case2, sp, tp, delta=0.3)
+    assert np.array_equal(mod2["dist"].view(np.uint32), ref2.dist.view(np.uint32))
+    assert np.array_equal(mod2["pred"], ref2.pred)
+
+
+def test_cvp_adversarial_weights_converge():
+    """Random per-vertex costs up to 1.2 with edge_cost_factor 1: single edges are inflated by up to
+    2.2x, most triangles violate the triangle inequality and updates undercut the pop front in
+    nested chains.  The schedule must terminate in every interleaving (well-founded pop keys); the
+    exact sibling order inside such chains is approximated (known limitation)."""
+    mesh = meshgen.terrain(96, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    invalid[[s, t]] = 0
+    costs[[s, t]] = 0
+    case = Case(mesh, costs, 1.0, invalid)
+    sp = mesh.xyz[s] + np.array([0.03, 0.02, 0], np.float32)
+    tp = mesh.xyz[t] + np.array([0.03, 0.02, 0], np.float32)
+    for order in (0, 3):
+        ref, mod = run_cvp(case, sp, tp, delta=0.36, order=order, max_steps=100000)
+        assert mod["code"] == 0
+        fin = np.isfinite(ref.dist)
+        assert np.array_equal(np.isfinite(mod["dist"]), fin)
+        rel = np.abs(mod["dist"][fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
+        assert (rel > 1e-5).mean() < 0.05
+    # moderate random costs (edges inflated by up to 1.6x): bit-exact again
+    case2 = Case(mesh, (costs * 0.5).astype(np.float32), 1.0, invalid)
+    ref2, mod2 = run_cvp(case2, sp, tp, delta=0.36, order=3, max_steps=100000)
+    assert np.array_equal(mod2["dist"].view(np.uint32), ref2.dist.view(np.uint32))
