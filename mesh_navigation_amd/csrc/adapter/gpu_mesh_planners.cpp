@@ -1,0 +1,247 @@
+// gpu_mesh_planners.cpp -- see gpu_mesh_planners.h.  Reference line numbers in the comments.
+#include "gpu_mesh_planners.h"
+
+#include <cmath>
+#include <cstring>
+
+using geometry_msgs::msg::PoseStamped;
+typedef mbf_msgs::action::GetPath::Result Result;
+
+namespace mnav_adapter {
+
+static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+MeshMapDevice::MeshMapDevice(int device) { ctx_ = mnav_create(device); }
+MeshMapDevice::~MeshMapDevice() { if (ctx_) mnav_destroy(ctx_); }
+
+bool MeshMapDevice::sync(const mesh_map::MeshMap& map, std::string& err)
+{
+  if (!ctx_) { err = "no MI355X device context (mnav_create failed)"; return false; }
+  if (uploaded_ != &map) {
+    if (mnav_upload_mesh(ctx_, map.V, map.F, map.E, map.positions.data(), map.faces.data(), map.edges.data(),
+                         map.vertex_normals.empty() ? nullptr : map.vertex_normals.data()) != 0) { err = mnav_last_error(ctx_); return false; }
+    uploaded_ = &map; cost_hash_ = 0;
+  }
+  // there is no version counter on vertex_costs / edge_weights: hash, re-upload on change
+  uint64_t h = fnv(map.vertex_costs.data(), map.vertex_costs.size() * 4);
+  h = fnv(map.edge_weights.data(), map.edge_weights.size() * 4, h);
+  h = fnv(map.invalid.data(), map.invalid.size(), h);
+  if (h != cost_hash_ || cost_hash_ == 0) {
+    if (mnav_upload_costs(ctx_, map.vertex_costs.data(), map.edge_weights.data(), map.invalid.data()) != 0) { err = mnav_last_error(ctx_); return false; }
+    cost_hash_ = h ? h : 1;
+  }
+  return true;
+}
+}  // namespace mnav_adapter
+
+// =============================================================================================
+namespace dijkstra_mesh_planner {
+
+// dijkstra_mesh_planner.cpp:55-134
+uint32_t DijkstraMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped& goal, double /*tolerance*/,
+                                       std::vector<PoseStamped>& plan, double& cost, std::string& /*message*/)
+{
+  const PoseStamped start_in_map = mesh_map_->transformToMapFrame(start);     // :63
+  const PoseStamped goal_in_map = mesh_map_->transformToMapFrame(goal);       // :64
+  mesh_map::Vector start_vec = mesh_map::toVector(start_in_map.pose.position);   // :72
+  const mesh_map::Vector goal_vec = mesh_map::toVector(goal_in_map.pose.position);   // :73
+  std::list<uint32_t> path;
+  const uint32_t outcome = dijkstra(goal_vec, start_vec, path);               // :81 the wave starts at the goal pose
+  path.reverse();                                                             // :83
+  std_msgs::msg::Header header;
+  header.stamp = node_ ? node_->now() : builtin_interfaces::msg::Time();
+  header.frame_id = mesh_map_->mapFrame();                                    // :87
+  cost = 0;                                                                   // :89
+  if (!path.empty()) {                                                        // :90
+    mesh_map::Vector& vec = start_vec;                                        // :92
+    mesh_map::Normal normal = mesh_map_->vertexNormal(path.front());          // :94
+    float dir_length;
+    PoseStamped pose;
+    pose.header = header;
+    while (!path.empty()) {                                                   // :100
+      const uint32_t vH = path.front();
+      const mesh_map::Vector next = mesh_map_->vertex(vH);                    // :104
+      pose.pose = mesh_map::calculatePoseFromPosition(vec, next, normal, dir_length);   // :106
+      cost += dir_length;                                                     // :107
+      vec = next;                                                             // :108
+      normal = mesh_map_->vertexNormal(vH);                                   // :109
+      plan.push_back(pose);
+      path.pop_front();
+    }
+    pose.pose = mesh_map::calculatePoseFromPosition(vec, goal_vec, normal, dir_length);   // :113
+    cost += dir_length;                                                       // :114
+    plan.push_back(pose);
+  }
+  // :118-131 publishing (path, "Potential" vertex costs, vector field) is ROS I/O and out of scope here
+  return outcome;
+}
+
+bool DijkstraMeshPlanner::cancel()                                            // :136-140
+{
+  cancel_planning_ = true;
+  if (dev_ && dev_->ok()) mnav_cancel(dev_->ctx());
+  return true;
+}
+
+bool DijkstraMeshPlanner::initialize(const std::string& plugin_name, const std::shared_ptr<mesh_map::MeshMap>& mesh_map_ptr,
+                                     const rclcpp::Node::SharedPtr& node)      // :142-169
+{
+  mesh_map_ = mesh_map_ptr;
+  name_ = plugin_name;
+  map_frame_ = mesh_map_->mapFrame();
+  node_ = node;
+  if (node_) {
+    config_.publish_vector_field = node_->declare_parameter(name_ + ".publish_vector_field", config_.publish_vector_field);   // :149
+    config_.publish_face_vectors = node_->declare_parameter(name_ + ".publish_face_vectors", config_.publish_face_vectors);   // :150
+    config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);               // :151
+    config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);                                 // :159
+  }
+  dev_.reset(new mnav_adapter::MeshMapDevice(0));     // CSR + float32 arrays are built and uploaded once
+  std::string err;
+  return dev_->ok() && dev_->sync(*mesh_map_, err);
+}
+
+// dijkstra_mesh_planner.cpp:217-398 with the loop :287-348 on the device
+uint32_t DijkstraMeshPlanner::dijkstra(const mesh_map::Vector& original_start, const mesh_map::Vector& original_goal,
+                                       std::list<uint32_t>& path)
+{
+  const uint32_t start_vertex = mesh_map_->getNearestVertexHandle(original_start);   // :235
+  const uint32_t goal_vertex = mesh_map_->getNearestVertexHandle(original_goal);     // :236
+  cancel_planning_ = false;                                                   // :238
+  if (start_vertex == mesh_map::kNoHandle) return Result::INVALID_START;      // :240
+  if (goal_vertex == mesh_map::kNoHandle) return Result::INVALID_GOAL;        // :242
+  path.clear();
+  std::string err;
+  if (!dev_ || !dev_->sync(*mesh_map_, err)) return Result::INTERNAL_ERROR;
+  const uint32_t V = mesh_map_->V;
+  potential_.assign(V, 0.f); predecessors_.assign(V, 0u); vector_map_.assign((size_t)V * 3, 0.f);
+  std::vector<uint32_t> p(V ? V : 1);
+  uint32_t n = 0;
+  const uint32_t code = mnav_plan_dijkstra(dev_->ctx(), start_vertex, goal_vertex, config_.goal_dist_offset, config_.cost_limit,
+                                           potential_.data(), predecessors_.data(), p.data(), V, &n, vector_map_.data());
+  if (code != Result::SUCCESS) return code;
+  for (uint32_t i = 0; i < n; ++i) path.push_back(p[i]);                      // :367-373 list order: seed first
+  std::vector<uint8_t> set(V, 0);
+  for (uint32_t v = 0; v < V; ++v) set[v] = predecessors_[v] != v;            // :197
+  mesh_map_->setVectorMap(vector_map_, set);                                  // :208
+  return Result::SUCCESS;
+}
+}  // namespace dijkstra_mesh_planner
+
+// =============================================================================================
+namespace cvp_mesh_planner {
+
+// cvp_mesh_planner.cpp:62-140
+uint32_t CVPMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped& goal, double /*tolerance*/,
+                                  std::vector<PoseStamped>& plan, double& cost, std::string& message)
+{
+  const PoseStamped start_in_map = mesh_map_->transformToMapFrame(start);     // :72
+  const PoseStamped goal_in_map = mesh_map_->transformToMapFrame(goal);       // :73
+  const mesh_map::Vector start_vec = mesh_map::toVector(start_in_map.pose.position);   // :82
+  const mesh_map::Vector goal_vec = mesh_map::toVector(goal_in_map.pose.position);     // :83
+  std::list<std::pair<mesh_map::Vector, uint32_t>> path;
+  const uint32_t outcome = waveFrontPropagation(goal_vec, start_vec, path, message);   // :89
+  path.reverse();                                                             // :93
+  std_msgs::msg::Header header;
+  header.stamp = node_ ? node_->now() : builtin_interfaces::msg::Time();
+  header.frame_id = mesh_map_->mapFrame();
+  cost = 0;                                                                   // :99
+  float dir_length;
+  if (!cancel_planning_ && !path.empty()) {                                   // :101
+    mesh_map::Vector vec = path.front().first;                                // :103
+    uint32_t fH = path.front().second;                                        // :104
+    path.pop_front();
+    for (auto& next : path) {                                                 // :108
+      PoseStamped pose;
+      pose.header = header;
+      pose.pose = mesh_map::calculatePoseFromPosition(vec, next.first, mesh_map_->faceNormal(fH), dir_length);   // :112
+      cost += dir_length;
+      vec = next.first;
+      fH = next.second;
+      plan.push_back(pose);
+    }
+    PoseStamped pose;                                                         // :119-123 goal pose verbatim
+    pose.header = header;
+    pose.pose = goal_in_map.pose;
+    plan.push_back(pose);
+  }
+  return outcome;
+}
+
+bool CVPMeshPlanner::cancel()                                                 // :142-146
+{
+  cancel_planning_ = true;
+  if (dev_ && dev_->ok()) mnav_cancel(dev_->ctx());
+  return true;
+}
+
+bool CVPMeshPlanner::initialize(const std::string& plugin_name, const std::shared_ptr<mesh_map::MeshMap>& mesh_map_ptr,
+                                const rclcpp::Node::SharedPtr& node)           // :148-186
+{
+  mesh_map_ = mesh_map_ptr;
+  name_ = plugin_name;
+  map_frame_ = mesh_map_->mapFrame();
+  node_ = node;
+  if (node_) {
+    config_.publish_vector_field = node_->declare_parameter(name_ + ".publish_vector_field", config_.publish_vector_field);   // :155
+    config_.publish_face_vectors = node_->declare_parameter(name_ + ".publish_face_vectors", config_.publish_face_vectors);   // :156
+    config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);               // :157
+    config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);                                 // :165
+    config_.step_width = node_->declare_parameter(name_ + ".step_width", config_.step_width);                                 // :175
+  }
+  direction_.assign(mesh_map_->V, 0.f);                                       // :179
+  dev_.reset(new mnav_adapter::MeshMapDevice(0));
+  std::string err;
+  return dev_->ok() && dev_->sync(*mesh_map_, err);
+}
+
+// cvp_mesh_planner.cpp:651-970 with the loop :747-886 and computeVectorMap :897 on the device
+uint32_t CVPMeshPlanner::waveFrontPropagation(const mesh_map::Vector& original_start, const mesh_map::Vector& original_goal,
+                                              std::list<std::pair<mesh_map::Vector, uint32_t>>& path, std::string& message)
+{
+  const mesh_map::Vector start = original_start, goal = original_goal;
+  const uint32_t start_face = mesh_map_->getContainingFace(start, 0.4f);      // :673
+  const uint32_t goal_face = mesh_map_->getContainingFace(goal, 0.4f);        // :674
+  cancel_planning_ = false;                                                   // :679
+  if (start_face == mesh_map::kNoHandle) { message = "Could not find a face close enough to the given start pose"; return Result::INVALID_START; }   // :681-685
+  if (goal_face == mesh_map::kNoHandle) { message = "Could not find a face close enough to the given goal pose"; return Result::INVALID_GOAL; }      // :686-690
+  path.clear();
+  std::string err;
+  if (!dev_ || !dev_->sync(*mesh_map_, err)) { message = err; return Result::INTERNAL_ERROR; }
+  const uint32_t V = mesh_map_->V;
+  potential_.assign(V, 0.f); predecessors_.assign(V, 0u); cutting_faces_.assign(V, mesh_map::kNoHandle); vector_map_.assign((size_t)V * 3, 0.f);
+  const float seed_pos[3] = { start.x, start.y, start.z };
+  const uint32_t code = mnav_plan_cvp(dev_->ctx(), seed_pos, start_face, goal_face, config_.goal_dist_offset, config_.cost_limit,
+                                      potential_.data(), predecessors_.data(), direction_.data(), cutting_faces_.data(), vector_map_.data());
+  if (code == Result::CANCELED) return code;                                  // :888-892
+  if (code == Result::INTERNAL_ERROR) { message = mnav_last_error(dev_->ctx()); return code; }
+  // MeshMap::setVectorMap (:238): seeds hold their raw offset vector (:722-724), updated vertices the rotated direction
+  std::vector<uint8_t> set(V, 0);
+  for (uint32_t v = 0; v < V; ++v) set[v] = (predecessors_[v] != v && cutting_faces_[v] != mesh_map::kNoHandle);
+  for (int k = 0; k < 3; ++k) set[mesh_map_->faces[3 * (size_t)start_face + k]] = 1;
+  mesh_map_->setVectorMap(vector_map_, set);
+  if (code == Result::NO_PATH_FOUND) { message = "Predecessor of the goal is not set! No path found!"; return code; }   // :912-918
+  // vector field back-tracking :920-951 (sequential, ~path_length / step_width iterations, host)
+  uint32_t current_face = goal_face;
+  mesh_map::Vector current_pos = goal;
+  path.push_front(std::make_pair(current_pos, current_face));                 // :924
+  size_t guard = 0;
+  while (current_pos.distance2(start) > config_.step_width && !cancel_planning_) {   // :927 (squared distance vs width, as is)
+    if (mesh_map_->meshAhead(current_pos, current_face, (float)config_.step_width)) {   // :933
+      path.push_front(std::make_pair(current_pos, current_face));             // :935
+    } else {
+      message = "Could not find a valid path, while back-tracking from the goal";   // :939
+      return Result::NO_PATH_FOUND;
+    }
+    if (++guard > 10u * (size_t)V + 1000u) { message = "vector field back-tracking does not terminate"; return Result::NO_PATH_FOUND; }
+  }
+  path.push_front(std::make_pair(start, start_face));                         // :951
+  if (cancel_planning_) return Result::CANCELED;                              // :962-966
+  return Result::SUCCESS;
+}
+}  // namespace cvp_mesh_planner
