@@ -95,10 +95,8 @@ def main() -> None:
             first = (g, t, r)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    from mesh_navigation_amd import multi
+    total_plans, elapsed = multi.aggregate_throughput(B * args.steps, elapsed, dist)   # sum of plans, MAX time over ranks
 
     # single-plan latency (ms/makePlan, device part) -- rank 0 only, outside the timed region
     single_ms = None
@@ -111,7 +109,6 @@ def main() -> None:
 
     out = None
     if rank == 0:
-        total_plans = world * B * args.steps
         ms_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (k_tile_round): algorithmic bytes per launch (SURVEY.md
         # §8d: 24 B per settled vertex + 24 B per incident edge, summed over the batch) divided by
