@@ -35,6 +35,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "64")))
     ap.add_argument("--grid", type=int, default=int(os.environ.get("MNAV_BENCH_N", "1000")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-plan latency runs (profiling)")
     args = ap.parse_args()
 
     import torch
@@ -80,7 +81,7 @@ def main() -> None:
         r = ctx.plan_dijkstra_batch(g, t, want_fields=False, path_cap=16384)
         if first is None:
             first = (g, t, r)
-    prop_ms = launches = algo = 0.0
+    prop_ms = kern_ms = launches = algo = 0.0
     settled = 0
     barrier()
     t0 = time.perf_counter()
@@ -89,7 +90,7 @@ def main() -> None:
         r = ctx.plan_dijkstra_batch(g, t, want_fields=False, path_cap=16384)
         assert (r["codes"] == 0).all(), r["codes"]
         st = r["stats"]
-        prop_ms += st["ms_propagation"]; launches += st["launches"]; algo += st["algorithmic_bytes"]
+        prop_ms += st["ms_propagation"]; kern_ms += st["ms_step_kernels"]; launches += st["launches"]; algo += st["algorithmic_bytes"]
         settled += st["settled"]
         if first is None:
             first = (g, t, r)
@@ -100,7 +101,7 @@ def main() -> None:
 
     # single-plan latency (ms/makePlan, device part) -- rank 0 only, outside the timed region
     single_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         lat = []
         for k in range(5):
             o = ctx.plan_dijkstra(int(first[0][k % B]), robot, want_fields=False)
@@ -112,10 +113,11 @@ def main() -> None:
         ms_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (k_tile_round): algorithmic bytes per launch (SURVEY.md
         # §8d: 24 B per settled vertex + 24 B per incident edge, summed over the batch) divided by
-        # the average launch duration from the HIP events the library records on its own stream
-        # around the propagation phase (all k_tile_round launches + the finalize gather).
+        # the average launch duration, measured live with HIP events that the library records on
+        # ITS OWN stream around every graph replay of 24 k_tile_round launches (back-to-back on the
+        # device; the host polls between replays are outside the brackets).
         per_launch_bytes = algo / max(launches, 1)
-        per_launch_s = prop_ms * 1e-3 / max(launches, 1)
+        per_launch_s = kern_ms * 1e-3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         out = {
             "metric": "plans/sec (Dijkstra makePlan device path, 1M-vertex mesh)",
@@ -140,7 +142,7 @@ def main() -> None:
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "k_tile_round", "launches_per_step": launches / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
-                         "avg_launch_us": per_launch_s * 1e6,
+                         "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,
                          "settled_vertices_per_plan": settled / max(args.steps * B, 1)},
         }
         if not args.no_cpu and world >= 1:

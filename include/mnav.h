@@ -52,6 +52,8 @@ typedef struct mnav_stats {
   float ms_path;           /* predecessor walk                                   */
   float ms_download;       /* device -> host copies of requested outputs         */
   float ms_total;          /* whole call                                         */
+  float ms_step_kernels;   /* sum over graph replays of the event-bracketed step/round launches
+                              (excludes the host polls between replays)          */
 } mnav_stats;
 
 /* -- life cycle -------------------------------------------------------------------------- */

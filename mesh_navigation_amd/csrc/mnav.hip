@@ -992,6 +992,10 @@ struct mnav_ctx {
   mnav_stats stats{};
   uint64_t algo_bytes = 0;
   hipEvent_t ev[8]{};
+  hipEvent_t evc[2]{};         // bracket one graph replay (chunk of step/round launches)
+  double ms_chunks = 0.0;      // sum of the bracketed chunk durations of the last call
+  Ctl* d_ctl_pool = nullptr; uint32_t ctl_pool_cap = 0;      // contiguous control blocks: one D2H copy per chunk
+  TCtl* d_tctl_pool = nullptr; uint32_t tctl_pool_cap = 0;
 };
 
 namespace {
@@ -1014,12 +1018,14 @@ int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
   return 0;
 }
 
+float ev_ms(hipEvent_t a, hipEvent_t b);
+
 void free_slot(Slot& s)
 {
   (void)hipFree(s.dist); (void)hipFree(s.tkey); (void)hipFree(s.dirn); (void)hipFree(s.vecmap);
   (void)hipFree(s.pred); (void)hipFree(s.cutf); (void)hipFree(s.stamp); (void)hipFree(s.list0); (void)hipFree(s.list1);
-  (void)hipFree(s.ctl); (void)hipFree(s.cnt);
-  (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tctl); (void)hipFree(s.tcnt);
+  (void)hipFree(s.cnt);
+  (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tcnt);
   s = Slot{};
 }
 
@@ -1037,7 +1043,7 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
     HIPCHK(hipMalloc((void**)&s.dist, 4 * V)); HIPCHK(hipMalloc((void**)&s.pred, 4 * V));
     HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.list0, 4 * V));
     HIPCHK(hipMalloc((void**)&s.list1, 4 * V)); HIPCHK(hipMalloc((void**)&s.vecmap, 12 * V));
-    HIPCHK(hipMalloc((void**)&s.ctl, 2 * sizeof(Ctl))); HIPCHK(hipMalloc((void**)&s.cnt, 3 * sizeof(Cnt)));
+    HIPCHK(hipMalloc((void**)&s.cnt, 3 * sizeof(Cnt)));
     ctx->slots.push_back(s);
   }
   if (cvp)
@@ -1049,6 +1055,13 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
         s.cvp_ready = true;
       }
     }
+  if (ctx->ctl_pool_cap < n) {
+    if (ctx->d_ctl_pool) (void)hipFree(ctx->d_ctl_pool);
+    ctx->d_ctl_pool = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_ctl_pool, 2 * sizeof(Ctl) * n));
+    ctx->ctl_pool_cap = n;
+  }
+  for (uint32_t i = 0; i < n; ++i) ctx->slots[i].ctl = ctx->d_ctl_pool + 2 * i;
   if (ctx->plans_cap < n) {
     if (ctx->d_plans) (void)hipFree(ctx->d_plans);
     if (ctx->d_res) (void)hipFree(ctx->d_res);
@@ -1193,15 +1206,18 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   uint32_t launches = 0;
   int rc = 0;
   const auto t_start = std::chrono::steady_clock::now();
+  ctx->ms_chunks = 0.0;
   for (;;) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
       ctx->err = "wavefront steps exceeded the wall-clock guard"; return -1;
     }
+    HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
     if (run_chunk<PLANNER>(ctx, n, G)) return -1;
+    HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
     launches += kChunk;
-    for (uint32_t i = 0; i < n; ++i)
-      HIPCHK(hipMemcpyAsync(ctx->h_ctl + 2 * i, ctx->slots[i].ctl, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl) * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->ms_chunks += ev_ms(ctx->evc[0], ctx->evc[1]);
     bool all_done = true;
     for (uint32_t i = 0; i < n; ++i) {
       const Ctl& a = ctx->h_ctl[2 * i];
@@ -1224,11 +1240,18 @@ int ensure_tile_state(mnav_ctx* ctx, uint32_t n)
     Slot& s = ctx->slots[i];
     if (!s.tile_ready) {
       HIPCHK(hipMalloc((void**)&s.tpend0, 4 * nt)); HIPCHK(hipMalloc((void**)&s.tpend1, 4 * nt));
-      HIPCHK(hipMalloc((void**)&s.tlast, 4 * nt)); HIPCHK(hipMalloc((void**)&s.tctl, 2 * sizeof(TCtl)));
+      HIPCHK(hipMalloc((void**)&s.tlast, 4 * nt));
       HIPCHK(hipMalloc((void**)&s.tcnt, 3 * sizeof(TCnt)));
       s.tile_ready = true;
     }
   }
+  if (ctx->tctl_pool_cap < n) {
+    if (ctx->d_tctl_pool) (void)hipFree(ctx->d_tctl_pool);
+    ctx->d_tctl_pool = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_tctl_pool, 2 * sizeof(TCtl) * n));
+    ctx->tctl_pool_cap = n;
+  }
+  for (uint32_t i = 0; i < n; ++i) ctx->slots[i].tctl = ctx->d_tctl_pool + 2 * i;
   if (ctx->tplans_cap < n) {
     if (ctx->d_tplans) (void)hipFree(ctx->d_tplans);
     if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
@@ -1346,15 +1369,18 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   uint32_t launches = 0;
   int rc = 0;
   const auto t_start = std::chrono::steady_clock::now();
+  ctx->ms_chunks = 0.0;
   for (;;) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
       ctx->err = "tile rounds exceeded the wall-clock guard"; return -1;
     }
+    HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
     if (run_tile_chunk(ctx, n, G)) return -1;
+    HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
     launches += kTileChunk;
-    for (uint32_t i = 0; i < n; ++i)
-      HIPCHK(hipMemcpyAsync(ctx->h_tctl + 2 * i, ctx->slots[i].tctl, 2 * sizeof(TCtl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_tctl, ctx->d_tctl_pool, 2 * sizeof(TCtl) * n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->ms_chunks += ev_ms(ctx->evc[0], ctx->evc[1]);
     bool all_done = true;
     for (uint32_t i = 0; i < n; ++i) {
       const TCtl& a = ctx->h_tctl[2 * i];
@@ -1404,6 +1430,7 @@ void finish_stats(mnav_ctx* ctx, uint32_t n, bool cvp)
   st.ms_vector_map = ev_ms(ctx->ev[4], ctx->ev[5]);
   st.ms_download = ev_ms(ctx->ev[5], ctx->ev[6]);
   st.ms_total = ev_ms(ctx->ev[0], ctx->ev[6]);
+  st.ms_step_kernels = (float)ctx->ms_chunks;
   // early-exit variant = settled vertices and their incident edges / faces
   const double V = ctx->V ? ctx->V : 1;
   const double frac = (double)st.settled / V;   // summed over plans
@@ -1436,6 +1463,8 @@ mnav_ctx* mnav_create(int device)
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   for (auto& e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return nullptr; }
+  for (auto& e : ctx->evc)
+    if (hipEventCreate(&e) != hipSuccess) { delete ctx; return nullptr; }
   if (hipMalloc((void**)&ctx->d_seed_pos, 3 * sizeof(float)) != hipSuccess) { delete ctx; return nullptr; }
   if (const char* e = getenv("MNAV_NO_GRAPH")) ctx->use_graph = !(atoi(e) != 0);
   if (const char* e = getenv("MNAV_DIJKSTRA_ENGINE")) ctx->dij_engine = (strcmp(e, "band") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
@@ -1462,6 +1491,8 @@ void mnav_destroy(mnav_ctx* ctx)
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->evc) if (e) (void)hipEventDestroy(e);
+  (void)hipFree(ctx->d_ctl_pool); (void)hipFree(ctx->d_tctl_pool);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
