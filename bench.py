@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- plans/sec of the MI355X wavefront planner on BASELINE config C2.
 
-One "step" = one batch of B independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex
+One "step" = one batch of B (default 1024) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex
 synthetic terrain (N=1000, h=0.1 m, seed 2, edge_cost_factor 0, reference default
 cut-offs goal_dist_offset 0.3 / cost_limit 1.0), B goal vertices drawn per step, common robot
 vertex (the concurrent-goals shape of BASELINE config 5).  Mesh and costs are resident in HBM
@@ -32,7 +32,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "64")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "1024")))
     ap.add_argument("--grid", type=int, default=int(os.environ.get("MNAV_BENCH_N", "1000")))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-plan latency runs (profiling)")
@@ -111,11 +111,11 @@ def main() -> None:
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        # roofline of the dominant kernel (k_tile_round): algorithmic bytes per launch (SURVEY.md
-        # §8d: 24 B per settled vertex + 24 B per incident edge, summed over the batch) divided by
-        # the average launch duration, measured live with HIP events that the library records on
-        # ITS OWN stream around every graph replay of 24 k_tile_round launches (back-to-back on the
-        # device; the host polls between replays are outside the brackets).
+        # roofline of the dominant kernel: algorithmic bytes per launch (24 B per
+        # settled vertex + 24 B per incident edge, summed over the batch) divided by the average
+        # launch duration, measured live with HIP events that the library records on ITS OWN stream
+        # around the launch(es): batches of >= 128 plans run as ONE launch of k_plan_persistent (one
+        # workgroup per plan); smaller batches as hipGraph replays of 24 k_tile_round launches.
         per_launch_bytes = algo / max(launches, 1)
         per_launch_s = kern_ms * 1e-3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
@@ -133,14 +133,14 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"C2: delta-stepping SSSP (tiled label-correcting), {N}x{N} terrain = {mesh.V} vertices, "
-                                   f"uniform edge costs, batch of {B} goals per step per GPU, goal_dist_offset 0.3",
+                                   f"uniform edge costs, batch of {B} goals per step per GPU, common robot vertex, goal_dist_offset 0.3",
                        "vertices": mesh.V, "edges": mesh.E, "batch_per_gpu": B,
                        "parallelism": f"{world} independent replicas (plans sharded by rank)"},
             "ms_per_makeplan_single": single_ms,
             "ms_per_plan_in_batch": ms_step / B,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_tile_round", "launches_per_step": launches / args.steps,
+                         "kernel": "k_plan_persistent" if launches <= args.steps else "k_tile_round", "launches_per_step": launches / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
                          "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,
                          "settled_vertices_per_plan": settled / max(args.steps * B, 1)},

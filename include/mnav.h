@@ -132,8 +132,11 @@ int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out);
 /* Band width of the wavefront engine in potential units; <= 0 selects the default
  * (3 x mean finite edge weight, recomputed on every cost upload). */
 int mnav_set_band_width(mnav_ctx* ctx, float delta);
-/* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (default), 1 = the
- * distance-band gather steps that the CVP planner uses.  Both give identical results. */
+/* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round,
+ * lowest latency for a single plan), 1 = the distance-band gather steps that the CVP planner uses,
+ * 2 = persistent per-plan workgroups walking the tiles best-first (highest throughput for large
+ * batches), 3 = automatic (default: 2 for batches of >= 128 plans, else 0).  All give identical
+ * results. */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
 /* Device pointers of the last plan's resident outputs (slot = plan index in a batch):
  * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available. */

@@ -174,8 +174,8 @@ class MnavContext:
         self._L.mnav_set_band_width(self._h, float(delta))
 
     def set_dijkstra_engine(self, engine: str):
-        """'tiled' (default) or 'band'."""
-        self._L.mnav_set_dijkstra_engine(self._h, 1 if engine == "band" else 0)
+        """'auto' (default), 'tiled', 'band' or 'persistent'."""
+        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3}[engine])
 
     def stats(self) -> dict:
         s = Stats()

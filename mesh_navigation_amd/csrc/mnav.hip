@@ -618,6 +618,192 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent per-plan variant (batches): ONE workgroup owns a plan from seed to convergence and
+// walks its tiles best-first -- always the tile with the smallest wake-up value, with the band
+// [m, m + band) -- without any launch or grid-wide round in between.  Independent plans never
+// talk to each other, so there is no inter-workgroup protocol at all; hundreds of plans run
+// concurrently (2 workgroups per CU).  Same tile solve as k_tile_round (LDS queue sweeps, ds_min
+// on float bits); state that the workgroup re-reads after writing it (dist, wake-ups, tlast) is
+// accessed with agent-scope relaxed atomics, i.e. served by the L2 and never by a stale L1 line.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ldg_u32(MNAV_GLOBAL const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldg_f32(MNAV_GLOBAL const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stg_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stg_f32(MNAV_GLOBAL float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* __restrict__ plans)
+{
+  const TilePlan& P = plans[blockIdx.x];
+  const int tid = threadIdx.x;
+  __shared__ unsigned long long s_best[kTileBlock / 64];
+  __shared__ uint32_t s_hdr[8];
+  __shared__ uint32_t s_nq[3];
+  __shared__ float s_bound;
+  MNAV_GLOBAL uint32_t* pend = as_global(P.pend[0]);
+  MNAV_GLOBAL const uint32_t* g_vptr = as_global(P.vptr);
+  MNAV_GLOBAL const uint32_t* g_hptr = as_global(P.hptr);
+  MNAV_GLOBAL const uint32_t* g_eptr = as_global(P.eptr);
+  MNAV_GLOBAL const uint32_t* g_rptr = as_global(P.rptr);
+  MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
+  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
+  MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
+  MNAV_GLOBAL float* g_dist = as_global(P.dist);
+  MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t nlmax = P.max_nv + P.max_nh;
+  uint2* lcw = reinterpret_cast<uint2*>(smem);
+  uint32_t* ldu = reinterpret_cast<uint32_t*>(lcw + pad_to(P.max_ne, 2));
+  uint32_t* inq = ldu + pad_to(nlmax, 4);
+  uint32_t* lh0 = inq + pad_to(P.max_nv, 4);
+  uint16_t* lrow = reinterpret_cast<uint16_t*>(lh0 + pad_to(P.max_nh, 4));
+  uint16_t* q0 = lrow + pad_to(nlmax + 1, 8);
+  uint16_t* q1 = q0 + pad_to(nlmax, 8);
+  const int sub = tid & (kGroup - 1);
+
+  uint32_t acts = 0, sweeps_total = 0;
+  uint32_t status = 0;   // 0 converged, 2 activation cap hit
+  for (;;) {
+    // best-first: the tile with the smallest wake-up value
+    unsigned long long best = ~0ull;
+    for (uint32_t t = tid; t < P.ntiles; t += kTileBlock) {
+      const unsigned long long k = ((unsigned long long)ldg_u32(pend + t) << 32) | t;
+      best = k < best ? k : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); best = ob < best ? ob : best; }
+    if ((tid & 63) == 0) s_best[tid >> 6] = best;
+    if (tid == 0) {
+      const float dt = ldg_f32(g_dist + P.target);
+      s_bound = (float)((double)dt + P.offset);                    // >= the final goal_dist (dijkstra :296)
+    }
+    __syncthreads();
+    best = s_best[0];
+#pragma unroll
+    for (int w = 1; w < kTileBlock / 64; ++w) best = s_best[w] < best ? s_best[w] : best;
+    const float bound = s_bound;
+    const float m = u2f((uint32_t)(best >> 32));
+    const uint32_t t = (uint32_t)best;
+    if (!(m < inf_f()) || m > bound) break;                        // nothing left that may propagate
+    if (acts >= P.max_rounds) { status = 2; break; }
+    float thr = m + P.band;
+    if (!(thr > m)) thr = next_up(m);
+    if (tid == 0) {
+      stg_u32(pend + t, kInfBits);
+      s_hdr[0] = g_vptr[t]; s_hdr[1] = g_vptr[t + 1]; s_hdr[2] = g_hptr[t]; s_hdr[3] = g_hptr[t + 1];
+      s_hdr[4] = g_eptr[t]; s_hdr[5] = g_eptr[t + 1]; s_hdr[6] = g_rptr[t]; s_hdr[7] = f2u(ldg_f32(g_tlast + t));
+      s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
+    }
+    __syncthreads();
+    const uint32_t v0 = s_hdr[0], nv = s_hdr[1] - v0;
+    const uint32_t h0 = s_hdr[2], nh = s_hdr[3] - h0;
+    const uint32_t e0 = s_hdr[4], ne = s_hdr[5] - e0;
+    const uint32_t r0 = s_hdr[6];
+    const uint32_t nl = nv + nh;
+    const float tl = u2f(s_hdr[7]);
+    // stage (see k_tile_round)
+    uint32_t gi[kTileVpt];
+#pragma unroll
+    for (int k = 0; k < kTileVpt; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
+    uint32_t hi[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
+    {
+      MNAV_GLOBAL const u32x4* src = (MNAV_GLOBAL const u32x4*)(P.cw + e0);
+      u32x4* dst = reinterpret_cast<u32x4*>(lcw);
+      const uint32_t n16 = ne / 2;
+      uint32_t base = tid;
+      for (; base + 7 * kTileBlock < n16; base += 8 * kTileBlock) {
+        const u32x4 a0 = src[base], a1 = src[base + kTileBlock], a2 = src[base + 2 * kTileBlock], a3 = src[base + 3 * kTileBlock];
+        const u32x4 a4 = src[base + 4 * kTileBlock], a5 = src[base + 5 * kTileBlock], a6 = src[base + 6 * kTileBlock], a7 = src[base + 7 * kTileBlock];
+        dst[base] = a0; dst[base + kTileBlock] = a1; dst[base + 2 * kTileBlock] = a2; dst[base + 3 * kTileBlock] = a3;
+        dst[base + 4 * kTileBlock] = a4; dst[base + 5 * kTileBlock] = a5; dst[base + 6 * kTileBlock] = a6; dst[base + 7 * kTileBlock] = a7;
+      }
+      for (; base < n16; base += kTileBlock) dst[base] = src[base];
+      MNAV_GLOBAL const u32x4* rs = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);
+      u32x4* rd = reinterpret_cast<u32x4*>(lrow);
+      const uint32_t nr16 = (nl + 1 + 7) / 8;
+      for (uint32_t i = tid; i < nr16; i += kTileBlock) rd[i] = rs[i];
+    }
+    uint32_t orig[kTileVpt];
+#pragma unroll
+    for (int k = 0; k < kTileVpt; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      orig[k] = 0u;
+      if (i < nv) {
+        const float d = ldg_f32(g_dist + gi[k]);
+        orig[k] = f2u(d); ldu[i] = orig[k]; inq[i] = 0u;
+        if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      if (i < nh) { const float d = ldg_f32(g_dist + hi[k]); ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i); }
+    }
+    for (uint32_t i = tid + 2 * kTileBlock; i < nh; i += kTileBlock) {
+      const float d = ldg_f32(g_dist + g_halo_verts[h0 + i]);
+      ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
+    }
+    __syncthreads();
+    uint32_t sweep = 0;
+    for (;;) {
+      const uint32_t nq = s_nq[sweep % 3];
+      if (nq == 0) break;
+      if (tid == 0) s_nq[(sweep + 2) % 3] = 0;
+      const uint16_t* qa = (sweep & 1) ? q1 : q0;
+      uint16_t* qb = (sweep & 1) ? q0 : q1;
+      uint32_t* nqb = &s_nq[(sweep + 1) % 3];
+      const uint32_t stamp = sweep + 1;
+      for (uint32_t idx = (uint32_t)tid >> 3; idx < nq; idx += kTileBlock / kGroup) {
+        const uint32_t x = qa[idx];
+        const uint32_t dib = ldu[x];
+        const uint32_t eb = lrow[x], ee = lrow[x + 1];
+        const float di = u2f(dib);
+        if (!(di < thr) || !(di <= bound)) continue;
+        for (uint32_t e = eb + sub; e < ee; e += kGroup) {
+          const uint2 cw = lcw[e];
+          const uint32_t ndb = f2u(di + u2f(cw.y));                 // the float add of dijkstra :331
+          const uint32_t old = atomicMin(&ldu[cw.x], ndb);
+          if (ndb < old && cw.x < nv && atomicMax(&inq[cw.x], stamp) < stamp) qb[atomicAdd(nqb, 1u)] = (uint16_t)cw.x;
+        }
+      }
+      ++sweep;
+      __syncthreads();
+    }
+    // wake-ups for the owners of undercut halo vertices, write-back, own left-over
+    uint32_t own_left = kInfBits;
+    for (uint32_t i = tid; i < nh; i += kTileBlock) {
+      const uint32_t b = ldu[nv + i];
+      if (b < lh0[i]) atomicMin((uint32_t*)&pend[g_halo_tile[h0 + i]], b);
+    }
+#pragma unroll
+    for (int k = 0; k < kTileVpt; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      if (i < nv) {
+        const uint32_t db = ldu[i];
+        if (db != orig[k]) stg_f32(g_dist + gi[k], u2f(db));
+        const float d = u2f(db);
+        if (!(d < thr) && d <= bound) own_left = min(own_left, db);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) own_left = min(own_left, (uint32_t)__shfl_xor((int)own_left, o));
+    if ((tid & 63) == 0 && own_left != kInfBits) atomicMin((uint32_t*)&pend[t], own_left);
+    if (tid == 0) stg_f32(g_tlast + t, thr);
+    ++acts; sweeps_total += sweep;
+    // every store / atomic of this activation must have reached the L2 before the next scan
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    TCtl c; memset(&c, 0, sizeof(c));
+    c.it = (int32_t)acts; c.done = 1; c.acts = acts; c.sweeps = sweeps_total; c.pad[0] = status;
+    P.ctl[0] = c; P.ctl[1] = c;
+  }
+}
+
 // per-plan initialisation of the tile state (dist/pred are set by k_init)
 __global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile)
 {
@@ -684,7 +870,7 @@ __global__ __launch_bounds__(kBlock) void k_dij_finalize(const Plan* __restrict_
     const TCtl last = (a.it > b.it) ? a : b;
     Ctl r; memset(&r, 0, sizeof(r));
     r.it = last.it; r.done = last.done; r.armed = c.armed; r.goal_dist = c.goal_dist; r.bands = last.sweeps;
-    r.evals = last.acts; r.thr = inf_f(); r.thr_fixed = inf_f();
+    r.evals = last.acts; r.thr = inf_f(); r.thr_fixed = inf_f(); r.overflow = last.pad[0];
     P.ctl[0] = r; P.ctl[1] = r;
   }
 }
@@ -972,10 +1158,13 @@ struct mnav_ctx {
   float* d_seed_pos = nullptr;
   std::map<uint64_t, hipGraphExec_t> graphs;
   // tiled SSSP engine
-  int dij_engine = 0;          // 0 tiled, 1 band
+  int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 2 persistent per-plan, 3 auto
+  int last_engine = 0;
+  uint32_t persistent_min_batch = 128;
   uint32_t max_steps = 1u << 20;   // per plan; set from the mesh size at upload (a wavefront needs O(diameter) steps)
   double max_wall_s = 120.0;   // host-side guard: a plan that takes longer is abandoned with an error
-  uint32_t tile_size = 1024;
+  uint32_t tile_size = 512;    // 4 workgroups of the tile kernels per CU (36 KB LDS each)
+  float rounds_band_mult = 4.0f;   // the round engine (latency) prefers wider bands than the persistent one
   float tile_band_user = 0.f, tile_band_auto = 1.f;
   uint32_t* d_t_rptr = nullptr;
   HostTiles tiles_meta;        // only the small per-tile vectors are kept (vert_tile, sizes)
@@ -1338,7 +1527,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.cw = ctx->d_t_cw;
     T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset; T.max_rounds = ctx->max_steps;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
+    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
     T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
   HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
@@ -1401,6 +1590,74 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   return rc;
+}
+
+// Dijkstra batches through the persistent per-plan kernel.  Returns 0 or -1.
+int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
+{
+  if (ensure_slots(ctx, n, false)) return -1;
+  if (ensure_paths(ctx, n)) return -1;
+  if (ensure_tile_state(ctx, n)) return -1;
+  if (tile_weights(ctx)) return -1;
+  const HostTiles& M = ctx->tiles_meta;
+  std::vector<Plan> hp(n);
+  std::vector<TilePlan> tp(n);
+  std::vector<float*> vecs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Slot& s = ctx->slots[i];
+    Plan& P = hp[i];
+    memset(&P, 0, sizeof(P));
+    P.planner = kPlannerDijkstra; P.V = ctx->V;
+    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
+    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
+    P.seed_face = kNone;
+    vecs[i] = s.vecmap;
+    TilePlan& T = tp[i];
+    memset(&T, 0, sizeof(T));
+    T.V = ctx->V; T.ntiles = M.ntiles;
+    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.cw = ctx->d_t_cw;
+    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
+    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
+    T.max_rounds = 64u * (M.ntiles ? M.ntiles : 1u) + 1024u;          // activation cap per plan
+    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
+    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  {
+    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
+    if (gt < 1) gt = 1;
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+  ctx->ms_chunks = 0.0;
+  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
+  hipLaunchKernelGGL(k_plan_persistent, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
+  uint32_t gf = (ctx->V + (kBlock / kGroup) - 1) / (kBlock / kGroup);
+  if (gf > 8192) gf = 8192;
+  if (gf < 1) gf = 1;
+  hipLaunchKernelGGL(k_dij_finalize, dim3(gf, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_mismatch);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
+  ctx->stats.launches = 1;
+  return 0;
 }
 
 float ev_ms(hipEvent_t a, hipEvent_t b)
@@ -1467,7 +1724,13 @@ mnav_ctx* mnav_create(int device)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return nullptr; }
   if (hipMalloc((void**)&ctx->d_seed_pos, 3 * sizeof(float)) != hipSuccess) { delete ctx; return nullptr; }
   if (const char* e = getenv("MNAV_NO_GRAPH")) ctx->use_graph = !(atoi(e) != 0);
-  if (const char* e = getenv("MNAV_DIJKSTRA_ENGINE")) ctx->dij_engine = (strcmp(e, "band") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+  if (const char* e = getenv("MNAV_DIJKSTRA_ENGINE")) {
+    if (!strcmp(e, "band") || !strcmp(e, "1")) ctx->dij_engine = 1;
+    else if (!strcmp(e, "tiled") || !strcmp(e, "0")) ctx->dij_engine = 0;
+    else if (!strcmp(e, "persistent") || !strcmp(e, "2")) ctx->dij_engine = 2;
+    else ctx->dij_engine = 3;
+  }
+  if (const char* e = getenv("MNAV_PERSISTENT_MIN_BATCH")) ctx->persistent_min_batch = (uint32_t)atoi(e);
   return ctx;
 }
 
@@ -1556,6 +1819,8 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     if (ctx->tile_lds > 160 * 1024) { ctx->err = "mesh valence too high for the LDS tile engine"; return -2; }
     if (ctx->tile_lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void*)k_tile_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+    if (ctx->tile_lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
     (void)hipFree(ctx->d_t_cw); ctx->d_t_cw = nullptr; ctx->tw_valid = false;
     ctx->t_nnz = (uint32_t)T.col.size();
     if (dev_upload(ctx, &ctx->d_t_vptr, T.vptr.data(), T.vptr.size())) return -1;
@@ -1591,6 +1856,7 @@ static void auto_delta(mnav_ctx* ctx, const float* w, uint32_t E)
   // tile band ~ the potential difference across one tile (sqrt(tile_size) mean edges)
   ctx->tile_band_auto = (ctx->delta_auto / 3.0f) * std::sqrt((float)ctx->tile_size);
   if (const char* e = getenv("MNAV_TILE_BAND")) ctx->tile_band_user = (float)atof(e);
+  if (const char* e = getenv("MNAV_ROUNDS_BAND_MULT")) ctx->rounds_band_mult = (float)atof(e);
 }
 
 int mnav_upload_costs(mnav_ctx* ctx, const float* vertex_costs, const float* edge_weights, const uint8_t* invalid)
@@ -1670,8 +1936,13 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   if (m) {
     if (materialize(ctx, false, cost_limit)) return MNAV_INTERNAL_ERROR;
     const bool want_path = true;
-    const int rc = (ctx->dij_engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
-                                          : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
+    // engine: 0 = tiled rounds, 1 = band steps, 2 = persistent per-plan, 3 = auto (persistent for large batches)
+    int engine = ctx->dij_engine;
+    if (engine == 3) engine = (m >= ctx->persistent_min_batch) ? 2 : 0;
+    const int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
+                 : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
+                                 : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
+    ctx->last_engine = engine;
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
     hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
@@ -1683,14 +1954,22 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     (void)hipEventRecord(ctx->ev[5], ctx->stream);
     if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
-    if (ctx->dij_engine == 0) {
+    if (ctx->last_engine != 1) {
       uint32_t mism = 0;
       if (hipMemcpy(&mism, ctx->d_mismatch, 4, hipMemcpyDeviceToHost) != hipSuccess || mism != 0) {
         ctx->err = "tiled SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)";
         return MNAV_INTERNAL_ERROR;
       }
     }
+    // all vertex paths in one strided copy (device order: pred[target] ... seed)
+    uint32_t maxlen = 0;
+    for (uint32_t k = 0; k < m; ++k) if (ctx->h_res[k].code == MNAV_SUCCESS && ctx->h_res[k].path_len > maxlen) maxlen = ctx->h_res[k].path_len;
     std::vector<uint32_t> tmp;
+    if (maxlen && path_out && path_cap) {
+      tmp.resize((size_t)maxlen * m);
+      if (hipMemcpy2D(tmp.data(), (size_t)maxlen * 4, ctx->d_paths, (size_t)V * 4, (size_t)maxlen * 4, m, hipMemcpyDeviceToHost) != hipSuccess)
+        { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
+    }
     for (uint32_t k = 0; k < m; ++k) {
       const uint32_t i = map[k];
       const PlanResult& r = ctx->h_res[k];
@@ -1698,12 +1977,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       if (r.code == MNAV_SUCCESS) {
         if (path_len) path_len[i] = r.path_len;
         if (path_out && path_cap) {
-          tmp.resize(r.path_len);
-          if (r.path_len && hipMemcpy(tmp.data(), ctx->d_paths + (size_t)k * V, sizeof(uint32_t) * r.path_len, hipMemcpyDeviceToHost) != hipSuccess)
-            { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
-          // device order: pred[target] ... seed ; reference list order: seed ... pred[target]
+          // reference list order: seed ... pred[target]
+          const uint32_t* src = tmp.data() + (size_t)k * maxlen;
           uint32_t* dst = path_out + (size_t)i * path_cap;
-          for (uint32_t q = 0; q < r.path_len && q < path_cap; ++q) dst[q] = tmp[r.path_len - 1 - q];
+          for (uint32_t q = 0; q < r.path_len && q < path_cap; ++q) dst[q] = src[r.path_len - 1 - q];
         }
       }
       if (dist_out && hipMemcpyAsync(dist_out + (size_t)i * V, ctx->slots[k].dist, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
@@ -1838,7 +2115,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta)
 
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 {
-  if (!ctx || engine < 0 || engine > 1) return -1;
+  if (!ctx || engine < 0 || engine > 3) return -1;
   ctx->dij_engine = engine;
   return 0;
 }

@@ -16,7 +16,7 @@ def c2(gpu_ctx_factory):
     return case, ctx
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "persistent"])
 def test_dijkstra_c2_bit_exact(c2, engine):
     case, ctx = c2
     ctx.set_dijkstra_engine(engine)
@@ -30,7 +30,7 @@ def test_dijkstra_c2_bit_exact(c2, engine):
     # predecessors: the device uses the documented (dist[u], u) tie rule, the oracle the emulated
     # Meap order; on jittered terrain they coincide (DESIGN.md "tie rule")
     assert np.array_equal(out.pred, ref.pred)
-    ctx.set_dijkstra_engine("tiled")
+    ctx.set_dijkstra_engine("auto")
 
 
 def test_dijkstra_c2_full_field_properties(c2):

@@ -46,7 +46,7 @@ def c1(gpu_ctx_factory):
     return case, ctx
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "persistent"])
 def test_dijkstra_c1_bit_exact_and_golden(c1, engine):
     case, ctx = c1
     ctx.set_dijkstra_engine(engine)
@@ -59,7 +59,7 @@ def test_dijkstra_c1_bit_exact_and_golden(c1, engine):
     assert sha(out.dist) == str(GOLD["c1_dij_dist_sha"]) and sha(out.pred) == str(GOLD["c1_dij_pred_sha"])
     vm = case.om.dijkstra_vector_map(ref.pred)                       # computeVectorMap :189-209
     assert np.array_equal(out.vecmap.view(np.uint32), vm.view(np.uint32))
-    ctx.set_dijkstra_engine("tiled")
+    ctx.set_dijkstra_engine("auto")
 
 
 def test_cvp_c1_and_golden(c1):
@@ -87,7 +87,7 @@ def test_cvp_c1_and_golden(c1):
     assert np.abs(pos_d - pos_r).max() < 1e-3
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "persistent"])
 @pytest.mark.parametrize("offset", [0.0, 0.01, 0.3, 5.0, float("inf")])
 def test_dijkstra_goal_dist_offsets(c1, engine, offset):
     case, ctx = c1
@@ -97,7 +97,7 @@ def test_dijkstra_goal_dist_offsets(c1, engine, offset):
     ref = case.om.dijkstra(case.weights, case.costs, s, t, goal_dist_offset=offset)
     out = ctx.plan_dijkstra(s, t, goal_dist_offset=offset)
     assert_dijkstra_equal(out, ref)
-    ctx.set_dijkstra_engine("tiled")
+    ctx.set_dijkstra_engine("auto")
 
 
 def test_return_codes(c1):
@@ -122,13 +122,13 @@ def test_cost_limit_invalid_unreachable(gpu_ctx_factory):
     case = Case(mesh, costs, 1.0, invalid)
     ctx = gpu_ctx_factory()
     case.upload(ctx)
-    for engine in ("tiled", "band"):
+    for engine in ("tiled", "band", "persistent"):
         ctx.set_dijkstra_engine(engine)
         for lim in (1.0, 0.6):
             ref = case.om.dijkstra(case.weights, case.costs, s, t, cost_limit=lim, invalid=case.invalid)
             out = ctx.plan_dijkstra(s, t, cost_limit=lim)
             assert_dijkstra_equal(out, ref)
-    ctx.set_dijkstra_engine("tiled")
+    ctx.set_dijkstra_engine("auto")
     sp = mesh.xyz[s] + np.array([0.03, 0.02, 0], np.float32)
     tp = mesh.xyz[t] + np.array([0.03, 0.02, 0], np.float32)
     sf, _ = case.om.containing_face(sp)
@@ -220,7 +220,14 @@ def test_batch_equals_single_plans(c1):
     goals[3] = goals[0]                                               # duplicate goal
     targets = np.full(12, m.vertex_at(0.9, 0.9), np.uint32)
     goals[5] = targets[5]                                             # seed == target inside a batch
-    b = ctx.plan_dijkstra_batch(goals, targets, want_fields=True)
+    for engine in ("tiled", "persistent"):
+        ctx.set_dijkstra_engine(engine)
+        b = ctx.plan_dijkstra_batch(goals, targets, want_fields=True)
+        check_batch(case, b, goals, targets)
+    ctx.set_dijkstra_engine("auto")
+
+
+def check_batch(case, b, goals, targets):
     for k in range(12):
         ref = case.om.dijkstra(case.weights, case.costs, int(goals[k]), int(targets[k]))
         assert b["codes"][k] == ref.code
