@@ -121,6 +121,12 @@ uint32_t mnav_plan_dijkstra_batch(mnav_ctx* ctx, uint32_t n, const uint32_t* see
                                   uint32_t* pred_out, uint32_t* path_out, uint32_t path_cap,
                                   uint32_t* path_len);
 
+/* n independent CVP plans on the same mesh in one sweep.  seed_pos n*3, seed_faces / target_faces n,
+ * codes_out n; dist_out / pred_out n*V, vecmap_out n*V*3 or NULL. */
+uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const uint32_t* seed_faces,
+                             const uint32_t* target_faces, double goal_dist_offset, double cost_limit,
+                             uint32_t* codes_out, float* dist_out, uint32_t* pred_out, float* vecmap_out);
+
 /* Replaces MeshPlanner::cancel(), mesh_planner.h:80 (dijkstra_mesh_planner.cpp:136-140):
  * async-signal/thread safe, only sets a flag that the running plan polls between step
  * batches; the plan then returns MNAV_CANCELED.  The flag is cleared when a plan starts

@@ -19,7 +19,7 @@ SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 
 # every symbol include/mnav.h declares
 SYMBOLS = [
     "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_upload_mesh", "mnav_upload_costs",
-    "mnav_compute_edge_weights", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch",
+    "mnav_compute_edge_weights", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes",
 ]
@@ -67,6 +67,8 @@ def load(path: str | None = None):
     L.mnav_plan_cvp.argtypes = [vp, vp, u32, u32, f64, f64, vp, vp, vp, vp, vp]
     L.mnav_plan_dijkstra_batch.restype = u32
     L.mnav_plan_dijkstra_batch.argtypes = [vp, u32, vp, vp, f64, f64, vp, vp, vp, vp, u32, vp]
+    L.mnav_plan_cvp_batch.restype = u32
+    L.mnav_plan_cvp_batch.argtypes = [vp, u32, vp, vp, vp, f64, f64, vp, vp, vp, vp]
     L.mnav_cancel.argtypes = [vp]
     L.mnav_get_stats.restype = C.c_int
     L.mnav_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -223,6 +225,21 @@ class MnavContext:
         return dict(rc=rc, codes=codes, dist=dist, pred=pred,
                     paths=[paths[i, : min(int(lens[i]), cap)].copy() for i in range(n)], path_len=lens,
                     stats=self.stats())
+
+    def plan_cvp_batch(self, seed_pos, seed_faces, target_faces, goal_dist_offset: float = 0.3, cost_limit: float = 1.0,
+                       want_fields: bool = False, want_vecmap: bool = False):
+        sp = _f32(seed_pos).reshape(-1, 3)
+        sf, tf = _u32(seed_faces), _u32(target_faces)
+        n, V = sf.shape[0], self.V
+        codes = np.empty(n, np.uint32)
+        dist = np.empty((n, V), np.float32) if want_fields else None
+        pred = np.empty((n, V), np.uint32) if want_fields else None
+        vm = np.empty((n, V, 3), np.float32) if want_vecmap else None
+        rc = self._L.mnav_plan_cvp_batch(self._h, n, _p(sp), _p(sf), _p(tf), float(goal_dist_offset), float(cost_limit),
+                                         _p(codes), _p(dist), _p(pred), _p(vm))
+        if rc == INTERNAL_ERROR:
+            raise RuntimeError(f"mnav_plan_cvp_batch internal error: {self._err()}")
+        return dict(rc=rc, codes=codes, dist=dist, pred=pred, vecmap=vm, stats=self.stats())
 
     def plan_cvp(self, seed_pos, seed_face: int, target_face: int, goal_dist_offset: float = 0.3,
                  cost_limit: float = 1.0, want_fields: bool = True, want_vecmap: bool = True) -> CvpOut:

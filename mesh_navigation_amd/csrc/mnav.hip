@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(kBlock) void k_vecmap_cvp(const Plan* __restrict__ 
     const uint32_t p = P.pred[v];
     float x = 0.f, y = 0.f, z = 0.f;
     if (is_seed(P, v)) {                                        // cvp :722-724 (un-normalised diff)
-      x = seed_pos[0] - xyz[3 * (size_t)v]; y = seed_pos[1] - xyz[3 * (size_t)v + 1]; z = seed_pos[2] - xyz[3 * (size_t)v + 2];
+      const float* sp = seed_pos + 3 * (size_t)blockIdx.y;
+      x = sp[0] - xyz[3 * (size_t)v]; y = sp[1] - xyz[3 * (size_t)v + 1]; z = sp[2] - xyz[3 * (size_t)v + 2];
     } else if (p != v && P.cutf[v] != kNone) {                  // :218, :222-225
       const float dx = xyz[3 * (size_t)p] - xyz[3 * (size_t)v];
       const float dy = xyz[3 * (size_t)p + 1] - xyz[3 * (size_t)v + 1];
@@ -1137,8 +1138,9 @@ struct mnav_ctx {
   std::atomic<int> cancel{ 0 };
   // host copies needed for seeding
   uint32_t V = 0, F = 0, E = 0;
-  std::vector<float> h_xyz;
+  std::vector<float> h_xyz, h_cost;
   std::vector<uint32_t> h_faces;
+  std::vector<uint8_t> h_invalid;
   bool have_mesh = false, have_costs = false, have_normals = false;
   // device mesh
   uint32_t *d_row_ptr = nullptr, *d_nbr_u = nullptr, *d_nbr_e = nullptr, *d_crn_ptr = nullptr, *d_edge_vtx = nullptr;
@@ -1155,7 +1157,7 @@ struct mnav_ctx {
   float** d_vecptrs = nullptr;
   uint32_t* d_paths = nullptr; uint32_t paths_cap = 0;
   Ctl* h_ctl = nullptr;       // pinned, 2 per plan
-  float* d_seed_pos = nullptr;
+  float* d_seed_pos = nullptr; uint32_t seed_pos_cap = 1;
   std::map<uint64_t, hipGraphExec_t> graphs;
   // tiled SSSP engine
   int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 2 persistent per-plan, 3 auto
@@ -1872,6 +1874,8 @@ int mnav_upload_costs(mnav_ctx* ctx, const float* vertex_costs, const float* edg
   if (!invalid) { zero.assign(ctx->V ? ctx->V : 1, 0); invalid = zero.data(); }
   if (dev_upload(ctx, &ctx->d_invalid, invalid, ctx->V)) return -1;
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->h_cost.assign(vertex_costs, vertex_costs + ctx->V);
+  ctx->h_invalid.assign(invalid, invalid + ctx->V);
   auto_delta(ctx, edge_weights, ctx->E);
   ctx->nbr_valid = ctx->crn_valid = false;
   ctx->have_costs = true;
@@ -1900,6 +1904,8 @@ int mnav_compute_edge_weights(mnav_ctx* ctx, const float* vertex_costs, const fl
   HIPCHK(hipMemcpyAsync(w.data(), ctx->d_w, sizeof(float) * ctx->E, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (edge_weights_out) memcpy(edge_weights_out, w.data(), sizeof(float) * ctx->E);
+  ctx->h_cost.assign(vertex_costs, vertex_costs + ctx->V);
+  ctx->h_invalid.assign(invalid, invalid + ctx->V);
   auto_delta(ctx, w.data(), ctx->E);
   ctx->nbr_valid = ctx->crn_valid = false;
   ctx->have_costs = true;
@@ -2030,71 +2036,111 @@ uint32_t mnav_plan_dijkstra_batch(mnav_ctx* ctx, uint32_t n, const uint32_t* see
                        path_len, nullptr, false);
 }
 
-uint32_t mnav_plan_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_face, uint32_t target_face, double goal_dist_offset,
-                       double cost_limit, float* dist_out, uint32_t* pred_out, float* direction_out, uint32_t* cutface_out,
-                       float* vecmap_out)
+static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const uint32_t* seed_faces, const uint32_t* target_faces,
+                         double goal_dist_offset, double cost_limit, uint32_t* codes_out, float* dist_out, uint32_t* pred_out,
+                         float* direction_out, uint32_t* cutface_out, float* vecmap_out)
 {
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
   ctx->cancel.store(0);                                               // cvp :679
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
   const uint32_t V = ctx->V;
-  if (seed_face >= ctx->F || !seed_pos) return MNAV_INVALID_START;   // cvp :681-685
-  if (target_face >= ctx->F) return MNAV_INVALID_GOAL;                // cvp :686-690
   if (!ctx->have_normals) { ctx->err = "vertex normals were not uploaded"; return MNAV_INTERNAL_ERROR; }
   if (V > (1u << kKeyIdBits)) { ctx->err = "CVP pop keys hold 26-bit vertex ids: mesh too large"; return MNAV_INTERNAL_ERROR; }
+  std::vector<uint32_t> codes(n, MNAV_SUCCESS), map;
+  std::vector<PlanIn> in;
+  std::vector<float> sp;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (seed_faces[i] >= ctx->F) { codes[i] = MNAV_INVALID_START; continue; }      // cvp :681-685
+    if (target_faces[i] >= ctx->F) { codes[i] = MNAV_INVALID_GOAL; continue; }     // cvp :686-690
+    PlanIn p{};
+    for (int k = 0; k < 3; ++k) {
+      p.seed[k] = ctx->h_faces[3 * (size_t)seed_faces[i] + k];
+      p.target[k] = ctx->h_faces[3 * (size_t)target_faces[i] + k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      // cvp :721-723  diff = start - vertex; dist = diff.length()  (float arithmetic)
+      const float dx = seed_pos[3 * (size_t)i] - ctx->h_xyz[3 * (size_t)p.seed[k]];
+      const float dy = seed_pos[3 * (size_t)i + 1] - ctx->h_xyz[3 * (size_t)p.seed[k] + 1];
+      const float dz = seed_pos[3 * (size_t)i + 2] - ctx->h_xyz[3 * (size_t)p.seed[k] + 2];
+      const float l2 = dx * dx + dy * dy + dz * dz;
+      p.seed_d[k] = sqrtf(l2);
+      p.seed_expands[k] = (!((double)ctx->h_cost[p.seed[k]] >= cost_limit) && !ctx->h_invalid[p.seed[k]]) ? 1u : 0u;       // cvp :757,760
+      p.target_expands[k] = (!((double)ctx->h_cost[p.target[k]] >= cost_limit) && !ctx->h_invalid[p.target[k]]) ? 1u : 0u;
+    }
+    p.seed_face = seed_faces[i];
+    in.push_back(p); map.push_back(i);
+    sp.insert(sp.end(), seed_pos + 3 * (size_t)i, seed_pos + 3 * (size_t)i + 3);
+  }
+  const uint32_t m = (uint32_t)in.size();
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
-  if (materialize(ctx, true, cost_limit)) return MNAV_INTERNAL_ERROR;
-  // the cut-off flags of the seed / robot-face vertices need cost + invalid on the host: fetch 6 values
-  PlanIn p{};
-  float costs[6]; uint8_t inv[6];
-  for (int k = 0; k < 3; ++k) {
-    p.seed[k] = ctx->h_faces[3 * (size_t)seed_face + k];
-    p.target[k] = ctx->h_faces[3 * (size_t)target_face + k];
+  ctx->last_planner = kPlannerCvp; ctx->last_n = m;
+  uint32_t worst = MNAV_SUCCESS;
+  if (m) {
+    if (materialize(ctx, true, cost_limit)) return MNAV_INTERNAL_ERROR;
+    if (ctx->seed_pos_cap < m) {
+      (void)hipFree(ctx->d_seed_pos); ctx->d_seed_pos = nullptr;
+      if (hipMalloc((void**)&ctx->d_seed_pos, 12 * (size_t)m) != hipSuccess) { ctx->err = "alloc failed"; return MNAV_INTERNAL_ERROR; }
+      ctx->seed_pos_cap = m;
+    }
+    if (hipMemcpyAsync(ctx->d_seed_pos, sp.data(), 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      { ctx->err = "seed upload failed"; return MNAV_INTERNAL_ERROR; }
+    const int rc = run_plans<kPlannerCvp>(ctx, m, in, goal_dist_offset, false);
+    if (rc < 0) return MNAV_INTERNAL_ERROR;
+    if (rc == 1) { if (codes_out) for (uint32_t i = 0; i < n; ++i) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // cvp :888-892
+    hipLaunchKernelGGL(k_finish<kPlannerCvp>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, (uint32_t*)nullptr, 0u);
+    const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
+    hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
+    (void)hipEventRecord(ctx->ev[4], ctx->stream);
+    hipLaunchKernelGGL(k_vecmap_cvp, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_xyz, ctx->d_nrm,
+                       ctx->d_vecptrs, ctx->d_seed_pos);                // cvp :897
+    (void)hipEventRecord(ctx->ev[5], ctx->stream);
+    bool ok = hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    for (uint32_t k = 0; k < m && ok; ++k) {
+      const uint32_t i = map[k];
+      Slot& s = ctx->slots[k];
+      if (ok && dist_out) ok = hipMemcpyAsync(dist_out + (size_t)i * V, s.dist, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+      if (ok && pred_out) ok = hipMemcpyAsync(pred_out + (size_t)i * V, s.pred, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+      if (ok && direction_out) ok = hipMemcpyAsync(direction_out + (size_t)i * V, s.dirn, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+      if (ok && cutface_out) ok = hipMemcpyAsync(cutface_out + (size_t)i * V, s.cutf, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+      if (ok && vecmap_out) ok = hipMemcpyAsync(vecmap_out + (size_t)i * 3 * V, s.vecmap, 12 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    }
+    (void)hipEventRecord(ctx->ev[6], ctx->stream);
+    if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "output download failed"; return MNAV_INTERNAL_ERROR; }
+    finish_stats(ctx, m, true);
+    for (uint32_t k = 0; k < m; ++k) {
+      codes[map[k]] = ctx->h_res[k].code;
+      if (ctx->h_res[k].code == MNAV_INTERNAL_ERROR) { ctx->err = "CVP wavefront did not converge (step cap)"; }
+    }
   }
-  for (int k = 0; k < 3; ++k) {
-    if (hipMemcpyAsync(&costs[k], ctx->d_cost + p.seed[k], 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(&costs[3 + k], ctx->d_cost + p.target[k], 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(&inv[k], ctx->d_invalid + p.seed[k], 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(&inv[3 + k], ctx->d_invalid + p.target[k], 1, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-      { ctx->err = "cost fetch failed"; return MNAV_INTERNAL_ERROR; }
+  for (uint32_t i = 0; i < n; ++i) {
+    if (codes_out) codes_out[i] = codes[i];
+    if (codes[i] != MNAV_SUCCESS && worst == MNAV_SUCCESS) worst = codes[i];
   }
-  if (hipMemcpyAsync(ctx->d_seed_pos, seed_pos, 12, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-      hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "seed upload failed"; return MNAV_INTERNAL_ERROR; }
-  for (int k = 0; k < 3; ++k) {
-    // cvp :721-723  diff = start - vertex; dist = diff.length()  (float arithmetic)
-    const float dx = seed_pos[0] - ctx->h_xyz[3 * (size_t)p.seed[k]];
-    const float dy = seed_pos[1] - ctx->h_xyz[3 * (size_t)p.seed[k] + 1];
-    const float dz = seed_pos[2] - ctx->h_xyz[3 * (size_t)p.seed[k] + 2];
-    const float l2 = dx * dx + dy * dy + dz * dz;
-    p.seed_d[k] = sqrtf(l2);
-    p.seed_expands[k] = (!((double)costs[k] >= cost_limit) && !inv[k]) ? 1u : 0u;           // cvp :757,760
-    p.target_expands[k] = (!((double)costs[3 + k] >= cost_limit) && !inv[3 + k]) ? 1u : 0u;
-  }
-  p.seed_face = seed_face;
-  std::vector<PlanIn> in{ p };
-  ctx->last_planner = kPlannerCvp; ctx->last_n = 1;
-  const int rc = run_plans<kPlannerCvp>(ctx, 1, in, goal_dist_offset, false);
-  if (rc < 0) return MNAV_INTERNAL_ERROR;
-  if (rc == 1) return MNAV_CANCELED;                                  // cvp :888-892
-  hipLaunchKernelGGL(k_finish<kPlannerCvp>, dim3(1), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, (uint32_t*)nullptr, 0u);
-  const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
-  hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
-  (void)hipEventRecord(ctx->ev[4], ctx->stream);
-  hipLaunchKernelGGL(k_vecmap_cvp, dim3(gc ? gc : 1, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_xyz, ctx->d_nrm,
-                     ctx->d_vecptrs, ctx->d_seed_pos);                // cvp :897
-  (void)hipEventRecord(ctx->ev[5], ctx->stream);
-  Slot& s = ctx->slots[0];
-  bool ok = hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-  if (ok && dist_out) ok = hipMemcpyAsync(dist_out, s.dist, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-  if (ok && pred_out) ok = hipMemcpyAsync(pred_out, s.pred, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-  if (ok && direction_out) ok = hipMemcpyAsync(direction_out, s.dirn, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-  if (ok && cutface_out) ok = hipMemcpyAsync(cutface_out, s.cutf, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-  if (ok && vecmap_out) ok = hipMemcpyAsync(vecmap_out, s.vecmap, 12 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
-  (void)hipEventRecord(ctx->ev[6], ctx->stream);
-  if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "output download failed"; return MNAV_INTERNAL_ERROR; }
-  finish_stats(ctx, 1, true);
-  return ctx->h_res[0].code;
+  return worst;
+}
+
+uint32_t mnav_plan_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_face, uint32_t target_face, double goal_dist_offset,
+                       double cost_limit, float* dist_out, uint32_t* pred_out, float* direction_out, uint32_t* cutface_out,
+                       float* vecmap_out)
+{
+  if (!ctx) return MNAV_INTERNAL_ERROR;
+  if (!seed_pos) return MNAV_INVALID_START;
+  uint32_t code = MNAV_INTERNAL_ERROR;
+  const uint32_t rc = cvp_impl(ctx, 1, seed_pos, &seed_face, &target_face, goal_dist_offset, cost_limit, &code, dist_out, pred_out,
+                               direction_out, cutface_out, vecmap_out);
+  return (rc == MNAV_INTERNAL_ERROR || rc == MNAV_CANCELED) ? rc : code;
+}
+
+uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const uint32_t* seed_faces, const uint32_t* target_faces,
+                             double goal_dist_offset, double cost_limit, uint32_t* codes_out, float* dist_out, uint32_t* pred_out,
+                             float* vecmap_out)
+{
+  if (!ctx) return MNAV_INTERNAL_ERROR;
+  if (n == 0) return MNAV_SUCCESS;
+  if (!seed_pos || !seed_faces || !target_faces) { ctx->err = "null seeds/targets"; return MNAV_INTERNAL_ERROR; }
+  return cvp_impl(ctx, n, seed_pos, seed_faces, target_faces, goal_dist_offset, cost_limit, codes_out, dist_out, pred_out, nullptr, nullptr,
+                  vecmap_out);
 }
 
 void mnav_cancel(mnav_ctx* ctx) { if (ctx) ctx->cancel.store(1, std::memory_order_relaxed); }

@@ -275,3 +275,29 @@ def test_stats_and_algorithmic_bytes(c1):
     st = out.stats
     assert st["settled"] == m.V and st["n_plans"] == 1 and st["steps"] > 0 and st["ms_propagation"] > 0
     assert st["algorithmic_bytes"] == 24 * m.V + 24 * m.E
+
+
+def test_cvp_batch_equals_single_plans(c1):
+    case, ctx = c1
+    m = case.mesh
+    rng = np.random.default_rng(9)
+    verts = rng.choice(m.V, size=5, replace=False)
+    off = np.array([0.02, 0.015, 0.0], np.float32)
+    sps = np.stack([m.xyz[v] + off for v in verts]).astype(np.float32)
+    tp = m.xyz[m.vertex_at(0.9, 0.9)] + off
+    sfs = np.array([case.om.containing_face(p)[0] for p in sps], np.uint32)
+    tf, _ = case.om.containing_face(tp)
+    tfs = np.full(5, tf, np.uint32)
+    tfs[2] = m.F + 7                                                    # one invalid goal face inside the batch
+    b = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True, want_vecmap=True)
+    assert b["codes"][2] == capi.INVALID_GOAL
+    for k in (0, 1, 3, 4):
+        ref = case.om.cvp(case.weights, case.costs, case.vn, sps[k], int(sfs[k]), int(tfs[k]))
+        assert b["codes"][k] == ref.code
+        fin = np.isfinite(ref.dist)
+        assert np.array_equal(np.isfinite(b["dist"][k]), fin)
+        rel = np.abs(b["dist"][k][fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
+        assert rel.max() <= CVP_RTOL
+        single = ctx.plan_cvp(sps[k], int(sfs[k]), int(tfs[k]))
+        assert np.array_equal(single.dist.view(np.uint32), b["dist"][k].view(np.uint32))
+        assert np.array_equal(single.vecmap.view(np.uint32), b["vecmap"][k].view(np.uint32))
