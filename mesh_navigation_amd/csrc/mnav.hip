@@ -72,10 +72,12 @@ struct StepCtx {
 
 // dedup'd, wave-aggregated append of v to the next work list (all lanes of the wave that reach
 // this point take part; `want` selects the lanes that actually push)
+template <bool DIRTY>
 __device__ __forceinline__ void push_agg(StepCtx& S, bool want, uint32_t v)
 {
   bool ok = false;
   if (want) {
+    if (DIRTY) S.P->dirty[v] = S.sv;                       // "a neighbour moved": re-evaluate next step
     if (S.P->stamp[v] != S.sv) ok = atomicExch(&S.P->stamp[v], S.sv) != S.sv;
   }
   const unsigned long long m = __ballot(ok);
@@ -208,8 +210,8 @@ __device__ __forceinline__ void group_push_neighbours(StepCtx& S, const Plan& P,
       const uint32_t i = beg + sub + r * kGroup;
       uint32_t a = kNone, b = kNone;
       if (want && i < end) { const Corner k = P.crn[i]; if (k.v1 != kNone) { a = k.v1; b = k.v2; } }
-      push_agg(S, a != kNone, a);
-      push_agg(S, b != kNone, b);
+      push_agg<true>(S, a != kNone, a);
+      push_agg<true>(S, b != kNone, b);
     }
   } else {
     const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
@@ -221,7 +223,7 @@ __device__ __forceinline__ void group_push_neighbours(StepCtx& S, const Plan& P,
       const uint32_t i = beg + sub + r * kGroup;
       const bool w = want && i < end;
       const uint32_t u = w ? P.nbr[i].u : kNone;
-      push_agg(S, w, u);
+      push_agg<true>(S, w, u);
     }
   }
 }
@@ -242,7 +244,10 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
     bool go;
     if (REPAIR) go = (old_d < inf_f());
     else go = !(old_t < c.thr_fixed) && !(cvp && P.blocked[v]);
-    if (go) {
+    // parked out of band and no neighbour moved since the last evaluation: keep waiting, as is
+    const bool parked = !REPAIR && go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && P.dirty[v] != (uint32_t)c.it;
+    if (parked) { retain = true; t_new = old_t; }
+    else if (go) {
       if (!REPAIR || old_d > c.goal_dist) {
         if (sub == 0) ++S.levals;
         const Eval e = group_eval<PLANNER>(P, c, v, sub);
@@ -266,7 +271,7 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
   }
   if (push_nb && sub == 0) S.lchanged = true;
   group_push_neighbours<PLANNER>(S, P, v, sub, push_nb);
-  push_agg(S, retain && sub == 0, v);
+  push_agg<false>(S, retain && sub == 0, v);
   if (retain && sub == 0) S.lmin = fminf(S.lmin, t_new);
 }
 
@@ -887,6 +892,7 @@ __global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
     P.dist[v] = inf_f();
     P.pred[v] = v;
     P.stamp[v] = 0u;
+    P.dirty[v] = 0u;
     if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; }
   }
 }
@@ -1117,7 +1123,7 @@ __global__ __launch_bounds__(kBlock) void k_build_crn(uint32_t V, const uint32_t
 struct Slot {
   float *dist = nullptr, *dirn = nullptr, *vecmap = nullptr;
   PopKey* tkey = nullptr;
-  uint32_t *pred = nullptr, *cutf = nullptr, *stamp = nullptr, *list0 = nullptr, *list1 = nullptr;
+  uint32_t *pred = nullptr, *cutf = nullptr, *stamp = nullptr, *dirty = nullptr, *list0 = nullptr, *list1 = nullptr;
   Ctl* ctl = nullptr;
   Cnt* cnt = nullptr;
   bool cvp_ready = false;
@@ -1214,7 +1220,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b);
 void free_slot(Slot& s)
 {
   (void)hipFree(s.dist); (void)hipFree(s.tkey); (void)hipFree(s.dirn); (void)hipFree(s.vecmap);
-  (void)hipFree(s.pred); (void)hipFree(s.cutf); (void)hipFree(s.stamp); (void)hipFree(s.list0); (void)hipFree(s.list1);
+  (void)hipFree(s.pred); (void)hipFree(s.cutf); (void)hipFree(s.stamp); (void)hipFree(s.dirty); (void)hipFree(s.list0); (void)hipFree(s.list1);
   (void)hipFree(s.cnt);
   (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tcnt);
   s = Slot{};
@@ -1232,7 +1238,7 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
   while (ctx->slots.size() < n) {
     Slot s;
     HIPCHK(hipMalloc((void**)&s.dist, 4 * V)); HIPCHK(hipMalloc((void**)&s.pred, 4 * V));
-    HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.list0, 4 * V));
+    HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.dirty, 4 * V)); HIPCHK(hipMalloc((void**)&s.list0, 4 * V));
     HIPCHK(hipMalloc((void**)&s.list1, 4 * V)); HIPCHK(hipMalloc((void**)&s.vecmap, 12 * V));
     HIPCHK(hipMalloc((void**)&s.cnt, 3 * sizeof(Cnt)));
     ctx->slots.push_back(s);
@@ -1370,7 +1376,7 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     memset(&P, 0, sizeof(P));
     P.planner = PLANNER; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = cvp ? s.tkey : nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.dist = s.dist; P.tkey = cvp ? s.tkey : nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = delta; P.offset = offset; P.max_steps = ctx->max_steps;
     for (int k = 0; k < 3; ++k) {
@@ -1514,7 +1520,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     memset(&P, 0, sizeof(P));
     P.planner = kPlannerDijkstra; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u;
     for (int k = 0; k < 3; ++k) {
@@ -1611,7 +1617,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
     memset(&P, 0, sizeof(P));
     P.planner = kPlannerDijkstra; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp;
+    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
     for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }

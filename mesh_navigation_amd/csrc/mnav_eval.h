@@ -185,6 +185,7 @@ struct Plan {
   float* dirn;             // V  (CVP)
   uint32_t* cutf;          // V  (CVP)
   uint32_t* stamp;         // V  work-list dedup
+  uint32_t* dirty;         // V  step for which a neighbour asked for a re-evaluation
   uint32_t* list[2];       // work lists, capacity `cap`
   uint32_t cap;
   Ctl* ctl;                // [2]
@@ -387,7 +388,8 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 }
 
 // ---------------------------------------------------------------------------------------
-// One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list),
+// One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list), push_dirty(u)
+// (the same, and marks u as "a neighbour moved" for the next step),
 // note_changed(), note_min(float), note_eval().
 // ---------------------------------------------------------------------------------------
 // R = state the rule reads, W = state it writes.  The kernels use R == W (in-place, racy but
@@ -403,6 +405,11 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
   const float old_t = cvp ? key_time(old_key) : P.dist[v];
   if (old_t < c.thr_fixed) return;                               // settled by an earlier band
   if (cvp && P.blocked[v]) return;                               // never updated (cvp :802,825,848)
+  // parked out of band, and no neighbour moved since it was evaluated: keep waiting, as is
+  if (!c.band_new && !(old_t < c.thr) && old_t < inf_f() && P.dirty[v] != (uint32_t)c.it) {
+    ops.push(v); ops.note_min(old_t);
+    return;
+  }
   ops.note_eval();
   Eval e;
   if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
@@ -423,10 +430,10 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
       for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) {
         const Corner k = P.crn[i];
         if (k.v1 == kNone) continue;
-        ops.push(k.v1); ops.push(k.v2);
+        ops.push_dirty(k.v1); ops.push_dirty(k.v2);
       }
     } else {
-      for (uint32_t i = P.row_ptr[v]; i < P.row_ptr[v + 1]; ++i) ops.push(P.nbr[i].u);
+      for (uint32_t i = P.row_ptr[v]; i < P.row_ptr[v + 1]; ++i) ops.push_dirty(P.nbr[i].u);
     }
   }
   if (!now_in && e.t < inf_f()) {

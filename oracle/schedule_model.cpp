@@ -27,6 +27,7 @@ struct HostOps {
     const uint32_t i = cnt->n_next++;
     if (i < P->cap) next[i] = v;
   }
+  void push_dirty(uint32_t v) { P->dirty[v] = stamp_val; push(v); }
   void note_changed() { cnt->changed++; }
   void note_min(float t) { const uint32_t b = f2u(t); if (b < cnt->minkey) cnt->minkey = b; }
   void note_eval() { cnt->evals++; }
@@ -51,7 +52,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
 
   std::vector<PopKey> tkey(V, key_inf());
-  std::vector<uint32_t> stamp(V, 0), l0(V), l1(V);
+  std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V);
   Ctl ctl[2]; Cnt cnt[3];
   std::memset(ctl, 0, sizeof(ctl)); std::memset(cnt, 0, sizeof(cnt));
 
@@ -60,7 +61,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   P.row_ptr = topo.row_ptr.data(); P.nbr = nbr.data();
   P.crn_ptr = topo.crn_ptr.data(); P.crn = crn.data(); P.blocked = blocked.data();
   P.dist = dist; P.tkey = tkey.data();
-  P.pred = pred; P.dirn = dirn; P.cutf = cutf; P.stamp = stamp.data();
+  P.pred = pred; P.dirn = dirn; P.cutf = cutf; P.stamp = stamp.data(); P.dirty = dirty.data();
   P.list[0] = l0.data(); P.list[1] = l1.data(); P.cap = V;
   P.ctl = ctl; P.cnt = cnt;
   P.delta = delta; P.offset = offset; P.max_steps = max_steps ? max_steps : 100000000u;
