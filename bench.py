@@ -116,6 +116,16 @@ def main() -> None:
         # launch duration, measured live with HIP events that the library records on ITS OWN stream
         # around the launch(es): batches of >= 128 plans run as ONE launch of k_plan_persistent (one
         # workgroup per plan); smaller batches as hipGraph replays of 24 k_tile_round launches.
+        # HBM traffic per launch from the PMC passes committed under profiles/ (tools/prof_pmc.sh, same
+        # command and workload; FETCH_SIZE doubled for the 16-byte staging reads as the microarch guide
+        # prescribes, WRITE_SIZE as is) -- only quoted when it was measured on this very workload.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm.get("kernel") == "k_plan_persistent" and launches <= args.steps and B == 1024 and N == 1000:
+                traffic = pm["traffic_bytes_per_launch_high"]
+        except (OSError, ValueError, KeyError):
+            pass
         per_launch_bytes = algo / max(launches, 1)
         per_launch_s = kern_ms * 1e-3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
@@ -139,7 +149,7 @@ def main() -> None:
             "ms_per_makeplan_single": single_ms,
             "ms_per_plan_in_batch": ms_step / B,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_plan_persistent" if launches <= args.steps else "k_tile_round", "launches_per_step": launches / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
                          "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,
