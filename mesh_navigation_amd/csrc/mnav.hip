@@ -515,14 +515,13 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
       MNAV_GLOBAL const u32x4* src = (MNAV_GLOBAL const u32x4*)(P.cw + e0);      // e0, ne multiples of 4 entries
       u32x4* dst = reinterpret_cast<u32x4*>(lcw);
       const uint32_t n16 = ne / 2;
-      uint32_t base = tid;
-      for (; base + 7 * kTileBlock < n16; base += 8 * kTileBlock) {              // 8 x 16 B in flight per thread
-        const u32x4 a0 = src[base], a1 = src[base + kTileBlock], a2 = src[base + 2 * kTileBlock], a3 = src[base + 3 * kTileBlock];
-        const u32x4 a4 = src[base + 4 * kTileBlock], a5 = src[base + 5 * kTileBlock], a6 = src[base + 6 * kTileBlock], a7 = src[base + 7 * kTileBlock];
-        dst[base] = a0; dst[base + kTileBlock] = a1; dst[base + 2 * kTileBlock] = a2; dst[base + 3 * kTileBlock] = a3;
-        dst[base + 4 * kTileBlock] = a4; dst[base + 5 * kTileBlock] = a5; dst[base + 6 * kTileBlock] = a6; dst[base + 7 * kTileBlock] = a7;
+      for (uint32_t base = tid; base < n16; base += 8 * kTileBlock) {   // 8 x 16 B in flight per thread
+        u32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; a[u] = src[i < n16 ? i : base]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; if (i < n16) dst[i] = a[u]; }
       }
-      for (; base < n16; base += kTileBlock) dst[base] = src[base];
       MNAV_GLOBAL const u32x4* rs = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);   // r0 multiple of 8 entries
       u32x4* rd = reinterpret_cast<u32x4*>(lrow);
       const uint32_t nr16 = (nl + 1 + 7) / 8;
@@ -630,12 +629,15 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
 // talk to each other, so there is no inter-workgroup protocol at all; hundreds of plans run
 // concurrently (2 workgroups per CU).  Same tile solve as k_tile_round (LDS queue sweeps, ds_min
 // on float bits); state that the workgroup re-reads after writing it (dist, wake-ups, tlast) is
-// accessed with agent-scope relaxed atomics, i.e. served by the L2 and never by a stale L1 line.
+// read with L1-bypassing (non-temporal) loads, i.e. served by the L2 and never by a stale L1 line.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ldg_u32(MNAV_GLOBAL const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ldg_f32(MNAV_GLOBAL const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stg_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void stg_f32(MNAV_GLOBAL float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Non-temporal loads bypass the per-CU L1 (served by the L2) like agent-scope atomic loads do, but
+// unlike those they are ordinary loads: many stay in flight, one wait at the first use.  Stores are
+// write-through to the L2 anyway; everything this workgroup re-reads is read through these.
+__device__ __forceinline__ uint32_t ldg_u32(MNAV_GLOBAL const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ldg_f32(MNAV_GLOBAL const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stg_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { *p = v; }
+__device__ __forceinline__ void stg_f32(MNAV_GLOBAL float* p, float v) { *p = v; }
 
 __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* __restrict__ plans)
 {
@@ -669,12 +671,25 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
 
   uint32_t acts = 0, sweeps_total = 0;
   uint32_t status = 0;   // 0 converged, 2 activation cap hit
+#ifdef MNAV_TILE_TIMING
+  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define PT_STAMP(k) do { if (tid == 0 && blockIdx.x == 0) tt[k] = clock64(); } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
   for (;;) {
+    PT_STAMP(0);
     // best-first: the tile with the smallest wake-up value
     unsigned long long best = ~0ull;
-    for (uint32_t t = tid; t < P.ntiles; t += kTileBlock) {
-      const unsigned long long k = ((unsigned long long)ldg_u32(pend + t) << 32) | t;
-      best = k < best ? k : best;
+    for (uint32_t t0 = tid; t0 < P.ntiles; t0 += 8 * kTileBlock) {        // 8 loads in flight per thread
+      uint32_t pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const uint32_t t = t0 + u * kTileBlock; pv[u] = (t < P.ntiles) ? ldg_u32(pend + t) : kInfBits; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long k = ((unsigned long long)pv[u] << 32) | (t0 + u * kTileBlock);
+        best = k < best ? k : best;
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); best = ob < best ? ob : best; }
@@ -694,6 +709,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
     if (acts >= P.max_rounds) { status = 2; break; }
     float thr = m + P.band;
     if (!(thr > m)) thr = next_up(m);
+    PT_STAMP(1);
     if (tid == 0) {
       stg_u32(pend + t, kInfBits);
       s_hdr[0] = g_vptr[t]; s_hdr[1] = g_vptr[t + 1]; s_hdr[2] = g_hptr[t]; s_hdr[3] = g_hptr[t + 1];
@@ -707,6 +723,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
     const uint32_t r0 = s_hdr[6];
     const uint32_t nl = nv + nh;
     const float tl = u2f(s_hdr[7]);
+    PT_STAMP(2);
     // stage (see k_tile_round)
     uint32_t gi[kTileVpt];
 #pragma unroll
@@ -718,14 +735,13 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
       MNAV_GLOBAL const u32x4* src = (MNAV_GLOBAL const u32x4*)(P.cw + e0);
       u32x4* dst = reinterpret_cast<u32x4*>(lcw);
       const uint32_t n16 = ne / 2;
-      uint32_t base = tid;
-      for (; base + 7 * kTileBlock < n16; base += 8 * kTileBlock) {
-        const u32x4 a0 = src[base], a1 = src[base + kTileBlock], a2 = src[base + 2 * kTileBlock], a3 = src[base + 3 * kTileBlock];
-        const u32x4 a4 = src[base + 4 * kTileBlock], a5 = src[base + 5 * kTileBlock], a6 = src[base + 6 * kTileBlock], a7 = src[base + 7 * kTileBlock];
-        dst[base] = a0; dst[base + kTileBlock] = a1; dst[base + 2 * kTileBlock] = a2; dst[base + 3 * kTileBlock] = a3;
-        dst[base + 4 * kTileBlock] = a4; dst[base + 5 * kTileBlock] = a5; dst[base + 6 * kTileBlock] = a6; dst[base + 7 * kTileBlock] = a7;
+      for (uint32_t base = tid; base < n16; base += 8 * kTileBlock) {   // 8 x 16 B in flight per thread
+        u32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; a[u] = src[i < n16 ? i : base]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; if (i < n16) dst[i] = a[u]; }
       }
-      for (; base < n16; base += kTileBlock) dst[base] = src[base];
       MNAV_GLOBAL const u32x4* rs = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);
       u32x4* rd = reinterpret_cast<u32x4*>(lrow);
       const uint32_t nr16 = (nl + 1 + 7) / 8;
@@ -752,6 +768,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
       ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
     }
     __syncthreads();
+    PT_STAMP(3);
     uint32_t sweep = 0;
     for (;;) {
       const uint32_t nq = s_nq[sweep % 3];
@@ -777,6 +794,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
       ++sweep;
       __syncthreads();
     }
+    PT_STAMP(4);
     // wake-ups for the owners of undercut halo vertices, write-back, own left-over
     uint32_t own_left = kInfBits;
     for (uint32_t i = tid; i < nh; i += kTileBlock) {
@@ -801,6 +819,13 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
     // every store / atomic of this activation must have reached the L2 before the next scan
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+#ifdef MNAV_TILE_TIMING
+    if (tid == 0 && blockIdx.x == 0) {
+      tt[5] = clock64(); tt[6] = sweep; tt[7] = nl;
+      const unsigned int k = atomicAdd(&g_tile_timing_n, 1u);
+      if (k < 4096) for (int q = 0; q < 8; ++q) g_tile_timing[k * 8 + q] = tt[q];
+    }
+#endif
   }
   if (tid == 0) {
     TCtl c; memset(&c, 0, sizeof(c));
