@@ -43,6 +43,7 @@ namespace {
 #define MNAV_GLOBAL __attribute__((address_space(1)))
 template <class T>
 __device__ __forceinline__ MNAV_GLOBAL T* as_global(T* p) { return (MNAV_GLOBAL T*)p; }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));   // one Nbr {u, w bits}
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte copy unit
 
 constexpr int kBlock = 256;   // streaming kernels (init, vector map, input preparation)
@@ -363,7 +364,8 @@ struct TilePlan {
   uint32_t V, ntiles;
   const uint32_t *vptr, *verts, *hptr, *halo_verts, *halo_tile, *eptr, *rptr;
   const uint16_t* rowptr;
-  const uint2* cw;         // per local edge {target, push weight bits}; tiles padded to 4 entries
+  const uint16_t* col;     // per local edge: local target            } split arrays: 6 B per edge in LDS;
+  const float* tw;         // per local edge: push weight (+inf on padding) } tiles padded to 8 entries
   float* dist;
   uint32_t* pend[2];       // per-tile wake-up value (float bits), ping-pong by round parity
   float* tlast;            // per-tile threshold of its last solve
@@ -377,17 +379,47 @@ struct TilePlan {
 };
 
 constexpr int kTileBlock = 256;
+#ifndef MNAV_PERSIST_WG_PER_CU
+#define MNAV_PERSIST_WG_PER_CU 6        // register budget of k_plan_persistent: 6 workgroups (24 waves) per CU -> <= 80 VGPRs
+#endif
 constexpr int kTileVpt = 8;              // owned vertices per thread: tile_size <= 2048
 constexpr int kTileTodo = 64;            // tiles one workgroup takes per round
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 __host__ __device__ inline uint32_t pad_to(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
+// LDS image of one tile (dynamic shared memory), shared by k_tile_round and k_plan_persistent
+struct TileLds {
+  float* lw;        // push weights                      4 B x ne
+  uint16_t* lcol;   // push targets (local ids)          2 B x ne
+  uint32_t* ldu;    // distances as float bits           owned, then halo
+  uint32_t* lh0;    // halo distances as loaded
+  uint32_t* mask;   // 3 rotating "already queued" bitmasks over the owned vertices
+  uint16_t* lrow;   // local row pointers
+  uint16_t *q0, *q1;
+  uint32_t mw;      // words per bitmask
+};
+__host__ __device__ inline uint32_t tile_mask_words(uint32_t max_nv) { return (max_nv + 31) / 32; }
 __host__ __device__ inline size_t tile_lds_bytes(uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
 {
   const uint32_t nl = max_nv + max_nh;
-  return 8 * (size_t)pad_to(max_ne, 2) + 4 * (size_t)pad_to(nl, 4) + 4 * (size_t)pad_to(max_nv, 4) +
-         4 * (size_t)pad_to(max_nh, 4) + 2 * (size_t)pad_to(nl + 1, 8) + 2 * 2 * (size_t)pad_to(nl, 8);
+  return 6 * (size_t)pad_to(max_ne, 8) + 4 * (size_t)pad_to(nl, 4) + 4 * (size_t)pad_to(max_nh, 4) +
+         4 * (size_t)pad_to(3 * tile_mask_words(max_nv), 4) + 2 * (size_t)pad_to(nl + 1, 8) + 2 * 2 * (size_t)pad_to(nl, 8);
+}
+__device__ __forceinline__ TileLds tile_lds_layout(char* smem, uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
+{
+  const uint32_t nl = max_nv + max_nh;
+  TileLds L;
+  L.lw = reinterpret_cast<float*>(smem);
+  L.lcol = reinterpret_cast<uint16_t*>(L.lw + pad_to(max_ne, 8));
+  L.ldu = reinterpret_cast<uint32_t*>(L.lcol + pad_to(max_ne, 8));
+  L.lh0 = L.ldu + pad_to(nl, 4);
+  L.mask = L.lh0 + pad_to(max_nh, 4);
+  L.mw = tile_mask_words(max_nv);
+  L.lrow = reinterpret_cast<uint16_t*>(L.mask + pad_to(3 * L.mw, 4));
+  L.q0 = L.lrow + pad_to(nl + 1, 8);
+  L.q1 = L.q0 + pad_to(nl, 8);
+  return L;
 }
 
 #ifdef MNAV_TILE_TIMING
@@ -397,6 +429,76 @@ __device__ unsigned int g_tile_timing_n;
 #else
 #define TT_STAMP(k) do { } while (0)
 #endif
+
+// Stage a tile's push graph (weights, targets, row pointers) into LDS: every 16-byte global load of
+// a thread is issued before the first LDS store, so one memory round trip covers the whole copy
+// for tiles of up to 4 x 256 x 4 edges (larger tiles loop).  The arrays have a 64-byte tail slack.
+__device__ __forceinline__ void stage_tile_graph(const TilePlan& P, const TileLds& L, uint32_t e0, uint32_t ne, uint32_t r0,
+                                                 uint32_t nl, int tid)
+{
+  MNAV_GLOBAL const u32x4* sw = (MNAV_GLOBAL const u32x4*)(P.tw + e0);          // e0, ne multiples of 8 entries
+  MNAV_GLOBAL const u32x4* sc = (MNAV_GLOBAL const u32x4*)(P.col + e0);
+  MNAV_GLOBAL const u32x4* sr = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);      // r0 multiple of 8 entries
+  u32x4* dw = reinterpret_cast<u32x4*>(L.lw);
+  u32x4* dc = reinterpret_cast<u32x4*>(L.lcol);
+  u32x4* dr = reinterpret_cast<u32x4*>(L.lrow);
+  const uint32_t nw16 = ne / 4, nc16 = ne / 8, nr16 = (nl + 1 + 7) / 8;
+  u32x4 aw[4], ac[2], ar;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const uint32_t i = tid + u * kTileBlock; aw[u] = sw[i < nw16 ? i : 0]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const uint32_t i = tid + u * kTileBlock; ac[u] = sc[i < nc16 ? i : 0]; }
+  ar = sr[(uint32_t)tid < nr16 ? tid : 0];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const uint32_t i = tid + u * kTileBlock; if (i < nw16) dw[i] = aw[u]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const uint32_t i = tid + u * kTileBlock; if (i < nc16) dc[i] = ac[u]; }
+  if ((uint32_t)tid < nr16) dr[tid] = ar;
+  for (uint32_t i = tid + 4 * kTileBlock; i < nw16; i += kTileBlock) dw[i] = sw[i];
+  for (uint32_t i = tid + 2 * kTileBlock; i < nc16; i += kTileBlock) dc[i] = sc[i];
+  for (uint32_t i = tid + kTileBlock; i < nr16; i += kTileBlock) dr[i] = sr[i];
+  for (uint32_t i = tid; i < 3 * L.mw; i += kTileBlock) L.mask[i] = 0u;
+}
+
+// Sweeps over the active queue of the staged tile until it runs dry: 8 lanes per active vertex push
+// along its row with ds_min on the float bits (the float add is dijkstra :331); improved owned
+// targets enter the next queue once (ds_or on a rotating bitmask).  s_nq[3] rotates like the masks:
+// [sweep % 3] is consumed, [(sweep+1) % 3] filled, [(sweep+2) % 3] cleared.  Returns the sweep count.
+__device__ __forceinline__ uint32_t tile_sweeps(const TileLds& L, uint32_t nv, float thr, float bound, uint32_t* s_nq, int tid)
+{
+  const int sub = tid & (kGroup - 1);
+  uint32_t sweep = 0;
+  for (;;) {
+    const uint32_t nq = s_nq[sweep % 3];
+    if (nq == 0) break;
+    if (tid == 0) s_nq[(sweep + 2) % 3] = 0;
+    if ((uint32_t)tid < L.mw) L.mask[((sweep + 2) % 3) * L.mw + tid] = 0u;
+    for (uint32_t i = tid + kTileBlock; i < L.mw; i += kTileBlock) L.mask[((sweep + 2) % 3) * L.mw + i] = 0u;
+    const uint16_t* qa = (sweep & 1) ? L.q1 : L.q0;
+    uint16_t* qb = (sweep & 1) ? L.q0 : L.q1;
+    uint32_t* nqb = &s_nq[(sweep + 1) % 3];
+    uint32_t* mk = L.mask + ((sweep + 1) % 3) * L.mw;
+    for (uint32_t idx = (uint32_t)tid >> 3; idx < nq; idx += kTileBlock / kGroup) {
+      const uint32_t x = qa[idx];
+      const uint32_t dib = L.ldu[x];
+      const uint32_t eb = L.lrow[x], ee = L.lrow[x + 1];          // issued together with ldu[x]
+      const float di = u2f(dib);
+      if (!(di < thr) || !(di <= bound)) continue;
+      for (uint32_t e = eb + sub; e < ee; e += kGroup) {
+        const uint32_t c = L.lcol[e];
+        const uint32_t ndb = f2u(di + L.lw[e]);
+        const uint32_t old = atomicMin(&L.ldu[c], ndb);
+        if (ndb < old && c < nv) {
+          const uint32_t bit = 1u << (c & 31);
+          if (!(atomicOr(&mk[c >> 5], bit) & bit)) qb[atomicAdd(nqb, 1u)] = (uint16_t)c;
+        }
+      }
+    }
+    ++sweep;
+    __syncthreads();
+  }
+  return sweep;
+}
 
 __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __restrict__ plans, int j)
 {
@@ -462,7 +564,10 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
     if (pb == kInfBits) continue;
     pc[t] = kInfBits;
     const float p = u2f(pb);
-    if (!(p <= bound)) continue;                                    // can never propagate any more
+    if (!(p <= bound)) {                                            // can never propagate any more; the finalize pass
+      if (!(g_tlast[t] > -inf_f())) g_tlast[t] = -3.0e38f;          // still has to visit the tile (finite mark, filters nothing)
+      continue;
+    }
     bool take = false;
     if (p < thr) {
       const uint32_t k = atomicAdd(&s_ntodo, 1u);
@@ -484,15 +589,8 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
   TT_STAMP(3);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t nlmax = P.max_nv + P.max_nh;
-  uint2* lcw = reinterpret_cast<uint2*>(smem);                                    // {target, weight bits}
-  uint32_t* ldu = reinterpret_cast<uint32_t*>(lcw + pad_to(P.max_ne, 2));         // distances (float bits)
-  uint32_t* inq = ldu + pad_to(nlmax, 4);                                         // queue stamps (owned)
-  uint32_t* lh0 = inq + pad_to(P.max_nv, 4);                                      // halo values as loaded
-  uint16_t* lrow = reinterpret_cast<uint16_t*>(lh0 + pad_to(P.max_nh, 4));
-  uint16_t* q0 = lrow + pad_to(nlmax + 1, 8);
-  uint16_t* q1 = q0 + pad_to(nlmax, 8);
-  const int sub = tid & (kGroup - 1);
+  const TileLds L = tile_lds_layout(smem, P.max_nv, P.max_nh, P.max_ne);
+  uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
 
   for (uint32_t ti = 0; ti < ntodo; ++ti) {
     const uint32_t t = s_todo[ti];
@@ -511,22 +609,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
     uint32_t hi[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
-    {
-      MNAV_GLOBAL const u32x4* src = (MNAV_GLOBAL const u32x4*)(P.cw + e0);      // e0, ne multiples of 4 entries
-      u32x4* dst = reinterpret_cast<u32x4*>(lcw);
-      const uint32_t n16 = ne / 2;
-      for (uint32_t base = tid; base < n16; base += 8 * kTileBlock) {   // 8 x 16 B in flight per thread
-        u32x4 a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; a[u] = src[i < n16 ? i : base]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; if (i < n16) dst[i] = a[u]; }
-      }
-      MNAV_GLOBAL const u32x4* rs = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);   // r0 multiple of 8 entries
-      u32x4* rd = reinterpret_cast<u32x4*>(lrow);
-      const uint32_t nr16 = (nl + 1 + 7) / 8;
-      for (uint32_t i = tid; i < nr16; i += kTileBlock) rd[i] = rs[i];
-    }
+    stage_tile_graph(P, L, e0, ne, r0, nl, tid);
     uint32_t orig[kTileVpt];
 #pragma unroll
     for (int k = 0; k < kTileVpt; ++k) {
@@ -534,7 +617,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
       orig[k] = 0u;
       if (i < nv) {
         const float d = g_dist[gi[k]];
-        orig[k] = f2u(d); ldu[i] = orig[k]; inq[i] = 0u;
+        orig[k] = f2u(d); ldu[i] = orig[k];
         if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;   // owned sources in [tlast, thr)
       }
     }
@@ -549,34 +632,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
     }
     __syncthreads();
     TT_STAMP(4);
-    // sweeps over the active queue: 8 lanes per active vertex push along its row with ds_min
-    // on the float bits; improved owned targets enter the next queue (stamp-dedup'd), lowered
-    // halo copies are turned into wake-ups for their owners after the sweeps
-    uint32_t sweep = 0;
-    for (;;) {
-      const uint32_t nq = s_nq[sweep % 3];
-      if (nq == 0) break;
-      if (tid == 0) s_nq[(sweep + 2) % 3] = 0;
-      const uint16_t* qa = (sweep & 1) ? q1 : q0;
-      uint16_t* qb = (sweep & 1) ? q0 : q1;
-      uint32_t* nqb = &s_nq[(sweep + 1) % 3];
-      const uint32_t stamp = sweep + 1;
-      for (uint32_t idx = (uint32_t)tid >> 3; idx < nq; idx += kTileBlock / kGroup) {
-        const uint32_t x = qa[idx];
-        const uint32_t dib = ldu[x];
-        const uint32_t eb = lrow[x], ee = lrow[x + 1];              // issued together with ldu[x]
-        const float di = u2f(dib);
-        if (!(di < thr) || !(di <= bound)) continue;
-        for (uint32_t e = eb + sub; e < ee; e += kGroup) {
-          const uint2 cw = lcw[e];
-          const uint32_t ndb = f2u(di + u2f(cw.y));                 // the float add of dijkstra :331
-          const uint32_t old = atomicMin(&ldu[cw.x], ndb);
-          if (ndb < old && cw.x < nv && atomicMax(&inq[cw.x], stamp) < stamp) qb[atomicAdd(nqb, 1u)] = (uint16_t)cw.x;
-        }
-      }
-      ++sweep;
-      __syncthreads();
-    }
+    const uint32_t sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
     TT_STAMP(5);
     // wake the owners of the halo vertices we undercut (value = the candidate we found for them)
     uint32_t left = kInfBits, own_left = kInfBits;
@@ -639,7 +695,8 @@ __device__ __forceinline__ float ldg_f32(MNAV_GLOBAL const float* p) { return __
 __device__ __forceinline__ void stg_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { *p = v; }
 __device__ __forceinline__ void stg_f32(MNAV_GLOBAL float* p, float v) { *p = v; }
 
-__global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* __restrict__ plans)
+template <int VPT>   // owned vertices per thread: tile_size <= VPT * 256
+__global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_persistent(const TilePlan* __restrict__ plans)
 {
   const TilePlan& P = plans[blockIdx.x];
   const int tid = threadIdx.x;
@@ -659,15 +716,8 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
   MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t nlmax = P.max_nv + P.max_nh;
-  uint2* lcw = reinterpret_cast<uint2*>(smem);
-  uint32_t* ldu = reinterpret_cast<uint32_t*>(lcw + pad_to(P.max_ne, 2));
-  uint32_t* inq = ldu + pad_to(nlmax, 4);
-  uint32_t* lh0 = inq + pad_to(P.max_nv, 4);
-  uint16_t* lrow = reinterpret_cast<uint16_t*>(lh0 + pad_to(P.max_nh, 4));
-  uint16_t* q0 = lrow + pad_to(nlmax + 1, 8);
-  uint16_t* q1 = q0 + pad_to(nlmax, 8);
-  const int sub = tid & (kGroup - 1);
+  const TileLds L = tile_lds_layout(smem, P.max_nv, P.max_nh, P.max_ne);
+  uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
 
   uint32_t acts = 0, sweeps_total = 0;
   uint32_t status = 0;   // 0 converged, 2 activation cap hit
@@ -725,36 +775,21 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
     const float tl = u2f(s_hdr[7]);
     PT_STAMP(2);
     // stage (see k_tile_round)
-    uint32_t gi[kTileVpt];
+    uint32_t gi[VPT];
 #pragma unroll
-    for (int k = 0; k < kTileVpt; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
+    for (int k = 0; k < VPT; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
     uint32_t hi[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
-    {
-      MNAV_GLOBAL const u32x4* src = (MNAV_GLOBAL const u32x4*)(P.cw + e0);
-      u32x4* dst = reinterpret_cast<u32x4*>(lcw);
-      const uint32_t n16 = ne / 2;
-      for (uint32_t base = tid; base < n16; base += 8 * kTileBlock) {   // 8 x 16 B in flight per thread
-        u32x4 a[8];
+    stage_tile_graph(P, L, e0, ne, r0, nl, tid);
+    uint32_t orig[VPT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; a[u] = src[i < n16 ? i : base]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t i = base + u * kTileBlock; if (i < n16) dst[i] = a[u]; }
-      }
-      MNAV_GLOBAL const u32x4* rs = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);
-      u32x4* rd = reinterpret_cast<u32x4*>(lrow);
-      const uint32_t nr16 = (nl + 1 + 7) / 8;
-      for (uint32_t i = tid; i < nr16; i += kTileBlock) rd[i] = rs[i];
-    }
-    uint32_t orig[kTileVpt];
-#pragma unroll
-    for (int k = 0; k < kTileVpt; ++k) {
+    for (int k = 0; k < VPT; ++k) {
       const uint32_t i = tid + k * kTileBlock;
       orig[k] = 0u;
       if (i < nv) {
         const float d = ldg_f32(g_dist + gi[k]);
-        orig[k] = f2u(d); ldu[i] = orig[k]; inq[i] = 0u;
+        orig[k] = f2u(d); ldu[i] = orig[k];
         if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;
       }
     }
@@ -769,31 +804,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
     }
     __syncthreads();
     PT_STAMP(3);
-    uint32_t sweep = 0;
-    for (;;) {
-      const uint32_t nq = s_nq[sweep % 3];
-      if (nq == 0) break;
-      if (tid == 0) s_nq[(sweep + 2) % 3] = 0;
-      const uint16_t* qa = (sweep & 1) ? q1 : q0;
-      uint16_t* qb = (sweep & 1) ? q0 : q1;
-      uint32_t* nqb = &s_nq[(sweep + 1) % 3];
-      const uint32_t stamp = sweep + 1;
-      for (uint32_t idx = (uint32_t)tid >> 3; idx < nq; idx += kTileBlock / kGroup) {
-        const uint32_t x = qa[idx];
-        const uint32_t dib = ldu[x];
-        const uint32_t eb = lrow[x], ee = lrow[x + 1];
-        const float di = u2f(dib);
-        if (!(di < thr) || !(di <= bound)) continue;
-        for (uint32_t e = eb + sub; e < ee; e += kGroup) {
-          const uint2 cw = lcw[e];
-          const uint32_t ndb = f2u(di + u2f(cw.y));                 // the float add of dijkstra :331
-          const uint32_t old = atomicMin(&ldu[cw.x], ndb);
-          if (ndb < old && cw.x < nv && atomicMax(&inq[cw.x], stamp) < stamp) qb[atomicAdd(nqb, 1u)] = (uint16_t)cw.x;
-        }
-      }
-      ++sweep;
-      __syncthreads();
-    }
+    const uint32_t sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
     PT_STAMP(4);
     // wake-ups for the owners of undercut halo vertices, write-back, own left-over
     uint32_t own_left = kInfBits;
@@ -802,7 +813,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_persistent(const TilePlan* 
       if (b < lh0[i]) atomicMin((uint32_t*)&pend[g_halo_tile[h0 + i]], b);
     }
 #pragma unroll
-    for (int k = 0; k < kTileVpt; ++k) {
+    for (int k = 0; k < VPT; ++k) {
       const uint32_t i = tid + k * kTileBlock;
       if (i < nv) {
         const uint32_t db = ldu[i];
@@ -859,47 +870,167 @@ __global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict
 
 // per-tile weights from the (cost-limit folded) gather CSR
 __global__ __launch_bounds__(kBlock) void k_tile_weights(uint32_t n, const uint32_t* __restrict__ src, const uint16_t* __restrict__ col,
-                                                         const Nbr* __restrict__ nbr, uint2* __restrict__ cw)
+                                                         const Nbr* __restrict__ nbr, float* __restrict__ tw)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) cw[i] = make_uint2((uint32_t)col[i], (src[i] == kNone) ? kInfBits : f2u(nbr[src[i]].w));
+  if (i < n) tw[i] = (src[i] == kNone) ? inf_f() : nbr[src[i]].w;       // padding never relaxes anything
+  (void)col;
 }
+
+struct PlanResult {
+  uint32_t code;
+  uint32_t path_len;
+  uint32_t steps, bands, armed, overflow;
+  float goal_dist;
+  uint32_t pad;
+  unsigned long long settled;
+  unsigned long long evals;
+};
 
 // Exact cut-off semantics + predecessors in one gather pass over all vertices (8 lanes per
 // vertex).  After the tile rounds every vertex with dist <= goal_dist holds its final value.
 // A vertex above goal_dist keeps, in the reference, the tentative value it got from expanded
 // (dist <= goal_dist) neighbours only, or +inf -- exactly eval_dijkstra with thr = +inf.
 // pred = first-popped neighbour attaining the minimum (DESIGN.md tie rule).
-__global__ __launch_bounds__(kBlock) void k_dij_finalize(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans,
-                                                         uint32_t* __restrict__ mismatch)
+constexpr int kFinVpt = 3;               // local vertices (owned + halo) per thread held in registers
+__host__ __device__ inline size_t finalize_lds_bytes(uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
 {
-  const Plan& P = plans[blockIdx.y];
-  const TilePlan& T = tplans[blockIdx.y];
-  const uint32_t target = P.target[0], seed = P.seed[0];
-  const float dt = P.dist[target];
-  Ctl c; memset(&c, 0, sizeof(c));
-  c.thr = inf_f(); c.thr_fixed = -inf_f();
-  c.armed = (dt < inf_f()) ? 1u : 0u;
-  c.goal_dist = c.armed ? (float)((double)dt + P.offset) : inf_f();  // dijkstra :296
-  const int sub = threadIdx.x & (kGroup - 1);
-  const uint32_t ngroups = gridDim.x * (kBlock / kGroup);
-  for (uint32_t v = blockIdx.x * (kBlock / kGroup) + (threadIdx.x >> 3); v < P.V; v += ngroups) {
-    if (v == seed) continue;
-    // NB: vertices the rounds never reached are evaluated too -- a wake-up above the bound is
-    // dropped by the rounds, yet its target still owes a tentative value to an expanded source.
-    const float old = P.dist[v];
-    const Eval e = group_eval_dijkstra(P, c, v, sub);
-    if (sub == 0) {
-      P.pred[v] = e.pred;
-      if (old > c.goal_dist) P.dist[v] = e.d;
-      else if (f2u(e.d) != f2u(old)) atomicAdd(mismatch, 1u);      // fixed point violated: internal error
+  return tile_lds_bytes(max_nv, max_nh, max_ne) + 4 * (size_t)pad_to(max_nv, 4) + 4 * (size_t)pad_to(max_nv + max_nh, 4) + 8 * (size_t)max_nv;
+}
+
+__global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans,
+                                                             uint32_t* __restrict__ mismatch, PlanResult* __restrict__ res,
+                                                             uint32_t tiles_per_block)
+{
+  // grid: x = plan, y = chunk of tiles.  Only tiles that were activated or woken are looked at: any
+  // vertex that owes a value to an expanded source sits in such a tile (its source pushed to it
+  // through a halo copy, which wakes the owner); everything else keeps dist = inf / pred = itself.
+  // Per tile the push graph is staged in LDS like in the solve and read backwards: every edge
+  // x -> y with an expanded source offers (d[x] + w, d[x], x) to its owned target y; pass 1 takes the
+  // smallest sum (ds_min on the float bits), pass 2 the smallest (d[x], x) among the edges that attain
+  // it (64-bit ds_min) -- the reference's predecessor under the (value, id) pop order.
+  const Plan& P = plans[blockIdx.x];
+  const TilePlan& T = tplans[blockIdx.x];
+  const int tid = threadIdx.x;
+  MNAV_GLOBAL float* g_dist = as_global(P.dist);
+  MNAV_GLOBAL uint32_t* g_pred = as_global(P.pred);
+  MNAV_GLOBAL const uint32_t* g_vptr = as_global(T.vptr);
+  MNAV_GLOBAL const uint32_t* g_hptr = as_global(T.hptr);
+  MNAV_GLOBAL const uint32_t* g_eptr = as_global(T.eptr);
+  MNAV_GLOBAL const uint32_t* g_rptr = as_global(T.rptr);
+  MNAV_GLOBAL const uint32_t* g_verts = as_global(T.verts);
+  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(T.halo_verts);
+  MNAV_GLOBAL const float* g_tlast = as_global((const float*)T.tlast);
+  MNAV_GLOBAL const uint32_t* g_p0 = as_global((const uint32_t*)T.pend[0]);
+  MNAV_GLOBAL const uint32_t* g_p1 = as_global((const uint32_t*)T.pend[1]);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileLds L = tile_lds_layout(smem, T.max_nv, T.max_nh, T.max_ne);
+  uint32_t* const lsum = reinterpret_cast<uint32_t*>(smem + tile_lds_bytes(T.max_nv, T.max_nh, T.max_ne));
+  uint32_t* const lgid = lsum + pad_to(T.max_nv, 4);
+  unsigned long long* const lkey = reinterpret_cast<unsigned long long*>(lgid + pad_to(T.max_nv + T.max_nh, 4));
+  const uint32_t seed = P.seed[0];
+  const float dt = g_dist[P.target[0]];
+  const bool armed = dt < inf_f();
+  const float goal_dist = armed ? (float)((double)dt + P.offset) : inf_f();   // dijkstra :296
+  const uint32_t t_beg = blockIdx.y * tiles_per_block;
+  const uint32_t t_end = min(t_beg + tiles_per_block, T.ntiles);
+  uint32_t settled = 0, bad = 0;
+  for (uint32_t t = t_beg; t < t_end; ++t) {
+    if (!(g_tlast[t] > -inf_f()) && g_p0[t] == kInfBits && g_p1[t] == kInfBits) continue;   // uniform over the workgroup
+    const uint32_t v0 = g_vptr[t], nv = g_vptr[t + 1] - v0;
+    const uint32_t h0 = g_hptr[t], nh = g_hptr[t + 1] - h0;
+    const uint32_t e0 = g_eptr[t], ne = g_eptr[t + 1] - e0;
+    const uint32_t r0 = g_rptr[t], nl = nv + nh;
+    __syncthreads();                                               // the previous tile's LDS image is dead
+    uint32_t g[kFinVpt];
+#pragma unroll
+    for (int k = 0; k < kFinVpt; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      g[k] = (i < nv) ? g_verts[v0 + i] : (i < nl ? g_halo_verts[h0 + i - nv] : 0u);
+    }
+    stage_tile_graph(T, L, e0, ne, r0, nl, tid);
+    uint32_t db[kFinVpt];
+#pragma unroll
+    for (int k = 0; k < kFinVpt; ++k) db[k] = f2u(g_dist[g[k]]);
+    int cut = 0;                                                   // owned vertices above goal_dist: their value is re-derived
+#pragma unroll
+    for (int k = 0; k < kFinVpt; ++k) {
+      const uint32_t i = tid + k * kTileBlock;
+      if (i < nl) {
+        lgid[i] = g[k]; L.ldu[i] = db[k];
+        if (i < nv) { const bool c = u2f(db[k]) > goal_dist; cut |= c; lsum[i] = c ? kInfBits : db[k]; lkey[i] = ~0ull; }
+      }
+    }
+    for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock) {
+      const uint32_t gg = (i < nv) ? g_verts[v0 + i] : g_halo_verts[h0 + i - nv];
+      const uint32_t b = f2u(g_dist[gg]);
+      lgid[i] = gg; L.ldu[i] = b;
+      if (i < nv) { const bool c = u2f(b) > goal_dist; cut |= c; lsum[i] = c ? kInfBits : b; lkey[i] = ~0ull; }
+    }
+    cut = __syncthreads_or(cut);
+    if (cut) {
+      // pass 1 (tiles on the cut-off boundary only): smallest sum offered to the vertices above goal_dist
+      for (uint32_t x = tid; x < nl; x += kTileBlock) {
+        const float dx = u2f(L.ldu[x]);
+        if (!(dx < inf_f()) || dx > goal_dist) continue;           // not expanded (dijkstra :293-300)
+        for (uint32_t e = L.lrow[x], ee = L.lrow[x + 1]; e < ee; ++e) {
+          const uint32_t y = L.lcol[e];
+          if (y < nv && u2f(L.ldu[y]) > goal_dist) atomicMin(&lsum[y], f2u(dx + L.lw[e]));   // dijkstra :331
+        }
+      }
+      __syncthreads();
+    }
+    // pass 2: every edge checks the fixed point (no expanded source may offer less than the target
+    // holds) and the edges that attain the value compete with (d[x], x) for the predecessor
+    for (uint32_t x = tid; x < nl; x += kTileBlock) {
+      const uint32_t dxb = L.ldu[x];
+      const uint32_t eb = L.lrow[x], ee = L.lrow[x + 1];
+      const float dx = u2f(dxb);
+      if (!(dx < inf_f()) || dx > goal_dist) continue;
+      const unsigned long long key = ((unsigned long long)dxb << 32) | lgid[x];
+      uint32_t y[8]; float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { y[u] = L.lcol[eb + u]; w[u] = L.lw[eb + u]; }   // reads past the row stay inside the LDS image
+      uint32_t sy[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const bool ok = eb + u < ee && y[u] < nv; y[u] = ok ? y[u] : 0xFFFFFFFFu; sy[u] = ok ? lsum[y[u]] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (y[u] == 0xFFFFFFFFu) continue;
+        const uint32_t sb = f2u(dx + w[u]);
+        if (sb < sy[u]) ++bad;                                      // fixed point violated: internal error
+        else if (sb == sy[u] && sb != kInfBits) atomicMin(&lkey[y[u]], key);
+      }
+      for (uint32_t e = eb + 8; e < ee; ++e) {                     // valence > 8: rare
+        const uint32_t yy = L.lcol[e];
+        if (yy >= nv) continue;
+        const uint32_t sb = f2u(dx + L.lw[e]), syy = lsum[yy];
+        if (sb < syy) ++bad;
+        else if (sb == syy && sb != kInfBits) atomicMin(&lkey[yy], key);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nv; i += kTileBlock) {
+      const uint32_t gg = lgid[i];
+      if (gg == seed) { ++settled; continue; }
+      const uint32_t sb = lsum[i], ob = L.ldu[i];
+      const unsigned long long key = lkey[i];
+      if (sb != kInfBits && key == ~0ull) ++bad;                    // a finite value no expanded neighbour supports
+      g_pred[gg] = (sb != kInfBits) ? (uint32_t)key : gg;
+      if (sb != ob) g_dist[gg] = u2f(sb);                           // only above goal_dist (tentative value, dijkstra :337-343)
+      if (sb != kInfBits) ++settled;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  settled = wave_sum(settled); bad = wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (settled) atomicAdd(&res[blockIdx.x].settled, (unsigned long long)settled);
+    if (bad) atomicAdd(mismatch, bad);
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
     const TCtl a = T.ctl[0], b = T.ctl[1];
     const TCtl last = (a.it > b.it) ? a : b;
     Ctl r; memset(&r, 0, sizeof(r));
-    r.it = last.it; r.done = last.done; r.armed = c.armed; r.goal_dist = c.goal_dist; r.bands = last.sweeps;
+    r.it = last.it; r.done = last.done; r.armed = armed ? 1u : 0u; r.goal_dist = goal_dist; r.bands = last.sweeps;
     r.evals = last.acts; r.thr = inf_f(); r.thr_fixed = inf_f(); r.overflow = last.pad[0];
     P.ctl[0] = r; P.ctl[1] = r;
   }
@@ -968,15 +1099,6 @@ __global__ void k_seed(const Plan* __restrict__ plans)
 // ---------------------------------------------------------------------------------------------
 // result assembly: code + vertex path (dijkstra :358-373) / reachability (cvp :902-918), stats
 // ---------------------------------------------------------------------------------------------
-struct PlanResult {
-  uint32_t code;
-  uint32_t path_len;
-  uint32_t steps, bands, armed, overflow;
-  float goal_dist;
-  uint32_t pad;
-  unsigned long long settled;
-  unsigned long long evals;
-};
 
 template <uint32_t PLANNER>
 __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict__ res,
@@ -1204,10 +1326,10 @@ struct mnav_ctx {
   uint32_t *d_t_vptr = nullptr, *d_t_verts = nullptr, *d_t_hptr = nullptr, *d_t_halo_verts = nullptr, *d_t_halo_tile = nullptr,
            *d_t_eptr = nullptr, *d_t_src = nullptr, *d_vert_tile = nullptr, *d_mismatch = nullptr;
   uint16_t *d_t_rowptr = nullptr, *d_t_col = nullptr;
-  uint2* d_t_cw = nullptr; bool tw_valid = false; uint32_t t_nnz = 0;
+  float* d_t_tw = nullptr; bool tw_valid = false; uint32_t t_nnz = 0;
   TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
   TCtl* h_tctl = nullptr;
-  size_t tile_lds = 0;
+  size_t tile_lds = 0, fin_lds = 0;
   bool use_graph = true;
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
@@ -1235,7 +1357,7 @@ template <class T>
 int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
 {
   if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
-  HIPCHK(hipMalloc((void**)dptr, sizeof(T) * (n ? n : 1)));
+  HIPCHK(hipMalloc((void**)dptr, sizeof(T) * (n ? n : 1) + 64));   // tail slack: clamped vector loads may touch element 0 of an empty tile
   if (n && host) HIPCHK(hipMemcpyAsync(*dptr, host, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
@@ -1487,12 +1609,25 @@ int ensure_tile_state(mnav_ctx* ctx, uint32_t n)
   return 0;
 }
 
+// one workgroup per (plan, chunk of tiles); small batches get more, smaller chunks to fill the chip
+void launch_finalize(mnav_ctx* ctx, uint32_t n)
+{
+  const uint32_t ntiles = ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1u;
+  uint32_t chunks = (4096u + n - 1) / n;                 // >= 4096 workgroups in flight
+  if (chunks > ntiles) chunks = ntiles;
+  if (chunks < 1) chunks = 1;
+  const uint32_t per = (ntiles + chunks - 1) / chunks;
+  chunks = (ntiles + per - 1) / per;
+  hipLaunchKernelGGL(k_dij_finalize, dim3(n, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
+                     ctx->d_mismatch, ctx->d_res, per);
+}
+
 int tile_weights(mnav_ctx* ctx)
 {
   if (ctx->tw_valid) return 0;
   const uint32_t n = ctx->t_nnz;
   const uint32_t gb = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_tile_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, n, ctx->d_t_src, ctx->d_t_col, ctx->d_nbr, ctx->d_t_cw);
+  hipLaunchKernelGGL(k_tile_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, n, ctx->d_t_src, ctx->d_t_col, ctx->d_nbr, ctx->d_t_tw);
   HIPCHK(hipGetLastError());
   ctx->tw_valid = true;
   return 0;
@@ -1557,7 +1692,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     memset(&T, 0, sizeof(T));
     T.V = ctx->V; T.ntiles = M.ntiles;
     T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.cw = ctx->d_t_cw;
+    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
     T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset; T.max_rounds = ctx->max_steps;
     T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
@@ -1615,10 +1750,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   }
   ctx->stats.launches = launches;
   if (rc == 0) {
-    uint32_t gf = (ctx->V + (kBlock / kGroup) - 1) / (kBlock / kGroup);
-    if (gf > 8192) gf = 8192;
-    if (gf < 1) gf = 1;
-    hipLaunchKernelGGL(k_dij_finalize, dim3(gf, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_mismatch);
+    launch_finalize(ctx, n);
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -1652,7 +1784,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
     memset(&T, 0, sizeof(T));
     T.V = ctx->V; T.ntiles = M.ntiles;
     T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.cw = ctx->d_t_cw;
+    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
     T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
     T.max_rounds = 64u * (M.ntiles ? M.ntiles : 1u) + 1024u;          // activation cap per plan
@@ -1678,13 +1810,12 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->ms_chunks = 0.0;
   HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-  hipLaunchKernelGGL(k_plan_persistent, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
+  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_persistent<2>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
+  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_persistent<4>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
+  else hipLaunchKernelGGL(k_plan_persistent<8>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  uint32_t gf = (ctx->V + (kBlock / kGroup) - 1) / (kBlock / kGroup);
-  if (gf > 8192) gf = 8192;
-  if (gf < 1) gf = 1;
-  hipLaunchKernelGGL(k_dij_finalize, dim3(gf, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_mismatch);
+  launch_finalize(ctx, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1781,7 +1912,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_res); (void)hipFree(ctx->d_vecptrs); (void)hipFree(ctx->d_paths); (void)hipFree(ctx->d_seed_pos);
   (void)hipFree(ctx->d_t_vptr); (void)hipFree(ctx->d_t_verts); (void)hipFree(ctx->d_t_hptr); (void)hipFree(ctx->d_t_halo_verts);
   (void)hipFree(ctx->d_t_halo_tile); (void)hipFree(ctx->d_t_eptr); (void)hipFree(ctx->d_t_src); (void)hipFree(ctx->d_vert_tile);
-  (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_cw);
+  (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
   (void)hipFree(ctx->d_tplans);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -1846,15 +1977,21 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
       try { T = build_tiles(t, xyz, ctx->tile_size); }
       catch (const std::exception& ex) { ctx->err = ex.what(); return -2; }
       ctx->tile_lds = tile_lds_bytes(T.max_nv, T.max_nh, T.max_ne);
-      if (ctx->tile_lds <= 150 * 1024 || ctx->tile_size <= 64) break;
+      ctx->fin_lds = finalize_lds_bytes(T.max_nv, T.max_nh, T.max_ne);
+      if (ctx->fin_lds <= 150 * 1024 || ctx->tile_size <= 64) break;
       ctx->tile_size /= 2;                       // irregular mesh: shrink until a tile fits the 160 KiB LDS
     }
-    if (ctx->tile_lds > 160 * 1024) { ctx->err = "mesh valence too high for the LDS tile engine"; return -2; }
+    if (ctx->fin_lds > 160 * 1024) { ctx->err = "mesh valence too high for the LDS tile engine"; return -2; }
+    if (ctx->fin_lds > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)k_dij_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->fin_lds));
     if (ctx->tile_lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void*)k_tile_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
-    if (ctx->tile_lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
-    (void)hipFree(ctx->d_t_cw); ctx->d_t_cw = nullptr; ctx->tw_valid = false;
+    if (ctx->tile_lds > 64 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+    }
+    (void)hipFree(ctx->d_t_tw); ctx->d_t_tw = nullptr; ctx->tw_valid = false;
     ctx->t_nnz = (uint32_t)T.col.size();
     if (dev_upload(ctx, &ctx->d_t_vptr, T.vptr.data(), T.vptr.size())) return -1;
     if (dev_upload(ctx, &ctx->d_t_verts, T.verts.data(), T.verts.size())) return -1;
@@ -1867,7 +2004,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     if (dev_upload(ctx, &ctx->d_t_col, T.col.data(), T.col.size())) return -1;
     if (dev_upload(ctx, &ctx->d_t_src, T.src.data(), T.src.size())) return -1;
     if (dev_upload(ctx, &ctx->d_vert_tile, T.vert_tile.data(), T.vert_tile.size())) return -1;
-    if (dev_upload(ctx, &ctx->d_t_cw, (const uint2*)nullptr, T.col.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_t_tw, (const float*)nullptr, T.col.size())) return -1;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     // keep only the sizes on the host
     T.verts.clear(); T.verts.shrink_to_fit(); T.halo_verts.clear(); T.halo_verts.shrink_to_fit();
@@ -1984,7 +2121,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
     hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
-    hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
+    if (engine == 1)   // the tile engines count the settled vertices in k_dij_finalize
+      hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
     if (want_vecmap)
       hipLaunchKernelGGL(k_vecmap_dijkstra, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_xyz, ctx->d_vecptrs);

@@ -176,7 +176,7 @@ struct HostTiles {
   std::vector<uint32_t> hptr;        // ntiles+1 -> halo_verts / halo_tile
   std::vector<uint32_t> halo_verts;  // vertex ids of the halo
   std::vector<uint32_t> halo_tile;   // owning tile of each halo vertex
-  std::vector<uint32_t> eptr;        // ntiles+1 -> col / src (each tile padded to a multiple of 4 entries)
+  std::vector<uint32_t> eptr;        // ntiles+1 -> col / src (each tile padded to a multiple of 8 entries)
   std::vector<uint32_t> rptr;        // ntiles+1 -> rowptr (nv+nh+1 entries per tile, padded to a multiple of 8)
   std::vector<uint16_t> rowptr;      // local row pointers
   std::vector<uint16_t> col;         // tile-local target index: < nv owned, else nv + halo index
@@ -283,7 +283,7 @@ inline HostTiles build_tiles(const HostTopology& t, const float* xyz, uint32_t t
     if (ne > 0xFFFFu) throw std::invalid_argument("tile too large for 16-bit local row pointers");
     T.rowptr.push_back(uint16_t(ne));
     while (T.rowptr.size() % 8) T.rowptr.push_back(uint16_t(ne));
-    while (T.col.size() % 4) { T.col.push_back(0); T.src.push_back(kNone); }
+    while (T.col.size() % 8) { T.col.push_back(0); T.src.push_back(kNone); }
     for (uint32_t h = 0; h < nh; ++h) { T.halo_verts.push_back(halo[h]); T.halo_tile.push_back(T.vert_tile[halo[h]]); local[halo[h]] = kNone; }
     for (uint32_t i = b; i < e; ++i) local[T.verts[i]] = kNone;
     T.hptr.push_back(uint32_t(T.halo_verts.size()));
