@@ -100,13 +100,16 @@ def main() -> None:
     total_plans, elapsed = multi.aggregate_throughput(B * args.steps, elapsed, dist)   # sum of plans, MAX time over ranks
 
     # single-plan latency (ms/makePlan, device part) -- rank 0 only, outside the timed region
-    single_ms = None
+    single_ms = single_p95 = None
     if rank == 0 and not args.no_latency:
+        # SURVEY.md §8d protocol: 3 warm-ups, 20 timed plans (different goals), median and p95
         lat = []
-        for k in range(5):
+        for k in range(23):
             o = ctx.plan_dijkstra(int(first[0][k % B]), robot, want_fields=False)
-            lat.append(o.stats["ms_total"])
+            if k >= 3:
+                lat.append(o.stats["ms_total"])
         single_ms = float(np.median(lat))
+        single_p95 = float(np.percentile(lat, 95))
 
     out = None
     if rank == 0:
@@ -147,6 +150,7 @@ def main() -> None:
                        "vertices": mesh.V, "edges": mesh.E, "batch_per_gpu": B,
                        "parallelism": f"{world} independent replicas (plans sharded by rank)"},
             "ms_per_makeplan_single": single_ms,
+            "ms_per_makeplan_single_p95": single_p95,
             "ms_per_plan_in_batch": ms_step / B,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

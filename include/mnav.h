@@ -86,6 +86,18 @@ int mnav_compute_edge_weights(mnav_ctx* ctx, const float* vertex_costs, const fl
                               double edge_cost_factor, const uint8_t* invalid,
                               float* edge_weights_out);
 
+/* Device version of the combination layers that produce the planners' vertex costs
+ * (mesh_layers/src/combination_layer.cpp:44-85 MaxCombinationLayer, :185-248 AvgCombinationLayer; the
+ * default layer copied by MeshMap::copyVertexCostsFromDefaultLayer, mesh_map.cpp:495-515), followed by
+ * the edge weights of mnav_compute_edge_weights: mode 0 = max, 1 = weighted sum (weights n_layers,
+ * AbstractLayer::combinationWeight()); layer_costs = n_layers dense V-sized arrays (missing entries
+ * already replaced by the layer's default value), combined in the given order starting from 0.
+ * The result becomes the context's vertex costs / edge weights; vertex_costs_out V and
+ * edge_weights_out E (either may be NULL) receive copies. */
+int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* const* layer_costs,
+                       const float* weights, const float* edge_distances, double edge_cost_factor,
+                       const uint8_t* invalid, float* vertex_costs_out, float* edge_weights_out);
+
 /* -- planning ---------------------------------------------------------------------------- */
 /* Replaces DijkstraMeshPlanner::dijkstra (7-arg) + computeVectorMap,
  * dijkstra_mesh_planner.cpp:217-398, :189-209.  seed_vertex = wave seed (navigation goal),
@@ -136,7 +148,8 @@ void mnav_cancel(mnav_ctx* ctx);
 /* -- introspection / tuning -------------------------------------------------------------- */
 int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out);
 /* Band width of the wavefront engine in potential units; <= 0 selects the default
- * (3 x mean finite edge weight, recomputed on every cost upload). */
+ * (3 x mean finite edge weight for the Dijkstra band steps, 12 x for CVP, recomputed on every cost
+ * upload).  Results do not depend on it. */
 int mnav_set_band_width(mnav_ctx* ctx, float delta);
 /* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round,
  * lowest latency for a single plan), 1 = the distance-band gather steps that the CVP planner uses,

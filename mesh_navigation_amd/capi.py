@@ -19,7 +19,7 @@ SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 
 # every symbol include/mnav.h declares
 SYMBOLS = [
     "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_upload_mesh", "mnav_upload_costs",
-    "mnav_compute_edge_weights", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
+    "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes",
 ]
@@ -61,6 +61,8 @@ def load(path: str | None = None):
     L.mnav_upload_costs.argtypes = [vp, vp, vp, vp]
     L.mnav_compute_edge_weights.restype = C.c_int
     L.mnav_compute_edge_weights.argtypes = [vp, vp, vp, f64, vp, vp]
+    L.mnav_combine_costs.restype = C.c_int
+    L.mnav_combine_costs.argtypes = [vp, C.c_int, u32, vp, vp, vp, f64, vp, vp, vp]
     L.mnav_plan_dijkstra.restype = u32
     L.mnav_plan_dijkstra.argtypes = [vp, u32, u32, f64, f64, vp, vp, vp, u32, C.POINTER(u32), vp]
     L.mnav_plan_cvp.restype = u32
@@ -171,6 +173,22 @@ class MnavContext:
         if rc != 0:
             raise RuntimeError(f"mnav_compute_edge_weights failed ({rc}): {self._err()}")
         return out
+
+    def combine_costs(self, layers, weights, edge_distances, edge_cost_factor: float, mode: str = "avg", invalid=None):
+        """Max/Avg combination of dense V-sized cost layers + edge weights, on the device.
+        Returns (vertex_costs, edge_weights); both also become the context's planning inputs."""
+        arrs = [_f32(a) for a in layers]
+        ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+        w = _f32(weights if weights is not None else np.ones(len(arrs), np.float32))
+        ed = _f32(edge_distances)
+        inv = None if invalid is None else np.ascontiguousarray(invalid, dtype=np.uint8)
+        vc = np.empty(self.V, dtype=np.float32)
+        ew = np.empty(self.E, dtype=np.float32)
+        rc = self._L.mnav_combine_costs(self._h, 0 if mode == "max" else 1, len(arrs), C.cast(ptrs, C.c_void_p), _p(w), _p(ed),
+                                        float(edge_cost_factor), _p(inv), _p(vc), _p(ew))
+        if rc != 0:
+            raise RuntimeError(f"mnav_combine_costs failed ({rc}): {self._err()}")
+        return vc, ew
 
     def set_band_width(self, delta: float):
         self._L.mnav_set_band_width(self._h, float(delta))

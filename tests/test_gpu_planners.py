@@ -177,6 +177,15 @@ def test_layered_costs_config3_shape(gpu_ctx_factory):
         ctx.upload_mesh(case.mesh.xyz, case.mesh.faces, case.mesh.edges, case.vn)
         w_dev = ctx.compute_edge_weights(case.costs, case.edge_dist, 1.0)
         assert np.array_equal(w_dev.view(np.uint32), case.weights.view(np.uint32))
+        # the combination layer itself on the device (combination_layer.cpp:44-85 / :185-248), non-trivial weights too
+        for wts in ([1.0, 1.0], [0.7, 1.9]):
+            vc_dev, w2 = ctx.combine_costs([parts["steepness"], parts["inflation"]], wts, case.edge_dist, 1.0, mode)
+            vc_ref = O.combine([parts["steepness"], parts["inflation"]], wts, mode)
+            assert np.array_equal(vc_dev.view(np.uint32), vc_ref.view(np.uint32))
+            w_ref = case.om.edge_weights(case.edge_dist, vc_ref, 1.0)
+            assert np.array_equal(w2.view(np.uint32), w_ref.view(np.uint32))
+        vc_dev, w2 = ctx.combine_costs([parts["steepness"], parts["inflation"]], [1.0, 1.0], case.edge_dist, 1.0, mode)
+        assert np.array_equal(vc_dev.view(np.uint32), costs.view(np.uint32)) and np.array_equal(w2.view(np.uint32), case.weights.view(np.uint32))
         m = case.mesh
         free = np.where(costs < 0.5)[0]
         def near(fi, fj):

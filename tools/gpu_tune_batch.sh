@@ -1,8 +1,9 @@
 #!/bin/bash
 # scratch: throughput of the persistent engine over tile size / batch size
-for cfg in "512 1024" "512 1280" "512 2560" "448 1536" "448 3072" "416 1536" "384 1792"; do
+for cfg in "512 1280" "496 1536" "480 1536" "464 1536" "448 1536" "432 1536" "384 1536" "384 1792"; do
   set -- $cfg; ts=$1; bt=$2
-  MNAV_TILE_SIZE=$ts timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu --no-latency --batch $bt 2>/dev/null | python -c "
+  MNAV_VERBOSE=1 MNAV_TILE_SIZE=$ts timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu --no-latency --batch $bt 2>gpurun_out/tune_err.log | python -c "
 import sys,json
-l=[x for x in sys.stdin if x.startswith('{')][-1]; b=json.loads(l); print('tile',$ts,'batch',$bt,'plans/s %.0f ms/step %.1f frac %.4f'%(b['value'],b['ms_per_step'],b['roofline']['frac']))"
+l=[x for x in sys.stdin if x.startswith('{')][-1]; b=json.loads(l); print('tile',$ts,'batch',$bt,'plans/s %.0f ms/step %.1f kernel_us %.0f'%(b['value'],b['ms_per_step'],b['roofline']['avg_launch_us']))"
+  grep "mnav" gpurun_out/tune_err.log | head -1
 done
