@@ -249,7 +249,7 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
     const bool parked = !REPAIR && go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && P.dirty[v] != (uint32_t)c.it;
     if (parked) { retain = true; t_new = old_t; }
     else if (go) {
-      if (!REPAIR || old_d > c.goal_dist) {
+      if (!REPAIR || old_t > c.goal_dist) {                          // spec: process_repair (pop time, not value)
         if (sub == 0) ++S.levals;
         const Eval e = group_eval<PLANNER>(P, c, v, sub);
         bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != P.pred[v]);
@@ -259,6 +259,7 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
           if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
         }
         t_new = e.t;
+        if (REPAIR && cvp && sub == 0 && (f2u(e.d) != f2u(old_d) || e.key != old_key)) S.lchanged = true;   // sweep again
         if (!REPAIR) {
           const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
           push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
@@ -316,11 +317,18 @@ __global__ __launch_bounds__(kWave) void k_step(const Plan* __restrict__ plans, 
   const int sub = lane & (kGroup - 1), grp = lane >> 3;
   const uint32_t ngroups = gridDim.x * kGroupsPerWave;
   const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
-  if (cur.repair) {
+  if (cur.repair == 1) {                                             // spec: process_repair
     const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t v = g0 + r * ngroups;
       group_process<PLANNER, true>(S, P, cur, v < P.V, v < P.V ? v : 0u, sub);
+    }
+  } else if (cur.repair == 2) {                                      // spec: process_rebuild (band shrink, band_new == 1)
+    const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint32_t v = g0 + r * ngroups;
+      const bool active = v < P.V && P.dist[v < P.V ? v : 0u] < inf_f();
+      group_process<PLANNER, false>(S, P, cur, active, active ? v : 0u, sub);
     }
   } else {
     const uint32_t* list = P.list[cur.it & 1];

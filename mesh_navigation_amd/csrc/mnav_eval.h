@@ -256,6 +256,10 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
   q.n = c.n_next;
   if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
   const bool out_of_steps = (uint32_t)q.it >= P.max_steps;
+  if (p.repair == 1 && c.changed > 0 && !out_of_steps) {             // repair sweep not yet at its fixed point (CVP)
+    q.repair = 1; q.band_new = 0;
+    return q;
+  }
   if (c.changed > 0 && !out_of_steps) {
     q.band_new = 0;
     q.band_steps = p.band_steps + 1;
@@ -455,10 +459,16 @@ MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
   if (!(d < inf_f())) return;
   float t = d;
   if constexpr (cvp) t = key_time(P.tkey[v]);
-  if (d > c.goal_dist) {
+  // CVP: a vertex whose value was set by a trigger beyond goal_dist pops after that trigger, i.e. its
+  // POP TIME (not necessarily its value: non-causal updates undercut the front) lies above goal_dist
+  if (t > c.goal_dist) {
     ops.note_eval();
     Eval e;
     if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
+    if constexpr (cvp) {
+      // such vertices can support each other (in pop order): sweep again until nothing moves
+      if (f2u(e.d) != f2u(d) || e.key != P.tkey[v]) ops.note_changed();
+    }
     P.dist[v] = e.d; P.pred[v] = e.pred;
     if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
     d = e.d; t = e.t;

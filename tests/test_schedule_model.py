@@ -185,3 +185,28 @@ def test_cvp_adversarial_weights_converge():
     case2 = Case(mesh, (costs * 0.5).astype(np.float32), 1.0, invalid)
     ref2, mod2 = run_cvp(case2, sp, tp, delta=0.36, order=3, max_steps=100000)
     assert np.array_equal(mod2["dist"].view(np.uint32), ref2.dist.view(np.uint32))
+
+
+@pytest.mark.parametrize("mult", [3, 12, 24])
+@pytest.mark.parametrize("order", [0, 3])
+def test_cvp_wide_bands_repair_after_arming(mult, order):
+    """A band much wider than goal_dist_offset lets vertices beyond goal_dist fire faces before the goal is
+    armed; some of the vertices they set get VALUES below goal_dist (non-causal updates) but pop after their
+    trigger.  The repair sweeps after arming must take back exactly those (cvp :754: a vertex beyond goal_dist
+    is popped but never expands), whatever the band width."""
+    mesh = meshgen.terrain(96, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = (rng.uniform(0, 1.2, mesh.V) * 0.5).astype(np.float32)   # edges inflated by up to 1.6x
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    invalid[[s, t]] = 0
+    costs[[s, t]] = 0
+    case = Case(mesh, costs, 1.0, invalid)
+    sp = mesh.xyz[s] + np.array([0.03, 0.02, 0], np.float32)
+    tp = mesh.xyz[t] + np.array([0.03, 0.02, 0], np.float32)
+    mean_w = float(case.weights[np.isfinite(case.weights)].mean())
+    ref, mod = run_cvp(case, sp, tp, delta=mult * mean_w, order=order, max_steps=200000)
+    assert mod["code"] == 0
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+    assert mod["goal_dist"] == ref.stats["goal_dist"]
