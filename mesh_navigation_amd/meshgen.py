@@ -127,3 +127,50 @@ CONFIGS = {
     "C4": dict(N=3163, seed=4),
     "C5": dict(N=1000, seed=2),
 }
+
+
+def from_faces(xyz, faces, N: int = 0, h: float = 0.0) -> TerrainMesh:
+    """Any triangle soup with shared vertices (edge ids = order of first appearance)."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    faces = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+    edges, face_edges = edges_from_faces(faces)
+    return TerrainMesh(N=N, h=h, xyz=xyz, faces=faces, edges=edges, face_edges=face_edges)
+
+
+def punched(N: int, h: float = 0.1, seed: int = 0, drop: float = 0.08, amplitude: float = 0.5,
+            cut_column: int | None = None) -> TerrainMesh:
+    """Terrain with a random `drop` fraction of its faces removed: holes, boundary loops, vertices of
+    valence 1..6, and a few vertices left without any face (ragged input for the planners).  With
+    `cut_column` every face touching that grid column goes too: two components, a column of face-less
+    vertices between them."""
+    t = terrain(N, h, seed, amplitude=amplitude)
+    rng = np.random.default_rng(seed + 7919)
+    keep = rng.uniform(size=t.F) >= drop
+    if cut_column is not None:
+        keep &= ~((t.faces % N) == cut_column).any(axis=1)
+    return from_faces(t.xyz, t.faces[keep], N=N, h=h)
+
+
+def fan_field(spokes: int = 40, rings: int = 6, seed: int = 0) -> TerrainMesh:
+    """A disc triangulated as concentric rings around ONE centre vertex of valence `spokes` (> 16: beyond
+    the lanes-per-vertex fast paths of the kernels), slightly bumpy."""
+    rng = np.random.default_rng(seed)
+    pts = [(0.0, 0.0)]
+    for r in range(1, rings + 1):
+        for s in range(spokes):
+            a = 2.0 * np.pi * (s + 0.5 * (r % 2)) / spokes
+            pts.append((0.1 * r * np.cos(a), 0.1 * r * np.sin(a)))
+    pts = np.asarray(pts)
+    z = 0.02 * rng.standard_normal(len(pts))
+    xyz = np.column_stack([pts, z]).astype(np.float32)
+    def vid(r, s):
+        return 0 if r == 0 else 1 + (r - 1) * spokes + (s % spokes)
+    faces = []
+    for s in range(spokes):
+        faces.append((0, vid(1, s), vid(1, s + 1)))
+    for r in range(1, rings):
+        for s in range(spokes):
+            a, b = vid(r, s), vid(r, s + 1)
+            c, d = vid(r + 1, s), vid(r + 1, s + 1)
+            faces.append((a, c, b)); faces.append((b, c, d))
+    return from_faces(xyz, np.asarray(faces, np.uint32))

@@ -1,0 +1,154 @@
+"""GPU parity on ragged inputs: meshes with holes, several components and face-less vertices, a vertex of
+valence 40 (beyond the 8-lanes-per-vertex fast paths of every kernel), the smallest meshes, empty batches and
+batches that mix every return code.  Same bars as elsewhere: Dijkstra bit-exact, CVP 1e-5 relative."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import capi, meshgen
+from oracle import oracle as O
+from tests.common import Case
+from tests.test_gpu_planners import assert_cvp_close, assert_dijkstra_equal
+
+pytestmark = pytest.mark.gpu
+ENGINES = ("tiled", "band", "persistent")
+
+
+def face_of(mesh, v):
+    return int(np.where((mesh.faces == v).any(axis=1))[0][0])
+
+
+def centroid(mesh, f):
+    return mesh.xyz[mesh.faces[f]].astype(np.float64).mean(axis=0).astype(np.float32)
+
+
+def components(mesh):
+    lab = np.arange(mesh.V)
+    for _ in range(mesh.V):
+        a, b = lab[mesh.edges[:, 0]], lab[mesh.edges[:, 1]]
+        m = np.minimum(a, b)
+        new = lab.copy()
+        np.minimum.at(new, mesh.edges[:, 0], m); np.minimum.at(new, mesh.edges[:, 1], m)
+        new = new[new]
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    return lab
+
+
+def test_punched_mesh_holes_components_and_faceless_vertices(gpu_ctx_factory):
+    mesh = meshgen.punched(96, 0.1, 5, drop=0.30, cut_column=60)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    assert (deg == 0).sum() > 0 and deg.max() <= 6                   # face-less vertices exist
+    case = Case(mesh)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    lab = components(mesh)
+    big = np.bincount(lab).argmax()
+    inside = np.where(lab == big)[0]
+    outside = np.where((lab != big) & (deg > 0))[0]
+    assert len(outside) > 0
+    rng = np.random.default_rng(1)
+    s, t = (int(x) for x in rng.choice(inside, 2, replace=False))
+    lonely = int(np.where(deg == 0)[0][0])
+    for engine in ENGINES:
+        ctx.set_dijkstra_engine(engine)
+        assert_dijkstra_equal(ctx.plan_dijkstra(s, t), case.om.dijkstra(case.weights, case.costs, s, t))
+        # target in another component / target without any face: NO_PATH_FOUND, the whole component is swept
+        for tt in (int(outside[0]), lonely):
+            ref = case.om.dijkstra(case.weights, case.costs, s, tt)
+            assert ref.code == O.NO_PATH_FOUND
+            assert_dijkstra_equal(ctx.plan_dijkstra(s, tt), ref)
+        # wave seeded on a face-less vertex: nothing to expand
+        ref = case.om.dijkstra(case.weights, case.costs, lonely, t)
+        assert_dijkstra_equal(ctx.plan_dijkstra(lonely, t), ref)
+    ctx.set_dijkstra_engine("auto")
+    sf, tf = face_of(mesh, s), face_of(mesh, t)
+    sp, tp = centroid(mesh, sf), centroid(mesh, tf)
+    for off in (0.3, float("inf")):
+        refc = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf, goal_dist_offset=off)
+        assert_cvp_close(ctx.plan_cvp(sp, sf, tf, goal_dist_offset=off), refc)
+    tf2 = face_of(mesh, int(outside[0]))
+    refc = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf2)
+    assert refc.code == O.NO_PATH_FOUND
+    assert ctx.plan_cvp(sp, sf, tf2).code == O.NO_PATH_FOUND
+
+
+def test_vertex_of_valence_40(gpu_ctx_factory):
+    mesh = meshgen.fan_field(40, 6, 1)
+    case = Case(mesh)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    s, t = 1 + 5 * 40 + 3, 1 + 5 * 40 + 23                           # opposite sides of the outer ring: paths cross the hub
+    for engine in ENGINES:
+        ctx.set_dijkstra_engine(engine)
+        for a, b in ((s, t), (0, t), (s, 0)):
+            assert_dijkstra_equal(ctx.plan_dijkstra(a, b, goal_dist_offset=float("inf")),
+                                  case.om.dijkstra(case.weights, case.costs, a, b, goal_dist_offset=float("inf")))
+    ctx.set_dijkstra_engine("auto")
+    for sv, tv in ((s, t), (0, t), (s, 0)):
+        sf, tf = face_of(mesh, sv), face_of(mesh, tv)
+        sp = centroid(mesh, sf)
+        refc = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf, goal_dist_offset=float("inf"))
+        out = ctx.plan_cvp(sp, sf, tf, goal_dist_offset=float("inf"), want_vecmap=True)
+        assert_cvp_close(out, refc)
+        same = (out.pred == refc.pred) & (refc.pred != np.arange(mesh.V))
+        assert np.abs(out.vecmap[same] - refc.vecmap[same]).max() < 1e-4
+
+
+def test_two_triangle_mesh_closed_form(gpu_ctx_factory):
+    """The smallest mesh with a free vertex: the unit-leg square of the reference's only numeric test shape
+    (inflation_layer_test.cpp:7-23 uses legs of 0.5), split along one diagonal."""
+    xyz = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0], [0.5, 0.5, 0]], np.float32)
+    mesh = meshgen.from_faces(xyz, np.array([[0, 1, 2], [1, 3, 2]], np.uint32))
+    case = Case(mesh)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    ref = case.om.dijkstra(case.weights, case.costs, 0, 3)
+    for engine in ENGINES:
+        ctx.set_dijkstra_engine(engine)
+        out = ctx.plan_dijkstra(0, 3)
+        assert_dijkstra_equal(out, ref)
+        assert out.dist[3] == np.float32(1.0) and out.dist[1] == np.float32(0.5)
+    ctx.set_dijkstra_engine("auto")
+    sp = np.array([0.0, 0.0, 0.0], np.float32)                        # wave seeded exactly on vertex 0
+    refc = case.om.cvp(case.weights, case.costs, case.vn, sp, 0, 1)
+    out = ctx.plan_cvp(sp, 0, 1)
+    assert out.code == refc.code == 0
+    assert np.array_equal(out.dist.view(np.uint32), refc.dist.view(np.uint32))
+    assert out.dist[3] == pytest.approx(np.sqrt(0.5), rel=1e-6)        # straight across the unfolded square
+
+
+def test_empty_batch_and_batch_mixing_all_codes(gpu_ctx_factory):
+    mesh = meshgen.punched(64, 0.1, 9, drop=0.30, cut_column=40)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    case = Case(mesh)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    empty = ctx.plan_dijkstra_batch(np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+    assert len(empty["codes"]) == 0 and len(empty["paths"]) == 0
+    lab = components(mesh)
+    big = np.bincount(lab).argmax()
+    inside = np.where(lab == big)[0]
+    outside = np.where((lab != big) & (deg > 0))[0]
+    rng = np.random.default_rng(2)
+    n = 160                                                          # >= 128: the persistent engine in 'auto'
+    goals = rng.choice(inside, n).astype(np.uint32)
+    targets = np.full(n, int(inside[len(inside) // 2]), np.uint32)
+    goals[7] = mesh.V + 3                                             # INVALID_START
+    targets[11] = mesh.V + 9                                          # INVALID_GOAL
+    goals[13] = targets[13]                                           # SUCCESS with an empty path (:252-255)
+    targets[17] = int(outside[0])                                     # NO_PATH_FOUND
+    goals[19] = int(np.where(deg == 0)[0][0])                         # wave seeded on a face-less vertex
+    for engine in ("auto", "tiled"):
+        ctx.set_dijkstra_engine(engine)
+        b = ctx.plan_dijkstra_batch(goals, targets, want_fields=False)
+        for k in range(n):
+            if goals[k] >= mesh.V:
+                assert b["codes"][k] == capi.INVALID_START and len(b["paths"][k]) == 0
+            elif targets[k] >= mesh.V:
+                assert b["codes"][k] == capi.INVALID_GOAL and len(b["paths"][k]) == 0
+            else:
+                ref = case.om.dijkstra(case.weights, case.costs, int(goals[k]), int(targets[k]))
+                assert b["codes"][k] == ref.code, k
+                assert np.array_equal(b["paths"][k], ref.path), k
+    ctx.set_dijkstra_engine("auto")

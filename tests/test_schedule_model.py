@@ -210,3 +210,32 @@ def test_cvp_wide_bands_repair_after_arming(mult, order):
     assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
     assert np.array_equal(mod["pred"], ref.pred)
     assert mod["goal_dist"] == ref.stats["goal_dist"]
+
+
+@pytest.mark.parametrize("which", ["punched", "fan"])
+def test_schedule_on_ragged_meshes(which):
+    """Holes, two components and face-less vertices; a hub vertex of valence 40."""
+    mesh = meshgen.punched(64, 0.1, 5, drop=0.3, cut_column=40) if which == "punched" else meshgen.fan_field(40, 6, 1)
+    case = Case(mesh)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    if which == "punched":
+        s, t = mesh.vertex_at(0.1, 0.2), mesh.vertex_at(0.5, 0.8)
+        while deg[s] == 0: s += 1
+        while deg[t] == 0: t += 1
+        far = mesh.vertex_at(0.9, 0.5)
+        while deg[far] == 0: far += 1
+    else:
+        s, t, far = 1 + 5 * 40 + 3, 1 + 5 * 40 + 23, 0
+    for a, b in ((s, t), (s, far)):
+        ref, mod = run_dijkstra(case, a, b, delta=0.3)
+        assert mod["code"] == ref.code
+        assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(mod["pred"], ref.pred)
+    sf = int(np.where((mesh.faces == s).any(axis=1))[0][0])
+    tf = int(np.where((mesh.faces == t).any(axis=1))[0][0])
+    sp = mesh.xyz[mesh.faces[sf]].mean(axis=0).astype(np.float32)
+    tp = mesh.xyz[mesh.faces[tf]].mean(axis=0).astype(np.float32)
+    for order in (0, 3):
+        ref, mod = run_cvp(case, sp, tp, delta=0.3, order=order)
+        assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(mod["pred"], ref.pred)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # scratch: throughput of the persistent engine over tile size / batch size
-for cfg in "512 1280" "496 1536" "480 1536" "464 1536" "448 1536" "432 1536" "384 1536" "384 1792"; do
+for cfg in "512 1280" "640 1024" "768 768" "768 1536" "1024 512" "1024 1024"; do
   set -- $cfg; ts=$1; bt=$2
   MNAV_VERBOSE=1 MNAV_TILE_SIZE=$ts timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu --no-latency --batch $bt 2>gpurun_out/tune_err.log | python -c "
 import sys,json
