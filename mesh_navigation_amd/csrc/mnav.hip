@@ -120,13 +120,24 @@ __device__ __forceinline__ Eval group_eval_dijkstra(const Plan& P, const Ctl& c,
       best_s = os; best_du = odu; best_u = ou;
     }
   }
-  Eval e; e.d = best_s; e.t = best_s; e.key = 0; e.pred = (best_s < inf_f()) ? best_u : v; e.dir = 0.0f; e.cut = kNone;
+  Eval e; e.d = best_s; e.t = best_s; e.key = key_inf(); e.pred = (best_s < inf_f()) ? best_u : v; e.dir = 0.0f; e.cut = kNone;
   return e;
 }
 
 // --- CVP replay over 8 lanes (spec: mnav_eval.h::eval_cvp) ------------------------------------
-struct CornerItem { PopKey fk; bool valid; CvpCand k; uint32_t v1, v2, face; };
+struct CornerItem { KeyRef fk; uint32_t trig; bool valid; CvpCand k; uint32_t v1, v2, face; };
 
+__device__ __forceinline__ KeyRef gshfl_key(const KeyRef& r, int src)
+{
+  KeyRef o;
+  o.k.hi = gshfl(r.k.hi, src); o.k.up = gshfl(r.k.up, src); o.k.lvl = gshfl(r.k.lvl, src); o.own = gshfl(r.own, src);
+  return o;
+}
+
+// Lanes hold one corner each (fire event + float64 candidate, computed in parallel); the replay walks
+// the triggers in pop order with in-group shuffles.  Pop keys of different main-front pops compare by
+// the integer `hi` alone; only keys inside one cascade need key_less()'s walk over the cascade tree
+// (PopKey, mnav_eval.h), which every lane of the group then performs on the same operands.
 __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint32_t v, int sub)
 {
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
@@ -135,35 +146,54 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const uint32_t i = beg + sub + r * kGroup;
-    it[r].fk = key_inf(); it[r].valid = false; it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone;
+    it[r].fk = key_ref_of(key_inf(), inf_f(), 0); it[r].trig = kNone; it[r].valid = false;
+    it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone;
     it[r].k.u3tmp = 0.0; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = 0; it[r].k.kind = 0;
     if (i < end) {
       const Corner k = P.crn[i];
       const Fire f = corner_fire(P, c, k);
       if (f.trig != kNone) {
-        it[r].valid = true; it[r].fk = f.key;
+        it[r].valid = true; it[r].fk = f.key; it[r].trig = f.trig;
         it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
         it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = k.face;
       }
     }
   }
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
-  constexpr PopKey kNoKey = ~0ull;
-  PopKey last = 0;
-  bool first = true;
   const int gbase = (threadIdx.x & (kWave - 1)) & ~(kGroup - 1);
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  constexpr unsigned long long kNoKey = ~0ull;
+  KeyRef last = key_ref_of(key_inf(), inf_f(), 0);
+  bool first = true;
   for (;;) {
-    PopKey m = kNoKey;
+    // next trigger pop strictly after the last one: smallest `hi` first, the tree decides among equals
+    bool el[2];
+    unsigned long long mh = kNoKey;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) if (it[r].valid && (first || it[r].fk > last) && it[r].fk < m) m = it[r].fk;
+    for (int r = 0; r < 2; ++r) {
+      el[r] = it[r].valid && (first || key_less(P, last, it[r].fk));
+      if (el[r] && it[r].fk.k.hi < mh) mh = it[r].fk.k.hi;
+    }
 #pragma unroll
-    for (int o = 1; o < kGroup; o <<= 1) { const PopKey om = __shfl_xor(m, o, kGroup); m = om < m ? om : m; }
-    if (m == kNoKey) break;
-    if (!(m < e.key)) break;                                       // v pops before this trigger
+    for (int o = 1; o < kGroup; o <<= 1) { const unsigned long long om = __shfl_xor(mh, o, kGroup); mh = om < mh ? om : mh; }
+    if (mh == kNoKey) break;
+    KeyRef m = last; uint32_t m_trig = kNone;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned gm = (unsigned)((__ballot(el[r] && it[r].fk.k.hi == mh) >> gbase) & 0xFFull);
+      while (gm) {
+        const int src = __ffs((int)gm) - 1;
+        gm &= gm - 1;
+        const uint32_t ct = gshfl(it[r].trig, src);
+        if (ct == m_trig) continue;
+        const KeyRef cand = gshfl_key(it[r].fk, src);
+        if (m_trig == kNone || key_less(P, cand, m)) { m = cand; m_trig = ct; }
+      }
+    }
+    if (e.d < inf_f() && !key_less(P, m, key_ref_of(e.key, e.d, v))) break;   // v pops before this trigger
     bool any = false;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {                                  // ascending corner index = ascending face id
-      unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].fk == m) >> gbase) & 0xFFull);
+      unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].trig == m_trig) >> gbase) & 0xFFull);
       while (gm) {
         const int src = __ffs((int)gm) - 1;
         gm &= gm - 1;
@@ -178,10 +208,7 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
         }
       }
     }
-    if (any) {
-      const PopKey own = make_key(e.d, v, 0), after = key_after(m);
-      e.key = own > after ? own : after;
-    }
+    if (any) e.key = key_for(P, e.d, v, m);                        // ordinary pop, or a place inside this trigger's cascade
     last = m; first = false;
   }
   if (!(e.d < inf_f())) { e.pred = v; e.key = key_inf(); }
@@ -239,7 +266,7 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
   float t_new = inf_f();
   if (active && !is_seed(P, v)) {
     const float old_d = P.dist[v];
-    PopKey old_key = 0;
+    PopKey old_key = key_inf();
     if constexpr (cvp) old_key = P.tkey[v];
     const float old_t = cvp ? key_time(old_key) : old_d;
     bool go;
@@ -1071,7 +1098,7 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   for (int k = 0; k < ns; ++k) {
     const uint32_t s = P.seed[k];
     P.dist[s] = P.seed_d[k];
-    if (PLANNER == kPlannerCvp) { P.tkey[s] = make_key(P.seed_d[k], s, 0); P.cutf[s] = P.seed_face; }
+    if (PLANNER == kPlannerCvp) { P.tkey[s] = make_key(P.seed_d[k], s); P.cutf[s] = P.seed_face; }
     m0 = fminf(m0, P.seed_d[k]);
   }
   uint32_t n = 0;
@@ -1095,6 +1122,7 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   Ctl c0; memset(&c0, 0, sizeof(c0));
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = m0 + P.delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
+  for (int k = 0; k < ns; ++k) if (!(P.seed_d[k] < c0.thr)) c0.thr = next_up(P.seed_d[k]);   // the first band holds every seed
   c0.band_new = 1; c0.width = P.delta;
   P.ctl[1] = c0;
   P.ctl[0] = c0;
@@ -1419,7 +1447,7 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
     for (uint32_t i = 0; i < n; ++i) {
       Slot& s = ctx->slots[i];
       if (!s.cvp_ready) {
-        HIPCHK(hipMalloc((void**)&s.tkey, 8 * V)); HIPCHK(hipMalloc((void**)&s.dirn, 4 * V));
+        HIPCHK(hipMalloc((void**)&s.tkey, sizeof(PopKey) * V)); HIPCHK(hipMalloc((void**)&s.dirn, 4 * V));
         HIPCHK(hipMalloc((void**)&s.cutf, 4 * V));
         s.cvp_ready = true;
       }

@@ -49,28 +49,44 @@ MNAV_HD uint32_t f2u(float f) { union { uint32_t u; float f; } x; x.f = f; retur
 MNAV_HD float inf_f() { return u2f(0x7f800000u); }
 MNAV_HD float next_up(float x) { return (x >= 0.0f) ? u2f(f2u(x) + 1u) : u2f(f2u(x) - 1u); }  // finite x
 
-// Total order of pops.  Among equal heap keys the smaller vertex id pops first (the tie rule fixed
-// for the un-vendored lvr2::Meap, see DESIGN.md "tie rule"); a vertex whose key was
-// set BELOW the current pop front by a face update (non-causal update on an obtuse / cost-inflated
-// triangle) pops right after the vertex whose pop fired that face, and so on down a chain of such
-// updates.  Both are captured by a 64-bit pop key compared as an integer:
-//     [ float bits of the pop time : 32 | tie id : 26 | chain depth : 6 ]
-// (d, v, 0) for an ordinary vertex; (time, tie id, depth + 1) of its trigger for a non-causal one.
-// A dependent therefore always has a strictly larger key than its trigger, which keeps the
-// gather iteration well-founded (no mutually supporting vertices).  Limits: V <= 2^26 for CVP.
-typedef unsigned long long PopKey;
-constexpr uint32_t kKeyIdBits = 26, kKeyDepthBits = 6, kKeyDepthMax = (1u << kKeyDepthBits) - 1u;
-MNAV_HD PopKey make_key(float t, uint32_t id, uint32_t depth)
+// Total order of pops.  The reference pops the heap minimum, ties to the smaller vertex id (the tie rule
+// fixed for the un-vendored lvr2::Meap, see DESIGN.md "tie rule").  A face update may set a vertex
+// BELOW the value that is popping (non-causal update: obtuse / cost-inflated triangles, and above all
+// waves that wrap around holes and obstacles and fill the shadow behind them backwards); that vertex
+// is then the heap minimum and pops next, and it can start a whole CASCADE of pops below the main
+// front -- which among themselves pop in (value, id) order again, and nest: a vertex set below the
+// value popping INSIDE a cascade opens a sub-cascade, and so on, as deep as the backward wave runs.
+// The pop order is therefore the PREORDER of a forest: roots = the pops of the main front in
+// (value, id) order; the children of a node = the vertices that pop inside its (sub-)cascade, i.e.
+// below its value but above that of any deeper node they could belong to, in (value, id) order.
+// A pop key stores a node's place in that forest without copying the path:
+//     hi  = [ float bits of the root's pop value : 32 | root id : 26 | 0 : 6 ]   (the main-front pop)
+//     up  = parent node (vertex id), kNone for a root;   lvl = depth in the tree (0 for a root)
+// the node's own (value, id) pair is (dist[v], v).  Keys of different roots compare by `hi` alone (one
+// integer compare, the common case); inside one cascade key_less() walks the `up` links to the
+// siblings that decide.  A dependent always sorts after the pop that set it, which keeps the gather
+// iteration well-founded.  Limits: V <= 2^26 for CVP.
+struct PopKey { unsigned long long hi; uint32_t up; uint32_t lvl; };
+MNAV_HD bool operator==(const PopKey& a, const PopKey& b) { return a.hi == b.hi && a.up == b.up && a.lvl == b.lvl; }
+MNAV_HD bool operator!=(const PopKey& a, const PopKey& b) { return !(a == b); }
+constexpr uint32_t kKeyIdBits = 26, kKeyPadBits = 6;
+constexpr int kKeyWalkMax = 4096;        // bound on the `up` walks (a half-converged tree may be inconsistent)
+MNAV_HD unsigned long long key_pair(float t, uint32_t id)
 {
-  return ((PopKey)f2u(t) << 32) | ((PopKey)(id & ((1u << kKeyIdBits) - 1u)) << kKeyDepthBits) | (PopKey)depth;
+  return ((unsigned long long)f2u(t) << 32) | ((unsigned long long)(id & ((1u << kKeyIdBits) - 1u)) << kKeyPadBits);
 }
-MNAV_HD PopKey key_after(PopKey trigger)
+MNAV_HD uint32_t pair_id(unsigned long long pr) { return (uint32_t)(pr >> kKeyPadBits) & ((1u << kKeyIdBits) - 1u); }
+// key of an ordinary (main front) pop of vertex id at value t
+MNAV_HD PopKey make_key(float t, uint32_t id)
 {
-  const uint32_t d = (uint32_t)(trigger & kKeyDepthMax);
-  return (trigger & ~(PopKey)kKeyDepthMax) | (PopKey)(d < kKeyDepthMax ? d + 1u : kKeyDepthMax);
+  PopKey k; k.hi = key_pair(t, id); k.up = kNone; k.lvl = 0u;
+  return k;
 }
-MNAV_HD float key_time(PopKey k) { return u2f((uint32_t)(k >> 32)); }
-MNAV_HD PopKey key_inf() { return make_key(inf_f(), 0, 0); }
+MNAV_HD float key_time(const PopKey& k) { return u2f((uint32_t)(k.hi >> 32)); }   // pop time on the main front (bands)
+MNAV_HD PopKey key_inf() { return make_key(inf_f(), 0); }
+// A key together with the node's own (value, id) pair -- what comparisons work on.
+struct KeyRef { PopKey k; unsigned long long own; };
+MNAV_HD KeyRef key_ref_of(const PopKey& k, float d, uint32_t v) { KeyRef r; r.k = k; r.own = key_pair(d, v); return r; }
 
 
 // ---------------------------------------------------------------------------------------
@@ -204,6 +220,47 @@ struct Plan {
 
 MNAV_HD bool is_seed(const Plan& P, uint32_t v) { return v == P.seed[0] || v == P.seed[1] || v == P.seed[2]; }
 
+// --- pop keys as positions in the cascade forest (see PopKey) --------------------------------
+MNAV_HD KeyRef key_ref(const Plan& P, uint32_t u) { return key_ref_of(P.tkey[u], P.dist[u], u); }
+
+// a pops before b
+MNAV_HD bool key_less(const Plan& P, KeyRef a, KeyRef b)
+{
+  if (a.k.hi != b.k.hi) return a.k.hi < b.k.hi;                    // different main-front pops
+  for (int guard = 0; guard < kKeyWalkMax; ++guard) {              // same cascade: preorder, siblings by (value, id)
+    if (a.k.lvl == b.k.lvl) {
+      if (a.own == b.own) return false;                            // the same node
+      if (a.k.lvl == 0u || a.k.up == b.k.up) return a.own < b.own; // siblings
+      a = key_ref(P, a.k.up); b = key_ref(P, b.k.up);
+    } else if (a.k.lvl > b.k.lvl) {
+      if (a.k.up == pair_id(b.own)) return false;                  // b is an ancestor of a: pops first
+      if (a.k.up == kNone) break;
+      a = key_ref(P, a.k.up);
+    } else {
+      if (b.k.up == pair_id(a.own)) return true;
+      if (b.k.up == kNone) break;
+      b = key_ref(P, b.k.up);
+    }
+  }
+  return a.own < b.own;                                            // inconsistent (half-converged) tree: any total order
+}
+
+// key of vertex v whose value d was set by the pop `trig`
+MNAV_HD PopKey key_for(const Plan& P, float d, uint32_t v, KeyRef trig)
+{
+  const unsigned long long x = key_pair(d, v);
+  PopKey k;
+  if (x > trig.k.hi) { k.hi = x; k.up = kNone; k.lvl = 0u; return k; }   // at or above the main front: ordinary pop
+  k.hi = trig.k.hi;                                                // below it: inside the cascade of trig's root
+  KeyRef a = trig;                                                 // climb to the node whose sub-cascade v pops in:
+  for (int guard = 0; guard < kKeyWalkMax; ++guard) {              // the deepest ancestor-or-self of trig above v
+    if (a.k.lvl == 0u || x < a.own || a.k.up == kNone) break;
+    a = key_ref(P, a.k.up);
+  }
+  k.up = pair_id(a.own); k.lvl = a.k.lvl + 1u;
+  return k;
+}
+
 // --- arming of goal_dist once the robot vertex / robot face is settled -----------------------
 // Dijkstra: goal_dist = dist[target] + offset when the target pops (dijkstra :293-297).
 // CVP: when a robot-face vertex pops that passes the cut-offs while all three are fixed
@@ -217,22 +274,22 @@ MNAV_HD void try_arm(const Plan& P, Ctl& q)
     if (d < q.thr_fixed) { q.goal_dist = (float)((double)d + P.offset); q.armed = 1; }
     return;
   }
-  PopKey k_all = 0; bool have_all = false;         // pop key of the last goal vertex to get fixed
+  KeyRef k_all = key_ref_of(key_inf(), 0.0f, 0); bool have_all = false;   // pop key of the last goal vertex to get fixed
   for (int k = 0; k < 3; ++k) {
     const uint32_t g = P.target[k];
     if (g == kNone) return;
     if (is_seed(P, g)) continue;                 // fixed from the start
-    const PopKey kg = P.tkey[g];
-    if (!(key_time(kg) < q.thr_fixed)) return;   // not all fixed yet
-    if (!have_all || kg > k_all) { k_all = kg; have_all = true; }
+    const KeyRef kg = key_ref(P, g);
+    if (!(key_time(kg.k) < q.thr_fixed)) return; // not all fixed yet
+    if (!have_all || key_less(P, k_all, kg)) { k_all = kg; have_all = true; }
   }
-  PopKey best_k = 0; float best_d = 0.0f; uint32_t best_i = kNone;
+  KeyRef best_k = k_all; float best_d = 0.0f; uint32_t best_i = kNone;
   for (int k = 0; k < 3; ++k) {
     const uint32_t g = P.target[k];
     if (!P.target_expands[k]) continue;
-    const PopKey kg = P.tkey[g];
-    if (!(key_time(kg) < q.thr_fixed)) continue; // has not popped yet
-    if ((!have_all || kg >= k_all) && (best_i == kNone || kg < best_k)) { best_k = kg; best_d = P.dist[g]; best_i = g; }
+    const KeyRef kg = key_ref(P, g);
+    if (!(key_time(kg.k) < q.thr_fixed)) continue; // has not popped yet
+    if ((!have_all || !key_less(P, kg, k_all)) && (best_i == kNone || key_less(P, kg, best_k))) { best_k = kg; best_d = P.dist[g]; best_i = g; }
   }
   if (best_i != kNone) { q.goal_dist = (float)((double)best_d + P.offset); q.armed = 1; }
 }
@@ -308,7 +365,7 @@ struct Eval { float d; float t; PopKey key; uint32_t pred; float dir; uint32_t c
 // (strict '<' at :332): argmin (sum, dist[u], u) -- DESIGN.md "tie rule".
 MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
 {
-  Eval e; e.d = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.key = 0;
+  Eval e; e.d = inf_f(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.key = key_inf();
   float best_du = inf_f();
   const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
   for (uint32_t i = beg; i < end; ++i) {
@@ -328,23 +385,24 @@ MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
 // Fire event of face (v1,v2 -> v): the pop of a support that passes the cut-offs (cvp :754-760)
 // while the other support is already fixed (seed, or popped earlier).  Returns the pop key of the
 // earliest such pop; trig == kNone when the face cannot fire in this band.
-struct Fire { PopKey key; uint32_t trig; };
+struct Fire { KeyRef key; uint32_t trig; };
 
 MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
 {
-  Fire f; f.key = key_inf(); f.trig = kNone;
+  Fire f; f.key = key_ref_of(key_inf(), inf_f(), 0); f.trig = kNone;
   if (k.v1 == kNone) return f;
   const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
-  const PopKey k1 = P.tkey[k.v1], k2 = P.tkey[k.v2];
-  const float t1 = key_time(k1), t2 = key_time(k2);
+  const KeyRef k1 = key_ref(P, k.v1), k2 = key_ref(P, k.v2);
+  const float t1 = key_time(k1.k), t2 = key_time(k2.k);
   if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return f;         // both supports fixed by this band
   bool ex1 = true, ex2 = true;
   if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
   if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
-  const bool trig1 = t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && (s2 || k2 <= k1);
-  const bool trig2 = t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && (s1 || k1 <= k2);
+  const bool one_first = key_less(P, k1, k2);                        // v1 pops before v2
+  const bool trig1 = t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && (s2 || !one_first);
+  const bool trig2 = t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && (s1 || one_first || k1.own == k2.own);
   if (trig1) { f.key = k1; f.trig = k.v1; }
-  if (trig2 && (!trig1 || k2 < k1)) { f.key = k2; f.trig = k.v2; }
+  if (trig2 && (!trig1 || key_less(P, k2, k1))) { f.key = k2; f.trig = k.v2; }
   return f;
 }
 
@@ -356,34 +414,31 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 {
   Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
-  PopKey last = 0;
+  KeyRef last = key_ref_of(key_inf(), inf_f(), 0);
   bool first = true;
   for (;;) {
     // next trigger pop strictly after the last one
-    PopKey m = key_inf(); bool have = false;
+    KeyRef m = last; uint32_t m_trig = kNone;
     for (uint32_t i = beg; i < end; ++i) {
       const Fire f = corner_fire(P, c, P.crn[i]);
       if (f.trig == kNone) continue;
-      if (!first && !(f.key > last)) continue;
-      if (!have || f.key < m) { m = f.key; have = true; }
+      if (!first && !key_less(P, last, f.key)) continue;
+      if (m_trig == kNone || key_less(P, f.key, m)) { m = f.key; m_trig = f.trig; }
     }
-    if (!have) break;
-    if (!(m < e.key)) break;                              // v pops before this trigger
+    if (m_trig == kNone) break;
+    if (e.d < inf_f() && !key_less(P, m, key_ref_of(e.key, e.d, v))) break;   // v pops before this trigger
     bool any = false;
     for (uint32_t i = beg; i < end; ++i) {                // faces of this pop, ascending face id
       const Corner k = P.crn[i];
       const Fire f = corner_fire(P, c, k);
-      if (f.trig == kNone || f.key != m) continue;
+      if (f.trig != m_trig) continue;
       const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
       if (u.ok) {
         e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = k.face;
         any = true;
       }
     }
-    if (any) {
-      const PopKey own = make_key(e.d, v, 0), after = key_after(m);  // ordinary pop vs right after the trigger
-      e.key = own > after ? own : after;
-    }
+    if (any) e.key = key_for(P, e.d, v, m);                // ordinary pop, or a place inside the cascade of this trigger
     last = m; first = false;
   }
   if (!(e.d < inf_f())) { e.pred = v; e.key = key_inf(); }
@@ -404,7 +459,7 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
 {
   if (is_seed(P, v)) return;                                     // seeds are fixed from the start
   constexpr bool cvp = (PLANNER == kPlannerCvp);
-  PopKey old_key = 0;
+  PopKey old_key = key_inf();
   if constexpr (cvp) old_key = P.tkey[v];
   const float old_t = cvp ? key_time(old_key) : P.dist[v];
   if (old_t < c.thr_fixed) return;                               // settled by an earlier band

@@ -77,7 +77,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     const uint32_t s = seed_v[k];
     P.seed[k] = s;
     const float d = (planner == kPlannerCvp) ? seed_d[k] : 0.0f;
-    dist[s] = d; P.tkey[s] = make_key(d, s, 0);
+    dist[s] = d; P.tkey[s] = make_key(d, s);
     if (planner == kPlannerCvp) {
       cutf[s] = seed_face;
       P.seed_expands[k] = !((double)vertex_costs[s] >= cost_limit) && !(invalid && invalid[s]);  // cvp :757,760
@@ -94,6 +94,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   }
   // initial list: neighbours of the seeds
   Cnt& c_init = cnt[2];   // "(0-1) mod 3"
+  cnt[0].minkey = cnt[1].minkey = f2u(inf_f());                  // like k_seed
   c_init.minkey = f2u(inf_f());
   {
     HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu };
@@ -113,9 +114,14 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   Ctl& c0 = ctl[1];
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = m0 + delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
+  for (int k = 0; k < ns; ++k) {                                   // the first band holds every seed (like k_seed)
+    const float d = (planner == kPlannerCvp) ? seed_d[k] : 0.0f;
+    if (!(d < c0.thr)) c0.thr = next_up(d);
+  }
   c0.band_new = 1; c0.width = delta;
 
   uint64_t evals = 0, rng = 88172645463325252ull;
+  const uint32_t trace_v = getenv("SM_TRACE_V") ? (uint32_t)atoi(getenv("SM_TRACE_V")) : kNone;   // debugging aid
   int j = 0;
   Ctl cur;
   std::vector<uint32_t> perm;
@@ -165,8 +171,19 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
         }
       } else
       for (uint32_t i = 0; i < cur.n; ++i) {
-        if (planner == kPlannerCvp) process_entry<kPlannerCvp>(P, cur, list[perm[i]], ops);
-        else process_entry<kPlannerDijkstra>(P, cur, list[perm[i]], ops);
+        const uint32_t vv = list[perm[i]];
+        const bool tr = trace_v == vv;
+        const float bd = dist[vv];
+        if (planner == kPlannerCvp) process_entry<kPlannerCvp>(P, cur, vv, ops);
+        else process_entry<kPlannerDijkstra>(P, cur, vv, ops);
+        if (tr) {
+          fprintf(stderr, "step %d thr [%.6f, %.6f) band_new %u v %u: d %.7f -> %.7f key t0 %.7f up %.0f lvl %u dirty %u\n", j, cur.thr_fixed, cur.thr, cur.band_new, vv, bd, dist[vv], key_time(tkey[vv]), (double)tkey[vv].up, (unsigned)tkey[vv].lvl, dirty[vv]);
+          for (uint32_t ci = P.crn_ptr[vv]; ci < P.crn_ptr[vv + 1]; ++ci) {
+            const Corner k = P.crn[ci];
+            const Fire f = corner_fire(P, cur, k);
+            fprintf(stderr, "    corner face %u v1 %u (d %.7f t0 %.7f up %.0f lvl %u) v2 %u (d %.7f t0 %.7f up %.0f lvl %u) trig %u\n", k.face, k.v1, dist[k.v1], key_time(tkey[k.v1]), (double)tkey[k.v1].up, (unsigned)tkey[k.v1].lvl, k.v2, dist[k.v2], key_time(tkey[k.v2]), (double)tkey[k.v2].up, (unsigned)tkey[k.v2].lvl, f.trig);
+          }
+        }
       }
     }
     evals += cc.evals;

@@ -159,11 +159,11 @@ def test_cvp_seed_face_equals_target_face_and_blocked_seed():
     assert np.array_equal(mod2["pred"], ref2.pred)
 
 
-def test_cvp_adversarial_weights_converge():
+def test_cvp_adversarial_weights_bit_exact():
     """Random per-vertex costs up to 1.2 with edge_cost_factor 1: single edges are inflated by up to
     2.2x, most triangles violate the triangle inequality and updates undercut the pop front in
-    nested chains.  The schedule must terminate in every interleaving (well-founded pop keys); the
-    exact sibling order inside such chains is approximated (known limitation)."""
+    nested cascades.  The pop keys order such pops exactly (cascade forest, mnav_eval.h::PopKey), so the
+    schedule reproduces the sequential loop bit for bit in every interleaving and for every band width."""
     mesh = meshgen.terrain(96, 0.1, 13)
     rng = np.random.default_rng(3)
     costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
@@ -174,17 +174,14 @@ def test_cvp_adversarial_weights_converge():
     case = Case(mesh, costs, 1.0, invalid)
     sp = mesh.xyz[s] + np.array([0.03, 0.02, 0], np.float32)
     tp = mesh.xyz[t] + np.array([0.03, 0.02, 0], np.float32)
-    for order in (0, 3):
-        ref, mod = run_cvp(case, sp, tp, delta=0.36, order=order, max_steps=100000)
+    for delta, order in ((0.12, 2), (0.36, 0), (0.36, 3), (1.4, 3)):
+        ref, mod = run_cvp(case, sp, tp, delta=delta, order=order, max_steps=200000)
         assert mod["code"] == 0
-        fin = np.isfinite(ref.dist)
-        assert np.array_equal(np.isfinite(mod["dist"]), fin)
-        rel = np.abs(mod["dist"][fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
-        assert (rel > 1e-5).mean() < 0.05
-    # moderate random costs (edges inflated by up to 1.6x): bit-exact again
-    case2 = Case(mesh, (costs * 0.5).astype(np.float32), 1.0, invalid)
-    ref2, mod2 = run_cvp(case2, sp, tp, delta=0.36, order=3, max_steps=100000)
-    assert np.array_equal(mod2["dist"].view(np.uint32), ref2.dist.view(np.uint32))
+        assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(mod["pred"], ref.pred)
+        upd = ref.pred != np.arange(mesh.V)
+        assert np.array_equal(mod["cutface"][upd], ref.cutface[upd])
+        assert np.array_equal(mod["direction"][upd], ref.direction[upd])
 
 
 @pytest.mark.parametrize("mult", [3, 12, 24])
@@ -234,7 +231,9 @@ def test_schedule_on_ragged_meshes(which):
     tf = int(np.where((mesh.faces == t).any(axis=1))[0][0])
     sp = mesh.xyz[mesh.faces[sf]].mean(axis=0).astype(np.float32)
     tp = mesh.xyz[mesh.faces[tf]].mean(axis=0).astype(np.float32)
-    for order in (0, 3):
-        ref, mod = run_cvp(case, sp, tp, delta=0.3, order=order)
+    # (on the punched mesh the wave wraps around the holes and fills their shadows backwards: deep cascades
+    # of pops below the main front; a band narrower than the spread of the seed values is covered too)
+    for delta, order in ((0.3, 0), (0.3, 3), (0.02, 2), (1.0, 3)):
+        ref, mod = run_cvp(case, sp, tp, delta=delta, order=order)
         assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
         assert np.array_equal(mod["pred"], ref.pred)
