@@ -29,13 +29,21 @@ def assert_dijkstra_equal(out, ref, case=None):
 
 
 def assert_cvp_close(out, ref):
+    """The north_star bar for the CVP potential is 1e-5 relative; since the pop order is reproduced exactly
+    (cascade-forest pop keys) the device matches the oracle bit for bit -- potential, predecessors, cutting
+    faces and directions -- and that is what is asserted."""
     assert out.code == ref.code
     fin = np.isfinite(ref.dist)
     assert np.array_equal(np.isfinite(out.dist), fin), "reached sets differ"
     rel = np.abs(out.dist[fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
-    assert rel.max() <= CVP_RTOL, f"CVP potential: max rel err {rel.max()}"
-    assert (out.pred != ref.pred).mean() < 1e-3
-    return float(rel.max())
+    assert (rel.max() if fin.any() else 0.0) <= CVP_RTOL, f"CVP potential: max rel err {rel.max()}"
+    assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)), "CVP potential must be bit-exact"
+    assert np.array_equal(out.pred, ref.pred)
+    upd = ref.pred != np.arange(len(ref.pred))
+    if getattr(out, "cutface", None) is not None and getattr(ref, "cutface", None) is not None:
+        assert np.array_equal(out.cutface[upd], ref.cutface[upd])
+        assert np.array_equal(out.direction[upd].view(np.uint32), ref.direction[upd].view(np.uint32))
+    return float(rel.max()) if fin.any() else 0.0
 
 
 @pytest.fixture(scope="module")
@@ -303,6 +311,7 @@ def test_cvp_batch_equals_single_plans(c1):
         assert np.array_equal(np.isfinite(b["dist"][k]), fin)
         rel = np.abs(b["dist"][k][fin] - ref.dist[fin]) / np.maximum(ref.dist[fin], 1e-12)
         assert rel.max() <= CVP_RTOL
+        assert np.array_equal(b["dist"][k].view(np.uint32), ref.dist.view(np.uint32))
         single = ctx.plan_cvp(sps[k], int(sfs[k]), int(tfs[k]))
         assert np.array_equal(single.dist.view(np.uint32), b["dist"][k].view(np.uint32))
         assert np.array_equal(single.vecmap.view(np.uint32), b["vecmap"][k].view(np.uint32))
