@@ -152,7 +152,7 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
     if (i < end) {
       const Corner k = P.crn[i];
       const Fire f = corner_fire(P, c, k);
-      if (f.trig != kNone) {
+      if (f.trig != kNone && !key_descends_from(P, f.trig, v)) {       // (spec: eval_cvp)
         it[r].valid = true; it[r].fk = f.key; it[r].trig = f.trig;
         it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
         it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = k.face;
@@ -262,7 +262,7 @@ template <uint32_t PLANNER, bool REPAIR>
 __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const Ctl& c, bool active, uint32_t v, int sub)
 {
   constexpr bool cvp = (PLANNER == kPlannerCvp);
-  bool push_nb = false, retain = false;
+  bool push_nb = false, retain = false, self_again = false;
   float t_new = inf_f();
   if (active && !is_seed(P, v)) {
     const float old_d = P.dist[v];
@@ -291,6 +291,7 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
           const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
           push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
           retain = !now_in && e.t < inf_f();
+          if constexpr (cvp) self_again = (e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key;   // spec: process_entry
         }
       } else {
         t_new = old_t;
@@ -298,8 +299,9 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
       if (REPAIR) retain = (t_new >= c.thr) && (t_new < inf_f());
     }
   }
-  if (push_nb && sub == 0) S.lchanged = true;
+  if ((push_nb || self_again) && sub == 0) S.lchanged = true;
   group_push_neighbours<PLANNER>(S, P, v, sub, push_nb);
+  push_agg<true>(S, self_again && sub == 0, v);
   push_agg<false>(S, retain && sub == 0, v);
   if (retain && sub == 0) S.lmin = fminf(S.lmin, t_new);
 }

@@ -261,6 +261,21 @@ MNAV_HD PopKey key_for(const Plan& P, float d, uint32_t v, KeyRef trig)
   return k;
 }
 
+// Does the stored key of t place it inside the sub-cascade of v (v is an ancestor of t)?  Such a t pops
+// after v, so it can never be a trigger FOR v; in a half-converged state it must not act as one either,
+// or the two would keep supporting each other (v set by its own child, the child by v, ...).
+constexpr int kDescendWalkMax = 64;
+MNAV_HD bool key_descends_from(const Plan& P, uint32_t t, uint32_t v)
+{
+  PopKey a = P.tkey[t];                                            // (no shortcut through hi / lvl: both may be stale)
+  for (int guard = 0; guard < kDescendWalkMax && a.lvl > 0u; ++guard) {
+    if (a.up == v) return true;
+    if (a.up == kNone) return false;
+    a = P.tkey[a.up];
+  }
+  return false;
+}
+
 // --- arming of goal_dist once the robot vertex / robot face is settled -----------------------
 // Dijkstra: goal_dist = dist[target] + offset when the target pops (dijkstra :293-297).
 // CVP: when a robot-face vertex pops that passes the cut-offs while all three are fixed
@@ -421,7 +436,7 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
     KeyRef m = last; uint32_t m_trig = kNone;
     for (uint32_t i = beg; i < end; ++i) {
       const Fire f = corner_fire(P, c, P.crn[i]);
-      if (f.trig == kNone) continue;
+      if (f.trig == kNone || key_descends_from(P, f.trig, v)) continue;
       if (!first && !key_less(P, last, f.key)) continue;
       if (m_trig == kNone || key_less(P, f.key, m)) { m = f.key; m_trig = f.trig; }
     }
@@ -479,6 +494,10 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
   if (changed) {
     W.dist[v] = e.d; W.pred[v] = e.pred;
     if constexpr (cvp) { W.tkey[v] = e.key; W.dirn[v] = e.dir; W.cutf[v] = e.cut; }
+  }
+  if constexpr (cvp) {
+    // the rule reads v's own stored key (key_descends_from): a cascade member whose key moved looks again
+    if ((e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key) { ops.push_dirty(v); ops.note_changed(); }
   }
   const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
   if ((changed && (was_in || now_in)) || (now_in && c.band_new)) {

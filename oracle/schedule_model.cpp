@@ -187,6 +187,17 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
       }
     }
     evals += cc.evals;
+    if (getenv("SM_CYCLE") && j >= atoi(getenv("SM_CYCLE")) && j < atoi(getenv("SM_CYCLE")) + 8) {   // debugging aid
+      static std::vector<float> pd; static std::vector<PopKey> pk;
+      if (pd.size() == V) {
+        fprintf(stderr, "== step %d thr [%.7f, %.7f) n=%u changed=%u\n", j, cur.thr_fixed, cur.thr, cur.n, cc.changed);
+        for (uint32_t v = 0; v < V; ++v)
+          if (f2u(pd[v]) != f2u(dist[v]) || pk[v] != tkey[v])
+            fprintf(stderr, "   v %u: d %.7f -> %.7f  key (t0 %.7f root %u up %d lvl %u) -> (t0 %.7f root %u up %d lvl %u) pred %u\n", v, pd[v], dist[v],
+                    key_time(pk[v]), pair_id(pk[v].hi), (int)pk[v].up, pk[v].lvl, key_time(tkey[v]), pair_id(tkey[v].hi), (int)tkey[v].up, tkey[v].lvl, pred[v]);
+      }
+      pd.assign(dist, dist + V); pk = tkey;
+    }
   }
   if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks; }
   if (goal_dist_out) *goal_dist_out = cur.goal_dist;

@@ -93,3 +93,37 @@ def test_cvp_c3_layered_costs_1m(gpu_ctx_factory):
     refd = case.om.dijkstra(case.weights, case.costs, s, t)
     outd = ctx.plan_dijkstra(s, t)
     assert np.array_equal(outd.dist.view(np.uint32), refd.dist.view(np.uint32)) and np.array_equal(outd.path, refd.path)
+
+
+def test_punched_terrain_1m_deep_cascades(gpu_ctx_factory):
+    """1M-vertex terrain with 20 % of its faces removed: the CVP wave wraps around thousands of holes and
+    fills their shadows backwards (cascades of pops below the main front, nested hundreds of levels deep).
+    Both planners must still match the sequential oracle bit for bit."""
+    mesh = meshgen.punched(1000, 0.1, 7, drop=0.2)
+    case = Case(mesh)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    assert (deg == 0).sum() > 0
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    while deg[s] == 0: s += 1
+    while deg[t] == 0: t += 1
+    ref = case.om.dijkstra(case.weights, case.costs, s, t)
+    for engine in ("tiled", "persistent"):
+        ctx.set_dijkstra_engine(engine)
+        out = ctx.plan_dijkstra(s, t)
+        assert out.code == ref.code == 0
+        assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(out.pred, ref.pred) and np.array_equal(out.path, ref.path)
+    ctx.set_dijkstra_engine("auto")
+    sf = int(np.where((mesh.faces == s).any(axis=1))[0][0])
+    tf = int(np.where((mesh.faces == t).any(axis=1))[0][0])
+    sp = mesh.xyz[mesh.faces[sf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    refc = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    outc = ctx.plan_cvp(sp, sf, tf)
+    assert outc.code == refc.code == 0
+    assert np.array_equal(outc.dist.view(np.uint32), refc.dist.view(np.uint32))
+    assert np.array_equal(outc.pred, refc.pred)
+    upd = refc.pred != np.arange(mesh.V)
+    assert np.array_equal(outc.cutface[upd], refc.cutface[upd])
+    assert np.array_equal(outc.direction[upd].view(np.uint32), refc.direction[upd].view(np.uint32))

@@ -237,3 +237,27 @@ def test_schedule_on_ragged_meshes(which):
         ref, mod = run_cvp(case, sp, tp, delta=delta, order=order)
         assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
         assert np.array_equal(mod["pred"], ref.pred)
+
+
+@pytest.mark.parametrize("order", [0, 2, 3])
+def test_cvp_deep_cascades_converge_without_band_shrink(order):
+    """200x200 terrain with 20 % of the faces punched out, band of 12 mean edges: cascades nest over a
+    thousand levels deep.  Regression for two transient traps of the gather iteration: a vertex adopting its
+    own (stale) child as a trigger, and a vertex whose result depends on its own stored key not looking again."""
+    mesh = meshgen.punched(200, 0.1, 7, drop=0.2)
+    case = Case(mesh)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    while deg[s] == 0: s += 1
+    while deg[t] == 0: t += 1
+    sf = int(np.where((mesh.faces == s).any(axis=1))[0][0])
+    tf = int(np.where((mesh.faces == t).any(axis=1))[0][0])
+    sp = mesh.xyz[mesh.faces[sf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    tp = mesh.xyz[mesh.faces[tf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    mean_w = float(case.weights[np.isfinite(case.weights)].mean())
+    ref, mod = run_cvp(case, sp, tp, delta=12 * mean_w, order=order, max_steps=100000)
+    assert mod["code"] == 0
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+    if order != 3:
+        assert mod["shrinks"] == 0
