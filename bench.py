@@ -60,7 +60,15 @@ def main() -> None:
     edge_w = meshgen.edge_lengths(mesh)                  # edge_cost_factor 0 -> weights == edge distances
     costs = np.zeros(mesh.V, np.float32)
     ctx = capi.MnavContext(local_rank)
-    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
+    # vertex normals (normalised sum of unit face normals) -- only the CVP vector map reads them
+    p = mesh.xyz.astype(np.float64)
+    fnrm = np.cross(p[mesh.faces[:, 1]] - p[mesh.faces[:, 0]], p[mesh.faces[:, 2]] - p[mesh.faces[:, 0]])
+    fnrm /= np.maximum(np.linalg.norm(fnrm, axis=1, keepdims=True), 1e-30)
+    vnrm = np.zeros_like(p)
+    for k in range(3):
+        np.add.at(vnrm, mesh.faces[:, k], fnrm)
+    vnrm /= np.maximum(np.linalg.norm(vnrm, axis=1, keepdims=True), 1e-30)
+    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, vnrm.astype(np.float32))
     ctx.upload_costs(costs, edge_w)
     robot = mesh.vertex_at(0.9, 0.9)
     rng = np.random.default_rng(5 + 1000 * rank)
@@ -111,6 +119,34 @@ def main() -> None:
         single_ms = float(np.median(lat))
         single_p95 = float(np.percentile(lat, 95))
 
+    # the second planner on the same mesh (CVP / FMM wavefront, cvp_mesh_planner.cpp:651-918): single-plan
+    # latency and a batch of 128 -- reported next to the headline metric, not part of `value`
+    cvp = None
+    if rank == 0 and not args.no_latency:
+        first_face = np.full(mesh.V, -1, np.int64)
+        fl = mesh.faces.ravel()
+        first_face[fl[::-1]] = (np.arange(fl.size)[::-1] // 3)           # some face of every vertex
+        def wave_seed(v):
+            f = int(first_face[v])
+            return mesh.xyz[mesh.faces[f]].astype(np.float64).mean(axis=0).astype(np.float32), f
+        tf = int(first_face[robot])
+        lat = []
+        for k in range(13):
+            sp, sf = wave_seed(int(first[0][k % B]))
+            o = ctx.plan_cvp(sp, sf, tf, want_fields=False, want_vecmap=False)
+            assert o.code == 0, o.code
+            if k >= 3:
+                lat.append(o.stats["ms_total"])
+        nb = 128
+        seeds = [wave_seed(int(v)) for v in first[0][:nb]]
+        sps = np.stack([x[0] for x in seeds]); sfs = np.array([x[1] for x in seeds], np.uint32)
+        ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
+        tb = time.perf_counter()
+        rb = ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
+        tb = time.perf_counter() - tb
+        cvp = {"ms_per_makeplan_single": float(np.median(lat)), "ms_per_makeplan_single_p95": float(np.percentile(lat, 95)),
+               "batch": nb, "plans_per_s_batch": nb / tb, "codes_ok": bool((rb["codes"] == 0).all())}
+
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -152,6 +188,7 @@ def main() -> None:
             "ms_per_makeplan_single": single_ms,
             "ms_per_makeplan_single_p95": single_p95,
             "ms_per_plan_in_batch": ms_step / B,
+            "cvp_planner_same_mesh": cvp,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_plan_persistent" if launches <= args.steps else "k_tile_round", "launches_per_step": launches / args.steps,

@@ -66,8 +66,9 @@ const char* mnav_last_error(const mnav_ctx* ctx);
 
 /* Upload the half-edge mesh once (MeshMap::mesh(), mesh_map.h:276-279) as flat arrays:
  * xyz V*3, face_vtx F*3 (reference face order), edge_vtx E*2 (reference edge ids),
- * vertex_normals V*3 (MeshMap::vertexNormals(), mesh_map.h:326-337; may be NULL if CVP
- * vector maps are never requested).  Returns 0 on success, <0 on error. */
+ * vertex_normals V*3 (MeshMap::vertexNormals(), mesh_map.h:326-337; may be NULL if only the
+ * Dijkstra planner is used: mnav_plan_cvp needs them for its vector map).  Returns 0 on success,
+ * <0 on error. */
 int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const float* xyz,
                      const uint32_t* face_vtx, const uint32_t* edge_vtx,
                      const float* vertex_normals);
