@@ -34,9 +34,14 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "1280")))
     ap.add_argument("--grid", type=int, default=int(os.environ.get("MNAV_BENCH_N", "1000")))
+    ap.add_argument("--offset", type=float, default=float(os.environ.get("MNAV_BENCH_OFFSET", "0.3")),
+                    help="goal_dist_offset (reference default 0.3; inf = full-field variant of SURVEY.md 8d)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-all-cores-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-latency", action="store_true", help="skip the single-plan latency runs (profiling)")
     args = ap.parse_args()
+    if args.cpu_all_cores_child:
+        return cpu_all_cores_child(args)
 
     import torch
 
@@ -86,7 +91,7 @@ def main() -> None:
     first = None
     for _ in range(max(args.warmup, 0)):
         g, t = batch_goals()
-        r = ctx.plan_dijkstra_batch(g, t, want_fields=False, path_cap=16384)
+        r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
         if first is None:
             first = (g, t, r)
     prop_ms = kern_ms = launches = algo = 0.0
@@ -95,7 +100,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g, t = batch_goals()
-        r = ctx.plan_dijkstra_batch(g, t, want_fields=False, path_cap=16384)
+        r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
         assert (r["codes"] == 0).all(), r["codes"]
         st = r["stats"]
         prop_ms += st["ms_propagation"]; kern_ms += st["ms_step_kernels"]; launches += st["launches"]; algo += st["algorithmic_bytes"]
@@ -113,7 +118,7 @@ def main() -> None:
         # SURVEY.md §8d protocol: 3 warm-ups, 20 timed plans (different goals), median and p95
         lat = []
         for k in range(23):
-            o = ctx.plan_dijkstra(int(first[0][k % B]), robot, want_fields=False)
+            o = ctx.plan_dijkstra(int(first[0][k % B]), robot, goal_dist_offset=args.offset, want_fields=False)
             if k >= 3:
                 lat.append(o.stats["ms_total"])
         single_ms = float(np.median(lat))
@@ -182,7 +187,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"C2: delta-stepping SSSP (tiled label-correcting), {N}x{N} terrain = {mesh.V} vertices, "
-                                   f"uniform edge costs, batch of {B} goals per step per GPU, common robot vertex, goal_dist_offset 0.3",
+                                   f"uniform edge costs, batch of {B} goals per step per GPU, common robot vertex, goal_dist_offset {args.offset:g}",
                        "vertices": mesh.V, "edges": mesh.E, "batch_per_gpu": B,
                        "parallelism": f"{world} independent replicas (plans sharded by rank)"},
             "ms_per_makeplan_single": single_ms,
@@ -197,7 +202,7 @@ def main() -> None:
                          "settled_vertices_per_plan": settled / max(args.steps * B, 1)},
         }
         if not args.no_cpu and world >= 1:
-            out["cpu_baseline"] = cpu_baseline(mesh, edge_w, costs, first, B)
+            out["cpu_baseline"] = cpu_baseline(mesh, edge_w, costs, first, B, args.offset)
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
@@ -205,7 +210,42 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(mesh, edge_w, costs, first, B):
+_OM = None
+
+
+def cpu_all_cores_child(args):
+    """CPU only (no torch, no HIP): the oracle on every host core, same mesh / goals / robot vertex as the GPU run."""
+    import multiprocessing as mp
+    from mesh_navigation_amd import meshgen
+    from oracle import oracle as O
+    global _OM
+    mesh = meshgen.terrain(args.grid, 0.1, 2)
+    edge_w = meshgen.edge_lengths(mesh)
+    costs = np.zeros(mesh.V, np.float32)
+    _OM = O.OracleMesh(mesh.xyz, mesh.faces)
+    robot = mesh.vertex_at(0.9, 0.9)
+    goals = np.random.default_rng(5).choice(mesh.V, size=args.batch, replace=False)
+    cores = os.cpu_count() or 1
+    per = 2
+    jobs = [(edge_w, costs, [int(goals[(c * per + i) % args.batch]) for i in range(per)], robot, args.offset) for c in range(cores)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_worker, jobs, chunksize=1)                      # warm: page in the forked mesh
+        ta = time.perf_counter()
+        done = sum(pool.map(_oracle_worker, jobs, chunksize=1))
+        ta = time.perf_counter() - ta
+    print(json.dumps({"value": done / ta, "unit": "plans/s", "cores": cores,
+                      "sample": f"{done} plans, {per} per forked worker, {ta:.2f} s wall"}), flush=True)
+
+
+def _oracle_worker(job):
+    """One host core: plans a few goals with the forked, read-only oracle mesh."""
+    edge_w, costs, goals, target, offset = job
+    for g in goals:
+        _OM.dijkstra(edge_w, costs, int(g), int(target), goal_dist_offset=offset)
+    return len(goals)
+
+
+def cpu_baseline(mesh, edge_w, costs, first, B, offset=0.3):
     """The oracle (C restatement of dijkstra_mesh_planner.cpp:217-398, -O3, one thread) timed on this
     box's host cores on the plans of the first batch; also checks the GPU paths of that batch."""
     from oracle import oracle as O
@@ -216,7 +256,7 @@ def cpu_baseline(mesh, edge_w, costs, first, B):
     ok = True
     tw = time.perf_counter()
     for k in range(n):
-        ref = om.dijkstra(edge_w, costs, int(g[k]), int(t[k]))
+        ref = om.dijkstra(edge_w, costs, int(g[k]), int(t[k]), goal_dist_offset=offset)
         t_sum += ref.stats["t_init_ms"] + ref.stats["t_propagation_ms"] + ref.stats["t_backtrack_ms"]
         ok = ok and ref.code == int(r["codes"][k]) and np.array_equal(ref.path, r["paths"][k])
     wall = time.perf_counter() - tw
@@ -228,7 +268,18 @@ def cpu_baseline(mesh, edge_w, costs, first, B):
                 break
     except OSError:
         pass
-    return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port",
+    # the same oracle on ALL host cores: measured by a fresh child process that never loads
+    # the GPU runtime and forks one worker per core over the shared, read-only mesh
+    all_cores = None
+    try:
+        import subprocess
+        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-all-cores-child", "--grid", str(mesh.N),
+                             "--offset", repr(float(offset)), "--batch", str(B)], capture_output=True, text=True, timeout=120)
+        lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+        all_cores = json.loads(lines[-1]) if lines else {"error": (cp.stderr or "no output")[-300:]}
+    except Exception as e:                                               # the single-core figure stands on its own
+        all_cores = {"error": repr(e)}
+    return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "all_host_cores": all_cores,
             "sample": f"first {n} plans of the first batch, oracle Dijkstra single thread, {wall:.1f} s wall",
             "ms_per_plan": t_sum / n, "host_cpu": model, "host_cores_available": os.cpu_count(),
             "gpu_paths_match_oracle": bool(ok)}
