@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- plans/sec of the MI355X wavefront planner on BASELINE config C2.
 
-One "step" = one batch of B (default 1280 = 5 resident plans per CU) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex
+One "step" = one batch of B (default 5120 = 4 x the 1280 plans the device runs at once, longest first) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex
 synthetic terrain (N=1000, h=0.1 m, seed 2, edge_cost_factor 0, reference default
 cut-offs goal_dist_offset 0.3 / cost_limit 1.0), B goal vertices drawn per step, common robot
 vertex (the concurrent-goals shape of BASELINE config 5).  Mesh and costs are resident in HBM
@@ -32,7 +32,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "1280")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "5120")))
     ap.add_argument("--grid", type=int, default=int(os.environ.get("MNAV_BENCH_N", "1000")))
     ap.add_argument("--offset", type=float, default=float(os.environ.get("MNAV_BENCH_OFFSET", "0.3")),
                     help="goal_dist_offset (reference default 0.3; inf = full-field variant of SURVEY.md 8d)")

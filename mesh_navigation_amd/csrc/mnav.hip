@@ -1084,8 +1084,7 @@ __global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
     P.dist[v] = inf_f();
     P.pred[v] = v;
-    P.stamp[v] = 0u;
-    P.dirty[v] = 0u;
+    if (P.stamp) { P.stamp[v] = 0u; P.dirty[v] = 0u; }              // work-list state of the band steps only
     if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; }
   }
 }
@@ -1328,7 +1327,7 @@ struct Slot {
   uint32_t *pred = nullptr, *cutf = nullptr, *stamp = nullptr, *dirty = nullptr, *list0 = nullptr, *list1 = nullptr;
   Ctl* ctl = nullptr;
   Cnt* cnt = nullptr;
-  bool cvp_ready = false;
+  bool cvp_ready = false, band_ready = false;
   // tiled engine
   uint32_t *tpend0 = nullptr, *tpend1 = nullptr;
   float* tlast = nullptr;
@@ -1347,6 +1346,8 @@ struct mnav_ctx {
   // host copies needed for seeding
   uint32_t V = 0, F = 0, E = 0;
   std::vector<float> h_xyz, h_cost;
+  bool want_vec = false;               // the running call asked for vector maps (lazy 12 B/vertex/plan)
+  std::vector<uint32_t> caller_slot;   // plan index of the caller's batch -> device slot of the last call (kNone: never ran)
   std::vector<uint32_t> h_faces;
   std::vector<uint8_t> h_invalid;
   bool have_mesh = false, have_costs = false, have_normals = false;
@@ -1434,16 +1435,23 @@ void drop_graphs(mnav_ctx* ctx)
   ctx->graphs.clear();
 }
 
-int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp)
+int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp, bool band, bool vec)
 {
   const size_t V = ctx->V ? ctx->V : 1;
   while (ctx->slots.size() < n) {
     Slot s;
-    HIPCHK(hipMalloc((void**)&s.dist, 4 * V)); HIPCHK(hipMalloc((void**)&s.pred, 4 * V));
-    HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.dirty, 4 * V)); HIPCHK(hipMalloc((void**)&s.list0, 4 * V));
-    HIPCHK(hipMalloc((void**)&s.list1, 4 * V)); HIPCHK(hipMalloc((void**)&s.vecmap, 12 * V));
+    HIPCHK(hipMalloc((void**)&s.dist, 4 * V)); HIPCHK(hipMalloc((void**)&s.pred, 4 * V));   // 8 B per vertex and plan ...
     HIPCHK(hipMalloc((void**)&s.cnt, 3 * sizeof(Cnt)));
     ctx->slots.push_back(s);
+  }
+  for (uint32_t i = 0; i < n; ++i) {                                   // ... the rest only for the paths that use it
+    Slot& s = ctx->slots[i];
+    if (band && !s.band_ready) {                                       // work lists of the band/gather steps
+      HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.dirty, 4 * V));
+      HIPCHK(hipMalloc((void**)&s.list0, 4 * V)); HIPCHK(hipMalloc((void**)&s.list1, 4 * V));
+      s.band_ready = true;
+    }
+    if (vec && !s.vecmap) HIPCHK(hipMalloc((void**)&s.vecmap, 12 * V));
   }
   if (cvp)
     for (uint32_t i = 0; i < n; ++i) {
@@ -1567,7 +1575,7 @@ template <uint32_t PLANNER>
 int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, bool want_path)
 {
   constexpr bool cvp = PLANNER == kPlannerCvp;
-  if (ensure_slots(ctx, n, cvp)) return -1;
+  if (ensure_slots(ctx, n, cvp, true, cvp || ctx->want_vec)) return -1;
   if (want_path && ensure_paths(ctx, n)) return -1;
   // default band width: 3 mean edge weights for the Dijkstra gather steps, 12 for CVP (measured on C3:
   // fewer, fuller bands -- 20 % less time for one plan and for batches; results do not depend on it)
@@ -1723,7 +1731,7 @@ int run_tile_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G)
 // Dijkstra through the tiled engine.  Returns 0, -1 (error) or 1 (cancelled).
 int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
-  if (ensure_slots(ctx, n, false)) return -1;
+  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
   if (ensure_paths(ctx, n)) return -1;
   if (ensure_tile_state(ctx, n)) return -1;
   if (tile_weights(ctx)) return -1;
@@ -1817,7 +1825,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
 // Dijkstra batches through the persistent per-plan kernel.  Returns 0 or -1.
 int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
-  if (ensure_slots(ctx, n, false)) return -1;
+  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
   if (ensure_paths(ctx, n)) return -1;
   if (ensure_tile_state(ctx, n)) return -1;
   if (tile_weights(ctx)) return -1;
@@ -2186,6 +2194,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
   ctx->cancel.store(0);                                               // dijkstra :238
+  ctx->want_vec = want_vecmap;
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
   const uint32_t V = ctx->V;
   uint32_t worst = MNAV_SUCCESS;
@@ -2203,6 +2212,26 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     p.seed[0] = seeds[i]; p.target[0] = targets[i]; p.seed_face = kNone;
     in.push_back(p); map.push_back(i);
   }
+  // Longest plans first: a plan's work grows with the area its wave sweeps before it reaches the robot
+  // vertex, i.e. with the squared seed-target distance.  Workgroups are dispatched in plan order, so when a
+  // batch holds more plans than the device runs at once the short ones back-fill behind the long ones
+  // instead of leaving a tail (results are mapped back through `map`).
+  if (in.size() > 1 && ctx->h_xyz.size() == 3 * (size_t)V) {
+    std::vector<uint32_t> ord(in.size());
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::vector<float> est(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+      const float* a = &ctx->h_xyz[3 * (size_t)in[i].seed[0]];
+      const float* b = &ctx->h_xyz[3 * (size_t)in[i].target[0]];
+      est[i] = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return est[x] > est[y]; });
+    std::vector<PlanIn> in2(in.size()); std::vector<uint32_t> map2(in.size());
+    for (size_t i = 0; i < in.size(); ++i) { in2[i] = in[ord[i]]; map2[i] = map[ord[i]]; }
+    in.swap(in2); map.swap(map2);
+  }
+  ctx->caller_slot.assign(n, kNone);
+  for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   const uint32_t m = (uint32_t)in.size();
   ctx->last_planner = kPlannerDijkstra; ctx->last_n = m;
@@ -2341,6 +2370,8 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
     sp.insert(sp.end(), seed_pos + 3 * (size_t)i, seed_pos + 3 * (size_t)i + 3);
   }
   const uint32_t m = (uint32_t)in.size();
+  ctx->caller_slot.assign(n, kNone);
+  for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   ctx->last_planner = kPlannerCvp; ctx->last_n = m;
   uint32_t worst = MNAV_SUCCESS;
@@ -2436,7 +2467,9 @@ int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 
 const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
 {
-  if (!ctx || slot >= ctx->slots.size()) return nullptr;
+  if (!ctx) return nullptr;
+  if (slot < ctx->caller_slot.size()) slot = ctx->caller_slot[slot];      // caller's plan index -> device slot
+  if (slot >= ctx->slots.size()) return nullptr;
   const Slot& s = ctx->slots[slot];
   switch (what) {
     case 0: return s.dist;
