@@ -28,4 +28,4 @@ for B in (1, 8, 32, 64, 128):
     out[B] = dict(wall_ms=dt * 1e3, plans_per_s=B / dt, steps=st["steps"], ms_prop=st["ms_propagation"], ms_kern=st["ms_step_kernels"], codes_ok=int((b["codes"] == 0).sum()), algo=st["algorithmic_bytes"])
     print(B, out[B], flush=True)
 t0 = time.time(); ref = case.om.cvp(case.weights, case.costs, case.vn, sps[0], int(sfs[0]), tf); print("oracle cvp ms", (time.time() - t0) * 1e3, ref.stats["t_propagation_ms"])
-json.dump(out, open("gpurun_out/cvp_batch.json", "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "cvp_batch.json"), "w"), indent=1)
