@@ -70,6 +70,56 @@ def main():
                 "g2_steepness": parts["steepness"], "g2_inflation": parts["inflation"]})
     np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "planner_golden.npz"), os.path.getsize(os.path.join(HERE, "planner_golden.npz")), "bytes")
+    ragged()
+
+
+def face_plan(case, s, t, prefix, out, full):
+    """Wave seeded at the centroid of a face of s, robot in a face of t (no geometric face lookup: holes)."""
+    m = case.mesh
+    r = case.om.dijkstra(case.weights, case.costs, s, t, invalid=case.invalid)
+    first_face = np.full(m.V, -1, np.int64)
+    fl = m.faces.ravel()
+    first_face[fl[::-1]] = np.arange(fl.size)[::-1] // 3
+    sf, tf = int(first_face[s]), int(first_face[t])
+    sp = m.xyz[m.faces[sf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    c = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf, invalid=case.invalid)
+    out.update({
+        prefix + "seed_target": np.array([s, t], np.uint32), prefix + "cvp_faces": np.array([sf, tf], np.uint32), prefix + "cvp_seed_pos": sp,
+        prefix + "dij_code": np.array([r.code], np.uint32), prefix + "dij_path": r.path,
+        prefix + "dij_dist_sha": np.array(sha(r.dist)), prefix + "dij_pred_sha": np.array(sha(r.pred)),
+        prefix + "cvp_code": np.array([c.code], np.uint32), prefix + "cvp_goal_dist": np.array([c.stats["goal_dist"]], np.float32),
+        prefix + "cvp_dist_sha": np.array(sha(c.dist)), prefix + "cvp_pred_sha": np.array(sha(c.pred)),
+        prefix + "cvp_cutface_sha": np.array(sha(c.cutface)), prefix + "cvp_direction_sha": np.array(sha(c.direction)),
+    })
+    if full:
+        out.update({prefix + "dij_dist": r.dist, prefix + "dij_pred": r.pred, prefix + "cvp_dist": c.dist, prefix + "cvp_pred": c.pred})
+
+
+def ragged():
+    """Second fixture file: the inputs on which pop ORDER decides the result (cascades below the main front)."""
+    out = {}
+    # G3: terrain with 30 % of the faces punched out and a cut column (holes, two components, face-less vertices)
+    mesh = meshgen.punched(64, 0.1, 5, drop=0.3, cut_column=40)
+    g3 = Case(mesh)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    s, t = mesh.vertex_at(0.1, 0.2), mesh.vertex_at(0.5, 0.8)
+    while deg[s] == 0: s += 1
+    while deg[t] == 0: t += 1
+    face_plan(g3, s, t, "g3_", out, full=True)
+    # G4: random per-vertex costs up to 1.2, edge_cost_factor 1 (most triangles violate the triangle inequality), 2 % invalid
+    mesh = meshgen.terrain(96, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    invalid[[s, t]] = 0
+    costs[[s, t]] = 0
+    g4 = Case(mesh, costs, 1.0, invalid)
+    face_plan(g4, s, t, "g4_", out, full=False)
+    out["g4_costs_sha"] = np.array(sha(costs)); out["g4_invalid_sha"] = np.array(sha(invalid)); out["g4_weights_sha"] = np.array(sha(g4.weights))
+    path = os.path.join(HERE, "planner_golden_ragged.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

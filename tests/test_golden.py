@@ -3,6 +3,7 @@ import hashlib
 import os
 
 import numpy as np
+import pytest
 
 from mesh_navigation_amd import meshgen
 from tests.common import Case, layered_costs
@@ -47,3 +48,41 @@ def test_oracle_layered_costs_against_golden():
     c = case.om.cvp(case.weights, case.costs, case.vn, GOLD["g2_cvp_seed_pos"], sf, tf)
     assert np.array_equal(c.dist.view(np.uint32), GOLD["g2_cvp_dist"].view(np.uint32))
     assert np.array_equal(c.pred, GOLD["g2_cvp_pred"])
+
+
+RAGGED = np.load(os.path.join(os.path.dirname(__file__), "golden", "planner_golden_ragged.npz"))
+
+
+def ragged_case(which):
+    """The inputs of tests/golden/make_golden.py::ragged, rebuilt from their seeds."""
+    if which == "g3":
+        return Case(meshgen.punched(64, 0.1, 5, drop=0.3, cut_column=40))
+    mesh = meshgen.terrain(96, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    s, t = (int(x) for x in RAGGED["g4_seed_target"])
+    invalid[[s, t]] = 0
+    costs[[s, t]] = 0
+    case = Case(mesh, costs, 1.0, invalid)
+    assert sha(costs) == str(RAGGED["g4_costs_sha"]) and sha(invalid) == str(RAGGED["g4_invalid_sha"])
+    assert sha(case.weights) == str(RAGGED["g4_weights_sha"])
+    return case
+
+
+@pytest.mark.parametrize("which", ["g3", "g4"])
+def test_oracle_reproduces_order_sensitive_fixtures(which):
+    """Punched terrain (cascades behind holes) and adversarial costs: the inputs where the pop ORDER decides."""
+    case = ragged_case(which)
+    s, t = (int(x) for x in RAGGED[which + "_seed_target"])
+    r = case.om.dijkstra(case.weights, case.costs, s, t, invalid=case.invalid)
+    assert r.code == int(RAGGED[which + "_dij_code"][0]) and np.array_equal(r.path, RAGGED[which + "_dij_path"])
+    assert sha(r.dist) == str(RAGGED[which + "_dij_dist_sha"]) and sha(r.pred) == str(RAGGED[which + "_dij_pred_sha"])
+    sf, tf = (int(x) for x in RAGGED[which + "_cvp_faces"])
+    c = case.om.cvp(case.weights, case.costs, case.vn, RAGGED[which + "_cvp_seed_pos"], sf, tf, invalid=case.invalid)
+    assert c.code == int(RAGGED[which + "_cvp_code"][0])
+    assert sha(c.dist) == str(RAGGED[which + "_cvp_dist_sha"]) and sha(c.pred) == str(RAGGED[which + "_cvp_pred_sha"])
+    assert sha(c.cutface) == str(RAGGED[which + "_cvp_cutface_sha"]) and sha(c.direction) == str(RAGGED[which + "_cvp_direction_sha"])
+    if which == "g3":
+        assert np.array_equal(c.dist.view(np.uint32), RAGGED["g3_cvp_dist"].view(np.uint32))
+        assert np.array_equal(r.dist.view(np.uint32), RAGGED["g3_dij_dist"].view(np.uint32))

@@ -225,6 +225,30 @@ def test_golden_layered_fixture(gpu_ctx_factory):
     assert (np.abs(outc.dist[fin] - g[fin]) / np.maximum(g[fin], 1e-12)).max() <= CVP_RTOL
 
 
+@pytest.mark.parametrize("which", ["g3", "g4"])
+def test_golden_order_sensitive_fixtures(gpu_ctx_factory, which):
+    """The device against the committed fixtures of the inputs where the pop order decides (punched terrain,
+    adversarial costs) -- no oracle call in this test: the arrays / hashes travel with the repository."""
+    from tests.test_golden import RAGGED, ragged_case
+    case = ragged_case(which)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    s, t = (int(x) for x in RAGGED[which + "_seed_target"])
+    for engine in ("tiled", "band", "persistent"):
+        ctx.set_dijkstra_engine(engine)
+        out = ctx.plan_dijkstra(s, t)
+        assert out.code == int(RAGGED[which + "_dij_code"][0]) and np.array_equal(out.path, RAGGED[which + "_dij_path"])
+        assert sha(out.dist) == str(RAGGED[which + "_dij_dist_sha"]) and sha(out.pred) == str(RAGGED[which + "_dij_pred_sha"])
+    ctx.set_dijkstra_engine("auto")
+    sf, tf = (int(x) for x in RAGGED[which + "_cvp_faces"])
+    outc = ctx.plan_cvp(RAGGED[which + "_cvp_seed_pos"], sf, tf, want_vecmap=False)
+    assert outc.code == int(RAGGED[which + "_cvp_code"][0])
+    assert np.float32(outc.stats["goal_dist"]) == RAGGED[which + "_cvp_goal_dist"][0]          # inf == inf when the goal is never armed
+    assert sha(outc.dist) == str(RAGGED[which + "_cvp_dist_sha"]) and sha(outc.pred) == str(RAGGED[which + "_cvp_pred_sha"])
+    if which == "g3":
+        assert np.array_equal(outc.dist.view(np.uint32), RAGGED["g3_cvp_dist"].view(np.uint32))
+
+
 def test_batch_equals_single_plans(c1):
     case, ctx = c1
     m = case.mesh
