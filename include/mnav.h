@@ -73,6 +73,15 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
                      const uint32_t* face_vtx, const uint32_t* edge_vtx,
                      const float* vertex_normals);
 
+/* Optional, BEFORE mnav_upload_mesh: the rows of lvr2::PMPMesh::getFacesOfVertex (half-edge circulator
+ * order) as CSR, vf_ptr V+1, vf 3F.  CVPMeshPlanner applies the faces of a popped vertex in that order
+ * (cvp_mesh_planner.cpp:775-778) and its update is not a pure minimum on cost-inflated triangles, so the
+ * order is part of the result.  Without this call (or with NULL rows) the library derives the order itself
+ * by replaying pmp::SurfaceMesh::add_face over face_vtx in index order, which is how the reference builds
+ * its mesh from the map file (mesh_map.cpp:273).  Returns 0. */
+int mnav_set_face_circulation(mnav_ctx* ctx, uint32_t V, uint32_t F, const uint32_t* vf_ptr,
+                              const uint32_t* vf);
+
 /* Upload the inputs the planners re-read on every plan (dijkstra_mesh_planner.cpp:214,
  * cvp_mesh_planner.cpp:245): vertex_costs V (MeshMap::vertexCosts(), mesh_map.h:292-295),
  * edge_weights E (MeshMap::edgeWeights(), mesh_map.h:342-345), invalid V bytes

@@ -18,7 +18,7 @@ SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 
 
 # every symbol include/mnav.h declares
 SYMBOLS = [
-    "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_upload_mesh", "mnav_upload_costs",
+    "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_set_face_circulation", "mnav_upload_mesh", "mnav_upload_costs",
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes",
@@ -55,6 +55,8 @@ def load(path: str | None = None):
     L.mnav_destroy.argtypes = [vp]
     L.mnav_last_error.restype = C.c_char_p
     L.mnav_last_error.argtypes = [vp]
+    L.mnav_set_face_circulation.restype = C.c_int
+    L.mnav_set_face_circulation.argtypes = [vp, u32, u32, vp, vp]
     L.mnav_upload_mesh.restype = C.c_int
     L.mnav_upload_mesh.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp]
     L.mnav_upload_costs.restype = C.c_int
@@ -150,10 +152,17 @@ class MnavContext:
     def _err(self) -> str:
         return (self._L.mnav_last_error(self._h) or b"").decode()
 
-    def upload_mesh(self, xyz, faces, edges, vertex_normals=None):
+    def upload_mesh(self, xyz, faces, edges, vertex_normals=None, face_circulation=None):
+        """face_circulation: optional (vf_ptr[V+1], vf[3F]) = getFacesOfVertex rows of the caller's half-edge
+        mesh; by default the library replays the half-edge construction over `faces` itself."""
         xyz, faces, edges = _f32(xyz), _u32(faces), _u32(edges)
         vn = None if vertex_normals is None else _f32(vertex_normals)
         self.V, self.F, self.E = xyz.shape[0], faces.shape[0], edges.shape[0]
+        if face_circulation is not None:
+            ptr, vf = _u32(face_circulation[0]), _u32(face_circulation[1])
+            self._L.mnav_set_face_circulation(self._h, self.V, self.F, _p(ptr), _p(vf))
+        else:
+            self._L.mnav_set_face_circulation(self._h, self.V, self.F, None, None)
         rc = self._L.mnav_upload_mesh(self._h, self.V, self.F, self.E, _p(xyz), _p(faces), _p(edges), _p(vn))
         if rc != 0:
             raise RuntimeError(f"mnav_upload_mesh failed ({rc}): {self._err()}")

@@ -1,6 +1,7 @@
 // mesh_map_host.cpp -- see mesh_map_host.h.  Float arithmetic follows the reference expressions
 // (lvr2::BaseVector<float> component ops, CONVENTION: lvr2 is not vendored).
 #include "mesh_map_host.h"
+#include "../mnav_build.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -70,13 +71,13 @@ void MeshMap::finalize()
 {
   V = (uint32_t)(positions.size() / 3); F = (uint32_t)(faces.size() / 3); E = (uint32_t)(edges.size() / 2);
   if (invalid.size() != V) invalid.assign(V, 0);
-  vf_ptr_.assign((size_t)V + 1, 0);
-  for (size_t i = 0; i < faces.size(); ++i) vf_ptr_[faces[i] + 1]++;
-  for (uint32_t v = 0; v < V; ++v) vf_ptr_[v + 1] += vf_ptr_[v];
-  vf_.resize(faces.size());
-  std::vector<uint32_t> fill((size_t)V + 1, 0);
-  for (uint32_t f = 0; f < F; ++f)
-    for (int k = 0; k < 3; ++k) { const uint32_t v = faces[3 * (size_t)f + k]; vf_[vf_ptr_[v] + fill[v]++] = f; }
+  // getFacesOfVertex rows: the caller's (the real lvr2 mesh) if given, else the half-edge replay of the face list
+  if (face_circulation_ptr.size() == (size_t)V + 1 && face_circulation.size() == faces.size()) {
+    vf_ptr_ = face_circulation_ptr; vf_ = face_circulation;
+  } else {
+    mnav::FaceCirculation c = mnav::build_face_circulation(V, F, faces.data());
+    vf_ptr_ = std::move(c.ptr); vf_ = std::move(c.faces);
+  }
   // uniform grid for nearest-vertex queries
   float x1 = -FLT_MAX, y1 = -FLT_MAX; gx0_ = FLT_MAX; gy0_ = FLT_MAX;
   for (uint32_t v = 0; v < V; ++v) {

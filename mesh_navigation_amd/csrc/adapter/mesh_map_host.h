@@ -54,6 +54,8 @@ public:
   std::vector<float> vertex_costs;    // V   (MeshMap::vertexCosts)
   std::vector<float> edge_weights;    // E   (MeshMap::edgeWeights)
   std::vector<uint8_t> invalid;       // V   (MeshMap::invalid)
+  // optional: rows of PMPMesh::getFacesOfVertex (circulator order) as CSR; empty -> derived from `faces`
+  std::vector<uint32_t> face_circulation_ptr, face_circulation;
   std::string map_frame = "map";
   // vector map set by the planners for the controller (MeshMap::setVectorMap, mesh_map.cpp:620-623)
   std::vector<float> vector_map;      // V*3
@@ -76,7 +78,7 @@ public:
 private:
   bool searchNeighbourFaces(const Vector& pos, uint32_t face, float max_radius, float max_dist, uint32_t& found,
                             std::array<float, 3>& bary) const;                      // :999-1068
-  std::vector<uint32_t> vf_ptr_, vf_;   // vertex -> faces, ascending face id
+  std::vector<uint32_t> vf_ptr_, vf_;   // vertex -> faces, half-edge circulator order (getFacesOfVertex)
   // uniform grid over xy for the 1-NN query (stands in for the nanoflann kd-tree, :307-309)
   float gx0_ = 0, gy0_ = 0, gcell_ = 1;
   uint32_t gnx_ = 1, gny_ = 1;

@@ -125,7 +125,7 @@ __device__ __forceinline__ Eval group_eval_dijkstra(const Plan& P, const Ctl& c,
 }
 
 // --- CVP replay over 8 lanes (spec: mnav_eval.h::eval_cvp) ------------------------------------
-struct CornerItem { KeyRef fk; uint32_t trig; bool valid; CvpCand k; uint32_t v1, v2, face; };
+struct CornerItem { KeyRef fk; uint32_t trig; bool valid; bool first; CvpCand k; uint32_t v1, v2, face; };
 
 __device__ __forceinline__ KeyRef gshfl_key(const KeyRef& r, int src)
 {
@@ -147,7 +147,7 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
   for (int r = 0; r < 2; ++r) {
     const uint32_t i = beg + sub + r * kGroup;
     it[r].fk = key_ref_of(key_inf(), inf_f(), 0); it[r].trig = kNone; it[r].valid = false;
-    it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone;
+    it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone; it[r].first = false;
     it[r].k.u3tmp = 0.0; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = 0; it[r].k.kind = 0;
     if (i < end) {
       const Corner k = P.crn[i];
@@ -155,7 +155,7 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
       if (f.trig != kNone && !key_descends_from(P, f.trig, v)) {       // (spec: eval_cvp)
         it[r].valid = true; it[r].fk = f.key; it[r].trig = f.trig;
         it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
-        it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = k.face;
+        it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = corner_face(k); it[r].first = corner_first_for(k, f.trig);
       }
     }
   }
@@ -192,8 +192,10 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
     if (e.d < inf_f() && !key_less(P, m, key_ref_of(e.key, e.d, v))) break;   // v pops before this trigger
     bool any = false;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {                                  // ascending corner index = ascending face id
-      unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].trig == m_trig) >> gbase) & 0xFFull);
+    for (int pr = 0; pr < 4; ++pr) {                               // trigger's circulator order: flagged face first
+      const int r = pr & 1;
+      const bool want_first = pr < 2;
+      unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].trig == m_trig && it[r].first == want_first) >> gbase) & 0xFFull);
       while (gm) {
         const int src = __ffs((int)gm) - 1;
         gm &= gm - 1;
@@ -1359,6 +1361,7 @@ struct mnav_ctx {
   // materialised per cost_limit
   Nbr* d_nbr = nullptr; double nbr_limit = NAN; bool nbr_valid = false;
   Corner* d_crn = nullptr; uint8_t* d_blocked = nullptr; double crn_limit = NAN; bool crn_valid = false;
+  FaceCirculation circ;                                            // caller-supplied getFacesOfVertex rows (optional)
   // plans
   std::vector<Slot> slots;
   Plan* d_plans = nullptr; uint32_t plans_cap = 0;
@@ -1991,6 +1994,18 @@ void mnav_destroy(mnav_ctx* ctx)
 
 const char* mnav_last_error(const mnav_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+int mnav_set_face_circulation(mnav_ctx* ctx, uint32_t V, uint32_t F, const uint32_t* vf_ptr, const uint32_t* vf)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  ctx->circ = FaceCirculation();
+  if (!vf_ptr || !vf) return 0;                                  // back to the built-in half-edge replay
+  ctx->circ.ptr.assign(vf_ptr, vf_ptr + (size_t)V + 1);
+  ctx->circ.faces.assign(vf, vf + 3 * (size_t)F);
+  ctx->circ.ok = true;
+  return 0;
+}
+
 int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const float* xyz, const uint32_t* face_vtx,
                      const uint32_t* edge_vtx, const float* vertex_normals)
 {
@@ -1999,7 +2014,15 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   if ((V && !xyz) || (F && !face_vtx) || (E && !edge_vtx)) { ctx->err = "null mesh array"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   HostTopology t;
-  try { t = build_topology(V, F, E, face_vtx, edge_vtx); }
+  try {
+    if (!ctx->circ.ptr.empty()) {
+      if (ctx->circ.ptr.size() != (size_t)V + 1 || ctx->circ.faces.size() != 3 * (size_t)F || ctx->circ.ptr[V] != 3 * (size_t)F)
+        throw std::invalid_argument("face circulation does not fit this mesh");
+      t = build_topology(V, F, E, face_vtx, edge_vtx, &ctx->circ);
+    } else {
+      t = build_topology(V, F, E, face_vtx, edge_vtx);
+    }
+  }
   catch (const std::exception& ex) { ctx->err = ex.what(); return -2; }
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& s : ctx->slots) free_slot(s);

@@ -23,11 +23,11 @@ struct HostTopology {
   std::vector<uint32_t> row_ptr;   // V+1
   std::vector<uint32_t> nbr_u;     // 2E other endpoint
   std::vector<uint32_t> nbr_e;     // 2E undirected edge id (index into edge_weights)
-  // CVP corners: row v lists its incident faces in ascending face id
+  // CVP corners: row v lists its incident faces in ascending face id; crn_face carries the order flags
   std::vector<uint32_t> crn_ptr;   // V+1
   std::vector<uint32_t> crn_v1, crn_v2;          // 3F
   std::vector<uint32_t> crn_ea, crn_eb, crn_ec;  // 3F edge ids of sides a=(v2,v3) b=(v1,v3) c=(v1,v2)
-  std::vector<uint32_t> crn_face;  // 3F
+  std::vector<uint32_t> crn_face;  // 3F  face id | kCornerFirst1/2
 };
 
 namespace detail {
@@ -72,9 +72,154 @@ struct EdgeIndex {
 };
 }  // namespace detail
 
+// ---------------------------------------------------------------------------------------------
+// Face circulation: the order in which lvr2::PMPMesh::getFacesOfVertex (a pmp::SurfaceMesh circulator)
+// lists the faces around a vertex -- counter-clockwise, starting at the vertex's stored outgoing
+// half-edge, which depends on the order in which the faces were added.  The reference builds its mesh by
+// adding the faces of the map file in index order (mesh_map.cpp:273), so the same incremental half-edge
+// construction (the published pmp / OpenMesh add_face algorithm) is replayed here on the face list.
+// A caller that holds the real lvr2 mesh can pass its own getFacesOfVertex rows instead
+// (mnav_upload_face_circulation).  ok == false: the face list is not manifold in pmp's sense (complex
+// vertex / edge); rows are then left in ascending face id.
+// ---------------------------------------------------------------------------------------------
+struct FaceCirculation {
+  std::vector<uint32_t> ptr;   // V+1
+  std::vector<uint32_t> faces; // 3F
+  bool ok = false;
+};
+
+namespace detail {
+class HalfEdgeBuild {
+public:
+  HalfEdgeBuild(uint32_t V, uint32_t F) : out_(V, kNone) { to_.reserve(size_t(F) * 3 + 8); }
+  // add triangle f = (v[0], v[1], v[2]); false on a topological error
+  bool add(uint32_t f, const uint32_t* v)
+  {
+    uint32_t h[3]; bool fresh[3], adjust[3] = { false, false, false };
+    relink_.clear();
+    for (int i = 0; i < 3; ++i) {
+      if (!open_vertex(v[i])) return false;                      // complex vertex
+      h[i] = find(v[i], v[(i + 1) % 3]);
+      fresh[i] = h[i] == kNone;
+      if (!fresh[i] && left_[h[i]] != kNone) return false;       // complex edge
+    }
+    for (int i = 0; i < 3; ++i) {                                // two existing boundary edges that are not yet
+      const int n = (i + 1) % 3;                                 // consecutive: move the patch between them
+      if (fresh[i] || fresh[n] || next_[h[i]] == h[n]) continue;
+      uint32_t gap = h[n] ^ 1u;
+      do { gap = next_[gap] ^ 1u; } while (left_[gap] != kNone || gap == h[i]);
+      const uint32_t gap_next = next_[gap];
+      if (gap_next == h[n]) return false;                        // patch re-linking failed
+      relink_.push_back({ gap, next_[h[i]] });
+      relink_.push_back({ prev_[h[n]], gap_next });
+      relink_.push_back({ h[i], h[n] });
+    }
+    for (int i = 0; i < 3; ++i)
+      if (fresh[i]) {                                            // pair 2e: v[i] -> v[i+1], 2e+1 back
+        h[i] = uint32_t(to_.size());
+        to_.push_back(v[(i + 1) % 3]); to_.push_back(v[i]);
+        left_.push_back(kNone); left_.push_back(kNone);
+        next_.push_back(kNone); next_.push_back(kNone);
+        prev_.push_back(kNone); prev_.push_back(kNone);
+      }
+    for (int i = 0; i < 3; ++i) {
+      const int n = (i + 1) % 3;
+      const uint32_t c = v[n], in = h[i], on = h[n];             // corner vertex, incoming and outgoing inner half-edge
+      if (fresh[i] || fresh[n]) {
+        const uint32_t outer_in = on ^ 1u, outer_out = in ^ 1u;  // boundary half-edges through c after the insert
+        if (!fresh[n]) {                                         // incoming side is new
+          relink_.push_back({ prev_[on], outer_out });
+          out_[c] = outer_out;
+        } else if (!fresh[i]) {                                  // outgoing side is new
+          relink_.push_back({ outer_in, next_[in] });
+          out_[c] = next_[in];
+        } else if (out_[c] == kNone) {                           // isolated vertex
+          out_[c] = outer_out;
+          relink_.push_back({ outer_in, outer_out });
+        } else {                                                 // both new at a vertex that already has a fan
+          const uint32_t b = out_[c];
+          relink_.push_back({ prev_[b], outer_out });
+          relink_.push_back({ outer_in, b });
+        }
+        relink_.push_back({ in, on });
+      } else {
+        adjust[n] = out_[c] == on;
+      }
+      left_[in] = f;
+    }
+    for (const auto& r : relink_) { next_[r.first] = r.second; prev_[r.second] = r.first; }
+    for (int i = 0; i < 3; ++i)
+      if (adjust[i]) {                                           // keep a boundary half-edge as the stored one
+        uint32_t x = out_[v[i]];
+        const uint32_t x0 = x;
+        do {
+          if (left_[x] == kNone) { out_[v[i]] = x; break; }
+          x = next_[x ^ 1u];
+        } while (x != x0);
+      }
+    return true;
+  }
+  // faces around v, counter-clockwise from the stored half-edge
+  template <class Fn> void faces_around(uint32_t v, Fn&& fn) const
+  {
+    uint32_t x = out_[v];
+    const uint32_t x0 = x;
+    if (x == kNone) return;
+    size_t guard = 0;
+    do {
+      if (left_[x] != kNone) fn(left_[x]);
+      x = prev_[x] ^ 1u;
+    } while (x != x0 && ++guard <= to_.size());
+  }
+private:
+  bool open_vertex(uint32_t v) const { const uint32_t x = out_[v]; return x == kNone || left_[x] == kNone; }
+  uint32_t find(uint32_t a, uint32_t b) const
+  {
+    uint32_t x = out_[a];
+    const uint32_t x0 = x;
+    if (x == kNone) return kNone;
+    do {
+      if (to_[x] == b) return x;
+      x = next_[x ^ 1u];
+    } while (x != x0);
+    return kNone;
+  }
+  std::vector<uint32_t> out_, to_, left_, next_, prev_;
+  std::vector<std::pair<uint32_t, uint32_t>> relink_;
+};
+}  // namespace detail
+
+inline FaceCirculation build_face_circulation(uint32_t V, uint32_t F, const uint32_t* face_vtx)
+{
+  FaceCirculation c;
+  c.ptr.assign(size_t(V) + 1, 0);
+  for (size_t i = 0; i < size_t(F) * 3; ++i) c.ptr[face_vtx[i] + 1]++;
+  for (uint32_t v = 0; v < V; ++v) c.ptr[v + 1] += c.ptr[v];
+  c.faces.assign(size_t(F) * 3, kNone);
+  detail::HalfEdgeBuild he(V, F);
+  bool ok = true;
+  for (uint32_t f = 0; f < F && ok; ++f) ok = he.add(f, face_vtx + 3 * size_t(f));
+  if (ok) {
+    for (uint32_t v = 0; v < V && ok; ++v) {
+      uint32_t n = 0;
+      const uint32_t cap = c.ptr[v + 1] - c.ptr[v];
+      he.faces_around(v, [&](uint32_t f) { if (n < cap) c.faces[size_t(c.ptr[v]) + n] = f; ++n; });
+      ok = n == cap;
+    }
+  }
+  if (!ok) {                                                     // not manifold: ascending face id
+    std::vector<uint32_t> fill(size_t(V) + 1, 0);
+    for (uint32_t f = 0; f < F; ++f)
+      for (int k = 0; k < 3; ++k) { const uint32_t v = face_vtx[3 * size_t(f) + k]; c.faces[size_t(c.ptr[v]) + fill[v]++] = f; }
+  }
+  c.ok = ok;
+  return c;
+}
+
 // Throws std::invalid_argument on out-of-range ids or a face side that is not a listed edge.
+// `circ`: getFacesOfVertex rows (nullptr: derived from the face list, build_face_circulation).
 inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx,
-                                   const uint32_t* edge_vtx)
+                                   const uint32_t* edge_vtx, const FaceCirculation* circ = nullptr)
 {
   HostTopology t;
   t.V = V; t.F = F; t.E = E;
@@ -125,6 +270,33 @@ inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uin
         t.crn_eb[i] = fe[k3];   // (v3,v1)
         t.crn_ea[i] = fe[k2];   // (v2,v3)
         t.crn_face[i] = f;
+      }
+    }
+  }
+  // order flags (Corner, mnav_eval.h): walk every vertex t's faces in circulator order; of the (at most two)
+  // faces that contain edge (t, v) the one met first gets the flag on v's corner for that face
+  if (F >= (1u << 30)) throw std::invalid_argument("face ids must fit 30 bits");
+  FaceCirculation own;
+  if (!circ) { own = build_face_circulation(V, F, face_vtx); circ = &own; }
+  {
+    std::vector<uint32_t> seen;                                  // the v's already met around t
+    for (uint32_t tv = 0; tv < V; ++tv) {
+      seen.clear();
+      for (uint32_t r = circ->ptr[tv]; r < circ->ptr[tv + 1]; ++r) {
+        const uint32_t f = circ->faces[r];
+        if (f >= F) throw std::invalid_argument("face circulation row names an unknown face");
+        for (int k = 0; k < 3; ++k) {
+          const uint32_t v = face_vtx[3 * size_t(f) + k];
+          if (v == tv) continue;
+          const bool first = std::find(seen.begin(), seen.end(), v) == seen.end();
+          if (!first) continue;
+          seen.push_back(v);
+          for (uint32_t i = t.crn_ptr[v]; i < t.crn_ptr[v + 1]; ++i)
+            if (t.crn_face[i] == f || (t.crn_face[i] & kCornerFaceMask) == f) {
+              t.crn_face[i] |= (t.crn_v1[i] == tv) ? kCornerFirst1 : kCornerFirst2;
+              break;
+            }
+        }
       }
     }
   }

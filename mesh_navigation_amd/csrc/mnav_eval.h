@@ -42,7 +42,15 @@ struct Nbr { uint32_t u; float w; };
 // face with v3 last (cvp_mesh_planner.cpp:811,834,857); a=w(v2,v3), b=w(v1,v3), c=w(v1,v2)
 // (cvp_mesh_planner.cpp:380-390).  v1 == kNone marks a face that must be skipped because one
 // of its vertices is invalid (cvp_mesh_planner.cpp:785).
+// `face` carries the face id in its low 30 bits and two order flags: the reference applies the faces of a
+// popped vertex t in the order of t's half-edge circulator (getFacesOfVertex, cvp :775-778), and on
+// cost-inflated triangles the update is not a pure minimum, so when both faces of edge (t, v3) fire on the
+// same pop their order matters.  kCornerFirst1 / kCornerFirst2: this face comes first of the two in the
+// circulator of v1 / v2.
 struct Corner { uint32_t v1, v2; float a, b, c; uint32_t face; };
+constexpr uint32_t kCornerFaceMask = 0x3FFFFFFFu, kCornerFirst1 = 0x40000000u, kCornerFirst2 = 0x80000000u;
+MNAV_HD uint32_t corner_face(const Corner& k) { return k.face & kCornerFaceMask; }
+MNAV_HD bool corner_first_for(const Corner& k, uint32_t trig) { return (k.face & (trig == k.v1 ? kCornerFirst1 : kCornerFirst2)) != 0u; }
 
 MNAV_HD float u2f(uint32_t u) { union { uint32_t u; float f; } x; x.u = u; return x.f; }
 MNAV_HD uint32_t f2u(float f) { union { uint32_t u; float f; } x; x.f = f; return x.u; }
@@ -423,8 +431,8 @@ MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
 
 // CVP: replay of the incident-face updates of vertex v in the order their trigger vertices
 // pop.  A face is applied to v only while v is still free, i.e. while the trigger pops before v
-// itself would.  Faces fired by the same pop are applied in ascending face id (cvp :778 loop
-// order; CONVENTION for getFacesOfVertex).
+// itself would.  Faces fired by the same pop are applied in the order of the trigger's half-edge
+// circulator (cvp :778 loop over getFacesOfVertex(trigger)): Corner order flags, mnav_build.h.
 MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 {
   Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
@@ -443,16 +451,17 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
     if (m_trig == kNone) break;
     if (e.d < inf_f() && !key_less(P, m, key_ref_of(e.key, e.d, v))) break;   // v pops before this trigger
     bool any = false;
-    for (uint32_t i = beg; i < end; ++i) {                // faces of this pop, ascending face id
-      const Corner k = P.crn[i];
-      const Fire f = corner_fire(P, c, k);
-      if (f.trig != m_trig) continue;
-      const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
-      if (u.ok) {
-        e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = k.face;
-        any = true;
+    for (int pass = 0; pass < 2; ++pass)                  // faces of this pop, in the trigger's circulator order
+      for (uint32_t i = beg; i < end; ++i) {
+        const Corner k = P.crn[i];
+        const Fire f = corner_fire(P, c, k);
+        if (f.trig != m_trig || corner_first_for(k, m_trig) != (pass == 0)) continue;
+        const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
+        if (u.ok) {
+          e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = corner_face(k);
+          any = true;
+        }
       }
-    }
     if (any) e.key = key_for(P, e.d, v, m);                // ordinary pop, or a place inside the cascade of this trigger
     last = m; first = false;
   }

@@ -74,15 +74,16 @@ static double now_ms(void)
 /* ------------------------------------------------------------------------- */
 struct mo_mesh {
   uint32_t V, F, E;
+  int manifold;        /* 0: pmp would reject faces of this list; rows stay in ascending id */
   float* xyz;          /* V*3 */
   uint32_t* fv;        /* F*3 */
   uint32_t* fe;        /* F*3: edge between fv[k] and fv[(k+1)%3] */
   uint32_t* ev;        /* E*2 */
   uint32_t* ef;        /* E*2 incident faces (NONE if boundary), in id order */
   uint32_t* ve_ptr;    /* V+1 */
-  uint32_t* ve;        /* 2E edge ids around vertex, ascending */
+  uint32_t* ve;        /* 2E edge ids around vertex, in half-edge circulator order (see he_build) */
   uint32_t* vf_ptr;    /* V+1 */
-  uint32_t* vf;        /* 3F face ids around vertex, ascending */
+  uint32_t* vf;        /* 3F face ids around vertex, in half-edge circulator order */
 };
 
 static uint64_t edge_key(uint32_t a, uint32_t b)
@@ -94,6 +95,174 @@ static uint64_t hash64(uint64_t x)
 {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return x;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Circulator order.  lvr2::PMPMesh wraps a pmp::SurfaceMesh; getEdgesOfVertex /
+ * getFacesOfVertex walk the outgoing half-edges of a vertex counter-clockwise,
+ * starting at the vertex's stored outgoing half-edge.  Which half-edge that is
+ * depends on the order in which the faces were added (pmp::SurfaceMesh::
+ * add_face, the OpenMesh algorithm, incl. adjust_outgoing_halfedge), so the
+ * mesh is rebuilt here face by face exactly like PMPMesh(MeshBufferPtr) does
+ * (mesh_map.cpp:273).  The order matters: CVP applies the faces of a popped
+ * vertex in this order and its update is not a pure minimum on cost-inflated
+ * triangles; vertex normals are summed in it; searchNeighbourFaces walks it.
+ * lvr2/pmp are un-vendored: this restates the published pmp algorithm and is
+ * checked against oracle/_ref (the reference's own code on the same model).
+ * Half-edge 2e goes ev[2e] -> ev[2e+1] (new_edge(start,end)), 2e+1 back.      */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t* vh;      /* V: outgoing half-edge of a vertex */
+  uint32_t* hto;     /* H: to-vertex */
+  uint32_t* hface;   /* H: face left of the half-edge, NONE on the boundary */
+  uint32_t* hnext;   /* H */
+  uint32_t* hprev;   /* H */
+  uint32_t* fh;      /* F: half-edge of a face */
+  uint32_t H, Hcap;
+} he_mesh;
+
+static uint32_t he_opp(uint32_t h) { return h ^ 1u; }
+static uint32_t he_cw(const he_mesh* m, uint32_t h) { return m->hnext[he_opp(h)]; }
+static uint32_t he_ccw(const he_mesh* m, uint32_t h) { return he_opp(m->hprev[h]); }
+static int he_vertex_is_boundary(const he_mesh* m, uint32_t v)
+{
+  const uint32_t h = m->vh[v];
+  return !(h != NONE && m->hface[h] != NONE);
+}
+static uint32_t he_find(const he_mesh* m, uint32_t start, uint32_t end)
+{
+  uint32_t h = m->vh[start];
+  const uint32_t hh = h;
+  if (h != NONE) {
+    do {
+      if (m->hto[h] == end) return h;
+      h = he_cw(m, h);
+    } while (h != hh);
+  }
+  return NONE;
+}
+static void he_set_next(he_mesh* m, uint32_t h, uint32_t nh) { m->hnext[h] = nh; m->hprev[nh] = h; }
+static void he_adjust_outgoing(he_mesh* m, uint32_t v)
+{
+  uint32_t h = m->vh[v];
+  const uint32_t hh = h;
+  if (h != NONE) {
+    do {
+      if (m->hface[h] == NONE) { m->vh[v] = h; return; }
+      h = he_cw(m, h);
+    } while (h != hh);
+  }
+}
+/* returns 0 on a topological error (complex vertex / complex edge / patch re-linking failed) */
+static int he_add_triangle(he_mesh* m, uint32_t f, const uint32_t vs[3])
+{
+  uint32_t hs[3]; int is_new[3], needs_adjust[3] = { 0, 0, 0 };
+  uint32_t nc[18][2]; int n_nc = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int ii = (i + 1) % 3;
+    if (!he_vertex_is_boundary(m, vs[i])) return 0;
+    hs[i] = he_find(m, vs[i], vs[ii]);
+    is_new[i] = hs[i] == NONE;
+    if (!is_new[i] && m->hface[hs[i]] != NONE) return 0;
+  }
+  for (int i = 0; i < 3; ++i) {
+    const int ii = (i + 1) % 3;
+    if (!is_new[i] && !is_new[ii]) {
+      const uint32_t inner_prev = hs[i], inner_next = hs[ii];
+      if (m->hnext[inner_prev] != inner_next) {
+        const uint32_t outer_prev = he_opp(inner_next);
+        uint32_t boundary_prev = outer_prev;
+        do {
+          boundary_prev = he_opp(m->hnext[boundary_prev]);
+        } while (m->hface[boundary_prev] != NONE || boundary_prev == inner_prev);
+        const uint32_t boundary_next = m->hnext[boundary_prev];
+        if (boundary_next == inner_next) return 0;
+        const uint32_t patch_start = m->hnext[inner_prev], patch_end = m->hprev[inner_next];
+        nc[n_nc][0] = boundary_prev; nc[n_nc++][1] = patch_start;
+        nc[n_nc][0] = patch_end; nc[n_nc++][1] = boundary_next;
+        nc[n_nc][0] = inner_prev; nc[n_nc++][1] = inner_next;
+      }
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const int ii = (i + 1) % 3;
+    if (is_new[i]) {                                /* new_edge(vs[i], vs[ii]) */
+      const uint32_t h0 = m->H, h1 = m->H + 1;
+      m->H += 2;
+      m->hto[h0] = vs[ii]; m->hto[h1] = vs[i];
+      m->hface[h0] = m->hface[h1] = NONE; m->hnext[h0] = m->hnext[h1] = NONE; m->hprev[h0] = m->hprev[h1] = NONE;
+      hs[i] = h0;
+    }
+  }
+  m->fh[f] = hs[2];
+  for (int i = 0; i < 3; ++i) {
+    const int ii = (i + 1) % 3;
+    const uint32_t v = vs[ii];
+    const uint32_t inner_prev = hs[i], inner_next = hs[ii];
+    const int id = (is_new[i] ? 1 : 0) | (is_new[ii] ? 2 : 0);
+    if (id) {
+      const uint32_t outer_prev = he_opp(inner_next), outer_next = he_opp(inner_prev);
+      if (id == 1) {
+        const uint32_t boundary_prev = m->hprev[inner_next];
+        nc[n_nc][0] = boundary_prev; nc[n_nc++][1] = outer_next;
+        m->vh[v] = outer_next;
+      } else if (id == 2) {
+        const uint32_t boundary_next = m->hnext[inner_prev];
+        nc[n_nc][0] = outer_prev; nc[n_nc++][1] = boundary_next;
+        m->vh[v] = boundary_next;
+      } else {
+        if (m->vh[v] == NONE) {
+          m->vh[v] = outer_next;
+          nc[n_nc][0] = outer_prev; nc[n_nc++][1] = outer_next;
+        } else {
+          const uint32_t boundary_next = m->vh[v];
+          const uint32_t boundary_prev = m->hprev[boundary_next];
+          nc[n_nc][0] = boundary_prev; nc[n_nc++][1] = outer_next;
+          nc[n_nc][0] = outer_prev; nc[n_nc++][1] = boundary_next;
+        }
+      }
+      nc[n_nc][0] = inner_prev; nc[n_nc++][1] = inner_next;
+    } else {
+      needs_adjust[ii] = (m->vh[v] == inner_next);
+    }
+    m->hface[hs[i]] = f;
+  }
+  for (int k = 0; k < n_nc; ++k) he_set_next(m, nc[k][0], nc[k][1]);
+  for (int i = 0; i < 3; ++i) if (needs_adjust[i]) he_adjust_outgoing(m, vs[i]);
+  return 1;
+}
+
+/* Re-orders the rows of ve / vf into circulator order.  Returns 0 if the face list is not a manifold
+ * in pmp's sense (the reference's loader would discard faces and re-index, mesh_map.cpp:276-300). */
+static int he_circulator_orders(mo_mesh* m)
+{
+  he_mesh h;
+  const size_t Hcap = 2 * (size_t)m->E + 2;
+  h.H = 0; h.Hcap = (uint32_t)Hcap;
+  h.vh = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)m->V + 1));
+  memset(h.vh, 0xFF, sizeof(uint32_t) * ((size_t)m->V + 1));
+  h.hto = (uint32_t*)malloc(sizeof(uint32_t) * Hcap); h.hface = (uint32_t*)malloc(sizeof(uint32_t) * Hcap);
+  h.hnext = (uint32_t*)malloc(sizeof(uint32_t) * Hcap); h.hprev = (uint32_t*)malloc(sizeof(uint32_t) * Hcap);
+  h.fh = (uint32_t*)malloc(sizeof(uint32_t) * ((size_t)m->F + 1));
+  int ok = 1;
+  for (uint32_t f = 0; f < m->F && ok; ++f) ok = he_add_triangle(&h, f, m->fv + 3 * (size_t)f);
+  if (ok && h.H != 2 * m->E) ok = 0;
+  if (ok) {
+    for (uint32_t v = 0; v < m->V; ++v) {
+      uint32_t ne = 0, nf = 0;
+      uint32_t x = h.vh[v];
+      const uint32_t xx = x;
+      if (x == NONE) continue;
+      do {
+        m->ve[m->ve_ptr[v] + ne++] = x >> 1;
+        if (h.hface[x] != NONE) m->vf[m->vf_ptr[v] + nf++] = h.hface[x];
+        x = he_ccw(&h, x);
+      } while (x != xx && ne <= m->ve_ptr[v + 1] - m->ve_ptr[v]);
+      if (ne != m->ve_ptr[v + 1] - m->ve_ptr[v] || nf != m->vf_ptr[v + 1] - m->vf_ptr[v]) { ok = 0; break; }
+    }
+  }
+  free(h.vh); free(h.hto); free(h.hface); free(h.hnext); free(h.hprev); free(h.fh);
+  return ok;
 }
 
 mo_mesh* mo_mesh_create(uint32_t V, uint32_t F, const float* xyz, const uint32_t* faces)
@@ -141,7 +310,7 @@ mo_mesh* mo_mesh_create(uint32_t V, uint32_t F, const float* xyz, const uint32_t
       else if (m->ef[2 * e + 1] == NONE && m->ef[2 * e] != f) m->ef[2 * e + 1] = f;
     }
 
-  /* vertex -> edges, ascending edge id (CONVENTION for getEdgesOfVertex) */
+  /* vertex -> edges (getEdgesOfVertex), first in ascending edge id */
   m->ve_ptr = (uint32_t*)calloc((size_t)V + 2, sizeof(uint32_t));
   for (uint32_t e = 0; e < E; ++e) { m->ve_ptr[m->ev[2 * e] + 1]++; m->ve_ptr[m->ev[2 * e + 1] + 1]++; }
   for (uint32_t v = 0; v < V; ++v) m->ve_ptr[v + 1] += m->ve_ptr[v];
@@ -155,7 +324,7 @@ mo_mesh* mo_mesh_create(uint32_t V, uint32_t F, const float* xyz, const uint32_t
       }
     free(fill);
   }
-  /* vertex -> faces, ascending face id (CONVENTION for getFacesOfVertex) */
+  /* vertex -> faces (getFacesOfVertex), first in ascending face id */
   m->vf_ptr = (uint32_t*)calloc((size_t)V + 2, sizeof(uint32_t));
   for (uint32_t f = 0; f < F; ++f)
     for (int k = 0; k < 3; ++k) m->vf_ptr[faces[3 * f + k] + 1]++;
@@ -170,7 +339,20 @@ mo_mesh* mo_mesh_create(uint32_t V, uint32_t F, const float* xyz, const uint32_t
       }
     free(fill);
   }
+  /* rows so far in ascending id; now into the half-edge circulator order of lvr2::PMPMesh */
+  m->manifold = he_circulator_orders(m);
   return m;
+}
+int mo_mesh_is_manifold(const mo_mesh* m) { return m->manifold; }
+void mo_mesh_vertex_faces(const mo_mesh* m, uint32_t* vf_ptr, uint32_t* vf)
+{
+  memcpy(vf_ptr, m->vf_ptr, sizeof(uint32_t) * ((size_t)m->V + 1));
+  memcpy(vf, m->vf, sizeof(uint32_t) * 3 * (size_t)m->F);
+}
+void mo_mesh_vertex_edges(const mo_mesh* m, uint32_t* ve_ptr, uint32_t* ve)
+{
+  memcpy(ve_ptr, m->ve_ptr, sizeof(uint32_t) * ((size_t)m->V + 1));
+  memcpy(ve, m->ve, sizeof(uint32_t) * 2 * (size_t)m->E);
 }
 
 void mo_mesh_destroy(mo_mesh* m)
@@ -278,9 +460,15 @@ static void meap_swap(mo_meap* h, uint32_t i, uint32_t j)
   h->keys[i] = kj; h->vals[i] = vj; h->pos[kj] = i;
   h->keys[j] = ki; h->vals[j] = vi; h->pos[ki] = j;
 }
+/* 1 (default): equal values pop in ascending vertex id -- the tie rule the device path implements.
+ * 0: values only, i.e. the plain array heap of lvr2::Meap as modelled in oracle/ref_build/stubs (which of
+ *    several equal keys pops first then follows from the sift mechanics); used to compare tie-heavy inputs
+ *    (all inflation seeds sit at 0) with oracle/_ref. */
+static int g_meap_ties_by_id = 1;
+void mo_set_heap_ties_by_id(int on) { g_meap_ties_by_id = on; }
 static int meap_lt(const mo_meap* h, uint32_t i, uint32_t j)
 {
-  return h->vals[i] < h->vals[j] || (h->vals[i] == h->vals[j] && h->keys[i] < h->keys[j]);
+  return h->vals[i] < h->vals[j] || (g_meap_ties_by_id && h->vals[i] == h->vals[j] && h->keys[i] < h->keys[j]);
 }
 static void meap_up(mo_meap* h, uint32_t i)
 {
@@ -569,7 +757,6 @@ uint32_t mo_cvp_propagate(const mo_mesh* m, const float* edge_weights, const flo
     if (distances[cur] > goal_dist) continue;                 /* :754 */
     if ((double)vertex_costs[cur] >= cost_limit) continue;    /* :757 */
     if (invalid && invalid[cur]) continue;                    /* :760 */
-    if (getenv("MO_DEBUG") && (cur == g0 || cur == g1 || cur == g2)) fprintf(stderr, "pop goal vertex %u d=%.9g fixed=%d%d%d goal_dist=%g\n", cur, distances[cur], fixed[g0], fixed[g1], fixed[g2], goal_dist);
     if (cur == g0 || cur == g1 || cur == g2) {                /* :763 */
       if (goal_dist == INFINITY && fixed[g0] && fixed[g1] && fixed[g2])   /* :765-766 */
         goal_dist = (float)((double)distances[cur] + goal_dist_offset);   /* :769 */
@@ -682,13 +869,18 @@ static vec3 inflation_vector_at(const mo_inflation_field* L, const uint32_t vs[3
     /* :507-510.  sqrt(float) - double ... evaluated in double, stored float */
     const float alpha = (float)(((double)sqrtf(distance) - L->cfg.inscribed_radius) /
                                 (L->cfg.inflation_radius - L->cfg.inscribed_radius) * M_PI);
-    /* Vector * double: lvr2 BaseVector<float>::operator*(float) -> CONVENTION:
-     * scale factor computed in double then narrowed to float */
-    const float s = (float)(L->cfg.inscribed_value * ((double)cosf(alpha) + 1) / 2.0);
-    return v3_scale(comb, s);
+    /* :509-510  vec * inscribed_value * (cos(alpha) + 1) / 2.0 evaluates left to right on
+     * lvr2::BaseVector<float>, whose operator* and operator/ take a float: three float
+     * vector operations, each scalar narrowed first (checked against oracle/_ref) */
+    return v3_div(v3_scale(v3_scale(comb, (float)L->cfg.inscribed_value), cosf(alpha) + 1), 2.0f);
   }
   if (distance > 0) return v3_scale(comb, (float)L->cfg.inscribed_value); /* :514-517 */
   return v3_scale(comb, (float)L->cfg.lethal_value);                      /* :520 */
+}
+
+void mo_inflation_vector_at(const mo_inflation_field* L, const uint32_t vs[3], const float bary[3], float out[3])
+{
+  v3_store(out, inflation_vector_at(L, vs, bary));
 }
 
 /* MeshMap::searchNeighbourFaces, mesh_map.cpp:999-1068.  Returns face or NONE. */
@@ -892,7 +1084,7 @@ uint32_t mo_cvp_poses(const mo_mesh* m, const float* face_normals, const float* 
 /* ------------------------------------------------------------------------- */
 /* Inflation layer: mesh_layers/src/inflation_layer.cpp                       */
 /* ------------------------------------------------------------------------- */
-#define MESH_LAYERS_EPSILON 1e-8f  /* CONVENTION: mesh_layers::EPSILON lives in a header not on this path */
+#define MESH_LAYERS_EPSILON 1e-9f  /* mesh_layers::EPSILON, mesh_layers/include/mesh_layers/inflation_layer.h:48 (`const float EPSILON = 1e-9;`) */
 
 /* :181-234 */
 float mo_inflation_sethian(float d1, float d2, float a, float b, float dot, float F)

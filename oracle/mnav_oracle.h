@@ -6,12 +6,18 @@
  * leg may load this library, and there only as the checker / reported CPU
  * baseline -- never as the thing measured or shipped.
  *
- * PARITY UNPINNED: the reference (naturerobots/mesh_navigation v3.0.1) holds
- * no test, golden vector or fixture for either planner, and cannot be built
- * in this environment (needs ROS 2 + lvr2 + Move Base Flex).  The only
- * reference-held known answer touching this code is the InflationLayer
- * single-triangle test (mesh_layers/test/inflation_layer_test.cpp:38-100),
- * which tests/test_oracle_kat.py replays against mo_inflation_*.
+ * PARITY PINNED AGAINST THE REFERENCE'S OWN CODE: oracle/ref_build/build.sh
+ * compiles the reference's planner, mesh_map and mesh_layers translation
+ * units unmodified (against stub lvr2/rclcpp/tf2 headers) into
+ * oracle/_ref/libmnav_ref.so, and tests/test_ref_pins_oracle.py asserts that
+ * this restatement returns the same bits (potential, predecessors, path,
+ * cutting faces, directions, layer costs, edge weights) on the seeded
+ * configurations; tests/golden/ fixtures are generated from that library.
+ * What stays a CONVENTION is what lives inside the un-vendored lvr2 / pmp
+ * (modelled in oracle/ref_build/stubs/lvr2_stub.hpp): heap behaviour among
+ * EQUAL keys, BaseVector::rotated.  The reference's own known-answer test
+ * (mesh_layers/test/inflation_layer_test.cpp:38-100) is run unmodified by the
+ * same build and replayed in tests/test_oracle_kat.py.
  *
  * Every function cites the reference file:line it restates (paths relative
  * to the reference checkout).  Conventions the reference delegates to the
@@ -42,12 +48,21 @@ typedef struct mo_mesh mo_mesh;
  * CONVENTION (lvr2 absent): vertex ids and face ids/vertex order are the
  * caller's; undirected edge ids are assigned in order of first appearance
  * while iterating faces 0..F-1 and, inside a face, the sides (v0,v1), (v1,v2),
- * (v2,v0); edges/faces around a vertex are enumerated in ascending id. */
+ * (v2,v0) -- which is what pmp::SurfaceMesh::add_face does; edges/faces around a
+ * vertex are enumerated in the half-edge circulator order of lvr2::PMPMesh
+ * (counter-clockwise from the vertex's outgoing half-edge after adding the
+ * faces 0..F-1 in order; he_add_triangle in the .c file). */
 mo_mesh* mo_mesh_create(uint32_t V, uint32_t F, const float* xyz, const uint32_t* faces);
 void mo_mesh_destroy(mo_mesh* m);
 uint32_t mo_mesh_num_vertices(const mo_mesh* m);
 uint32_t mo_mesh_num_faces(const mo_mesh* m);
 uint32_t mo_mesh_num_edges(const mo_mesh* m);
+/* 0 if pmp would reject a face of the list (complex vertex / edge): the reference's loader then discards
+ * faces and re-indexes (mesh_map.cpp:276-300); incidence rows stay in ascending id order */
+int mo_mesh_is_manifold(const mo_mesh* m);
+/* getFacesOfVertex / getEdgesOfVertex orders as CSR (V+1 row pointers, 3F / 2E entries) */
+void mo_mesh_vertex_faces(const mo_mesh* m, uint32_t* vf_ptr, uint32_t* vf);
+void mo_mesh_vertex_edges(const mo_mesh* m, uint32_t* ve_ptr, uint32_t* ve);
 /* out: E*2 vertex ids per undirected edge */
 void mo_mesh_edges(const mo_mesh* m, uint32_t* edge_vtx);
 /* out: F*3, face_edges[f*3+k] = edge between face vertex k and (k+1)%3 */
@@ -104,6 +119,8 @@ void mo_combine(uint32_t V, int mode, int n_layers, const float* const* layers, 
 /* lvr2::Meap<VertexHandle,float> emulation hooks (CONVENTION, see .c) exposed
  * for unit tests. */
 typedef struct mo_meap mo_meap;
+/* tie rule of the heap: 1 = (value, vertex id) [default, the device path's rule], 0 = plain lvr2-style array heap */
+void mo_set_heap_ties_by_id(int on);
 mo_meap* mo_meap_create(uint32_t capacity);
 void mo_meap_destroy(mo_meap* h);
 void mo_meap_insert(mo_meap* h, uint32_t key, float value);
@@ -169,6 +186,9 @@ typedef struct {
   mo_inflation_cfg cfg;
   int repulsive_field;
 } mo_inflation_field;
+
+/* InflationLayer::vectorAt(handles, barycentric coords), inflation_layer.cpp:493-521 */
+void mo_inflation_vector_at(const mo_inflation_field* L, const uint32_t vs[3], const float bary[3], float out[3]);
 
 /* CVP vector-field back-tracking, cvp_mesh_planner.cpp:920-951 with
  * MeshMap::meshAhead mesh_map.cpp:1070-1108.  path_pos: cap*3, path_face: cap

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg; never from the product package (mesh_navigation_amd/).
-PARITY UNPINNED: see oracle/mnav_oracle.h.
+Pinned against the reference's own code (oracle/_ref, tests/test_ref_pins_oracle.py); see oracle/mnav_oracle.h.
 """
 from __future__ import annotations
 
@@ -66,6 +66,10 @@ def lib():
         for n in ("mo_mesh_num_vertices", "mo_mesh_num_faces", "mo_mesh_num_edges"):
             getattr(L, n).restype = u32
             getattr(L, n).argtypes = [vp]
+        L.mo_mesh_is_manifold.restype = C.c_int
+        L.mo_mesh_is_manifold.argtypes = [vp]
+        L.mo_mesh_vertex_faces.argtypes = [vp, vp, vp]
+        L.mo_mesh_vertex_edges.argtypes = [vp, vp, vp]
         L.mo_mesh_edges.argtypes = [vp, vp]
         L.mo_mesh_face_edges.argtypes = [vp, vp]
         L.mo_edge_distances.argtypes = [vp, vp]
@@ -81,6 +85,7 @@ def lib():
         L.mo_inflation_wavefront_update.argtypes = [vp, vp, vp, f32, vp, u32, u32, u32]
         L.mo_inflation.argtypes = [vp, C.POINTER(InflationCfg), vp, vp, vp, vp, vp, vp]
         L.mo_combine.argtypes = [u32, C.c_int, C.c_int, vp, vp, vp]
+        L.mo_set_heap_ties_by_id.argtypes = [C.c_int]
         L.mo_meap_create.restype = vp
         L.mo_meap_create.argtypes = [u32]
         L.mo_meap_destroy.argtypes = [vp]
@@ -101,6 +106,7 @@ def lib():
                                        vp, C.POINTER(_Stats)]
         L.mo_cvp_backtrack.restype = u32
         L.mo_cvp_backtrack.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, f64, u32, vp, vp, C.POINTER(u32)]
+        L.mo_inflation_vector_at.argtypes = [C.POINTER(_InflationField), vp, vp, vp]
         L.mo_nearest_vertex.restype = u32
         L.mo_nearest_vertex.argtypes = [vp, vp]
         L.mo_containing_face.restype = u32
@@ -181,6 +187,23 @@ class OracleMesh:
         out = np.empty((self.E, 2), dtype=np.uint32)
         lib().mo_mesh_edges(self._h, _p(out))
         return out
+
+    @property
+    def manifold(self) -> bool:
+        return bool(lib().mo_mesh_is_manifold(self._h))
+
+    def vertex_faces(self):
+        """getFacesOfVertex order (half-edge circulator) as CSR: (ptr[V+1], faces[3F])."""
+        ptr = np.empty(self.V + 1, dtype=np.uint32)
+        vf = np.empty(3 * self.F, dtype=np.uint32)
+        lib().mo_mesh_vertex_faces(self._h, _p(ptr), _p(vf))
+        return ptr, vf
+
+    def vertex_edges(self):
+        ptr = np.empty(self.V + 1, dtype=np.uint32)
+        ve = np.empty(2 * self.E, dtype=np.uint32)
+        lib().mo_mesh_vertex_edges(self._h, _p(ptr), _p(ve))
+        return ptr, ve
 
     def face_edges(self) -> np.ndarray:
         out = np.empty((self.F, 3), dtype=np.uint32)
@@ -318,6 +341,19 @@ class OracleMesh:
         cost = C.c_double(0)
         n = lib().mo_cvp_poses(self._h, _p(fn), _p(pp), _p(pf), len(pf), _p(gp), _p(poses), C.byref(cost))
         return poses[:n].copy(), cost.value
+
+
+def inflation_vector_at(distances, vecmap, cfg: InflationCfg, repulsive_field: bool, vs, bary) -> np.ndarray:
+    d, v = _f32(distances), _f32(vecmap)
+    fld = _InflationField(d.ctypes.data, v.ctypes.data, cfg, int(repulsive_field))
+    out = np.zeros(3, dtype=np.float32)
+    lib().mo_inflation_vector_at(C.byref(fld), _p(_u32(vs)), _p(_f32(bary)), _p(out))
+    return out
+
+
+def set_heap_ties_by_id(on: bool) -> None:
+    """True (default): equal keys pop in ascending vertex id (the device rule); False: plain lvr2-style heap."""
+    lib().mo_set_heap_ties_by_id(1 if on else 0)
 
 
 def combine(layers, weights=None, mode: str = "avg") -> np.ndarray:

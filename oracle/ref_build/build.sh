@@ -1,0 +1,50 @@
+#!/bin/bash
+# Builds oracle/_ref/libmnav_ref.so: the REFERENCE's own planner / mesh_map / mesh_layers translation units,
+# compiled UNMODIFIED from where they lie under /root/reference (never copied), against the stub headers in
+# oracle/ref_build/stubs (lvr2, pmp, rclcpp, tf2, pluginlib, MBF, boost, assimp: all absent in this image),
+# plus the C-ABI harness ref_harness.cpp.  Also builds oracle/_ref/ref_inflation_test from the reference's
+# own gtest file.  Outputs only into oracle/_ref/ (git-ignored; travels to the GPU box with gpurun).
+# Flags mirror the reference's Release build: -O3 -DNDEBUG, C++17, no -march, no -ffast-math.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+REF="${MNAV_REFERENCE_DIR:-/root/reference}"
+OUT="$HERE/../_ref"
+if [ ! -d "$REF/dijkstra_mesh_planner" ]; then
+  echo "build.sh: reference checkout not found at $REF (prebuilt oracle/_ref is used as is)" >&2
+  exit 0
+fi
+mkdir -p "$OUT/obj"
+CXX="${CXX:-g++}"
+CXXFLAGS="-std=c++17 -O3 -DNDEBUG -fPIC -ffp-contract=off -w"
+INC="-I$HERE/stubs -I$REF/mesh_map/include -I$REF/mbf_mesh_core/include -I$REF/dijkstra_mesh_planner/include -I$REF/cvp_mesh_planner/include -I$REF/mesh_layers/include"
+SRCS="
+dijkstra_mesh_planner/src/dijkstra_mesh_planner.cpp
+cvp_mesh_planner/src/cvp_mesh_planner.cpp
+mesh_map/src/mesh_map.cpp
+mesh_map/src/util.cpp
+mesh_map/src/abstract_layer.cpp
+mesh_map/src/layer_manager.cpp
+mesh_map/src/timer.cpp
+mesh_layers/src/inflation_layer.cpp
+mesh_layers/src/steepness_layer.cpp
+mesh_layers/src/combination_layer.cpp
+"
+OBJS=""
+pids=()
+for s in $SRCS; do
+  o="$OUT/obj/$(basename "$s" .cpp).o"
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ] || [ -n "$(find "$HERE/stubs" -newer "$o" -type f | head -1)" ]; then
+    $CXX $CXXFLAGS $INC -c "$REF/$s" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+# the harness reads the planners' private result maps: -fno-access-control (this TU only)
+$CXX $CXXFLAGS -fno-access-control $INC -c "$HERE/ref_harness.cpp" -o "$OUT/obj/ref_harness.o"
+$CXX -shared -o "$OUT/libmnav_ref.so" $OBJS "$OUT/obj/ref_harness.o" -lpthread
+# the reference's own known-answer test (mesh_layers/test/inflation_layer_test.cpp), stub gtest
+$CXX $CXXFLAGS $INC -c "$REF/mesh_layers/test/inflation_layer_test.cpp" -o "$OUT/obj/inflation_layer_test.o"
+$CXX $CXXFLAGS $INC -c "$HERE/gtest_main.cpp" -o "$OUT/obj/gtest_main.o"
+$CXX -o "$OUT/ref_inflation_test" "$OUT/obj/inflation_layer_test.o" "$OUT/obj/gtest_main.o" $OBJS -lpthread
+echo "built $OUT/libmnav_ref.so $OUT/ref_inflation_test"

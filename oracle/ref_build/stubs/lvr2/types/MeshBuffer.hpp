@@ -1,0 +1,1 @@
+#include "../../lvr2_stub.hpp"

@@ -125,6 +125,8 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   int j = 0;
   Ctl cur;
   std::vector<uint32_t> perm;
+  const int sm_debug = getenv("SM_DEBUG") ? atoi(getenv("SM_DEBUG")) : -1;   // debugging aids, read once
+  const int sm_cycle = getenv("SM_CYCLE") ? atoi(getenv("SM_CYCLE")) : -1;
   for (;; ++j) {
     const Ctl& prev = ctl[(j + 1) & 1];
     const Cnt& cprev = cnt[(j + 2) % 3];
@@ -132,7 +134,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     ctl[j & 1] = cur;
     Cnt& cnext = cnt[(j + 1) % 3];
     cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0;
-    if (getenv("SM_DEBUG") && j >= atoi(getenv("SM_DEBUG")) && j < atoi(getenv("SM_DEBUG")) + 140)
+    if (sm_debug >= 0 && j >= sm_debug && j < sm_debug + 140)
       fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
     if (cur.done) break;
     Cnt& cc = cnt[j % 3];
@@ -187,7 +189,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
       }
     }
     evals += cc.evals;
-    if (getenv("SM_CYCLE") && j >= atoi(getenv("SM_CYCLE")) && j < atoi(getenv("SM_CYCLE")) + 8) {   // debugging aid
+    if (sm_cycle >= 0 && j >= sm_cycle && j < sm_cycle + 8) {   // debugging aid
       static std::vector<float> pd; static std::vector<PopKey> pk;
       if (pd.size() == V) {
         fprintf(stderr, "== step %d thr [%.7f, %.7f) n=%u changed=%u\n", j, cur.thr_fixed, cur.thr, cur.n, cc.changed);

@@ -1,0 +1,314 @@
+"""Pins the C restatement (oracle/mnav_oracle.c) to the REFERENCE's own code -- CPU.
+
+oracle/_ref/libmnav_ref.so holds the reference's planner, mesh_map and mesh_layers translation units compiled
+unmodified (oracle/ref_build/build.sh).  Every assertion below compares an output of that library with the
+restatement on the same seeded input, bit for bit unless a tolerance is written out.  What the comparison cannot
+pin is what lives inside the un-vendored lvr2 (modelled in oracle/ref_build/stubs): see DESIGN.md section 5.
+"""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from oracle import oracle as O
+from oracle import ref as R
+from tests.common import Case, layered_costs
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref is not built and /root/reference is absent")
+
+
+def beq(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_reference_own_gtests_pass_on_reference_code():
+    """mesh_layers/test/inflation_layer_test.cpp, unmodified, against the reference's InflationLayer."""
+    rc, out = R.run_reference_gtests()
+    assert rc == 0, out
+    assert "InflationLayer.test_wave_front_update" in out and "2 tests, 0 failures" in out
+
+
+MESHES = {
+    "terrain": lambda: meshgen.terrain(64, 0.1, 13),
+    "punched": lambda: meshgen.punched(64, 0.1, 5, drop=0.3, cut_column=40),
+    "fan": lambda: meshgen.fan_field(),
+    "punched_light": lambda: meshgen.punched(48, 0.1, 9, drop=0.08),
+}
+
+
+@pytest.mark.parametrize("name", list(MESHES))
+def test_topology_conventions_match_the_half_edge_mesh(name):
+    """edge ids, face vertex order, getEdgesOfVertex / getFacesOfVertex circulator order, derived attributes"""
+    mesh = MESHES[name]()
+    om = O.OracleMesh(mesh.xyz, mesh.faces)
+    rm = R.RefMap(mesh.xyz, mesh.faces)
+    assert om.manifold and rm.E == om.E == mesh.E
+    assert np.array_equal(np.sort(rm.edges(), 1), np.sort(om.edges(), 1))        # same id -> same vertex pair
+    assert np.array_equal(rm.face_vertices(), mesh.faces)
+    ptr, vf = om.vertex_faces()
+    eptr, ve = om.vertex_edges()
+    for v in range(mesh.V):
+        assert np.array_equal(vf[ptr[v]:ptr[v + 1]], rm.faces_of_vertex(v)), v
+        assert np.array_equal(ve[eptr[v]:eptr[v + 1]], rm.edges_of_vertex(v)), v
+    assert beq(rm.edge_distances(), om.edge_distances())
+    assert beq(rm.face_normals(), om.face_normals())
+    has_face = np.diff(ptr) > 0                                                   # face-less vertices have no normal
+    assert beq(rm.vertex_normals()[has_face], om.vertex_normals()[has_face])
+
+
+def compare_plans(case, rm, s, t, sp=None, tp=None, **kw):
+    m = case.mesh
+    rd = rm.dijkstra(m.xyz[s], m.xyz[t], **kw)
+    od = case.om.dijkstra(case.weights, case.costs, s, t, invalid=case.invalid, **kw)
+    assert rd.code == od.code
+    assert beq(rd.dist, od.dist) and np.array_equal(rd.pred, od.pred) and np.array_equal(rd.path, od.path)
+    if rd.code == 0:
+        vm = case.om.dijkstra_vector_map(od.pred)
+        assert np.array_equal(rd.has_vec.astype(bool), od.pred != np.arange(m.V)) and beq(rd.vecmap, vm)
+    if sp is None:
+        off = np.array([0.03, 0.02, 0.0], np.float32)
+        sp, tp = m.xyz[s] + off, m.xyz[t] + off
+    sf, sb = case.om.containing_face(sp)
+    tf, tb = case.om.containing_face(tp)
+    rsf, rsb = rm.containing_face(sp)
+    rtf, rtb = rm.containing_face(tp)
+    assert (sf, tf) == (rsf, rtf) and beq(sb, rsb) and beq(tb, rtb)
+    rc = rm.cvp(sp, tp, **kw)
+    oc = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf, invalid=case.invalid, **kw)
+    backtrack_failed = rc.message.startswith("Could not find a valid path, while back-tracking")
+    assert (0 if backtrack_failed else rc.code) == oc.code, rc.message
+    assert beq(rc.dist, oc.dist) and np.array_equal(rc.pred, oc.pred)
+    assert beq(rc.direction, oc.direction) and np.array_equal(rc.cutface, oc.cutface)
+    assert np.array_equal(rc.has_vec, oc.has_vec) and beq(rc.vecmap, oc.vecmap)
+    if oc.code == 0:
+        step = kw.get("step_width", 0.4)
+        code, ppos, pface = case.om.cvp_backtrack(oc.vecmap, oc.has_vec, sp, sf, tp, tf, step_width=step)
+        assert code == rc.code
+        if code == 0:
+            assert np.array_equal(pface, rc.path_face) and beq(ppos, rc.path_pos)
+    return rd, rc
+
+
+@pytest.mark.parametrize("offset", [0.0, 0.3, 2.5, float("inf")])
+def test_c1_planners_bit_equal(offset):
+    case = Case(meshgen.terrain(224, 0.1, 1))
+    rm = R.RefMap(case.mesh.xyz, case.mesh.faces)
+    assert beq(rm.edge_weights(), case.weights) and beq(rm.vertex_costs(), case.costs)
+    s, t = case.mesh.vertex_at(0.1, 0.1), case.mesh.vertex_at(0.9, 0.9)
+    rd, rc = compare_plans(case, rm, s, t, goal_dist_offset=offset)
+    assert rd.code == 0 and rc.code == 0 and len(rc.path_face) > 10       # step_width 0.4 (reference default) works
+
+
+@pytest.mark.parametrize("mode", ["avg", "max"])
+def test_config3_layer_stack_and_planners(mode):
+    """Steepness + Inflation + combination through the reference's LayerManager vs the restated layers."""
+    base = Case(meshgen.terrain(48, 0.1, 3, amplitude=0.8))
+    costs, parts = layered_costs(base, mode)
+    rm = R.RefMap(base.mesh.xyz, base.mesh.faces, layers="c3", combination=mode, edge_cost_factor=1.0,
+                  extra_params={"mesh_map.inflation.repulsive_field": False})
+    st, le = rm.layer_costs("steepness")
+    ic, _ = rm.layer_costs("inflation")
+    cc, cl = rm.layer_costs("combined")
+    assert beq(st, parts["steepness"]) and np.array_equal(le, parts["lethal"]) and le.sum() > 0
+    assert beq(ic, parts["inflation"]) and beq(cc, costs) and np.array_equal(cl, parts["lethal"])
+    d, _ = rm.inflation_fields()
+    assert beq(d, parts["infl_dist"])
+    case = Case(base.mesh, costs, 1.0)
+    assert beq(rm.vertex_costs(), costs) and beq(rm.edge_weights(), case.weights)
+    free = np.where(costs < 0.5)[0]
+    m = case.mesh
+    def near(f):
+        v = m.vertex_at(*f)
+        return int(free[((m.xyz[free, :2] - m.xyz[v, :2]) ** 2).sum(1).argmin()])
+    compare_plans(case, rm, near((0.15, 0.15)), near((0.85, 0.85)))
+
+
+def test_inflation_vector_field_with_the_plain_heap():
+    """All inflation seeds sit at 0: which of them pops first is decided inside lvr2::Meap.  With the oracle's
+    heap switched to the plain array heap of the stub (no id tie-break) even the order-dependent repulsive
+    vector field agrees bit for bit; distances and costs agree under either rule (previous test)."""
+    base = Case(meshgen.terrain(48, 0.1, 3, amplitude=0.8))
+    rm = R.RefMap(base.mesh.xyz, base.mesh.faces, layers="c3", edge_cost_factor=1.0)
+    rd, rv = rm.inflation_fields()
+    O.set_heap_ties_by_id(False)
+    try:
+        _, le = base.om.steepness(base.vn, 0.3)
+        _, od, ov = base.om.inflation(le, base.edge_dist)
+    finally:
+        O.set_heap_ties_by_id(True)
+    assert beq(od, rd) and beq(ov, rv)
+
+
+def adversarial_case():
+    mesh = meshgen.terrain(96, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    invalid[[s, t]] = 0
+    costs[[s, t]] = 0
+    return mesh, costs, invalid, s, t
+
+
+def face_centroids(mesh, s, t):
+    fl = mesh.faces.ravel()
+    first_face = np.full(mesh.V, -1, np.int64)
+    first_face[fl[::-1]] = np.arange(fl.size)[::-1] // 3
+    sf, tf = int(first_face[s]), int(first_face[t])
+    sp = mesh.xyz[mesh.faces[sf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    tp = mesh.xyz[mesh.faces[tf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    return sp, tp
+
+
+@pytest.mark.parametrize("use_invalid,limit", [(False, 1.0), (True, 1.0), (False, 5.0), (True, 0.6)])
+def test_adversarial_costs_where_the_circulator_order_decides(use_invalid, limit):
+    """Random vertex costs up to 1.2 with edge_cost_factor 1: most triangles violate the triangle inequality, the
+    CVP update is then not a pure minimum and the order in which one pop applies its faces changes the result."""
+    mesh, costs, invalid, s, t = adversarial_case()
+    inv = invalid if use_invalid else None
+    case = Case(mesh, costs, 1.0, inv)
+    rm = R.RefMap(mesh.xyz, mesh.faces, vertex_costs=costs, edge_cost_factor=1.0)
+    if use_invalid:
+        rm.set_invalid(invalid)
+    assert beq(rm.edge_weights(), case.weights)
+    sp, tp = face_centroids(mesh, s, t)
+    compare_plans(case, rm, s, t, sp, tp, cost_limit=limit)
+
+
+def test_punched_terrain_with_holes_and_components():
+    mesh = meshgen.punched(64, 0.1, 5, drop=0.3, cut_column=40)
+    case = Case(mesh)
+    rm = R.RefMap(mesh.xyz, mesh.faces)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    s, t = mesh.vertex_at(0.1, 0.2), mesh.vertex_at(0.5, 0.8)
+    while deg[s] == 0: s += 1
+    while deg[t] == 0: t += 1
+    sp, tp = face_centroids(mesh, s, t)
+    compare_plans(case, rm, s, t, sp, tp)
+    # the other component is unreachable
+    u = mesh.vertex_at(0.9, 0.5)
+    while deg[u] == 0: u += 1
+    rd = rm.dijkstra(mesh.xyz[s], mesh.xyz[u])
+    od = case.om.dijkstra(case.weights, case.costs, s, u)
+    assert rd.code == od.code == O.NO_PATH_FOUND and beq(rd.dist, od.dist)
+
+
+def test_make_plan_poses():
+    """makePlan end to end: Dijkstra (dijkstra_mesh_planner.cpp:55-134) and CVP (cvp_mesh_planner.cpp:62-140).
+    Positions are the float32 path bit for bit; orientations go through lvr2::Normal (normalises on every
+    construction) and tf2 in doubles: 1e-6 absolute."""
+    case = Case(meshgen.terrain(96, 0.1, 7, amplitude=0.8))
+    m = case.mesh
+    rm = R.RefMap(m.xyz, m.faces)
+    goal_v, robot_v = m.vertex_at(0.15, 0.2), m.vertex_at(0.85, 0.8)
+    off = np.array([0.02, 0.03, 0.0], np.float32)
+    start = np.concatenate([(m.xyz[robot_v] + off).astype(np.float64), [0, 0, 0, 1]])
+    goal = np.concatenate([(m.xyz[goal_v] + off).astype(np.float64), [0, 0, 0.6, 0.8]])
+    code, poses, cost = rm.dijkstra_make_plan(start, goal)
+    sv, tv = case.om.nearest_vertex(goal[:3]), case.om.nearest_vertex(start[:3])
+    od = case.om.dijkstra(case.weights, case.costs, sv, tv)
+    oposes, ocost = case.om.dijkstra_poses(case.vn, od.path, start[:3], goal[:3])
+    assert code == od.code == 0 and len(poses) == len(oposes) == len(od.path) + 1
+    assert np.array_equal(poses[:, :3], oposes[:, :3]) and np.abs(poses[:, 3:] - oposes[:, 3:]).max() < 1e-6
+    assert cost == ocost
+    code, poses, cost, msg = rm.cvp_make_plan(start, goal)
+    sp, tp = goal[:3].astype(np.float32), start[:3].astype(np.float32)
+    sf, _ = case.om.containing_face(sp)
+    tf, _ = case.om.containing_face(tp)
+    oc = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    bcode, ppos, pface = case.om.cvp_backtrack(oc.vecmap, oc.has_vec, sp, sf, tp, tf)
+    oposes, ocost = case.om.cvp_poses(case.fn, ppos, pface, goal)      # last pose = the goal pose verbatim (:119-123)
+    assert code == bcode == 0, msg
+    assert len(poses) == len(oposes)
+    assert np.array_equal(poses[:, :3], oposes[:, :3]) and np.abs(poses[:, 3:] - oposes[:, 3:]).max() < 1e-6
+    assert cost == ocost
+
+
+def test_incremental_edge_weight_update_equals_full_recompute():
+    """layer change -> LayerManager::layer_changed -> MeshMap::layerChanged -> updateEdgeWeights(changed)
+    (mesh_map.cpp:454-493, :563-618) against the restated computeEdgeWeights on the new cost vector."""
+    mesh = meshgen.terrain(64, 0.1, 21)
+    rng = np.random.default_rng(9)
+    costs = rng.uniform(0, 0.9, mesh.V).astype(np.float32)
+    om = O.OracleMesh(mesh.xyz, mesh.faces)
+    ed = om.edge_distances()
+    rm = R.RefMap(mesh.xyz, mesh.faces, vertex_costs=costs, edge_cost_factor=0.7)
+    assert beq(rm.edge_weights(), om.edge_weights(ed, costs, 0.7))
+    ids = rng.choice(mesh.V, 300, replace=False).astype(np.uint32)
+    vals = rng.uniform(0, 1.5, ids.size).astype(np.float32)
+    vals[:5] = np.inf                                       # lethal: infinite edge weights (:539-543)
+    rm.update_array_layer(ids, vals)
+    costs2 = costs.copy()
+    costs2[ids] = vals
+    assert beq(rm.vertex_costs(), costs2)
+    assert beq(rm.edge_weights(), om.edge_weights(ed, costs2, 0.7))
+
+
+def test_seed_lookup_kd_tree_and_containing_face():
+    """getNearestVertexHandle (nanoflann, vendored in the reference) and searchContainingFace on random queries,
+    including points off the mesh."""
+    mesh = meshgen.terrain(64, 0.1, 5)
+    om = O.OracleMesh(mesh.xyz, mesh.faces)
+    rm = R.RefMap(mesh.xyz, mesh.faces)
+    rng = np.random.default_rng(2)
+    lo, hi = mesh.xyz.min(0), mesh.xyz.max(0)
+    q = rng.uniform(lo - 0.5, hi + 0.5, size=(400, 3)).astype(np.float32)
+    q[:200, 2] = mesh.xyz[rng.integers(0, mesh.V, 200), 2]
+    for p in q:
+        assert rm.nearest_vertex(p) == om.nearest_vertex(p)
+        f, b = rm.containing_face(p)
+        of, ob = om.containing_face(p)
+        assert f == of
+        if f != R.NONE:
+            assert beq(b, ob)
+
+
+def test_regular_grid_ties_distances_agree_predecessors_need_the_tie_rule():
+    """Un-jittered unit grid: thousands of equal keys.  The potential does not depend on the pop order among equal
+    keys; predecessors do -- the restatement (and the device) break ties by vertex id, lvr2::Meap by its sift
+    mechanics.  Both predecessor fields must still be shortest-path trees."""
+    mesh = meshgen.flat_grid(40, 1.0)
+    case = Case(mesh)
+    rm = R.RefMap(mesh.xyz, mesh.faces)
+    s, t = mesh.vertex_at(0.0, 0.0), mesh.vertex_at(1.0, 1.0)
+    rd = rm.dijkstra(mesh.xyz[s], mesh.xyz[t], goal_dist_offset=float("inf"))
+    od = case.om.dijkstra(case.weights, case.costs, s, t, goal_dist_offset=float("inf"))
+    assert beq(rd.dist, od.dist)
+    w = {}
+    for e, (a, b) in enumerate(mesh.edges):
+        w[(int(a), int(b))] = w[(int(b), int(a))] = case.weights[e]
+    for pred in (rd.pred, od.pred):
+        for v in range(mesh.V):
+            if v != s:
+                assert np.float32(od.dist[pred[v]] + w[(int(pred[v]), v)]) == od.dist[v]
+    O.set_heap_ties_by_id(False)
+    try:
+        od2 = case.om.dijkstra(case.weights, case.costs, s, t, goal_dist_offset=float("inf"))
+    finally:
+        O.set_heap_ties_by_id(True)
+    assert np.array_equal(od2.pred, rd.pred) and np.array_equal(od2.path, rd.path)   # same heap -> same ties
+
+
+def test_inflation_repulsive_field_sampling():
+    """InflationLayer::vectorAt (inflation_layer.cpp:493-521) on faces the inflation wave covered."""
+    base = Case(meshgen.terrain(48, 0.1, 3, amplitude=0.8))
+    rm = R.RefMap(base.mesh.xyz, base.mesh.faces, layers="c3", edge_cost_factor=1.0)
+    d, vec = rm.inflation_fields()
+    covered = np.isfinite(d)
+    faces = base.mesh.faces[covered[base.mesh.faces].all(1)]
+    assert len(faces) > 50
+    rng = np.random.default_rng(4)
+    cfg = O.InflationCfg.defaults()
+    checked = panicked = 0
+    for f in faces[rng.choice(len(faces), 80, replace=False)]:
+        b = rng.dirichlet([1, 1, 1]).astype(np.float32)
+        got = rm.layer_vector_at("inflation", f, b)
+        if got is None:           # a vertex the wave gave a distance but no vector: the reference's map lookup panics
+            panicked += 1
+            continue
+        want = O.inflation_vector_at(d, vec, cfg, True, f, b)
+        assert beq(got, want)
+        checked += 1
+    assert checked >= 30, (checked, panicked)
+    # ... and on a face the wave never reached the lookup of distances_ panics (caught in cvp_mesh_planner.cpp:944):
+    far = base.mesh.faces[(~covered[base.mesh.faces]).all(1)]
+    assert len(far) > 0 and rm.layer_vector_at("inflation", far[0], np.float32([0.3, 0.3, 0.4])) is None
