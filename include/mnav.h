@@ -30,7 +30,7 @@ extern "C" {
 #define MNAV_INVALID_START 52u  /* ...::INVALID_START                       */
 #define MNAV_INVALID_GOAL 53u   /* ...::INVALID_GOAL                        */
 #define MNAV_NO_PATH_FOUND 54u  /* ...::NO_PATH_FOUND                       */
-#define MNAV_INTERNAL_ERROR 59u /* ...::INTERNAL_ERROR (device/runtime failure) */
+#define MNAV_INTERNAL_ERROR 60u /* ...::INTERNAL_ERROR (device/runtime failure) */
 #define MNAV_NONE 0xFFFFFFFFu
 
 typedef struct mnav_ctx mnav_ctx;

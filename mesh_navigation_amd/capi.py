@@ -14,7 +14,7 @@ import numpy as np
 from . import build as _build
 
 NONE = 0xFFFFFFFF
-SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 0, 51, 52, 53, 54, 59
+SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 0, 51, 52, 53, 54, 60
 
 # every symbol include/mnav.h declares
 SYMBOLS = [

@@ -19,7 +19,7 @@ struct PoseStamped { std_msgs::msg::Header header; Pose pose; };
 
 // mbf_msgs::action::GetPath::Result codes used by the planners (dijkstra_mesh_planner.h:72-85)
 namespace mbf_msgs { namespace action { struct GetPath { struct Result { enum : uint32_t {
-  SUCCESS = 0, CANCELED = 51, INVALID_START = 52, INVALID_GOAL = 53, NO_PATH_FOUND = 54, TF_ERROR = 57, INTERNAL_ERROR = 59 }; }; }; } }
+  SUCCESS = 0, CANCELED = 51, INVALID_START = 52, INVALID_GOAL = 53, NO_PATH_FOUND = 54, TF_ERROR = 57, NOT_INITIALIZED = 58, INVALID_PLUGIN = 59, INTERNAL_ERROR = 60 }; }; }; } }
 
 namespace rclcpp {
 // parameter store with the declare_parameter() contract the planners rely on

@@ -381,6 +381,44 @@ __global__ __launch_bounds__(kWave) void k_step(const Plan* __restrict__ plans, 
   }
 }
 
+// CVP verification sweep, run once after the last step (the CVP counterpart of k_dij_finalize's fixed-point
+// check): every vertex is evaluated once more on the CONVERGED state.  (1) Its stored (potential, pop key,
+// predecessor, direction, cutting face) must be reproduced exactly -- a vertex that was evaluated against a
+// stale or torn key of a far cascade ancestor and never re-queued shows up here; (2) a walk over the cascade
+// tree that hits its bound on the converged tree would silently change the pop order -- during the iteration
+// such hits are transient and ignored (k_flags_reset clears them), here they count.  Either way the plan
+// returns INTERNAL_ERROR instead of a potential that may not be the reference's.
+__global__ void k_flags_reset(const Plan* __restrict__ plans)
+{
+  if (threadIdx.x == 0) { Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; plans[blockIdx.x].cnt[3] = z; }
+}
+
+__global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans)
+{
+  const Plan& P = plans[blockIdx.y];
+  const int lane = threadIdx.x;
+  const Ctl a = P.ctl[0], b = P.ctl[1];
+  const Ctl cur = (a.it > b.it) ? a : b;
+  if (!cur.done || cur.overflow) return;                               // reported as an error anyway
+  const int sub = lane & (kGroup - 1), grp = lane >> 3;
+  const uint32_t ngroups = gridDim.x * kGroupsPerWave;
+  const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
+  uint32_t bad = 0;
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t v = blockIdx.x * kGroupsPerWave + grp + r * ngroups;
+    const bool act = v < P.V && !is_seed(P, v < P.V ? v : 0u) && !P.blocked[v < P.V ? v : 0u];
+    if (!act) continue;                                               // whole 8-lane groups skip together
+    const Eval e = group_eval_cvp(P, cur, v, sub);
+    if (sub == 0) {
+      const bool same = f2u(e.d) == f2u(P.dist[v]) && e.key == P.tkey[v] && e.pred == P.pred[v] &&
+                        (!(e.d < inf_f()) || (e.cut == P.cutf[v] && f2u(e.dir) == f2u(P.dirn[v])));
+      if (!same) ++bad;
+    }
+  }
+  bad = wave_sum(bad);
+  if (lane == 0 && bad) atomicAdd(&P.cnt[3].changed, bad);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tiled label-correcting SSSP (Dijkstra planner).  The final float32 distances of the reference
 // loop (dijkstra :287-348) are the unique fixed point of d[v] = min_u fl(d[u] + w(u,v)) over
@@ -415,6 +453,7 @@ struct TilePlan {
   float band;
   uint32_t max_rounds;
   uint32_t max_nv, max_nh, max_ne;
+  const uint32_t* cancel;  // host-pinned flag set by mnav_cancel (polled by k_plan_persistent), may be null
 };
 
 constexpr int kTileBlock = 256;
@@ -743,6 +782,8 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
   __shared__ uint32_t s_hdr[8];
   __shared__ uint32_t s_nq[3];
   __shared__ float s_bound;
+  __shared__ uint32_t s_stop;
+  if (tid == 0) s_stop = 0u;
   MNAV_GLOBAL uint32_t* pend = as_global(P.pend[0]);
   MNAV_GLOBAL const uint32_t* g_vptr = as_global(P.vptr);
   MNAV_GLOBAL const uint32_t* g_hptr = as_global(P.hptr);
@@ -786,8 +827,12 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
     if (tid == 0) {
       const float dt = ldg_f32(g_dist + P.target);
       s_bound = (float)((double)dt + P.offset);                    // >= the final goal_dist (dijkstra :296)
+      // mnav_cancel (dijkstra :287 `&& !cancel_planning_`): a word in device memory that mnav_cancel sets with a
+      // 4-byte copy on its own stream; one agent-scope load every 16 tile activations (~0.3 ms)
+      if ((acts & 15u) == 0u) s_stop = P.cancel ? __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     __syncthreads();
+    if (s_stop) { status = 3; break; }
     best = s_best[0];
 #pragma unroll
     for (int w = 1; w < kTileBlock / 64; ++w) best = s_best[w] < best ? s_best[w] : best;
@@ -1132,12 +1177,14 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   Cnt ci; ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u; ci.evals = 0;
   P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"
   Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
-  P.cnt[0] = z; P.cnt[1] = z;
+  P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;                         // cnt[3]: sticky flags (mnav_eval.h kFlag*)
 }
 
 // ---------------------------------------------------------------------------------------------
 // result assembly: code + vertex path (dijkstra :358-373) / reachability (cvp :902-918), stats
 // ---------------------------------------------------------------------------------------------
+
+constexpr uint32_t kPathOverflow = 0xFFFFFFF0u;   // internal: the path row was too short, the host retries with rows of V ids
 
 template <uint32_t PLANNER>
 __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict__ res,
@@ -1153,7 +1200,11 @@ __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict_
   R.evals = last.evals;
   R.path_len = 0;
   uint32_t code = kSuccess;
-  if (last.overflow || !last.done) code = kInternalError;
+  if (PLANNER == kPlannerCvp) {                                     // k_cvp_verify
+    if (P.cnt[3].n_next & kFlagWalkLimit) R.overflow |= 8u;         // cascade-tree walk bound hit on the converged tree
+    if (P.cnt[3].changed) R.overflow |= 16u;                        // a vertex is not a fixed point of the gather rule
+  }
+  if (R.overflow || !last.done) code = kInternalError;
   else if (PLANNER == kPlannerDijkstra) {
     const uint32_t seed = P.seed[0], target = P.target[0];
     if (P.pred[target] == target) code = kNoPathFound;             // dijkstra :358
@@ -1161,7 +1212,7 @@ __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict_
       uint32_t* path = paths + (size_t)blockIdx.x * path_stride;   // written target-side first
       uint32_t n = 0, v = target;
       while (v != seed && n < path_stride) { v = P.pred[v]; path[n++] = v; }   // :369-373
-      if (v != seed) code = kInternalError;
+      if (v != seed) code = (path_stride < P.V) ? kPathOverflow : kInternalError;   // row too short: the host retries with V ids
       R.path_len = n;
     }
   } else {
@@ -1345,6 +1396,9 @@ struct mnav_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   std::atomic<int> cancel{ 0 };
+  uint32_t* d_cancel = nullptr;            // the same flag in device memory: long-running kernels poll it (agent-scope load)
+  uint32_t* h_one = nullptr;               // pinned source word (1) for the copy mnav_cancel issues on its own stream
+  hipStream_t cancel_stream = nullptr;
   // host copies needed for seeding
   uint32_t V = 0, F = 0, E = 0;
   std::vector<float> h_xyz, h_cost;
@@ -1362,12 +1416,15 @@ struct mnav_ctx {
   Nbr* d_nbr = nullptr; double nbr_limit = NAN; bool nbr_valid = false;
   Corner* d_crn = nullptr; uint8_t* d_blocked = nullptr; double crn_limit = NAN; bool crn_valid = false;
   FaceCirculation circ;                                            // caller-supplied getFacesOfVertex rows (optional)
+  bool cvp_verify = true;                                          // k_cvp_verify after every CVP plan (MNAV_CVP_VERIFY=0 to skip)
+  int walk_max = kKeyWalkMax, descend_max = kDescendWalkMax;       // cascade-tree walk bounds (MNAV_KEY_WALK_MAX / MNAV_DESCEND_WALK_MAX: tests)
   // plans
   std::vector<Slot> slots;
   Plan* d_plans = nullptr; uint32_t plans_cap = 0;
   PlanResult* d_res = nullptr; PlanResult* h_res = nullptr;
   float** d_vecptrs = nullptr;
-  uint32_t* d_paths = nullptr; uint32_t paths_cap = 0;
+  uint32_t* d_paths = nullptr; size_t paths_words = 0; uint32_t path_stride = 0;   // n plans x path_stride vertex ids
+  std::unordered_map<void*, size_t> alloc_bytes;                   // sizes of the dev_upload buffers (re-used when unchanged)
   Ctl* h_ctl = nullptr;       // pinned, 2 per plan
   float* d_seed_pos = nullptr; uint32_t seed_pos_cap = 1;
   std::map<uint64_t, hipGraphExec_t> graphs;
@@ -1403,11 +1460,12 @@ struct mnav_ctx {
 
 namespace {
 
+#define MTRACE(msg) do { if (getenv("MNAV_TRACE")) { fprintf(stderr, "[mnav] %s:%d %s\n", __func__, __LINE__, msg); fflush(stderr); } } while (0)
 #define HIPCHK(call)                                                                               \
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
     if (e_ != hipSuccess) {                                                                        \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_) + " (mnav.hip:" + std::to_string(__LINE__) + ")"; \
       return -1;                                                                                   \
     }                                                                                              \
   } while (0)
@@ -1415,8 +1473,13 @@ namespace {
 template <class T>
 int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
 {
-  if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
-  HIPCHK(hipMalloc((void**)dptr, sizeof(T) * (n ? n : 1) + 64));   // tail slack: clamped vector loads may touch element 0 of an empty tile
+  const size_t bytes = sizeof(T) * (n ? n : 1) + 64;               // tail slack: clamped vector loads may touch element 0 of an empty tile
+  auto it = *dptr ? ctx->alloc_bytes.find((void*)*dptr) : ctx->alloc_bytes.end();
+  if (!*dptr || it == ctx->alloc_bytes.end() || it->second != bytes) {   // same size as last time (cost re-uploads): keep the buffer
+    if (*dptr) { ctx->alloc_bytes.erase((void*)*dptr); (void)hipFree(*dptr); *dptr = nullptr; }
+    HIPCHK(hipMalloc((void**)dptr, bytes));
+    ctx->alloc_bytes[(void*)*dptr] = bytes;
+  }
   if (n && host) HIPCHK(hipMemcpyAsync(*dptr, host, sizeof(T) * n, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }
@@ -1444,7 +1507,7 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp, bool band, bool vec)
   while (ctx->slots.size() < n) {
     Slot s;
     HIPCHK(hipMalloc((void**)&s.dist, 4 * V)); HIPCHK(hipMalloc((void**)&s.pred, 4 * V));   // 8 B per vertex and plan ...
-    HIPCHK(hipMalloc((void**)&s.cnt, 3 * sizeof(Cnt)));
+    HIPCHK(hipMalloc((void**)&s.cnt, 4 * sizeof(Cnt)));                                       // 3 rotating + sticky flags
     ctx->slots.push_back(s);
   }
   for (uint32_t i = 0; i < n; ++i) {                                   // ... the rest only for the paths that use it
@@ -1490,16 +1553,27 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp, bool band, bool vec)
   return 0;
 }
 
-int ensure_paths(mnav_ctx* ctx, uint32_t n)
+// Vertex paths of a batch: n rows of `stride` ids.  A path has ~1.4 sqrt(V) hops on a terrain, so rows of
+// 16 sqrt(V) + 1024 ids hold it with a wide margin (84 MB instead of 20 GB for 5120 plans on the 1M mesh); a path
+// that does not fit makes k_finish report kPathOverflow and the batch is finished again with rows of V ids.
+uint32_t default_path_stride(const mnav_ctx* ctx)
 {
-  if (ctx->paths_cap < n) {
+  const double s = 16.0 * std::sqrt((double)ctx->V) + 1024.0;
+  return (uint32_t)std::min<double>(s, (double)(ctx->V ? ctx->V : 1));
+}
+int ensure_paths(mnav_ctx* ctx, uint32_t n, uint32_t stride)
+{
+  const size_t words = (size_t)n * (stride ? stride : 1);
+  if (ctx->paths_words < words) {
     if (ctx->d_paths) (void)hipFree(ctx->d_paths);
-    ctx->d_paths = nullptr;
-    HIPCHK(hipMalloc((void**)&ctx->d_paths, sizeof(uint32_t) * (size_t)n * (ctx->V ? ctx->V : 1)));
-    ctx->paths_cap = n;
+    ctx->d_paths = nullptr; ctx->paths_words = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_paths, sizeof(uint32_t) * words));
+    ctx->paths_words = words;
   }
+  ctx->path_stride = stride;
   return 0;
 }
+int ensure_paths(mnav_ctx* ctx, uint32_t n) { return ensure_paths(ctx, n, default_path_stride(ctx)); }
 
 uint32_t blocks_per_plan(const mnav_ctx* ctx)
 {
@@ -1593,7 +1667,7 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
     P.dist = s.dist; P.tkey = cvp ? s.tkey : nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = delta; P.offset = offset; P.max_steps = ctx->max_steps;
+    P.delta = delta; P.offset = offset; P.max_steps = ctx->max_steps; P.walk_max = ctx->walk_max; P.descend_max = ctx->descend_max;
     for (int k = 0; k < 3; ++k) {
       P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = in[i].seed_d[k];
       P.seed_expands[k] = in[i].seed_expands[k]; P.target_expands[k] = in[i].target_expands[k];
@@ -1641,6 +1715,14 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
   }
   ctx->stats.launches = launches;
+  if (cvp && rc == 0 && ctx->cvp_verify) {
+    hipLaunchKernelGGL(k_flags_reset, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
+    uint32_t gv = (ctx->V / kGroupsPerWave + 3) / 4;                // ~4 vertices per 8-lane group
+    if (gv < 1) gv = 1;
+    if (gv > 8192) gv = 8192;
+    hipLaunchKernelGGL(k_cvp_verify, dim3(gv, n), dim3(kWave), 0, ctx->stream, ctx->d_plans);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   return rc;
 }
@@ -1750,7 +1832,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
     P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
     P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u;
+    P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
     for (int k = 0; k < 3; ++k) {
       P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1;
     }
@@ -1856,6 +1938,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
     T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
     T.max_rounds = 64u * (M.ntiles ? M.ntiles : 1u) + 1024u;          // activation cap per plan
+    T.cancel = ctx->d_cancel;
     T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
     T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
@@ -1889,6 +1972,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
   ctx->stats.launches = 1;
+  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;        // the kernel left its loops early (status 3): :350-354
   return 0;
 }
 
@@ -1955,6 +2039,10 @@ mnav_ctx* mnav_create(int device)
   for (auto& e : ctx->evc)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return nullptr; }
   if (hipMalloc((void**)&ctx->d_seed_pos, 3 * sizeof(float)) != hipSuccess) { delete ctx; return nullptr; }
+  if (hipMalloc((void**)&ctx->d_cancel, 64) != hipSuccess || hipMemset(ctx->d_cancel, 0, 64) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->h_one, 64, hipHostMallocDefault) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  *ctx->h_one = 1u;
   if (const char* e = getenv("MNAV_NO_GRAPH")) ctx->use_graph = !(atoi(e) != 0);
   if (const char* e = getenv("MNAV_DIJKSTRA_ENGINE")) {
     if (!strcmp(e, "band") || !strcmp(e, "1")) ctx->dij_engine = 1;
@@ -1982,6 +2070,9 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_t_halo_tile); (void)hipFree(ctx->d_t_eptr); (void)hipFree(ctx->d_t_src); (void)hipFree(ctx->d_vert_tile);
   (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
   (void)hipFree(ctx->d_tplans);
+  if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
+  if (ctx->h_one) (void)hipHostFree(ctx->h_one);
+  (void)hipFree(ctx->d_cancel);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
@@ -2028,7 +2119,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   for (auto& s : ctx->slots) free_slot(s);
   ctx->slots.clear();
   drop_graphs(ctx);
-  (void)hipFree(ctx->d_paths); ctx->d_paths = nullptr; ctx->paths_cap = 0;
+  (void)hipFree(ctx->d_paths); ctx->d_paths = nullptr; ctx->paths_words = 0;
   (void)hipFree(ctx->d_nbr); ctx->d_nbr = nullptr; (void)hipFree(ctx->d_crn); ctx->d_crn = nullptr;
   (void)hipFree(ctx->d_blocked); ctx->d_blocked = nullptr;
   (void)hipFree(ctx->d_cost); ctx->d_cost = nullptr; (void)hipFree(ctx->d_w); ctx->d_w = nullptr;
@@ -2041,6 +2132,9 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     ctx->max_steps = cap > 2.0e9 ? 2000000000u : (uint32_t)cap;
     if (const char* e = getenv("MNAV_MAX_STEPS")) ctx->max_steps = (uint32_t)atoll(e);
     if (const char* e = getenv("MNAV_MAX_WALL_S")) ctx->max_wall_s = atof(e);
+    if (const char* e = getenv("MNAV_CVP_VERIFY")) ctx->cvp_verify = atoi(e) != 0;
+    if (const char* e = getenv("MNAV_KEY_WALK_MAX")) ctx->walk_max = atoi(e);
+    if (const char* e = getenv("MNAV_DESCEND_WALK_MAX")) ctx->descend_max = atoi(e);
   }
   ctx->h_xyz.assign(xyz, xyz + 3 * (size_t)V);
   ctx->h_faces.assign(face_vtx, face_vtx + 3 * (size_t)F);
@@ -2217,8 +2311,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
   ctx->cancel.store(0);                                               // dijkstra :238
+  if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   ctx->want_vec = want_vecmap;
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
+  MTRACE("start");
   const uint32_t V = ctx->V;
   uint32_t worst = MNAV_SUCCESS;
   // id checks stand in for the optional-handle tests of dijkstra :240-243
@@ -2268,9 +2364,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
                  : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
                                  : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
     ctx->last_engine = engine;
+    MTRACE("engine returned");
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
-    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
+    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, ctx->path_stride);
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
     if (engine == 1)   // the tile engines count the settled vertices in k_dij_finalize
       hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
@@ -2280,6 +2377,18 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     (void)hipEventRecord(ctx->ev[5], ctx->stream);
     if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
+    {
+      bool overflow = false;
+      for (uint32_t k = 0; k < m; ++k) overflow = overflow || ctx->h_res[k].code == kPathOverflow;
+      if (overflow) {                                               // a path longer than the default rows: rows of V ids
+        std::vector<PlanResult> keep(ctx->h_res, ctx->h_res + m);   // settled / evals were accumulated by other kernels
+        if (ensure_paths(ctx, m, V)) return MNAV_INTERNAL_ERROR;
+        hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
+        if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
+        for (uint32_t k = 0; k < m; ++k) ctx->h_res[k].settled = keep[k].settled;
+      }
+    }
     if (ctx->last_engine != 1) {
       uint32_t mism = 0;
       if (hipMemcpy(&mism, ctx->d_mismatch, 4, hipMemcpyDeviceToHost) != hipSuccess || mism != 0) {
@@ -2287,15 +2396,17 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
         return MNAV_INTERNAL_ERROR;
       }
     }
+    MTRACE("results downloaded");
     // all vertex paths in one strided copy (device order: pred[target] ... seed)
     uint32_t maxlen = 0;
     for (uint32_t k = 0; k < m; ++k) if (ctx->h_res[k].code == MNAV_SUCCESS && ctx->h_res[k].path_len > maxlen) maxlen = ctx->h_res[k].path_len;
     std::vector<uint32_t> tmp;
     if (maxlen && path_out && path_cap) {
       tmp.resize((size_t)maxlen * m);
-      if (hipMemcpy2D(tmp.data(), (size_t)maxlen * 4, ctx->d_paths, (size_t)V * 4, (size_t)maxlen * 4, m, hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy2D(tmp.data(), (size_t)maxlen * 4, ctx->d_paths, (size_t)ctx->path_stride * 4, (size_t)maxlen * 4, m, hipMemcpyDeviceToHost) != hipSuccess)
         { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
     }
+    MTRACE("paths downloaded");
     for (uint32_t k = 0; k < m; ++k) {
       const uint32_t i = map[k];
       const PlanResult& r = ctx->h_res[k];
@@ -2319,6 +2430,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     (void)hipEventRecord(ctx->ev[6], ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "sync failed"; return MNAV_INTERNAL_ERROR; }
     finish_stats(ctx, m, false);
+    MTRACE("stats done");
   }
   // plans rejected before reaching the device: the reference has cleared its maps by then
   for (uint32_t i = 0; i < n; ++i) {
@@ -2363,6 +2475,7 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
   ctx->cancel.store(0);                                               // cvp :679
+  if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
   const uint32_t V = ctx->V;
   if (!ctx->have_normals) { ctx->err = "vertex normals were not uploaded"; return MNAV_INTERNAL_ERROR; }
@@ -2432,7 +2545,12 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
     finish_stats(ctx, m, true);
     for (uint32_t k = 0; k < m; ++k) {
       codes[map[k]] = ctx->h_res[k].code;
-      if (ctx->h_res[k].code == MNAV_INTERNAL_ERROR) { ctx->err = "CVP wavefront did not converge (step cap)"; }
+      if (ctx->h_res[k].code == MNAV_INTERNAL_ERROR) {
+        const uint32_t o = ctx->h_res[k].overflow;
+        ctx->err = (o & 8u) ? "CVP: a walk over the cascade tree hit its bound on the converged state (pop order not guaranteed)"
+                 : (o & 16u) ? "CVP: verification sweep found a vertex that is not a fixed point of the gather rule"
+                             : "CVP wavefront did not converge (step cap)";
+      }
     }
   }
   for (uint32_t i = 0; i < n; ++i) {
@@ -2465,7 +2583,13 @@ uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
                   vecmap_out);
 }
 
-void mnav_cancel(mnav_ctx* ctx) { if (ctx) ctx->cancel.store(1, std::memory_order_relaxed); }
+void mnav_cancel(mnav_ctx* ctx)
+{
+  if (!ctx) return;
+  ctx->cancel.store(1, std::memory_order_relaxed);
+  // thread-safe (MBF calls cancel() from the action-server thread), fire and forget: SDMA copy beside the running kernel
+  if (ctx->d_cancel && ctx->h_one) (void)hipMemcpyAsync(ctx->d_cancel, ctx->h_one, 4, hipMemcpyHostToDevice, ctx->cancel_stream);
+}
 
 int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out)
 {

@@ -29,7 +29,7 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // MBF GetPath result codes, dijkstra_mesh_planner.h:72-85
 enum : uint32_t { kSuccess = 0, kCanceled = 51, kInvalidStart = 52, kInvalidGoal = 53, kNoPathFound = 54,
-                  kInternalError = 59 };
+                  kInternalError = 60 };   // INVALID_PLUGIN is 59
 
 enum : uint32_t { kPlannerDijkstra = 0, kPlannerCvp = 1 };
 
@@ -78,7 +78,7 @@ struct PopKey { unsigned long long hi; uint32_t up; uint32_t lvl; };
 MNAV_HD bool operator==(const PopKey& a, const PopKey& b) { return a.hi == b.hi && a.up == b.up && a.lvl == b.lvl; }
 MNAV_HD bool operator!=(const PopKey& a, const PopKey& b) { return !(a == b); }
 constexpr uint32_t kKeyIdBits = 26, kKeyPadBits = 6;
-constexpr int kKeyWalkMax = 4096;        // bound on the `up` walks (a half-converged tree may be inconsistent)
+constexpr int kKeyWalkMax = 4096;        // default bound on the `up` walks (a half-converged tree may be inconsistent); Plan.walk_max
 MNAV_HD unsigned long long key_pair(float t, uint32_t id)
 {
   return ((unsigned long long)f2u(t) << 32) | ((unsigned long long)(id & ((1u << kKeyIdBits) - 1u)) << kKeyPadBits);
@@ -213,7 +213,7 @@ struct Plan {
   uint32_t* list[2];       // work lists, capacity `cap`
   uint32_t cap;
   Ctl* ctl;                // [2]
-  Cnt* cnt;                // [3]
+  Cnt* cnt;                // [4]: three rotating step counters + cnt[3] = sticky flags of the plan (kFlag*)
   // parameters
   float delta;             // band width
   double offset;           // goal_dist_offset
@@ -224,7 +224,15 @@ struct Plan {
   uint32_t target[3];      // robot vertex / robot-face vertices
   uint32_t target_expands[3];
   uint32_t max_steps;
+  int32_t walk_max;        // bound of key_less / key_for walks (kKeyWalkMax)
+  int32_t descend_max;     // bound of key_descends_from (kDescendWalkMax)
 };
+
+// Sticky per-plan flags (P.cnt[3].n_next).  kFlagWalkLimit: a walk over the cascade tree hit its bound and
+// the comparison fell back to another order -- the result may no longer be the reference's, so the plan is
+// reported as INTERNAL_ERROR instead of being returned (racy stores of the same bit: benign).
+constexpr uint32_t kFlagWalkLimit = 1u;
+MNAV_HD void raise_flag(const Plan& P, uint32_t f) { if (!(P.cnt[3].n_next & f)) P.cnt[3].n_next |= f; }
 
 MNAV_HD bool is_seed(const Plan& P, uint32_t v) { return v == P.seed[0] || v == P.seed[1] || v == P.seed[2]; }
 
@@ -235,7 +243,8 @@ MNAV_HD KeyRef key_ref(const Plan& P, uint32_t u) { return key_ref_of(P.tkey[u],
 MNAV_HD bool key_less(const Plan& P, KeyRef a, KeyRef b)
 {
   if (a.k.hi != b.k.hi) return a.k.hi < b.k.hi;                    // different main-front pops
-  for (int guard = 0; guard < kKeyWalkMax; ++guard) {              // same cascade: preorder, siblings by (value, id)
+  int guard = 0;
+  for (; guard < P.walk_max; ++guard) {                            // same cascade: preorder, siblings by (value, id)
     if (a.k.lvl == b.k.lvl) {
       if (a.own == b.own) return false;                            // the same node
       if (a.k.lvl == 0u || a.k.up == b.k.up) return a.own < b.own; // siblings
@@ -250,7 +259,11 @@ MNAV_HD bool key_less(const Plan& P, KeyRef a, KeyRef b)
       b = key_ref(P, b.k.up);
     }
   }
-  return a.own < b.own;                                            // inconsistent (half-converged) tree: any total order
+  // Left the loop without a decision: the two nodes are not in one consistent tree.  In a half-converged state
+  // that is transient and any total order will do (the vertex is evaluated again); a walk that ran into its
+  // bound on a CONVERGED tree would silently change the order, so it is flagged.
+  if (guard == P.walk_max) raise_flag(P, kFlagWalkLimit);
+  return a.own < b.own;
 }
 
 // key of vertex v whose value d was set by the pop `trig`
@@ -261,10 +274,12 @@ MNAV_HD PopKey key_for(const Plan& P, float d, uint32_t v, KeyRef trig)
   if (x > trig.k.hi) { k.hi = x; k.up = kNone; k.lvl = 0u; return k; }   // at or above the main front: ordinary pop
   k.hi = trig.k.hi;                                                // below it: inside the cascade of trig's root
   KeyRef a = trig;                                                 // climb to the node whose sub-cascade v pops in:
-  for (int guard = 0; guard < kKeyWalkMax; ++guard) {              // the deepest ancestor-or-self of trig above v
+  int guard = 0;
+  for (; guard < P.walk_max; ++guard) {                            // the deepest ancestor-or-self of trig above v
     if (a.k.lvl == 0u || x < a.own || a.k.up == kNone) break;
     a = key_ref(P, a.k.up);
   }
+  if (guard == P.walk_max) raise_flag(P, kFlagWalkLimit);
   k.up = pair_id(a.own); k.lvl = a.k.lvl + 1u;
   return k;
 }
@@ -276,11 +291,13 @@ constexpr int kDescendWalkMax = 64;
 MNAV_HD bool key_descends_from(const Plan& P, uint32_t t, uint32_t v)
 {
   PopKey a = P.tkey[t];                                            // (no shortcut through hi / lvl: both may be stale)
-  for (int guard = 0; guard < kDescendWalkMax && a.lvl > 0u; ++guard) {
+  int guard = 0;
+  for (; guard < P.descend_max && a.lvl > 0u; ++guard) {
     if (a.up == v) return true;
     if (a.up == kNone) return false;
     a = P.tkey[a.up];
   }
+  if (guard == P.descend_max && a.lvl > 0u) raise_flag(P, kFlagWalkLimit);
   return false;
 }
 

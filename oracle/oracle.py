@@ -417,10 +417,11 @@ def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_
     pred = np.empty(V, np.uint32)
     dirn = np.zeros(V, np.float32)
     cutf = np.full(V, NONE, np.uint32)
-    stats = np.zeros(5, np.uint64)
+    stats = np.zeros(8, np.uint64)
     gd = C.c_float(0)
     code = model_lib().sm_run(planner, V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(sv), _p(sd),
                               int(seed_face), _p(tv), float(offset), float(cost_limit), float(delta), int(order),
                               int(max_steps), _p(dist), _p(pred), _p(dirn), _p(cutf), _p(stats), C.byref(gd))
     return dict(code=code, dist=dist, pred=pred, direction=dirn, cutface=cutf, steps=int(stats[0]),
-                bands=int(stats[1]), evals=int(stats[2]), armed=int(stats[3]), shrinks=int(stats[4]), goal_dist=gd.value)
+                bands=int(stats[1]), evals=int(stats[2]), armed=int(stats[3]), shrinks=int(stats[4]),
+                verify_bad=int(stats[5]), verify_flags=int(stats[6]), goal_dist=gd.value)

@@ -53,7 +53,8 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
 
   std::vector<PopKey> tkey(V, key_inf());
   std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V);
-  Ctl ctl[2]; Cnt cnt[3];
+  Ctl ctl[2]; Cnt cnt[4];   // cnt[3]: sticky flags (mnav_eval.h kFlag*)
+  cnt[3].n_next = 0; cnt[3].changed = 0;
   std::memset(ctl, 0, sizeof(ctl)); std::memset(cnt, 0, sizeof(cnt));
 
   Plan P{};
@@ -65,6 +66,8 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   P.list[0] = l0.data(); P.list[1] = l1.data(); P.cap = V;
   P.ctl = ctl; P.cnt = cnt;
   P.delta = delta; P.offset = offset; P.max_steps = max_steps ? max_steps : 100000000u;
+  P.walk_max = getenv("MNAV_KEY_WALK_MAX") ? atoi(getenv("MNAV_KEY_WALK_MAX")) : kKeyWalkMax;
+  P.descend_max = getenv("MNAV_DESCEND_WALK_MAX") ? atoi(getenv("MNAV_DESCEND_WALK_MAX")) : kDescendWalkMax;
   for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.seed_expands[k] = 0; P.target[k] = kNone; P.target_expands[k] = 0; }
 
   for (uint32_t v = 0; v < V; ++v) { dist[v] = inf_f(); pred[v] = v; }
@@ -201,7 +204,22 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
       pd.assign(dist, dist + V); pk = tkey;
     }
   }
-  if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks; }
+  // model of k_cvp_verify: one more evaluation of every vertex on the converged state must reproduce it, and no
+  // walk over the cascade tree may hit its bound there (flags raised during the iteration are transient)
+  uint64_t verify_bad = 0, verify_flags = 0;
+  if (planner == kPlannerCvp && cur.done && !cur.overflow) {
+    cnt[3].n_next = 0; cnt[3].changed = 0;
+    for (uint32_t v = 0; v < V; ++v) {
+      if (is_seed(P, v) || blocked[v]) continue;
+      const Eval e = eval_cvp(P, cur, v);
+      const bool same = f2u(e.d) == f2u(dist[v]) && e.key == tkey[v] && e.pred == pred[v] &&
+                        (!(e.d < inf_f()) || (e.cut == cutf[v] && f2u(e.dir) == f2u(dirn[v])));
+      if (!same) ++verify_bad;
+    }
+    verify_flags = cnt[3].n_next;
+  }
+  if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks;
+                   stats_out[5] = verify_bad; stats_out[6] = verify_flags; }
   if (goal_dist_out) *goal_dist_out = cur.goal_dist;
   return cur.overflow ? kInternalError : kSuccess;   // overflow == 2: step cap hit (no convergence)
 }

@@ -127,3 +127,40 @@ def test_punched_terrain_1m_deep_cascades(gpu_ctx_factory):
     upd = refc.pred != np.arange(mesh.V)
     assert np.array_equal(outc.cutface[upd], refc.cutface[upd])
     assert np.array_equal(outc.direction[upd].view(np.uint32), refc.direction[upd].view(np.uint32))
+
+
+def test_cancel_stops_a_running_persistent_batch(c2):
+    """mnav_cancel during a long k_plan_persistent launch (1280 full-field plans on the 1M mesh, ~0.2 s): the
+    kernel polls the pinned flag, leaves its loops and every plan reports CANCELED (51), like the reference's
+    `while (!pq.isEmpty() && !cancel_planning_)` + `:350-354`.  A later plan is unaffected (flag reset, :238)."""
+    import threading
+    import time
+    from mesh_navigation_amd import capi
+    case, ctx = c2
+    m = case.mesh
+    rng = np.random.default_rng(11)
+    n = 1280
+    seeds = rng.choice(m.V, n, replace=False).astype(np.uint32)
+    targets = np.full(n, m.vertex_at(0.5, 0.5), np.uint32)
+    ctx.set_dijkstra_engine("persistent")
+    t0 = time.perf_counter()
+    full = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=float("inf"), path_cap=4096)   # warm-up + reference time
+    t_full = time.perf_counter() - t0
+    assert full["rc"] == 0 and (full["codes"] == 0).all()
+    t0 = time.perf_counter()
+    full = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=float("inf"), path_cap=4096)
+    t_full = time.perf_counter() - t0
+    out = {}
+    th = threading.Thread(target=lambda: out.update(ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=float("inf"), path_cap=4096)))
+    t0 = time.perf_counter()
+    th.start()
+    time.sleep(min(0.05, 0.25 * t_full))
+    ctx.cancel()
+    th.join(timeout=60)
+    t_cancel = time.perf_counter() - t0
+    assert not th.is_alive()
+    assert out["rc"] == capi.CANCELED and (out["codes"] == capi.CANCELED).all(), (out["rc"], t_full, t_cancel)
+    assert t_cancel < t_full, (t_cancel, t_full)
+    again = ctx.plan_dijkstra_batch(seeds[:128], targets[:128], goal_dist_offset=0.3, path_cap=4096)
+    assert again["rc"] == 0 and (again["codes"] == 0).all()
+    ctx.set_dijkstra_engine("auto")

@@ -152,3 +152,30 @@ def test_empty_batch_and_batch_mixing_all_codes(gpu_ctx_factory):
                 assert b["codes"][k] == ref.code, k
                 assert np.array_equal(b["paths"][k], ref.path), k
     ctx.set_dijkstra_engine("auto")
+
+
+def test_walk_bound_hit_returns_internal_error_instead_of_a_reordered_plan(gpu_ctx_factory, monkeypatch):
+    """Cascade-tree walks cut to 3 links (MNAV_KEY_WALK_MAX, read at mesh upload) on a punched terrain whose
+    cascades nest hundreds of levels deep: the comparison falls back to another pop order.  k_cvp_verify has to
+    notice (walk-limit flag on the converged tree, or a vertex that is no fixed point) and the plan must come back
+    as INTERNAL_ERROR (60); with the default bounds the same plan is clean and bit-equal to the oracle."""
+    mesh = meshgen.punched(160, 0.1, 7, drop=0.2)
+    case = Case(mesh)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    while deg[s] == 0: s += 1
+    while deg[t] == 0: t += 1
+    sf, tf = face_of(mesh, s), face_of(mesh, t)
+    sp = centroid(mesh, sf)
+    ref = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    out = ctx.plan_cvp(sp, sf, tf)
+    assert out.code == ref.code == 0
+    assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
+    monkeypatch.setenv("MNAV_KEY_WALK_MAX", "3")
+    monkeypatch.setenv("MNAV_DESCEND_WALK_MAX", "1")
+    cut = gpu_ctx_factory()
+    case.upload(cut)                                  # the bounds are read here
+    with pytest.raises(RuntimeError, match="internal error"):
+        cut.plan_cvp(sp, sf, tf)

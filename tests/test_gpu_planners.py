@@ -81,6 +81,9 @@ def test_cvp_c1_and_golden(c1):
     gs = GOLD["c1_cvp_dist_sample"]
     fin = np.isfinite(gs)
     assert np.allclose(out.dist[::step][fin], gs[fin], rtol=CVP_RTOL, atol=0)
+    # the fixture holds the outputs of the reference's own code (oracle/_ref): same bits on the device
+    assert sha(out.dist) == str(GOLD["c1_cvp_dist_sha"]) and sha(out.pred) == str(GOLD["c1_cvp_pred_sha"])
+    assert sha(out.cutface) == str(GOLD["c1_cvp_cutface_sha"]) and sha(out.direction) == str(GOLD["c1_cvp_direction_sha"])
     upd = ref.pred != np.arange(case.mesh.V)
     assert (out.cutface[upd] != ref.cutface[upd]).mean() < 1e-3
     assert np.abs(out.direction[upd] - ref.direction[upd]).max() < 1e-4 or \
@@ -222,7 +225,10 @@ def test_golden_layered_fixture(gpu_ctx_factory):
     g = GOLD["g2_cvp_dist"]
     fin = np.isfinite(g)
     assert np.array_equal(np.isfinite(outc.dist), fin)
-    assert (np.abs(outc.dist[fin] - g[fin]) / np.maximum(g[fin], 1e-12)).max() <= CVP_RTOL
+    assert (np.abs(outc.dist[fin] - g[fin]) / np.maximum(g[fin], 1e-12)).max() <= CVP_RTOL       # the north_star bar ...
+    assert np.array_equal(outc.dist.view(np.uint32), g.view(np.uint32))                            # ... and what we hold: the reference's bits
+    assert np.array_equal(outc.pred, GOLD["g2_cvp_pred"]) and np.array_equal(outc.cutface, GOLD["g2_cvp_cutface"])
+    assert np.array_equal(outc.direction.view(np.uint32), GOLD["g2_cvp_direction"].view(np.uint32))
 
 
 @pytest.mark.parametrize("which", ["g3", "g4"])
@@ -243,8 +249,10 @@ def test_golden_order_sensitive_fixtures(gpu_ctx_factory, which):
     sf, tf = (int(x) for x in RAGGED[which + "_cvp_faces"])
     outc = ctx.plan_cvp(RAGGED[which + "_cvp_seed_pos"], sf, tf, want_vecmap=False)
     assert outc.code == int(RAGGED[which + "_cvp_code"][0])
-    assert np.float32(outc.stats["goal_dist"]) == RAGGED[which + "_cvp_goal_dist"][0]          # inf == inf when the goal is never armed
     assert sha(outc.dist) == str(RAGGED[which + "_cvp_dist_sha"]) and sha(outc.pred) == str(RAGGED[which + "_cvp_pred_sha"])
+    assert sha(outc.direction) == str(RAGGED[which + "_cvp_direction_sha"])
+    # the reference never clears cutting_faces_: it holds a face exactly where this wave set a vertex
+    assert sha(outc.cutface) == str(RAGGED[which + "_cvp_cutface_sha"])
     if which == "g3":
         assert np.array_equal(outc.dist.view(np.uint32), RAGGED["g3_cvp_dist"].view(np.uint32))
 

@@ -29,6 +29,8 @@ def run_cvp(case, sp, tp, **kw):
     sv = case.mesh.faces[sf]
     mod = O.schedule_model(1, case.mesh.faces, case.mesh.edges, case.weights, case.costs, sv, ref.dist[sv], sf,
                            case.mesh.faces[tf], offset=off, cost_limit=lim, invalid=case.invalid, **kw)
+    if mod["code"] == 0:      # model of k_cvp_verify: the converged state is a fixed point, no walk bound was hit on it
+        assert mod["verify_bad"] == 0 and mod["verify_flags"] == 0, (mod["verify_bad"], mod["verify_flags"])
     return ref, mod
 
 
@@ -293,3 +295,35 @@ def test_cvp_random_pairs_converge_and_match(kind):
             assert mod["code"] == 0
             assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
             assert np.array_equal(mod["pred"], ref.pred)
+
+
+def test_walk_bound_hit_is_reported_not_silently_reordered(monkeypatch):
+    """Deep cascades with the cascade-tree walk bounds cut down to a few links: the comparison falls back to
+    another order.  The verification sweep (model of k_cvp_verify) must notice -- a raised walk-limit flag on
+    the converged tree or a vertex that is no fixed point -- so the device returns INTERNAL_ERROR instead of a
+    potential that may differ from the reference's.  With the default bounds the same input is clean."""
+    mesh = meshgen.punched(120, 0.1, 7, drop=0.2)
+    case = Case(mesh)
+    deg = np.bincount(mesh.edges.ravel(), minlength=mesh.V)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    while deg[s] == 0: s += 1
+    while deg[t] == 0: t += 1
+    sf = int(np.where((mesh.faces == s).any(axis=1))[0][0])
+    tf = int(np.where((mesh.faces == t).any(axis=1))[0][0])
+    sp = mesh.xyz[mesh.faces[sf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    tp = mesh.xyz[mesh.faces[tf]].astype(np.float64).mean(axis=0).astype(np.float32)
+    mean_w = float(case.weights[np.isfinite(case.weights)].mean())
+    ref = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf)
+    sv = mesh.faces[sf]
+
+    def run():
+        return O.schedule_model(1, mesh.faces, mesh.edges, case.weights, case.costs, sv, ref.dist[sv], sf, mesh.faces[tf],
+                                delta=12 * mean_w, max_steps=100000)
+    clean = run()
+    assert clean["code"] == 0 and clean["verify_bad"] == 0 and clean["verify_flags"] == 0
+    assert np.array_equal(clean["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    monkeypatch.setenv("MNAV_KEY_WALK_MAX", "3")
+    monkeypatch.setenv("MNAV_DESCEND_WALK_MAX", "1")
+    cut = run()
+    reported = cut["code"] != 0 or cut["verify_flags"] != 0 or cut["verify_bad"] != 0
+    assert reported, "a walk bound of 3 links on cascades hundreds of levels deep went unnoticed"
