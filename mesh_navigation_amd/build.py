@@ -11,6 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libmnav.so")
 ADAPTER_LIB = os.path.join(_HERE, "libmnav_adapter.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-strict-aliasing",        # LDS images are staged as 16-byte vectors and read as u16 / f32
                "-Wall", "-Wno-unused-function"]
 
 

@@ -203,8 +203,8 @@ class MnavContext:
         self._L.mnav_set_band_width(self._h, float(delta))
 
     def set_dijkstra_engine(self, engine: str):
-        """'auto' (default), 'tiled', 'band' or 'persistent'."""
-        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3}[engine])
+        """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
+        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4}[engine])
 
     def stats(self) -> dict:
         s = Stats()
