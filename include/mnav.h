@@ -149,6 +149,27 @@ uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
                              const uint32_t* target_faces, double goal_dist_offset, double cost_limit,
                              uint32_t* codes_out, float* dist_out, uint32_t* pred_out, float* vecmap_out);
 
+/* -- one plan over several GPUs (BASELINE config 4) ---------------------------------------------
+ * The reference's loop (dijkstra_mesh_planner.cpp:287-348) on a mesh that is range-partitioned over `world`
+ * processes, one per GPU: the LDS tiles are in Morton order and process `rank` owns a contiguous range of them.
+ * Every process uploads the same mesh and costs, then
+ *   n = mnav_shard_setup(ctx, rank, world)            floats in the exchange buffer (interface vertices + robot vertex)
+ *   mnav_shard_begin(ctx, seed, target, offset, limit)
+ *   repeat { mnav_shard_rounds(ctx, R, buf);           R local tile rounds, then buf[i] = own interface values / +inf
+ *            min-allreduce(buf) over the processes      (RCCL over xGMI; ncclAllReduce(ncclMin) / torch.distributed)
+ *            mnav_shard_apply(ctx, buf, &local_min, &target_dist);
+ *          } until min-allreduce(local_min) is +inf or > target_dist + offset
+ *   mnav_shard_finalize(ctx, dist_buf, pred_buf);       owned entries, +inf / 0xFFFFFFFF elsewhere: min-allreduce both
+ * `buf`, `dist_buf` (V floats) and `pred_buf` (V uint32) are DEVICE pointers owned by the caller (the collective runs on
+ * them in place).  The result is bit-identical to the single-GPU plan: the schedule is label-correcting, only the
+ * fixed point matters.  Returns 0, <0 on error, 1 if cancelled. */
+int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world);
+int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_t* ntiles, uint32_t* n_exchange);
+int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit);
+int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev);
+int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out);
+int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev);
+
 /* Replaces MeshPlanner::cancel(), mesh_planner.h:80 (dijkstra_mesh_planner.cpp:136-140):
  * async-signal/thread safe, only sets a flag that the running plan polls between step
  * batches; the plan then returns MNAV_CANCELED.  The flag is cleared when a plan starts
@@ -164,8 +185,8 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
 /* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round,
  * lowest latency for a single plan), 1 = the distance-band gather steps that the CVP planner uses,
  * 2 = persistent per-plan workgroups walking the tiles best-first (highest throughput for large
- * batches), 3 = automatic (default: 2 for batches of >= 128 plans, else 0).  All give identical
- * results. */
+ * batches), 3 = automatic (default: 2 for batches of >= 128 plans, else 0), 4 = one wave per plan on a finer
+ * tiling (experimental, slower than 2 at 1M vertices).  All give identical results. */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
 /* Device pointers of the last plan's resident outputs (slot = plan index in a batch):
  * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available. */

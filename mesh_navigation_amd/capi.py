@@ -21,7 +21,8 @@ SYMBOLS = [
     "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_set_face_circulation", "mnav_upload_mesh", "mnav_upload_costs",
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
-    "mnav_algorithmic_bytes",
+    "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
+    "mnav_shard_finalize",
 ]
 
 
@@ -82,6 +83,18 @@ def load(path: str | None = None):
     L.mnav_set_dijkstra_engine.argtypes = [vp, C.c_int]
     L.mnav_device_output.restype = vp
     L.mnav_device_output.argtypes = [vp, u32, C.c_int]
+    L.mnav_shard_setup.restype = C.c_int
+    L.mnav_shard_setup.argtypes = [vp, u32, u32]
+    L.mnav_shard_info.restype = C.c_int
+    L.mnav_shard_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.mnav_shard_begin.restype = C.c_int
+    L.mnav_shard_begin.argtypes = [vp, u32, u32, f64, f64]
+    L.mnav_shard_rounds.restype = C.c_int
+    L.mnav_shard_rounds.argtypes = [vp, u32, vp]
+    L.mnav_shard_apply.restype = C.c_int
+    L.mnav_shard_apply.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mnav_shard_finalize.restype = C.c_int
+    L.mnav_shard_finalize.argtypes = [vp, vp, vp]
     L.mnav_algorithmic_bytes.restype = C.c_uint64
     L.mnav_algorithmic_bytes.argtypes = [vp]
     if path is None:
@@ -205,6 +218,40 @@ class MnavContext:
     def set_dijkstra_engine(self, engine: str):
         """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
         self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4}[engine])
+
+    # ---- one plan over several GPUs (mesh_navigation_amd/sharded.py drives these) ----
+    def shard_setup(self, rank: int, world: int) -> int:
+        n = self._L.mnav_shard_setup(self._h, int(rank), int(world))
+        if n < 0:
+            raise RuntimeError(f"mnav_shard_setup failed: {self._err()}")
+        return n
+
+    def shard_info(self) -> dict:
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        if self._L.mnav_shard_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0:
+            raise RuntimeError("mnav_shard_setup has not been called")
+        return dict(t_lo=a.value, t_hi=b.value, ntiles=c.value, n_exchange=d.value)
+
+    def shard_begin(self, seed: int, target: int, goal_dist_offset: float = 0.3, cost_limit: float = 1.0):
+        if self._L.mnav_shard_begin(self._h, int(seed), int(target), float(goal_dist_offset), float(cost_limit)) != 0:
+            raise RuntimeError(f"mnav_shard_begin failed: {self._err()}")
+
+    def shard_rounds(self, rounds: int, buf_ptr: int) -> int:
+        rc = self._L.mnav_shard_rounds(self._h, int(rounds), C.c_void_p(buf_ptr))
+        if rc < 0:
+            raise RuntimeError(f"mnav_shard_rounds failed: {self._err()}")
+        return rc
+
+    def shard_apply(self, buf_ptr: int):
+        lm, td = C.c_float(), C.c_float()
+        if self._L.mnav_shard_apply(self._h, C.c_void_p(buf_ptr), C.byref(lm), C.byref(td)) != 0:
+            raise RuntimeError(f"mnav_shard_apply failed: {self._err()}")
+        return lm.value, td.value
+
+    def shard_finalize(self, dist_ptr: int, pred_ptr: int):
+        rc = self._L.mnav_shard_finalize(self._h, C.c_void_p(dist_ptr), C.c_void_p(pred_ptr))
+        if rc != 0:
+            raise RuntimeError(f"mnav_shard_finalize failed ({rc}): {self._err()}")
 
     def stats(self) -> dict:
         s = Stats()

@@ -457,6 +457,7 @@ struct TilePlan {
   uint32_t max_nv, max_nh, max_ne;
   const uint32_t* cancel;  // device word set by mnav_cancel (polled by the persistent kernels), may be null
   const uint32_t* thdr;    // k_plan_wave: 8 words per tile {v0, nv, h0, nh, e0, ne, r0, 0}
+  uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
 };
 
 constexpr int kTileBlock = 256;
@@ -640,7 +641,8 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
 
   // every tile is looked at by exactly one thread of one workgroup per round
   uint32_t carry_min = kInfBits;
-  for (uint32_t t = blockIdx.x + (uint32_t)tid * gridDim.x; t < P.ntiles; t += gridDim.x * kTileBlock) {
+  const uint32_t t_end_owned = P.t_hi ? P.t_hi : P.ntiles;
+  for (uint32_t t = P.t_lo + blockIdx.x + (uint32_t)tid * gridDim.x; t < t_end_owned; t += gridDim.x * kTileBlock) {
     const uint32_t pb = pc[t];
     if (pb == kInfBits) continue;
     pc[t] = kInfBits;
@@ -1238,6 +1240,83 @@ __global__ __launch_bounds__(kBlock) void k_tile_weights(uint32_t n, const uint3
   (void)col;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE plan on a mesh that is range-partitioned over several processes / GPUs (BASELINE config 4,
+// SURVEY.md 8e).  The tiles are in Morton order; process r owns a contiguous range of them and, with
+// them, their vertices.  Every process runs the ordinary tile rounds (k_tile_round) on its own tiles
+// only; between blocks of rounds the distances of the INTERFACE vertices (vertices with a neighbour
+// owned by somebody else, plus the robot vertex) are exchanged with one min-allreduce over a dense
+// buffer (RCCL over xGMI; torch.distributed in the Python driver), and a vertex whose value dropped
+// wakes the local tiles that have it in their halo.  Label-correcting: the fixed point, and with it
+// every bit of the potential, is the one of the unpartitioned run.
+// ---------------------------------------------------------------------------------------------
+struct ShardDev {
+  uint32_t n_iface, rank, target;
+  const uint32_t* iface_vert;    // n_iface vertex ids, the same list on every process
+  const uint8_t* iface_owner;    // n_iface owning process
+  const uint32_t* wake_ptr;      // n_iface+1 -> wake_tile: local tiles that hold the vertex in their halo
+  const uint32_t* wake_tile;
+};
+
+// pack: own interface values, +inf for the others (the min-allreduce then delivers every owner's value)
+__global__ __launch_bounds__(kBlock) void k_shard_pack(ShardDev S, const float* __restrict__ dist, float* __restrict__ buf)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < S.n_iface) buf[i] = (S.iface_owner[i] == S.rank) ? dist[S.iface_vert[i]] : inf_f();
+  if (i == S.n_iface) buf[i] = dist[S.target];      // last slot: the robot vertex (bound / goal_dist need it everywhere); stale copies are larger
+}
+
+// apply: ghost values that dropped are stored and wake the local tiles around them for the next round;
+// the round controller is re-armed (its `done` is sticky) and told about the new smallest wake-up value
+__global__ __launch_bounds__(kBlock) void k_shard_apply(ShardDev S, const TilePlan* __restrict__ plans, const float* __restrict__ buf,
+                                                        uint32_t* __restrict__ changed)
+{
+  const TilePlan& P = plans[0];
+  const TCtl a = P.ctl[0], b = P.ctl[1];
+  const int32_t j = (a.it > b.it) ? a.it : b.it;                     // last round executed (-1: none yet)
+  uint32_t* pn = P.pend[(j + 1) & 1];                                // the buffer round j+1 reads
+  TCnt* cnt = &P.cnt[((j % 3) + 3) % 3];                             // ... and the counters it reads as "previous"
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) { P.ctl[0].done = 0; P.ctl[1].done = 0; }
+  if (i == S.n_iface) { if (buf[i] < P.dist[S.target]) P.dist[S.target] = buf[i]; return; }
+  if (i >= S.n_iface || S.iface_owner[i] == S.rank) return;
+  const uint32_t v = S.iface_vert[i];
+  const float nv = buf[i];
+  if (!(nv < P.dist[v])) return;
+  P.dist[v] = nv;
+  const uint32_t bits = f2u(nv);
+  for (uint32_t k = S.wake_ptr[i]; k < S.wake_ptr[i + 1]; ++k) atomicMin(&pn[S.wake_tile[k]], bits);
+  if (S.wake_ptr[i + 1] > S.wake_ptr[i]) { atomicMin(&cnt->minpend, bits); atomicOr(changed, 1u); }
+}
+
+// smallest wake-up value among the owned tiles (what this process still has to do), as float bits
+__global__ __launch_bounds__(kBlock) void k_shard_minpend(const TilePlan* __restrict__ plans, uint32_t* __restrict__ out)
+{
+  const TilePlan& P = plans[0];
+  const TCtl a = P.ctl[0], b = P.ctl[1];
+  const int32_t j = (a.it > b.it) ? a.it : b.it;
+  const uint32_t* pn = P.pend[(j + 1) & 1];
+  const uint32_t hi = P.t_hi ? P.t_hi : P.ntiles;
+  uint32_t m = kInfBits;
+  for (uint32_t t = P.t_lo + blockIdx.x * kBlock + threadIdx.x; t < hi; t += gridDim.x * kBlock) m = min(m, pn[t]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m != kInfBits) atomicMin(out, m);
+}
+
+// final gather buffers: owned entries, neutral elements elsewhere (min-allreduce over dist, pred)
+__global__ __launch_bounds__(kBlock) void k_shard_owned(uint32_t V, const uint32_t* __restrict__ vert_tile, uint32_t t_lo, uint32_t t_hi,
+                                                        const float* __restrict__ dist, const uint32_t* __restrict__ pred,
+                                                        float* __restrict__ dist_out, uint32_t* __restrict__ pred_out)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const uint32_t t = vert_tile[v];
+  const bool mine = t >= t_lo && t < t_hi;
+  dist_out[v] = mine ? dist[v] : inf_f();
+  pred_out[v] = mine ? pred[v] : 0xFFFFFFFFu;
+}
+
 struct PlanResult {
   uint32_t code;
   uint32_t path_len;
@@ -1293,8 +1372,8 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
   const float dt = g_dist[P.target[0]];
   const bool armed = dt < inf_f();
   const float goal_dist = armed ? (float)((double)dt + P.offset) : inf_f();   // dijkstra :296
-  const uint32_t t_beg = blockIdx.y * tiles_per_block;
-  const uint32_t t_end = min(t_beg + tiles_per_block, T.ntiles);
+  const uint32_t t_beg = T.t_lo + blockIdx.y * tiles_per_block;
+  const uint32_t t_end = min(t_beg + tiles_per_block, T.t_hi ? T.t_hi : T.ntiles);
   uint32_t settled = 0, bad = 0;
   for (uint32_t t = t_beg; t < t_end; ++t) {
     if (!(g_tlast[t] > -inf_f()) && g_p0[t] == kInfBits && g_p1[t] == kInfBits) continue;   // uniform over the workgroup
@@ -1732,6 +1811,15 @@ struct mnav_ctx {
     uint16_t *rowptr = nullptr, *col = nullptr;
     float* tw = nullptr;
   } wt;
+  // sharded single plan (mnav_shard_*)
+  struct Shard {
+    bool ready = false, active = false;
+    uint32_t rank = 0, world = 1, t_lo = 0, t_hi = 0, n_iface = 0, rounds_per_exchange = 8, j = 0;
+    uint32_t seed = 0, target = 0; double offset = 0.3;
+    uint32_t *d_iface_vert = nullptr, *d_wake_ptr = nullptr, *d_wake_tile = nullptr, *d_changed = nullptr, *d_minpend = nullptr;
+    uint8_t* d_iface_owner = nullptr;
+    std::vector<uint32_t> iface_vert;
+  } shard;
   uint32_t* d_next_plan = nullptr;
   uint32_t wave_min_batch = 0;                                     // auto engine: 0 = never pick k_plan_wave (MNAV_WAVE_MIN_BATCH to opt in)
   TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
@@ -2589,11 +2677,11 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     if (dev_upload(ctx, &ctx->d_vert_tile, T.vert_tile.data(), T.vert_tile.size())) return -1;
     if (dev_upload(ctx, &ctx->d_t_tw, (const float*)nullptr, T.col.size())) return -1;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    // keep only the sizes on the host
-    T.verts.clear(); T.verts.shrink_to_fit(); T.halo_verts.clear(); T.halo_verts.shrink_to_fit();
+    // keep the sizes, and the small per-vertex maps the partitioner of mnav_shard_setup needs, on the host
     T.halo_tile.clear(); T.halo_tile.shrink_to_fit(); T.rowptr.clear(); T.rowptr.shrink_to_fit();
-    T.col.clear(); T.col.shrink_to_fit(); T.src.clear(); T.src.shrink_to_fit(); T.vert_tile.clear(); T.vert_tile.shrink_to_fit();
+    T.col.clear(); T.col.shrink_to_fit(); T.src.clear(); T.src.shrink_to_fit();
     ctx->tiles_meta = std::move(T);
+    ctx->shard.ready = false;
   }
   // the finer tiling of the wave-per-plan engine
   {
@@ -3031,6 +3119,197 @@ uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
   if (!seed_pos || !seed_faces || !target_faces) { ctx->err = "null seeds/targets"; return MNAV_INTERNAL_ERROR; }
   return cvp_impl(ctx, n, seed_pos, seed_faces, target_faces, goal_dist_offset, cost_limit, codes_out, dist_out, pred_out, nullptr, nullptr,
                   vecmap_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sharded single plan: C ABI (include/mnav.h "one plan over several GPUs")
+// ---------------------------------------------------------------------------------------------
+int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world)
+{
+  if (!ctx || !ctx->have_mesh || world == 0 || rank >= world) { if (ctx) ctx->err = "mnav_shard_setup: bad arguments or no mesh"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  const HostTiles& M = ctx->tiles_meta;
+  if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
+  if (M.ntiles < world) { ctx->err = "fewer tiles than processes"; return -1; }
+  auto& S = ctx->shard;
+  S.rank = rank; S.world = world;
+  auto lo = [&](uint32_t r) { return (uint32_t)(((uint64_t)M.ntiles * r) / world); };
+  S.t_lo = lo(rank); S.t_hi = lo(rank + 1);
+  std::vector<uint32_t> bound(world + 1);
+  for (uint32_t r = 0; r <= world; ++r) bound[r] = lo(r);
+  auto owner_of_tile = [&](uint32_t t) { return (uint32_t)(std::upper_bound(bound.begin(), bound.end(), t) - bound.begin() - 1); };
+  // interface = halo vertices owned by another process than the tile that sees them (covers both sides of every cut)
+  std::vector<uint8_t> is_iface(ctx->V, 0);
+  for (uint32_t t = 0; t < M.ntiles; ++t) {
+    const uint32_t ot = owner_of_tile(t);
+    for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
+      const uint32_t h = M.halo_verts[k];
+      if (owner_of_tile(M.vert_tile[h]) != ot) is_iface[h] = 1;
+    }
+  }
+  S.iface_vert.clear();
+  for (uint32_t v = 0; v < ctx->V; ++v) if (is_iface[v]) S.iface_vert.push_back(v);
+  S.n_iface = (uint32_t)S.iface_vert.size();
+  std::vector<uint32_t> idx_of(ctx->V, kNone);
+  std::vector<uint8_t> owner(S.n_iface ? S.n_iface : 1, 0);
+  for (uint32_t i = 0; i < S.n_iface; ++i) { idx_of[S.iface_vert[i]] = i; owner[i] = (uint8_t)owner_of_tile(M.vert_tile[S.iface_vert[i]]); }
+  if (world > 255) { ctx->err = "at most 255 processes"; return -1; }
+  // local tiles to wake per ghost vertex
+  std::vector<uint32_t> wptr(S.n_iface + 1, 0), wtile;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<uint32_t> fill(S.n_iface + 1, 0);
+    for (uint32_t t = S.t_lo; t < S.t_hi; ++t)
+      for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
+        const uint32_t i = idx_of[M.halo_verts[k]];
+        if (i == kNone || owner[i] == rank) continue;
+        if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = t;
+      }
+    if (pass == 0) { for (uint32_t i = 0; i < S.n_iface; ++i) wptr[i + 1] += wptr[i]; wtile.assign(wptr[S.n_iface] ? wptr[S.n_iface] : 1, 0); }
+  }
+  if (dev_upload(ctx, &S.d_iface_vert, S.iface_vert.data(), S.iface_vert.size())) return -1;
+  if (dev_upload(ctx, &S.d_iface_owner, owner.data(), S.n_iface)) return -1;
+  if (dev_upload(ctx, &S.d_wake_ptr, wptr.data(), wptr.size())) return -1;
+  if (dev_upload(ctx, &S.d_wake_tile, wtile.data(), wtile.size())) return -1;
+  if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
+  if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.ready = true; S.active = false;
+  return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
+}
+
+int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_t* ntiles, uint32_t* n_iface)
+{
+  if (!ctx || !ctx->shard.ready) return -1;
+  if (t_lo) *t_lo = ctx->shard.t_lo;
+  if (t_hi) *t_hi = ctx->shard.t_hi;
+  if (ntiles) *ntiles = ctx->tiles_meta.ntiles;
+  if (n_iface) *n_iface = ctx->shard.n_iface + 1;
+  return 0;
+}
+
+static ShardDev shard_dev(const mnav_ctx* ctx)
+{
+  ShardDev D;
+  D.n_iface = ctx->shard.n_iface; D.rank = ctx->shard.rank; D.target = ctx->shard.target; D.iface_vert = ctx->shard.d_iface_vert; D.iface_owner = ctx->shard.d_iface_owner;
+  D.wake_ptr = ctx->shard.d_wake_ptr; D.wake_tile = ctx->shard.d_wake_tile;
+  return D;
+}
+
+int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit)
+{
+  if (check_ready(ctx)) return -1;
+  if (!ctx->shard.ready) { ctx->err = "mnav_shard_setup has not been called"; return -1; }
+  if (seed_vertex >= ctx->V || target_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  ctx->err.clear();
+  ctx->cancel.store(0);
+  if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
+  ctx->want_vec = false;
+  if (materialize(ctx, false, cost_limit)) return -1;
+  if (ensure_slots(ctx, 1, false, false, false)) return -1;
+  if (ensure_paths(ctx, 1)) return -1;
+  if (ensure_tile_state(ctx, 1)) return -1;
+  if (tile_weights(ctx)) return -1;
+  auto& S = ctx->shard;
+  const HostTiles& M = ctx->tiles_meta;
+  Slot& s = ctx->slots[0];
+  Plan P; memset(&P, 0, sizeof(P));
+  P.planner = kPlannerDijkstra; P.V = ctx->V;
+  P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+  P.dist = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
+  P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+  P.offset = goal_dist_offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
+  for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
+  P.seed[0] = seed_vertex; P.target[0] = target_vertex; P.seed_face = kNone;
+  TilePlan T; memset(&T, 0, sizeof(T));
+  T.V = ctx->V; T.ntiles = M.ntiles;
+  T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+  T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
+  T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
+  T.seed = seed_vertex; T.target = target_vertex; T.offset = goal_dist_offset; T.max_rounds = 0x7FFFFFF0u;
+  T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
+  T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
+  T.t_lo = S.t_lo; T.t_hi = S.t_hi;
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, &P, sizeof(Plan), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, &T, sizeof(TilePlan), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
+  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
+  if (gt < 1) gt = 1;
+  hipLaunchKernelGGL(k_tile_init, dim3(gt, 1), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.j = 0; S.seed = seed_vertex; S.target = target_vertex; S.offset = goal_dist_offset; S.active = true;
+  return 0;
+}
+
+int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  const uint32_t own = S.t_hi - S.t_lo;
+  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
+  if (G > own) G = own ? own : 1;
+  for (uint32_t r = 0; r < rounds; ++r, ++S.j)
+    hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)(S.j % 6));
+  if (iface_buf_dev)
+    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->slots[0].dist, iface_buf_dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;
+  return 0;
+}
+
+int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  HIPCHK(hipMemsetAsync(S.d_changed, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)S.d_minpend, (int)kInfBits, 1, ctx->stream));   // +inf: "nothing pending"
+  const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
+  const uint32_t own = S.t_hi - S.t_lo;
+  const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
+  HIPCHK(hipGetLastError());
+  uint32_t mp = 0; float td = INFINITY;
+  HIPCHK(hipMemcpyAsync(&mp, S.d_minpend, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&td, ctx->slots[0].dist + S.target, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (local_min_out) *local_min_out = (mp >= 0x7f800000u) ? INFINITY : u2f(mp);
+  if (target_dist_out) *target_dist_out = td;
+  return 0;
+}
+
+int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  const uint32_t own = S.t_hi - S.t_lo;
+  if (own) {
+    uint32_t chunks = std::min<uint32_t>(4096u, own);
+    const uint32_t per = (own + chunks - 1) / chunks;
+    chunks = (own + per - 1) / per;
+    hipLaunchKernelGGL(k_dij_finalize, dim3(1, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
+                       ctx->d_mismatch, ctx->d_res, per);
+  }
+  const uint32_t gv = (ctx->V + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_shard_owned, dim3(gv ? gv : 1), dim3(kBlock), 0, ctx->stream, ctx->V, ctx->d_vert_tile, S.t_lo, S.t_hi,
+                     ctx->slots[0].dist, ctx->slots[0].pred, dist_buf_dev, pred_buf_dev);
+  HIPCHK(hipGetLastError());
+  uint32_t mism = 0;
+  HIPCHK(hipMemcpyAsync(&mism, ctx->d_mismatch, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.active = false;
+  if (mism) { ctx->err = "sharded SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)"; return -2; }
+  return 0;
 }
 
 void mnav_cancel(mnav_ctx* ctx)

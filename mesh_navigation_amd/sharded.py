@@ -1,0 +1,184 @@
+"""ONE Dijkstra plan on a mesh that is range-partitioned over several GPUs (BASELINE config 4).
+
+One process per GPU.  Every process holds the whole (read-only) mesh description but OWNS a contiguous range of
+the Morton-ordered LDS tiles and, with them, their vertices: only the owner relaxes into a vertex.  The loop is
+
+    repeat:  R local tile rounds on the own tiles                      (k_tile_round, mnav_shard_rounds)
+             ONE min-allreduce of the interface buffer                 (RCCL over xGMI: halo-vertex distances
+                                                                        + the robot vertex, a few 10^4 floats)
+             ghost values that dropped wake the tiles around them      (mnav_shard_apply)
+             ONE 2-float min-allreduce: smallest pending wake-up, dist[robot]
+    until nothing that may still propagate is pending anywhere
+    finalize the own tiles (cut-off semantics + predecessors), min-allreduce dist / pred once
+
+The schedule is label-correcting, so the potential is the unique fixed point of the reference's float32
+relaxation (dijkstra_mesh_planner.cpp:331): bit-identical to the single-GPU plan and to the reference.  Messages
+are latency bound (tens of microseconds each, xGMI bandwidth is irrelevant at these sizes); expect poor strong
+scaling for one plan -- what this mode buys is a mesh that no longer has to fit one GPU's caches.
+
+`run_sharded_plan` is written against a small engine protocol so that the same loop drives the GPU engine
+(`GpuShardEngine`, the C ABI mnav_shard_*) with torch.distributed, several engines inside one process
+(`plan_virtual_ranks`: one GPU standing in for several, used by the GPU tests) and the CPU model of the tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Sequence
+
+import numpy as np
+
+SUCCESS, CANCELED, NO_PATH_FOUND = 0, 51, 54
+
+
+@dataclass
+class ShardedResult:
+    code: int
+    dist: np.ndarray | None       # V float32 (gathered)
+    pred: np.ndarray | None       # V uint32 (gathered)
+    path: np.ndarray              # dijkstra() list order: seed first ... pred[target]
+    exchanges: int
+    rounds: int
+
+
+def walk_path(pred: np.ndarray, seed: int, target: int) -> tuple[int, np.ndarray]:
+    """dijkstra_mesh_planner.cpp:358-373 on the gathered predecessor array."""
+    if int(pred[target]) == target:
+        return NO_PATH_FOUND, np.zeros(0, np.uint32)
+    out = []
+    v = target
+    while v != seed and len(out) <= pred.shape[0]:
+        v = int(pred[v])
+        out.append(v)
+    return SUCCESS, np.asarray(out[::-1], np.uint32)
+
+
+def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, goal_dist_offset: float = 0.3,
+                     rounds_per_exchange: int = 8, max_exchanges: int = 100_000, gather: bool = True) -> ShardedResult:
+    """The loop above for ONE rank.  `engine`: begin/rounds/apply/finalize (see GpuShardEngine).
+    `allreduce_min(x)`: in-place elementwise MIN over all ranks of a buffer the engine handed out (a torch tensor
+    or a numpy array, the engine decides) -- the only communication there is."""
+    engine.begin(seed, target, goal_dist_offset)
+    exchanges = rounds = 0
+    ctl = engine.control_buffer()                                     # 2 floats: [smallest pending wake-up, dist[target]]
+    while True:
+        buf = engine.rounds(rounds_per_exchange)
+        rounds += rounds_per_exchange
+        allreduce_min(buf)                                            # halo-vertex distances (+ robot vertex)
+        local_min, target_dist = engine.apply(buf)
+        ctl[0] = local_min
+        ctl[1] = target_dist
+        allreduce_min(ctl)                                            # termination: 8 bytes
+        exchanges += 1
+        gmin, gtarget = float(ctl[0]), float(ctl[1])
+        if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
+            break                                                     # nothing left that may still propagate
+        if exchanges >= max_exchanges:
+            raise RuntimeError("sharded plan did not terminate")
+    dist_buf, pred_buf = engine.finalize()
+    if not gather:
+        return ShardedResult(SUCCESS, None, None, np.zeros(0, np.uint32), exchanges, rounds)
+    allreduce_min(dist_buf)                                           # every vertex has exactly one owner
+    allreduce_min(pred_buf)
+    dist = engine.to_numpy(dist_buf).view(np.float32)
+    pred = engine.to_numpy(pred_buf).view(np.uint32)
+    code, path = walk_path(pred, seed, target)
+    return ShardedResult(code, dist, pred, path, exchanges, rounds)
+
+
+class GpuShardEngine:
+    """The C ABI mnav_shard_* on one GPU; exchange buffers are torch CUDA tensors (RCCL reduces them in place)."""
+
+    def __init__(self, ctx, rank: int, world: int, cost_limit: float = 1.0, device=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        self.cost_limit = cost_limit
+        self.n = ctx.shard_setup(rank, world)
+        self.info = ctx.shard_info()
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.buf = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.ctl = torch.empty(2, dtype=torch.float32, device=dev)
+        self.dist = torch.empty(ctx.V, dtype=torch.float32, device=dev)
+        # predecessors travel as int32 bit patterns (RCCL has no uint32 MIN in torch): ids < 2^31 keep their order,
+        # and the neutral element 0xFFFFFFFF is -1, which MIN would prefer -> flip the sign bit around the collective
+        self.pred = torch.empty(ctx.V, dtype=torch.int32, device=dev)
+
+    def begin(self, seed, target, offset):
+        self.ctx.shard_begin(seed, target, offset, self.cost_limit)
+
+    def control_buffer(self):
+        return self.ctl
+
+    def rounds(self, r):
+        self.torch.cuda.synchronize()
+        self.ctx.shard_rounds(r, self.buf.data_ptr())
+        return self.buf
+
+    def apply(self, buf):
+        self.torch.cuda.synchronize()
+        return self.ctx.shard_apply(buf.data_ptr())
+
+    def finalize(self):
+        self.torch.cuda.synchronize()
+        self.ctx.shard_finalize(self.dist.data_ptr(), self.pred.data_ptr())
+        self.pred ^= -2147483648            # uint32 order -> int32 order (0xFFFFFFFF becomes INT32_MAX: neutral for MIN)
+        return self.dist, self.pred
+
+    def to_numpy(self, t):
+        if t is self.pred:
+            return (t ^ -2147483648).cpu().numpy()
+        return t.cpu().numpy()
+
+
+def torch_allreduce_min(dist):
+    """in-place MIN all-reduce over the default process group (backend nccl == RCCL on ROCm; gloo on CPU)"""
+    import torch
+
+    def f(x):
+        if isinstance(x, np.ndarray):
+            t = torch.from_numpy(x)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.MIN)
+    return f
+
+
+def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offset: float = 0.3,
+                       rounds_per_exchange: int = 8, max_exchanges: int = 100_000) -> ShardedResult:
+    """`world` engines inside ONE process (one GPU standing in for several): the same protocol, the collective
+    replaced by an elementwise minimum over the engines' buffers.  Lock-step version of run_sharded_plan."""
+    for e in engines:
+        e.begin(seed, target, goal_dist_offset)
+    ctls = [e.control_buffer() for e in engines]
+
+    def reduce_min(bufs):
+        m = bufs[0].clone() if hasattr(bufs[0], "clone") else bufs[0].copy()
+        for b in bufs[1:]:
+            m = (m.minimum(b) if hasattr(m, "minimum") else np.minimum(m, b))
+        for b in bufs:
+            b[...] = m
+
+    exchanges = rounds = 0
+    while True:
+        bufs = [e.rounds(rounds_per_exchange) for e in engines]
+        rounds += rounds_per_exchange
+        reduce_min(bufs)
+        for e, b, c in zip(engines, bufs, ctls):
+            lm, td = e.apply(b)
+            c[0] = lm
+            c[1] = td
+        reduce_min(ctls)
+        exchanges += 1
+        gmin, gtarget = float(ctls[0][0]), float(ctls[0][1])
+        if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
+            break
+        if exchanges >= max_exchanges:
+            raise RuntimeError("sharded plan did not terminate")
+    outs = [e.finalize() for e in engines]
+    reduce_min([o[0] for o in outs])
+    reduce_min([o[1] for o in outs])
+    e0 = engines[0]
+    dist = e0.to_numpy(outs[0][0]).view(np.float32)
+    pred = e0.to_numpy(outs[0][1]).view(np.uint32)
+    code, path = walk_path(pred, seed, target)
+    return ShardedResult(code, dist, pred, path, exchanges, rounds)

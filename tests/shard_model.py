@@ -1,0 +1,107 @@
+"""CPU model of ONE rank of the sharded single plan (mesh_navigation_amd/sharded.py) -- test infrastructure.
+
+Same protocol as the GPU engine (own a part of the vertices, relax only into owned vertices, exchange the
+interface values with a min-allreduce, wake on dropped ghosts, finalize the owned part with the reference's
+cut-off semantics), in plain numpy on small meshes.  Ownership here is by vertex-id range (row strips of the grid
+terrain); the GPU engine owns ranges of Morton tiles -- the protocol does not care."""
+import numpy as np
+
+
+class ModelShardEngine:
+    def __init__(self, mesh, weights, costs, rank, world, cost_limit=1.0, invalid=None):
+        self.V = mesh.V
+        self.rank, self.world = rank, world
+        lo = (mesh.V * np.arange(world + 1)) // world
+        self.owner = (np.searchsorted(lo, np.arange(mesh.V), side="right") - 1).astype(np.int64)
+        e = mesh.edges.astype(np.int64)
+        self.src = np.concatenate([e[:, 0], e[:, 1]])
+        self.dst = np.concatenate([e[:, 1], e[:, 0]])
+        w = np.concatenate([weights, weights]).astype(np.float32)
+        inv = np.zeros(mesh.V, bool) if invalid is None else np.asarray(invalid, bool)
+        # cut-offs folded into the gather weights like the device does (dijkstra :302, :328)
+        w = np.where(inv[self.dst] | (costs[self.src].astype(np.float64) > cost_limit), np.float32(np.inf), w)
+        self.w = w
+        self.mine = self.owner[self.dst] == rank                       # edges this rank relaxes
+        cross = self.owner[self.src] != self.owner[self.dst]
+        self.iface = np.unique(np.concatenate([self.src[cross], self.dst[cross]]))
+        self.iface_owned = self.owner[self.iface] == rank
+
+    def begin(self, seed, target, offset):
+        self.seed, self.target, self.offset = seed, target, offset
+        self.dist = np.full(self.V, np.inf, np.float32)
+        self.dist[seed] = 0.0
+        self.pending = True                                           # something may still propagate locally
+        self.ctl = np.zeros(2, np.float32)
+
+    def control_buffer(self):
+        return self.ctl
+
+    def _bound(self):
+        return np.float32(np.float64(self.dist[self.target]) + self.offset)
+
+    def rounds(self, r):
+        d = self.dist
+        self.moved = np.zeros(self.V, bool)
+        for _ in range(r):
+            ok = self.mine & (d[self.src] <= self._bound())            # sources above the bound never relax
+            cand = (d[self.src] + self.w).astype(np.float32)           # the float add of dijkstra :331
+            new = d.copy()
+            np.minimum.at(new, self.dst[ok], cand[ok])
+            ch = new < d
+            if not ch.any():
+                break
+            self.moved |= ch
+            d = new
+        self.dist = d
+        buf = np.full(len(self.iface) + 1, np.inf, np.float32)
+        buf[:-1][self.iface_owned] = d[self.iface[self.iface_owned]]
+        buf[-1] = d[self.target]
+        return buf
+
+    def apply(self, buf):
+        g = ~self.iface_owned
+        v = self.iface[g]
+        drop = buf[:-1][g] < self.dist[v]
+        self.dist[v[drop]] = buf[:-1][g][drop]
+        if buf[-1] < self.dist[self.target]:
+            self.dist[self.target] = buf[-1]
+        # pending = values that still have to be pushed: what moved in the last local sweeps + the dropped ghosts
+        cand = np.concatenate([self.dist[self.moved & (self.owner == self.rank)], self.dist[v[drop]]])
+        cand = cand[cand <= self._bound()]
+        # (a vertex that moved in the LAST sweep of rounds() has not propagated yet; earlier ones have -- a coarse
+        #  but safe over-approximation: one more exchange at the end finds nothing moved)
+        local_min = np.float32(cand.min()) if cand.size else np.float32(np.inf)
+        return float(local_min), float(self.dist[self.target])
+
+    def finalize(self):
+        """cut-off semantics + predecessors for the owned vertices (what k_dij_finalize does per tile)"""
+        d = self.dist
+        goal = np.float32(np.float64(d[self.target]) + self.offset) if np.isfinite(d[self.target]) else np.float32(np.inf)
+        expanded = np.isfinite(d) & (d <= goal)
+        ok = self.mine & expanded[self.src]
+        cand = (d[self.src] + self.w).astype(np.float32)
+        best = np.full(self.V, np.inf, np.float32)
+        np.minimum.at(best, self.dst[ok], cand[ok])
+        out = d.copy()
+        above = (self.owner == self.rank) & ~(d <= goal)
+        out[above] = best[above]                                      # tentative value from expanded sources only
+        out[self.seed] = 0.0
+        pred = np.arange(self.V, dtype=np.int64)
+        att = ok & (cand == out[self.dst]) & np.isfinite(cand)
+        key = np.full(self.V, np.iinfo(np.int64).max, np.int64)        # argmin (d[u], u) among the attaining edges
+        k = (d[self.src].view(np.uint32).astype(np.int64) << 32) | self.src
+        np.minimum.at(key, self.dst[att], k[att])
+        has = key != np.iinfo(np.int64).max
+        pred[has] = key[has] & 0xFFFFFFFF
+        pred[self.seed] = self.seed
+        mine = self.owner == self.rank
+        dist_buf = np.where(mine, out, np.float32(np.inf)).astype(np.float32)
+        pred_buf = np.where(mine, pred, 0xFFFFFFFF).astype(np.uint32)
+        # like the GPU engine: uint32 order -> int32 order around the MIN collective (gloo / RCCL have no uint32)
+        self._pred = (pred_buf ^ np.uint32(0x80000000)).view(np.int32)
+        return dist_buf, self._pred
+
+    def to_numpy(self, x):
+        if x is self._pred:
+            return (x.view(np.uint32) ^ np.uint32(0x80000000))
+        return x

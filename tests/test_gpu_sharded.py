@@ -1,0 +1,68 @@
+"""Config 4 on the GPU: ONE plan on a mesh range-partitioned over `world` ranks.  The multi-GPU run is the driver's
+(bench.py --gpus N --config C4); here several device contexts on the one GPU of the test box stand in for the
+ranks: same kernels (k_tile_round restricted to the owned tiles, k_shard_pack / k_shard_apply / k_dij_finalize per
+rank), the min-allreduce replaced by an elementwise minimum of the ranks' device buffers."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen, sharded
+from tests.common import Case, terrain_case
+
+pytestmark = pytest.mark.gpu
+
+
+def engines(case, world, gpu_ctx_factory, cost_limit=1.0):
+    out = []
+    for r in range(world):
+        ctx = gpu_ctx_factory()
+        case.upload(ctx)
+        out.append(sharded.GpuShardEngine(ctx, r, world, cost_limit))
+    return out
+
+
+@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0)])
+def test_sharded_plan_c1_bit_exact(gpu_ctx_factory, world, offset):
+    case = terrain_case(224, 1)
+    m = case.mesh
+    seed, target = m.vertex_at(0.1, 0.1), m.vertex_at(0.9, 0.9)
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target, goal_dist_offset=offset)
+    eng = engines(case, world, gpu_ctx_factory)
+    infos = [e.info for e in eng]
+    assert infos[0]["t_lo"] == 0 and infos[-1]["t_hi"] == infos[0]["ntiles"]
+    assert all(a["t_hi"] == b["t_lo"] for a, b in zip(infos, infos[1:]))
+    res = sharded.plan_virtual_ranks(eng, seed, target, offset, rounds_per_exchange=4, max_exchanges=5000)
+    assert res.code == ref.code == 0 and res.exchanges > 2
+    assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(res.pred, ref.pred) and np.array_equal(res.path, ref.path)
+
+
+def test_sharded_plan_with_costs_invalid_and_unreachable(gpu_ctx_factory):
+    mesh = meshgen.terrain(96, 0.1, 13)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
+    invalid = (rng.uniform(size=mesh.V) < 0.02).astype(np.uint8)
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    invalid[[s, t]] = 0
+    costs[[s, t]] = 0
+    case = Case(mesh, costs, 1.0, invalid)
+    ref = case.om.dijkstra(case.weights, case.costs, s, t, invalid=invalid)
+    res = sharded.plan_virtual_ranks(engines(case, 2, gpu_ctx_factory), s, t, max_exchanges=5000)
+    assert res.code == ref.code
+    assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(res.pred, ref.pred)
+    # unreachable: cost limit below every neighbour of the target
+    ref2 = case.om.dijkstra(case.weights, case.costs, s, t, invalid=invalid, cost_limit=-1.0)
+    res2 = sharded.plan_virtual_ranks(engines(case, 2, gpu_ctx_factory, cost_limit=-1.0), s, t, max_exchanges=5000)
+    assert res2.code == ref2.code == sharded.NO_PATH_FOUND
+    assert np.array_equal(res2.dist.view(np.uint32), ref2.dist.view(np.uint32))
+
+
+def test_sharded_plan_1m_two_ranks(gpu_ctx_factory):
+    """BASELINE's 1M-vertex mesh cut in two: potential, predecessors and the vertex path of the reference."""
+    case = Case(meshgen.terrain(1000, 0.1, 2))
+    m = case.mesh
+    seed, target = m.vertex_at(0.1, 0.1), m.vertex_at(0.9, 0.9)
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target)
+    res = sharded.plan_virtual_ranks(engines(case, 2, gpu_ctx_factory), seed, target, rounds_per_exchange=8, max_exchanges=5000)
+    assert res.code == ref.code == 0
+    assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(res.pred, ref.pred) and np.array_equal(res.path, ref.path)

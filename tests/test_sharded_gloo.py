@@ -1,0 +1,92 @@
+"""Config 4 on CPU: ONE plan on a range-partitioned mesh, world_size-2 (and 3) gloo processes.  Every process runs
+the production loop (mesh_navigation_amd.sharded.run_sharded_plan) with real torch.distributed min-allreduces;
+the device engine is replaced by its CPU model (tests/shard_model.py).  The gathered potential, predecessors and
+vertex path must be bit-equal to the oracle's single-process plan."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mesh_navigation_amd import meshgen, sharded
+from tests.common import Case
+from tests.shard_model import ModelShardEngine
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    mesh = meshgen.terrain(40, 0.1, 17)
+    rng = np.random.default_rng(4)
+    costs = rng.uniform(0, 0.6, mesh.V).astype(np.float32)
+    costs[rng.choice(mesh.V, 40, replace=False)] = 2.0             # above cost_limit: never act as sources
+    return Case(mesh, costs, 0.5)
+
+
+def _worker(rank, world, port, seed, target, offset, rpe, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = _case()
+    eng = ModelShardEngine(case.mesh, case.weights, case.costs, rank, world)
+    res = sharded.run_sharded_plan(eng, sharded.torch_allreduce_min(dist), seed, target, offset, rounds_per_exchange=rpe)
+    if rank == 0:
+        q.put((res.code, res.dist.tobytes(), res.pred.tobytes(), res.path.tolist(), res.exchanges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,offset,rpe", [(2, 0.3, 4), (3, float("inf"), 2), (2, 0.0, 16)])
+def test_sharded_single_plan_matches_oracle(world, offset, rpe):
+    case = _case()
+    m = case.mesh
+    seed, target = m.vertex_at(0.1, 0.15), m.vertex_at(0.9, 0.85)       # the path crosses every strip
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target, goal_dist_offset=offset)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, target, offset, rpe, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    code, dbytes, pbytes, path, exchanges = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    d = np.frombuffer(dbytes, np.float32)
+    pr = np.frombuffer(pbytes, np.uint32)
+    assert code == ref.code == 0 and exchanges > 2
+    assert np.array_equal(d.view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(pr, ref.pred) and path == ref.path.tolist()
+
+
+def test_virtual_ranks_in_one_process_and_unreachable_target():
+    """the lock-step variant of the loop (what the GPU test uses with several contexts on one GPU)"""
+    case = _case()
+    m = case.mesh
+    seed, target = m.vertex_at(0.2, 0.2), m.vertex_at(0.8, 0.7)
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target)
+    engines = [ModelShardEngine(m, case.weights, case.costs, r, 4) for r in range(4)]
+    res = sharded.plan_virtual_ranks(engines, seed, target, rounds_per_exchange=3)
+    assert res.code == ref.code == 0
+    assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(res.pred, ref.pred)
+    assert np.array_equal(res.path, ref.path)
+    # a target nobody reaches: invalid ring around it
+    inv = np.zeros(m.V, np.uint8)
+    ring = np.unique(m.edges[(m.edges == target).any(1)].ravel())
+    inv[ring] = 1
+    inv[target] = 0
+    case2 = Case(m, case.costs, 0.5, inv)
+    ref2 = case2.om.dijkstra(case2.weights, case2.costs, seed, target, invalid=inv)
+    engines = [ModelShardEngine(m, case2.weights, case2.costs, r, 2, invalid=inv) for r in range(2)]
+    res2 = sharded.plan_virtual_ranks(engines, seed, target)
+    assert res2.code == ref2.code == sharded.NO_PATH_FOUND
+    assert np.array_equal(res2.dist.view(np.uint32), ref2.dist.view(np.uint32))
