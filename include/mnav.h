@@ -149,6 +149,15 @@ uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
                              const uint32_t* target_faces, double goal_dist_offset, double cost_limit,
                              uint32_t* codes_out, float* dist_out, uint32_t* pred_out, float* vecmap_out);
 
+/* Incremental cost change: MeshMap::layerChanged (mesh_map.cpp:454-493) + updateEdgeWeights(changed) (:563-618) on
+ * the device.  The n vertices get their new costs; if the resident weights were computed here with a non-zero
+ * edge_cost_factor (mnav_compute_edge_weights / mnav_combine_costs) the edges around them are re-weighted with the
+ * same mixed float/double expression (:606-610), otherwise only the vertex costs change ("edge_cost_factor is 0,
+ * skipping edge cost update", :568-572).  Nothing but the n ids and values crosses PCIe.  Returns 0 / <0. */
+int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, const float* values);
+/* Copies of the resident vertex costs (V) and edge weights (E); either pointer may be NULL. */
+int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weights_out);
+
 /* -- one plan over several GPUs (BASELINE config 4) ---------------------------------------------
  * The reference's loop (dijkstra_mesh_planner.cpp:287-348) on a mesh that is range-partitioned over `world`
  * processes, one per GPU: the LDS tiles are in Morton order and process `rank` owns a contiguous range of them.

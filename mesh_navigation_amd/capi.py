@@ -22,7 +22,7 @@ SYMBOLS = [
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
-    "mnav_shard_finalize",
+    "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs",
 ]
 
 
@@ -83,6 +83,10 @@ def load(path: str | None = None):
     L.mnav_set_dijkstra_engine.argtypes = [vp, C.c_int]
     L.mnav_device_output.restype = vp
     L.mnav_device_output.argtypes = [vp, u32, C.c_int]
+    L.mnav_update_costs.restype = C.c_int
+    L.mnav_update_costs.argtypes = [vp, u32, vp, vp]
+    L.mnav_download_costs.restype = C.c_int
+    L.mnav_download_costs.argtypes = [vp, vp, vp]
     L.mnav_shard_setup.restype = C.c_int
     L.mnav_shard_setup.argtypes = [vp, u32, u32]
     L.mnav_shard_info.restype = C.c_int
@@ -218,6 +222,20 @@ class MnavContext:
     def set_dijkstra_engine(self, engine: str):
         """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
         self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4}[engine])
+
+    def update_costs(self, vertex_ids, values):
+        """Incremental cost change (layerChanged + updateEdgeWeights(changed)) on the device."""
+        ids, vals = _u32(vertex_ids), _f32(values)
+        rc = self._L.mnav_update_costs(self._h, ids.shape[0], _p(ids), _p(vals))
+        if rc != 0:
+            raise RuntimeError(f"mnav_update_costs failed ({rc}): {self._err()}")
+
+    def download_costs(self):
+        vc = np.empty(self.V, np.float32)
+        w = np.empty(self.E, np.float32)
+        if self._L.mnav_download_costs(self._h, _p(vc), _p(w)) != 0:
+            raise RuntimeError(f"mnav_download_costs failed: {self._err()}")
+        return vc, w
 
     # ---- one plan over several GPUs (mesh_navigation_amd/sharded.py drives these) ----
     def shard_setup(self, rank: int, world: int) -> int:

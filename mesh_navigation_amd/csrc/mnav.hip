@@ -1688,6 +1688,36 @@ __global__ __launch_bounds__(kBlock) void k_edge_weights(uint32_t E, const uint3
   w[e] = (float)((double)vd + factor * (double)edge_cost);                                   // :552
 }
 
+// Incremental cost change (MeshMap::layerChanged mesh_map.cpp:454-493 + updateEdgeWeights :563-618): the changed
+// vertices get their new cost, then only the edges around them are re-weighted -- same expressions as :550-552.
+__global__ __launch_bounds__(kBlock) void k_scatter_costs(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ values,
+                                                          float* __restrict__ cost)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) cost[ids[i]] = values[i];
+}
+__global__ __launch_bounds__(kBlock) void k_update_edge_weights(uint32_t n, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ row_ptr,
+                                                                const uint32_t* __restrict__ nbr_u, const uint32_t* __restrict__ nbr_e,
+                                                                const float* __restrict__ edge_dist, const float* __restrict__ cost,
+                                                                double factor, float* __restrict__ w)
+{
+  // 8 lanes per changed vertex, one incident edge each (an edge between two changed vertices is written twice with
+  // the same value)
+  const uint32_t i = (blockIdx.x * kBlock + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  if (i >= n) return;
+  const uint32_t v = ids[i];
+  const float c1 = cost[v];
+  for (uint32_t k = row_ptr[v] + sub; k < row_ptr[v + 1]; k += 8) {
+    const uint32_t e = nbr_e[k];
+    const float c2 = cost[nbr_u[k]];
+    if (isinf(c1) || isinf(c2)) { w[e] = inf_f(); continue; }       // :596-600
+    const float vd = edge_dist[e];                                   // :606
+    const float edge_cost = (float)((double)(vd * (c1 + c2)) / 2.0); // :608 (float sum: commutative, the endpoint order is free)
+    w[e] = (float)((double)vd + factor * (double)edge_cost);        // :610
+  }
+}
+
 // gather CSR for Dijkstra: {u, w(u,v)}; w=+inf when v is invalid (:328) or u is over the cost
 // limit (:302, u would be popped but never expanded)
 __global__ __launch_bounds__(kBlock) void k_build_nbr(uint32_t V, const uint32_t* __restrict__ row_ptr,
@@ -1820,6 +1850,7 @@ struct mnav_ctx {
     uint8_t* d_iface_owner = nullptr;
     std::vector<uint32_t> iface_vert;
   } shard;
+  double edge_cost_factor = 0.0;                                   // factor of the resident edge weights (mnav_update_costs)
   uint32_t* d_next_plan = nullptr;
   uint32_t wave_min_batch = 0;                                     // auto engine: 0 = never pick k_plan_wave (MNAV_WAVE_MIN_BATCH to opt in)
   TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
@@ -2768,6 +2799,34 @@ int mnav_upload_costs(mnav_ctx* ctx, const float* vertex_costs, const float* edg
   auto_delta(ctx, edge_weights, ctx->E);
   ctx->nbr_valid = ctx->crn_valid = false;
   ctx->have_costs = true;
+  ctx->edge_cost_factor = 0.0;                                       // weights came from the caller: mnav_update_costs only touches vertex costs
+  return 0;
+}
+
+// device pass shared by mnav_compute_edge_weights / mnav_combine_costs: d_cost and d_edge_dist are resident, d_w is
+// (re)computed; host mirrors (cost for the seed cut-offs, mean weight for the band widths) are refreshed
+static int edge_weight_pass(mnav_ctx* ctx, double edge_cost_factor, const uint8_t* invalid, float* vertex_costs_out, float* edge_weights_out)
+{
+  if (dev_upload(ctx, &ctx->d_w, (const float*)nullptr, ctx->E)) return -1;
+  std::vector<uint8_t> zero;
+  if (!invalid) { zero.assign(ctx->V ? ctx->V : 1, 0); invalid = zero.data(); }
+  if (dev_upload(ctx, &ctx->d_invalid, invalid, ctx->V)) return -1;
+  const uint32_t gb = (ctx->E + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_edge_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, ctx->E, ctx->d_edge_vtx, ctx->d_edge_dist,
+                     ctx->d_cost, edge_cost_factor, ctx->d_w);
+  HIPCHK(hipGetLastError());
+  std::vector<float> w(ctx->E ? ctx->E : 1);
+  ctx->h_cost.resize(ctx->V);
+  HIPCHK(hipMemcpyAsync(w.data(), ctx->d_w, sizeof(float) * ctx->E, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_cost.data(), ctx->d_cost, sizeof(float) * ctx->V, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (edge_weights_out) memcpy(edge_weights_out, w.data(), sizeof(float) * ctx->E);
+  if (vertex_costs_out) memcpy(vertex_costs_out, ctx->h_cost.data(), sizeof(float) * ctx->V);
+  ctx->h_invalid.assign(invalid, invalid + ctx->V);
+  auto_delta(ctx, w.data(), ctx->E);
+  ctx->nbr_valid = ctx->crn_valid = false;
+  ctx->edge_cost_factor = edge_cost_factor;
+  ctx->have_costs = true;
   return 0;
 }
 
@@ -2781,24 +2840,7 @@ int mnav_compute_edge_weights(mnav_ctx* ctx, const float* vertex_costs, const fl
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   if (dev_upload(ctx, &ctx->d_cost, vertex_costs, ctx->V)) return -1;
   if (dev_upload(ctx, &ctx->d_edge_dist, edge_distances, ctx->E)) return -1;
-  if (dev_upload(ctx, &ctx->d_w, (const float*)nullptr, ctx->E)) return -1;
-  std::vector<uint8_t> zero;
-  if (!invalid) { zero.assign(ctx->V ? ctx->V : 1, 0); invalid = zero.data(); }
-  if (dev_upload(ctx, &ctx->d_invalid, invalid, ctx->V)) return -1;
-  const uint32_t gb = (ctx->E + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_edge_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, ctx->E, ctx->d_edge_vtx, ctx->d_edge_dist,
-                     ctx->d_cost, edge_cost_factor, ctx->d_w);
-  HIPCHK(hipGetLastError());
-  std::vector<float> w(ctx->E ? ctx->E : 1);
-  HIPCHK(hipMemcpyAsync(w.data(), ctx->d_w, sizeof(float) * ctx->E, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (edge_weights_out) memcpy(edge_weights_out, w.data(), sizeof(float) * ctx->E);
-  ctx->h_cost.assign(vertex_costs, vertex_costs + ctx->V);
-  ctx->h_invalid.assign(invalid, invalid + ctx->V);
-  auto_delta(ctx, w.data(), ctx->E);
-  ctx->nbr_valid = ctx->crn_valid = false;
-  ctx->have_costs = true;
-  return 0;
+  return edge_weight_pass(ctx, edge_cost_factor, invalid, nullptr, edge_weights_out);
 }
 
 int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* const* layer_costs, const float* weights,
@@ -2809,7 +2851,7 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
   ctx->err.clear();
   if (!ctx->have_mesh) { ctx->err = "mnav_upload_mesh has not been called"; return -1; }
   if (mode != 0 && mode != 1) { ctx->err = "combination mode must be 0 (max) or 1 (weighted sum)"; return -1; }
-  if ((n_layers && !layer_costs) || (mode == 1 && n_layers && !weights) || (ctx->E && !edge_distances)) { ctx->err = "null input array"; return -1; }
+  if ((n_layers && !layer_costs) || (mode == 1 && n_layers && !weights) || (ctx->E && !edge_distances && !ctx->d_edge_dist)) { ctx->err = "null input array"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   const uint32_t V = ctx->V;
   float *d_layers = nullptr, *d_wts = nullptr;
@@ -2822,22 +2864,61 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
   }
   if (rc == 0 && mode == 1 && n_layers &&
       hipMemcpyAsync(d_wts, weights, sizeof(float) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "weight upload failed"; rc = -1; }
-  std::vector<float> cost(V ? V : 1);
-  if (rc == 0) {
-    if (dev_upload(ctx, &ctx->d_cost, (const float*)nullptr, V)) rc = -1;
-  }
+  if (rc == 0 && dev_upload(ctx, &ctx->d_cost, (const float*)nullptr, V)) rc = -1;
+  if (rc == 0 && edge_distances && dev_upload(ctx, &ctx->d_edge_dist, edge_distances, ctx->E)) rc = -1;   // NULL: keep the resident ones
   if (rc == 0) {
     const uint32_t gb = (V + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_combine, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, V, mode, n_layers, d_layers, d_wts, ctx->d_cost);
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(cost.data(), ctx->d_cost, sizeof(float) * V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "cost combination failed"; rc = -1; }
+    if (hipGetLastError() != hipSuccess) { ctx->err = "cost combination failed"; rc = -1; }
   }
+  // the combined costs never leave the device: the edge-weight pass reads them where they are
+  if (rc == 0) rc = edge_weight_pass(ctx, edge_cost_factor, invalid, vertex_costs_out, edge_weights_out);
+  (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_layers); (void)hipFree(d_wts);
+  return rc;
+}
+
+int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, const float* values)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!ctx->have_costs) { ctx->err = "no costs resident yet (mnav_upload_costs / mnav_compute_edge_weights / mnav_combine_costs first)"; return -1; }
+  if (n == 0) return 0;
+  if (!vertex_ids || !values) { ctx->err = "null input array"; return -1; }
+  for (uint32_t i = 0; i < n; ++i) if (vertex_ids[i] >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  uint32_t* d_ids = nullptr; float* d_vals = nullptr;
+  HIPCHK(hipMalloc((void**)&d_ids, sizeof(uint32_t) * n));
+  HIPCHK(hipMalloc((void**)&d_vals, sizeof(float) * n));
+  int rc = 0;
+  if (hipMemcpyAsync(d_ids, vertex_ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(d_vals, values, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "upload failed"; rc = -1; }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_scatter_costs, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, d_ids, d_vals, ctx->d_cost);
+    // "Edge costs are only affected by vertex costs if layer_factor is not 0" (:568-572)
+    if (ctx->edge_cost_factor != 0.0) {
+      if (!ctx->d_edge_dist) { ctx->err = "edge distances are not resident (weights were uploaded, not computed here)"; rc = -1; }
+      else hipLaunchKernelGGL(k_update_edge_weights, dim3((8 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, d_ids, ctx->d_row_ptr,
+                              ctx->d_nbr_u, ctx->d_nbr_e, ctx->d_edge_dist, ctx->d_cost, ctx->edge_cost_factor, ctx->d_w);
+    }
+    if (rc == 0 && hipGetLastError() != hipSuccess) { ctx->err = "cost update failed"; rc = -1; }
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_ids); (void)hipFree(d_vals);
   if (rc) return rc;
-  if (vertex_costs_out) memcpy(vertex_costs_out, cost.data(), sizeof(float) * V);
-  // edge weights from the combined costs (same device pass as mnav_compute_edge_weights)
-  return mnav_compute_edge_weights(ctx, cost.data(), edge_distances, edge_cost_factor, invalid, edge_weights_out);
+  for (uint32_t i = 0; i < n; ++i) ctx->h_cost[vertex_ids[i]] = values[i];
+  ctx->nbr_valid = ctx->crn_valid = false;                          // the cost-limit folded copies are rebuilt on the next plan
+  return 0;
+}
+
+int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weights_out)
+{
+  if (!ctx || !ctx->have_costs) { if (ctx) ctx->err = "no costs resident"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  if (vertex_costs_out) HIPCHK(hipMemcpyAsync(vertex_costs_out, ctx->d_cost, sizeof(float) * ctx->V, hipMemcpyDeviceToHost, ctx->stream));
+  if (edge_weights_out) HIPCHK(hipMemcpyAsync(edge_weights_out, ctx->d_w, sizeof(float) * ctx->E, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, const uint32_t* targets, double offset,

@@ -1,0 +1,82 @@
+"""Cost preparation on the device: edge weights, Max/Avg combination and the INCREMENTAL update
+(MeshMap::layerChanged + updateEdgeWeights(changed), mesh_map.cpp:454-493, :563-618) -- bit-equal to the restated
+reference formula (which tests/test_ref_pins_oracle.py pins to the reference's own code, incl. its incremental path)."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from tests.common import Case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_incremental_cost_update_matches_full_recompute(gpu_ctx_factory):
+    mesh = meshgen.terrain(96, 0.1, 21)
+    rng = np.random.default_rng(9)
+    costs = rng.uniform(0, 0.9, mesh.V).astype(np.float32)
+    base = Case(mesh, costs, 0.7)
+    ctx = gpu_ctx_factory()
+    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, base.vn)
+    w = ctx.compute_edge_weights(costs, base.edge_dist, 0.7)
+    assert np.array_equal(w.view(np.uint32), base.weights.view(np.uint32))
+    ids = rng.choice(mesh.V, 400, replace=False).astype(np.uint32)
+    vals = rng.uniform(0, 1.5, ids.size).astype(np.float32)
+    vals[:7] = np.inf                                          # lethal vertices: infinite weights around them
+    s, t = mesh.vertex_at(0.1, 0.1), mesh.vertex_at(0.9, 0.9)
+    keep = ~np.isin(ids, [s, t])
+    ids, vals = ids[keep], vals[keep]
+    ctx.update_costs(ids, vals)                                # only the ids and values cross PCIe
+    costs2 = costs.copy()
+    costs2[ids] = vals
+    want = Case(mesh, costs2, 0.7)
+    vc, w2 = ctx.download_costs()
+    assert np.array_equal(vc.view(np.uint32), costs2.view(np.uint32))
+    assert np.array_equal(w2.view(np.uint32), want.weights.view(np.uint32))
+    # the planners see the change (cost-limit folded copies are rebuilt)
+    ref = want.om.dijkstra(want.weights, costs2, s, t)
+    out = ctx.plan_dijkstra(s, t)
+    assert out.code == ref.code
+    assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
+    # a second, overlapping update
+    ids3 = np.concatenate([ids[:50], rng.choice(mesh.V, 50, replace=False).astype(np.uint32)])
+    ids3 = np.unique(ids3[~np.isin(ids3, [s, t])])
+    vals3 = rng.uniform(0, 0.5, ids3.size).astype(np.float32)
+    ctx.update_costs(ids3, vals3)
+    costs3 = costs2.copy()
+    costs3[ids3] = vals3
+    want3 = Case(mesh, costs3, 0.7)
+    vc, w3 = ctx.download_costs()
+    assert np.array_equal(w3.view(np.uint32), want3.weights.view(np.uint32))
+
+
+def test_update_with_factor_zero_leaves_the_weights_alone(gpu_ctx_factory):
+    """edge_cost_factor 0 (the reference default): "skipping edge cost update" (:568-572); only the cut-offs change."""
+    case = Case(meshgen.terrain(64, 0.1, 5))
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)                                           # weights uploaded by the caller
+    m = case.mesh
+    s, t = m.vertex_at(0.1, 0.1), m.vertex_at(0.9, 0.9)
+    wall = np.array([m.vertex_at(0.5, f) for f in np.linspace(0.0, 0.8, 60)], np.uint32)
+    wall = np.unique(wall)
+    ctx.update_costs(wall, np.full(wall.size, 2.0, np.float32))   # above cost_limit: a wall the plan must go around
+    costs = case.costs.copy()
+    costs[wall] = 2.0
+    _, w = ctx.download_costs()
+    assert np.array_equal(w.view(np.uint32), case.weights.view(np.uint32))
+    ref = case.om.dijkstra(case.weights, costs, s, t)
+    out = ctx.plan_dijkstra(s, t)
+    assert out.code == ref.code == 0 and np.array_equal(out.path, ref.path)
+    assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32))
+
+
+def test_combination_stays_on_the_device(gpu_ctx_factory):
+    from tests.common import layered_costs
+    base = Case(meshgen.terrain(48, 0.1, 3, amplitude=0.8))
+    costs, parts = layered_costs(base, "avg")
+    want = Case(base.mesh, costs, 1.0)
+    ctx = gpu_ctx_factory()
+    ctx.upload_mesh(base.mesh.xyz, base.mesh.faces, base.mesh.edges, base.vn)
+    vc, ew = ctx.combine_costs([parts["steepness"], parts["inflation"]], [1.0, 1.0], base.edge_dist, 1.0, "avg")
+    assert np.array_equal(vc.view(np.uint32), costs.view(np.uint32)) and np.array_equal(ew.view(np.uint32), want.weights.view(np.uint32))
+    vc2, ew2 = ctx.download_costs()
+    assert np.array_equal(vc2.view(np.uint32), vc.view(np.uint32)) and np.array_equal(ew2.view(np.uint32), ew.view(np.uint32))
