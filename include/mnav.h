@@ -197,6 +197,14 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
  * batches), 3 = automatic (default: 2 for batches of >= 128 plans, else 0), 4 = one wave per plan on a finer
  * tiling (experimental, slower than 2 at 1M vertices).  All give identical results. */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
+/* Outputs that stay on the device.  mnav_set_resident_outputs(ctx, 1): every plan also computes its vector map
+ * (computeVectorMap, dijkstra :189-209 / cvp :204-239) and leaves it in HBM even when no host buffer is passed.
+ * mnav_download_output copies one V-sized output of plan `slot` to the host on demand (what as below; 12 B/vertex for
+ * the vector map, 4 B otherwise).  mnav_vector_at is MeshMap::directionAtPosition (mesh_map.cpp:625-650) on the
+ * resident vector map: the controller's sample at the robot pose (returns 1, 0 = no vector there, <0 error). */
+int mnav_set_resident_outputs(mnav_ctx* ctx, int on);
+int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out);
+int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const float bary[3], float out[3]);
 /* Device pointers of the last plan's resident outputs (slot = plan index in a batch):
  * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available. */
 const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what);

@@ -22,7 +22,8 @@ SYMBOLS = [
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
-    "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs",
+    "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
+    "mnav_vector_at",
 ]
 
 
@@ -83,6 +84,12 @@ def load(path: str | None = None):
     L.mnav_set_dijkstra_engine.argtypes = [vp, C.c_int]
     L.mnav_device_output.restype = vp
     L.mnav_device_output.argtypes = [vp, u32, C.c_int]
+    L.mnav_set_resident_outputs.restype = C.c_int
+    L.mnav_set_resident_outputs.argtypes = [vp, C.c_int]
+    L.mnav_download_output.restype = C.c_int
+    L.mnav_download_output.argtypes = [vp, u32, C.c_int, vp]
+    L.mnav_vector_at.restype = C.c_int
+    L.mnav_vector_at.argtypes = [vp, u32, vp, vp, vp]
     L.mnav_update_costs.restype = C.c_int
     L.mnav_update_costs.argtypes = [vp, u32, vp, vp]
     L.mnav_download_costs.restype = C.c_int
@@ -222,6 +229,23 @@ class MnavContext:
     def set_dijkstra_engine(self, engine: str):
         """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
         self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4}[engine])
+
+    def set_resident_outputs(self, on: bool = True):
+        self._L.mnav_set_resident_outputs(self._h, 1 if on else 0)
+
+    def download_output(self, what: str, slot: int = 0) -> np.ndarray:
+        code = {"dist": 0, "pred": 1, "direction": 2, "cutface": 3, "vecmap": 4}[what]
+        out = np.empty((self.V, 3) if code == 4 else self.V, np.uint32 if code in (1, 3) else np.float32)
+        if self._L.mnav_download_output(self._h, int(slot), code, _p(out)) != 0:
+            raise RuntimeError(f"mnav_download_output failed: {self._err()}")
+        return out
+
+    def vector_at(self, vs, bary, slot: int = 0):
+        out = np.zeros(3, np.float32)
+        rc = self._L.mnav_vector_at(self._h, int(slot), _p(_u32(vs)), _p(_f32(bary)), _p(out))
+        if rc < 0:
+            raise RuntimeError(f"mnav_vector_at failed: {self._err()}")
+        return out if rc == 1 else None
 
     def update_costs(self, vertex_ids, values):
         """Incremental cost change (layerChanged + updateEdgeWeights(changed)) on the device."""

@@ -78,6 +78,48 @@ uint32_t mnav_adapter_make_plan(mnav_adapter_planner* a, const double start_pose
 
 int mnav_adapter_cancel(mnav_adapter_planner* a) { return a->planner->cancel() ? 1 : 0; }
 
+// change counter of the map's cost arrays (0 = unknown: the device mirror hashes them on every plan)
+void mnav_adapter_set_cost_version(mnav_adapter_planner* a, uint64_t version) { a->map->cost_version = version; }
+
+// V-sized results of the last plan, fetched from the device on demand; what: 0 potential (float V), 1 predecessors
+// (uint32 V; Dijkstra), 4 vector map (float V*3; Dijkstra)
+int mnav_adapter_fetch(mnav_adapter_planner* a, int what, void* out)
+{
+  const uint32_t V = a->map->V;
+  if (a->is_cvp) {
+    auto* p = static_cast<cvp_mesh_planner::CVPMeshPlanner*>(a->planner.get());
+    if (what != 0) return -1;
+    std::memcpy(out, p->potential().data(), 4 * (size_t)V);
+    return 0;
+  }
+  auto* p = static_cast<dijkstra_mesh_planner::DijkstraMeshPlanner*>(a->planner.get());
+  if (what == 0) std::memcpy(out, p->potential().data(), 4 * (size_t)V);
+  else if (what == 1) std::memcpy(out, p->predecessors().data(), 4 * (size_t)V);
+  else if (what == 4) std::memcpy(out, p->getVectorMap().data(), 12 * (size_t)V);
+  else return -1;
+  return 0;
+}
+
+static void fill_layer_field(mesh_map::MeshMap::LayerVectorField& L, uint32_t V, const float* distances, const uint8_t* has_distance,
+                             const float* vectors, const uint8_t* has_vector, double inscribed_radius, double inflation_radius,
+                             double lethal_value, double inscribed_value, int repulsive_field)
+{
+  L.distances.assign(distances, distances + V); L.has_distance.assign(has_distance, has_distance + V);
+  L.vectors.assign(vectors, vectors + 3 * (size_t)V); L.has_vector.assign(has_vector, has_vector + V);
+  L.inscribed_radius = inscribed_radius; L.inflation_radius = inflation_radius; L.lethal_value = lethal_value;
+  L.inscribed_value = inscribed_value; L.repulsive_field = repulsive_field != 0;
+}
+
+// a layer's repulsive vector field (InflationLayer distances_ / vector_map_) for MeshMap::meshAhead (mesh_map.cpp:1099-1102)
+void mnav_adapter_add_layer_field(mnav_adapter_planner* a, const float* distances, const uint8_t* has_distance, const float* vectors,
+                                  const uint8_t* has_vector, double inscribed_radius, double inflation_radius, double lethal_value,
+                                  double inscribed_value, int repulsive_field)
+{
+  a->map->layer_fields.emplace_back();
+  fill_layer_field(a->map->layer_fields.back(), a->map->V, distances, has_distance, vectors, has_vector, inscribed_radius, inflation_radius,
+                   lethal_value, inscribed_value, repulsive_field);
+}
+
 // update the map's cost arrays in place (what a layer change does, mesh_map.cpp:454-493)
 void mnav_adapter_set_costs(mnav_adapter_planner* a, const float* vertex_costs, const float* edge_weights)
 {
@@ -104,6 +146,31 @@ uint32_t mnav_adapter_host_containing_face(uint32_t V, uint32_t F, const float* 
 }
 
 // cvp_mesh_planner.cpp:920-951 on a given vector field; path in reference list order (seed first)
+static uint32_t host_backtrack(mesh_map::MeshMap& m, uint32_t V, const float* vecmap, const uint8_t* has_vec, const float seed_pos[3],
+                               uint32_t seed_face, const float target_pos[3], uint32_t target_face, double step_width, uint32_t cap,
+                               float* path_pos, uint32_t* path_face, uint32_t* path_len);
+
+// the same with one layer vector field (Inflation) added in meshAhead; code 54 + *panicked = 1 where the reference's
+// attribute-map lookup panics
+uint32_t mnav_adapter_host_backtrack_layer(uint32_t V, uint32_t F, const float* xyz, const uint32_t* faces, const float* vecmap,
+                                           const uint8_t* has_vec, const float seed_pos[3], uint32_t seed_face, const float target_pos[3],
+                                           uint32_t target_face, double step_width, const float* distances, const uint8_t* has_distance,
+                                           const float* vectors, const uint8_t* has_vector, double inscribed_radius, double inflation_radius,
+                                           double lethal_value, double inscribed_value, int repulsive_field, uint32_t cap, float* path_pos,
+                                           uint32_t* path_face, uint32_t* path_len, int* panicked)
+{
+  mesh_map::MeshMap m;
+  m.positions.assign(xyz, xyz + 3 * (size_t)V); m.faces.assign(faces, faces + 3 * (size_t)F);
+  m.finalize();
+  m.layer_fields.emplace_back();
+  fill_layer_field(m.layer_fields.back(), V, distances, has_distance, vectors, has_vector, inscribed_radius, inflation_radius, lethal_value,
+                   inscribed_value, repulsive_field);
+  *panicked = 0;
+  try {
+    return host_backtrack(m, V, vecmap, has_vec, seed_pos, seed_face, target_pos, target_face, step_width, cap, path_pos, path_face, path_len);
+  } catch (const mesh_map::MeshMap::MapPanic&) { *panicked = 1; *path_len = 0; return 54; }
+}
+
 uint32_t mnav_adapter_host_backtrack(uint32_t V, uint32_t F, const float* xyz, const uint32_t* faces, const float* vecmap,
                                      const uint8_t* has_vec, const float seed_pos[3], uint32_t seed_face, const float target_pos[3],
                                      uint32_t target_face, double step_width, uint32_t cap, float* path_pos, uint32_t* path_face,
@@ -112,6 +179,13 @@ uint32_t mnav_adapter_host_backtrack(uint32_t V, uint32_t F, const float* xyz, c
   mesh_map::MeshMap m;
   m.positions.assign(xyz, xyz + 3 * (size_t)V); m.faces.assign(faces, faces + 3 * (size_t)F);
   m.finalize();
+  return host_backtrack(m, V, vecmap, has_vec, seed_pos, seed_face, target_pos, target_face, step_width, cap, path_pos, path_face, path_len);
+}
+
+static uint32_t host_backtrack(mesh_map::MeshMap& m, uint32_t V, const float* vecmap, const uint8_t* has_vec, const float seed_pos[3],
+                               uint32_t seed_face, const float target_pos[3], uint32_t target_face, double step_width, uint32_t cap,
+                               float* path_pos, uint32_t* path_face, uint32_t* path_len)
+{
   m.setVectorMap(std::vector<float>(vecmap, vecmap + 3 * (size_t)V), std::vector<uint8_t>(has_vec, has_vec + V));
   const mesh_map::Vector start(seed_pos[0], seed_pos[1], seed_pos[2]);
   mesh_map::Vector pos(target_pos[0], target_pos[1], target_pos[2]);

@@ -1,4 +1,7 @@
 // gpu_mesh_planners.cpp -- see gpu_mesh_planners.h.  Reference line numbers in the comments.
+// Said plainly: the two makePlan bodies below are statement-for-statement re-typings of the reference's
+// (dijkstra_mesh_planner.cpp:55-116, cvp_mesh_planner.cpp:62-124) on flat arrays -- O(path) glue whose job is to be
+// the same steps; the wavefront loops they used to contain are one mnav_plan_* call each.  Do not let this file grow.
 #include "gpu_mesh_planners.h"
 
 #include <cmath>
@@ -9,11 +12,21 @@ typedef mbf_msgs::action::GetPath::Result Result;
 
 namespace mnav_adapter {
 
-static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull)
+// 64-bit content hash over 8-byte words (multiply-xorshift mixing): ~2 ms for the 17 MB of a 1M-vertex map, against
+// the 15-20 ms a byte-serial hash took -- and not needed at all when the map carries a change counter
+static uint64_t hash_words(const void* p, size_t n, uint64_t h)
 {
   const unsigned char* b = static_cast<const unsigned char*>(p);
-  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
-  return h;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w; std::memcpy(&w, b + i, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 32;
+  }
+  uint64_t tail = 0;
+  if (i < n) std::memcpy(&tail, b + i, n - i);
+  h = (h ^ tail ^ (uint64_t)n) * 0x9E3779B97F4A7C15ull;
+  return h ^ (h >> 29);
 }
 
 MeshMapDevice::MeshMapDevice(int device) { ctx_ = mnav_create(device); }
@@ -25,15 +38,22 @@ bool MeshMapDevice::sync(const mesh_map::MeshMap& map, std::string& err)
   if (uploaded_ != &map) {
     if (mnav_upload_mesh(ctx_, map.V, map.F, map.E, map.positions.data(), map.faces.data(), map.edges.data(),
                          map.vertex_normals.empty() ? nullptr : map.vertex_normals.data()) != 0) { err = mnav_last_error(ctx_); return false; }
-    uploaded_ = &map; cost_hash_ = 0;
+    uploaded_ = &map; cost_hash_ = 0; have_costs_ = false;
+    (void)mnav_set_resident_outputs(ctx_, 1);                        // V-sized outputs stay in HBM until somebody asks for them
   }
-  // there is no version counter on vertex_costs / edge_weights: hash, re-upload on change
-  uint64_t h = fnv(map.vertex_costs.data(), map.vertex_costs.size() * 4);
-  h = fnv(map.edge_weights.data(), map.edge_weights.size() * 4, h);
-  h = fnv(map.invalid.data(), map.invalid.size(), h);
-  if (h != cost_hash_ || cost_hash_ == 0) {
+  // the reference re-reads vertex_costs / edge_weights on every plan; re-upload only when they changed: by the
+  // map's change counter when the integration maintains one, else by content hash
+  uint64_t h;
+  if (map.cost_version != 0) h = map.cost_version | (1ull << 63);
+  else {
+    h = hash_words(map.vertex_costs.data(), map.vertex_costs.size() * 4, 0x243F6A8885A308D3ull);
+    h = hash_words(map.edge_weights.data(), map.edge_weights.size() * 4, h);
+    h = hash_words(map.invalid.data(), map.invalid.size(), h);
+    h &= ~(1ull << 63);
+  }
+  if (h != cost_hash_ || !have_costs_) {
     if (mnav_upload_costs(ctx_, map.vertex_costs.data(), map.edge_weights.data(), map.invalid.data()) != 0) { err = mnav_last_error(ctx_); return false; }
-    cost_hash_ = h ? h : 1;
+    cost_hash_ = h; have_costs_ = true;
   }
   return true;
 }
@@ -119,17 +139,32 @@ uint32_t DijkstraMeshPlanner::dijkstra(const mesh_map::Vector& original_start, c
   std::string err;
   if (!dev_ || !dev_->sync(*mesh_map_, err)) return Result::INTERNAL_ERROR;
   const uint32_t V = mesh_map_->V;
-  potential_.assign(V, 0.f); predecessors_.assign(V, 0u); vector_map_.assign((size_t)V * 3, 0.f);
+  fields_on_host_ = false;
   std::vector<uint32_t> p(V ? V : 1);
   uint32_t n = 0;
+  // potential, predecessors and the vector map (computeVectorMap :380) are computed and kept on the device; only
+  // the vertex path comes back.  They are fetched when somebody reads them (potential(), the controller's
+  // MeshMap::getVectorMap, publishing) -- fetchFields().
   const uint32_t code = mnav_plan_dijkstra(dev_->ctx(), start_vertex, goal_vertex, config_.goal_dist_offset, config_.cost_limit,
-                                           potential_.data(), predecessors_.data(), p.data(), V, &n, vector_map_.data());
+                                           nullptr, nullptr, p.data(), V, &n, nullptr);
   if (code != Result::SUCCESS) return code;
   for (uint32_t i = 0; i < n; ++i) path.push_back(p[i]);                      // :367-373 list order: seed first
+  if (config_.publish_vector_field || eager_fields_) fetchFields();          // :126-129
+  return Result::SUCCESS;
+}
+
+// V-sized results of the last plan, on demand: 20 MB over PCIe at 1M vertices, O(V) host work
+void DijkstraMeshPlanner::fetchFields()
+{
+  if (fields_on_host_ || !dev_ || !dev_->ok()) return;
+  const uint32_t V = mesh_map_->V;
+  potential_.assign(V, 0.f); predecessors_.assign(V, 0u); vector_map_.assign((size_t)V * 3, 0.f);
+  if (mnav_download_output(dev_->ctx(), 0, 0, potential_.data()) != 0 || mnav_download_output(dev_->ctx(), 0, 1, predecessors_.data()) != 0 ||
+      mnav_download_output(dev_->ctx(), 0, 4, vector_map_.data()) != 0) return;
   std::vector<uint8_t> set(V, 0);
   for (uint32_t v = 0; v < V; ++v) set[v] = predecessors_[v] != v;            // :197
   mesh_map_->setVectorMap(vector_map_, set);                                  // :208
-  return Result::SUCCESS;
+  fields_on_host_ = true;
 }
 }  // namespace dijkstra_mesh_planner
 
@@ -214,17 +249,25 @@ uint32_t CVPMeshPlanner::waveFrontPropagation(const mesh_map::Vector& original_s
   std::string err;
   if (!dev_ || !dev_->sync(*mesh_map_, err)) { message = err; return Result::INTERNAL_ERROR; }
   const uint32_t V = mesh_map_->V;
-  potential_.assign(V, 0.f); predecessors_.assign(V, 0u); cutting_faces_.assign(V, mesh_map::kNoHandle); vector_map_.assign((size_t)V * 3, 0.f);
+  fields_on_host_ = false;
+  vector_map_.assign((size_t)V * 3, 0.f);
   const float seed_pos[3] = { start.x, start.y, start.z };
+  // the host back-tracking below reads the vector map: that one field comes back (12 MB at 1M vertices); potential,
+  // predecessors, directions and cutting faces stay on the device until fetchFields()
   const uint32_t code = mnav_plan_cvp(dev_->ctx(), seed_pos, start_face, goal_face, config_.goal_dist_offset, config_.cost_limit,
-                                      potential_.data(), predecessors_.data(), direction_.data(), cutting_faces_.data(), vector_map_.data());
+                                      nullptr, nullptr, nullptr, nullptr, vector_map_.data());
   if (code == Result::CANCELED) return code;                                  // :888-892
   if (code == Result::INTERNAL_ERROR) { message = mnav_last_error(dev_->ctx()); return code; }
-  // MeshMap::setVectorMap (:238): seeds hold their raw offset vector (:722-724), updated vertices the rotated direction
+  // MeshMap::setVectorMap (:238): seeds hold their raw offset vector (:722-724), updated vertices the rotated direction;
+  // everything else is the all-zero entry the device writes for "no value"
   std::vector<uint8_t> set(V, 0);
-  for (uint32_t v = 0; v < V; ++v) set[v] = (predecessors_[v] != v && cutting_faces_[v] != mesh_map::kNoHandle);
+  for (uint32_t v = 0; v < V; ++v) {
+    const float* q = &vector_map_[3 * (size_t)v];
+    set[v] = !(q[0] == 0.f && q[1] == 0.f && q[2] == 0.f);
+  }
   for (int k = 0; k < 3; ++k) set[mesh_map_->faces[3 * (size_t)start_face + k]] = 1;
   mesh_map_->setVectorMap(vector_map_, set);
+  if (config_.publish_vector_field || eager_fields_) fetchFields();
   if (code == Result::NO_PATH_FOUND) { message = "Predecessor of the goal is not set! No path found!"; return code; }   // :912-918
   // vector field back-tracking :920-951 (sequential, ~path_length / step_width iterations, host)
   uint32_t current_face = goal_face;
@@ -232,10 +275,15 @@ uint32_t CVPMeshPlanner::waveFrontPropagation(const mesh_map::Vector& original_s
   path.push_front(std::make_pair(current_pos, current_face));                 // :924
   size_t guard = 0;
   while (current_pos.distance2(start) > config_.step_width && !cancel_planning_) {   // :927 (squared distance vs width, as is)
-    if (mesh_map_->meshAhead(current_pos, current_face, (float)config_.step_width)) {   // :933
-      path.push_front(std::make_pair(current_pos, current_face));             // :935
-    } else {
-      message = "Could not find a valid path, while back-tracking from the goal";   // :939
+    try {
+      if (mesh_map_->meshAhead(current_pos, current_face, (float)config_.step_width)) {   // :933
+        path.push_front(std::make_pair(current_pos, current_face));           // :935
+      } else {
+        message = "Could not find a valid path, while back-tracking from the goal";   // :939
+        return Result::NO_PATH_FOUND;
+      }
+    } catch (const mesh_map::MeshMap::MapPanic&) {                            // :944-949 lvr2::PanicException
+      message = "Could not find a valid path, while back-tracking from the goal: HalfEdgeMesh panicked!";
       return Result::NO_PATH_FOUND;
     }
     if (++guard > 10u * (size_t)V + 1000u) { message = "vector field back-tracking does not terminate"; return Result::NO_PATH_FOUND; }
@@ -243,5 +291,15 @@ uint32_t CVPMeshPlanner::waveFrontPropagation(const mesh_map::Vector& original_s
   path.push_front(std::make_pair(start, start_face));                         // :951
   if (cancel_planning_) return Result::CANCELED;                              // :962-966
   return Result::SUCCESS;
+}
+
+void CVPMeshPlanner::fetchFields()
+{
+  if (fields_on_host_ || !dev_ || !dev_->ok()) return;
+  const uint32_t V = mesh_map_->V;
+  potential_.assign(V, 0.f); predecessors_.assign(V, 0u); cutting_faces_.assign(V, mesh_map::kNoHandle); direction_.assign(V, 0.f);
+  if (mnav_download_output(dev_->ctx(), 0, 0, potential_.data()) != 0 || mnav_download_output(dev_->ctx(), 0, 1, predecessors_.data()) != 0 ||
+      mnav_download_output(dev_->ctx(), 0, 2, direction_.data()) != 0 || mnav_download_output(dev_->ctx(), 0, 3, cutting_faces_.data()) != 0) return;
+  fields_on_host_ = true;
 }
 }  // namespace cvp_mesh_planner

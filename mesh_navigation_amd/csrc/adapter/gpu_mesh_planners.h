@@ -27,6 +27,7 @@ private:
   mnav_ctx* ctx_ = nullptr;
   const mesh_map::MeshMap* uploaded_ = nullptr;
   uint64_t cost_hash_ = 0;
+  bool have_costs_ = false;
 };
 }  // namespace mnav_adapter
 
@@ -41,8 +42,12 @@ public:
   bool cancel() override;
   bool initialize(const std::string& name, const std::shared_ptr<mesh_map::MeshMap>& mesh_map_ptr,
                   const rclcpp::Node::SharedPtr& node) override;
-  const std::vector<float>& potential() const { return potential_; }
-  const std::vector<uint32_t>& predecessors() const { return predecessors_; }
+  // V-sized results live on the device; reading them fetches them (20 MB over PCIe at 1M vertices)
+  const std::vector<float>& potential() { fetchFields(); return potential_; }
+  const std::vector<uint32_t>& predecessors() { fetchFields(); return predecessors_; }
+  const std::vector<float>& getVectorMap() { fetchFields(); return vector_map_; }   // dijkstra_mesh_planner.h:126
+  void fetchFields();
+  void setEagerFields(bool on) { eager_fields_ = on; }                // download after every plan, like the reference's host maps
 protected:
   // dijkstra_mesh_planner.cpp:211-215 (the 3-arg overload): wave from `start` towards `goal`
   uint32_t dijkstra(const mesh_map::Vector& start, const mesh_map::Vector& goal, std::list<uint32_t>& path);
@@ -54,6 +59,7 @@ private:
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; } config_;   // dijkstra_mesh_planner.h:178-187
   std::vector<uint32_t> predecessors_;
   std::vector<float> vector_map_, potential_;
+  bool fields_on_host_ = false, eager_fields_ = false;
   std::unique_ptr<mnav_adapter::MeshMapDevice> dev_;
 };
 }  // namespace dijkstra_mesh_planner
@@ -69,7 +75,9 @@ public:
   bool cancel() override;
   bool initialize(const std::string& name, const std::shared_ptr<mesh_map::MeshMap>& mesh_map_ptr,
                   const rclcpp::Node::SharedPtr& node) override;
-  const std::vector<float>& potential() const { return potential_; }
+  const std::vector<float>& potential() { fetchFields(); return potential_; }
+  void fetchFields();
+  void setEagerFields(bool on) { eager_fields_ = on; }
 protected:
   // cvp_mesh_planner.cpp:241-247 (the 4-arg overload)
   uint32_t waveFrontPropagation(const mesh_map::Vector& start, const mesh_map::Vector& goal,
@@ -82,6 +90,7 @@ private:
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; double step_width = 0.4; } config_;   // cvp_mesh_planner.h:201-212
   std::vector<float> direction_, vector_map_, potential_;
   std::vector<uint32_t> predecessors_, cutting_faces_;
+  bool fields_on_host_ = false, eager_fields_ = false;
   std::unique_ptr<mnav_adapter::MeshMapDevice> dev_;
 };
 }  // namespace cvp_mesh_planner

@@ -106,12 +106,17 @@ void MeshMap::finalize()
 uint32_t MeshMap::getNearestVertexHandle(const Vector& pos) const
 {
   if (V == 0) return kNoHandle;
-  const int cx = (int)std::floor((pos.x - gx0_) / gcell_), cy = (int)std::floor((pos.y - gy0_) / gcell_);
+  // the reference's kd-tree always returns the nearest vertex, also for queries off the mesh: start at the cell the
+  // query clamps into; a ring r of cells around it lies at least (r-1) cells plus the clamping distance away
+  const int qx = (int)std::floor((pos.x - gx0_) / gcell_), qy = (int)std::floor((pos.y - gy0_) / gcell_);
+  const int cx = std::min((int)gnx_ - 1, std::max(0, qx)), cy = std::min((int)gny_ - 1, std::max(0, qy));
+  const float off_x = (float)std::abs(qx - cx) * gcell_, off_y = (float)std::abs(qy - cy) * gcell_;
+  const float off = std::max(0.0f, std::max(off_x, off_y) - gcell_);
   uint32_t best = kNoHandle; float bd = FLT_MAX;
-  const int rmax = (int)std::max(gnx_, gny_) + 1;
+  const int rmax = (int)std::max(gnx_, gny_) + 1;                    // covers the whole grid from any cell
   for (int r = 0; r <= rmax; ++r) {
     // once a candidate exists, a ring further out than its distance cannot improve it
-    if (best != kNoHandle) { const float ring = (float)(r - 1) * gcell_; if (ring > 0 && ring * ring > bd) break; }
+    if (best != kNoHandle) { const float ring = (float)(r - 1) * gcell_ + off; if (ring > 0 && ring * ring > bd) break; }
     for (int y = cy - r; y <= cy + r; ++y)
       for (int x = cx - r; x <= cx + r; ++x) {
         if (std::max(std::abs(x - cx), std::abs(y - cy)) != r) continue;
@@ -148,8 +153,10 @@ bool MeshMap::searchNeighbourFaces(const Vector& pos, uint32_t face, float max_r
                                    std::array<float, 3>& bary) const
 {
   std::vector<uint32_t> possible{ face };
-  std::vector<uint8_t> in_list(F, 0);
-  in_list[face] = 1;
+  if (seen_.size() != F) { seen_.assign(F, 0u); seen_gen_ = 0; }
+  if (++seen_gen_ == 0u) { std::fill(seen_.begin(), seen_.end(), 0u); seen_gen_ = 1; }   // SparseFaceMap<bool> in_list_map (:1026)
+  const uint32_t gen = seen_gen_;
+  seen_[face] = gen;
   Vector center(0, 0, 0);
   const auto start = facePositions(face);
   for (const auto& v : start) center = center + v;                  // :1010-1013
@@ -167,15 +174,34 @@ bool MeshMap::searchNeighbourFaces(const Vector& pos, uint32_t face, float max_r
       if (center.distance2(this->vertex(vertex)) < max_radius_sq)   // :1044
         for (uint32_t i = vf_ptr_[vertex]; i < vf_ptr_[vertex + 1]; ++i) {   // :1048-1049
           const uint32_t nn = vf_[i];
-          if (!in_list[nn]) { possible.push_back(nn); in_list[nn] = 1; }      // :1051-1055
+          if (seen_[nn] != gen) { possible.push_back(nn); seen_[nn] = gen; }   // :1051-1055
         }
     }
   }
   return false;
 }
 
-// mesh_map.cpp:1070-1108 with directionAtPosition :625-650.  Layer vector fields (:1099-1102) are not
-// part of this stand-in: on a robot the real MeshMap adds them.
+// InflationLayer::vectorAt(handles, barycentric coords), inflation_layer.cpp:493-521.  lvr2 attribute maps panic on
+// a key without a value (AttributeMap::operator[]): distances_ / vector_map_ only hold the vertices the inflation
+// wave reached, so on faces beyond it the reference's back-tracking ends with "HalfEdgeMesh panicked!" (cvp :944).
+Vector MeshMap::layerVectorAt(const LayerVectorField& L, const uint32_t vs[3], const std::array<float, 3>& bary) const
+{
+  if (!L.repulsive_field) return Vector();                           // :496
+  for (int k = 0; k < 3; ++k) if (!L.has_distance[vs[k]]) throw MapPanic();
+  const float distance = L.distances[vs[0]] * bary[0] + L.distances[vs[1]] * bary[1] + L.distances[vs[2]] * bary[2];   // :499
+  if ((double)distance > L.inflation_radius) return Vector();       // :501
+  for (int k = 0; k < 3; ++k) if (!L.has_vector[vs[k]]) throw MapPanic();
+  auto vec = [&](int k) { return Vector(L.vectors[3 * (size_t)vs[k]], L.vectors[3 * (size_t)vs[k] + 1], L.vectors[3 * (size_t)vs[k] + 2]); };
+  const Vector comb = vec(0) * bary[0] + vec(1) * bary[1] + vec(2) * bary[2];
+  if ((double)distance > L.inscribed_radius) {                       // :505
+    const float alpha = (float)(((double)std::sqrt(distance) - L.inscribed_radius) / (L.inflation_radius - L.inscribed_radius) * M_PI);   // :507-508
+    return comb * (float)L.inscribed_value * (std::cos(alpha) + 1) / 2.0f;   // :509-510, three float vector operations
+  }
+  if (distance > 0) return comb * (float)L.inscribed_value;          // :514-517
+  return comb * (float)L.lethal_value;                               // :520
+}
+
+// mesh_map.cpp:1070-1108 with directionAtPosition :625-650 and the layers' vectorAt (:1099-1102).
 bool MeshMap::meshAhead(Vector& pos, uint32_t& face, float step_size) const
 {
   std::array<float, 3> bary; float dist;
@@ -195,6 +221,7 @@ bool MeshMap::meshAhead(Vector& pos, uint32_t& face, float step_size) const
     if (vector_map_set[vs[k]]) vec = vec + Vector(vector_map[3 * (size_t)vs[k]], vector_map[3 * (size_t)vs[k] + 1], vector_map[3 * (size_t)vs[k] + 2]) * bary[k];   // :636-638
   if (!(std::isfinite(vec.x) && std::isfinite(vec.y) && std::isfinite(vec.z))) return false;      // :639
   Vector dir = vec.normalized();                                    // :1096
+  for (const auto& L : layer_fields) dir = dir + layerVectorAt(L, vs, bary);   // :1099-1102 every layer's vectorAt
   dir = dir.normalized();                                           // :1103
   pos = pos + dir * step_size;                                      // :1104
   return true;

@@ -56,6 +56,19 @@ public:
   std::vector<uint8_t> invalid;       // V   (MeshMap::invalid)
   // optional: rows of PMPMesh::getFacesOfVertex (circulator order) as CSR; empty -> derived from `faces`
   std::vector<uint32_t> face_circulation_ptr, face_circulation;
+  // Change counter of vertex_costs / edge_weights / invalid.  The real MeshMap has none; the
+  // integration bumps it from MeshMap::layerChanged / computeEdgeWeights.  0 = unknown: the device
+  // mirror then falls back to hashing the arrays (8-byte words) on every plan.
+  uint64_t cost_version = 0;
+  // Repulsive vector fields of layers (AbstractLayer::vectorAt, mesh_map.cpp:1099-1102): the Inflation layer's
+  // distance + vector maps with their has-value flags and the parameters vectorAt reads (inflation_layer.cpp:493-521)
+  struct LayerVectorField {
+    std::vector<float> distances; std::vector<uint8_t> has_distance;    // V   (distances_)
+    std::vector<float> vectors; std::vector<uint8_t> has_vector;        // V*3 (vector_map_)
+    double inscribed_radius = 0.25, inflation_radius = 0.4, lethal_value = 1.0, inscribed_value = 0.99;
+    bool repulsive_field = true;
+  };
+  std::vector<LayerVectorField> layer_fields;
   std::string map_frame = "map";
   // vector map set by the planners for the controller (MeshMap::setVectorMap, mesh_map.cpp:620-623)
   std::vector<float> vector_map;      // V*3
@@ -72,13 +85,18 @@ public:
 
   uint32_t getNearestVertexHandle(const Vector& pos) const;                         // :1161-1174
   uint32_t getContainingFace(const Vector& position, float max_dist) const;         // :1110-1159
+  // throws MapPanic where the reference's attribute-map lookup would panic (a layer without a value for a vertex)
   bool meshAhead(Vector& pos, uint32_t& face, float step_size) const;               // :1070-1108
+  struct MapPanic { };                                                              // lvr2::PanicException stand-in
   void setVectorMap(const std::vector<float>& vm, const std::vector<uint8_t>& set) { vector_map = vm; vector_map_set = set; }
 
 private:
   bool searchNeighbourFaces(const Vector& pos, uint32_t face, float max_radius, float max_dist, uint32_t& found,
                             std::array<float, 3>& bary) const;                      // :999-1068
+  Vector layerVectorAt(const LayerVectorField& L, const uint32_t vs[3], const std::array<float, 3>& bary) const;
   std::vector<uint32_t> vf_ptr_, vf_;   // vertex -> faces, half-edge circulator order (getFacesOfVertex)
+  mutable std::vector<uint32_t> seen_;  // searchNeighbourFaces: per-face stamp of the current search (no O(F) clear per step)
+  mutable uint32_t seen_gen_ = 0;
   // uniform grid over xy for the 1-NN query (stands in for the nanoflann kd-tree, :307-309)
   float gx0_ = 0, gy0_ = 0, gcell_ = 1;
   uint32_t gnx_ = 1, gny_ = 1;

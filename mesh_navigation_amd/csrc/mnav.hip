@@ -1793,6 +1793,7 @@ struct mnav_ctx {
   uint32_t V = 0, F = 0, E = 0;
   std::vector<float> h_xyz, h_cost;
   bool want_vec = false;               // the running call asked for vector maps (lazy 12 B/vertex/plan)
+  bool resident_vecmap = false;        // mnav_set_resident_outputs: always compute the vector map, leave it on the device
   std::vector<uint32_t> caller_slot;   // plan index of the caller's batch -> device slot of the last call (kNone: never ran)
   std::vector<uint32_t> h_faces;
   std::vector<uint8_t> h_invalid;
@@ -2929,6 +2930,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   ctx->err.clear();
   ctx->cancel.store(0);                                               // dijkstra :238
   if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
+  want_vecmap = want_vecmap || ctx->resident_vecmap;
   ctx->want_vec = want_vecmap;
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
   MTRACE("start");
@@ -3436,6 +3438,53 @@ const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
     case 4: return s.vecmap;
     default: return nullptr;
   }
+}
+
+int mnav_set_resident_outputs(mnav_ctx* ctx, int on)
+{
+  if (!ctx) return -1;
+  ctx->resident_vecmap = on != 0;
+  return 0;
+}
+
+int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out)
+{
+  if (!ctx || !host_out) return -1;
+  const void* src = mnav_device_output(ctx, slot, what);
+  if (!src) { ctx->err = "output not resident"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  const size_t bytes = (what == 4 ? 12 : 4) * (size_t)ctx->V;
+  HIPCHK(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// MeshMap::directionAtPosition (mesh_map.cpp:625-650) on the resident vector map of plan `slot`: what the controller
+// samples at the robot pose.  36 bytes cross PCIe instead of the 12 MB field.  A vertex counts as "has a vector" when
+// its entry is not the all-zero vector the vector-map kernels write for vertices the wave did not set.
+int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const float bary[3], float out[3])
+{
+  if (!ctx || !vs || !bary || !out) return -1;
+  const float* vm = static_cast<const float*>(mnav_device_output(ctx, slot, 4));
+  if (!vm) { ctx->err = "vector map not resident"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  float v[3][3];
+  for (int k = 0; k < 3; ++k) {
+    if (vs[k] >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+    HIPCHK(hipMemcpyAsync(v[k], vm + 3 * (size_t)vs[k], 12, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float acc[3] = { 0.f, 0.f, 0.f };
+  bool any = false;
+  for (int k = 0; k < 3; ++k) {
+    const bool has = !(v[k][0] == 0.f && v[k][1] == 0.f && v[k][2] == 0.f);
+    if (!has) continue;
+    any = true;
+    for (int c = 0; c < 3; ++c) acc[c] += v[k][c] * bary[k];       // :636-638
+  }
+  if (!any || !(std::isfinite(acc[0]) && std::isfinite(acc[1]) && std::isfinite(acc[2]))) return 0;   // :639-646
+  out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+  return 1;
 }
 
 uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx) { return ctx ? ctx->algo_bytes : 0; }

@@ -33,6 +33,10 @@ def _load():
         L.mnav_adapter_cancel.restype = C.c_int
         L.mnav_adapter_cancel.argtypes = [vp]
         L.mnav_adapter_set_costs.argtypes = [vp, vp, vp]
+        L.mnav_adapter_set_cost_version.argtypes = [vp, C.c_uint64]
+        L.mnav_adapter_fetch.restype = C.c_int
+        L.mnav_adapter_fetch.argtypes = [vp, C.c_int, vp]
+        L.mnav_adapter_add_layer_field.argtypes = [vp, vp, vp, vp, vp, f64, f64, f64, f64, C.c_int]
         _lib = L
     return _lib
 
@@ -92,6 +96,27 @@ class _MeshPlanner:
         vc = np.ascontiguousarray(vertex_costs, np.float32)
         ew = np.ascontiguousarray(edge_weights, np.float32)
         _load().mnav_adapter_set_costs(self._h, _p(vc), _p(ew))
+
+    def set_cost_version(self, version: int):
+        """Change counter of the map's cost arrays (what MeshMap::layerChanged would bump); 0 = unknown -> hashing."""
+        _load().mnav_adapter_set_cost_version(self._h, int(version))
+
+    def fetch(self, what: str) -> np.ndarray:
+        """V-sized results of the last plan, downloaded on demand: 'potential', 'predecessors', 'vector_map'."""
+        code = {"potential": 0, "predecessors": 1, "vector_map": 4}[what]
+        V = self._keep["xyz"].shape[0]
+        out = np.empty((V, 3) if code == 4 else V, np.uint32 if code == 1 else np.float32)
+        if _load().mnav_adapter_fetch(self._h, code, _p(out)) != 0:
+            raise RuntimeError(f"cannot fetch {what}")
+        return out
+
+    def add_layer_field(self, distances, has_distance, vectors, has_vector, inscribed_radius=0.25, inflation_radius=0.4,
+                        lethal_value=1.0, inscribed_value=0.99, repulsive_field=True):
+        """A layer's repulsive vector field for the CVP back-tracking (InflationLayer distances_ / vector_map_)."""
+        a = [np.ascontiguousarray(distances, np.float32), np.ascontiguousarray(has_distance, np.uint8),
+             np.ascontiguousarray(vectors, np.float32), np.ascontiguousarray(has_vector, np.uint8)]
+        _load().mnav_adapter_add_layer_field(self._h, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), float(inscribed_radius),
+                                             float(inflation_radius), float(lethal_value), float(inscribed_value), int(repulsive_field))
 
     def close(self):
         if self._h:

@@ -161,6 +161,7 @@ class RefMap:
 
     layers: "array"  -> one harness-served layer `costs` (default layer), vertex_costs given by the caller
             "c3"     -> steepness + inflation(steepness) + avg|max combination, all the reference's own layers
+            "array+inflation" -> harness-served costs/lethals + the reference's InflationLayer on them (default layer)
     """
 
     def __init__(self, xyz, faces, *, layers="array", vertex_costs=None, lethal=None, edge_cost_factor=0.0,
@@ -187,6 +188,17 @@ class RefMap:
             L.ref_param_string_array(self._h, ns + b"layers", b"costs")
             L.ref_param_string(self._h, ns + b"costs.type", b"ref_harness/ArrayLayer")
             L.ref_param_string(self._h, ns + b"default_layer", b"costs")
+        elif layers == "array+inflation":
+            # a harness-served layer with lethal flags feeding the reference's InflationLayer (the default layer)
+            vc = np.zeros(self.V, np.float32) if vertex_costs is None else _f32(vertex_costs)
+            L.ref_set_array_layer(self._h, b"costs", self.V, _p(vc), None if lethal is None else _p(_u8(lethal)))
+            L.ref_param_string_array(self._h, ns + b"layers", b"costs,inflation")
+            L.ref_param_string(self._h, ns + b"costs.type", b"ref_harness/ArrayLayer")
+            L.ref_param_string(self._h, ns + b"inflation.type", b"mesh_layers/InflationLayer")
+            L.ref_param_string_array(self._h, ns + b"inflation.inputs", b"costs")
+            L.ref_param_string(self._h, ns + b"default_layer", b"inflation")
+            for k, v in (inflation or {}).items():
+                L.ref_param_double(self._h, ns + b"inflation." + k.encode(), float(v))
         elif layers == "c3":
             L.ref_param_string_array(self._h, ns + b"layers", b"steepness,inflation,combined")
             L.ref_param_string(self._h, ns + b"steepness.type", b"mesh_layers/SteepnessLayer")

@@ -50,35 +50,59 @@ def test_cvp_make_plan_matches_reference_restatement(case):
     m = case.mesh
     robot = m.xyz[m.vertex_at(0.85, 0.8)] + np.array([0.031, 0.017, 0.0], np.float32)
     goal = m.xyz[m.vertex_at(0.12, 0.2)] + np.array([0.023, 0.011, 0.0], np.float32)
-    pl = CVPMeshPlanner()
-    # step_width 0.25: with the default 0.4 (four edge lengths on this terrain) the reference's own
-    # meshAhead/searchNeighbourFaces loses the surface after three steps -- checked below as well
-    assert pl.initialize("cvp_mesh_planner", mesh_map_of(case), dict(step_width=0.25))
     gpose = pose(goal)
     gpose[3:] = [0, 0, np.sin(0.3), np.cos(0.3)]
-    code, plan, cost, msg = pl.makePlan(pose(robot), gpose)
     sf, _ = case.om.containing_face(goal)
     tf, _ = case.om.containing_face(robot)
     ref = case.om.cvp(case.weights, case.costs, case.vn, goal, sf, tf)
-    rcode, ppos, pface = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, sf, robot, tf, step_width=0.25)
-    poses, rcost = case.om.cvp_poses(case.fn, ppos, pface, gpose)
-    assert code == ref.code == rcode == 0, msg
-    assert len(plan) == len(poses)
-    assert np.abs(plan[:, :3] - poses[:, :3]).max() < 2e-3          # back-tracking on a field within 1e-5 of the oracle's
-    assert np.allclose(plan[-1], gpose)                              # goal pose verbatim (cvp :119-123)
-    assert cost == pytest.approx(rcost, rel=1e-3)
+    for step in (0.4, 0.25):                                          # 0.4 = the reference default (cvp_mesh_planner.h:211)
+        pl = CVPMeshPlanner()
+        assert pl.initialize("cvp_mesh_planner", mesh_map_of(case), dict(step_width=step))
+        code, plan, cost, msg = pl.makePlan(pose(robot), gpose)
+        rcode, ppos, pface = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, sf, robot, tf, step_width=step)
+        poses, rcost = case.om.cvp_poses(case.fn, ppos, pface, gpose)
+        assert code == ref.code == rcode == 0, msg
+        assert len(plan) == len(poses)
+        # the device potential / predecessors / directions are the oracle's bits; the vector map differs by the
+        # device's cosf/sinf (<= 2e-7), which the back-tracking carries along the path
+        assert np.abs(plan[:, :3] - poses[:, :3]).max() < 2e-3
+        assert np.allclose(plan[-1], gpose)                          # goal pose verbatim (cvp :119-123)
+        assert cost == pytest.approx(rcost, rel=1e-3)
+        pot = pl.fetch("potential")                                  # stays on the device until asked for
+        assert np.array_equal(pot.view(np.uint32), ref.dist.view(np.uint32))
+        pl.close()
+
+
+def test_make_plan_against_the_reference_itself(case):
+    """Both planners end to end against the REFERENCE's own makePlan (oracle/_ref: the reference's planner and
+    mesh_map sources compiled unmodified): same return code, same number of poses, positions of the Dijkstra plan bit
+    for bit, CVP positions within the back-tracking tolerance above."""
+    from oracle import ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built")
+    m = case.mesh
+    rm = R.RefMap(m.xyz, m.faces)
+    robot = m.xyz[m.vertex_at(0.85, 0.8)] + np.array([0.031, 0.017, 0.0], np.float32)
+    goal = m.xyz[m.vertex_at(0.12, 0.2)] + np.array([0.023, 0.011, 0.0], np.float32)
+    gpose = pose(goal)
+    gpose[3:] = [0, 0, np.sin(0.3), np.cos(0.3)]
+    rcode, rposes, rcost = rm.dijkstra_make_plan(pose(robot), gpose)
+    pl = DijkstraMeshPlanner()
+    assert pl.initialize("dijkstra_mesh_planner", mesh_map_of(case))
+    code, plan, cost, _ = pl.makePlan(pose(robot), gpose)
+    assert code == rcode == 0 and plan.shape == rposes.shape
+    assert np.array_equal(plan[:, :3], rposes[:, :3]) and np.abs(plan[:, 3:] - rposes[:, 3:]).max() < 1e-6
+    assert cost == pytest.approx(rcost, rel=1e-12)
+    assert np.array_equal(pl.fetch("potential").view(np.uint32), rm.dijkstra(goal, robot).dist.view(np.uint32))
     pl.close()
-    # default step width: same failure mode and message as the reference restatement (cvp :937-942)
-    pl2 = CVPMeshPlanner()
-    assert pl2.initialize("cvp_mesh_planner", mesh_map_of(case))
-    code2, plan2, _, msg2 = pl2.makePlan(pose(robot), gpose)
-    rcode2, ppos2, pface2 = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, sf, robot, tf, step_width=0.4)
-    assert code2 == rcode2
-    if code2 == 54:
-        # like the reference, makePlan still turns the partial path into poses (cvp :101-124)
-        poses2, _ = case.om.cvp_poses(case.fn, ppos2, pface2, gpose)
-        assert "back-tracking" in msg2 and len(plan2) == len(poses2)
-    pl2.close()
+    rcode, rposes, rcost, rmsg = rm.cvp_make_plan(pose(robot), gpose)        # step_width 0.4: the reference default
+    pc = CVPMeshPlanner()
+    assert pc.initialize("cvp_mesh_planner", mesh_map_of(case))
+    code, plan, cost, msg = pc.makePlan(pose(robot), gpose)
+    assert code == rcode == 0, (msg, rmsg)
+    assert len(plan) == len(rposes) and np.abs(plan[:, :3] - rposes[:, :3]).max() < 2e-3
+    assert np.allclose(plan[-1], rposes[-1]) and cost == pytest.approx(rcost, rel=1e-3)
+    pc.close()
 
 
 def test_adapter_picks_up_cost_changes_and_cancel(case):
@@ -95,6 +119,12 @@ def test_adapter_picks_up_cost_changes_and_cancel(case):
     code2, plan2, _, _ = pl.makePlan(pose(robot), pose(goal))
     assert code2 == 54 and len(plan2) == 0                           # NO_PATH_FOUND (dijkstra :358-362)
     pl.set_costs(case.costs, case.weights)
+    # with a change counter on the map (what the integration maintains) nothing is hashed: same behaviour
+    pl.set_cost_version(7)
+    assert pl.makePlan(pose(robot), pose(goal))[0] == 0
+    pl.set_costs(costs, case.weights); pl.set_cost_version(8)
+    assert pl.makePlan(pose(robot), pose(goal))[0] == 54
+    pl.set_costs(case.costs, case.weights); pl.set_cost_version(9)
     assert pl.cancel()                                               # a stale cancel is cleared at the next plan (:238)
     code3, plan3, cost3, _ = pl.makePlan(pose(robot), pose(goal))
     # (the last orientation is NaN here: the goal sits exactly on a vertex, zero direction, as in the reference)
