@@ -55,13 +55,18 @@ def test_cvp_make_plan_matches_reference_restatement(case):
     sf, _ = case.om.containing_face(goal)
     tf, _ = case.om.containing_face(robot)
     ref = case.om.cvp(case.weights, case.costs, case.vn, goal, sf, tf)
-    for step in (0.4, 0.25):                                          # 0.4 = the reference default (cvp_mesh_planner.h:211)
+    for step in (0.4, 0.3, 0.25):                                     # 0.4 = the reference default (cvp_mesh_planner.h:211)
         pl = CVPMeshPlanner()
         assert pl.initialize("cvp_mesh_planner", mesh_map_of(case), dict(step_width=step))
         code, plan, cost, msg = pl.makePlan(pose(robot), gpose)
         rcode, ppos, pface = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, sf, robot, tf, step_width=step)
         poses, rcost = case.om.cvp_poses(case.fn, ppos, pface, gpose)
-        assert code == ref.code == rcode == 0, msg
+        assert ref.code == 0 and code == rcode, msg
+        if step == 0.4:
+            # on THIS 0.1 m terrain the reference's own meshAhead loses the surface at its default step width
+            # (oracle/_ref returns the same NO_PATH_FOUND): the adapter reproduces that outcome, message included
+            # (and the partial path is still converted to poses, cvp_mesh_planner.cpp:84-118)
+            assert code == 54 and "back-tracking" in msg
         assert len(plan) == len(poses)
         # the device potential / predecessors / directions are the oracle's bits; the vector map differs by the
         # device's cosf/sinf (<= 2e-7), which the back-tracking carries along the path
@@ -95,9 +100,9 @@ def test_make_plan_against_the_reference_itself(case):
     assert cost == pytest.approx(rcost, rel=1e-12)
     assert np.array_equal(pl.fetch("potential").view(np.uint32), rm.dijkstra(goal, robot).dist.view(np.uint32))
     pl.close()
-    rcode, rposes, rcost, rmsg = rm.cvp_make_plan(pose(robot), gpose)        # step_width 0.4: the reference default
+    rcode, rposes, rcost, rmsg = rm.cvp_make_plan(pose(robot), gpose, step_width=0.3)
     pc = CVPMeshPlanner()
-    assert pc.initialize("cvp_mesh_planner", mesh_map_of(case))
+    assert pc.initialize("cvp_mesh_planner", mesh_map_of(case), dict(step_width=0.3))
     code, plan, cost, msg = pc.makePlan(pose(robot), gpose)
     assert code == rcode == 0, (msg, rmsg)
     assert len(plan) == len(rposes) and np.abs(plan[:, :3] - rposes[:, :3]).max() < 2e-3
