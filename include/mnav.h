@@ -158,6 +158,37 @@ int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, con
 /* Copies of the resident vertex costs (V) and edge weights (E); either pointer may be NULL. */
 int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weights_out);
 
+/* -- cost layers on the device (mesh_layers) ------------------------------------------------------
+ * The reference's layer plugins compute per-vertex costs on the CPU (AbstractLayer::computeLayer) and MeshMap
+ * combines them.  These entry points keep that stack in HBM: layer `k` (0..63) is a resident cost array + lethal set.
+ *   mnav_layer_upload      a layer computed elsewhere (ObstacleLayer, a costs file ...): costs V floats, lethal V bytes
+ *                          or NULL
+ *   mnav_layer_steepness   SteepnessLayer::computeLayer (steepness_layer.cpp:157-166) from the resident vertex normals:
+ *                          cost = acos(n.z) in float, lethal when > threshold (:82-93)
+ *   mnav_layer_inflation   InflationLayer::computeLayer (inflation_layer.cpp:96-178): the lethal set of `input_layer`
+ *                          is the source of waveCostInflation (:341-491), a multi-source ordered fast-marching wave over
+ *                          the edge distances, run here on the same ordered-wave engine as the CVP planner (replay of the
+ *                          face updates in the reference's pop order, float32 Sethian update :181-234, re-queue rule
+ *                          :311, invalid vertices never fixed :417); then riskiness = fading(distance) (:315-339).
+ *                          `invalid` = the map's non-manifold flags (V bytes) or NULL.  Distances are bit-identical to
+ *                          the reference's; a converged state that fails the verification sweep returns <0 instead of a
+ *                          result.  Not computed here: the layer's repulsive vector field (vector_map_, :277-309).
+ *   mnav_layer_download    copies of a layer's costs / lethal flags / wave distances (NULL to skip; distances only for an
+ *                          inflation layer, +inf where the wave never arrived)
+ *   mnav_combine_layers    CombinationLayer (mode 0 = max :44-85, 1 = weighted sum :185-248) over resident layers, then
+ *                          MeshMap::computeEdgeWeights (mesh_map.cpp:495-561): the resident vertex costs and edge weights
+ *                          the planners read are replaced; edge distances are computed on the device if none are resident
+ * All return 0 / <0 (mnav_last_error). */
+int mnav_layer_upload(mnav_ctx* ctx, uint32_t layer, const float* costs, const uint8_t* lethal);
+int mnav_layer_steepness(mnav_ctx* ctx, uint32_t layer, double threshold);
+int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, double inflation_radius, double inscribed_radius,
+                         double inscribed_value, double lethal_value, double cost_scaling_factor, const uint8_t* invalid);
+int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t* lethal_out, float* distances_out);
+int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights,
+                        double edge_cost_factor, const uint8_t* invalid);
+/* Counters of the last inflation wave: band steps, bands, vertex evaluations, device milliseconds. */
+int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms);
+
 /* -- one plan over several GPUs (BASELINE config 4) ---------------------------------------------
  * The reference's loop (dijkstra_mesh_planner.cpp:287-348) on a mesh that is range-partitioned over `world`
  * processes, one per GPU: the LDS tiles are in Morton order and process `rank` owns a contiguous range of them.

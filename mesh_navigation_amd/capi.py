@@ -23,7 +23,8 @@ SYMBOLS = [
     "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
-    "mnav_vector_at",
+    "mnav_vector_at", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
+    "mnav_combine_layers", "mnav_layer_stats",
 ]
 
 
@@ -94,6 +95,18 @@ def load(path: str | None = None):
     L.mnav_update_costs.argtypes = [vp, u32, vp, vp]
     L.mnav_download_costs.restype = C.c_int
     L.mnav_download_costs.argtypes = [vp, vp, vp]
+    L.mnav_layer_upload.restype = C.c_int
+    L.mnav_layer_upload.argtypes = [vp, u32, vp, vp]
+    L.mnav_layer_steepness.restype = C.c_int
+    L.mnav_layer_steepness.argtypes = [vp, u32, f64]
+    L.mnav_layer_inflation.restype = C.c_int
+    L.mnav_layer_inflation.argtypes = [vp, u32, u32, f64, f64, f64, f64, f64, vp]
+    L.mnav_layer_download.restype = C.c_int
+    L.mnav_layer_download.argtypes = [vp, u32, vp, vp, vp]
+    L.mnav_combine_layers.restype = C.c_int
+    L.mnav_combine_layers.argtypes = [vp, C.c_int, u32, vp, vp, f64, vp]
+    L.mnav_layer_stats.restype = C.c_int
+    L.mnav_layer_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.mnav_shard_setup.restype = C.c_int
     L.mnav_shard_setup.argtypes = [vp, u32, u32]
     L.mnav_shard_info.restype = C.c_int
@@ -260,6 +273,46 @@ class MnavContext:
         if self._L.mnav_download_costs(self._h, _p(vc), _p(w)) != 0:
             raise RuntimeError(f"mnav_download_costs failed: {self._err()}")
         return vc, w
+
+    # ---- cost layers on the device (mesh_layers: Steepness, Inflation, Combination) ----
+    def layer_upload(self, layer: int, costs, lethal=None):
+        c = np.ascontiguousarray(costs, np.float32)
+        le = None if lethal is None else np.ascontiguousarray(lethal, np.uint8)
+        if self._L.mnav_layer_upload(self._h, int(layer), _p(c), None if le is None else _p(le)) != 0:
+            raise RuntimeError(f"mnav_layer_upload failed: {self._err()}")
+
+    def layer_steepness(self, layer: int, threshold: float = 0.3):
+        if self._L.mnav_layer_steepness(self._h, int(layer), float(threshold)) != 0:
+            raise RuntimeError(f"mnav_layer_steepness failed: {self._err()}")
+
+    def layer_inflation(self, layer: int, input_layer: int, inflation_radius=0.4, inscribed_radius=0.25, inscribed_value=0.99,
+                        lethal_value=1.0, cost_scaling_factor=1.0, invalid=None) -> dict:
+        """InflationLayer defaults: inflation_layer.cpp:676-712.  Returns the wave's counters."""
+        inv = None if invalid is None else np.ascontiguousarray(invalid, np.uint8)
+        rc = self._L.mnav_layer_inflation(self._h, int(layer), int(input_layer), float(inflation_radius), float(inscribed_radius),
+                                          float(inscribed_value), float(lethal_value), float(cost_scaling_factor),
+                                          None if inv is None else _p(inv))
+        if rc != 0:
+            raise RuntimeError(f"mnav_layer_inflation failed: {self._err()}")
+        a, b, e, ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_float()
+        self._L.mnav_layer_stats(self._h, C.byref(a), C.byref(b), C.byref(e), C.byref(ms))
+        return dict(steps=a.value, bands=b.value, evals=e.value, ms=ms.value)
+
+    def layer_download(self, layer: int, distances: bool = False):
+        c = np.empty(self.V, np.float32)
+        le = np.empty(self.V, np.uint8)
+        d = np.empty(self.V, np.float32) if distances else None
+        if self._L.mnav_layer_download(self._h, int(layer), _p(c), _p(le), None if d is None else _p(d)) != 0:
+            raise RuntimeError(f"mnav_layer_download failed: {self._err()}")
+        return (c, le, d) if distances else (c, le)
+
+    def combine_layers(self, layers, weights=None, mode: str = "avg", edge_cost_factor: float = 1.0, invalid=None):
+        ls = np.ascontiguousarray(layers, np.uint32)
+        w = np.ascontiguousarray(weights if weights is not None else [1.0] * len(ls), np.float32)
+        inv = None if invalid is None else np.ascontiguousarray(invalid, np.uint8)
+        if self._L.mnav_combine_layers(self._h, 0 if mode == "max" else 1, len(ls), _p(ls), _p(w), float(edge_cost_factor),
+                                       None if inv is None else _p(inv)) != 0:
+            raise RuntimeError(f"mnav_combine_layers failed: {self._err()}")
 
     # ---- one plan over several GPUs (mesh_navigation_amd/sharded.py drives these) ----
     def shard_setup(self, rank: int, world: int) -> int:

@@ -144,6 +144,8 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
 {
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
   if (end - beg > 2 * kGroup) return eval_cvp(P, c, v);           // rare high-valence vertex: serial rule
+  const bool infl = P.seed_mask != nullptr;
+  const bool mute = infl && P.seed_mask[v] == kInflMute;
   CornerItem it[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -156,17 +158,23 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
       const Fire f = corner_fire(P, c, k);
       if (f.trig != kNone && !key_descends_from(P, f.trig, v)) {       // (spec: eval_cvp)
         it[r].valid = true; it[r].fk = f.key; it[r].trig = f.trig;
+        if (infl) {                                                    // inflation wave: float32 rule (spec: eval_cvp)
+          const InflCand u = infl_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c, P.infl_max);
+          it[r].k.u3tmp = (double)u.u3tmp; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = u.requeue ? 1 : 0; it[r].k.kind = u.ok ? 3 : 0;
+        } else
         it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
         it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = corner_face(k); it[r].first = corner_first_for(k, f.trig);
       }
     }
   }
   const int gbase = (threadIdx.x & (kWave - 1)) & ~(kGroup - 1);
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
   constexpr unsigned long long kNoKey = ~0ull;
   KeyRef last = key_ref_of(key_inf(), inf_f(), 0);
-  bool first = true;
-  for (;;) {
+  bool first = true, queued = false;
+  const uint32_t max_pass = 2u * (end - beg) + 2u;                  // (spec: eval_cvp)
+  for (uint32_t pass_no = 0;; ++pass_no) {
+    if (pass_no == max_pass) { raise_flag(P, kFlagWalkLimit); break; }
     // next trigger pop strictly after the last one: smallest `hi` first, the tree decides among equals
     bool el[2];
     unsigned long long mh = kNoKey;
@@ -191,8 +199,9 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
         if (m_trig == kNone || key_less(P, cand, m)) { m = cand; m_trig = ct; }
       }
     }
-    if (e.d < inf_f() && !key_less(P, m, key_ref_of(e.key, e.d, v))) break;   // v pops before this trigger
+    if (queued && !key_less(P, m, key_ref_of(e.key, e.keyd, v))) break;   // v pops before this trigger
     bool any = false;
+    float ins_d = 0.0f;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {                               // trigger's circulator order: flagged face first
       const int r = pr & 1;
@@ -205,17 +214,20 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
         k.u3tmp = gshfl(it[r].k.u3tmp, src); k.cand = gshfl(it[r].k.cand, src); k.dir = gshfl(it[r].k.dir, src);
         k.sel = gshfl(it[r].k.sel, src); k.kind = gshfl(it[r].k.kind, src);
         int sel = 0; float dir = 0.0f;
-        if (cvp_apply(k, e.d, sel, dir)) {
+        if (k.kind == 3) {                                           // inflation :252,:298-311
+          const float u3tmp = (float)k.u3tmp;
+          if (e.d != 0.0f && u3tmp < e.d) { e.d = u3tmp; if (k.sel) { any = true; ins_d = e.d; } }
+        } else if (k.kind != 0 && cvp_apply(k, e.d, sel, dir)) {
           const uint32_t v1 = gshfl(it[r].v1, src), v2 = gshfl(it[r].v2, src);
           e.pred = (sel == 1) ? v1 : v2; e.dir = dir; e.cut = gshfl(it[r].face, src);
-          any = true;
+          any = true; ins_d = e.d;
         }
       }
     }
-    if (any) e.key = key_for(P, e.d, v, m);                        // ordinary pop, or a place inside this trigger's cascade
+    if (any && !mute) { e.key = key_for(P, ins_d, v, m); e.keyd = ins_d; queued = true; }   // ordinary pop, or a place inside this trigger's cascade
     last = m; first = false;
   }
-  if (!(e.d < inf_f())) { e.pred = v; e.key = key_inf(); }
+  if (!queued) { e.pred = v; e.key = key_inf(); e.keyd = inf_f(); }
   e.t = key_time(e.key);
   return e;
 }
@@ -284,10 +296,11 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
         if (sub == 0) ++S.levals;
         const Eval e = group_eval<PLANNER>(P, c, v, sub);
         bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != P.pred[v]);
-        if (cvp) changed = changed || (e.key != old_key) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
+        if (cvp) changed = changed || (e.key != old_key) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v])) ||
+                           (P.keyd && f2u(e.keyd) != f2u(P.keyd[v]));
         if ((changed || REPAIR) && sub == 0) {
           P.dist[v] = e.d; P.pred[v] = e.pred;
-          if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+          if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; if (P.keyd) P.keyd[v] = e.keyd; }
         }
         t_new = e.t;
         if (REPAIR && cvp && sub == 0 && (f2u(e.d) != f2u(old_d) || e.key != old_key)) S.lchanged = true;   // sweep again
@@ -395,7 +408,7 @@ __global__ void k_flags_reset(const Plan* __restrict__ plans)
   if (threadIdx.x == 0) { Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; plans[blockIdx.x].cnt[3] = z; }
 }
 
-__global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans)
+__global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans, int fix, uint32_t* __restrict__ any_bad)
 {
   const Plan& P = plans[blockIdx.y];
   const int lane = threadIdx.x;
@@ -411,14 +424,10 @@ __global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ p
     const bool act = v < P.V && !is_seed(P, v < P.V ? v : 0u) && !P.blocked[v < P.V ? v : 0u];
     if (!act) continue;                                               // whole 8-lane groups skip together
     const Eval e = group_eval_cvp(P, cur, v, sub);
-    if (sub == 0) {
-      const bool same = f2u(e.d) == f2u(P.dist[v]) && e.key == P.tkey[v] && e.pred == P.pred[v] &&
-                        (!(e.d < inf_f()) || (e.cut == P.cutf[v] && f2u(e.dir) == f2u(P.dirn[v])));
-      if (!same) ++bad;
-    }
+    if (sub == 0 && !verify_entry(P, cur, v, e, fix != 0)) ++bad;     // spec: mnav_eval.h (with fix: stores the re-evaluated state)
   }
   bad = wave_sum(bad);
-  if (lane == 0 && bad) atomicAdd(&P.cnt[3].changed, bad);
+  if (lane == 0 && bad) { atomicAdd(&P.cnt[3].changed, bad); atomicOr(any_bad, 1u); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1488,7 +1497,7 @@ __global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
     P.dist[v] = inf_f();
     P.pred[v] = v;
     if (P.stamp) { P.stamp[v] = 0u; P.dirty[v] = 0u; }              // work-list state of the band steps only
-    if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; }
+    if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
   }
 }
 
@@ -1758,6 +1767,132 @@ __global__ __launch_bounds__(kBlock) void k_build_crn(uint32_t V, const uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// Layers on the device (mesh_layers): Steepness (steepness_layer.cpp:157-166, :82-93), Inflation
+// (inflation_layer.cpp:341-491 as a multi-source wave on the band engine; spec: mnav_eval.h eval_cvp / Plan.seed_mask)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_edge_dist(uint32_t E, const uint32_t* __restrict__ edge_vtx, const float* __restrict__ xyz,
+                                                      float* __restrict__ out)
+{
+  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= E) return;
+  const float* a = xyz + 3 * (size_t)edge_vtx[2 * (size_t)e];
+  const float* b = xyz + 3 * (size_t)edge_vtx[2 * (size_t)e + 1];
+  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  out[e] = sqrtf(dx * dx + dy * dy + dz * dz);                     // lvr2 BaseVector::distanceFrom in float (mesh_map.cpp:347)
+}
+
+__global__ __launch_bounds__(kBlock) void k_steepness(uint32_t V, const float* __restrict__ nrm, double threshold,
+                                                      float* __restrict__ cost, uint8_t* __restrict__ lethal)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const float st = acosf(nrm[3 * (size_t)v + 2]);                  // :165 (float overload of acos)
+  cost[v] = st;
+  lethal[v] = ((double)st > threshold) ? 1 : 0;                    // :88
+}
+
+// corners with the edge DISTANCES as side lengths (waveCostInflation reads map->edgeDistances() :383); no face is
+// skipped here: what may fire is decided by Plan.seed_mask
+__global__ __launch_bounds__(kBlock) void k_build_crn_infl(uint32_t V, const uint32_t* __restrict__ crn_ptr,
+                                                           const CornerIdx* __restrict__ idx, const float* __restrict__ w,
+                                                           Corner* __restrict__ out)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  for (uint32_t i = crn_ptr[v]; i < crn_ptr[v + 1]; ++i) {
+    const CornerIdx k = idx[i];
+    Corner c;
+    c.v1 = k.v1; c.v2 = k.v2; c.a = w[k.ea]; c.b = w[k.eb]; c.c = w[k.ec]; c.face = corner_face_for_inflation(k.face);
+    out[i] = c;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_infl_mask(uint32_t V, const uint8_t* __restrict__ lethal, const uint8_t* __restrict__ invalid,
+                                                      uint8_t* __restrict__ mask)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const bool l = lethal[v] != 0, inv = invalid && invalid[v] != 0;
+  mask[v] = l ? (inv ? kInflSeedMute : kInflSeed) : (inv ? kInflMute : kInflFree);
+}
+
+// control blocks of the wave (the single-thread part of k_seed), then the seeds in parallel: every lethal vertex is
+// fixed at distance 0 (:397-402) and the free vertices around it form the first work list
+__global__ void k_infl_ctl(const Plan* __restrict__ plans)
+{
+  const Plan& P = plans[0];
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Ctl c0; memset(&c0, 0, sizeof(c0));
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.thr = P.delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
+  c0.band_new = 1; c0.width = P.delta;
+  P.ctl[1] = c0;
+  P.ctl[0] = c0;
+  Cnt ci; ci.n_next = 0; ci.changed = 1; ci.minkey = 0x7f800000u; ci.evals = 0;
+  P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"; k_infl_seed counts the list into it
+  Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
+  P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;
+}
+
+__global__ __launch_bounds__(kBlock) void k_infl_seed(const Plan* __restrict__ plans)
+{
+  const Plan& P = plans[0];
+  const uint32_t stride = gridDim.x * kBlock;
+  uint32_t* l0 = P.list[0];
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
+    if (!is_seed(P, v)) continue;
+    P.dist[v] = 0.0f; P.tkey[v] = make_key(0.0f, v); P.keyd[v] = 0.0f;
+    for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) {
+      const Corner c = P.crn[i];
+      const uint32_t nb[2] = { c.v1, c.v2 };
+      for (int q = 0; q < 2; ++q) {
+        const uint32_t u = nb[q];
+        if (u == kNone || is_seed(P, u)) continue;
+        if (P.stamp[u] != 0xFFFFFFFFu && atomicExch(&P.stamp[u], 0xFFFFFFFFu) != 0xFFFFFFFFu) {
+          const uint32_t at = atomicAdd(&P.cnt[2].n_next, 1u);
+          if (at < P.cap) l0[at] = u;
+        }
+      }
+    }
+  }
+}
+
+// riskiness from the distances: fading() :315-339; vertices the wave never reached keep the default 0
+// (inflation_layer.h:74-77).  The exponential runs in float64 and is rounded to float32 (:326).
+__global__ __launch_bounds__(kBlock) void k_infl_cost(uint32_t V, const float* __restrict__ dist, double inflation_radius,
+                                                      double inscribed_radius, double inscribed_value, double lethal_value,
+                                                      double cost_scaling_factor, float* __restrict__ cost)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  const float d = dist[v];
+  float c;
+  if (!(d < inf_f())) c = 0.0f;
+  else if ((double)d > inflation_radius) c = 0.0f;                                        // :317-320
+  else if ((double)d > inscribed_radius) {                                                // :323
+    const float factor = (float)exp(-1.0 * cost_scaling_factor * ((double)d - inscribed_radius));   // :326
+    c = (float)(inscribed_value * (double)factor);                                        // :327
+  }
+  else if (d > 0) c = (float)inscribed_value;                                             // :332-335
+  else c = (float)lethal_value;                                                           // :338
+  cost[v] = c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_combine_resident(uint32_t V, int mode, uint32_t n_layers, const float* const* __restrict__ layers,
+                                                             const float* __restrict__ weights, float* __restrict__ out)
+{
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= V) return;
+  float cost = 0.0f;                                               // defaultValue(), combination_layer.h:52,94
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    const float tmp = layers[l][v];
+    if (mode == 0) cost = (cost < tmp) ? tmp : cost;               // std::max(cost, tmp) :66
+    else cost += weights[l] * tmp;                                 // :206
+  }
+  out[v] = cost;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 struct Slot {
@@ -1807,6 +1942,7 @@ struct mnav_ctx {
   Nbr* d_nbr = nullptr; double nbr_limit = NAN; bool nbr_valid = false;
   Corner* d_crn = nullptr; uint8_t* d_blocked = nullptr; double crn_limit = NAN; bool crn_valid = false;
   FaceCirculation circ;                                            // caller-supplied getFacesOfVertex rows (optional)
+  uint32_t* d_verify_any = nullptr; uint32_t verify_sweeps_used = 0;
   bool cvp_verify = true;                                          // k_cvp_verify after every CVP plan (MNAV_CVP_VERIFY=0 to skip)
   int walk_max = kKeyWalkMax, descend_max = kDescendWalkMax;       // cascade-tree walk bounds (MNAV_KEY_WALK_MAX / MNAV_DESCEND_WALK_MAX: tests)
   // plans
@@ -1852,6 +1988,13 @@ struct mnav_ctx {
     std::vector<uint32_t> iface_vert;
   } shard;
   double edge_cost_factor = 0.0;                                   // factor of the resident edge weights (mnav_update_costs)
+  // layers computed / kept on the device (mnav_layer_*)
+  struct Layer { float* cost = nullptr; uint8_t* lethal = nullptr; float* dist = nullptr; bool ready = false; };
+  std::vector<Layer> layers;
+  Corner* d_crn_infl = nullptr; bool crn_infl_valid = false;       // corners over the edge distances (inflation wave)
+  uint8_t *d_infl_mask = nullptr, *d_zero_u8 = nullptr;
+  float* d_infl_keyd = nullptr;
+  uint32_t infl_steps = 0, infl_bands = 0; uint64_t infl_evals = 0; float infl_ms = 0.f;   // last inflation wave
   uint32_t* d_next_plan = nullptr;
   uint32_t wave_min_batch = 0;                                     // auto engine: 0 = never pick k_plan_wave (MNAV_WAVE_MIN_BATCH to opt in)
   TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
@@ -1896,6 +2039,14 @@ int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
 }
 
 float ev_ms(hipEvent_t a, hipEvent_t b);
+
+void drop_layers(mnav_ctx* ctx)
+{
+  for (auto& L : ctx->layers) { (void)hipFree(L.cost); (void)hipFree(L.lethal); (void)hipFree(L.dist); }
+  ctx->layers.clear();
+  (void)hipFree(ctx->d_crn_infl); (void)hipFree(ctx->d_infl_mask); (void)hipFree(ctx->d_zero_u8); (void)hipFree(ctx->d_infl_keyd);
+  ctx->d_crn_infl = nullptr; ctx->d_infl_mask = nullptr; ctx->d_zero_u8 = nullptr; ctx->d_infl_keyd = nullptr; ctx->crn_infl_valid = false;
+}
 
 void free_slot(Slot& s)
 {
@@ -2052,6 +2203,29 @@ int materialize(mnav_ctx* ctx, bool cvp, double cost_limit)
   return 0;
 }
 
+// k_cvp_verify until a sweep finds every vertex at its fixed point: sweeps that find stale deep-cascade members store
+// the re-evaluated state (verify_entry) and are followed by another one; the last allowed sweep only checks.
+int verify_sweeps(mnav_ctx* ctx, uint32_t n)
+{
+  if (!ctx->d_verify_any) HIPCHK(hipMalloc((void**)&ctx->d_verify_any, 4));
+  uint32_t gv = (ctx->V / kGroupsPerWave + 3) / 4;                  // ~4 vertices per 8-lane group
+  if (gv < 1) gv = 1;
+  if (gv > 8192) gv = 8192;
+  ctx->verify_sweeps_used = 0;
+  for (int sweep = 0; sweep <= kVerifySweeps; ++sweep) {
+    uint32_t any = 0;
+    HIPCHK(hipMemsetAsync(ctx->d_verify_any, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_flags_reset, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
+    hipLaunchKernelGGL(k_cvp_verify, dim3(gv, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, sweep < kVerifySweeps ? 1 : 0, ctx->d_verify_any);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&any, ctx->d_verify_any, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!any) break;
+    ++ctx->verify_sweeps_used;
+  }
+  return 0;
+}
+
 struct PlanIn {
   uint32_t seed[3], target[3];
   float seed_d[3];
@@ -2127,14 +2301,7 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
   }
   ctx->stats.launches = launches;
-  if (cvp && rc == 0 && ctx->cvp_verify) {
-    hipLaunchKernelGGL(k_flags_reset, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
-    uint32_t gv = (ctx->V / kGroupsPerWave + 3) / 4;                // ~4 vertices per 8-lane group
-    if (gv < 1) gv = 1;
-    if (gv > 8192) gv = 8192;
-    hipLaunchKernelGGL(k_cvp_verify, dim3(gv, n), dim3(kWave), 0, ctx->stream, ctx->d_plans);
-    HIPCHK(hipGetLastError());
-  }
+  if (cvp && rc == 0 && ctx->cvp_verify && verify_sweeps(ctx, n)) return -1;
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   return rc;
 }
@@ -2576,6 +2743,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipStreamSynchronize(ctx->stream);
   drop_graphs(ctx);
   for (auto& s : ctx->slots) free_slot(s);
+  drop_layers(ctx);
   (void)hipFree(ctx->d_row_ptr); (void)hipFree(ctx->d_nbr_u); (void)hipFree(ctx->d_nbr_e); (void)hipFree(ctx->d_crn_ptr);
   (void)hipFree(ctx->d_edge_vtx); (void)hipFree(ctx->d_crn_idx); (void)hipFree(ctx->d_xyz); (void)hipFree(ctx->d_nrm);
   (void)hipFree(ctx->d_cost); (void)hipFree(ctx->d_w); (void)hipFree(ctx->d_edge_dist); (void)hipFree(ctx->d_invalid);
@@ -2590,7 +2758,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->wt.vert_tile); (void)hipFree(ctx->wt.thdr); (void)hipFree(ctx->wt.rowptr); (void)hipFree(ctx->wt.col); (void)hipFree(ctx->wt.tw);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
-  (void)hipFree(ctx->d_cancel);
+  (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
@@ -2636,6 +2804,8 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& s : ctx->slots) free_slot(s);
   ctx->slots.clear();
+  drop_layers(ctx);
+  if (ctx->d_edge_dist) { ctx->alloc_bytes.erase((void*)ctx->d_edge_dist); (void)hipFree(ctx->d_edge_dist); ctx->d_edge_dist = nullptr; }   // belongs to the old mesh
   drop_graphs(ctx);
   (void)hipFree(ctx->d_paths); ctx->d_paths = nullptr; ctx->paths_words = 0;
   (void)hipFree(ctx->d_nbr); ctx->d_nbr = nullptr; (void)hipFree(ctx->d_crn); ctx->d_crn = nullptr;
@@ -2841,6 +3011,7 @@ int mnav_compute_edge_weights(mnav_ctx* ctx, const float* vertex_costs, const fl
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   if (dev_upload(ctx, &ctx->d_cost, vertex_costs, ctx->V)) return -1;
   if (dev_upload(ctx, &ctx->d_edge_dist, edge_distances, ctx->E)) return -1;
+  ctx->crn_infl_valid = false;
   return edge_weight_pass(ctx, edge_cost_factor, invalid, nullptr, edge_weights_out);
 }
 
@@ -2866,7 +3037,7 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
   if (rc == 0 && mode == 1 && n_layers &&
       hipMemcpyAsync(d_wts, weights, sizeof(float) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "weight upload failed"; rc = -1; }
   if (rc == 0 && dev_upload(ctx, &ctx->d_cost, (const float*)nullptr, V)) rc = -1;
-  if (rc == 0 && edge_distances && dev_upload(ctx, &ctx->d_edge_dist, edge_distances, ctx->E)) rc = -1;   // NULL: keep the resident ones
+  if (rc == 0 && edge_distances) { ctx->crn_infl_valid = false; if (dev_upload(ctx, &ctx->d_edge_dist, edge_distances, ctx->E)) rc = -1; }   // NULL: keep the resident ones
   if (rc == 0) {
     const uint32_t gb = (V + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_combine, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, V, mode, n_layers, d_layers, d_wts, ctx->d_cost);
@@ -2920,6 +3091,211 @@ int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weig
   if (edge_weights_out) HIPCHK(hipMemcpyAsync(edge_weights_out, ctx->d_w, sizeof(float) * ctx->E, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+// -- layers on the device ------------------------------------------------------------------------
+static int layer_slot(mnav_ctx* ctx, uint32_t layer, bool want_dist)
+{
+  if (!ctx->have_mesh) { ctx->err = "mnav_upload_mesh has not been called"; return -1; }
+  if (layer >= 64) { ctx->err = "layer index out of range (64 layers)"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  if (ctx->layers.size() <= layer) ctx->layers.resize(layer + 1);
+  mnav_ctx::Layer& L = ctx->layers[layer];
+  const size_t V = ctx->V ? ctx->V : 1;
+  if (!L.cost) HIPCHK(hipMalloc((void**)&L.cost, 4 * V));
+  if (!L.lethal) HIPCHK(hipMalloc((void**)&L.lethal, V));
+  if (want_dist && !L.dist) HIPCHK(hipMalloc((void**)&L.dist, 4 * V));
+  return 0;
+}
+
+static int ensure_edge_distances(mnav_ctx* ctx)
+{
+  if (ctx->d_edge_dist) return 0;
+  if (dev_upload(ctx, &ctx->d_edge_dist, (const float*)nullptr, ctx->E)) return -1;
+  const uint32_t gb = (ctx->E + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_edge_dist, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, ctx->E, ctx->d_edge_vtx, ctx->d_xyz, ctx->d_edge_dist);
+  HIPCHK(hipGetLastError());
+  ctx->crn_infl_valid = false;
+  return 0;
+}
+
+int mnav_layer_upload(mnav_ctx* ctx, uint32_t layer, const float* costs, const uint8_t* lethal)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (layer_slot(ctx, layer, false)) return -1;
+  mnav_ctx::Layer& L = ctx->layers[layer];
+  if (!costs) { ctx->err = "null cost array"; return -1; }
+  HIPCHK(hipMemcpyAsync(L.cost, costs, sizeof(float) * ctx->V, hipMemcpyHostToDevice, ctx->stream));
+  if (lethal) HIPCHK(hipMemcpyAsync(L.lethal, lethal, ctx->V, hipMemcpyHostToDevice, ctx->stream));
+  else HIPCHK(hipMemsetAsync(L.lethal, 0, ctx->V ? ctx->V : 1, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  L.ready = true;
+  return 0;
+}
+
+int mnav_layer_steepness(mnav_ctx* ctx, uint32_t layer, double threshold)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (layer_slot(ctx, layer, false)) return -1;
+  if (!ctx->have_normals) { ctx->err = "vertex normals are not resident (mnav_upload_mesh with vertex_normals)"; return -1; }
+  mnav_ctx::Layer& L = ctx->layers[layer];
+  const uint32_t gb = (ctx->V + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_steepness, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, ctx->V, ctx->d_nrm, threshold, L.cost, L.lethal);
+  HIPCHK(hipGetLastError());
+  L.ready = true;
+  return 0;
+}
+
+// InflationLayer::computeLayer (inflation_layer.cpp:96-178 / :577-600): lethals of the input layer -> distances_
+// (multi-source wave) -> riskiness.  Runs the wave on the band engine with plan slot 0's work arrays.
+int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, double inflation_radius, double inscribed_radius,
+                         double inscribed_value, double lethal_value, double cost_scaling_factor, const uint8_t* invalid)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (input_layer >= ctx->layers.size() || !ctx->layers[input_layer].ready) { ctx->err = "input layer is not resident"; return -1; }
+  if (layer == input_layer) { ctx->err = "a layer cannot inflate itself"; return -1; }
+  if (layer_slot(ctx, layer, true)) return -1;
+  if (ctx->V > (1u << kKeyIdBits)) { ctx->err = "the ordered wave supports meshes of up to 2^26 vertices"; return -1; }
+  if (ensure_edge_distances(ctx)) return -1;
+  const uint32_t V = ctx->V;
+  const uint32_t gb = (V + kBlock - 1) / kBlock ? (V + kBlock - 1) / kBlock : 1;
+  if (!ctx->d_crn_infl) HIPCHK(hipMalloc((void**)&ctx->d_crn_infl, sizeof(Corner) * (size_t)(ctx->F ? 3 * (size_t)ctx->F : 1)));
+  if (!ctx->crn_infl_valid) {
+    hipLaunchKernelGGL(k_build_crn_infl, dim3(gb), dim3(kBlock), 0, ctx->stream, V, ctx->d_crn_ptr, ctx->d_crn_idx, ctx->d_edge_dist, ctx->d_crn_infl);
+    HIPCHK(hipGetLastError());
+    ctx->crn_infl_valid = true;
+  }
+  const size_t Vn = V ? V : 1;
+  if (!ctx->d_infl_mask) HIPCHK(hipMalloc((void**)&ctx->d_infl_mask, Vn));
+  if (!ctx->d_zero_u8) { HIPCHK(hipMalloc((void**)&ctx->d_zero_u8, Vn)); HIPCHK(hipMemsetAsync(ctx->d_zero_u8, 0, Vn, ctx->stream)); }
+  if (!ctx->d_infl_keyd) HIPCHK(hipMalloc((void**)&ctx->d_infl_keyd, 4 * Vn));
+  uint8_t* d_inv = nullptr;
+  if (invalid) { HIPCHK(hipMalloc((void**)&d_inv, Vn)); HIPCHK(hipMemcpyAsync(d_inv, invalid, V, hipMemcpyHostToDevice, ctx->stream)); }
+  mnav_ctx::Layer& L = ctx->layers[layer];
+  mnav_ctx::Layer& In = ctx->layers[input_layer];
+  hipLaunchKernelGGL(k_infl_mask, dim3(gb), dim3(kBlock), 0, ctx->stream, V, In.lethal, d_inv, ctx->d_infl_mask);
+  HIPCHK(hipMemcpyAsync(L.lethal, In.lethal, V, hipMemcpyDeviceToDevice, ctx->stream));    // lethal_vertices_ = input->lethals() :170,:584
+  if (ensure_slots(ctx, 1, true, true, false)) return -1;
+  Slot& s = ctx->slots[0];
+  Plan P;
+  memset(&P, 0, sizeof(P));
+  P.planner = kPlannerCvp; P.V = V;
+  P.row_ptr = ctx->d_row_ptr; P.nbr = nullptr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn_infl; P.blocked = ctx->d_zero_u8;
+  P.dist = L.dist; P.tkey = s.tkey; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
+  P.list[0] = s.list0; P.list[1] = s.list1; P.cap = V; P.ctl = s.ctl; P.cnt = s.cnt;
+  const float maxd = (float)inflation_radius;                                               // :438 (const float&)
+  P.delta = maxd > 0.f ? maxd : 1.0f;                                                       // one band per radius: the wave dies out within ~2
+  P.offset = 0.0; P.max_steps = ctx->max_steps; P.walk_max = ctx->walk_max; P.descend_max = ctx->descend_max;
+  for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 0; }
+  P.seed_face = kNone;
+  P.seed_mask = ctx->d_infl_mask; P.keyd = ctx->d_infl_keyd; P.infl_max = maxd;
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, &P, sizeof(Plan), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  uint32_t gi = (V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<kPlannerCvp>, dim3(gi, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  hipLaunchKernelGGL(k_infl_ctl, dim3(1), dim3(64), 0, ctx->stream, ctx->d_plans);
+  hipLaunchKernelGGL(k_infl_seed, dim3(gi), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  HIPCHK(hipGetLastError());
+  // the wave front of an inflation is as long as the lethal contours, not O(sqrt V): more waves than a plan gets
+  uint32_t G = blocks_per_plan(ctx) * 4u;
+  if (G > 8192u) G = 8192u;
+  const auto t_start = std::chrono::steady_clock::now();
+  Ctl last{};
+  for (;;) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
+      ctx->err = "inflation wave exceeded the wall-clock guard"; if (d_inv) (void)hipFree(d_inv); return -1;
+    }
+    if (run_chunk<kPlannerCvp>(ctx, 1, G)) { if (d_inv) (void)hipFree(d_inv); return -1; }
+    HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
+    if (last.done) break;
+  }
+  // verification: every vertex must be a fixed point of the replay rule on the converged state (k_cvp_verify)
+  if (verify_sweeps(ctx, 1)) { if (d_inv) (void)hipFree(d_inv); return -1; }
+  hipLaunchKernelGGL(k_infl_cost, dim3(gb), dim3(kBlock), 0, ctx->stream, V, L.dist, inflation_radius, inscribed_radius, inscribed_value,
+                     lethal_value, cost_scaling_factor, L.cost);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  Cnt flags{};
+  HIPCHK(hipMemcpyAsync(&flags, s.cnt + 3, sizeof(Cnt), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (d_inv) (void)hipFree(d_inv);
+  ctx->infl_steps = (uint32_t)(last.it < 0 ? 0 : last.it); ctx->infl_bands = last.bands; ctx->infl_evals = last.evals;
+  ctx->infl_ms = ev_ms(ctx->ev[1], ctx->ev[3]);
+  if (last.overflow) { ctx->err = "inflation wave did not converge (work-list overflow or step limit)"; return -1; }
+  if (flags.n_next & kFlagWalkLimit) { ctx->err = "inflation wave: cascade-tree walk bound hit; the result may not be the reference's"; return -1; }
+  if (flags.changed) { ctx->err = "inflation wave: the converged state is not a fixed point of the replay rule"; return -1; }
+  L.ready = true;
+  return 0;
+}
+
+int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t* lethal_out, float* distances_out)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (layer >= ctx->layers.size() || !ctx->layers[layer].ready) { ctx->err = "layer is not resident"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  mnav_ctx::Layer& L = ctx->layers[layer];
+  if (costs_out) HIPCHK(hipMemcpyAsync(costs_out, L.cost, sizeof(float) * ctx->V, hipMemcpyDeviceToHost, ctx->stream));
+  if (lethal_out) HIPCHK(hipMemcpyAsync(lethal_out, L.lethal, ctx->V, hipMemcpyDeviceToHost, ctx->stream));
+  if (distances_out) {
+    if (!L.dist) { ctx->err = "this layer keeps no distances"; return -1; }
+    HIPCHK(hipMemcpyAsync(distances_out, L.dist, sizeof(float) * ctx->V, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms)
+{
+  if (!ctx) return -1;
+  if (steps) *steps = ctx->infl_steps;
+  if (bands) *bands = ctx->infl_bands;
+  if (evals) *evals = ctx->infl_evals;
+  if (ms) *ms = ctx->infl_ms;
+  return 0;
+}
+
+// CombinationLayer (max :44-85 / weighted sum :185-248) over resident layers, then MeshMap::computeEdgeWeights:
+// the whole cost preparation of a map without a host copy of a single V-sized array.
+int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights, double edge_cost_factor,
+                        const uint8_t* invalid)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!ctx->have_mesh) { ctx->err = "mnav_upload_mesh has not been called"; return -1; }
+  if (mode != 0 && mode != 1) { ctx->err = "combination mode must be 0 (max) or 1 (weighted sum)"; return -1; }
+  if ((n_layers && !layers) || (mode == 1 && n_layers && !weights) || n_layers > 64) { ctx->err = "bad layer list"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  std::vector<const float*> ptrs(n_layers ? n_layers : 1, nullptr);
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    if (layers[l] >= ctx->layers.size() || !ctx->layers[layers[l]].ready) { ctx->err = "layer is not resident"; return -1; }
+    ptrs[l] = ctx->layers[layers[l]].cost;
+  }
+  if (ensure_edge_distances(ctx)) return -1;
+  const float** d_ptrs = nullptr; float* d_wts = nullptr;
+  HIPCHK(hipMalloc((void**)&d_ptrs, sizeof(float*) * (n_layers + 1)));
+  HIPCHK(hipMalloc((void**)&d_wts, sizeof(float) * (n_layers + 1)));
+  int rc = 0;
+  if (n_layers && hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float*) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
+  if (rc == 0 && mode == 1 && n_layers && hipMemcpyAsync(d_wts, weights, sizeof(float) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
+  if (rc == 0 && dev_upload(ctx, &ctx->d_cost, (const float*)nullptr, ctx->V)) rc = -1;
+  if (rc == 0) {
+    const uint32_t gb = (ctx->V + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_combine_resident, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, ctx->V, mode, n_layers, d_ptrs, d_wts, ctx->d_cost);
+    if (hipGetLastError() != hipSuccess) rc = -1;
+  }
+  if (rc != 0 && ctx->err.empty()) ctx->err = "layer combination failed";
+  if (rc == 0) rc = edge_weight_pass(ctx, edge_cost_factor, invalid, nullptr, nullptr);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_ptrs); (void)hipFree(d_wts);
+  return rc;
 }
 
 static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, const uint32_t* targets, double offset,

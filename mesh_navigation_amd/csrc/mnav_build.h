@@ -275,27 +275,41 @@ inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uin
   }
   // order flags (Corner, mnav_eval.h): walk every vertex t's faces in circulator order; of the (at most two)
   // faces that contain edge (t, v) the one met first gets the flag on v's corner for that face
-  if (F >= (1u << 30)) throw std::invalid_argument("face ids must fit 30 bits");
+  if (F >= (1u << 28)) throw std::invalid_argument("face ids must fit 28 bits");
   FaceCirculation own;
   if (!circ) { own = build_face_circulation(V, F, face_vtx); circ = &own; }
   {
-    std::vector<uint32_t> seen;                                  // the v's already met around t
-    for (uint32_t tv = 0; tv < V; ++tv) {
-      seen.clear();
-      for (uint32_t r = circ->ptr[tv]; r < circ->ptr[tv + 1]; ++r) {
-        const uint32_t f = circ->faces[r];
-        if (f >= F) throw std::invalid_argument("face circulation row names an unknown face");
-        for (int k = 0; k < 3; ++k) {
-          const uint32_t v = face_vtx[3 * size_t(f) + k];
-          if (v == tv) continue;
-          const bool first = std::find(seen.begin(), seen.end(), v) == seen.end();
-          if (!first) continue;
-          seen.push_back(v);
-          for (uint32_t i = t.crn_ptr[v]; i < t.crn_ptr[v + 1]; ++i)
-            if (t.crn_face[i] == f || (t.crn_face[i] & kCornerFaceMask) == f) {
-              t.crn_face[i] |= (t.crn_v1[i] == tv) ? kCornerFirst1 : kCornerFirst2;
-              break;
-            }
+    std::vector<uint32_t> seen, order;                           // the v's already met around t; the walk order
+    for (int pass = 0; pass < 2; ++pass) {                       // 0: getFacesOfVertex order (CVP), 1: inflation wave order
+      const uint32_t flag1 = pass == 0 ? kCornerFirst1 : kCornerInfl1, flag2 = pass == 0 ? kCornerFirst2 : kCornerInfl2;
+      for (uint32_t tv = 0; tv < V; ++tv) {
+        const uint32_t r0 = circ->ptr[tv], m = circ->ptr[tv + 1] - r0;
+        order.clear();
+        for (uint32_t r = 0; r < m; ++r) order.push_back(circ->faces[r0 + r]);
+        if (pass == 1 && m >= 2) {
+          // pmp vertex circulator from halfedge(tv): for h_i = tv->n_i the faces {left(h_i), left(opposite h_i)} =
+          // {F_i, F_(i-1)}.  Interior vertex (as many faces as edges): first visits F_0, F_last, F_1, ...; boundary
+          // vertex (halfedge(tv) is the boundary one, its left face is missing): F_last, F_1, F_2, ...
+          const uint32_t degree = t.row_ptr[tv + 1] - t.row_ptr[tv];
+          const uint32_t last = order.back();
+          order.pop_back();
+          order.insert(order.begin() + ((m == degree) ? 1 : 0), last);
+        }
+        seen.clear();
+        for (uint32_t f : order) {
+          if (f >= F) throw std::invalid_argument("face circulation row names an unknown face");
+          for (int k = 0; k < 3; ++k) {
+            const uint32_t v = face_vtx[3 * size_t(f) + k];
+            if (v == tv) continue;
+            const bool first = std::find(seen.begin(), seen.end(), v) == seen.end();
+            if (!first) continue;
+            seen.push_back(v);
+            for (uint32_t i = t.crn_ptr[v]; i < t.crn_ptr[v + 1]; ++i)
+              if ((t.crn_face[i] & kCornerFaceMask) == f) {
+                t.crn_face[i] |= (t.crn_v1[i] == tv) ? flag1 : flag2;
+                break;
+              }
+          }
         }
       }
     }

@@ -42,15 +42,22 @@ struct Nbr { uint32_t u; float w; };
 // face with v3 last (cvp_mesh_planner.cpp:811,834,857); a=w(v2,v3), b=w(v1,v3), c=w(v1,v2)
 // (cvp_mesh_planner.cpp:380-390).  v1 == kNone marks a face that must be skipped because one
 // of its vertices is invalid (cvp_mesh_planner.cpp:785).
-// `face` carries the face id in its low 30 bits and two order flags: the reference applies the faces of a
+// `face` carries the face id in its low 28 bits and order flags: the reference applies the faces of a
 // popped vertex t in the order of t's half-edge circulator (getFacesOfVertex, cvp :775-778), and on
 // cost-inflated triangles the update is not a pure minimum, so when both faces of edge (t, v3) fire on the
 // same pop their order matters.  kCornerFirst1 / kCornerFirst2: this face comes first of the two in the
 // circulator of v1 / v2.
 struct Corner { uint32_t v1, v2; float a, b, c; uint32_t face; };
-constexpr uint32_t kCornerFaceMask = 0x3FFFFFFFu, kCornerFirst1 = 0x40000000u, kCornerFirst2 = 0x80000000u;
+constexpr uint32_t kCornerFaceMask = 0x0FFFFFFFu, kCornerFirst1 = 0x40000000u, kCornerFirst2 = 0x80000000u;
+// The inflation wave visits the faces of a popped vertex in another order than getFacesOfVertex: for every
+// neighbour nh of the vertex circulator, the face left of cur->nh and then the face left of nh->cur
+// (inflation_layer.cpp:423-427), so the LAST face of the circulator is met right after (interior vertex) or before
+// (boundary vertex) the first one.  Its update is a minimum, but which update RE-QUEUES the vertex (:311) depends on
+// the order.  The topology carries these flags in bits 28/29; the inflation corner table moves them to 30/31.
+constexpr uint32_t kCornerInfl1 = 0x10000000u, kCornerInfl2 = 0x20000000u;
 MNAV_HD uint32_t corner_face(const Corner& k) { return k.face & kCornerFaceMask; }
 MNAV_HD bool corner_first_for(const Corner& k, uint32_t trig) { return (k.face & (trig == k.v1 ? kCornerFirst1 : kCornerFirst2)) != 0u; }
+MNAV_HD uint32_t corner_face_for_inflation(uint32_t face) { return (face & kCornerFaceMask) | ((face & (kCornerInfl1 | kCornerInfl2)) << 2); }
 
 MNAV_HD float u2f(uint32_t u) { union { uint32_t u; float f; } x; x.u = u; return x.f; }
 MNAV_HD uint32_t f2u(float f) { union { uint32_t u; float f; } x; x.f = f; return x.u; }
@@ -162,6 +169,54 @@ MNAV_HD CvpUpd cvp_update(float u1f, float u2f_, float u3f, float af, float bf, 
 }
 
 // ---------------------------------------------------------------------------------------
+// Inflation triangle update, inflation_layer.cpp:181-313, on plain numbers: float32 throughout (the reference's
+// locals are float and <math.h> supplies the float overloads of sqrt), no FMA contraction.
+// ---------------------------------------------------------------------------------------
+constexpr float kLayersEpsilon = 1e-9f;                    // mesh_layers::EPSILON, inflation_layer.h:48
+
+// computeUpdateSethianMethod(d1, d2, a, b, dot, F = 1.0) :181-234
+MNAV_HD float infl_sethian(float d1, float d2, float a, float b, float dot)
+{
+  const float F = 1.0f;
+  float t = inf_f();                                        // :186
+  const float rc = dot;                                     // :188
+  const float rs = sqrtf(1 - dot * dot);                    // :189
+  const float u = d2 - d1;                                  // :191
+  const float f2 = a * a + b * b - 2 * a * b * rc;          // :193
+  const float f1 = b * u * (a * rc - b);                    // :194
+  const float f0 = b * b * (u * u - F * F * a * a * rs);    // :195
+  const float delta = f1 * f1 - f0 * f2;                    // :197
+  if (delta >= 0) {                                         // :199
+    if (fabsf(f2) > kLayersEpsilon) {                       // :201
+      t = (-f1 - sqrtf(delta)) / f2;                        // :203
+      if (t < u || b * (t - u) / t < a * rc || a / rc < b * (t - u) / 2) {   // :204
+        t = (-f1 + sqrtf(delta)) / f2;                      // :206
+      } else {
+        if (f1 != 0) t = -f0 / f1;                          // :210-213
+        else t = -inf_f();                                  // :216
+      }
+    }
+  } else {
+    t = -inf_f();                                           // :223
+  }
+  if (u < t && a * rc < b * (t - u) / t && b * (t - u) / t < a / rc) return t + d1;   // :226-229
+  return fminf(b * F + d1, a * F + d2);                     // :232
+}
+
+// waveFrontUpdate :236-313 without its stores: the value offered to the free vertex and whether a successful
+// update re-queues it (:311).  ok == false: u3tmp is not finite (:271).
+struct InflCand { float u3tmp; bool ok; bool requeue; };
+MNAV_HD InflCand infl_candidate(float u1, float u2, float a, float b, float c, float max_distance)
+{
+  InflCand r;
+  const float dot = (a * a + b * b - c * c) / (2 * a * b);  // :260-268
+  r.u3tmp = infl_sethian(u1, u2, a, b, dot);                // :269
+  r.ok = (f2u(r.u3tmp) & 0x7f800000u) != 0x7f800000u;       // std::isfinite :271
+  r.requeue = u1 <= max_distance && u2 <= max_distance;     // :311
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
 // Per-plan control block.  Two copies ping-pong between consecutive steps (step j reads
 // slot (j-1)&1 and block 0 writes slot j&1); three counter blocks rotate (step j counts
 // into j%3, reads (j-1)%3, clears (j+1)%3).  See DESIGN.md §3.3.
@@ -226,7 +281,15 @@ struct Plan {
   uint32_t max_steps;
   int32_t walk_max;        // bound of key_less / key_for walks (kKeyWalkMax)
   int32_t descend_max;     // bound of key_descends_from (kDescendWalkMax)
+  // Inflation wave (InflationLayer::waveCostInflation, inflation_layer.cpp:341-491) on the CVP machinery: set iff
+  // seed_mask != nullptr.  seed_mask[v]: kInflSeed = lethal vertex (distance 0, fixed from the start :397-402),
+  // kInflSeedMute = lethal and invalid (fixed, but its pop is skipped :417), kInflMute = invalid free vertex (is
+  // updated, queued and popped like any other, but the pop is skipped before `fixed` is set :417-422: never a support).
+  const uint8_t* seed_mask;
+  float* keyd;             // V  value the vertex sits in the queue with (the last update that re-queued it, :311,:451)
+  float infl_max;          // max_distance: an update only (re-)queues its vertex while both supports lie within (:311)
 };
+enum : uint8_t { kInflFree = 0, kInflSeed = 1, kInflSeedMute = 2, kInflMute = 3 };
 
 // Sticky per-plan flags (P.cnt[3].n_next).  kFlagWalkLimit: a walk over the cascade tree hit its bound and
 // the comparison fell back to another order -- the result may no longer be the reference's, so the plan is
@@ -234,10 +297,15 @@ struct Plan {
 constexpr uint32_t kFlagWalkLimit = 1u;
 MNAV_HD void raise_flag(const Plan& P, uint32_t f) { if (!(P.cnt[3].n_next & f)) P.cnt[3].n_next |= f; }
 
-MNAV_HD bool is_seed(const Plan& P, uint32_t v) { return v == P.seed[0] || v == P.seed[1] || v == P.seed[2]; }
+MNAV_HD bool is_seed(const Plan& P, uint32_t v)
+{
+  if (P.seed_mask) { const uint8_t m = P.seed_mask[v]; return m == kInflSeed || m == kInflSeedMute; }
+  return v == P.seed[0] || v == P.seed[1] || v == P.seed[2];
+}
 
 // --- pop keys as positions in the cascade forest (see PopKey) --------------------------------
-MNAV_HD KeyRef key_ref(const Plan& P, uint32_t u) { return key_ref_of(P.tkey[u], P.dist[u], u); }
+// (inflation: a vertex can sit in the queue with an older, larger value than its distance -- keyd, see Plan)
+MNAV_HD KeyRef key_ref(const Plan& P, uint32_t u) { return key_ref_of(P.tkey[u], P.keyd ? P.keyd[u] : P.dist[u], u); }
 
 // a pops before b
 MNAV_HD bool key_less(const Plan& P, KeyRef a, KeyRef b)
@@ -397,7 +465,7 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
 // ---------------------------------------------------------------------------------------
 // Gather rules
 // ---------------------------------------------------------------------------------------
-struct Eval { float d; float t; PopKey key; uint32_t pred; float dir; uint32_t cut; };
+struct Eval { float d; float t; PopKey key; uint32_t pred; float dir; uint32_t cut; float keyd; };
 
 // Dijkstra: dist[v] = min over neighbours u that expand (popped: dist[u] < thr; not cut off:
 // dist[u] <= goal_dist, dijkstra :299; cost cut-off folded into w) of dist[u] + w(u,v), the very
@@ -436,8 +504,14 @@ MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
   const float t1 = key_time(k1.k), t2 = key_time(k2.k);
   if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return f;         // both supports fixed by this band
   bool ex1 = true, ex2 = true;
-  if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
-  if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+  if (P.seed_mask) {
+    const uint8_t m1 = P.seed_mask[k.v1], m2 = P.seed_mask[k.v2];
+    if (m1 == kInflMute || m2 == kInflMute) return f;                 // never fixed: the face never has two fixed supports
+    ex1 = m1 != kInflSeedMute; ex2 = m2 != kInflSeedMute;
+  } else {
+    if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
+    if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+  }
   const bool one_first = key_less(P, k1, k2);                        // v1 pops before v2
   const bool trig1 = t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && (s2 || !one_first);
   const bool trig2 = t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && (s1 || one_first || k1.own == k2.own);
@@ -452,11 +526,19 @@ MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
 // circulator (cvp :778 loop over getFacesOfVertex(trigger)): Corner order flags, mnav_build.h.
 MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 {
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone;
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
+  const bool infl = P.seed_mask != nullptr;
+  // an invalid free vertex is queued and popped like the others, but its pop is skipped before it is fixed (:417-422):
+  // it never stops taking updates and never supports one -> it simply has no pop key here
+  const bool mute = infl && P.seed_mask[v] == kInflMute;
   KeyRef last = key_ref_of(key_inf(), inf_f(), 0);
-  bool first = true;
-  for (;;) {
+  bool first = true, queued = false;
+  // every pass consumes one trigger vertex (<= 2 per corner); on a half-converged, inconsistent cascade tree the
+  // "next pop after the last one" can run in a circle -- transient there, flagged if it happens on a converged state
+  const uint32_t max_pass = 2u * (end - beg) + 2u;
+  for (uint32_t pass_no = 0;; ++pass_no) {
+    if (pass_no == max_pass) { raise_flag(P, kFlagWalkLimit); break; }
     // next trigger pop strictly after the last one
     KeyRef m = last; uint32_t m_trig = kNone;
     for (uint32_t i = beg; i < end; ++i) {
@@ -466,23 +548,33 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
       if (m_trig == kNone || key_less(P, f.key, m)) { m = f.key; m_trig = f.trig; }
     }
     if (m_trig == kNone) break;
-    if (e.d < inf_f() && !key_less(P, m, key_ref_of(e.key, e.d, v))) break;   // v pops before this trigger
+    if (queued && !key_less(P, m, key_ref_of(e.key, e.keyd, v))) break;   // v pops before this trigger
     bool any = false;
+    float ins_d = 0.0f;
     for (int pass = 0; pass < 2; ++pass)                  // faces of this pop, in the trigger's circulator order
       for (uint32_t i = beg; i < end; ++i) {
         const Corner k = P.crn[i];
         const Fire f = corner_fire(P, c, k);
         if (f.trig != m_trig || corner_first_for(k, m_trig) != (pass == 0)) continue;
-        const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
-        if (u.ok) {
-          e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = corner_face(k);
-          any = true;
+        if (infl) {
+          const InflCand u = infl_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c, P.infl_max);
+          if (e.d == 0.0f || !u.ok || !(u.u3tmp < e.d)) continue;       // :252, :271, :298
+          e.d = u.u3tmp;                                                // :300
+          if (u.requeue) { any = true; ins_d = e.d; }                   // :311 -> pq.insert(v, distances[v]) :451,459,467
+        } else {
+          const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
+          if (u.ok) {
+            e.d = u.u3; e.pred = (u.sel == 1) ? k.v1 : k.v2; e.dir = u.dir; e.cut = corner_face(k);
+            any = true; ins_d = e.d;
+          }
         }
       }
-    if (any) e.key = key_for(P, e.d, v, m);                // ordinary pop, or a place inside the cascade of this trigger
+    if (any && !mute) {                                    // ordinary pop, or a place inside the cascade of this trigger
+      e.key = key_for(P, ins_d, v, m); e.keyd = ins_d; queued = true;
+    }
     last = m; first = false;
   }
-  if (!(e.d < inf_f())) { e.pred = v; e.key = key_inf(); }
+  if (!queued) { e.key = key_inf(); e.keyd = inf_f(); e.pred = v; }
   e.t = key_time(e.key);
   return e;
 }
@@ -515,11 +607,12 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
   if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
   const float old_d = P.dist[v];
   bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t));
-  if (cvp) changed = changed || (e.key != old_key) || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v]));
+  if (cvp) changed = changed || (e.key != old_key) || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v])) ||
+                     (P.keyd && f2u(e.keyd) != f2u(P.keyd[v]));
   else changed = changed || (e.pred != P.pred[v]);
   if (changed) {
     W.dist[v] = e.d; W.pred[v] = e.pred;
-    if constexpr (cvp) { W.tkey[v] = e.key; W.dirn[v] = e.dir; W.cutf[v] = e.cut; }
+    if constexpr (cvp) { W.tkey[v] = e.key; W.dirn[v] = e.dir; W.cutf[v] = e.cut; if (W.keyd) W.keyd[v] = e.keyd; }
   }
   if constexpr (cvp) {
     // the rule reads v's own stored key (key_descends_from): a cascade member whose key moved looks again
@@ -570,7 +663,7 @@ MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
       if (f2u(e.d) != f2u(d) || e.key != P.tkey[v]) ops.note_changed();
     }
     P.dist[v] = e.d; P.pred[v] = e.pred;
-    if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+    if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; if (P.keyd) P.keyd[v] = e.keyd; }
     d = e.d; t = e.t;
   }
   if (t >= c.thr && t < inf_f()) { ops.push(v); ops.note_min(t); }
@@ -584,5 +677,24 @@ MNAV_HD void process_rebuild(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
   if (!(P.dist[v] < inf_f())) return;
   process_entry<PLANNER>(P, c, v, ops);      // c.band_new == 1: in-band vertices wake their neighbours
 }
+
+// Verification sweep entry (k_cvp_verify): on the CONVERGED state every vertex must be a fixed point of the replay
+// rule.  The work-list iteration notifies the corner neighbours of a vertex that moved; a vertex whose pop key hangs
+// off a FAR cascade ancestor (key_for climbs the tree) is not told when that ancestor's place in the tree changes, so
+// a few deep-cascade members can be left with a stale key.  The sweep finds them; with `fix` it stores the
+// re-evaluated state, and the caller sweeps again until a sweep finds nothing (only then is the result returned).
+MNAV_HD bool verify_entry(const Plan& P, const Ctl& c, uint32_t v, const Eval& e, bool fix)
+{
+  const bool same = f2u(e.d) == f2u(P.dist[v]) && e.key == P.tkey[v] && e.pred == P.pred[v] &&
+                    (!(e.d < inf_f()) || (e.cut == P.cutf[v] && f2u(e.dir) == f2u(P.dirn[v]))) &&
+                    (!P.keyd || f2u(e.keyd) == f2u(P.keyd[v]));
+  if (!same && fix) {
+    P.dist[v] = e.d; P.pred[v] = e.pred; P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut;
+    if (P.keyd) P.keyd[v] = e.keyd;
+  }
+  (void)c;
+  return same;
+}
+constexpr int kVerifySweeps = 8;         // fixing sweeps before the plan is given up as INTERNAL_ERROR
 
 }  // namespace mnav

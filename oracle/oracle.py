@@ -400,8 +400,35 @@ def model_lib():
         L.sm_run.restype = u32
         L.sm_run.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, vp, C.c_double, C.c_double,
                              C.c_float, C.c_int, u32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+        L.sm_infl_candidate.restype = C.c_float
+        L.sm_infl_candidate.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_int)]
+        L.sm_run_inflation.restype = u32
+        L.sm_run_inflation.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, u32, vp, vp, vp]
         _model = L
     return _model
+
+
+def product_inflation_update(u1, u2, a, b, c, max_distance):
+    """mnav_eval.h infl_candidate (the device's waveFrontUpdate arithmetic): (value or NaN, re-queue flag)."""
+    rq = C.c_int(0)
+    v = model_lib().sm_infl_candidate(u1, u2, a, b, c, max_distance, C.byref(rq))
+    return float(v), bool(rq.value)
+
+
+def schedule_model_inflation(faces, edges, edge_dist, lethal, max_distance=0.4, delta=None, order=0, invalid=None,
+                             max_steps=0):
+    """The device's inflation wave (mnav_layer_inflation) on the CPU model: distances + queue values."""
+    faces, edges, ed, le = _u32(faces), _u32(edges), _f32(edge_dist), _u8(lethal)
+    V, F, E = le.shape[0], faces.shape[0], edges.shape[0]
+    inv = None if invalid is None else _u8(invalid)
+    dist = np.empty(V, np.float32)
+    keyd = np.empty(V, np.float32)
+    stats = np.zeros(8, np.uint64)
+    code = model_lib().sm_run_inflation(V, F, E, _p(faces), _p(edges), _p(ed), _p(le), _p(inv), float(max_distance),
+                                        float(max_distance if delta is None else delta), int(order), int(max_steps),
+                                        _p(dist), _p(keyd), _p(stats))
+    return dict(code=code, dist=dist, keyd=keyd, steps=int(stats[0]), bands=int(stats[1]), evals=int(stats[2]),
+                verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]))
 
 
 def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_v, seed_d, seed_face,
@@ -424,4 +451,4 @@ def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_
                               int(max_steps), _p(dist), _p(pred), _p(dirn), _p(cutf), _p(stats), C.byref(gd))
     return dict(code=code, dist=dist, pred=pred, direction=dirn, cutface=cutf, steps=int(stats[0]),
                 bands=int(stats[1]), evals=int(stats[2]), armed=int(stats[3]), shrinks=int(stats[4]),
-                verify_bad=int(stats[5]), verify_flags=int(stats[6]), goal_dist=gd.value)
+                verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]), goal_dist=gd.value)

@@ -34,6 +34,121 @@ struct HostOps {
 };
 }  // namespace
 
+// the step loop of the model (controller + one pass over the work list per step) and the model of k_cvp_verify
+static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, std::vector<PopKey>& tkey,
+                      const std::vector<uint8_t>& blocked, uint64_t* stats_out, float* goal_dist_out)
+{
+  const uint32_t V = P.V;
+  float* dist = P.dist; uint32_t* pred = P.pred; float* dirn = P.dirn; uint32_t* cutf = P.cutf;
+  std::vector<uint32_t> dirty_dummy;
+  uint32_t* dirty = P.dirty;
+  uint64_t evals = 0, rng = 88172645463325252ull;
+  const uint32_t trace_v = getenv("SM_TRACE_V") ? (uint32_t)atoi(getenv("SM_TRACE_V")) : kNone;   // debugging aid
+  int j = 0;
+  Ctl cur;
+  std::vector<uint32_t> perm;
+  const int sm_debug = getenv("SM_DEBUG") ? atoi(getenv("SM_DEBUG")) : -1;   // debugging aids, read once
+  const int sm_cycle = getenv("SM_CYCLE") ? atoi(getenv("SM_CYCLE")) : -1;
+  for (;; ++j) {
+    const Ctl& prev = ctl[(j + 1) & 1];
+    const Cnt& cprev = cnt[(j + 2) % 3];
+    cur = controller(P, prev, cprev);
+    ctl[j & 1] = cur;
+    Cnt& cnext = cnt[(j + 1) % 3];
+    cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0;
+    if (sm_debug >= 0 && j >= sm_debug && j < sm_debug + 140)
+      fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
+    if (cur.done) break;
+    Cnt& cc = cnt[j % 3];
+    HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1) };
+    const uint32_t* list = P.list[j & 1];
+    if (cur.repair == 2) {
+      for (uint32_t v = 0; v < V; ++v) {
+        if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
+        else process_rebuild<kPlannerDijkstra>(P, cur, v, ops);
+      }
+    } else if (cur.repair) {
+      for (uint32_t v = 0; v < V; ++v) {
+        if (planner == kPlannerCvp) process_repair<kPlannerCvp>(P, cur, v, ops);
+        else process_repair<kPlannerDijkstra>(P, cur, v, ops);
+      }
+    } else {
+      perm.resize(cur.n);
+      for (uint32_t i = 0; i < cur.n; ++i) perm[i] = i;
+      if (order == 1) std::reverse(perm.begin(), perm.end());
+      if (order == 2)
+        for (uint32_t i = cur.n; i > 1; --i) {
+          rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+          std::swap(perm[i - 1], perm[rng % i]);
+        }
+      if (order == 3) {
+        // snapshot of everything the rules read
+        std::vector<float> sd(dist, dist + V), sdir; std::vector<uint32_t> sp(pred, pred + V), scut;
+        std::vector<PopKey> sk(tkey); std::vector<float> skd; if (P.keyd) skd.assign(P.keyd, P.keyd + V);
+        if (planner == kPlannerCvp) { sdir.assign(dirn, dirn + V); scut.assign(cutf, cutf + V); }
+        Plan R = P;
+        R.dist = sd.data(); R.pred = sp.data(); R.tkey = sk.data(); if (P.keyd) R.keyd = skd.data();
+        if (planner == kPlannerCvp) { R.dirn = sdir.data(); R.cutf = scut.data(); }
+        for (uint32_t i = 0; i < cur.n; ++i) {
+          if (planner == kPlannerCvp) process_entry_rw<kPlannerCvp>(R, P, cur, list[i], ops);
+          else process_entry_rw<kPlannerDijkstra>(R, P, cur, list[i], ops);
+        }
+      } else
+      for (uint32_t i = 0; i < cur.n; ++i) {
+        const uint32_t vv = list[perm[i]];
+        const bool tr = trace_v == vv;
+        const float bd = dist[vv];
+        if (planner == kPlannerCvp) process_entry<kPlannerCvp>(P, cur, vv, ops);
+        else process_entry<kPlannerDijkstra>(P, cur, vv, ops);
+        if (tr) {
+          fprintf(stderr, "step %d thr [%.6f, %.6f) band_new %u v %u: d %.7f -> %.7f key t0 %.7f up %.0f lvl %u dirty %u\n", j, cur.thr_fixed, cur.thr, cur.band_new, vv, bd, dist[vv], key_time(tkey[vv]), (double)tkey[vv].up, (unsigned)tkey[vv].lvl, dirty[vv]);
+          for (uint32_t ci = P.crn_ptr[vv]; ci < P.crn_ptr[vv + 1]; ++ci) {
+            const Corner k = P.crn[ci];
+            const Fire f = corner_fire(P, cur, k);
+            fprintf(stderr, "    corner face %u v1 %u (d %.7f t0 %.7f up %.0f lvl %u) v2 %u (d %.7f t0 %.7f up %.0f lvl %u) trig %u\n", k.face, k.v1, dist[k.v1], key_time(tkey[k.v1]), (double)tkey[k.v1].up, (unsigned)tkey[k.v1].lvl, k.v2, dist[k.v2], key_time(tkey[k.v2]), (double)tkey[k.v2].up, (unsigned)tkey[k.v2].lvl, f.trig);
+          }
+        }
+      }
+    }
+    evals += cc.evals;
+    if (sm_cycle >= 0 && j >= sm_cycle && j < sm_cycle + 8) {   // debugging aid
+      static std::vector<float> pd; static std::vector<PopKey> pk;
+      if (pd.size() == V) {
+        fprintf(stderr, "== step %d thr [%.7f, %.7f) n=%u changed=%u\n", j, cur.thr_fixed, cur.thr, cur.n, cc.changed);
+        for (uint32_t v = 0; v < V; ++v)
+          if (f2u(pd[v]) != f2u(dist[v]) || pk[v] != tkey[v])
+            fprintf(stderr, "   v %u: d %.7f -> %.7f  key (t0 %.7f root %u up %d lvl %u) -> (t0 %.7f root %u up %d lvl %u) pred %u\n", v, pd[v], dist[v],
+                    key_time(pk[v]), pair_id(pk[v].hi), (int)pk[v].up, pk[v].lvl, key_time(tkey[v]), pair_id(tkey[v].hi), (int)tkey[v].up, tkey[v].lvl, pred[v]);
+      }
+      pd.assign(dist, dist + V); pk = tkey;
+    }
+  }
+  // model of k_cvp_verify: one more evaluation of every vertex on the converged state must reproduce it, and no
+  // walk over the cascade tree may hit its bound there (flags raised during the iteration are transient)
+  uint64_t verify_bad = 0, verify_flags = 0, verify_sweeps = 0;
+  if (planner == kPlannerCvp && cur.done && !cur.overflow) {
+    for (int sweep = 0; sweep <= kVerifySweeps; ++sweep) {          // like run_plans: fix, sweep again, until clean
+      cnt[3].n_next = 0; cnt[3].changed = 0;
+      verify_bad = 0;
+      for (uint32_t v = 0; v < V; ++v) {
+        if (is_seed(P, v) || blocked[v]) continue;
+        const Eval e = eval_cvp(P, cur, v);
+        if (getenv("SM_VERIFY_DEBUG") && !verify_entry(P, cur, v, e, false))
+          fprintf(stderr, "verify sweep %d: v %u stored d %.9g key(t0 %.9g root %u up %d lvl %u) | eval d %.9g key(t0 %.9g root %u up %d lvl %u)\n", sweep, v, dist[v],
+                  key_time(tkey[v]), pair_id(tkey[v].hi), (int)tkey[v].up, tkey[v].lvl, e.d, key_time(e.key), pair_id(e.key.hi), (int)e.key.up, e.key.lvl);
+        if (!verify_entry(P, cur, v, e, sweep < kVerifySweeps)) ++verify_bad;
+      }
+      verify_flags = cnt[3].n_next;
+      if (verify_bad == 0) break;
+      ++verify_sweeps;
+    }
+  }
+  if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks;
+                   stats_out[5] = verify_bad; stats_out[6] = verify_flags; stats_out[7] = verify_sweeps; }
+  if (goal_dist_out) *goal_dist_out = cur.goal_dist;
+  return cur.overflow ? kInternalError : kSuccess;   // overflow == 2: step cap hit (no convergence)
+}
+
 extern "C" {
 
 // order: 0 = list order, 1 = reversed list order, 2 = pseudo-random permutation per step,
@@ -123,105 +238,73 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   }
   c0.band_new = 1; c0.width = delta;
 
-  uint64_t evals = 0, rng = 88172645463325252ull;
-  const uint32_t trace_v = getenv("SM_TRACE_V") ? (uint32_t)atoi(getenv("SM_TRACE_V")) : kNone;   // debugging aid
-  int j = 0;
-  Ctl cur;
-  std::vector<uint32_t> perm;
-  const int sm_debug = getenv("SM_DEBUG") ? atoi(getenv("SM_DEBUG")) : -1;   // debugging aids, read once
-  const int sm_cycle = getenv("SM_CYCLE") ? atoi(getenv("SM_CYCLE")) : -1;
-  for (;; ++j) {
-    const Ctl& prev = ctl[(j + 1) & 1];
-    const Cnt& cprev = cnt[(j + 2) % 3];
-    cur = controller(P, prev, cprev);
-    ctl[j & 1] = cur;
-    Cnt& cnext = cnt[(j + 1) % 3];
-    cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0;
-    if (sm_debug >= 0 && j >= sm_debug && j < sm_debug + 140)
-      fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
-    if (cur.done) break;
-    Cnt& cc = cnt[j % 3];
-    HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1) };
-    const uint32_t* list = P.list[j & 1];
-    if (cur.repair == 2) {
-      for (uint32_t v = 0; v < V; ++v) {
-        if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
-        else process_rebuild<kPlannerDijkstra>(P, cur, v, ops);
+  return drive(P, planner, order, ctl, cnt, tkey, blocked, stats_out, goal_dist_out);
+}
+
+// Inflation wave (InflationLayer::waveCostInflation) through the same rules: lethal = sources, edge_dist = side
+// lengths, `invalid` optional.  dist/keyd: V floats out.  The model of mnav_layer_inflation (mnav.hip).
+uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx,
+                          const float* edge_dist, const uint8_t* lethal, const uint8_t* invalid, float max_distance,
+                          float delta, int order, uint32_t max_steps, float* dist, float* keyd, uint64_t* stats_out)
+{
+  HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
+  std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
+  std::vector<float> zero_cost(V, 0.0f);
+  materialize_host(topo, edge_dist, zero_cost.data(), nullptr, INFINITY, nbr, crn, blocked);   // no face skipped, nothing blocked
+  for (Corner& k : crn) k.face = corner_face_for_inflation(k.face);                           // like k_build_crn_infl
+  std::vector<uint8_t> mask(V);
+  for (uint32_t v = 0; v < V; ++v) {
+    const bool l = lethal[v] != 0, inv = invalid && invalid[v];
+    mask[v] = l ? (inv ? kInflSeedMute : kInflSeed) : (inv ? kInflMute : kInflFree);
+  }
+  std::vector<PopKey> tkey(V, key_inf());
+  std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V), pred(V), cutf(V, kNone);
+  std::vector<float> dirn(V, 0.0f);
+  Ctl ctl[2]; Cnt cnt[4];
+  std::memset(ctl, 0, sizeof(ctl)); std::memset(cnt, 0, sizeof(cnt));
+  Plan P{};
+  P.planner = kPlannerCvp; P.V = V;
+  P.row_ptr = topo.row_ptr.data(); P.nbr = nbr.data();
+  P.crn_ptr = topo.crn_ptr.data(); P.crn = crn.data(); P.blocked = blocked.data();
+  P.dist = dist; P.tkey = tkey.data(); P.keyd = keyd;
+  P.pred = pred.data(); P.dirn = dirn.data(); P.cutf = cutf.data(); P.stamp = stamp.data(); P.dirty = dirty.data();
+  P.list[0] = l0.data(); P.list[1] = l1.data(); P.cap = V;
+  P.ctl = ctl; P.cnt = cnt;
+  P.delta = delta; P.offset = 0.0; P.max_steps = max_steps ? max_steps : 100000000u;
+  P.walk_max = getenv("MNAV_KEY_WALK_MAX") ? atoi(getenv("MNAV_KEY_WALK_MAX")) : kKeyWalkMax;
+  P.descend_max = getenv("MNAV_DESCEND_WALK_MAX") ? atoi(getenv("MNAV_DESCEND_WALK_MAX")) : kDescendWalkMax;
+  for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.seed_expands[k] = 1; P.target[k] = kNone; P.target_expands[k] = 0; }
+  P.seed_mask = mask.data(); P.infl_max = max_distance;
+  for (uint32_t v = 0; v < V; ++v) { dist[v] = inf_f(); keyd[v] = inf_f(); pred[v] = v; }
+  Cnt& c_init = cnt[2];
+  cnt[0].minkey = cnt[1].minkey = f2u(inf_f());
+  c_init.minkey = f2u(inf_f());
+  {
+    HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu };
+    for (uint32_t s = 0; s < V; ++s) {                              // like k_infl_seed
+      if (!is_seed(P, s)) continue;
+      dist[s] = 0.0f; tkey[s] = make_key(0.0f, s); keyd[s] = 0.0f;
+      for (uint32_t i = P.crn_ptr[s]; i < P.crn_ptr[s + 1]; ++i) {
+        if (!is_seed(P, P.crn[i].v1)) ops.push(P.crn[i].v1);
+        if (!is_seed(P, P.crn[i].v2)) ops.push(P.crn[i].v2);
       }
-    } else if (cur.repair) {
-      for (uint32_t v = 0; v < V; ++v) {
-        if (planner == kPlannerCvp) process_repair<kPlannerCvp>(P, cur, v, ops);
-        else process_repair<kPlannerDijkstra>(P, cur, v, ops);
-      }
-    } else {
-      perm.resize(cur.n);
-      for (uint32_t i = 0; i < cur.n; ++i) perm[i] = i;
-      if (order == 1) std::reverse(perm.begin(), perm.end());
-      if (order == 2)
-        for (uint32_t i = cur.n; i > 1; --i) {
-          rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
-          std::swap(perm[i - 1], perm[rng % i]);
-        }
-      if (order == 3) {
-        // snapshot of everything the rules read
-        std::vector<float> sd(dist, dist + V), sdir; std::vector<uint32_t> sp(pred, pred + V), scut;
-        std::vector<PopKey> sk(tkey);
-        if (planner == kPlannerCvp) { sdir.assign(dirn, dirn + V); scut.assign(cutf, cutf + V); }
-        Plan R = P;
-        R.dist = sd.data(); R.pred = sp.data(); R.tkey = sk.data();
-        if (planner == kPlannerCvp) { R.dirn = sdir.data(); R.cutf = scut.data(); }
-        for (uint32_t i = 0; i < cur.n; ++i) {
-          if (planner == kPlannerCvp) process_entry_rw<kPlannerCvp>(R, P, cur, list[i], ops);
-          else process_entry_rw<kPlannerDijkstra>(R, P, cur, list[i], ops);
-        }
-      } else
-      for (uint32_t i = 0; i < cur.n; ++i) {
-        const uint32_t vv = list[perm[i]];
-        const bool tr = trace_v == vv;
-        const float bd = dist[vv];
-        if (planner == kPlannerCvp) process_entry<kPlannerCvp>(P, cur, vv, ops);
-        else process_entry<kPlannerDijkstra>(P, cur, vv, ops);
-        if (tr) {
-          fprintf(stderr, "step %d thr [%.6f, %.6f) band_new %u v %u: d %.7f -> %.7f key t0 %.7f up %.0f lvl %u dirty %u\n", j, cur.thr_fixed, cur.thr, cur.band_new, vv, bd, dist[vv], key_time(tkey[vv]), (double)tkey[vv].up, (unsigned)tkey[vv].lvl, dirty[vv]);
-          for (uint32_t ci = P.crn_ptr[vv]; ci < P.crn_ptr[vv + 1]; ++ci) {
-            const Corner k = P.crn[ci];
-            const Fire f = corner_fire(P, cur, k);
-            fprintf(stderr, "    corner face %u v1 %u (d %.7f t0 %.7f up %.0f lvl %u) v2 %u (d %.7f t0 %.7f up %.0f lvl %u) trig %u\n", k.face, k.v1, dist[k.v1], key_time(tkey[k.v1]), (double)tkey[k.v1].up, (unsigned)tkey[k.v1].lvl, k.v2, dist[k.v2], key_time(tkey[k.v2]), (double)tkey[k.v2].up, (unsigned)tkey[k.v2].lvl, f.trig);
-          }
-        }
-      }
-    }
-    evals += cc.evals;
-    if (sm_cycle >= 0 && j >= sm_cycle && j < sm_cycle + 8) {   // debugging aid
-      static std::vector<float> pd; static std::vector<PopKey> pk;
-      if (pd.size() == V) {
-        fprintf(stderr, "== step %d thr [%.7f, %.7f) n=%u changed=%u\n", j, cur.thr_fixed, cur.thr, cur.n, cc.changed);
-        for (uint32_t v = 0; v < V; ++v)
-          if (f2u(pd[v]) != f2u(dist[v]) || pk[v] != tkey[v])
-            fprintf(stderr, "   v %u: d %.7f -> %.7f  key (t0 %.7f root %u up %d lvl %u) -> (t0 %.7f root %u up %d lvl %u) pred %u\n", v, pd[v], dist[v],
-                    key_time(pk[v]), pair_id(pk[v].hi), (int)pk[v].up, pk[v].lvl, key_time(tkey[v]), pair_id(tkey[v].hi), (int)tkey[v].up, tkey[v].lvl, pred[v]);
-      }
-      pd.assign(dist, dist + V); pk = tkey;
     }
   }
-  // model of k_cvp_verify: one more evaluation of every vertex on the converged state must reproduce it, and no
-  // walk over the cascade tree may hit its bound there (flags raised during the iteration are transient)
-  uint64_t verify_bad = 0, verify_flags = 0;
-  if (planner == kPlannerCvp && cur.done && !cur.overflow) {
-    cnt[3].n_next = 0; cnt[3].changed = 0;
-    for (uint32_t v = 0; v < V; ++v) {
-      if (is_seed(P, v) || blocked[v]) continue;
-      const Eval e = eval_cvp(P, cur, v);
-      const bool same = f2u(e.d) == f2u(dist[v]) && e.key == tkey[v] && e.pred == pred[v] &&
-                        (!(e.d < inf_f()) || (e.cut == cutf[v] && f2u(e.dir) == f2u(dirn[v])));
-      if (!same) ++verify_bad;
-    }
-    verify_flags = cnt[3].n_next;
-  }
-  if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks;
-                   stats_out[5] = verify_bad; stats_out[6] = verify_flags; }
-  if (goal_dist_out) *goal_dist_out = cur.goal_dist;
-  return cur.overflow ? kInternalError : kSuccess;   // overflow == 2: step cap hit (no convergence)
+  c_init.changed = 1;
+  Ctl& c0 = ctl[1];                                                 // like k_infl_ctl
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.thr = delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
+  c0.band_new = 1; c0.width = delta;
+  return drive(P, kPlannerCvp, order, ctl, cnt, tkey, blocked, stats_out, nullptr);
+}
+
+// the product's waveFrontUpdate arithmetic on plain numbers (mnav_eval.h infl_candidate): value offered to the free
+// vertex, or NaN when it is not finite; *requeue = the :311 condition
+float sm_infl_candidate(float u1, float u2, float a, float b, float c, float max_distance, int* requeue)
+{
+  const InflCand k = infl_candidate(u1, u2, a, b, c, max_distance);
+  if (requeue) *requeue = k.requeue ? 1 : 0;
+  return k.ok ? k.u3tmp : NAN;
 }
 
 }  // extern "C"

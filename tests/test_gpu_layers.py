@@ -1,0 +1,90 @@
+"""Cost layers on the device: Steepness, the Inflation wave (InflationLayer::waveCostInflation,
+inflation_layer.cpp:341-491, replayed on the ordered-wave engine), Combination and the edge weights without a host
+copy of a V-sized array -- against the oracle, which tests/test_ref_pins_oracle.py pins to the reference's own
+InflationLayer / CombinationLayer / MeshMap code."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from oracle import oracle as O
+from tests.common import Case
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def upload(ctx, case):
+    ctx.upload_mesh(case.mesh.xyz, case.mesh.faces, case.mesh.edges, case.vn)
+
+
+@pytest.mark.parametrize("N,seed", [(96, 7), (300, 3)])
+def test_inflation_distances_and_costs_are_the_reference_bits(gpu_ctx_factory, N, seed):
+    case = Case(meshgen.terrain(N, 0.1, seed))
+    steep, lethal = case.om.steepness(case.vn, 0.3)
+    cost, dist, _ = case.om.inflation(lethal, case.edge_dist)
+    ctx = gpu_ctx_factory()
+    upload(ctx, case)
+    ctx.layer_upload(0, steep, lethal)                          # the input layer as computed by the oracle: same lethal set
+    st = ctx.layer_inflation(1, 0)
+    c, le, d = ctx.layer_download(1, distances=True)
+    assert np.array_equal(bits(d), bits(dist)), int((bits(d) != bits(dist)).sum())
+    assert np.array_equal(bits(c), bits(cost))
+    assert np.array_equal(le, lethal)                           # lethal_vertices_ = input->lethals() (:170)
+    assert st["bands"] <= 3 and st["steps"] > 0
+
+
+def test_sparse_sources_wide_radius_invalid_vertices(gpu_ctx_factory):
+    rng = np.random.default_rng(0)
+    case = Case(meshgen.terrain(128, 0.1, 2))
+    m = case.mesh
+    lethal = np.zeros(m.V, np.uint8)
+    lethal[m.edges[rng.choice(m.E, m.E // 200, replace=False)].ravel()] = 1
+    lethal[rng.choice(m.V, m.V // 60, replace=False)] = 1       # plus isolated ones: zero-distance vertices the wave fills around backwards
+    invalid = np.zeros(m.V, np.uint8)
+    invalid[rng.choice(m.V, m.V // 40, replace=False)] = 1
+    ctx = gpu_ctx_factory()
+    upload(ctx, case)
+    ctx.layer_upload(0, np.zeros(m.V, np.float32), lethal)
+    for radius, inv in ((0.4, None), (1.3, None), (1.3, invalid), (0.4, invalid)):
+        cfg = O.InflationCfg.defaults()
+        cfg.inflation_radius = radius
+        cost, dist, _ = case.om.inflation(lethal, case.edge_dist, cfg, invalid=inv)
+        ctx.layer_inflation(1, 0, inflation_radius=radius, invalid=inv)
+        c, _, d = ctx.layer_download(1, distances=True)
+        assert np.array_equal(bits(d), bits(dist)), (radius, inv is not None, int((bits(d) != bits(dist)).sum()))
+        assert np.array_equal(bits(c), bits(cost))
+
+
+def test_c3_cost_stack_stays_on_the_device(gpu_ctx_factory):
+    """Steepness -> Inflation -> weighted sum -> edge weights (BASELINE config 3's costs), all resident; then both
+    planners on those costs against the oracle on the SAME costs.  Steepness uses the device's acosf, which may
+    differ from the host libm's by an ulp, so the stack is compared layer by layer with the device's steepness as
+    the common input; the lethal sets must agree exactly on this mesh."""
+    case = Case(meshgen.terrain(160, 0.1, 3))
+    m = case.mesh
+    ctx = gpu_ctx_factory()
+    upload(ctx, case)
+    ctx.layer_steepness(0, 0.3)
+    steep_d, lethal_d = ctx.layer_download(0)
+    steep, lethal = case.om.steepness(case.vn, 0.3)
+    assert np.array_equal(lethal_d, lethal)
+    assert np.max(np.abs(steep_d - steep)) <= 2.5e-7             # acosf: <= 2 ulp near pi/2... 1 ulp of 1.0 = 1.2e-7
+    ctx.layer_inflation(1, 0)
+    infl_d, _, dist_d = ctx.layer_download(1, distances=True)
+    infl, dist, _ = case.om.inflation(lethal, case.edge_dist)
+    assert np.array_equal(bits(dist_d), bits(dist)) and np.array_equal(bits(infl_d), bits(infl))
+    for mode in ("avg", "max"):
+        ctx.combine_layers([0, 1], [1.0, 1.0], mode=mode, edge_cost_factor=1.0)
+        vc, w = ctx.download_costs()
+        want_vc = O.combine([steep_d, infl_d], [1.0, 1.0], mode)
+        want_w = case.om.edge_weights(case.edge_dist, want_vc, 1.0)
+        assert np.array_equal(bits(vc), bits(want_vc)) and np.array_equal(bits(w), bits(want_w))
+    # planners on the resident costs (max combination left resident)
+    free = np.nonzero(want_vc < 0.5)[0]
+    s, t = int(free[len(free) // 7]), int(free[-len(free) // 9])
+    ref = case.om.dijkstra(want_w, want_vc, s, t)
+    out = ctx.plan_dijkstra(s, t)
+    assert out.code == ref.code and np.array_equal(bits(out.dist), bits(ref.dist)) and np.array_equal(out.pred, ref.pred)
