@@ -9,7 +9,15 @@ before the timed region; each plan returns its vertex-index path, the V-sized fi
 device.  For N > 1 every rank (one per GPU) runs its own batches on its own replica of the mesh:
 the path shards by plan, there is no data-path collective (weak scaling).
 
-Prints ONE JSON line (see the task contract).  `value` = plans/s of the whole job.
+Prints ONE JSON line (see the task contract).  `value` = plans/s of the whole job (C2).  Rank 0 then measures, outside
+the timed region, the other BASELINE configurations on the same GPU and reports them under "configs", each with its own
+roofline and cpu_baseline objects:
+  C5  64 concurrent goals on the C2 mesh (one batch)
+  C3  CVP wavefront on the 1M mesh (seed 3) with Steepness + Inflation costs, the whole cost stack built on the device
+  C4  Dijkstra on the 10M-vertex mesh (N=3163, seed 4): single plan and a batch (skip with --skip-c4)
+plus the vector-map-inclusive batch rate and the adapter-inclusive ms/makePlan (MeshPlanner surface, 1M).
+`--config C4 --gpus N` (under torch.distributed.run) times ONE plan range-partitioned over N GPUs instead (strong scaling,
+mesh_navigation_amd/sharded.py: RCCL min-allreduce of the interface distances).
 """
 from __future__ import annotations
 
@@ -27,6 +35,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy
 
 
+def vertex_normals(mesh) -> np.ndarray:
+    """normalised sum of the unit face normals (only the vector maps and the Steepness layer read them)"""
+    p = mesh.xyz.astype(np.float64)
+    fnrm = np.cross(p[mesh.faces[:, 1]] - p[mesh.faces[:, 0]], p[mesh.faces[:, 2]] - p[mesh.faces[:, 0]])
+    fnrm /= np.maximum(np.linalg.norm(fnrm, axis=1, keepdims=True), 1e-30)
+    vnrm = np.zeros_like(p)
+    for k in range(3):
+        for c in range(3):
+            vnrm[:, c] += np.bincount(mesh.faces[:, k], weights=fnrm[:, c], minlength=mesh.V)
+    vnrm /= np.maximum(np.linalg.norm(vnrm, axis=1, keepdims=True), 1e-30)
+    return vnrm.astype(np.float32), fnrm.astype(np.float32)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,6 +60,11 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-all-cores-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-latency", action="store_true", help="skip the single-plan latency runs (profiling)")
+    ap.add_argument("--config", default="C2", choices=["C2", "C4"], help="C2: the headline batch bench; C4: one sharded plan on the 10M mesh")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C3/C4/C5 legs (profiling the headline kernel)")
+    ap.add_argument("--skip-c4", action="store_true", help="skip the 10M-vertex leg")
+    ap.add_argument("--c4-grid", type=int, default=int(os.environ.get("MNAV_BENCH_C4_N", "3163")))
+    ap.add_argument("--c4-batch", type=int, default=int(os.environ.get("MNAV_BENCH_C4_BATCH", "512")))
     args = ap.parse_args()
     if args.cpu_all_cores_child:
         return cpu_all_cores_child(args)
@@ -60,19 +86,15 @@ def main() -> None:
 
     from mesh_navigation_amd import capi, meshgen
 
+    if args.config == "C4":
+        return sharded_c4(args, torch, dist, rank, local_rank, world)
+
     N, B = args.grid, args.batch
     mesh = meshgen.terrain(N, 0.1, 2)
     edge_w = meshgen.edge_lengths(mesh)                  # edge_cost_factor 0 -> weights == edge distances
     costs = np.zeros(mesh.V, np.float32)
     ctx = capi.MnavContext(local_rank)
-    # vertex normals (normalised sum of unit face normals) -- only the CVP vector map reads them
-    p = mesh.xyz.astype(np.float64)
-    fnrm = np.cross(p[mesh.faces[:, 1]] - p[mesh.faces[:, 0]], p[mesh.faces[:, 2]] - p[mesh.faces[:, 0]])
-    fnrm /= np.maximum(np.linalg.norm(fnrm, axis=1, keepdims=True), 1e-30)
-    vnrm = np.zeros_like(p)
-    for k in range(3):
-        np.add.at(vnrm, mesh.faces[:, k], fnrm)
-    vnrm /= np.maximum(np.linalg.norm(vnrm, axis=1, keepdims=True), 1e-30)
+    vnrm, fnrm = vertex_normals(mesh)
     ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, vnrm.astype(np.float32))
     ctx.upload_costs(costs, edge_w)
     robot = mesh.vertex_at(0.9, 0.9)
@@ -165,7 +187,7 @@ def main() -> None:
         # prescribes, WRITE_SIZE as is) -- only quoted when it was measured on this very workload.
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             if pm.get("kernel") == "k_plan_persistent" and launches <= args.steps and B == pm.get("batch", 1024) and N == 1000:
                 traffic = pm["traffic_bytes_per_launch_high"]
         except (OSError, ValueError, KeyError):
@@ -203,6 +225,321 @@ def main() -> None:
         }
         if not args.no_cpu and world >= 1:
             out["cpu_baseline"] = cpu_baseline(mesh, edge_w, costs, first, B, args.offset)
+        if not args.no_configs:
+            cfgs = {}
+            t_cfg = time.perf_counter()
+            for name, leg in (("C2_vector_map_inclusive", lambda: leg_vecmap_inclusive(ctx, batch_goals, args)),
+                              ("C5", lambda: leg_c5(ctx, mesh, edge_w, costs, robot, args))):
+                cfgs[name] = run_leg(leg)
+            ctx.close(); ctx = None                                   # free the 5120 plan slots before the other meshes
+            cfgs["C2_adapter_inclusive"] = run_leg(lambda: leg_adapter(mesh, vnrm, fnrm, edge_w, costs, first, robot))
+            cfgs["C3"] = run_leg(lambda: leg_c3(local_rank, args))
+            if not args.skip_c4:
+                cfgs["C4"] = run_leg(lambda: leg_c4(local_rank, args))
+            cfgs["wall_s"] = time.perf_counter() - t_cfg
+            out["configs"] = cfgs
+        print(json.dumps(out), flush=True)
+    if ctx is not None:
+        ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+
+def run_leg(fn):
+    """A failing side leg must not take the headline line with it: its error is reported in its place."""
+    t = time.perf_counter()
+    try:
+        r = fn()
+    except Exception as e:                                              # noqa: BLE001 -- reported, not swallowed
+        r = {"error": repr(e)[:400]}
+    r["leg_wall_s"] = round(time.perf_counter() - t, 2)
+    return r
+
+
+def roofline_of(stats, kernel):
+    """achieved = algorithmic bytes per launch / average launch duration (HIP events on the library's stream)"""
+    launches = max(int(stats["launches"]), 1)
+    per_s = stats["ms_step_kernels"] * 1e-3 / launches
+    ach = (stats["algorithmic_bytes"] / launches) / per_s / 1e9 if per_s > 0 else 0.0
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": kernel, "launches": launches, "avg_launch_us": per_s * 1e6,
+            "algorithmic_bytes": int(stats["algorithmic_bytes"]), "propagation_ms": stats["ms_propagation"]}
+
+
+def host_cpu():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def leg_vecmap_inclusive(ctx, batch_goals, args):
+    """The headline batch with the vector map of every plan computed on the device (what makePlan leaves behind for
+    getVectorMap(), dijkstra_mesh_planner.cpp:189-209); V-sized outputs stay resident, paths come back."""
+    ctx.set_resident_outputs(True)
+    try:
+        g, t = batch_goals()
+        ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
+        ts = []
+        vm = 0.0
+        for _ in range(2):
+            g, t = batch_goals()
+            t0 = time.perf_counter()
+            r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
+            ts.append(time.perf_counter() - t0)
+            vm += r["stats"]["ms_vector_map"]
+        return {"workload": f"C2 batch of {len(g)} plans incl. computeVectorMap on the device", "plans_per_s": len(g) / float(np.median(ts)),
+                "ms_per_step": float(np.median(ts)) * 1e3, "ms_vector_map_per_step": vm / 2}
+    finally:
+        ctx.set_resident_outputs(False)
+
+
+def leg_c5(ctx, mesh, edge_w, costs, robot, args):
+    """BASELINE config 5 on one GPU: 64 goal vertices drawn with rng(5) among the cost-free vertices, common robot
+    vertex, ONE batch (with N GPUs the goals are sharded by rank, mesh_navigation_amd/multi.py)."""
+    goals = np.random.default_rng(5).choice(mesh.V, size=64, replace=False).astype(np.uint32)
+    tg = np.full(64, robot, np.uint32)
+    ts = []
+    r = None
+    for k in range(13):
+        t0 = time.perf_counter()
+        r = ctx.plan_dijkstra_batch(goals, tg, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
+        if k >= 3:
+            ts.append(time.perf_counter() - t0)
+    assert (r["codes"] == 0).all()
+    med = float(np.median(ts))
+    st = r["stats"]
+    out = {"workload": "C5: 64 concurrent goals, common robot vertex, 1M-vertex C2 mesh, one batch on one GPU",
+           "plans_per_s": 64 / med, "ms_per_batch": med * 1e3, "ms_per_batch_p95": float(np.percentile(ts, 95)) * 1e3,
+           "roofline": roofline_of(st, "k_tile_round" if st["launches"] > 1 else "k_plan_persistent")}
+    if not args.no_cpu:
+        from oracle import oracle as O
+        om = O.OracleMesh(mesh.xyz, mesh.faces)
+        t_sum, ok = 0.0, True
+        n = 8
+        for k in range(n):
+            ref = om.dijkstra(edge_w, costs, int(goals[k]), robot, goal_dist_offset=args.offset)
+            t_sum += ref.stats["t_init_ms"] + ref.stats["t_propagation_ms"] + ref.stats["t_backtrack_ms"]
+            ok = ok and ref.code == int(r["codes"][k]) and np.array_equal(ref.path, r["paths"][k])
+        out["cpu_baseline"] = {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n} of the 64 goals, oracle Dijkstra single thread", "gpu_paths_match_oracle": bool(ok)}
+    return out
+
+
+def leg_adapter(mesh, vnrm, fnrm, edge_w, costs, first, robot):
+    """ms per MeshPlanner::makePlan through the adapter (mesh_navigation_amd/csrc/adapter: nearest-vertex lookup, device
+    plan, pose assembly; V-sized results stay on the device), 1M mesh, cost arrays unchanged between calls."""
+    from mesh_navigation_amd.planner import DijkstraMeshPlanner
+    pl = DijkstraMeshPlanner()
+    t0 = time.perf_counter()
+    ok = pl.initialize("dijkstra_mesh_planner", dict(xyz=mesh.xyz, faces=mesh.faces, edges=mesh.edges, vertex_normals=vnrm, face_normals=fnrm,
+                                                      vertex_costs=costs, edge_weights=edge_w, invalid=None))
+    t_init = time.perf_counter() - t0
+    assert ok
+    pl.set_cost_version(1)                                              # the map's change counter: nothing is hashed per call
+    def pose(v):
+        p = mesh.xyz[int(v)]
+        return np.array([p[0], p[1], p[2], 0, 0, 0, 1], np.float64)
+    ts, n_poses = [], 0
+    for k in range(23):
+        g = int(first[0][k])
+        t0 = time.perf_counter()
+        code, plan, cost, msg = pl.makePlan(pose(robot), pose(g))
+        if k >= 3:
+            ts.append(time.perf_counter() - t0)
+            n_poses += len(plan)
+        assert code == 0, (code, msg)
+    pl.close()
+    return {"workload": "DijkstraMeshPlanner::makePlan through the plugin adapter, 1M-vertex C2 mesh, 20 goals after 3 warm-ups",
+            "ms_per_makeplan": float(np.median(ts)) * 1e3, "ms_per_makeplan_p95": float(np.percentile(ts, 95)) * 1e3,
+            "poses_per_plan": n_poses / len(ts), "initialize_s": t_init}
+
+
+def leg_c3(local_rank, args):
+    """BASELINE config 3: CVP wavefront on the 1M mesh (N=1000, seed 3) with Steepness + Inflation vertex costs.  The
+    cost stack (steepness -> inflation wave -> weighted sum -> edge weights, edge_cost_factor 1) is built ON THE DEVICE."""
+    from mesh_navigation_amd import capi, meshgen
+    N = args.grid
+    mesh = meshgen.terrain(N, 0.1, 3)
+    vnrm, _ = vertex_normals(mesh)
+    ctx = capi.MnavContext(local_rank)
+    try:
+        ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, vnrm)
+        t0 = time.perf_counter()
+        ctx.layer_steepness(0, 0.3)
+        infl = ctx.layer_inflation(1, 0)                                # InflationLayer defaults
+        ctx.combine_layers([0, 1], [1.0, 1.0], mode="avg", edge_cost_factor=1.0)
+        t_costs = time.perf_counter() - t0
+        vc, w = ctx.download_costs()
+        _, lethal = ctx.layer_download(0)
+        free = np.nonzero(vc < 0.5)[0]
+        rng = np.random.default_rng(5)
+        first_face = np.full(mesh.V, -1, np.int64)
+        fl = mesh.faces.ravel()
+        first_face[fl[::-1]] = (np.arange(fl.size)[::-1] // 3)
+        def wave_seed(v):
+            f = int(first_face[v])
+            return mesh.xyz[mesh.faces[f]].astype(np.float64).mean(axis=0).astype(np.float32), f
+        robot = int(free[np.argmin(np.abs(mesh.xyz[free, 0] - 0.9 * N * 0.1) + np.abs(mesh.xyz[free, 1] - 0.9 * N * 0.1))])
+        tf = int(first_face[robot])
+        goals = rng.choice(free, size=160, replace=False)
+        lat, codes, st = [], [], None
+        for k in range(13):
+            sp, sf = wave_seed(int(goals[k]))
+            o = ctx.plan_cvp(sp, sf, tf, want_fields=False, want_vecmap=False)
+            codes.append(int(o.code))
+            if k >= 3:
+                lat.append(o.stats["ms_total"])
+                st = o.stats
+        # with the vector map (what the back-tracking of makePlan reads), left resident
+        ctx.set_resident_outputs(True)
+        latv = []
+        for k in range(8):
+            sp, sf = wave_seed(int(goals[k]))
+            o = ctx.plan_cvp(sp, sf, tf, want_fields=False, want_vecmap=False)
+            if k >= 2:
+                latv.append(o.stats["ms_total"])
+        ctx.set_resident_outputs(False)
+        nb = 128
+        seeds = [wave_seed(int(v)) for v in goals[16:16 + nb]]
+        sps = np.stack([x[0] for x in seeds]); sfs = np.array([x[1] for x in seeds], np.uint32)
+        ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
+        tb = time.perf_counter()
+        rb = ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
+        tb = time.perf_counter() - tb
+        out = {"workload": f"C3: CVP wavefront, {N}x{N} terrain seed 3 = {mesh.V} vertices, Steepness(0.3) + Inflation(defaults) avg-combined, "
+                           f"edge_cost_factor 1, cost_limit 1, goal_dist_offset 0.3",
+               "lethal_vertices": int(lethal.sum()), "cost_stack_on_device_ms": t_costs * 1e3, "inflation_wave": infl,
+               "ms_per_plan_single": float(np.median(lat)), "ms_per_plan_single_p95": float(np.percentile(lat, 95)),
+               "ms_per_plan_single_with_vector_map": float(np.median(latv)),
+               "codes_single": sorted(set(codes)), "batch": nb, "plans_per_s_batch": nb / tb,
+               "codes_batch": sorted(set(int(c) for c in rb["codes"])),
+               "roofline": roofline_of(rb["stats"], "k_step<cvp>"), "roofline_single_plan": roofline_of(st, "k_step<cvp>")}
+        if not args.no_cpu:
+            from oracle import oracle as O
+            om = O.OracleMesh(mesh.xyz, mesh.faces)
+            vn = vnrm
+            t_sum, n, ok = 0.0, 3, True
+            tw = time.perf_counter()
+            for k in range(n):
+                sp, sf = wave_seed(int(goals[k]))
+                ref = om.cvp(w, vc, vn, sp, sf, tf)
+                t_sum += ref.stats["t_init_ms"] + ref.stats["t_propagation_ms"]
+                ok = ok and ref.code == codes[k]
+            out["cpu_baseline"] = {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "ms_per_plan": t_sum / n,
+                                   "sample": f"{n} of the single plans, oracle CVP wavefront single thread (propagation, no back-tracking), {time.perf_counter() - tw:.1f} s wall",
+                                   "codes_match_oracle": bool(ok)}
+        return out
+    finally:
+        ctx.close()
+
+
+def leg_c4(local_rank, args):
+    """BASELINE config 4 on ONE GPU: Dijkstra on the 10M-vertex terrain (N=3163, seed 4, C2 settings): single plan and a
+    batch.  The range-partitioned version of the same plan over N GPUs is `--config C4 --gpus N`."""
+    from mesh_navigation_amd import capi, meshgen
+    N = args.c4_grid
+    t0 = time.perf_counter()
+    mesh = meshgen.terrain(N, 0.1, 4)
+    edge_w = meshgen.edge_lengths(mesh)
+    costs = np.zeros(mesh.V, np.float32)
+    t_gen = time.perf_counter() - t0
+    ctx = capi.MnavContext(local_rank)
+    try:
+        t0 = time.perf_counter()
+        ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
+        ctx.upload_costs(costs, edge_w)
+        t_up = time.perf_counter() - t0
+        robot = mesh.vertex_at(0.9, 0.9)
+        rng = np.random.default_rng(5)
+        B = args.c4_batch
+        goals = rng.choice(mesh.V, size=B, replace=False).astype(np.uint32)
+        lat, st = [], None
+        for k in range(7):
+            o = ctx.plan_dijkstra(int(goals[k]), robot, goal_dist_offset=args.offset, want_fields=False)
+            assert o.code == 0
+            if k >= 2:
+                lat.append(o.stats["ms_total"]); st = o.stats
+        tg = np.full(B, robot, np.uint32)
+        ctx.plan_dijkstra_batch(goals, tg, goal_dist_offset=args.offset, want_fields=False, path_cap=65536)
+        tb = time.perf_counter()
+        rb = ctx.plan_dijkstra_batch(goals, tg, goal_dist_offset=args.offset, want_fields=False, path_cap=65536)
+        tb = time.perf_counter() - tb
+        assert (rb["codes"] == 0).all()
+        sb = rb["stats"]
+        out = {"workload": f"C4: delta-stepping SSSP, {N}x{N} terrain seed 4 = {mesh.V} vertices, uniform edge costs, goal_dist_offset {args.offset:g}, one GPU",
+               "vertices": mesh.V, "edges": mesh.E, "mesh_generation_s": t_gen, "upload_and_tiling_s": t_up,
+               "ms_per_makeplan_single": float(np.median(lat)), "ms_per_makeplan_single_p95": float(np.percentile(lat, 95)),
+               "batch": B, "plans_per_s_batch": B / tb, "ms_per_batch": tb * 1e3,
+               "roofline": roofline_of(sb, "k_plan_persistent" if sb["launches"] <= 1 else "k_tile_round"),
+               "roofline_single_plan": roofline_of(st, "k_tile_round")}
+        if not args.no_cpu:
+            from oracle import oracle as O
+            om = O.OracleMesh(mesh.xyz, mesh.faces)
+            t_sum, n, ok = 0.0, 2, True
+            for k in range(n):
+                ref = om.dijkstra(edge_w, costs, int(goals[k]), robot, goal_dist_offset=args.offset)
+                t_sum += ref.stats["t_init_ms"] + ref.stats["t_propagation_ms"] + ref.stats["t_backtrack_ms"]
+                ok = ok and ref.code == 0 and np.array_equal(ref.path, rb["paths"][k])
+            out["cpu_baseline"] = {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "ms_per_plan": t_sum / n,
+                                   "sample": f"{n} plans of the batch, oracle Dijkstra single thread", "gpu_paths_match_oracle": bool(ok)}
+        return out
+    finally:
+        ctx.close()
+
+
+def sharded_c4(args, torch, dist, rank, local_rank, world):
+    """`--config C4 --gpus N`: ONE Dijkstra plan on the 10M mesh, range-partitioned over the N GPUs (strong scaling).
+    A step = one plan; every rank holds the mesh, owns a range of the Morton-ordered tiles and exchanges the interface
+    distances with one RCCL min-allreduce per block of local rounds (mesh_navigation_amd/sharded.py)."""
+    from mesh_navigation_amd import capi, meshgen, sharded
+    N = args.c4_grid
+    mesh = meshgen.terrain(N, 0.1, 4)
+    edge_w = meshgen.edge_lengths(mesh)
+    costs = np.zeros(mesh.V, np.float32)
+    ctx = capi.MnavContext(local_rank)
+    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
+    ctx.upload_costs(costs, edge_w)
+    eng = sharded.GpuShardEngine(ctx, rank, world)
+    red = sharded.torch_allreduce_min(dist) if dist is not None else (lambda x: None)
+    robot = mesh.vertex_at(0.9, 0.9)
+    goals = np.random.default_rng(5).choice(mesh.V, size=args.steps + args.warmup, replace=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for k in range(args.warmup):
+        res = sharded.run_sharded_plan(eng, red, int(goals[k]), robot, args.offset, max_exchanges=200000)
+    barrier()
+    t0 = time.perf_counter()
+    exch = 0
+    for k in range(args.steps):
+        res = sharded.run_sharded_plan(eng, red, int(goals[args.warmup + k]), robot, args.offset, max_exchanges=200000)
+        assert res.code == 0
+        exch += res.exchanges
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        out = {"metric": "plans/sec (one Dijkstra plan range-partitioned over the GPUs, 10M-vertex mesh)", "value": args.steps / elapsed,
+               "unit": "plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"C4 sharded: {N}x{N} terrain = {mesh.V} vertices, tiles range-partitioned over {world} GPU(s), "
+                                      f"min-allreduce of {eng.n} interface floats per exchange", "exchanges_per_plan": exch / args.steps,
+                          "path_len": int(len(res.path))},
+               "roofline": None, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:

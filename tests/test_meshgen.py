@@ -23,3 +23,12 @@ def test_terrain_is_seeded_and_ccw():
     assert not np.array_equal(a.xyz, meshgen.terrain(20, 0.1, 10).xyz)
     om = O.OracleMesh(a.xyz, a.faces)
     assert (om.face_normals()[:, 2] > 0).all()
+
+
+def test_grid_edges_closed_form_matches_first_appearance_order():
+    """meshgen.grid_edges (no sort; the 10M-vertex bench mesh) == edges_from_faces(grid_faces) (lvr2/pmp edge ids)"""
+    from mesh_navigation_amd import meshgen
+    for N in (2, 3, 7, 33):
+        e1, fe1 = meshgen.edges_from_faces(meshgen.grid_faces(N))
+        e2, fe2 = meshgen.grid_edges(N)
+        assert np.array_equal(e1, e2) and np.array_equal(fe1, fe2)
