@@ -370,14 +370,33 @@ def leg_c3(local_rank, args):
     ctx = capi.MnavContext(local_rank)
     try:
         ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, vnrm)
-        t0 = time.perf_counter()
-        ctx.layer_steepness(0, 0.3)
-        infl = ctx.layer_inflation(1, 0)                                # InflationLayer defaults
-        ctx.combine_layers([0, 1], [1.0, 1.0], mode="avg", edge_cost_factor=1.0)
-        t_costs = time.perf_counter() - t0
-        vc, w = ctx.download_costs()
-        _, lethal = ctx.layer_download(0)
-        free = np.nonzero(vc < 0.5)[0]
+        def stack(threshold):
+            t0 = time.perf_counter()
+            ctx.layer_steepness(0, threshold)
+            infl = ctx.layer_inflation(1, 0)                            # InflationLayer defaults
+            ctx.combine_layers([0, 1], [1.0, 1.0], mode="avg", edge_cost_factor=1.0)
+            ms = (time.perf_counter() - t0) * 1e3
+            vc, w = ctx.download_costs()
+            _, lethal = ctx.layer_download(0)
+            import scipy.sparse as sp
+            import scipy.sparse.csgraph as cg
+            fr = vc < 1.0                                               # vertices a wave may run over (cost_limit 1)
+            e = mesh.edges
+            ok = fr[e[:, 0]] & fr[e[:, 1]]
+            g = sp.coo_matrix((np.ones(int(ok.sum()), np.int8), (e[ok, 0], e[ok, 1])), shape=(mesh.V, mesh.V)).tocsr()
+            _, lab = cg.connected_components(g, directed=False)
+            sizes = np.bincount(lab[fr]) if fr.any() else np.zeros(1, np.int64)
+            big = int(np.argmax(sizes))
+            info = {"steepness_threshold": threshold, "lethal_vertices": int(lethal.sum()), "traversable_vertices": int(fr.sum()),
+                    "largest_traversable_component": int(sizes.max()), "cost_stack_on_device_ms": ms, "inflation_wave": infl}
+            return vc, w, lethal, np.nonzero((lab == big) & fr)[0], info
+        # As specified (threshold 0.3 rad) the seed-3 terrain is 56 % lethal and, after inflation, falls apart into
+        # islands of < 300 vertices: no wave gets anywhere.  The cost stack is timed on it; the PLANS are measured with
+        # the threshold at 0.6 rad (3 % lethal, one component of 87 % of the mesh) -- stated in `workload`.
+        _, _, _, _, spec = stack(0.3)
+        vc, w, lethal, free, used = stack(0.6)
+        t_costs = used["cost_stack_on_device_ms"] * 1e-3
+        infl = used["inflation_wave"]
         rng = np.random.default_rng(5)
         first_face = np.full(mesh.V, -1, np.int64)
         fl = mesh.faces.ravel()
@@ -386,6 +405,7 @@ def leg_c3(local_rank, args):
             f = int(first_face[v])
             return mesh.xyz[mesh.faces[f]].astype(np.float64).mean(axis=0).astype(np.float32), f
         robot = int(free[np.argmin(np.abs(mesh.xyz[free, 0] - 0.9 * N * 0.1) + np.abs(mesh.xyz[free, 1] - 0.9 * N * 0.1))])
+        free = free[vc[free] < 0.5]                                       # goals well inside the traversable component
         tf = int(first_face[robot])
         goals = rng.choice(free, size=160, replace=False)
         lat, codes, st = [], [], None
@@ -412,9 +432,15 @@ def leg_c3(local_rank, args):
         tb = time.perf_counter()
         rb = ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
         tb = time.perf_counter() - tb
-        out = {"workload": f"C3: CVP wavefront, {N}x{N} terrain seed 3 = {mesh.V} vertices, Steepness(0.3) + Inflation(defaults) avg-combined, "
-                           f"edge_cost_factor 1, cost_limit 1, goal_dist_offset 0.3",
-               "lethal_vertices": int(lethal.sum()), "cost_stack_on_device_ms": t_costs * 1e3, "inflation_wave": infl,
+        # full-field variant (goal_dist_offset = +inf): the cleanest roofline denominator
+        sp0, sf0 = wave_seed(int(goals[0]))
+        ctx.plan_cvp(sp0, sf0, tf, goal_dist_offset=float("inf"), want_fields=False, want_vecmap=False)
+        of = ctx.plan_cvp(sp0, sf0, tf, goal_dist_offset=float("inf"), want_fields=False, want_vecmap=False)
+        out = {"workload": f"C3: CVP wavefront, {N}x{N} terrain seed 3 = {mesh.V} vertices, Steepness + Inflation(defaults) avg-combined on the device, "
+                           f"edge_cost_factor 1, cost_limit 1, goal_dist_offset 0.3; steepness threshold 0.6 rad for the plans "
+                           f"(the specified 0.3 leaves no traversable component above {spec['largest_traversable_component']} vertices)",
+               "cost_stack_as_specified": spec, "cost_stack_used": used,
+               "full_field": {"ms_per_plan": of.stats["ms_total"], "code": int(of.code), "roofline": roofline_of(of.stats, "k_step<cvp>")},
                "ms_per_plan_single": float(np.median(lat)), "ms_per_plan_single_p95": float(np.percentile(lat, 95)),
                "ms_per_plan_single_with_vector_map": float(np.median(latv)),
                "codes_single": sorted(set(codes)), "batch": nb, "plans_per_s_batch": nb / tb,

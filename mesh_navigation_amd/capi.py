@@ -46,7 +46,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or _build.LIB
+    p = path or os.environ.get("MNAV_LIB") or _build.LIB      # MNAV_LIB: a differently built libmnav.so (perf experiments)
     if path is None and not os.path.exists(p):
         _build.build_lib()
     if not os.path.exists(p):

@@ -338,8 +338,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 
 // grid = (waves per plan, plans).  slot j (0..5) selects the ping-pong control block (j&1) and
 // the counter block (j%3).
+#ifdef MNAV_STEP_OCC                      // experiment knob: waves per SIMD the register allocator must reach (spills if needed)
+#define MNAV_STEP_BOUNDS __launch_bounds__(kWave, MNAV_STEP_OCC)
+#else
+#define MNAV_STEP_BOUNDS __launch_bounds__(kWave)
+#endif
 template <uint32_t PLANNER>
-__global__ __launch_bounds__(kWave) void k_step(const Plan* __restrict__ plans, int j)
+__global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
 {
   const Plan& P = plans[blockIdx.y];
   const int lane = threadIdx.x;
