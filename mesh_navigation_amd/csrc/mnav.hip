@@ -71,6 +71,8 @@ struct StepCtx {
   float lmin;
   uint32_t levals;
   bool lchanged;
+  uint32_t* wcur;       // waiting list of the current epoch (Plan.wlist), entries before this step, epoch id
+  uint32_t wbase, epoch;
 };
 
 // dedup'd, wave-aggregated append of v to the next work list (all lanes of the wave that reach
@@ -93,6 +95,24 @@ __device__ __forceinline__ void push_agg(StepCtx& S, bool want, uint32_t v)
   if (ok) {
     const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (idx < S.P->cap) S.next[idx] = v;
+  }
+}
+
+// dedup'd (per epoch), wave-aggregated append of v to the waiting list (spec: Ops::park, mnav_eval.h)
+__device__ __forceinline__ void park_agg(StepCtx& S, bool want, uint32_t v)
+{
+  bool ok = false;
+  if (want && S.P->wstamp[v] != S.epoch) ok = atomicExch(&S.P->wstamp[v], S.epoch) != S.epoch;
+  const unsigned long long m = __ballot(ok);
+  if (m == 0ull) return;
+  const int leader = __ffsll((long long)m) - 1;
+  const int lane = threadIdx.x & (kWave - 1);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&S.cnt->n_wait, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (ok) {
+    const uint32_t idx = S.wbase + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (idx < S.P->cap) S.wcur[idx] = v;
   }
 }
 
@@ -319,7 +339,7 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
   if ((push_nb || self_again) && sub == 0) S.lchanged = true;
   group_push_neighbours<PLANNER>(S, P, v, sub, push_nb);
   push_agg<true>(S, self_again && sub == 0, v);
-  push_agg<false>(S, retain && sub == 0, v);
+  park_agg(S, retain && sub == 0, v);
   if (retain && sub == 0) S.lmin = fminf(S.lmin, t_new);
 }
 
@@ -356,7 +376,7 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
     s_ctl = cur;
     if (blockIdx.x == 0) {
       P.ctl[j & 1] = cur;
-      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
+      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.pad[0] = z.pad[1] = z.pad[2] = 0;
       P.cnt[(j + 1) % 3] = z;
     }
   }
@@ -364,7 +384,7 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
   const Ctl cur = s_ctl;
   if (cur.done) return;
   Cnt* cnt = &P.cnt[j % 3];
-  StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false };
+  StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch };
   const int sub = lane & (kGroup - 1), grp = lane >> 3;
   const uint32_t ngroups = gridDim.x * kGroupsPerWave;
   const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
@@ -382,12 +402,15 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
       group_process<PLANNER, false>(S, P, cur, active, active ? v : 0u, sub);
     }
   } else {
+    // the work list; in the first step of a band also the waiting list the previous band left behind
     const uint32_t* list = P.list[cur.it & 1];
-    const uint32_t rounds = (cur.n + ngroups - 1) / ngroups;
+    const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
+    const uint32_t ntot = cur.n + cur.wread;
+    const uint32_t rounds = (ntot + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t i = g0 + r * ngroups;
-      const bool active = i < cur.n;
-      const uint32_t v = active ? list[i] : 0u;
+      const bool active = i < ntot;
+      const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
       group_process<PLANNER, false>(S, P, cur, active, v, sub);
     }
   }
@@ -410,7 +433,7 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
 // returns INTERNAL_ERROR instead of a potential that may not be the reference's.
 __global__ void k_flags_reset(const Plan* __restrict__ plans)
 {
-  if (threadIdx.x == 0) { Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; plans[blockIdx.x].cnt[3] = z; }
+  if (threadIdx.x == 0) { Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; plans[blockIdx.x].cnt[3] = z; }
 }
 
 __global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans, int fix, uint32_t* __restrict__ any_bad)
@@ -1501,7 +1524,7 @@ __global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
     P.dist[v] = inf_f();
     P.pred[v] = v;
-    if (P.stamp) { P.stamp[v] = 0u; P.dirty[v] = 0u; }              // work-list state of the band steps only
+    if (P.stamp) { P.stamp[v] = 0u; P.dirty[v] = 0u; P.wstamp[v] = 0u; }   // work-list state of the band steps only
     if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
   }
 }
@@ -1541,12 +1564,12 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = m0 + P.delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
   for (int k = 0; k < ns; ++k) if (!(P.seed_d[k] < c0.thr)) c0.thr = next_up(P.seed_d[k]);   // the first band holds every seed
-  c0.band_new = 1; c0.width = P.delta;
+  c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
   P.ctl[1] = c0;
   P.ctl[0] = c0;
-  Cnt ci; ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u; ci.evals = 0;
+  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u;
   P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"
-  Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
+  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u;
   P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;                         // cnt[3]: sticky flags (mnav_eval.h kFlag*)
 }
 
@@ -1830,12 +1853,12 @@ __global__ void k_infl_ctl(const Plan* __restrict__ plans)
   Ctl c0; memset(&c0, 0, sizeof(c0));
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = P.delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
-  c0.band_new = 1; c0.width = P.delta;
+  c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
   P.ctl[1] = c0;
   P.ctl[0] = c0;
-  Cnt ci; ci.n_next = 0; ci.changed = 1; ci.minkey = 0x7f800000u; ci.evals = 0;
+  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.changed = 1; ci.minkey = 0x7f800000u;
   P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"; k_infl_seed counts the list into it
-  Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0;
+  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u;
   P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;
 }
 
@@ -1904,6 +1927,7 @@ struct Slot {
   float *dist = nullptr, *dirn = nullptr, *vecmap = nullptr;
   PopKey* tkey = nullptr;
   uint32_t *pred = nullptr, *cutf = nullptr, *stamp = nullptr, *dirty = nullptr, *list0 = nullptr, *list1 = nullptr;
+  uint32_t *wlist0 = nullptr, *wlist1 = nullptr, *wstamp = nullptr;
   Ctl* ctl = nullptr;
   Cnt* cnt = nullptr;
   bool cvp_ready = false, band_ready = false;
@@ -2057,6 +2081,7 @@ void free_slot(Slot& s)
 {
   (void)hipFree(s.dist); (void)hipFree(s.tkey); (void)hipFree(s.dirn); (void)hipFree(s.vecmap);
   (void)hipFree(s.pred); (void)hipFree(s.cutf); (void)hipFree(s.stamp); (void)hipFree(s.dirty); (void)hipFree(s.list0); (void)hipFree(s.list1);
+  (void)hipFree(s.wlist0); (void)hipFree(s.wlist1); (void)hipFree(s.wstamp);
   (void)hipFree(s.cnt);
   (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tcnt);
   (void)hipFree(s.wpend); (void)hipFree(s.wtlast);
@@ -2083,6 +2108,7 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp, bool band, bool vec)
     if (band && !s.band_ready) {                                       // work lists of the band/gather steps
       HIPCHK(hipMalloc((void**)&s.stamp, 4 * V)); HIPCHK(hipMalloc((void**)&s.dirty, 4 * V));
       HIPCHK(hipMalloc((void**)&s.list0, 4 * V)); HIPCHK(hipMalloc((void**)&s.list1, 4 * V));
+      HIPCHK(hipMalloc((void**)&s.wlist0, 4 * V)); HIPCHK(hipMalloc((void**)&s.wlist1, 4 * V)); HIPCHK(hipMalloc((void**)&s.wstamp, 4 * V));
       s.band_ready = true;
     }
     if (vec && !s.vecmap) HIPCHK(hipMalloc((void**)&s.vecmap, 12 * V));
@@ -2145,8 +2171,10 @@ int ensure_paths(mnav_ctx* ctx, uint32_t n) { return ensure_paths(ctx, n, defaul
 
 uint32_t blocks_per_plan(const mnav_ctx* ctx)
 {
-  // the work list of a planar mesh is O(sqrt(V)) long; 8 entries per wave and round
-  const double want = 12.0 * std::sqrt((double)ctx->V) / kGroupsPerWave;
+  // the work list of a planar mesh is O(sqrt(V)) long; 8 entries per wave and round.  Measured on the 1M mesh (CVP,
+  // MI355X): 500 waves per plan are as fast as 1500 for a single plan (41.8 vs 41.4 ms) and 25 % faster in a batch of
+  // 128 (225 vs 178 plans/s: fewer idle waves to dispatch per step); 256 waves cost 5 % / 10 %.
+  const double want = 4.0 * std::sqrt((double)ctx->V) / kGroupsPerWave;
   uint32_t g = (uint32_t)std::ceil(want);
   if (const char* e = getenv("MNAV_BLOCKS_PER_PLAN")) g = (uint32_t)atoi(e);
   if (g < 4) g = 4;
@@ -2257,7 +2285,7 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     P.planner = PLANNER; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
     P.dist = s.dist; P.tkey = cvp ? s.tkey : nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = delta; P.offset = offset; P.max_steps = ctx->max_steps; P.walk_max = ctx->walk_max; P.descend_max = ctx->descend_max;
     for (int k = 0; k < 3; ++k) {
       P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = in[i].seed_d[k];
@@ -2417,7 +2445,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     P.planner = kPlannerDijkstra; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
     P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
     for (int k = 0; k < 3; ++k) {
       P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1;
@@ -2532,7 +2560,7 @@ int run_dijkstra_wave(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, 
     P.planner = kPlannerDijkstra; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
     P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
     for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
     P.seed_face = kNone;
@@ -2610,7 +2638,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
     P.planner = kPlannerDijkstra; P.V = ctx->V;
     P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
     P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
     P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
     for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
     P.seed_face = kNone;
@@ -3190,7 +3218,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   P.planner = kPlannerCvp; P.V = V;
   P.row_ptr = ctx->d_row_ptr; P.nbr = nullptr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn_infl; P.blocked = ctx->d_zero_u8;
   P.dist = L.dist; P.tkey = s.tkey; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-  P.list[0] = s.list0; P.list[1] = s.list1; P.cap = V; P.ctl = s.ctl; P.cnt = s.cnt;
+  P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = V; P.ctl = s.ctl; P.cnt = s.cnt;
   const float maxd = (float)inflation_radius;                                               // :438 (const float&)
   P.delta = maxd > 0.f ? maxd : 1.0f;                                                       // one band per radius: the wave dies out within ~2
   P.offset = 0.0; P.max_steps = ctx->max_steps; P.walk_max = ctx->walk_max; P.descend_max = ctx->descend_max;
@@ -3207,7 +3235,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   hipLaunchKernelGGL(k_infl_seed, dim3(gi), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
   HIPCHK(hipGetLastError());
   // the wave front of an inflation is as long as the lethal contours, not O(sqrt V): more waves than a plan gets
-  uint32_t G = blocks_per_plan(ctx) * 4u;
+  uint32_t G = blocks_per_plan(ctx) * 12u;
   if (G > 8192u) G = 8192u;
   const auto t_start = std::chrono::steady_clock::now();
   Ctl last{};
@@ -3681,7 +3709,7 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   P.planner = kPlannerDijkstra; P.V = ctx->V;
   P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
   P.dist = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-  P.list[0] = s.list0; P.list[1] = s.list1; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+  P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
   P.offset = goal_dist_offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
   for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
   P.seed[0] = seed_vertex; P.target[0] = target_vertex; P.seed_face = kNone;

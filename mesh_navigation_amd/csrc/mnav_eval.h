@@ -256,14 +256,23 @@ struct Ctl {
   uint32_t band_steps; // steps spent in the current band
   float width;         // current band width (<= Plan.delta; shrinks when a band does not converge)
   uint32_t shrinks;    // statistics: band shrinks
-  uint32_t pad;
+  // waiting list (see Plan.wlist): keyed vertices beyond the band wait there instead of being carried through every step
+  uint32_t wsel;       // buffer the current band appends to
+  uint32_t wread;      // epoch steps only: entries of the OTHER buffer (the previous band's waiting list) to process
+  uint32_t wbase;      // entries already in the current buffer when this step starts (0 in an epoch step)
+  float wmin;          // smallest pop time parked in the current buffer before this step (+inf in an epoch step); may be
+                       // stale-low when a parked vertex moved up later: the next band then starts lower, never wrong
+  uint32_t epoch;      // id of the current waiting list (1 for the list the first steps append to, then step index of the
+                       // epoch step + 2); Plan.wstamp (0 = never parked) dedups with it
 };
 
 struct Cnt {
   uint32_t n_next;     // entries pushed to the next work list
   uint32_t changed;    // in-band vertices whose (dist, pop time) changed this step
-  uint32_t minkey;     // min pop time (float bits) over retained out-of-band entries
+  uint32_t minkey;     // min pop time (float bits) over the entries parked this step
   uint32_t evals;      // statistics: vertex evaluations
+  uint32_t n_wait;     // entries appended to the waiting list this step
+  uint32_t pad[3];
 };
 
 // Constant per-plan parameters + state pointers.  All pointers address the plan's own slices.
@@ -284,7 +293,11 @@ struct Plan {
   uint32_t* cutf;          // V  (CVP)
   uint32_t* stamp;         // V  work-list dedup
   uint32_t* dirty;         // V  step for which a neighbour asked for a re-evaluation
-  uint32_t* list[2];       // work lists, capacity `cap`
+  uint32_t* list[2];       // work lists, capacity `cap`: vertices to (re-)evaluate in the next step
+  uint32_t* wlist[2];      // waiting lists, capacity `cap`: keyed vertices beyond the band.  They are looked at again when
+                           // a neighbour moves (which puts them on the work list) or when the band advances (the epoch
+                           // step of the next band processes the whole list), not in every step in between
+  uint32_t* wstamp;        // V  epoch in which the vertex was last appended to a waiting list
   uint32_t cap;
   Ctl* ctl;                // [2]
   Cnt* cnt;                // [4]: three rotating step counters + cnt[3] = sticky flags of the plan (kFlag*)
@@ -430,7 +443,7 @@ MNAV_HD void try_arm(const Plan& P, Ctl& q)
 // rebuilds the work list (process_repair below).
 constexpr uint32_t kBandStepLimit = 64;   // a band that is still moving after this many steps is cut down
 
-MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
+MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_wait, uint32_t n_wait)
 {
   Ctl q = p;
   q.it = p.it + 1;
@@ -469,15 +482,29 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
     try_arm(P, q);
     if (q.armed) { q.repair = 1; q.band_new = 0; return q; }
   }
-  const float m = u2f(c.minkey);
+  const float m = m_wait;                                              // smallest pop time on the waiting list
   if (out_of_steps) { q.overflow = 2; q.done = 1; q.n = 0; return q; }   // did not converge: reported as an error
-  if (c.n_next == 0 || !(m < inf_f())) { q.done = 1; q.n = 0; return q; }
+  if ((c.n_next == 0 && n_wait == 0) || !(m < inf_f())) { q.done = 1; q.n = 0; return q; }
   if (q.armed && m > q.goal_dist) { q.done = 1; q.n = 0; return q; }   // nothing left that may expand
   q.width = fminf(P.delta, p.width * 2.0f);
   float thr = m + q.width;
   if (!(thr > m)) thr = next_up(m);
   q.thr = thr;
   q.band_new = 1;
+  return q;
+}
+
+// The waiting-list bookkeeping around controller_core: totals of the list the previous step appended to, and the
+// switch to the other buffer whenever the next step starts a new epoch (first step of a band, repair / rebuild sweeps).
+MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
+{
+  const uint32_t wtot = p.wbase + c.n_wait;
+  const float wmin = fminf(p.wmin, u2f(c.minkey));
+  Ctl q = controller_core(P, p, c, wmin, wtot);
+  q.wsel = p.wsel; q.wread = 0; q.wbase = wtot; q.wmin = wmin; q.epoch = p.epoch;
+  if (!q.done && (q.band_new || q.repair)) {
+    q.wsel = p.wsel ^ 1u; q.wread = q.repair ? 0u : wtot; q.wbase = 0; q.wmin = inf_f(); q.epoch = (uint32_t)q.it + 2u;
+  }
   return q;
 }
 
@@ -601,7 +628,7 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 // ---------------------------------------------------------------------------------------
 // One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list), push_dirty(u)
 // (the same, and marks u as "a neighbour moved" for the next step),
-// note_changed(), note_min(float), note_eval().
+// note_changed(), note_min(float), note_eval(), park(v, t) (dedup'd append to the waiting list + note_min(t)).
 // ---------------------------------------------------------------------------------------
 // R = state the rule reads, W = state it writes.  The kernels use R == W (in-place, racy but
 // monotone towards the fixed point); the CPU model can also run it Jacobi-style on a snapshot to
@@ -618,7 +645,7 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
   if (cvp && P.blocked[v]) return;                               // never updated (cvp :802,825,848)
   // parked out of band, and no neighbour moved since it was evaluated: keep waiting, as is
   if (!c.band_new && !(old_t < c.thr) && old_t < inf_f() && P.dirty[v] != (uint32_t)c.it) {
-    ops.push(v); ops.note_min(old_t);
+    ops.park(v, old_t);
     return;
   }
   ops.note_eval();
@@ -653,8 +680,7 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
     }
   }
   if (!now_in && e.t < inf_f()) {
-    ops.push(v);                                                 // keyed, waits for its band
-    ops.note_min(e.t);
+    ops.park(v, e.t);                                            // keyed, waits for its band
   }
 }
 
@@ -685,7 +711,7 @@ MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
     if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; if (P.keyd) P.keyd[v] = e.keyd; }
     d = e.d; t = e.t;
   }
-  if (t >= c.thr && t < inf_f()) { ops.push(v); ops.note_min(t); }
+  if (t >= c.thr && t < inf_f()) ops.park(v, t);
 }
 
 // Work-list rebuild after a band shrink (step with ctl.repair == 2): every keyed vertex that is

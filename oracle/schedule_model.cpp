@@ -31,6 +31,16 @@ struct HostOps {
   void note_changed() { cnt->changed++; }
   void note_min(float t) { const uint32_t b = f2u(t); if (b < cnt->minkey) cnt->minkey = b; }
   void note_eval() { cnt->evals++; }
+  // waiting list of the current epoch (mnav_eval.h Plan.wlist): dedup by epoch id, position = entries before this step + this step's
+  uint32_t* wcur; uint32_t wbase; uint32_t epoch;
+  void park(uint32_t v, float t)
+  {
+    note_min(t);
+    if (P->wstamp[v] == epoch) return;
+    P->wstamp[v] = epoch;
+    const uint32_t i = wbase + cnt->n_wait++;
+    if (i < P->cap) wcur[i] = v;
+  }
 };
 }  // namespace
 
@@ -55,13 +65,17 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
     cur = controller(P, prev, cprev);
     ctl[j & 1] = cur;
     Cnt& cnext = cnt[(j + 1) % 3];
-    cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0;
+    cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0; cnext.n_wait = 0;
     if (sm_debug >= 0 && j >= sm_debug && j < sm_debug + 140)
       fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
     if (cur.done) break;
     Cnt& cc = cnt[j % 3];
-    HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1) };
+    HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1), P.wlist[cur.wsel], cur.wbase, cur.epoch };
     const uint32_t* list = P.list[j & 1];
+    std::vector<uint32_t> ent(list, list + cur.n);                   // work list, plus the previous band's waiting list in an epoch step
+    if (cur.wread) ent.insert(ent.end(), P.wlist[cur.wsel ^ 1u], P.wlist[cur.wsel ^ 1u] + cur.wread);
+    const uint32_t nent = (uint32_t)ent.size();
+    list = ent.data();
     if (cur.repair == 2) {
       for (uint32_t v = 0; v < V; ++v) {
         if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
@@ -73,11 +87,11 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
         else process_repair<kPlannerDijkstra>(P, cur, v, ops);
       }
     } else {
-      perm.resize(cur.n);
-      for (uint32_t i = 0; i < cur.n; ++i) perm[i] = i;
+      perm.resize(nent);
+      for (uint32_t i = 0; i < nent; ++i) perm[i] = i;
       if (order == 1) std::reverse(perm.begin(), perm.end());
       if (order == 2)
-        for (uint32_t i = cur.n; i > 1; --i) {
+        for (uint32_t i = nent; i > 1; --i) {
           rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
           std::swap(perm[i - 1], perm[rng % i]);
         }
@@ -89,12 +103,12 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
         Plan R = P;
         R.dist = sd.data(); R.pred = sp.data(); R.tkey = sk.data(); if (P.keyd) R.keyd = skd.data();
         if (planner == kPlannerCvp) { R.dirn = sdir.data(); R.cutf = scut.data(); }
-        for (uint32_t i = 0; i < cur.n; ++i) {
+        for (uint32_t i = 0; i < nent; ++i) {
           if (planner == kPlannerCvp) process_entry_rw<kPlannerCvp>(R, P, cur, list[i], ops);
           else process_entry_rw<kPlannerDijkstra>(R, P, cur, list[i], ops);
         }
       } else
-      for (uint32_t i = 0; i < cur.n; ++i) {
+      for (uint32_t i = 0; i < nent; ++i) {
         const uint32_t vv = list[perm[i]];
         const bool tr = trace_v == vv;
         const float bd = dist[vv];
@@ -167,7 +181,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
 
   std::vector<PopKey> tkey(V, key_inf());
-  std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V);
+  std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V), w0(V), w1(V), wstamp(V, 0);
   Ctl ctl[2]; Cnt cnt[4];   // cnt[3]: sticky flags (mnav_eval.h kFlag*)
   cnt[3].n_next = 0; cnt[3].changed = 0;
   std::memset(ctl, 0, sizeof(ctl)); std::memset(cnt, 0, sizeof(cnt));
@@ -179,6 +193,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   P.dist = dist; P.tkey = tkey.data();
   P.pred = pred; P.dirn = dirn; P.cutf = cutf; P.stamp = stamp.data(); P.dirty = dirty.data();
   P.list[0] = l0.data(); P.list[1] = l1.data(); P.cap = V;
+  P.wlist[0] = w0.data(); P.wlist[1] = w1.data(); P.wstamp = wstamp.data();
   P.ctl = ctl; P.cnt = cnt;
   P.delta = delta; P.offset = offset; P.max_steps = max_steps ? max_steps : 100000000u;
   P.walk_max = getenv("MNAV_KEY_WALK_MAX") ? atoi(getenv("MNAV_KEY_WALK_MAX")) : kKeyWalkMax;
@@ -215,7 +230,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   cnt[0].minkey = cnt[1].minkey = f2u(inf_f());                  // like k_seed
   c_init.minkey = f2u(inf_f());
   {
-    HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu };
+    HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu, nullptr, 0u, 0u };
     for (int k = 0; k < ns; ++k) {
       const uint32_t s = seed_v[k];
       if (planner == kPlannerCvp) {
@@ -236,7 +251,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
     const float d = (planner == kPlannerCvp) ? seed_d[k] : 0.0f;
     if (!(d < c0.thr)) c0.thr = next_up(d);
   }
-  c0.band_new = 1; c0.width = delta;
+  c0.band_new = 1; c0.width = delta; c0.wmin = inf_f(); c0.epoch = 1;
 
   return drive(P, planner, order, ctl, cnt, tkey, blocked, stats_out, goal_dist_out);
 }
@@ -258,7 +273,7 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
     mask[v] = l ? (inv ? kInflSeedMute : kInflSeed) : (inv ? kInflMute : kInflFree);
   }
   std::vector<PopKey> tkey(V, key_inf());
-  std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V), pred(V), cutf(V, kNone);
+  std::vector<uint32_t> stamp(V, 0), dirty(V, 0), l0(V), l1(V), w0(V), w1(V), wstamp(V, 0), pred(V), cutf(V, kNone);
   std::vector<float> dirn(V, 0.0f);
   Ctl ctl[2]; Cnt cnt[4];
   std::memset(ctl, 0, sizeof(ctl)); std::memset(cnt, 0, sizeof(cnt));
@@ -269,6 +284,7 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
   P.dist = dist; P.tkey = tkey.data(); P.keyd = keyd;
   P.pred = pred.data(); P.dirn = dirn.data(); P.cutf = cutf.data(); P.stamp = stamp.data(); P.dirty = dirty.data();
   P.list[0] = l0.data(); P.list[1] = l1.data(); P.cap = V;
+  P.wlist[0] = w0.data(); P.wlist[1] = w1.data(); P.wstamp = wstamp.data();
   P.ctl = ctl; P.cnt = cnt;
   P.delta = delta; P.offset = 0.0; P.max_steps = max_steps ? max_steps : 100000000u;
   P.walk_max = getenv("MNAV_KEY_WALK_MAX") ? atoi(getenv("MNAV_KEY_WALK_MAX")) : kKeyWalkMax;
@@ -280,7 +296,7 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
   cnt[0].minkey = cnt[1].minkey = f2u(inf_f());
   c_init.minkey = f2u(inf_f());
   {
-    HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu };
+    HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu, nullptr, 0u, 0u };
     for (uint32_t s = 0; s < V; ++s) {                              // like k_infl_seed
       if (!is_seed(P, s)) continue;
       dist[s] = 0.0f; tkey[s] = make_key(0.0f, s); keyd[s] = 0.0f;
@@ -294,7 +310,7 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
   Ctl& c0 = ctl[1];                                                 // like k_infl_ctl
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
-  c0.band_new = 1; c0.width = delta;
+  c0.band_new = 1; c0.width = delta; c0.wmin = inf_f(); c0.epoch = 1;
   return drive(P, kPlannerCvp, order, ctl, cnt, tkey, blocked, stats_out, nullptr);
 }
 
