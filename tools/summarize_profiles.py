@@ -33,15 +33,17 @@ def pmc_per_launch(counter, kernel):
 rows = list(csv.DictReader(open(os.path.join(G, "prof_bench", "bench_kernel_stats.csv"))))
 shutil.copy(os.path.join(G, "prof_bench", "bench_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
 prof_line = last_json_line(os.path.join(G, "prof_bench_line.json"))
-bench_line = last_json_line(os.path.join(G, f"bench_{tag}.json"))
-json.dump(bench_line, open(os.path.join(P, f"{tag}_bench_line.json"), "w"))
+bench_path = os.path.join(G, f"bench_{tag}.json")      # the un-profiled default run (made AFTER the PMC passes: it quotes their traffic)
+bench_line = last_json_line(bench_path) if os.path.exists(bench_path) else None
+if bench_line:
+    json.dump(bench_line, open(os.path.join(P, f"{tag}_bench_line.json"), "w"))
 
 kernel = prof_line["roofline"]["kernel"]
 fetch, nl = pmc_per_launch("FETCH_SIZE", kernel)
 write, _ = pmc_per_launch("WRITE_SIZE", kernel)
 pmc_line = last_json_line(os.path.join(G, "pmc_FETCH_SIZE.log"))
 traffic = {
-    "command": "tools/prof_pmc.sh: rocprofv3 --pmc FETCH_SIZE (then, separately, WRITE_SIZE) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu --no-latency",
+    "command": "tools/prof_pmc.sh: rocprofv3 --pmc FETCH_SIZE (then, separately, WRITE_SIZE) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu --no-latency --no-configs",
     "kernel": kernel, "batch": pmc_line["config"]["batch_per_gpu"], "launches": nl,
     "fetch_kb_per_launch_raw": fetch, "write_kb_per_launch_raw": write,
     "note": "FETCH_SIZE/WRITE_SIZE are in KB. gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads "
@@ -57,7 +59,7 @@ with open(os.path.join(P, f"{tag}_bench_kernel_stats.md"), "w") as f:
     w = prof_line["config"]
     f.write(f"# profiles/{tag}_bench_kernel_stats.md — rocprofv3 kernel trace of the bench command\n\n")
     f.write("MI355X (gfx950). Command (tools/prof_bench.sh): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats "
-            "--output-format csv -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu --no-latency`.\n")
+            "--output-format csv -d gpurun_out/prof_bench -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu --no-latency --no-configs`.\n")
     f.write(f"Raw CSV: `profiles/{tag}_bench_kernel_stats.csv`. Workload: {w['workload']}; 4 batches (1 warm-up + 3 timed), one launch of "
             f"`{kernel}` (one workgroup per plan) per batch. Summary written by tools/summarize_profiles.py.\n\n")
     f.write("| kernel | calls | total ms | avg µs | min µs | max µs | % |\n|---|---|---|---|---|---|---|\n")
@@ -71,11 +73,29 @@ with open(os.path.join(P, f"{tag}_bench_kernel_stats.md"), "w") as f:
     f.write("\nBench line printed by the profiled run:\n```json\n" + json.dumps(prof_line) + "\n```\n\n")
     f.write(f"Agreement check: rocprofv3 average duration of `{kernel}` = **{avg_dom:.1f} µs**; `roofline.avg_launch_us` measured live in "
             f"the same run with HIP events on the library's stream around the launch = **{prof_line['roofline']['avg_launch_us']:.1f} µs**.\n\n")
-    f.write(f"Un-profiled bench line of the same build (`python bench.py --steps 5 --warmup 1`, also `profiles/{tag}_bench_line.json`):\n"
-            "```json\n" + json.dumps(bench_line) + "\n```\n\n")
+    if bench_line:
+        f.write(f"Un-profiled bench line of the same build (`python bench.py`, all legs; also `profiles/{tag}_bench_line.json`):\n"
+                "```json\n" + json.dumps(bench_line) + "\n```\n\n")
     f.write("## HBM traffic (PMC, separate passes)\n\n```json\n" + json.dumps(traffic, indent=1) + "\n```\n")
 for src, dst in (("c4_10m.json", f"{tag}_c4_10m_single_gpu.json"), ("cvp_batch.json", f"{tag}_cvp_batch_c3.json"), ("cvp_band.json", f"{tag}_cvp_band_width.json")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+# CVP planner kernel trace (tools/prof_cvp.sh)
+cvp_csv = os.path.join(G, "prof_cvp", "cvp_kernel_stats.csv")
+if os.path.exists(cvp_csv):
+    shutil.copy(cvp_csv, os.path.join(P, f"{tag}_cvp_kernel_stats.csv"))
+    crow = list(csv.DictReader(open(cvp_csv)))
+    lines = [l.strip() for l in open(os.path.join(G, "prof_cvp.log")) if l.startswith("{")]
+    with open(os.path.join(P, f"{tag}_cvp_kernel_stats.md"), "w") as f:
+        f.write(f"# profiles/{tag}_cvp_kernel_stats.md — rocprofv3 kernel trace of the CVP planner and the device cost stack\n\n")
+        f.write("MI355X (gfx950). Command (tools/prof_cvp.sh): `MNAV_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -- env PERF_BATCHES=1,128 "
+                "python tools/gpu_cvp_perf.py` (rocprofv3 segfaults inside hipGraph replays, so the steps are launched one by one: kernel durations "
+                "are representative, launch gaps are not).  Workload: 1000x1000 terrain seed 3, Steepness(0.6) + Inflation + weighted sum + edge "
+                "weights built on the device, then one CVP plan (twice) and a batch of 128 (twice).\n\n")
+        f.write("| kernel | calls | total ms | avg µs | min µs | max µs | % |\n|---|---|---|---|---|---|---|\n")
+        for r in crow[:16]:
+            f.write(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
+                    f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
+        f.write("\nLines printed by the profiled run:\n```json\n" + "\n".join(lines) + "\n```\n")
 print("dominant kernel", kernel, "avg us", avg_dom, "live", prof_line["roofline"]["avg_launch_us"])
 print(json.dumps(traffic, indent=1))
