@@ -54,6 +54,8 @@ typedef struct mnav_stats {
   float ms_total;          /* whole call                                         */
   float ms_step_kernels;   /* sum over graph replays of the event-bracketed step/round launches
                               (excludes the host polls between replays)          */
+  uint32_t band_shrinks;   /* bands cut down because they did not converge (all plans)   */
+  uint32_t band_cuts;      /* bands restarted under a lower bound after kCutAfter steps     */
 } mnav_stats;
 
 /* -- life cycle -------------------------------------------------------------------------- */

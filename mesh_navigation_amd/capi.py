@@ -32,7 +32,8 @@ class Stats(C.Structure):
     _fields_ = [("steps", C.c_uint32), ("launches", C.c_uint32), ("bands", C.c_uint32), ("armed", C.c_uint32),
                 ("goal_dist", C.c_float), ("n_plans", C.c_uint32), ("evals", C.c_uint64), ("settled", C.c_uint64),
                 ("ms_init", C.c_float), ("ms_propagation", C.c_float), ("ms_vector_map", C.c_float),
-                ("ms_path", C.c_float), ("ms_download", C.c_float), ("ms_total", C.c_float), ("ms_step_kernels", C.c_float)]
+                ("ms_path", C.c_float), ("ms_download", C.c_float), ("ms_total", C.c_float), ("ms_step_kernels", C.c_float),
+                ("band_shrinks", C.c_uint32), ("band_cuts", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_}

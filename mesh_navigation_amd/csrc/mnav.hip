@@ -73,6 +73,7 @@ struct StepCtx {
   bool lchanged;
   uint32_t* wcur;       // waiting list of the current epoch (Plan.wlist), entries before this step, epoch id
   uint32_t wbase, epoch;
+  float lcut;           // min pop time over in-band vertices that moved (Cnt.minchg)
 };
 
 // dedup'd, wave-aggregated append of v to the next work list (all lanes of the wave that reach
@@ -299,12 +300,13 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
 {
   constexpr bool cvp = (PLANNER == kPlannerCvp);
   bool push_nb = false, retain = false, self_again = false;
-  float t_new = inf_f();
+  float t_new = inf_f(), t_old_for_cut = inf_f();
   if (active && !is_seed(P, v)) {
     const float old_d = P.dist[v];
     PopKey old_key = key_inf();
     if constexpr (cvp) old_key = P.tkey[v];
     const float old_t = cvp ? key_time(old_key) : old_d;
+    t_old_for_cut = old_t;
     bool go;
     if (REPAIR) go = (old_d < inf_f());
     else go = !(old_t < c.thr_fixed) && !(cvp && P.blocked[v]);
@@ -318,6 +320,11 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
         bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != P.pred[v]);
         if (cvp) changed = changed || (e.key != old_key) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v])) ||
                            (P.keyd && f2u(e.keyd) != f2u(P.keyd[v]));
+#ifdef MNAV_DEBUG_FLIP                    // debugging aid: who keeps changing in a band that does not settle
+        if (changed && sub == 0 && !REPAIR && c.band_steps >= 40 && c.band_steps < 44)
+          printf("flip it %d v %u d %.9g->%.9g t %.9g->%.9g key hi %llx->%llx up %d->%d lvl %u->%u keyd %.9g->%.9g\n", c.it, v, old_d, e.d, old_t, e.t,
+                 old_key.hi, e.key.hi, (int)old_key.up, (int)e.key.up, old_key.lvl, e.key.lvl, P.keyd ? P.keyd[v] : 0.f, e.keyd);
+#endif
         if ((changed || REPAIR) && sub == 0) {
           P.dist[v] = e.d; P.pred[v] = e.pred;
           if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; if (P.keyd) P.keyd[v] = e.keyd; }
@@ -336,7 +343,10 @@ __device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const C
       if (REPAIR) retain = (t_new >= c.thr) && (t_new < inf_f());
     }
   }
-  if ((push_nb || self_again) && sub == 0) S.lchanged = true;
+  if ((push_nb || self_again) && sub == 0) {
+    S.lchanged = true;
+    if (push_nb && ((t_old_for_cut < c.thr) != (t_new < c.thr))) S.lcut = fminf(S.lcut, fminf(t_old_for_cut, t_new));   // crossed the bound (spec: note_cut)
+  }
   group_push_neighbours<PLANNER>(S, P, v, sub, push_nb);
   push_agg<true>(S, self_again && sub == 0, v);
   park_agg(S, retain && sub == 0, v);
@@ -358,11 +368,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 
 // grid = (waves per plan, plans).  slot j (0..5) selects the ping-pong control block (j&1) and
 // the counter block (j%3).
-#ifdef MNAV_STEP_OCC                      // experiment knob: waves per SIMD the register allocator must reach (spills if needed)
+#ifndef MNAV_STEP_OCC                     // waves per SIMD the register allocator must reach: 3 (<= 168 VGPRs).  The CVP replay sits
+#define MNAV_STEP_OCC 3                   // right at that edge (159-170 VGPRs); at 2 waves a batch is 20 % slower, forcing 4 or 5
+#endif                                    // spills and is slower still (measured: 179 / 150 / 120 plans/s at 3 / 4 / 5)
 #define MNAV_STEP_BOUNDS __launch_bounds__(kWave, MNAV_STEP_OCC)
-#else
-#define MNAV_STEP_BOUNDS __launch_bounds__(kWave)
-#endif
 template <uint32_t PLANNER>
 __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
 {
@@ -376,7 +385,7 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
     s_ctl = cur;
     if (blockIdx.x == 0) {
       P.ctl[j & 1] = cur;
-      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.pad[0] = z.pad[1] = z.pad[2] = 0;
+      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
       P.cnt[(j + 1) % 3] = z;
     }
   }
@@ -384,11 +393,28 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
   const Ctl cur = s_ctl;
   if (cur.done) return;
   Cnt* cnt = &P.cnt[j % 3];
-  StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch };
+  StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
   const int sub = lane & (kGroup - 1), grp = lane >> 3;
   const uint32_t ngroups = gridDim.x * kGroupsPerWave;
   const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
-  if (cur.repair == 1) {                                             // spec: process_repair
+  if (cur.repair == 3) {                                             // spec: process_cut -- no evaluation
+    const uint32_t nthreads = gridDim.x * kWave, tid = blockIdx.x * kWave + lane;
+    const uint32_t* list = P.list[cur.it & 1];
+    for (uint32_t base = 0; base < cur.n; base += nthreads) {         // the work list is carried over
+      const uint32_t i = base + tid;
+      push_agg<true>(S, i < cur.n, i < cur.n ? list[i] : 0u);
+    }
+    for (uint32_t base = 0; base < P.V; base += nthreads) {           // keyed vertices at or above the cut wait for the restarted band
+      const uint32_t v = base + tid;
+      bool want = false; float t = inf_f();
+      if (v < P.V && !is_seed(P, v)) {
+        t = (PLANNER == kPlannerCvp) ? key_time(P.tkey[v]) : P.dist[v];
+        want = t >= cur.thr && t < inf_f();
+      }
+      park_agg(S, want, v);
+      if (want) S.lmin = fminf(S.lmin, t);
+    }
+  } else if (cur.repair == 1) {                                      // spec: process_repair
     const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t v = g0 + r * ngroups;
@@ -415,10 +441,12 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
     }
   }
   const float wmin = wave_min(S.lmin);
+  const float wcut = wave_min(S.lcut);
   const uint32_t wev = wave_sum(S.levals);
   const bool wch = __any(S.lchanged);
   if (lane == 0) {
     if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
+    if (wcut < inf_f()) atomicMin(&cnt->minchg, f2u(wcut));
     if (wev) atomicAdd(&cnt->evals, wev);
     if (wch) atomicOr(&cnt->changed, 1u);
   }
@@ -1359,7 +1387,7 @@ struct PlanResult {
   uint32_t path_len;
   uint32_t steps, bands, armed, overflow;
   float goal_dist;
-  uint32_t pad;
+  uint32_t shrinks;
   unsigned long long settled;
   unsigned long long evals;
 };
@@ -1567,9 +1595,9 @@ __global__ void k_seed(const Plan* __restrict__ plans)
   c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
   P.ctl[1] = c0;
   P.ctl[0] = c0;
-  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u;
+  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u; ci.minchg = 0x7f800000u;
   P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"
-  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u;
+  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; z.minchg = 0x7f800000u;
   P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;                         // cnt[3]: sticky flags (mnav_eval.h kFlag*)
 }
 
@@ -1589,7 +1617,7 @@ __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict_
   const Ctl a = P.ctl[0], b = P.ctl[1];
   const Ctl last = (a.it > b.it) ? a : b;
   R.steps = (uint32_t)(last.it < 0 ? 0 : last.it);
-  R.bands = last.bands; R.armed = last.armed; R.overflow = last.overflow; R.goal_dist = last.goal_dist;
+  R.bands = last.bands; R.armed = last.armed; R.overflow = last.overflow; R.goal_dist = last.goal_dist; R.shrinks = last.shrinks | (last.cuts << 16);
   R.evals = last.evals;
   R.path_len = 0;
   uint32_t code = kSuccess;
@@ -1856,9 +1884,9 @@ __global__ void k_infl_ctl(const Plan* __restrict__ plans)
   c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
   P.ctl[1] = c0;
   P.ctl[0] = c0;
-  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.changed = 1; ci.minkey = 0x7f800000u;
+  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.changed = 1; ci.minkey = 0x7f800000u; ci.minchg = 0x7f800000u;
   P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"; k_infl_seed counts the list into it
-  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u;
+  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; z.minchg = 0x7f800000u;
   P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;
 }
 
@@ -2195,7 +2223,7 @@ int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count)
 template <uint32_t PLANNER>
 int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G)
 {
-  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, kChunk);
+  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, getenv("MNAV_DEBUG_CHUNK") ? atoi(getenv("MNAV_DEBUG_CHUNK")) : kChunk);   // debug: finer control-block trace
   const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)n << 32) | G;
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
@@ -2700,11 +2728,12 @@ void finish_stats(mnav_ctx* ctx, uint32_t n, bool cvp)
 {
   mnav_stats& st = ctx->stats;
   st.n_plans = n;
-  st.steps = 0; st.bands = 0; st.armed = 0; st.goal_dist = INFINITY; st.settled = 0; st.evals = 0;
+  st.steps = 0; st.bands = 0; st.armed = 0; st.goal_dist = INFINITY; st.settled = 0; st.evals = 0; st.band_shrinks = 0; st.band_cuts = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const PlanResult& r = ctx->h_res[i];
     if (r.steps > st.steps) st.steps = r.steps;
     if (r.bands > st.bands) st.bands = r.bands;
+    st.band_shrinks += r.shrinks & 0xFFFFu; st.band_cuts += r.shrinks >> 16;
     st.armed += r.armed;
     if (i == 0) st.goal_dist = r.goal_dist;
     st.settled += r.settled;
@@ -3247,6 +3276,9 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
+    if (getenv("MNAV_TRACE"))
+      fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u)\n", last.it,
+              last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used);
     if (last.done) break;
   }
   // verification: every vertex must be a fixed point of the replay rule on the converged state (k_cvp_verify)

@@ -19,8 +19,10 @@
 
 #if defined(__HIPCC__)
 #define MNAV_HD __host__ __device__ __forceinline__
+#define MNAV_HD_COLD __host__ __device__ __attribute__((noinline))   // rare paths: kept out of the callers' register budget
 #else
 #define MNAV_HD inline
+#define MNAV_HD_COLD inline
 #endif
 
 namespace mnav {
@@ -262,6 +264,7 @@ struct Ctl {
   uint32_t wbase;      // entries already in the current buffer when this step starts (0 in an epoch step)
   float wmin;          // smallest pop time parked in the current buffer before this step (+inf in an epoch step); may be
                        // stale-low when a parked vertex moved up later: the next band then starts lower, never wrong
+  uint32_t cuts;       // statistics: band cuts (kCutAfter)
   uint32_t epoch;      // id of the current waiting list (1 for the list the first steps append to, then step index of the
                        // epoch step + 2); Plan.wstamp (0 = never parked) dedups with it
 };
@@ -272,7 +275,9 @@ struct Cnt {
   uint32_t minkey;     // min pop time (float bits) over the entries parked this step
   uint32_t evals;      // statistics: vertex evaluations
   uint32_t n_wait;     // entries appended to the waiting list this step
-  uint32_t pad[3];
+  uint32_t minchg;     // min pop time (float bits) over the vertices that moved ACROSS the band's upper bound this step
+                       // (in band before and beyond it now, or the other way round; see kCutAfter)
+  uint32_t pad[2];
 };
 
 // Constant per-plan parameters + state pointers.  All pointers address the plan's own slices.
@@ -339,24 +344,43 @@ MNAV_HD bool is_seed(const Plan& P, uint32_t v)
 // (inflation: a vertex can sit in the queue with an older, larger value than its distance -- keyd, see Plan)
 MNAV_HD KeyRef key_ref(const Plan& P, uint32_t u) { return key_ref_of(P.tkey[u], P.keyd ? P.keyd[u] : P.dist[u], u); }
 
-// a pops before b
-MNAV_HD bool key_less(const Plan& P, KeyRef a, KeyRef b)
+// Walks over the cascade tree follow `up` links.  A half-converged tree can hold anything, even CYCLES of links, and a
+// walk that runs around one until the bound costs milliseconds (one dependent global load per step).  CycleGuard is
+// Brent's detector: it remembers a node of the walk, at doubling distances, and reports when the walk comes back to it.
+struct CycleGuard {
+  unsigned long long mark; int span, n;
+  MNAV_HD void start(unsigned long long own) { mark = own; span = 1; n = 0; }
+  MNAV_HD bool visit(unsigned long long own)                       // true: this node was seen before
+  {
+    if (own == mark) return true;
+    if (++n == span) { mark = own; span <<= 1; n = 0; }
+    return false;
+  }
+};
+
+// a pops before b, for two nodes of the SAME cascade (equal `hi`): the walk over the tree.  Rare against the one-compare
+// case of key_less below, and heavy on registers: a real call, not inlined into the replay.
+MNAV_HD_COLD bool key_less_walk(const Plan& P, KeyRef a, KeyRef b)
 {
-  if (a.k.hi != b.k.hi) return a.k.hi < b.k.hi;                    // different main-front pops
   int guard = 0;
+  CycleGuard ga, gb;
+  ga.start(a.own); gb.start(b.own);
   for (; guard < P.walk_max; ++guard) {                            // same cascade: preorder, siblings by (value, id)
     if (a.k.lvl == b.k.lvl) {
       if (a.own == b.own) return false;                            // the same node
       if (a.k.lvl == 0u || a.k.up == b.k.up) return a.own < b.own; // siblings
       a = key_ref(P, a.k.up); b = key_ref(P, b.k.up);
+      if (ga.visit(a.own) || gb.visit(b.own)) break;
     } else if (a.k.lvl > b.k.lvl) {
       if (a.k.up == pair_id(b.own)) return false;                  // b is an ancestor of a: pops first
       if (a.k.up == kNone) break;
       a = key_ref(P, a.k.up);
+      if (ga.visit(a.own)) break;
     } else {
       if (b.k.up == pair_id(a.own)) return true;
       if (b.k.up == kNone) break;
       b = key_ref(P, b.k.up);
+      if (gb.visit(b.own)) break;
     }
   }
   // Left the loop without a decision: the two nodes are not in one consistent tree.  In a half-converged state
@@ -364,6 +388,13 @@ MNAV_HD bool key_less(const Plan& P, KeyRef a, KeyRef b)
   // bound on a CONVERGED tree would silently change the order, so it is flagged.
   if (guard == P.walk_max) raise_flag(P, kFlagWalkLimit);
   return a.own < b.own;
+}
+
+// a pops before b
+MNAV_HD bool key_less(const Plan& P, const KeyRef& a, const KeyRef& b)
+{
+  if (a.k.hi != b.k.hi) return a.k.hi < b.k.hi;                    // different main-front pops
+  return key_less_walk(P, a, b);
 }
 
 // key of vertex v whose value d was set by the pop `trig`
@@ -375,9 +406,12 @@ MNAV_HD PopKey key_for(const Plan& P, float d, uint32_t v, KeyRef trig)
   k.hi = trig.k.hi;                                                // below it: inside the cascade of trig's root
   KeyRef a = trig;                                                 // climb to the node whose sub-cascade v pops in:
   int guard = 0;
+  CycleGuard ga;
+  ga.start(a.own);
   for (; guard < P.walk_max; ++guard) {                            // the deepest ancestor-or-self of trig above v
     if (a.k.lvl == 0u || x < a.own || a.k.up == kNone) break;
     a = key_ref(P, a.k.up);
+    if (ga.visit(a.own)) break;
   }
   if (guard == P.walk_max) raise_flag(P, kFlagWalkLimit);
   k.up = pair_id(a.own); k.lvl = a.k.lvl + 1u;
@@ -442,6 +476,17 @@ MNAV_HD void try_arm(const Plan& P, Ctl& q)
 // one REPAIR step that re-evaluates every vertex above goal_dist under the final cut-off and
 // rebuilds the work list (process_repair below).
 constexpr uint32_t kBandStepLimit = 64;   // a band that is still moving after this many steps is cut down
+// Before that, the cheap remedy.  What keeps a band from settling is almost always a small cluster of cascade members
+// whose states straddle the band's upper bound: in one state a vertex pops just below `thr` (and supports its
+// neighbours), in the other just above (and does not), and the cluster flips between the two.  After kCutAfter steps
+// the band is CUT right below the lowest vertex that still moved across the bound (a band that merely needs many
+// steps -- a deep cascade unwinding -- has no such vertex and is left alone): everything below is converged and settles, the
+// cluster falls entirely into the next band, where both of its states are in band.  The cut costs one scan step
+// (repair == 3: no evaluation, keyed vertices at or above the cut are parked, the work list is carried over).
+// Used by the inflation wave only (one band per radius, the whole wave sits at the bound); the CVP planner's bands are
+// narrow against its wave and a cut costs it more steps than the rare kBandStepLimit shrink (measured: -15 % plans/s).
+constexpr uint32_t kCutAfter = 24, kCutMaxList = 512;   // ... and only when the work list has shrunk to a remainder (a band
+                                                         // that is still making progress has thousands of entries)
 
 MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_wait, uint32_t n_wait)
 {
@@ -453,6 +498,10 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
   q.n = c.n_next;
   if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
   const bool out_of_steps = (uint32_t)q.it >= P.max_steps;
+  if (p.repair == 3 && !out_of_steps) {                               // the band was cut: start it again under the lower bound
+    q.band_new = 1; q.band_steps = 0;
+    return q;
+  }
   if (p.repair == 1 && c.changed > 0 && !out_of_steps) {             // repair sweep not yet at its fixed point (CVP)
     q.repair = 1; q.band_new = 0;
     return q;
@@ -460,6 +509,15 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
   if (c.changed > 0 && !out_of_steps) {
     q.band_new = 0;
     q.band_steps = p.band_steps + 1;
+    if (P.seed_mask != nullptr && q.band_steps >= kCutAfter && q.band_steps < kBandStepLimit && !p.repair && !p.band_new &&
+        c.n_next <= kCutMaxList) {
+      const float lo = p.thr_fixed > 0.0f ? p.thr_fixed : 0.0f;
+      const float cut = u2f(c.minchg);
+      if (cut > next_up(lo) && cut < p.thr) {                          // (otherwise: keep stepping, kBandStepLimit is the backstop)
+        q.thr = cut; q.repair = 3; q.band_steps = 0; q.cuts = p.cuts + 1;
+        return q;
+      }
+    }
     if (P.planner == kPlannerCvp && q.band_steps >= kBandStepLimit && p.thr > next_up(p.thr_fixed > 0.0f ? p.thr_fixed : 0.0f)) {
       // Not converging: on triangles that grossly violate the triangle inequality the in-band
       // vertices can support each other in a cycle.  Cut the band down from the bottom (at the
@@ -628,7 +686,7 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 // ---------------------------------------------------------------------------------------
 // One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list), push_dirty(u)
 // (the same, and marks u as "a neighbour moved" for the next step),
-// note_changed(), note_min(float), note_eval(), park(v, t) (dedup'd append to the waiting list + note_min(t)).
+// note_changed(), note_cut(float) (pop time of an in-band vertex that moved), note_min(float), note_eval(), park(v, t) (dedup'd append to the waiting list + note_min(t)).
 // ---------------------------------------------------------------------------------------
 // R = state the rule reads, W = state it writes.  The kernels use R == W (in-place, racy but
 // monotone towards the fixed point); the CPU model can also run it Jacobi-style on a snapshot to
@@ -669,6 +727,7 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
     // v is (or was) usable by its neighbours and moved, or only just entered the band:
     // the neighbours must look again, and the band cannot complete in this step.
     ops.note_changed();
+    if (was_in != now_in) ops.note_cut(fminf(old_t, e.t));      // moved across the band's upper bound (kCutAfter)
     if (cvp) {
       for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) {
         const Corner k = P.crn[i];
@@ -711,6 +770,18 @@ MNAV_HD void process_repair(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
     if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; if (P.keyd) P.keyd[v] = e.keyd; }
     d = e.d; t = e.t;
   }
+  if (t >= c.thr && t < inf_f()) ops.park(v, t);
+}
+
+// Band cut (step with ctl.repair == 3, c.thr = the cut): nothing is evaluated.  Every keyed vertex at or above the cut
+// goes to the (fresh) waiting list -- among them those that were in band until now -- so that the first step of the
+// restarted band looks at all of them; the caller carries the work list over (push_dirty of every entry).
+template <uint32_t PLANNER, class Ops>
+MNAV_HD void process_cut(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
+{
+  if (is_seed(P, v)) return;
+  float t = P.dist[v];
+  if constexpr (PLANNER == kPlannerCvp) t = key_time(P.tkey[v]);
   if (t >= c.thr && t < inf_f()) ops.park(v, t);
 }
 

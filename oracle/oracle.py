@@ -428,7 +428,7 @@ def schedule_model_inflation(faces, edges, edge_dist, lethal, max_distance=0.4, 
                                         float(max_distance if delta is None else delta), int(order), int(max_steps),
                                         _p(dist), _p(keyd), _p(stats))
     return dict(code=code, dist=dist, keyd=keyd, steps=int(stats[0]), bands=int(stats[1]), evals=int(stats[2]),
-                verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]))
+                verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]) & 0xFFFFFFFF, cuts=int(stats[7]) >> 32)
 
 
 def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_v, seed_d, seed_face,
@@ -451,4 +451,4 @@ def schedule_model(planner: int, faces, edges, edge_weights, vertex_costs, seed_
                               int(max_steps), _p(dist), _p(pred), _p(dirn), _p(cutf), _p(stats), C.byref(gd))
     return dict(code=code, dist=dist, pred=pred, direction=dirn, cutface=cutf, steps=int(stats[0]),
                 bands=int(stats[1]), evals=int(stats[2]), armed=int(stats[3]), shrinks=int(stats[4]),
-                verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]), goal_dist=gd.value)
+                verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]) & 0xFFFFFFFF, cuts=int(stats[7]) >> 32, goal_dist=gd.value)

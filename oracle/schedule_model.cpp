@@ -29,6 +29,7 @@ struct HostOps {
   }
   void push_dirty(uint32_t v) { P->dirty[v] = stamp_val; push(v); }
   void note_changed() { cnt->changed++; }
+  void note_cut(float t) { const uint32_t b = f2u(t); if (b < cnt->minchg) cnt->minchg = b; }
   void note_min(float t) { const uint32_t b = f2u(t); if (b < cnt->minkey) cnt->minkey = b; }
   void note_eval() { cnt->evals++; }
   // waiting list of the current epoch (mnav_eval.h Plan.wlist): dedup by epoch id, position = entries before this step + this step's
@@ -65,7 +66,7 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
     cur = controller(P, prev, cprev);
     ctl[j & 1] = cur;
     Cnt& cnext = cnt[(j + 1) % 3];
-    cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0; cnext.n_wait = 0;
+    cnext.n_next = 0; cnext.changed = 0; cnext.minkey = f2u(inf_f()); cnext.evals = 0; cnext.n_wait = 0; cnext.minchg = f2u(inf_f());
     if (sm_debug >= 0 && j >= sm_debug && j < sm_debug + 140)
       fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
     if (cur.done) break;
@@ -76,7 +77,13 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
     if (cur.wread) ent.insert(ent.end(), P.wlist[cur.wsel ^ 1u], P.wlist[cur.wsel ^ 1u] + cur.wread);
     const uint32_t nent = (uint32_t)ent.size();
     list = ent.data();
-    if (cur.repair == 2) {
+    if (cur.repair == 3) {                                           // band cut: park what lies at or above the cut, keep the work list
+      for (uint32_t i = 0; i < cur.n; ++i) ops.push_dirty(P.list[j & 1][i]);
+      for (uint32_t v = 0; v < V; ++v) {
+        if (planner == kPlannerCvp) process_cut<kPlannerCvp>(P, cur, v, ops);
+        else process_cut<kPlannerDijkstra>(P, cur, v, ops);
+      }
+    } else if (cur.repair == 2) {
       for (uint32_t v = 0; v < V; ++v) {
         if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
         else process_rebuild<kPlannerDijkstra>(P, cur, v, ops);
@@ -158,7 +165,7 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
     }
   }
   if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks;
-                   stats_out[5] = verify_bad; stats_out[6] = verify_flags; stats_out[7] = verify_sweeps; }
+                   stats_out[5] = verify_bad; stats_out[6] = verify_flags; stats_out[7] = verify_sweeps | ((uint64_t)cur.cuts << 32); }
   if (goal_dist_out) *goal_dist_out = cur.goal_dist;
   return cur.overflow ? kInternalError : kSuccess;   // overflow == 2: step cap hit (no convergence)
 }
@@ -228,6 +235,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   // initial list: neighbours of the seeds
   Cnt& c_init = cnt[2];   // "(0-1) mod 3"
   cnt[0].minkey = cnt[1].minkey = f2u(inf_f());                  // like k_seed
+  cnt[0].minchg = cnt[1].minchg = cnt[2].minchg = f2u(inf_f());
   c_init.minkey = f2u(inf_f());
   {
     HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu, nullptr, 0u, 0u };
@@ -294,6 +302,7 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
   for (uint32_t v = 0; v < V; ++v) { dist[v] = inf_f(); keyd[v] = inf_f(); pred[v] = v; }
   Cnt& c_init = cnt[2];
   cnt[0].minkey = cnt[1].minkey = f2u(inf_f());
+  cnt[0].minchg = cnt[1].minchg = cnt[2].minchg = f2u(inf_f());
   c_init.minkey = f2u(inf_f());
   {
     HostOps ops{ &P, &c_init, P.list[0], 0xFFFFFFFFu, nullptr, 0u, 0u };

@@ -37,6 +37,6 @@ for nb in [int(x) for x in os.environ.get("PERF_BATCHES", "1,128,512").split(","
     dt = time.perf_counter() - t0
     st = rb["stats"]
     print(json.dumps({"lib": tag, "batch": nb, "plans_per_s": nb / dt, "ms": dt * 1e3, "steps": st["steps"], "launches": st["launches"],
-                      "evals_per_plan": st["evals"] / nb, "settled_per_plan": st["settled"] / nb, "ms_step_kernels": st["ms_step_kernels"],
+                      "evals_per_plan": st["evals"] / nb, "band_shrinks": st["band_shrinks"], "settled_per_plan": st["settled"] / nb, "ms_step_kernels": st["ms_step_kernels"],
                       "codes": sorted(set(int(c) for c in rb["codes"]))}), flush=True)
 ctx.close()
