@@ -188,8 +188,10 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
 int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t* lethal_out, float* distances_out);
 int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights,
                         double edge_cost_factor, const uint8_t* invalid);
-/* Counters of the last inflation wave: band steps, bands, vertex evaluations, device milliseconds. */
-int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms);
+/* Counters of the last inflation wave: band steps, bands, vertex evaluations, device milliseconds (whole call), fixing
+ * verification sweeps that were needed, device milliseconds of the wave alone.  Any pointer may be NULL. */
+int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms, uint32_t* verify_sweeps,
+                     float* ms_wave);
 
 /* -- one plan over several GPUs (BASELINE config 4) ---------------------------------------------
  * The reference's loop (dijkstra_mesh_planner.cpp:287-348) on a mesh that is range-partitioned over `world`

@@ -107,7 +107,7 @@ def load(path: str | None = None):
     L.mnav_combine_layers.restype = C.c_int
     L.mnav_combine_layers.argtypes = [vp, C.c_int, u32, vp, vp, f64, vp]
     L.mnav_layer_stats.restype = C.c_int
-    L.mnav_layer_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.mnav_layer_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(u32), C.POINTER(C.c_float)]
     L.mnav_shard_setup.restype = C.c_int
     L.mnav_shard_setup.argtypes = [vp, u32, u32]
     L.mnav_shard_info.restype = C.c_int
@@ -295,9 +295,9 @@ class MnavContext:
                                           None if inv is None else _p(inv))
         if rc != 0:
             raise RuntimeError(f"mnav_layer_inflation failed: {self._err()}")
-        a, b, e, ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_float()
-        self._L.mnav_layer_stats(self._h, C.byref(a), C.byref(b), C.byref(e), C.byref(ms))
-        return dict(steps=a.value, bands=b.value, evals=e.value, ms=ms.value)
+        a, b, e, ms, vs, mw = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_float(), C.c_uint32(), C.c_float()
+        self._L.mnav_layer_stats(self._h, C.byref(a), C.byref(b), C.byref(e), C.byref(ms), C.byref(vs), C.byref(mw))
+        return dict(steps=a.value, bands=b.value, evals=e.value, ms=ms.value, ms_wave=mw.value, verify_sweeps=vs.value)
 
     def layer_download(self, layer: int, distances: bool = False):
         c = np.empty(self.V, np.float32)

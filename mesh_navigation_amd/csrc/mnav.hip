@@ -2051,7 +2051,7 @@ struct mnav_ctx {
   Corner* d_crn_infl = nullptr; bool crn_infl_valid = false;       // corners over the edge distances (inflation wave)
   uint8_t *d_infl_mask = nullptr, *d_zero_u8 = nullptr;
   float* d_infl_keyd = nullptr;
-  uint32_t infl_steps = 0, infl_bands = 0; uint64_t infl_evals = 0; float infl_ms = 0.f;   // last inflation wave
+  uint32_t infl_steps = 0, infl_bands = 0; uint64_t infl_evals = 0; float infl_ms = 0.f, infl_ms_wave = 0.f;   // last inflation wave
   uint32_t* d_next_plan = nullptr;
   uint32_t wave_min_batch = 0;                                     // auto engine: 0 = never pick k_plan_wave (MNAV_WAVE_MIN_BATCH to opt in)
   TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
@@ -3281,6 +3281,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
               last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used);
     if (last.done) break;
   }
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
   // verification: every vertex must be a fixed point of the replay rule on the converged state (k_cvp_verify)
   if (verify_sweeps(ctx, 1)) { if (d_inv) (void)hipFree(d_inv); return -1; }
   hipLaunchKernelGGL(k_infl_cost, dim3(gb), dim3(kBlock), 0, ctx->stream, V, L.dist, inflation_radius, inscribed_radius, inscribed_value,
@@ -3292,7 +3293,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (d_inv) (void)hipFree(d_inv);
   ctx->infl_steps = (uint32_t)(last.it < 0 ? 0 : last.it); ctx->infl_bands = last.bands; ctx->infl_evals = last.evals;
-  ctx->infl_ms = ev_ms(ctx->ev[1], ctx->ev[3]);
+  ctx->infl_ms = ev_ms(ctx->ev[1], ctx->ev[3]); ctx->infl_ms_wave = ev_ms(ctx->ev[1], ctx->ev[2]);
   if (last.overflow) { ctx->err = "inflation wave did not converge (work-list overflow or step limit)"; return -1; }
   if (flags.n_next & kFlagWalkLimit) { ctx->err = "inflation wave: cascade-tree walk bound hit; the result may not be the reference's"; return -1; }
   if (flags.changed) { ctx->err = "inflation wave: the converged state is not a fixed point of the replay rule"; return -1; }
@@ -3317,13 +3318,15 @@ int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t
   return 0;
 }
 
-int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms)
+int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms, uint32_t* verify_sweeps, float* ms_wave)
 {
   if (!ctx) return -1;
   if (steps) *steps = ctx->infl_steps;
   if (bands) *bands = ctx->infl_bands;
   if (evals) *evals = ctx->infl_evals;
   if (ms) *ms = ctx->infl_ms;
+  if (verify_sweeps) *verify_sweeps = ctx->verify_sweeps_used;
+  if (ms_wave) *ms_wave = ctx->infl_ms_wave;
   return 0;
 }
 

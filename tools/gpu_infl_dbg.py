@@ -8,7 +8,7 @@ mesh = meshgen.terrain(1000, 0.1, 3)
 vnrm, _ = vertex_normals(mesh)
 ctx = capi.MnavContext(0)
 ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, vnrm)
-for thr in (0.3, 0.6, 0.3):
+for thr in (0.3, 0.6, 0.3, 0.6, 0.6, 0.6):
     ctx.layer_steepness(0, thr)
     t = time.perf_counter(); st = ctx.layer_inflation(1, 0); print("thr", thr, st, "wall ms", (time.perf_counter() - t) * 1e3, flush=True)
 ctx.close()
