@@ -1,0 +1,357 @@
+// mesh_gpu_planners -- see include/mesh_gpu_planners/gpu_mesh_planners.h.
+// Reference line numbers (dijkstra_mesh_planner.cpp / cvp_mesh_planner.cpp / mesh_map.cpp) mark the step of the
+// reference each block stands in for.
+#include <mesh_gpu_planners/gpu_mesh_planners.h>
+
+#include <cstring>
+#include <limits>
+
+#include <mesh_map/util.h>
+#include <pluginlib/class_list_macros.hpp>
+
+PLUGINLIB_EXPORT_CLASS(mesh_gpu_planners::GpuDijkstraMeshPlanner, mbf_mesh_core::MeshPlanner)
+PLUGINLIB_EXPORT_CLASS(mesh_gpu_planners::GpuCVPMeshPlanner, mbf_mesh_core::MeshPlanner)
+
+namespace mesh_gpu_planners
+{
+using Result = mbf_msgs::action::GetPath::Result;
+using geometry_msgs::msg::PoseStamped;
+
+namespace
+{
+uint64_t mix_words(const void* data, size_t bytes, uint64_t h)
+{
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  size_t i = 0;
+  for (; i + 8 <= bytes; i += 8) {
+    uint64_t w;
+    std::memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  for (; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+  return h;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+DeviceMap::DeviceMap(int device) : ctx_(mnav_create(device)) {}
+DeviceMap::~DeviceMap() { if (ctx_) mnav_destroy(ctx_); }
+
+// The half-edge mesh as flat arrays, in the reference's own ids (handle indices), once per map.
+bool DeviceMap::uploadMesh(mesh_map::MeshMap& map, std::string& err)
+{
+  if (!ctx_) { err = "no usable GPU (mnav_create failed)"; return false; }
+  const auto mesh = map.mesh();
+  if (!mesh) { err = "the map holds no mesh"; return false; }
+  V_ = (uint32_t)mesh->nextVertexIndex(); F_ = (uint32_t)mesh->nextFaceIndex(); E_ = (uint32_t)mesh->nextEdgeIndex();
+  if (mesh->numVertices() != V_ || mesh->numFaces() != F_ || mesh->numEdges() != E_) {
+    err = "meshes with deleted elements (gaps in the handle indices) are not supported";
+    return false;
+  }
+  std::vector<float> xyz((size_t)V_ * 3), nrm((size_t)V_ * 3, 0.f);
+  std::vector<uint32_t> faces((size_t)F_ * 3), edges((size_t)E_ * 2), vf_ptr, vf;
+  const auto& normals = map.vertexNormals();
+  vf_ptr.reserve((size_t)V_ + 1); vf.reserve((size_t)F_ * 3);
+  vf_ptr.push_back(0);
+  for (uint32_t v = 0; v < V_; ++v) {
+    const lvr2::VertexHandle vH(v);
+    const auto p = mesh->getVertexPosition(vH);
+    xyz[3 * (size_t)v] = p.x; xyz[3 * (size_t)v + 1] = p.y; xyz[3 * (size_t)v + 2] = p.z;
+    const auto n = std::as_const(normals).get(vH);
+    if (n) { nrm[3 * (size_t)v] = n->x; nrm[3 * (size_t)v + 1] = n->y; nrm[3 * (size_t)v + 2] = n->z; }
+    for (const auto fH : mesh->getFacesOfVertex(vH)) vf.push_back(fH.idx());   // the circulator ORDER the CVP loop depends on (:775-778)
+    vf_ptr.push_back((uint32_t)vf.size());
+  }
+  for (uint32_t f = 0; f < F_; ++f) {
+    const auto vs = mesh->getVerticesOfFace(lvr2::FaceHandle(f));
+    for (int k = 0; k < 3; ++k) faces[3 * (size_t)f + k] = vs[k].idx();
+  }
+  for (uint32_t e = 0; e < E_; ++e) {
+    const auto vs = mesh->getVerticesOfEdge(lvr2::EdgeHandle(e));
+    edges[2 * (size_t)e] = vs[0].idx(); edges[2 * (size_t)e + 1] = vs[1].idx();
+  }
+  if (mnav_set_face_circulation(ctx_, V_, F_, vf_ptr.data(), vf.data()) != 0 ||
+      mnav_upload_mesh(ctx_, V_, F_, E_, xyz.data(), faces.data(), edges.data(), nrm.data()) != 0) {
+    err = mnav_last_error(ctx_);
+    return false;
+  }
+  mnav_set_resident_outputs(ctx_, 1);            // potential / predecessors / vector map stay on the device until asked for
+  have_costs_ = false;
+  return true;
+}
+
+// vertexCosts() / edgeWeights() / invalid, re-read like the reference does on every plan; uploaded when they changed.
+bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err)
+{
+  const auto& vc = map.vertexCosts();
+  const auto& ew = map.edgeWeights();
+  costs_.resize(V_); weights_.resize(E_); invalid_.resize(V_);
+  for (uint32_t v = 0; v < V_; ++v) {
+    const lvr2::VertexHandle vH(v);
+    const auto c = std::as_const(vc).get(vH);
+    costs_[v] = c ? *c : 0.f;
+    invalid_[v] = map.invalid[vH] ? 1 : 0;
+  }
+  for (uint32_t e = 0; e < E_; ++e) {
+    const auto w = std::as_const(ew).get(lvr2::EdgeHandle(e));
+    weights_[e] = w ? *w : std::numeric_limits<float>::infinity();
+  }
+  uint64_t h = mix_words(costs_.data(), sizeof(float) * V_, 0xCBF29CE484222325ull);
+  h = mix_words(weights_.data(), sizeof(float) * E_, h);
+  h = mix_words(invalid_.data(), V_, h);
+  if (have_costs_ && h == cost_hash_) return true;
+  if (mnav_upload_costs(ctx_, costs_.data(), weights_.data(), invalid_.data()) != 0) { err = mnav_last_error(ctx_); return false; }
+  cost_hash_ = h; have_costs_ = true;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Dijkstra
+// ------------------------------------------------------------------------------------------------------------------
+bool GpuDijkstraMeshPlanner::initialize(const std::string& plugin_name, const std::shared_ptr<mesh_map::MeshMap>& mesh_map_ptr,
+                                        const rclcpp::Node::SharedPtr& node)                     // dijkstra :142-169
+{
+  mesh_map_ = mesh_map_ptr; name_ = plugin_name; node_ = node;
+  map_frame_ = mesh_map_->mapFrame();
+  config_.publish_vector_field = node_->declare_parameter(name_ + ".publish_vector_field", config_.publish_vector_field);
+  config_.publish_face_vectors = node_->declare_parameter(name_ + ".publish_face_vectors", config_.publish_face_vectors);
+  config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);
+  config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
+  const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
+  dev_ = std::make_unique<DeviceMap>(device);
+  std::string err;
+  if (!dev_->uploadMesh(*mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
+    RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
+    return false;
+  }
+  return true;
+}
+
+bool GpuDijkstraMeshPlanner::cancel()                                                              // :136-140
+{
+  cancel_planning_ = true;
+  if (dev_ && dev_->ok()) mnav_cancel(dev_->ctx());
+  return true;
+}
+
+// dijkstra(start, goal, path) :217-398: the wave starts in the vertex next to `wave_seed` and runs until the vertex
+// next to `wave_target` is settled; `path` = vertices from the seed side to the predecessor of the target (:358-373)
+uint32_t GpuDijkstraMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_map::Vector& wave_target, std::list<lvr2::VertexHandle>& path)
+{
+  const auto seed_opt = mesh_map_->getNearestVertexHandle(wave_seed);                             // :235
+  const auto target_opt = mesh_map_->getNearestVertexHandle(wave_target);                         // :236
+  cancel_planning_ = false;                                                                        // :238
+  if (!seed_opt) return Result::INVALID_START;                                                     // :240
+  if (!target_opt) return Result::INVALID_GOAL;                                                    // :242
+  path.clear();
+  std::string err;
+  if (!dev_->syncCosts(*mesh_map_, err)) { RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err); return Result::INTERNAL_ERROR; }
+  const uint32_t V = dev_->numVertices();
+  std::vector<uint32_t> ids(V ? V : 1);
+  uint32_t n = 0;
+  const uint32_t code = mnav_plan_dijkstra(dev_->ctx(), seed_opt.unwrap().idx(), target_opt.unwrap().idx(), config_.goal_dist_offset,
+                                           config_.cost_limit, nullptr, nullptr, ids.data(), V, &n, nullptr);
+  if (code != Result::SUCCESS) return code;
+  for (uint32_t i = 0; i < n; ++i) path.push_back(lvr2::VertexHandle(ids[i]));
+  if (config_.publish_vector_field) exportVectorMap();
+  return Result::SUCCESS;
+}
+
+// computeVectorMap's side effect, MeshMap::setVectorMap (:189-209): only when somebody wants the field on the host
+void GpuDijkstraMeshPlanner::exportVectorMap()
+{
+  const uint32_t V = dev_->numVertices();
+  std::vector<float> vm((size_t)V * 3);
+  std::vector<uint32_t> pred(V);
+  if (mnav_download_output(dev_->ctx(), 0, 4, vm.data()) != 0 || mnav_download_output(dev_->ctx(), 0, 1, pred.data()) != 0) return;
+  lvr2::DenseVertexMap<mesh_map::Vector> field;
+  for (uint32_t v = 0; v < V; ++v)
+    if (pred[v] != v) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(vm[3 * (size_t)v], vm[3 * (size_t)v + 1], vm[3 * (size_t)v + 2]));   // :197
+  mesh_map_->setVectorMap(field);                                                                  // :208
+}
+
+bool GpuDijkstraMeshPlanner::potential(std::vector<float>& out)
+{
+  out.assign(dev_->numVertices(), 0.f);
+  return mnav_download_output(dev_->ctx(), 0, 0, out.data()) == 0;
+}
+
+uint32_t GpuDijkstraMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped& goal, double /*tolerance*/,
+                                          std::vector<PoseStamped>& plan_out, double& cost, std::string& /*message*/)   // :55-134
+{
+  PoseStamped start_in_map, goal_in_map;
+  try {
+    start_in_map = mesh_map_->transformToMapFrame(start);
+    goal_in_map = mesh_map_->transformToMapFrame(goal);
+  } catch (tf2::TransformException& ex) {
+    RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": cannot transform start or goal into '" << map_frame_ << "': " << ex.what());
+    return Result::TF_ERROR;
+  }
+  mesh_map::Vector robot = mesh_map::toVector(start_in_map.pose.position);
+  const mesh_map::Vector target = mesh_map::toVector(goal_in_map.pose.position);
+  std::list<lvr2::VertexHandle> path;
+  const uint32_t outcome = plan(target, robot, path);              // the wave runs from the goal towards the robot (:84)
+  path.reverse();                                                  // robot side first
+  std_msgs::msg::Header header;
+  header.stamp = node_->now();
+  header.frame_id = mesh_map_->mapFrame();
+  cost = 0;
+  if (!path.empty()) {                                             // one pose per path vertex, looking at the next one (:90-116)
+    const auto mesh = mesh_map_->mesh();
+    const auto& normals = mesh_map_->vertexNormals();
+    mesh_map::Vector here = robot;
+    mesh_map::Normal up = normals[path.front()];
+    float step = 0.f;
+    PoseStamped pose;
+    pose.header = header;
+    for (const lvr2::VertexHandle vH : path) {
+      const mesh_map::Vector next = mesh->getVertexPosition(vH);
+      pose.pose = mesh_map::calculatePoseFromPosition(here, next, up, step);
+      cost += step;
+      here = next;
+      up = normals[vH];
+      plan_out.push_back(pose);
+    }
+    pose.pose = mesh_map::calculatePoseFromPosition(here, target, up, step);
+    cost += step;
+    plan_out.push_back(pose);
+  }
+  // publishing of the path / potential / vector field (:118-131) is ROS I/O of the hosting node and not done here
+  return outcome;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// CVP
+// ------------------------------------------------------------------------------------------------------------------
+bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::shared_ptr<mesh_map::MeshMap>& mesh_map_ptr,
+                                   const rclcpp::Node::SharedPtr& node)                            // cvp :148-186
+{
+  mesh_map_ = mesh_map_ptr; name_ = plugin_name; node_ = node;
+  map_frame_ = mesh_map_->mapFrame();
+  config_.publish_vector_field = node_->declare_parameter(name_ + ".publish_vector_field", config_.publish_vector_field);
+  config_.publish_face_vectors = node_->declare_parameter(name_ + ".publish_face_vectors", config_.publish_face_vectors);
+  config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);
+  config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
+  config_.step_width = node_->declare_parameter(name_ + ".step_width", config_.step_width);
+  const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
+  dev_ = std::make_unique<DeviceMap>(device);
+  std::string err;
+  if (!dev_->uploadMesh(*mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
+    RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
+    return false;
+  }
+  return true;
+}
+
+bool GpuCVPMeshPlanner::cancel()                                                                   // :142-146
+{
+  cancel_planning_ = true;
+  if (dev_ && dev_->ok()) mnav_cancel(dev_->ctx());
+  return true;
+}
+
+bool GpuCVPMeshPlanner::potential(std::vector<float>& out)
+{
+  out.assign(dev_->numVertices(), 0.f);
+  return mnav_download_output(dev_->ctx(), 0, 0, out.data()) == 0;
+}
+
+// waveFrontPropagation(start, goal, path, message) :651-970: wave from the face under `wave_seed` until the face under
+// `wave_target` is settled (GPU), then the walk along the vector field from the target back to the seed (host, the
+// map's own meshAhead)
+uint32_t GpuCVPMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_map::Vector& wave_target,
+                                 std::list<std::pair<mesh_map::Vector, lvr2::FaceHandle>>& path, std::string& message)
+{
+  mesh_map::Vector seed = wave_seed, target = wave_target;        // getContainingFace projects its argument (:673-674)
+  const lvr2::OptionalFaceHandle seed_opt = mesh_map_->getContainingFace(seed, 0.4);
+  const lvr2::OptionalFaceHandle target_opt = mesh_map_->getContainingFace(target, 0.4);
+  cancel_planning_ = false;                                                                        // :679
+  if (!seed_opt) { message = "Could not find a face close enough to the given start pose"; return Result::INVALID_START; }   // :681
+  if (!target_opt) { message = "Could not find a face close enough to the given goal pose"; return Result::INVALID_GOAL; }   // :686
+  const lvr2::FaceHandle seed_face = seed_opt.unwrap(), target_face = target_opt.unwrap();
+  path.clear();
+  std::string err;
+  if (!dev_->syncCosts(*mesh_map_, err)) { message = err; return Result::INTERNAL_ERROR; }
+  const uint32_t V = dev_->numVertices();
+  std::vector<float> vm((size_t)V * 3);
+  const float seed_pos[3] = { seed.x, seed.y, seed.z };
+  const uint32_t code = mnav_plan_cvp(dev_->ctx(), seed_pos, seed_face.idx(), target_face.idx(), config_.goal_dist_offset, config_.cost_limit,
+                                      nullptr, nullptr, nullptr, nullptr, vm.data());              // only the vector map comes back
+  if (code == Result::CANCELED) return code;
+  if (code == Result::INTERNAL_ERROR) { message = mnav_last_error(dev_->ctx()); return code; }
+  // MeshMap::setVectorMap (:238): the field the map's meshAhead walks on.  Present for the three seed vertices (their
+  // offset from the seed position, :722-724) and for every vertex the wave updated; the device writes zeros elsewhere.
+  lvr2::DenseVertexMap<mesh_map::Vector> field;
+  const auto mesh = mesh_map_->mesh();
+  for (uint32_t v = 0; v < V; ++v) {
+    const float* q = &vm[3 * (size_t)v];
+    if (q[0] != 0.f || q[1] != 0.f || q[2] != 0.f) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(q[0], q[1], q[2]));
+  }
+  for (const auto vH : mesh->getVerticesOfFace(seed_face)) {
+    const float* q = &vm[3 * (size_t)vH.idx()];
+    field.insert(vH, mesh_map::Vector(q[0], q[1], q[2]));
+  }
+  mesh_map_->setVectorMap(field);
+  if (code == Result::NO_PATH_FOUND) { message = "Predecessor of the goal is not set! No path found!"; return code; }   // :912-918
+  lvr2::FaceHandle face = target_face;                                                             // :920-951
+  mesh_map::Vector pos = target;
+  path.push_front(std::make_pair(pos, face));
+  while (pos.distance2(seed) > config_.step_width && !cancel_planning_) {                          // (squared distance against the width, as is)
+    try {
+      if (!mesh_map_->meshAhead(pos, face, config_.step_width)) {
+        message = "Could not find a valid path, while back-tracking from the goal";
+        return Result::NO_PATH_FOUND;
+      }
+      path.push_front(std::make_pair(pos, face));
+    } catch (lvr2::PanicException&) {
+      message = "Could not find a valid path, while back-tracking from the goal: HalfEdgeMesh panicked!";
+      return Result::NO_PATH_FOUND;
+    }
+  }
+  path.push_front(std::make_pair(seed, seed_face));
+  if (cancel_planning_) return Result::CANCELED;
+  return Result::SUCCESS;
+}
+
+uint32_t GpuCVPMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped& goal, double /*tolerance*/,
+                                     std::vector<PoseStamped>& plan_out, double& cost, std::string& message)   // :62-140
+{
+  PoseStamped start_in_map, goal_in_map;
+  try {
+    start_in_map = mesh_map_->transformToMapFrame(start);
+    goal_in_map = mesh_map_->transformToMapFrame(goal);
+  } catch (tf2::TransformException& ex) {
+    RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": cannot transform start or goal into '" << map_frame_ << "': " << ex.what());
+    return Result::TF_ERROR;
+  }
+  const mesh_map::Vector robot = mesh_map::toVector(start_in_map.pose.position);
+  const mesh_map::Vector target = mesh_map::toVector(goal_in_map.pose.position);
+  std::list<std::pair<mesh_map::Vector, lvr2::FaceHandle>> path;
+  const uint32_t outcome = plan(target, robot, path, message);     // wave from the goal (:89)
+  path.reverse();
+  std_msgs::msg::Header header;
+  header.stamp = node_->now();
+  header.frame_id = mesh_map_->mapFrame();
+  cost = 0;
+  if (!cancel_planning_ && !path.empty()) {                        // :101-124
+    const auto& face_normals = mesh_map_->faceNormals();
+    mesh_map::Vector here = path.front().first;
+    lvr2::FaceHandle face = path.front().second;
+    path.pop_front();
+    float step = 0.f;
+    PoseStamped pose;
+    pose.header = header;
+    for (const auto& next : path) {
+      pose.pose = mesh_map::calculatePoseFromPosition(here, next.first, face_normals[face], step);
+      cost += step;
+      here = next.first;
+      face = next.second;
+      plan_out.push_back(pose);
+    }
+    pose.pose = goal_in_map.pose;                                  // the goal pose itself closes the plan
+    plan_out.push_back(pose);
+  }
+  return outcome;
+}
+}  // namespace mesh_gpu_planners

@@ -16,6 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libmnav_ref.so")
+# the same library + the product's ROS plugin package (integration/mesh_gpu_planners) linked against libmnav.so
+GPU_LIB_PATH = os.path.join(_HERE, "_ref", "libmnav_ref_gpu.so")
 INFLATION_TEST = os.path.join(_HERE, "_ref", "ref_inflation_test")
 NONE = 0xFFFFFFFF
 
@@ -28,6 +30,7 @@ def build(force: bool = False) -> str | None:
     """(Re)build from /root/reference when it is there; otherwise use the prebuilt library as is."""
     if reference_present():
         srcs = [os.path.join(_HERE, "ref_build", f) for f in ("ref_harness.cpp", "build.sh")]
+        srcs.append(os.path.join(_HERE, "..", "integration", "mesh_gpu_planners", "src", "gpu_mesh_planners.cpp"))
         stale = (force or not os.path.exists(LIB_PATH)
                  or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
         if stale:
@@ -49,8 +52,22 @@ def lib():
         path = build()
         if path is None:
             raise RuntimeError("oracle/_ref/libmnav_ref.so is missing and /root/reference is not here to build it")
-        L = C.CDLL(path)
+        L = None
+        if os.path.exists(GPU_LIB_PATH):                 # one process, one copy of the reference code: prefer the GPU build
+            try:
+                L = C.CDLL(GPU_LIB_PATH)
+            except OSError:                              # libmnav.so / the HIP runtime cannot be loaded here: CPU build
+                L = None
+        globals()["_has_plugins"] = L is not None
+        if L is None:
+            L = C.CDLL(path)
         vp, u32, f32, f64, cp = C.c_void_p, C.c_uint32, C.c_float, C.c_double, C.c_char_p
+        L.ref_plugin_init.restype = C.c_int
+        L.ref_plugin_init.argtypes = [vp, cp, cp]
+        L.ref_plugin_make_plan.restype = u32
+        L.ref_plugin_make_plan.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(f64)]
+        L.ref_plugin_cancel.argtypes = [vp]
+        L.ref_plugin_release.argtypes = [vp]
         L.ref_new.restype = vp
         L.ref_free.argtypes = [vp]
         L.ref_param_double.argtypes = [vp, cp, f64]
@@ -392,6 +409,24 @@ class RefMap:
         return RefCvp(code, dist, pred, dirn, cut, vm, hv, pp[:k].copy(), pf[:k].copy(),
                       lib().ref_message(self._h).decode())
 
+    def plugin_init(self, lookup_name: str, name: str, **params) -> bool:
+        """Loads a MeshPlanner plugin by its pluginlib lookup name (like mbf_mesh_nav does) and initializes it on THIS
+        map; `params` are set as ROS parameters `<name>.<key>` first."""
+        for k, v in params.items():
+            lib().ref_param_double(self._h, f"{name}.{k}".encode(), float(v))
+        return bool(lib().ref_plugin_init(self._h, lookup_name.encode(), name.encode()))
+
+    def plugin_make_plan(self, start_pose7, goal_pose7):
+        poses = np.zeros((200000, 7), np.float64)
+        n = C.c_uint32(0)
+        cost = C.c_double(0)
+        s, g = np.ascontiguousarray(start_pose7, np.float64), np.ascontiguousarray(goal_pose7, np.float64)
+        code = lib().ref_plugin_make_plan(self._h, _p(s), _p(g), _p(poses), poses.shape[0], C.byref(n), C.byref(cost))
+        return code, poses[: n.value].copy(), cost.value, lib().ref_message(self._h).decode()
+
+    def plugin_release(self):
+        lib().ref_plugin_release(self._h)
+
     def cvp_make_plan(self, start_pose7, goal_pose7, goal_dist_offset=0.3, cost_limit=1.0, step_width=0.4):
         self._init_cvp(goal_dist_offset, cost_limit, step_width)
         poses = np.zeros((200000, 7), np.float64)
@@ -400,6 +435,12 @@ class RefMap:
         s, g = np.ascontiguousarray(start_pose7, np.float64), np.ascontiguousarray(goal_pose7, np.float64)
         code = lib().ref_cvp_make_plan(self._h, _p(s), _p(g), _p(poses), poses.shape[0], C.byref(n), C.byref(cost))
         return code, poses[: n.value].copy(), cost.value, lib().ref_message(self._h).decode()
+
+
+def gpu_plugins_linked() -> bool:
+    """True when the loaded library is the GPU build (the product's MeshPlanner plugins are registered in it)."""
+    lib()
+    return bool(globals().get("_has_plugins"))
 
 
 def run_reference_gtests() -> tuple[int, str]:

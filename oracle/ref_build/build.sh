@@ -47,4 +47,15 @@ $CXX -shared -o "$OUT/libmnav_ref.so" $OBJS "$OUT/obj/ref_harness.o" -lpthread
 $CXX $CXXFLAGS $INC -c "$REF/mesh_layers/test/inflation_layer_test.cpp" -o "$OUT/obj/inflation_layer_test.o"
 $CXX $CXXFLAGS $INC -c "$HERE/gtest_main.cpp" -o "$OUT/obj/gtest_main.o"
 $CXX -o "$OUT/ref_inflation_test" "$OUT/obj/inflation_layer_test.o" "$OUT/obj/gtest_main.o" $OBJS -lpthread
+# GPU build of the same library: + the product's ROS plugin package (integration/mesh_gpu_planners, compiled against the
+# same stub headers and the reference's own mesh_map / mbf_mesh_core headers), linked against libmnav.so.  The reference
+# planners and the GPU plugins then live in one process, on one MeshMap object (tests/test_gpu_plugin_dropin.py).
+REPO="$HERE/../.."
+if [ -f "$REPO/mesh_navigation_amd/libmnav.so" ]; then
+  $CXX $CXXFLAGS $INC -I"$REPO/integration/mesh_gpu_planners/include" -I"$REPO/include" \
+    -c "$REPO/integration/mesh_gpu_planners/src/gpu_mesh_planners.cpp" -o "$OUT/obj/gpu_mesh_planners.o"
+  $CXX -shared -o "$OUT/libmnav_ref_gpu.so" $OBJS "$OUT/obj/ref_harness.o" "$OUT/obj/gpu_mesh_planners.o" \
+    -L"$REPO/mesh_navigation_amd" -lmnav -Wl,-rpath,'$ORIGIN/../../mesh_navigation_amd' -lpthread
+  echo "built $OUT/libmnav_ref_gpu.so"
+fi
 echo "built $OUT/libmnav_ref.so $OUT/ref_inflation_test"

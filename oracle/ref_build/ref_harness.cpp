@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include <mbf_mesh_core/mesh_planner.h>
 #include <mesh_map/mesh_map.h>
 #include <mesh_map/util.h>
 #include <dijkstra_mesh_planner/dijkstra_mesh_planner.h>
@@ -83,6 +84,7 @@ struct Ref
   std::shared_ptr<mesh_map::MeshMap> map;
   std::shared_ptr<dijkstra_mesh_planner::DijkstraMeshPlanner> dij;
   std::shared_ptr<cvp_mesh_planner::CVPMeshPlanner> cvp;
+  std::shared_ptr<mbf_mesh_core::MeshPlanner> plugin;     // any planner loaded by lookup name (ref_plugin_*)
   std::string message;
 };
 int g_counter = 0;
@@ -366,6 +368,32 @@ uint32_t ref_dijkstra_make_plan(void* h, const double start7[7], const double go
   return code;
 }
 void ref_dijkstra_cancel(void* h) { static_cast<Ref*>(h)->dij->cancel(); }
+
+// ---- any MeshPlanner plugin, loaded the way mbf_mesh_nav loads planners (mesh_navigation_server.cpp:74-124): by
+// lookup name through pluginlib, then used through the MeshPlanner interface only.  With the GPU build of this
+// library (build.sh: libmnav_ref_gpu.so) "mesh_gpu_planners/GpuDijkstraMeshPlanner" and ".../GpuCVPMeshPlanner"
+// are registered next to the reference's own planners, on the same MeshMap object.
+int ref_plugin_init(void* h, const char* lookup_name, const char* name)
+{
+  auto* r = static_cast<Ref*>(h);
+  try {
+    pluginlib::ClassLoader<mbf_mesh_core::MeshPlanner> loader("mbf_mesh_core", "mbf_mesh_core::MeshPlanner");
+    r->plugin = loader.createSharedInstance(lookup_name);
+  } catch (const std::exception& e) { r->message = e.what(); r->plugin.reset(); return 0; }
+  return r->plugin->initialize(name, r->map, r->node) ? 1 : 0;
+}
+uint32_t ref_plugin_make_plan(void* h, const double start7[7], const double goal7[7], double* poses, uint32_t cap, uint32_t* n_poses, double* cost)
+{
+  auto* r = static_cast<Ref*>(h);
+  std::vector<geometry_msgs::msg::PoseStamped> plan;
+  r->message.clear();
+  const uint32_t code = r->plugin->makePlan(pose_from(start7, r->map->mapFrame()), pose_from(goal7, r->map->mapFrame()), 0.0, plan, *cost, r->message);
+  *n_poses = plan.size();
+  for (uint32_t i = 0; i < plan.size() && i < cap; ++i) pose_to(plan[i].pose, poses + 7 * i);
+  return code;
+}
+void ref_plugin_cancel(void* h) { auto* r = static_cast<Ref*>(h); if (r->plugin) r->plugin->cancel(); }
+void ref_plugin_release(void* h) { static_cast<Ref*>(h)->plugin.reset(); }
 
 // ---- CVP planner ----
 int ref_cvp_init(void* h, const char* name)

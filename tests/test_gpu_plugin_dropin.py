@@ -1,0 +1,73 @@
+"""The drop-in, end to end: the product's ROS package (integration/mesh_gpu_planners: real mbf_mesh_core::MeshPlanner
+subclasses against the reference's own headers) is loaded BY LOOKUP NAME through pluginlib -- the way
+mbf_mesh_nav/src/mesh_navigation_server.cpp:74-124 loads planners -- and initialized on the REFERENCE's own
+mesh_map::MeshMap object (the reference's mesh_map sources compiled unmodified, oracle/ref_build), next to the
+reference's own planners.  Same map, same poses in, plans compared."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from oracle import ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def pose(p, q=(0, 0, 0, 1)):
+    return np.array([p[0], p[1], p[2], *q], np.float64)
+
+
+@pytest.fixture(scope="module")
+def world():
+    if not R.available() or not R.gpu_plugins_linked():
+        pytest.skip("oracle/_ref/libmnav_ref_gpu.so not built")
+    m = meshgen.terrain(128, 0.1, 21)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0.0, 0.6, m.V).astype(np.float32)
+    rm = R.RefMap(m.xyz, m.faces, vertex_costs=costs, edge_cost_factor=1.0)
+    robot = m.xyz[m.vertex_at(0.85, 0.8)] + np.array([0.031, 0.017, 0.0], np.float32)
+    goal = m.xyz[m.vertex_at(0.12, 0.2)] + np.array([0.023, 0.011, 0.0], np.float32)
+    return m, rm, robot, goal
+
+
+def test_gpu_dijkstra_plugin_equals_the_reference_planner_on_the_reference_map(world):
+    m, rm, robot, goal = world
+    code_r, plan_r, cost_r = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra")
+    code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert code == code_r == 0
+    assert plan.shape == plan_r.shape and len(plan) > 20
+    assert np.array_equal(plan, plan_r)                          # every pose, position and quaternion, bit for bit
+    assert cost == cost_r
+    # a second goal on the same (resident) map, and a start == goal plan
+    goal2 = m.xyz[m.vertex_at(0.5, 0.9)]
+    c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal2))
+    cr, pr, kr = rm.dijkstra_make_plan(pose(robot), pose(goal2))
+    assert c2 == cr == 0 and np.array_equal(p2, pr) and k2 == kr
+    rm.plugin_release()
+
+
+def test_gpu_cvp_plugin_equals_the_reference_planner_on_the_reference_map(world):
+    m, rm, robot, goal = world
+    gq = (0, 0, np.sin(0.3), np.cos(0.3))
+    code_r, plan_r, cost_r, msg_r = rm.cvp_make_plan(pose(robot), pose(goal, gq), step_width=0.3)
+    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp", step_width=0.3)
+    code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal, gq))
+    assert code == code_r == 0, (msg, msg_r)
+    assert len(plan) == len(plan_r) and len(plan) > 10
+    # the device's potential / predecessors / directions are the reference's bits; its vector map differs by the
+    # device cosf/sinf (<= 2e-7), which the reference's own meshAhead then carries along the path
+    assert np.abs(plan[:, :3] - plan_r[:, :3]).max() < 2e-3
+    assert np.array_equal(plan[-1], plan_r[-1])                  # the goal pose closes the plan verbatim
+    assert cost == pytest.approx(cost_r, rel=1e-3)
+    # the reference's default step width loses the surface on this 0.1 m terrain: same outcome, same message
+    rm2 = R.RefMap(m.xyz, m.faces)
+    cr, pr, kr, mr = rm2.cvp_make_plan(pose(robot), pose(goal))
+    assert rm2.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_default")
+    c, p, k, mm = rm2.plugin_make_plan(pose(robot), pose(goal))
+    assert c == cr and mm == mr and len(p) == len(pr)
+    rm.plugin_release(); rm2.plugin_release()
+
+
+def test_unknown_plugin_name_is_reported(world):
+    _, rm, _, _ = world
+    assert not rm.plugin_init("mesh_gpu_planners/NoSuchPlanner", "x")

@@ -312,3 +312,18 @@ def test_inflation_repulsive_field_sampling():
     # ... and on a face the wave never reached the lookup of distances_ panics (caught in cvp_mesh_planner.cpp:944):
     far = base.mesh.faces[(~covered[base.mesh.faces]).all(1)]
     assert len(far) > 0 and rm.layer_vector_at("inflation", far[0], np.float32([0.3, 0.3, 0.4])) is None
+
+
+def test_product_ros_package_builds_against_the_reference_headers_and_refuses_to_run_without_a_gpu():
+    """integration/mesh_gpu_planners (the real mbf_mesh_core::MeshPlanner plugins) compiles against the reference's own
+    mesh_map / mbf_mesh_core headers and links into the reference build; its classes are found by lookup name.  On a
+    box without a GPU initialize() must FAIL (mnav_create returns NULL) -- there is no CPU fallback behind the plugin."""
+    import torch
+    if not R.gpu_plugins_linked():
+        pytest.skip("GPU build of oracle/_ref not present")
+    m = meshgen.terrain(24, 0.1, 1)
+    rm = R.RefMap(m.xyz, m.faces)
+    assert not rm.plugin_init("mesh_gpu_planners/NoSuchPlanner", "x")
+    if not torch.cuda.is_available():
+        assert not rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra")
+        assert not rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp")
