@@ -42,7 +42,7 @@ def test_gpu_dijkstra_plugin_equals_the_reference_planner_on_the_reference_map(w
     goal2 = m.xyz[m.vertex_at(0.5, 0.9)]
     c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal2))
     cr, pr, kr = rm.dijkstra_make_plan(pose(robot), pose(goal2))
-    assert c2 == cr == 0 and np.array_equal(p2, pr) and k2 == kr
+    assert c2 == cr == 0 and np.array_equal(p2, pr, equal_nan=True) and k2 == kr     # (goal ON a vertex: the reference's last pose has a NaN quaternion, so has ours)
     rm.plugin_release()
 
 
