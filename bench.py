@@ -642,7 +642,28 @@ def cpu_baseline(mesh, edge_w, costs, first, B, offset=0.3):
         all_cores = json.loads(lines[-1]) if lines else {"error": (cp.stderr or "no output")[-300:]}
     except Exception as e:                                               # the single-core figure stands on its own
         all_cores = {"error": repr(e)}
-    return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "all_host_cores": all_cores,
+    # the reference's OWN planner code on the same plans (oracle/_ref: dijkstra_mesh_planner.cpp + mesh_map.cpp compiled
+    # unmodified against stub lvr2 / ROS headers -- the containers are the stubs', so this is the reference's algorithm and
+    # code, not lvr2's memory behaviour): reported next to the port, which is the faster of the two and stays the `value`
+    reference_code = None
+    try:
+        from oracle import ref as R
+        if R.available():
+            tb = time.perf_counter()
+            rm = R.RefMap(mesh.xyz, mesh.faces)
+            t_build = time.perf_counter() - tb
+            nr, t_ref, same = min(n, 8), 0.0, True
+            for k in range(nr):
+                t1 = time.perf_counter()
+                rr = rm.dijkstra(mesh.xyz[int(g[k])], mesh.xyz[int(t[k])], goal_dist_offset=offset, fields=False)
+                t_ref += time.perf_counter() - t1
+                same = same and rr.code == int(r["codes"][k]) and np.array_equal(rr.path, r["paths"][k])
+            reference_code = {"value": nr / t_ref, "unit": "plans/s", "cores": 1, "ms_per_plan": t_ref / nr * 1e3,
+                              "sample": f"first {nr} plans of the first batch through DijkstraMeshPlanner::dijkstra of oracle/_ref (wall clock incl. nearest-vertex lookup)",
+                              "map_build_s": t_build, "gpu_paths_match_reference_code": bool(same)}
+    except Exception as e:                                               # noqa: BLE001 -- the port figure stands on its own
+        reference_code = {"error": repr(e)[:200]}
+    return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "reference_code": reference_code, "all_host_cores": all_cores,
             "sample": f"first {n} plans of the first batch, oracle Dijkstra single thread, {wall:.1f} s wall",
             "ms_per_plan": t_sum / n, "host_cpu": model, "host_cores_available": os.cpu_count(),
             "gpu_paths_match_oracle": bool(ok)}

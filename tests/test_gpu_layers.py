@@ -20,7 +20,7 @@ def upload(ctx, case):
     ctx.upload_mesh(case.mesh.xyz, case.mesh.faces, case.mesh.edges, case.vn)
 
 
-@pytest.mark.parametrize("N,seed", [(96, 7), (300, 3)])
+@pytest.mark.parametrize("N,seed", [(96, 7), (300, 3), (1000, 3)])      # the last one is BASELINE config 3's mesh, 56 % lethal
 def test_inflation_distances_and_costs_are_the_reference_bits(gpu_ctx_factory, N, seed):
     case = Case(meshgen.terrain(N, 0.1, seed))
     steep, lethal = case.om.steepness(case.vn, 0.3)
