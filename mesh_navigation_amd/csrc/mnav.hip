@@ -2284,6 +2284,7 @@ int verify_sweeps(mnav_ctx* ctx, uint32_t n)
     if (!any) break;
     ++ctx->verify_sweeps_used;
   }
+  if (getenv("MNAV_TRACE")) fprintf(stderr, "[mnav] verification: %u fixing sweep(s)\n", ctx->verify_sweeps_used);
   return 0;
 }
 
