@@ -174,7 +174,9 @@ int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weig
  *                          :311, invalid vertices never fixed :417); then riskiness = fading(distance) (:315-339).
  *                          `invalid` = the map's non-manifold flags (V bytes) or NULL.  Distances are bit-identical to
  *                          the reference's; a converged state that fails the verification sweep returns <0 instead of a
- *                          result.  Not computed here: the layer's repulsive vector field (vector_map_, :277-309).
+ *                          result.  The layer's repulsive vector field (vector_map_, :277-309: an order-dependent
+ *                          accumulation over the lethal contours, then assignments in pop order) is computed as well
+ *                          (mnav_layer_download_vectors), under the (value, id) heap-tie convention of the library.
  *   mnav_layer_download    copies of a layer's costs / lethal flags / wave distances (NULL to skip; distances only for an
  *                          inflation layer, +inf where the wave never arrived)
  *   mnav_combine_layers    CombinationLayer (mode 0 = max :44-85, 1 = weighted sum :185-248) over resident layers, then
@@ -186,6 +188,8 @@ int mnav_layer_steepness(mnav_ctx* ctx, uint32_t layer, double threshold);
 int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, double inflation_radius, double inscribed_radius,
                          double inscribed_value, double lethal_value, double cost_scaling_factor, const uint8_t* invalid);
 int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t* lethal_out, float* distances_out);
+/* vector_map_ of an inflation layer: V*3 floats and V flags (1 = the reference's map holds an entry); NULL to skip. */
+int mnav_layer_download_vectors(mnav_ctx* ctx, uint32_t layer, float* vectors_out, uint8_t* has_vector_out);
 int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights,
                         double edge_cost_factor, const uint8_t* invalid);
 /* Counters of the last inflation wave: band steps, bands, vertex evaluations, device milliseconds (whole call), fixing

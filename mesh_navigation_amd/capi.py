@@ -24,7 +24,7 @@ SYMBOLS = [
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
-    "mnav_combine_layers", "mnav_layer_stats",
+    "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors",
 ]
 
 
@@ -104,6 +104,8 @@ def load(path: str | None = None):
     L.mnav_layer_inflation.argtypes = [vp, u32, u32, f64, f64, f64, f64, f64, vp]
     L.mnav_layer_download.restype = C.c_int
     L.mnav_layer_download.argtypes = [vp, u32, vp, vp, vp]
+    L.mnav_layer_download_vectors.restype = C.c_int
+    L.mnav_layer_download_vectors.argtypes = [vp, u32, vp, vp]
     L.mnav_combine_layers.restype = C.c_int
     L.mnav_combine_layers.argtypes = [vp, C.c_int, u32, vp, vp, f64, vp]
     L.mnav_layer_stats.restype = C.c_int
@@ -306,6 +308,14 @@ class MnavContext:
         if self._L.mnav_layer_download(self._h, int(layer), _p(c), _p(le), None if d is None else _p(d)) != 0:
             raise RuntimeError(f"mnav_layer_download failed: {self._err()}")
         return (c, le, d) if distances else (c, le)
+
+    def layer_vectors(self, layer: int):
+        """vector_map_ of an inflation layer: (V, 3) floats and the has-entry flags"""
+        vec = np.empty((self.V, 3), np.float32)
+        has = np.empty(self.V, np.uint8)
+        if self._L.mnav_layer_download_vectors(self._h, int(layer), _p(vec), _p(has)) != 0:
+            raise RuntimeError(f"mnav_layer_download_vectors failed: {self._err()}")
+        return vec, has
 
     def combine_layers(self, layers, weights=None, mode: str = "avg", edge_cost_factor: float = 1.0, invalid=None):
         ls = np.ascontiguousarray(layers, np.uint32)

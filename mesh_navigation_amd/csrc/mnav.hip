@@ -237,7 +237,10 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
         int sel = 0; float dir = 0.0f;
         if (k.kind == 3) {                                           // inflation :252,:298-311
           const float u3tmp = (float)k.u3tmp;
-          if (e.d != 0.0f && u3tmp < e.d) { e.d = u3tmp; if (k.sel) { any = true; ins_d = e.d; } }
+          if (e.d != 0.0f && u3tmp < e.d) {
+            e.d = u3tmp; e.pred = gshfl(it[r].v1, src); e.cut = gshfl(it[r].v2, src);   // supports of the last lowering update (vector field)
+            if (k.sel) { any = true; ins_d = e.d; }
+          }
         } else if (k.kind != 0 && cvp_apply(k, e.d, sel, dir)) {
           const uint32_t v1 = gshfl(it[r].v1, src), v2 = gshfl(it[r].v2, src);
           e.pred = (sel == 1) ? v1 : v2; e.dir = dir; e.cut = gshfl(it[r].face, src);
@@ -248,7 +251,7 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
     if (any && !mute) { e.key = key_for(P, ins_d, v, m); e.keyd = ins_d; queued = true; }   // ordinary pop, or a place inside this trigger's cascade
     last = m; first = false;
   }
-  if (!queued) { e.pred = v; e.key = key_inf(); e.keyd = inf_f(); }
+  if (!queued) { if (!infl) e.pred = v; e.key = key_inf(); e.keyd = inf_f(); }
   e.t = key_time(e.key);
   return e;
 }
@@ -1913,6 +1916,42 @@ __global__ __launch_bounds__(kBlock) void k_infl_seed(const Plan* __restrict__ p
   }
 }
 
+// The inflation layer's repulsive vector field from the converged wave (spec: mnav_eval.h infl_accumulate / infl_assign).
+// state: 0 = open (a free vertex with a distance whose vector may still be assigned), 1 = final with a vector, 2 = final
+// without one.  k_infl_assign is launched until nothing is open; it reads the states of the PREVIOUS launch and writes the
+// next ones to a second array, so a vector is only ever read after the launch that wrote it has ended.
+__global__ __launch_bounds__(kBlock) void k_infl_accum(const Plan* __restrict__ plans, const uint32_t* __restrict__ crn_walk,
+                                                       const float* __restrict__ xyz, float* __restrict__ vec, uint8_t* __restrict__ state,
+                                                       uint8_t* __restrict__ acc, uint32_t* __restrict__ ctl)
+{
+  const Plan& P = plans[0];
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= P.V) return;
+  float o[3] = { 0.f, 0.f, 0.f };
+  const int r = infl_accumulate(P, crn_walk, xyz, v, o);
+  if (r < 0) { atomicOr(&ctl[2], 1u); return; }
+  vec[3 * (size_t)v] = o[0]; vec[3 * (size_t)v + 1] = o[1]; vec[3 * (size_t)v + 2] = o[2];
+  acc[v] = r == 1 ? 1 : 0;
+  const bool open = !is_seed(P, v) && P.dist[v] < inf_f();
+  state[v] = open ? 0 : (r == 1 ? 1 : 2);
+}
+
+__global__ __launch_bounds__(kBlock) void k_infl_assign(const Plan* __restrict__ plans, float* __restrict__ vec, const uint8_t* __restrict__ state,
+                                                        uint8_t* __restrict__ state_next, const uint8_t* __restrict__ acc, uint32_t* __restrict__ ctl)
+{
+  const Plan& P = plans[0];
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= P.V) return;
+  const uint8_t st = state[v];
+  if (st != 0) { state_next[v] = st; return; }
+  float o[3];
+  const int r = infl_assign(P, vec, state, v, o);
+  if (r == 2) { state_next[v] = 0; atomicAdd(&ctl[0], 1u); return; }   // a support is still open: next launch
+  if (r == 1) { vec[3 * (size_t)v] = o[0]; vec[3 * (size_t)v + 1] = o[1]; vec[3 * (size_t)v + 2] = o[2]; }
+  state_next[v] = (r == 1 || acc[v]) ? 1 : 2;
+  atomicAdd(&ctl[1], 1u);
+}
+
 // riskiness from the distances: fading() :315-339; vertices the wave never reached keep the default 0
 // (inflation_layer.h:74-77).  The exponential runs in float64 and is rounded to float32 (:326).
 __global__ __launch_bounds__(kBlock) void k_infl_cost(uint32_t V, const float* __restrict__ dist, double inflation_radius,
@@ -1993,6 +2032,7 @@ struct mnav_ctx {
   // device mesh
   uint32_t *d_row_ptr = nullptr, *d_nbr_u = nullptr, *d_nbr_e = nullptr, *d_crn_ptr = nullptr, *d_edge_vtx = nullptr;
   CornerIdx* d_crn_idx = nullptr;
+  uint32_t* d_crn_walk = nullptr;                                   // HostTopology::crn_walk (inflation vector field)
   float *d_xyz = nullptr, *d_nrm = nullptr, *d_cost = nullptr, *d_w = nullptr, *d_edge_dist = nullptr;
   uint8_t* d_invalid = nullptr;
   // materialised per cost_limit
@@ -2046,7 +2086,8 @@ struct mnav_ctx {
   } shard;
   double edge_cost_factor = 0.0;                                   // factor of the resident edge weights (mnav_update_costs)
   // layers computed / kept on the device (mnav_layer_*)
-  struct Layer { float* cost = nullptr; uint8_t* lethal = nullptr; float* dist = nullptr; bool ready = false; };
+  struct Layer { float* cost = nullptr; uint8_t* lethal = nullptr; float* dist = nullptr; float* vec = nullptr; uint8_t* vstate = nullptr;   // vstate: 3 x V (two state arrays + the accumulate flags)
+                 bool ready = false, have_vec = false; };
   std::vector<Layer> layers;
   Corner* d_crn_infl = nullptr; bool crn_infl_valid = false;       // corners over the edge distances (inflation wave)
   uint8_t *d_infl_mask = nullptr, *d_zero_u8 = nullptr;
@@ -2099,7 +2140,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b);
 
 void drop_layers(mnav_ctx* ctx)
 {
-  for (auto& L : ctx->layers) { (void)hipFree(L.cost); (void)hipFree(L.lethal); (void)hipFree(L.dist); }
+  for (auto& L : ctx->layers) { (void)hipFree(L.cost); (void)hipFree(L.lethal); (void)hipFree(L.dist); (void)hipFree(L.vec); (void)hipFree(L.vstate); }
   ctx->layers.clear();
   (void)hipFree(ctx->d_crn_infl); (void)hipFree(ctx->d_infl_mask); (void)hipFree(ctx->d_zero_u8); (void)hipFree(ctx->d_infl_keyd);
   ctx->d_crn_infl = nullptr; ctx->d_infl_mask = nullptr; ctx->d_zero_u8 = nullptr; ctx->d_infl_keyd = nullptr; ctx->crn_infl_valid = false;
@@ -2808,7 +2849,7 @@ void mnav_destroy(mnav_ctx* ctx)
   for (auto& s : ctx->slots) free_slot(s);
   drop_layers(ctx);
   (void)hipFree(ctx->d_row_ptr); (void)hipFree(ctx->d_nbr_u); (void)hipFree(ctx->d_nbr_e); (void)hipFree(ctx->d_crn_ptr);
-  (void)hipFree(ctx->d_edge_vtx); (void)hipFree(ctx->d_crn_idx); (void)hipFree(ctx->d_xyz); (void)hipFree(ctx->d_nrm);
+  (void)hipFree(ctx->d_edge_vtx); (void)hipFree(ctx->d_crn_idx); (void)hipFree(ctx->d_crn_walk); (void)hipFree(ctx->d_xyz); (void)hipFree(ctx->d_nrm);
   (void)hipFree(ctx->d_cost); (void)hipFree(ctx->d_w); (void)hipFree(ctx->d_edge_dist); (void)hipFree(ctx->d_invalid);
   (void)hipFree(ctx->d_nbr); (void)hipFree(ctx->d_crn); (void)hipFree(ctx->d_blocked); (void)hipFree(ctx->d_plans);
   (void)hipFree(ctx->d_res); (void)hipFree(ctx->d_vecptrs); (void)hipFree(ctx->d_paths); (void)hipFree(ctx->d_seed_pos);
@@ -2896,6 +2937,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   if (dev_upload(ctx, &ctx->d_edge_vtx, edge_vtx, 2 * (size_t)E)) return -1;
   std::vector<CornerIdx> ci(t.crn_v1.size());
   for (size_t i = 0; i < ci.size(); ++i) ci[i] = CornerIdx{ t.crn_v1[i], t.crn_v2[i], t.crn_ea[i], t.crn_eb[i], t.crn_ec[i], t.crn_face[i] };
+  if (dev_upload(ctx, &ctx->d_crn_walk, t.crn_walk.data(), t.crn_walk.size())) return -1;
   if (dev_upload(ctx, &ctx->d_crn_idx, ci.data(), ci.size())) return -1;
   if (dev_upload(ctx, &ctx->d_xyz, xyz, 3 * (size_t)V)) return -1;
   ctx->have_normals = vertex_normals != nullptr;
@@ -3288,6 +3330,31 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   hipLaunchKernelGGL(k_infl_cost, dim3(gb), dim3(kBlock), 0, ctx->stream, V, L.dist, inflation_radius, inscribed_radius, inscribed_value,
                      lethal_value, cost_scaling_factor, L.cost);
   HIPCHK(hipGetLastError());
+  // vector_map_ (:277-309): accumulation over the lethal contours, then assignments in pop order (launches until settled)
+  L.have_vec = false;
+  if (!L.vec) HIPCHK(hipMalloc((void**)&L.vec, 12 * Vn));
+  if (!L.vstate) HIPCHK(hipMalloc((void**)&L.vstate, 3 * Vn));
+  if (!ctx->d_verify_any) HIPCHK(hipMalloc((void**)&ctx->d_verify_any, 4));
+  uint32_t* d_vctl = nullptr;
+  HIPCHK(hipMalloc((void**)&d_vctl, 16));
+  HIPCHK(hipMemsetAsync(d_vctl, 0, 16, ctx->stream));
+  uint8_t *st0 = L.vstate, *st1 = L.vstate + Vn, *acc = L.vstate + 2 * Vn;
+  hipLaunchKernelGGL(k_infl_accum, dim3(gb), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_crn_walk, ctx->d_xyz, L.vec, st0, acc, d_vctl);
+  uint32_t vctl[4] = { 0, 0, 0, 0 };
+  bool vec_ok = true;
+  for (int sweep = 0; sweep < 4096; ++sweep) {
+    HIPCHK(hipMemsetAsync(d_vctl, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_infl_assign, dim3(gb), dim3(kBlock), 0, ctx->stream, ctx->d_plans, L.vec, st0, st1, acc, d_vctl);
+    HIPCHK(hipMemcpyAsync(vctl, d_vctl, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::swap(st0, st1);
+    if (vctl[2]) { vec_ok = false; break; }                          // a vertex with too many neighbours for the walk positions
+    if (vctl[0] == 0) break;
+    if (vctl[1] == 0) { vec_ok = false; break; }                     // nothing moved although something waits: not on a verified state
+  }
+  if (st0 != L.vstate) HIPCHK(hipMemcpyAsync(L.vstate, st0, Vn, hipMemcpyDeviceToDevice, ctx->stream));   // final states in the first array
+  (void)hipFree(d_vctl);
+  L.have_vec = vec_ok;
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   Cnt flags{};
   HIPCHK(hipMemcpyAsync(&flags, s.cnt + 3, sizeof(Cnt), hipMemcpyDeviceToHost, ctx->stream));
@@ -3316,6 +3383,23 @@ int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t
     HIPCHK(hipMemcpyAsync(distances_out, L.dist, sizeof(float) * ctx->V, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int mnav_layer_download_vectors(mnav_ctx* ctx, uint32_t layer, float* vectors_out, uint8_t* has_vector_out)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (layer >= ctx->layers.size() || !ctx->layers[layer].ready) { ctx->err = "layer is not resident"; return -1; }
+  mnav_ctx::Layer& L = ctx->layers[layer];
+  if (!L.have_vec) { ctx->err = "this layer has no vector field (not an inflation layer, or a vertex with more than 15 neighbours)"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  const uint32_t V = ctx->V;
+  if (vectors_out) HIPCHK(hipMemcpyAsync(vectors_out, L.vec, 12 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint8_t> st(V ? V : 1);
+  if (has_vector_out) HIPCHK(hipMemcpyAsync(st.data(), L.vstate, V, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (has_vector_out) for (uint32_t v = 0; v < V; ++v) has_vector_out[v] = st[v] == 1 ? 1 : 0;
   return 0;
 }
 

@@ -28,7 +28,14 @@ struct HostTopology {
   std::vector<uint32_t> crn_v1, crn_v2;          // 3F
   std::vector<uint32_t> crn_ea, crn_eb, crn_ec;  // 3F edge ids of sides a=(v2,v3) b=(v1,v3) c=(v1,v2)
   std::vector<uint32_t> crn_face;  // 3F  face id | kCornerFirst1/2
+  // 3F  where the face is visited in the inflation wave's walk around each of its three vertices (inflation_layer.cpp
+  // :423-427: for every neighbour of the popped vertex the face left of cur->nh, then the one left of nh->cur, so a
+  // face comes up twice): 6 x 5 bits {v1: first, second; v2: first, second; the row's own vertex: first, second};
+  // kWalkUnknown when a vertex has too many neighbours for 5 bits (the repulsive field is then not computed there)
+  std::vector<uint32_t> crn_walk;
 };
+constexpr uint32_t kWalkUnknown = 0xFFFFFFFFu;
+inline uint32_t walk_pos(uint32_t walk, int slot) { return (walk >> (5 * slot)) & 31u; }   // slot 0..5
 
 namespace detail {
 inline uint64_t mix64(uint64_t x)
@@ -217,6 +224,41 @@ inline FaceCirculation build_face_circulation(uint32_t V, uint32_t F, const uint
 }
 
 // Throws std::invalid_argument on out-of-range ids or a face side that is not a listed edge.
+// The inflation wave's walk around vertex tv (inflation_layer.cpp:423-427): for every outgoing halfedge h of the vertex
+// circulator the face left of h, then the face left of its opposite.  `rows` = tv's faces in getFacesOfVertex order.
+// The faces around tv form fans (runs of edge-adjacent faces); an interior vertex has one closed fan.  pmp's circulators
+// start at halfedge(tv), which for a boundary vertex is the boundary halfedge that ENDS a fan (no face on its left):
+// that fan's faces come last in `rows`, and its closing visit [-, last face] opens the walk.  Per fan, in row order:
+// [F_0], [F_1, F_0], ..., [F_(k-1), F_(k-2)] and, except for that last fan, its own closing [F_(k-1)].
+inline void inflation_walk(const uint32_t* rows, uint32_t m, const uint32_t* face_vtx, uint32_t tv, uint32_t degree, std::vector<uint32_t>& walk)
+{
+  walk.clear();
+  if (m == 0) return;
+  auto adjacent = [&](uint32_t f, uint32_t g) {                  // share an edge at tv
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t x = face_vtx[3 * size_t(f) + a];
+      if (x == tv) continue;
+      for (int b = 0; b < 3; ++b) if (face_vtx[3 * size_t(g) + b] == x) return true;
+    }
+    return false;
+  };
+  bool closed = (m == degree) && (m == 1 || adjacent(rows[m - 1], rows[0]));
+  for (uint32_t i = 0; closed && i + 1 < m; ++i) closed = adjacent(rows[i], rows[i + 1]);
+  if (closed) {                                                   // interior vertex: pair i = [R_i, R_(i-1)]
+    for (uint32_t i = 0; i < m; ++i) { walk.push_back(rows[i]); walk.push_back(rows[(i + m - 1) % m]); }
+    return;
+  }
+  walk.push_back(rows[m - 1]);                                    // closing visit of the fan that halfedge(tv) ends
+  uint32_t beg = 0;
+  while (beg < m) {
+    uint32_t end = beg + 1;
+    while (end < m && adjacent(rows[end - 1], rows[end])) ++end;
+    for (uint32_t i = beg; i < end; ++i) { walk.push_back(rows[i]); if (i > beg) walk.push_back(rows[i - 1]); }
+    if (end < m) walk.push_back(rows[end - 1]);                   // this fan's closing visit (not the last fan's: it came first)
+    beg = end;
+  }
+}
+
 // `circ`: getFacesOfVertex rows (nullptr: derived from the face list, build_face_circulation).
 inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx,
                                    const uint32_t* edge_vtx, const FaceCirculation* circ = nullptr)
@@ -251,7 +293,7 @@ inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uin
   for (uint32_t v = 0; v < V; ++v) t.crn_ptr[v + 1] += t.crn_ptr[v];
   const size_t C = size_t(F) * 3;
   t.crn_v1.resize(C); t.crn_v2.resize(C); t.crn_ea.resize(C); t.crn_eb.resize(C); t.crn_ec.resize(C);
-  t.crn_face.resize(C);
+  t.crn_face.resize(C); t.crn_walk.assign(C, 0u);
   {
     std::vector<uint32_t> fill(size_t(V) + 1, 0);
     for (uint32_t f = 0; f < F; ++f) {                       // ascending face id per row
@@ -279,21 +321,17 @@ inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uin
   FaceCirculation own;
   if (!circ) { own = build_face_circulation(V, F, face_vtx); circ = &own; }
   {
-    std::vector<uint32_t> seen, order;                           // the v's already met around t; the walk order
+    std::vector<uint32_t> seen, order, walk_tmp;                 // the v's already met around t; the walk order
     for (int pass = 0; pass < 2; ++pass) {                       // 0: getFacesOfVertex order (CVP), 1: inflation wave order
       const uint32_t flag1 = pass == 0 ? kCornerFirst1 : kCornerInfl1, flag2 = pass == 0 ? kCornerFirst2 : kCornerInfl2;
       for (uint32_t tv = 0; tv < V; ++tv) {
         const uint32_t r0 = circ->ptr[tv], m = circ->ptr[tv + 1] - r0;
         order.clear();
         for (uint32_t r = 0; r < m; ++r) order.push_back(circ->faces[r0 + r]);
-        if (pass == 1 && m >= 2) {
-          // pmp vertex circulator from halfedge(tv): for h_i = tv->n_i the faces {left(h_i), left(opposite h_i)} =
-          // {F_i, F_(i-1)}.  Interior vertex (as many faces as edges): first visits F_0, F_last, F_1, ...; boundary
-          // vertex (halfedge(tv) is the boundary one, its left face is missing): F_last, F_1, F_2, ...
-          const uint32_t degree = t.row_ptr[tv + 1] - t.row_ptr[tv];
-          const uint32_t last = order.back();
-          order.pop_back();
-          order.insert(order.begin() + ((m == degree) ? 1 : 0), last);
+        if (pass == 1) {                                            // first visits of the walk, in order
+          inflation_walk(circ->faces.data() + r0, m, face_vtx, tv, t.row_ptr[tv + 1] - t.row_ptr[tv], walk_tmp);
+          order.clear();
+          for (uint32_t f : walk_tmp) if (std::find(order.begin(), order.end(), f) == order.end()) order.push_back(f);
         }
         seen.clear();
         for (uint32_t f : order) {
@@ -310,6 +348,32 @@ inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uin
                 break;
               }
           }
+        }
+      }
+    }
+  }
+  // walk positions (crn_walk): where each face comes up (at most twice) in inflation_walk(tv)
+  {
+    std::vector<uint32_t> walk;
+    for (uint32_t tv = 0; tv < V; ++tv) {
+      const uint32_t r0 = circ->ptr[tv], m = circ->ptr[tv + 1] - r0;
+      if (m == 0) continue;
+      inflation_walk(circ->faces.data() + r0, m, face_vtx, tv, t.row_ptr[tv + 1] - t.row_ptr[tv], walk);
+      const bool fits = walk.size() <= 32;
+      for (uint32_t r = 0; r < m; ++r) {
+        const uint32_t f = circ->faces[r0 + r];
+        uint32_t pa = 0, pb = 0; int seen = 0;
+        for (uint32_t q = 0; q < walk.size(); ++q) if (walk[q] == f) { if (seen == 0) pa = q; else pb = q; ++seen; }
+        if (seen == 1) pb = pa;                                     // boundary: the first / last face comes up once
+        for (int k = 0; k < 3; ++k) {                               // the corner of every vertex of f gets tv's two positions
+          const uint32_t u = face_vtx[3 * size_t(f) + k];
+          for (uint32_t i = t.crn_ptr[u]; i < t.crn_ptr[u + 1]; ++i)
+            if ((t.crn_face[i] & kCornerFaceMask) == f) {
+              const int slot = (t.crn_v1[i] == tv) ? 0 : (t.crn_v2[i] == tv) ? 2 : 4;
+              if (!fits || t.crn_walk[i] == kWalkUnknown) { t.crn_walk[i] = kWalkUnknown; break; }
+              t.crn_walk[i] |= (pa << (5 * slot)) | (pb << (5 * (slot + 1)));
+              break;
+            }
         }
       }
     }

@@ -664,6 +664,7 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
           const InflCand u = infl_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c, P.infl_max);
           if (e.d == 0.0f || !u.ok || !(u.u3tmp < e.d)) continue;       // :252, :271, :298
           e.d = u.u3tmp;                                                // :300
+          e.pred = k.v1; e.cut = k.v2;                                  // supports of the last lowering update (vector field :302-309)
           if (u.requeue) { any = true; ins_d = e.d; }                   // :311 -> pq.insert(v, distances[v]) :451,459,467
         } else {
           const CvpUpd u = cvp_update(P.dist[k.v1], P.dist[k.v2], e.d, k.a, k.b, k.c);
@@ -678,7 +679,7 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
     }
     last = m; first = false;
   }
-  if (!queued) { e.key = key_inf(); e.keyd = inf_f(); e.pred = v; }
+  if (!queued) { e.key = key_inf(); e.keyd = inf_f(); if (!infl) e.pred = v; }
   e.t = key_time(e.key);
   return e;
 }
@@ -792,6 +793,101 @@ MNAV_HD void process_rebuild(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 {
   if (!(P.dist[v] < inf_f())) return;
   process_entry<PLANNER>(P, c, v, ops);      // c.band_new == 1: in-band vertices wake their neighbours
+}
+
+// ---------------------------------------------------------------------------------------
+// The inflation layer's repulsive vector field (vector_map_, inflation_layer.cpp:277-309), from the converged wave.
+// Two parts.  (A) Faces with two lethal corners and one free one add their direction to the vectors of all three
+// vertices, `vec = normalized(vec + dir)`, every time the face is visited: at the pops of both lethal corners (all at
+// time 0, in (0, id) order, before any free vertex pops), twice per pop (:423-427) -- an order-dependent float
+// accumulation, but each vertex's sequence only involves its own faces: infl_accumulate replays it.  (B) A later
+// update that lowers a free vertex from supports that are not both lethal ASSIGNS its vector from the supports' (:302
+// -309); the last lowering update wins, and eval_cvp records its supports in pred / cutf: infl_assign.
+// ---------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+MNAV_HD V3 v3_of(const float* p) { V3 r; r.x = p[0]; r.y = p[1]; r.z = p[2]; return r; }
+MNAV_HD V3 v3_add(V3 a, V3 b) { V3 r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
+MNAV_HD V3 v3_sub(V3 a, V3 b) { V3 r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z; return r; }
+MNAV_HD V3 v3_mul(V3 a, float s) { V3 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
+MNAV_HD V3 v3_unit(V3 a)                                           // lvr2 BaseVector::normalized(): divide by the length
+{
+  const float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+  V3 r; r.x = a.x / l; r.y = a.y / l; r.z = a.z / l;
+  return r;
+}
+MNAV_HD bool infl_is_lethal(uint8_t m) { return m == kInflSeed || m == kInflSeedMute; }
+
+constexpr int kInflMaxEvents = 64;
+// (A) for vertex h.  crn / crn_walk: the inflation corner table (edge distances) and the walk positions of
+// HostTopology::crn_walk.  Returns 0 = no such face around h, 1 = out holds the vector, -1 = cannot be replayed here
+// (a vertex with too many neighbours for the 5-bit positions, or more than kInflMaxEvents visits).
+MNAV_HD int infl_accumulate(const Plan& P, const uint32_t* crn_walk, const float* xyz, uint32_t h, float out[3])
+{
+  unsigned long long key[kInflMaxEvents];
+  V3 dir[kInflMaxEvents];
+  int n = 0;
+  const uint8_t mh = P.seed_mask[h];
+  for (uint32_t i = P.crn_ptr[h]; i < P.crn_ptr[h + 1]; ++i) {
+    const Corner k = P.crn[i];
+    if (k.v1 == kNone) continue;
+    const uint8_t m1 = P.seed_mask[k.v1], m2 = P.seed_mask[k.v2];
+    const int nl = (infl_is_lethal(m1) ? 1 : 0) + (infl_is_lethal(m2) ? 1 : 0) + (infl_is_lethal(mh) ? 1 : 0);
+    if (nl != 2) continue;
+    // the free corner and, in the cyclic order (v1, v2, h), its two predecessors = the update's (v1, v2) (:444-470)
+    uint32_t fv, s1, s2; float a, b, c;                              // a = |s2 fv|, b = |s1 fv|, c = |s1 s2|
+    if (!infl_is_lethal(mh)) { fv = h; s1 = k.v1; s2 = k.v2; a = k.a; b = k.b; c = k.c; }
+    else if (!infl_is_lethal(m1)) { fv = k.v1; s1 = k.v2; s2 = h; a = k.b; b = k.c; c = k.a; }
+    else { fv = k.v2; s1 = h; s2 = k.v1; a = k.c; b = k.a; c = k.b; }
+    const InflCand u = infl_candidate(0.0f, 0.0f, a, b, c, P.infl_max);
+    if (!u.ok) continue;                                             // :271 comes before the vector part
+    const V3 p3 = v3_of(xyz + 3 * (size_t)fv), p1 = v3_of(xyz + 3 * (size_t)s1), p2 = v3_of(xyz + 3 * (size_t)s2);
+    const V3 d = v3_unit(v3_add(v3_sub(p3, p2), v3_sub(p3, p1)));    // :282
+    const uint32_t walk = crn_walk[i];
+    if (walk == 0xFFFFFFFFu) return -1;
+    const uint32_t xs[3] = { k.v1, k.v2, h };
+    const uint8_t ms[3] = { m1, m2, mh };
+    for (int q = 0; q < 3; ++q) {
+      if (ms[q] != kInflSeed) continue;                              // a free corner does not pop here; an invalid lethal one is skipped (:417)
+      const uint32_t pa = (walk >> (10 * q)) & 31u, pb = (walk >> (10 * q + 5)) & 31u;
+      for (int t = 0; t < (pa == pb ? 1 : 2); ++t) {
+        if (n == kInflMaxEvents) return -1;
+        key[n] = ((unsigned long long)xs[q] << 5) | (t == 0 ? pa : pb);
+        dir[n] = d;
+        ++n;
+      }
+    }
+  }
+  if (n == 0) return 0;
+  for (int i = 1; i < n; ++i) {                                      // visit order: pop (vertex id), then position in its walk
+    const unsigned long long kk = key[i]; const V3 dd = dir[i];
+    int j = i - 1;
+    for (; j >= 0 && key[j] > kk; --j) { key[j + 1] = key[j]; dir[j + 1] = dir[j]; }
+    key[j + 1] = kk; dir[j + 1] = dd;
+  }
+  V3 v; v.x = 0.0f; v.y = 0.0f; v.z = 0.0f;
+  for (int i = 0; i < n; ++i) v = v3_unit(v3_add(v, dir[i]));        // :293-295
+  out[0] = v.x; out[1] = v.y; out[2] = v.z;
+  return 1;
+}
+
+// (B) for a free vertex w with a distance: 0 = keeps what (A) gave it (its last lowering update had two lethal supports,
+// or it was never lowered), 1 = out holds the assigned vector, 2 = a support's vector is not final yet (sweep again).
+// state[u]: 0 unknown, 1 final with vector, 2 final without (value_or(zero) :306-307).
+MNAV_HD int infl_assign(const Plan& P, const float* vec, const uint8_t* state, uint32_t w, float out[3])
+{
+  const float d = P.dist[w];
+  const uint32_t s1 = P.pred[w], s2 = P.cutf[w];
+  if (!(d < inf_f()) || s1 == w || s2 == kNone) return 0;
+  const float u1 = P.dist[s1], u2 = P.dist[s2];
+  if (u1 == 0.0f && u2 == 0.0f) return 0;                            // :302
+  if (state[s1] == 0 || state[s2] == 0) return 2;
+  V3 va, vb; va.x = va.y = va.z = 0.0f; vb = va;
+  if (state[s1] == 1) va = v3_of(vec + 3 * (size_t)s1);
+  if (state[s2] == 1) vb = v3_of(vec + 3 * (size_t)s2);
+  const float d31 = d - u1, d32 = d - u2;                            // :274-275
+  const V3 r = v3_unit(v3_add(v3_mul(va, d31), v3_mul(vb, d32)));    // :308
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+  return 1;
 }
 
 // Verification sweep entry (k_cvp_verify): on the CONVERGED state every vertex must be a fixed point of the replay

@@ -403,7 +403,7 @@ def model_lib():
         L.sm_infl_candidate.restype = C.c_float
         L.sm_infl_candidate.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_int)]
         L.sm_run_inflation.restype = u32
-        L.sm_run_inflation.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, u32, vp, vp, vp]
+        L.sm_run_inflation.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, u32, vp, vp, vp, vp, vp, vp]
         _model = L
     return _model
 
@@ -416,7 +416,7 @@ def product_inflation_update(u1, u2, a, b, c, max_distance):
 
 
 def schedule_model_inflation(faces, edges, edge_dist, lethal, max_distance=0.4, delta=None, order=0, invalid=None,
-                             max_steps=0):
+                             max_steps=0, xyz=None):
     """The device's inflation wave (mnav_layer_inflation) on the CPU model: distances + queue values."""
     faces, edges, ed, le = _u32(faces), _u32(edges), _f32(edge_dist), _u8(lethal)
     V, F, E = le.shape[0], faces.shape[0], edges.shape[0]
@@ -424,10 +424,13 @@ def schedule_model_inflation(faces, edges, edge_dist, lethal, max_distance=0.4, 
     dist = np.empty(V, np.float32)
     keyd = np.empty(V, np.float32)
     stats = np.zeros(8, np.uint64)
+    pos = None if xyz is None else _f32(xyz)
+    vec = None if xyz is None else np.zeros((V, 3), np.float32)
+    has = None if xyz is None else np.zeros(V, np.uint8)
     code = model_lib().sm_run_inflation(V, F, E, _p(faces), _p(edges), _p(ed), _p(le), _p(inv), float(max_distance),
                                         float(max_distance if delta is None else delta), int(order), int(max_steps),
-                                        _p(dist), _p(keyd), _p(stats))
-    return dict(code=code, dist=dist, keyd=keyd, steps=int(stats[0]), bands=int(stats[1]), evals=int(stats[2]),
+                                        _p(dist), _p(keyd), _p(stats), _p(pos), _p(vec), _p(has))
+    return dict(code=code, dist=dist, keyd=keyd, vec=vec, has_vec=has, steps=int(stats[0]), bands=int(stats[1]), evals=int(stats[2]),
                 verify_bad=int(stats[5]), verify_flags=int(stats[6]), verify_sweeps=int(stats[7]) & 0xFFFFFFFF, cuts=int(stats[7]) >> 32)
 
 

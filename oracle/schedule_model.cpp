@@ -268,7 +268,8 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
 // lengths, `invalid` optional.  dist/keyd: V floats out.  The model of mnav_layer_inflation (mnav.hip).
 uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx,
                           const float* edge_dist, const uint8_t* lethal, const uint8_t* invalid, float max_distance,
-                          float delta, int order, uint32_t max_steps, float* dist, float* keyd, uint64_t* stats_out)
+                          float delta, int order, uint32_t max_steps, float* dist, float* keyd, uint64_t* stats_out,
+                          const float* xyz, float* vec_out, uint8_t* has_out)
 {
   HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
@@ -320,7 +321,35 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
   c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
   c0.thr = delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
   c0.band_new = 1; c0.width = delta; c0.wmin = inf_f(); c0.epoch = 1;
-  return drive(P, kPlannerCvp, order, ctl, cnt, tkey, blocked, stats_out, nullptr);
+  const uint32_t code = drive(P, kPlannerCvp, order, ctl, cnt, tkey, blocked, stats_out, nullptr);
+  // the layer's vector field from the converged wave (mnav_eval.h infl_accumulate / infl_assign), like k_infl_accum /
+  // k_infl_assign do on the device
+  if (code == kSuccess && xyz && vec_out && has_out) {
+    std::vector<uint8_t> state(V, 0);
+    for (uint32_t v = 0; v < V; ++v) {
+      float o[3] = { 0.f, 0.f, 0.f };
+      const int r = infl_accumulate(P, topo.crn_walk.data(), xyz, v, o);
+      if (r < 0) return kInternalError;
+      vec_out[3 * (size_t)v] = o[0]; vec_out[3 * (size_t)v + 1] = o[1]; vec_out[3 * (size_t)v + 2] = o[2];
+      has_out[v] = r == 1;
+      if (is_seed(P, v) || !(dist[v] < inf_f())) state[v] = r == 1 ? 1 : 2;
+    }
+    for (int sweep = 0; sweep < 100000; ++sweep) {
+      uint32_t waiting = 0, moved = 0;
+      for (uint32_t v = 0; v < V; ++v) {
+        if (state[v]) continue;
+        float o[3];
+        const int r = infl_assign(P, vec_out, state.data(), v, o);
+        if (r == 2) { ++waiting; continue; }
+        if (r == 1) { vec_out[3 * (size_t)v] = o[0]; vec_out[3 * (size_t)v + 1] = o[1]; vec_out[3 * (size_t)v + 2] = o[2]; has_out[v] = 1; }
+        state[v] = has_out[v] ? 1 : 2;
+        ++moved;
+      }
+      if (!waiting) break;
+      if (!moved) return kInternalError;                           // a dependency cycle: cannot happen on a verified state
+    }
+  }
+  return code;
 }
 
 // the product's waveFrontUpdate arithmetic on plain numbers (mnav_eval.h infl_candidate): value offered to the free

@@ -88,3 +88,29 @@ def test_c3_cost_stack_stays_on_the_device(gpu_ctx_factory):
     ref = case.om.dijkstra(want_w, want_vc, s, t)
     out = ctx.plan_dijkstra(s, t)
     assert out.code == ref.code and np.array_equal(bits(out.dist), bits(ref.dist)) and np.array_equal(out.pred, ref.pred)
+
+
+def test_inflation_vector_field_on_the_device(gpu_ctx_factory):
+    """vector_map_ of the inflation layer computed on the device == the sequential oracle, bit for bit (NaN where the
+    reference normalises a zero vector), on a terrain and on a punched mesh with boundary / multi-fan vertices."""
+    rng = np.random.default_rng(2)
+    for mesh in (meshgen.terrain(128, 0.1, 2), meshgen.punched(96, 0.1, 5, drop=0.15)):
+        case = Case(mesh)
+        _, lethal = case.om.steepness(case.vn, 0.5)
+        lethal[mesh.edges[rng.choice(mesh.E, mesh.E // 200, replace=False)].ravel()] = 1
+        ctx = gpu_ctx_factory()
+        upload(ctx, case)
+        ctx.layer_upload(0, np.zeros(mesh.V, np.float32), lethal)
+        for radius in (0.4, 1.0):
+            cfg = O.InflationCfg.defaults()
+            cfg.inflation_radius = radius
+            _, dist, vec = case.om.inflation(lethal, case.edge_dist, cfg)
+            ctx.layer_inflation(1, 0, inflation_radius=radius)
+            _, _, d = ctx.layer_download(1, distances=True)
+            assert np.array_equal(bits(d), bits(dist))
+            dv, has = ctx.layer_vectors(1)
+            a, b = dv.view(np.uint32), np.ascontiguousarray(vec, np.float32).view(np.uint32)
+            same = (a == b).all(axis=1) | (np.isnan(dv).any(axis=1) & np.isnan(vec).any(axis=1))
+            same |= (has == 0) & (vec == 0).all(axis=1)            # no entry in the reference's map
+            assert same.all(), (radius, int((~same).sum()))
+            assert has.sum() > lethal.sum() // 2

@@ -108,3 +108,41 @@ def _gtest_cfg():
     cfg = O.InflationCfg.defaults()
     cfg.inflation_radius, cfg.inscribed_radius, cfg.lethal_value, cfg.inscribed_value, cfg.cost_scaling_factor = 1.5, 0.5, 1.0, 0.9, 1.0
     return cfg
+
+
+def same_vectors(a, b):
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)).all(axis=1) | (np.isnan(a).any(axis=1) & np.isnan(b).any(axis=1))
+
+
+@pytest.mark.parametrize("kind", ["terrain", "punched"])
+def test_repulsive_vector_field_is_the_reference_restatement_bit_for_bit(kind):
+    """vector_map_ (inflation_layer.cpp:277-309): the order-dependent accumulation over the lethal contours (every face
+    with two lethal corners is visited four times, in the order of the lethal corners' pops and of the walk around each)
+    and the assignments from the supports of each vertex's last lowering update -- computed from the converged wave
+    (mnav_eval.h infl_accumulate / infl_assign, what k_infl_accum / k_infl_assign run) against the sequential oracle.
+    The punched mesh has boundary vertices and vertices whose faces form several fans (the walk crosses the gaps)."""
+    rng = np.random.default_rng(1)
+    for s in range(2):
+        mesh = meshgen.terrain(40, 0.1, s) if kind == "terrain" else meshgen.punched(40, 0.1, s, drop=0.15)
+        case = Case(mesh)
+        for trial in range(2):
+            lethal = np.zeros(mesh.V, np.uint8)
+            if trial == 0:
+                lethal[mesh.edges[rng.choice(mesh.E, mesh.E // 100, replace=False)].ravel()] = 1
+            else:
+                _, lethal = case.om.steepness(case.vn, 0.5)
+                lethal[rng.choice(mesh.V, mesh.V // 60, replace=False)] = 1
+            invalid = np.zeros(mesh.V, np.uint8)
+            invalid[rng.choice(mesh.V, mesh.V // 30, replace=False)] = 1
+            for radius, inv in ((0.4, None), (1.0, invalid)):
+                cfg = O.InflationCfg.defaults()
+                cfg.inflation_radius = radius
+                _, dist, vec = case.om.inflation(lethal, case.edge_dist, cfg, invalid=inv)
+                r = O.schedule_model_inflation(mesh.faces, mesh.edges, case.edge_dist, lethal, radius, order=2, invalid=inv,
+                                               max_steps=20000, xyz=mesh.xyz)
+                assert r["code"] == 0 and np.array_equal(bits(r["dist"]), bits(dist))
+                ok = same_vectors(r["vec"], vec)
+                assert ok.all(), (kind, s, trial, radius, int((~ok).sum()))
+                wave = int(np.isfinite(dist).sum()) > int(lethal.sum())     # scattered single lethal vertices start no wave
+                assert (r["has_vec"].sum() > 0) == wave
