@@ -64,7 +64,7 @@ def main() -> None:
     ap.add_argument("--no-configs", action="store_true", help="skip the C3/C4/C5 legs (profiling the headline kernel)")
     ap.add_argument("--skip-c4", action="store_true", help="skip the 10M-vertex leg")
     ap.add_argument("--c4-grid", type=int, default=int(os.environ.get("MNAV_BENCH_C4_N", "3163")))
-    ap.add_argument("--c4-batch", type=int, default=int(os.environ.get("MNAV_BENCH_C4_BATCH", "512")))
+    ap.add_argument("--c4-batch", type=int, default=int(os.environ.get("MNAV_BENCH_C4_BATCH", "1536")))   # one workgroup per plan: 1536 are resident at once (123 GB of per-plan state at 10M)
     args = ap.parse_args()
     if args.cpu_all_cores_child:
         return cpu_all_cores_child(args)
