@@ -532,6 +532,16 @@ constexpr int kTileBlock = 256;
 #ifndef MNAV_PERSIST_WG_PER_CU
 #define MNAV_PERSIST_WG_PER_CU 6        // register budget of k_plan_persistent: 6 workgroups (24 waves) per CU -> <= 80 VGPRs
 #endif
+// Tiles solved per best-first scan of k_plan_persistent (<= kTileBlock / 64) and how far behind the best one a further
+// candidate may lie, in bands.  Measured on C2 (5120 plans, ms per launch): 1 -> 408.5; 2 within one band -> 398.4;
+// 4 within one band -> 453.7 (the order matters more than the scans cost); 4 within 0.1 / 0.25 / 0.5 bands -> 405.6 /
+// 408.5 / 413.0; 2 within 0.5 -> 402.6.
+#ifndef MNAV_SCAN_SLACK
+#define MNAV_SCAN_SLACK 1.0f
+#endif
+#ifndef MNAV_SCAN_CANDS
+#define MNAV_SCAN_CANDS 2
+#endif
 constexpr int kTileVpt = 8;              // owned vertices per thread: tile_size <= 2048
 constexpr int kTileTodo = 64;            // tiles one workgroup takes per round
 constexpr uint32_t kInfBits = 0x7f800000u;
@@ -906,17 +916,30 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
     }
     __syncthreads();
     if (s_stop) { status = 3; break; }
-    best = s_best[0];
+    // the four waves scanned disjoint quarters of the tiles: their four minima, in ascending order, are the candidates
+    // of this scan.  Every candidate below the band threshold is solved without another scan (MNAV_SCAN_CANDS of them at
+    // most; label-correcting: the order of the solves does not change the fixed point, only the work).
+    unsigned long long cand[kTileBlock / 64];
 #pragma unroll
-    for (int w = 1; w < kTileBlock / 64; ++w) best = s_best[w] < best ? s_best[w] : best;
+    for (int w = 0; w < kTileBlock / 64; ++w) cand[w] = s_best[w];
+#pragma unroll
+    for (int a = 0; a < kTileBlock / 64; ++a)
+#pragma unroll
+      for (int b = a + 1; b < kTileBlock / 64; ++b)
+        if (cand[b] < cand[a]) { const unsigned long long x = cand[a]; cand[a] = cand[b]; cand[b] = x; }
+    best = cand[0];
     const float bound = s_bound;
     const float m = u2f((uint32_t)(best >> 32));
-    const uint32_t t = (uint32_t)best;
     if (!(m < inf_f()) || m > bound) break;                        // nothing left that may propagate
     if (acts >= P.max_rounds) { status = 2; break; }
     float thr = m + P.band;
     if (!(thr > m)) thr = next_up(m);
     PT_STAMP(1);
+#pragma unroll 1
+    for (int ci = 0; ci < MNAV_SCAN_CANDS; ++ci) {
+    const float mc = u2f((uint32_t)(cand[ci] >> 32));
+    if (ci > 0 && (!(mc < m + MNAV_SCAN_SLACK * P.band) || mc > bound)) break;   // only tiles about as urgent as the best one (uniform over the workgroup)
+    const uint32_t t = (uint32_t)cand[ci];
     if (tid == 0) {
       stg_u32(pend + t, kInfBits);
       s_hdr[0] = g_vptr[t]; s_hdr[1] = g_vptr[t + 1]; s_hdr[2] = g_hptr[t]; s_hdr[3] = g_hptr[t + 1];
@@ -987,6 +1010,7 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
     // every store / atomic of this activation must have reached the L2 before the next scan
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    }                                                              // candidates of this scan
 #ifdef MNAV_TILE_TIMING
     if (tid == 0 && blockIdx.x == 0) {
       tt[5] = clock64(); tt[6] = sweep; tt[7] = nl;
