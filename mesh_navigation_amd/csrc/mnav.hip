@@ -648,10 +648,27 @@ __device__ __forceinline__ uint32_t tile_sweeps(const TileLds& L, uint32_t nv, f
         const uint32_t c = L.lcol[e];
         const uint32_t ndb = f2u(di + L.lw[e]);
         const uint32_t old = atomicMin(&L.ldu[c], ndb);
+#ifdef MNAV_SWEEP_BALLOT                  // tried: one queue-slot atomic per wave instead of one per pushing lane -- 453 vs 411 ms
+                                          // per launch on C2 (the extra ballot / shuffle instructions cost more than the atomics)
+        bool want = false;
+        if (ndb < old && c < nv) {
+          const uint32_t bit = 1u << (c & 31);
+          want = !(atomicOr(&mk[c >> 5], bit) & bit);
+        }
+        const unsigned long long wm = __ballot(want);
+        if (wm) {
+          const int leader = __ffsll((long long)wm) - 1, lane = tid & 63;
+          uint32_t base = 0;
+          if (lane == leader) base = atomicAdd(nqb, (uint32_t)__popcll(wm));
+          base = __shfl(base, leader);
+          if (want) qb[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = (uint16_t)c;
+        }
+#else
         if (ndb < old && c < nv) {
           const uint32_t bit = 1u << (c & 31);
           if (!(atomicOr(&mk[c >> 5], bit) & bit)) qb[atomicAdd(nqb, 1u)] = (uint16_t)c;
         }
+#endif
       }
     }
     ++sweep;
