@@ -135,3 +135,49 @@ def test_adapter_picks_up_cost_changes_and_cancel(case):
     # (the last orientation is NaN here: the goal sits exactly on a vertex, zero direction, as in the reference)
     assert code3 == 0 and np.array_equal(plan3, plan, equal_nan=True) and cost3 == cost
     pl.close()
+
+
+def test_cvp_make_plan_with_the_device_built_inflation_layer():
+    """The whole chain on the device's own data: lethal walls -> inflation wave, riskiness and repulsive vector field on
+    the GPU (mnav_layer_inflation) -> combined costs and edge weights on the GPU -> CVP wavefront on the GPU -> the
+    adapter's meshAhead walks the planner's field PLUS the layer's vectorAt (mesh_map.cpp:1099-1102), fed with the
+    device-built distances / vectors.  Expected: the oracle's back-tracking with ITS inflation field, which the device
+    fields equal bit for bit."""
+    from mesh_navigation_amd import capi
+    from oracle import oracle as O
+    mesh = meshgen.terrain(44, 0.1, 12, amplitude=0.3)
+    N = mesh.N
+    lethal = np.zeros(mesh.V, np.uint8)
+    i, j = np.meshgrid(np.arange(N), np.arange(N))
+    lethal[(((j == 18) | (j == 25)) & (i > 3) & (i < N - 4)).ravel()] = 1            # a corridor between two lethal walls
+    case = Case(mesh)
+    cfg = O.InflationCfg.defaults()
+    icost, idist, ivec = case.om.inflation(lethal, case.edge_dist, cfg)
+    with capi.MnavContext(0) as ctx:
+        ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, case.vn)
+        ctx.layer_upload(0, np.zeros(mesh.V, np.float32), lethal)
+        ctx.layer_inflation(1, 0)
+        dcost, _, ddist = ctx.layer_download(1, distances=True)
+        dvec, dhas = ctx.layer_vectors(1)
+        ctx.combine_layers([1], [1.0], mode="max", edge_cost_factor=1.0)
+        vc, w = ctx.download_costs()
+    assert np.array_equal(ddist.view(np.uint32), idist.view(np.uint32)) and np.array_equal(dcost.view(np.uint32), icost.view(np.uint32))
+    assert np.array_equal(dvec[dhas == 1].view(np.uint32), ivec[dhas == 1].view(np.uint32))
+    goal = mesh.xyz[21 * N + 6] + np.array([0.02, 0.03, 0.0], np.float32)
+    robot = mesh.xyz[22 * N + N - 8] + np.array([0.03, 0.01, 0.0], np.float32)
+    sf, _ = case.om.containing_face(goal)
+    tf, _ = case.om.containing_face(robot)
+    ref = case.om.cvp(w, vc, case.vn, goal, sf, tf)
+    has_d = np.isfinite(ddist).astype(np.uint8)
+    field = (np.where(np.isfinite(idist), idist, 0).astype(np.float32), ivec, cfg, True)
+    rcode, ppos, pface = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, sf, robot, tf, step_width=0.2, inflation_field=field)
+    poses, rcost = case.om.cvp_poses(case.fn, ppos, pface, pose(goal))
+    pl = CVPMeshPlanner()
+    assert pl.initialize("cvp_mesh_planner", dict(xyz=mesh.xyz, faces=mesh.faces, edges=mesh.edges, vertex_normals=case.vn, face_normals=case.fn,
+                                                  vertex_costs=vc, edge_weights=w, invalid=None), dict(step_width=0.2))
+    pl.add_layer_field(np.where(np.isfinite(ddist), ddist, 0), has_d, dvec, dhas)      # the DEVICE's layer fields
+    code, plan, cost, msg = pl.makePlan(pose(robot), pose(goal))
+    assert code == rcode == 0, msg
+    assert len(plan) == len(poses) and len(plan) > 10
+    assert np.abs(plan[:, :3] - poses[:, :3]).max() < 2e-3 and cost == pytest.approx(rcost, rel=1e-3)
+    pl.close()
