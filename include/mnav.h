@@ -174,7 +174,8 @@ int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weig
  *                          :311, invalid vertices never fixed :417); then riskiness = fading(distance) (:315-339).
  *                          `invalid` = the map's non-manifold flags (V bytes) or NULL.  Distances are bit-identical to
  *                          the reference's; a converged state that fails the verification sweep returns <0 instead of a
- *                          result.  The layer's repulsive vector field (vector_map_, :277-309: an order-dependent
+ *                          result; it works in the first plan slot, so the resident outputs of the last plan are gone
+ *                          afterwards (mnav_download_output fails until the next plan).  The layer's repulsive vector field (vector_map_, :277-309: an order-dependent
  *                          accumulation over the lethal contours, then assignments in pop order) is computed as well
  *                          (mnav_layer_download_vectors), under the (value, id) heap-tie convention of the library.
  *   mnav_layer_download    copies of a layer's costs / lethal flags / wave distances (NULL to skip; distances only for an

@@ -3326,6 +3326,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   HIPCHK(hipMemcpyAsync(L.lethal, In.lethal, V, hipMemcpyDeviceToDevice, ctx->stream));    // lethal_vertices_ = input->lethals() :170,:584
   if (ensure_slots(ctx, 1, true, true, false)) return -1;
   Slot& s = ctx->slots[0];
+  ctx->caller_slot.assign(1, kNone);                                // the wave works in plan slot 0: the last plan's resident outputs are gone
   Plan P;
   memset(&P, 0, sizeof(P));
   P.planner = kPlannerCvp; P.V = V;
@@ -3997,7 +3998,7 @@ int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
 {
   if (!ctx) return nullptr;
-  if (slot < ctx->caller_slot.size()) slot = ctx->caller_slot[slot];      // caller's plan index -> device slot
+  if (slot < ctx->caller_slot.size()) slot = ctx->caller_slot[slot];      // caller's plan index -> device slot (kNone: never ran / overwritten)
   if (slot >= ctx->slots.size()) return nullptr;
   const Slot& s = ctx->slots[slot];
   switch (what) {
