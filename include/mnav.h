@@ -193,6 +193,12 @@ int mnav_layer_download(mnav_ctx* ctx, uint32_t layer, float* costs_out, uint8_t
 int mnav_layer_download_vectors(mnav_ctx* ctx, uint32_t layer, float* vectors_out, uint8_t* has_vector_out);
 int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights,
                         double edge_cost_factor, const uint8_t* invalid);
+/* CombinationLayer::onInputChanged (combination_layer.cpp:87-147, :250-302) + MeshMap::layerChanged (mesh_map.cpp:454-493)
+ * + updateEdgeWeights(changed) (:563-618): after a layer changed on n vertices (re-uploaded or recomputed on the device)
+ * only those vertices are recombined and only the edges around them re-weighted.  Same mode / layers / weights as the full
+ * mnav_combine_layers that came before. */
+int mnav_combine_layers_update(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights, uint32_t n,
+                               const uint32_t* vertex_ids);
 /* Counters of the last inflation wave: band steps, bands, vertex evaluations, device milliseconds (whole call), fixing
  * verification sweeps that were needed, device milliseconds of the wave alone.  Any pointer may be NULL. */
 int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint64_t* evals, float* ms, uint32_t* verify_sweeps,

@@ -24,7 +24,7 @@ SYMBOLS = [
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
-    "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors",
+    "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
 ]
 
 
@@ -104,6 +104,8 @@ def load(path: str | None = None):
     L.mnav_layer_inflation.argtypes = [vp, u32, u32, f64, f64, f64, f64, f64, vp]
     L.mnav_layer_download.restype = C.c_int
     L.mnav_layer_download.argtypes = [vp, u32, vp, vp, vp]
+    L.mnav_combine_layers_update.restype = C.c_int
+    L.mnav_combine_layers_update.argtypes = [vp, C.c_int, u32, vp, vp, u32, vp]
     L.mnav_layer_download_vectors.restype = C.c_int
     L.mnav_layer_download_vectors.argtypes = [vp, u32, vp, vp]
     L.mnav_combine_layers.restype = C.c_int
@@ -324,6 +326,13 @@ class MnavContext:
         if self._L.mnav_combine_layers(self._h, 0 if mode == "max" else 1, len(ls), _p(ls), _p(w), float(edge_cost_factor),
                                        None if inv is None else _p(inv)) != 0:
             raise RuntimeError(f"mnav_combine_layers failed: {self._err()}")
+
+    def combine_layers_update(self, layers, ids, weights=None, mode: str = "avg"):
+        ls = np.ascontiguousarray(layers, np.uint32)
+        w = np.ascontiguousarray(weights if weights is not None else [1.0] * len(ls), np.float32)
+        ii = np.ascontiguousarray(ids, np.uint32)
+        if self._L.mnav_combine_layers_update(self._h, 0 if mode == "max" else 1, len(ls), _p(ls), _p(w), ii.shape[0], _p(ii)) != 0:
+            raise RuntimeError(f"mnav_combine_layers_update failed: {self._err()}")
 
     # ---- one plan over several GPUs (mesh_navigation_amd/sharded.py drives these) ----
     def shard_setup(self, rank: int, world: int) -> int:

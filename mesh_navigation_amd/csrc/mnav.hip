@@ -2028,6 +2028,24 @@ __global__ __launch_bounds__(kBlock) void k_combine_resident(uint32_t V, int mod
   out[v] = cost;
 }
 
+// CombinationLayer::onInputChanged (combination_layer.cpp:87-147 max, :250-302 weighted sum): only the changed vertices
+__global__ __launch_bounds__(kBlock) void k_combine_resident_ids(uint32_t n, const uint32_t* __restrict__ ids, int mode, uint32_t n_layers,
+                                                                 const float* const* __restrict__ layers, const float* __restrict__ weights,
+                                                                 float* __restrict__ out, float* __restrict__ values)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t v = ids[i];
+  float cost = 0.0f;
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    const float tmp = layers[l][v];
+    if (mode == 0) cost = (tmp < cost) ? cost : tmp;               // std::max(tmp, cost) :117
+    else cost += weights[l] * tmp;                                 // :281
+  }
+  out[v] = cost;
+  values[i] = cost;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -3491,6 +3509,53 @@ int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_ptrs); (void)hipFree(d_wts);
   return rc;
+}
+
+// The incremental counterpart of mnav_combine_layers: CombinationLayer::onInputChanged + MeshMap::layerChanged +
+// updateEdgeWeights(changed) for the n vertices a layer reported as changed (the layers themselves were updated on the
+// device or re-uploaded before).  Same combination mode / layer list / weights as the full pass.
+int mnav_combine_layers_update(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32_t* layers, const float* weights, uint32_t n,
+                               const uint32_t* vertex_ids)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!ctx->have_costs) { ctx->err = "no combined costs resident yet (mnav_combine_layers first)"; return -1; }
+  if (mode != 0 && mode != 1) { ctx->err = "combination mode must be 0 (max) or 1 (weighted sum)"; return -1; }
+  if ((n_layers && !layers) || (mode == 1 && n_layers && !weights) || n_layers > 64) { ctx->err = "bad layer list"; return -1; }
+  if (n == 0) return 0;
+  if (!vertex_ids) { ctx->err = "null id array"; return -1; }
+  for (uint32_t i = 0; i < n; ++i) if (vertex_ids[i] >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  std::vector<const float*> ptrs(n_layers ? n_layers : 1, nullptr);
+  for (uint32_t l = 0; l < n_layers; ++l) {
+    if (layers[l] >= ctx->layers.size() || !ctx->layers[layers[l]].ready) { ctx->err = "layer is not resident"; return -1; }
+    ptrs[l] = ctx->layers[layers[l]].cost;
+  }
+  const float** d_ptrs = nullptr; float *d_wts = nullptr, *d_vals = nullptr; uint32_t* d_ids = nullptr;
+  HIPCHK(hipMalloc((void**)&d_ptrs, sizeof(float*) * (n_layers + 1)));
+  HIPCHK(hipMalloc((void**)&d_wts, sizeof(float) * (n_layers + 1)));
+  HIPCHK(hipMalloc((void**)&d_vals, sizeof(float) * n));
+  HIPCHK(hipMalloc((void**)&d_ids, sizeof(uint32_t) * n));
+  std::vector<float> vals(n);
+  int rc = 0;
+  if (n_layers && hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float*) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
+  if (rc == 0 && mode == 1 && n_layers && hipMemcpyAsync(d_wts, weights, sizeof(float) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
+  if (rc == 0 && hipMemcpyAsync(d_ids, vertex_ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_combine_resident_ids, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, d_ids, mode, n_layers, d_ptrs, d_wts,
+                       ctx->d_cost, d_vals);
+    if (ctx->edge_cost_factor != 0.0)                               // "Edge costs are only affected by vertex costs if layer_factor is not 0" (:568-572)
+      hipLaunchKernelGGL(k_update_edge_weights, dim3((8 * n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, d_ids, ctx->d_row_ptr,
+                         ctx->d_nbr_u, ctx->d_nbr_e, ctx->d_edge_dist, ctx->d_cost, ctx->edge_cost_factor, ctx->d_w);
+    if (hipGetLastError() != hipSuccess) rc = -1;
+  }
+  if (rc == 0 && hipMemcpyAsync(vals.data(), d_vals, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = -1;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_ptrs); (void)hipFree(d_wts); (void)hipFree(d_vals); (void)hipFree(d_ids);
+  if (rc != 0) { if (ctx->err.empty()) ctx->err = "incremental combination failed"; return rc; }
+  for (uint32_t i = 0; i < n; ++i) ctx->h_cost[vertex_ids[i]] = vals[i];
+  ctx->nbr_valid = ctx->crn_valid = false;                          // the cost-limit folded copies are rebuilt on the next plan
+  return 0;
 }
 
 static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, const uint32_t* targets, double offset,

@@ -114,3 +114,30 @@ def test_inflation_vector_field_on_the_device(gpu_ctx_factory):
             same |= (has == 0) & (vec == 0).all(axis=1)            # no entry in the reference's map
             assert same.all(), (radius, int((~same).sum()))
             assert has.sum() > lethal.sum() // 2
+
+
+def test_incremental_combination_equals_the_full_pass(gpu_ctx_factory):
+    """CombinationLayer::onInputChanged + layerChanged + updateEdgeWeights(changed): a layer changes on a few hundred
+    vertices; recombining only those and re-weighting only the edges around them must give the very arrays the full
+    pass gives (both modes, edge_cost_factor 1)."""
+    rng = np.random.default_rng(4)
+    case = Case(meshgen.terrain(96, 0.1, 9))
+    m = case.mesh
+    a = rng.uniform(0, 0.6, m.V).astype(np.float32)
+    b = rng.uniform(0, 0.6, m.V).astype(np.float32)
+    ids = rng.choice(m.V, 300, replace=False).astype(np.uint32)
+    b2 = b.copy()
+    b2[ids] = rng.uniform(0, 1.4, ids.size).astype(np.float32)
+    for mode in ("max", "avg"):
+        ctx = gpu_ctx_factory()
+        upload(ctx, case)
+        ctx.layer_upload(0, a); ctx.layer_upload(1, b)
+        ctx.combine_layers([0, 1], [1.0, 0.5], mode=mode, edge_cost_factor=1.0)
+        ctx.layer_upload(1, b2)                                      # the layer changed (here: re-uploaded)
+        ctx.combine_layers_update([0, 1], ids, [1.0, 0.5], mode=mode)
+        vc, w = ctx.download_costs()
+        ctx.combine_layers([0, 1], [1.0, 0.5], mode=mode, edge_cost_factor=1.0)
+        vc_full, w_full = ctx.download_costs()
+        assert np.array_equal(bits(vc), bits(vc_full)) and np.array_equal(bits(w), bits(w_full))
+        want = O.combine([a, b2], [1.0, 0.5], mode)
+        assert np.array_equal(bits(vc), bits(want))
