@@ -28,6 +28,9 @@ robot = int(free[np.argmin(np.abs(mesh.xyz[free, 0] - 0.9 * N * 0.1) + np.abs(me
 tf = int(first_face[robot])
 goals = rng.choice(free, size=1100, replace=False)
 tag = os.environ.get("MNAV_LIB", "default").split("/")[-1]
+mean_w = float(w[np.isfinite(w)].mean())
+if os.environ.get("PERF_BAND_EDGES"):
+    ctx.set_band_width(float(os.environ["PERF_BAND_EDGES"]) * mean_w)     # band width in mean edge weights (default 12)
 for nb in [int(x) for x in os.environ.get("PERF_BATCHES", "1,128,512").split(",")]:
     seeds = [wave_seed(int(v)) for v in goals[:nb]]
     sps = np.stack([x[0] for x in seeds]); sfs = np.array([x[1] for x in seeds], np.uint32)
@@ -36,7 +39,7 @@ for nb in [int(x) for x in os.environ.get("PERF_BATCHES", "1,128,512").split(","
     rb = ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
     dt = time.perf_counter() - t0
     st = rb["stats"]
-    print(json.dumps({"lib": tag, "batch": nb, "plans_per_s": nb / dt, "ms": dt * 1e3, "steps": st["steps"], "launches": st["launches"],
+    print(json.dumps({"band_edges": os.environ.get("PERF_BAND_EDGES", "12"), "lib": tag, "batch": nb, "plans_per_s": nb / dt, "ms": dt * 1e3, "steps": st["steps"], "launches": st["launches"],
                       "evals_per_plan": st["evals"] / nb, "band_shrinks": st["band_shrinks"], "settled_per_plan": st["settled"] / nb, "ms_step_kernels": st["ms_step_kernels"],
                       "codes": sorted(set(int(c) for c in rb["codes"]))}), flush=True)
 ctx.close()

@@ -77,25 +77,5 @@ with open(os.path.join(P, f"{tag}_bench_kernel_stats.md"), "w") as f:
         f.write(f"Un-profiled bench line of the same build (`python bench.py`, all legs; also `profiles/{tag}_bench_line.json`):\n"
                 "```json\n" + json.dumps(bench_line) + "\n```\n\n")
     f.write("## HBM traffic (PMC, separate passes)\n\n```json\n" + json.dumps(traffic, indent=1) + "\n```\n")
-for src, dst in (("c4_10m.json", f"{tag}_c4_10m_single_gpu.json"), ("cvp_batch.json", f"{tag}_cvp_batch_c3.json"), ("cvp_band.json", f"{tag}_cvp_band_width.json")):
-    if os.path.exists(os.path.join(G, src)):
-        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
-# CVP planner kernel trace (tools/prof_cvp.sh)
-cvp_csv = os.path.join(G, "prof_cvp", "cvp_kernel_stats.csv")
-if os.path.exists(cvp_csv):
-    shutil.copy(cvp_csv, os.path.join(P, f"{tag}_cvp_kernel_stats.csv"))
-    crow = list(csv.DictReader(open(cvp_csv)))
-    lines = [l.strip() for l in open(os.path.join(G, "prof_cvp.log")) if l.startswith("{")]
-    with open(os.path.join(P, f"{tag}_cvp_kernel_stats.md"), "w") as f:
-        f.write(f"# profiles/{tag}_cvp_kernel_stats.md — rocprofv3 kernel trace of the CVP planner and the device cost stack\n\n")
-        f.write("MI355X (gfx950). Command (tools/prof_cvp.sh): `MNAV_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -- env PERF_BATCHES=1,128 "
-                "python tools/gpu_cvp_perf.py` (rocprofv3 segfaults inside hipGraph replays, so the steps are launched one by one: kernel durations "
-                "are representative, launch gaps are not).  Workload: 1000x1000 terrain seed 3, Steepness(0.6) + Inflation + weighted sum + edge "
-                "weights built on the device, then one CVP plan (twice) and a batch of 128 (twice).\n\n")
-        f.write("| kernel | calls | total ms | avg µs | min µs | max µs | % |\n|---|---|---|---|---|---|---|\n")
-        for r in crow[:16]:
-            f.write(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
-                    f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
-        f.write("\nLines printed by the profiled run:\n```json\n" + "\n".join(lines) + "\n```\n")
 print("dominant kernel", kernel, "avg us", avg_dom, "live", prof_line["roofline"]["avg_launch_us"])
 print(json.dumps(traffic, indent=1))
