@@ -138,7 +138,10 @@ uint32_t mnav_plan_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_fac
 
 /* n independent Dijkstra plans on the same mesh in one sweep (BASELINE config 5: concurrent
  * goals).  seeds/targets: n each.  codes_out n.  dist_out/pred_out: n*V or NULL.
- * path_out: n*path_cap or NULL, path_len n. */
+ * path_out: n*path_cap or NULL, path_len n.  * A call that asks for nothing V-sized (dist_out, pred_out, vecmap_out all NULL, resident outputs off) only derives the
+ * predecessors along the returned path (no finalize pass over the touched tiles): mnav_device_output(slot, pred) is
+ * NULL afterwards and the resident potential is final up to goal_dist only.  MNAV_LAZY_PATHS=0 restores the full pass.
+ */
 uint32_t mnav_plan_dijkstra_batch(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds,
                                   const uint32_t* targets, double goal_dist_offset,
                                   double cost_limit, uint32_t* codes_out, float* dist_out,

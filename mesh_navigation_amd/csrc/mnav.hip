@@ -1689,6 +1689,86 @@ __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict_
   R.code = code;
 }
 
+// Paths without the finalize pass.  When a caller only wants the vertex path (no potential, predecessors or vector map:
+// the batch bench, mbf_mesh_nav's getPath), k_dij_finalize -- which re-stages every touched tile to derive ALL
+// predecessors and the tentative values beyond goal_dist -- is 10 % of a batch for nothing: after the tile rounds
+// every vertex with dist <= goal_dist is final (its shortest paths only use such sources), the path only visits such
+// vertices, and a path vertex's predecessor is the argmin (dist[u] + w, dist[u], u) over its neighbours of eval_dijkstra,
+// computed here on the fly along the walk (one wave per plan, one neighbour per lane).  Every hop also checks that the
+// minimum IS the vertex's distance (the fixed-point property k_dij_finalize verifies everywhere; here along the path).
+__global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans, PlanResult* __restrict__ res,
+                                                     uint32_t* __restrict__ paths, uint32_t path_stride, uint32_t* __restrict__ mismatch)
+{
+  const Plan& P = plans[blockIdx.x];
+  const TilePlan& T = tplans[blockIdx.x];
+  const int lane = threadIdx.x;
+  PlanResult& R = res[blockIdx.x];
+  const TCtl a = T.ctl[0], b = T.ctl[1];
+  const TCtl last = (a.it > b.it) ? a : b;
+  const uint32_t seed = P.seed[0], target = P.target[0];
+  const float dt = P.dist[target];
+  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + P.offset) : inf_f();
+  uint32_t code = kSuccess, n = 0, bad = 0;
+  if (last.pad[0] || !last.done) code = kInternalError;               // activation cap hit / not finished
+  else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
+  else {
+    uint32_t* path = paths + (size_t)blockIdx.x * path_stride;        // written target-side first
+    uint32_t v = target;
+    while (v != seed && n < path_stride) {
+      const float dv = P.dist[v];
+      float best_s = inf_f(), best_du = inf_f();
+      uint32_t best_u = v;
+      const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
+      for (uint32_t i = beg + lane; i < end; i += kWave) {
+        const Nbr nb = P.nbr[i];
+        const float du = P.dist[nb.u];
+        if (du > goal_dist) continue;                                 // never expanded (dijkstra :299)
+        const float sm = du + nb.w;                                   // :331
+        if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
+      }
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const float os = __shfl_xor(best_s, o), odu = __shfl_xor(best_du, o);
+        const uint32_t ou = __shfl_xor(best_u, o);
+        if (os < best_s || (os == best_s && os < inf_f() && (odu < best_du || (odu == best_du && ou < best_u)))) { best_s = os; best_du = odu; best_u = ou; }
+      }
+      if (f2u(best_s) != f2u(dv) || best_u == v) { bad = 1; break; }  // not a fixed point here: reported, never returned
+      v = best_u;
+      if (lane == 0) path[n] = v;
+      ++n;
+    }
+    if (!bad && v != seed) code = (path_stride < P.V) ? kPathOverflow : kInternalError;
+    if (bad) code = kInternalError;
+  }
+  if (lane == 0) {
+    R.code = code; R.path_len = (code == kSuccess) ? n : 0;
+    R.steps = (uint32_t)(last.it < 0 ? 0 : last.it); R.bands = last.sweeps; R.armed = (dt < inf_f()) ? 1u : 0u; R.overflow = last.pad[0];
+    R.goal_dist = goal_dist; R.evals = last.acts; R.shrinks = 0;
+    if (bad) atomicAdd(mismatch, 1u);
+  }
+}
+
+// settled vertices of a lazily finished plan: the popped ones, dist <= goal_dist (conservative against k_dij_finalize's
+// count, which includes the tentative ring beyond goal_dist)
+__global__ __launch_bounds__(kBlock) void k_count_goal(const Plan* __restrict__ plans, PlanResult* __restrict__ res)
+{
+  const Plan& P = plans[blockIdx.y];
+  const float dt = P.dist[P.target[0]];
+  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + P.offset) : inf_f();
+  uint32_t c = 0;
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) { const float d = P.dist[v]; c += (d < inf_f() && d <= goal_dist) ? 1u : 0u; }
+  c = wave_sum(c);
+  __shared__ uint32_t s_c[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int k = 0; k < kBlock / 64; ++k) tot += s_c[k];
+    if (tot) atomicAdd(&res[blockIdx.y].settled, (unsigned long long)tot);
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_count(const Plan* __restrict__ plans, PlanResult* __restrict__ res)
 {
   const Plan& P = plans[blockIdx.y];
@@ -2115,6 +2195,8 @@ struct mnav_ctx {
   int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 2 persistent per-plan, 3 auto
   int last_engine = 0;
   uint32_t persistent_min_batch = 128;
+  bool lazy_paths = false;      // this call only wants vertex paths: k_path_lazy instead of k_dij_finalize + k_finish
+  bool allow_lazy_paths = true; // MNAV_LAZY_PATHS=0: always finalize (predecessors / tentative values for everybody)
   uint32_t max_steps = 1u << 20;   // per plan; set from the mesh size at upload (a wavefront needs O(diameter) steps)
   double max_wall_s = 120.0;   // host-side guard: a plan that takes longer is abandoned with an error
   uint32_t tile_size = 512;    // 4 workgroups of the tile kernels per CU (36 KB LDS each)
@@ -2642,7 +2724,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
   }
   ctx->stats.launches = launches;
-  if (rc == 0) {
+  if (rc == 0 && !ctx->lazy_paths) {
     launch_finalize(ctx, n);
     HIPCHK(hipGetLastError());
   }
@@ -2740,7 +2822,7 @@ int run_dijkstra_wave(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, 
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  launch_finalize(ctx, n, M.ntiles, ctx->wt.fin_lds);
+  if (!ctx->lazy_paths) launch_finalize(ctx, n, M.ntiles, ctx->wt.fin_lds);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2808,7 +2890,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   else hipLaunchKernelGGL(k_plan_persistent<8>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  launch_finalize(ctx, n);
+  if (!ctx->lazy_paths) launch_finalize(ctx, n);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -3004,6 +3086,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   // LDS tiles of the SSSP engine
   {
     if (const char* e = getenv("MNAV_TILE_SIZE")) ctx->tile_size = (uint32_t)atoi(e);
+    if (const char* e = getenv("MNAV_LAZY_PATHS")) ctx->allow_lazy_paths = atoi(e) != 0;
     if (ctx->tile_size < 64) ctx->tile_size = 64;
     if (ctx->tile_size > (uint32_t)(kTileBlock * kTileVpt)) ctx->tile_size = kTileBlock * kTileVpt;
     HostTiles T;
@@ -3614,6 +3697,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     const bool want_path = true;
     // engine: 0 = tiled rounds, 1 = band steps, 2 = persistent per-plan, 3 = auto (persistent for large batches)
     int engine = ctx->dij_engine;
+    // paths only (nothing V-sized asked for, nothing kept resident): no finalize pass, predecessors along the path only
+    ctx->lazy_paths = ctx->allow_lazy_paths && !dist_out && !pred_out && !want_vecmap && !ctx->resident_vecmap;
     // auto: one workgroup per plan for batches; the wave-per-plan engine (4) is opt-in -- measured slower at C2
     if (engine == 3) engine = (ctx->wave_min_batch && m >= ctx->wave_min_batch) ? 4 : (m >= ctx->persistent_min_batch) ? 2 : 0;
     const int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
@@ -3624,8 +3709,13 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     MTRACE("engine returned");
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
-    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, ctx->path_stride);
+    if (engine == 1) ctx->lazy_paths = false;                         // the band steps keep their predecessors as they go
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
+    if (ctx->lazy_paths) {
+      hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
+      hipLaunchKernelGGL(k_count_goal, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
+    } else
+    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, ctx->path_stride);
     if (engine == 1)   // the tile engines count the settled vertices in k_dij_finalize
       hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
@@ -3640,7 +3730,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       if (overflow) {                                               // a path longer than the default rows: rows of V ids
         std::vector<PlanResult> keep(ctx->h_res, ctx->h_res + m);   // settled / evals were accumulated by other kernels
         if (ensure_paths(ctx, m, V)) return MNAV_INTERNAL_ERROR;
-        hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
+        if (ctx->lazy_paths) hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
+        else hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
         if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
         for (uint32_t k = 0; k < m; ++k) ctx->h_res[k].settled = keep[k].settled;
@@ -4068,7 +4159,7 @@ const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
   const Slot& s = ctx->slots[slot];
   switch (what) {
     case 0: return s.dist;
-    case 1: return s.pred;
+    case 1: return (ctx->lazy_paths && ctx->last_planner == kPlannerDijkstra) ? nullptr : s.pred;   // a paths-only call derived no predecessor array
     case 2: return s.dirn;
     case 3: return s.cutf;
     case 4: return s.vecmap;
