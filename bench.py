@@ -100,9 +100,16 @@ def main() -> None:
     robot = mesh.vertex_at(0.9, 0.9)
     rng = np.random.default_rng(5 + 1000 * rank)
 
+    # the goal sets of all batches are drawn BEFORE the timed region (inputs, like the mesh and the costs)
+    n_batches = max(args.warmup, 0) + args.steps + 4
+    goal_sets = [rng.choice(mesh.V, size=B, replace=False).astype(np.uint32) for _ in range(n_batches)]
+    robots = np.full(B, robot, np.uint32)
+    next_set = [0]
+
     def batch_goals():
-        g = rng.choice(mesh.V, size=B, replace=False).astype(np.uint32)
-        return g, np.full(B, robot, np.uint32)
+        g = goal_sets[next_set[0] % n_batches]
+        next_set[0] += 1
+        return g, robots
 
     def barrier():
         torch.cuda.synchronize()
