@@ -1748,6 +1748,17 @@ __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ pl
   }
 }
 
+// vertex paths of a batch, packed back to back and turned into the reference's list order (seed ... pred[target]) on the
+// device: ONE dense copy to a pinned buffer instead of a strided 2-D copy of n rows
+__global__ __launch_bounds__(kBlock) void k_pack_paths(const uint32_t* __restrict__ paths, uint32_t path_stride, const uint32_t* __restrict__ offs,
+                                                       const uint32_t* __restrict__ lens, uint32_t* __restrict__ out)
+{
+  const uint32_t k = blockIdx.x, len = lens[k];
+  const uint32_t* src = paths + (size_t)k * path_stride;
+  uint32_t* dst = out + offs[k];
+  for (uint32_t q = threadIdx.x; q < len; q += kBlock) dst[q] = src[len - 1 - q];
+}
+
 // settled vertices of a lazily finished plan: the popped ones, dist <= goal_dist (conservative against k_dij_finalize's
 // count, which includes the tentative ring beyond goal_dist)
 __global__ __launch_bounds__(kBlock) void k_count_goal(const Plan* __restrict__ plans, PlanResult* __restrict__ res)
@@ -2187,6 +2198,7 @@ struct mnav_ctx {
   PlanResult* d_res = nullptr; PlanResult* h_res = nullptr;
   float** d_vecptrs = nullptr;
   uint32_t* d_paths = nullptr; size_t paths_words = 0; uint32_t path_stride = 0;   // n plans x path_stride vertex ids
+  uint32_t *d_pack = nullptr, *h_pack = nullptr, *d_pack_meta = nullptr; size_t pack_words = 0, pack_meta_n = 0;   // packed paths (device, pinned host), offsets + lengths
   std::unordered_map<void*, size_t> alloc_bytes;                   // sizes of the dev_upload buffers (re-used when unchanged)
   Ctl* h_ctl = nullptr;       // pinned, 2 per plan
   float* d_seed_pos = nullptr; uint32_t seed_pos_cap = 1;
@@ -3004,6 +3016,7 @@ void mnav_destroy(mnav_ctx* ctx)
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
   (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
+  (void)hipFree(ctx->d_pack); (void)hipFree(ctx->d_pack_meta); if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
@@ -3745,14 +3758,35 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       }
     }
     MTRACE("results downloaded");
-    // all vertex paths in one strided copy (device order: pred[target] ... seed)
-    uint32_t maxlen = 0;
-    for (uint32_t k = 0; k < m; ++k) if (ctx->h_res[k].code == MNAV_SUCCESS && ctx->h_res[k].path_len > maxlen) maxlen = ctx->h_res[k].path_len;
-    std::vector<uint32_t> tmp;
-    if (maxlen && path_out && path_cap) {
-      tmp.resize((size_t)maxlen * m);
-      if (hipMemcpy2D(tmp.data(), (size_t)maxlen * 4, ctx->d_paths, (size_t)ctx->path_stride * 4, (size_t)maxlen * 4, m, hipMemcpyDeviceToHost) != hipSuccess)
+    // all vertex paths: packed and reversed on the device (k_pack_paths), one dense copy into a pinned buffer
+    std::vector<uint32_t> offs(m + 1, 0), lens(m, 0);
+    for (uint32_t k = 0; k < m; ++k) {
+      lens[k] = (ctx->h_res[k].code == MNAV_SUCCESS) ? ctx->h_res[k].path_len : 0u;
+      offs[k + 1] = offs[k] + lens[k];
+    }
+    const size_t total = offs[m];
+    if (total && path_out && path_cap) {
+      if (ctx->pack_words < total) {
+        if (ctx->d_pack) (void)hipFree(ctx->d_pack);
+        if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
+        ctx->d_pack = nullptr; ctx->h_pack = nullptr; ctx->pack_words = 0;
+        const size_t want = total + total / 4 + 1024;
+        if (hipMalloc((void**)&ctx->d_pack, 4 * want) != hipSuccess || hipHostMalloc((void**)&ctx->h_pack, 4 * want, hipHostMallocDefault) != hipSuccess)
+          { ctx->err = "path buffers: out of memory"; return MNAV_INTERNAL_ERROR; }
+        ctx->pack_words = want;
+      }
+      if (ctx->pack_meta_n < 2 * (size_t)m) {
+        if (ctx->d_pack_meta) (void)hipFree(ctx->d_pack_meta);
+        ctx->d_pack_meta = nullptr; ctx->pack_meta_n = 0;
+        if (hipMalloc((void**)&ctx->d_pack_meta, 4 * 2 * (size_t)m) != hipSuccess) { ctx->err = "path buffers: out of memory"; return MNAV_INTERNAL_ERROR; }
+        ctx->pack_meta_n = 2 * (size_t)m;
+      }
+      if (hipMemcpyAsync(ctx->d_pack_meta, offs.data(), 4 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(ctx->d_pack_meta + m, lens.data(), 4 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
+      hipLaunchKernelGGL(k_pack_paths, dim3(m), dim3(kBlock), 0, ctx->stream, ctx->d_paths, ctx->path_stride, ctx->d_pack_meta, ctx->d_pack_meta + m, ctx->d_pack);
+      if (hipMemcpyAsync(ctx->h_pack, ctx->d_pack, 4 * total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
     }
     MTRACE("paths downloaded");
     for (uint32_t k = 0; k < m; ++k) {
@@ -3761,12 +3795,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       codes[i] = r.code;
       if (r.code == MNAV_SUCCESS) {
         if (path_len) path_len[i] = r.path_len;
-        if (path_out && path_cap) {
-          // reference list order: seed ... pred[target]
-          const uint32_t* src = tmp.data() + (size_t)k * maxlen;
-          uint32_t* dst = path_out + (size_t)i * path_cap;
-          for (uint32_t q = 0; q < r.path_len && q < path_cap; ++q) dst[q] = src[r.path_len - 1 - q];
-        }
+        if (path_out && path_cap && r.path_len)                         // reference list order: seed ... pred[target]
+          memcpy(path_out + (size_t)i * path_cap, ctx->h_pack + offs[k], 4 * (size_t)std::min(r.path_len, path_cap));
       }
       if (dist_out && hipMemcpyAsync(dist_out + (size_t)i * V, ctx->slots[k].dist, 4 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         { ctx->err = "dist download failed"; return MNAV_INTERNAL_ERROR; }
