@@ -148,6 +148,13 @@ __device__ __forceinline__ Eval group_eval_dijkstra(const Plan& P, const Ctl& c,
 }
 
 // --- CVP replay over 8 lanes (spec: mnav_eval.h::eval_cvp) ------------------------------------
+// corners per lane in the 8-lane replay: 2 = vertices of up to 16 faces in parallel, the rest through the serial rule.
+// 1 saves 18 VGPRs (152 instead of 170 unconstrained) but not enough for a fourth wave per SIMD without spilling, and
+// measured the same (207 vs 203 plans/s in batches of 128)
+#ifndef MNAV_CVP_ROUNDS
+#define MNAV_CVP_ROUNDS 2
+#endif
+constexpr int kCvpRounds = MNAV_CVP_ROUNDS;
 struct CornerItem { KeyRef fk; uint32_t trig; bool valid; bool first; CvpCand k; uint32_t v1, v2, face; };
 
 __device__ __forceinline__ KeyRef gshfl_key(const KeyRef& r, int src)
@@ -164,12 +171,12 @@ __device__ __forceinline__ KeyRef gshfl_key(const KeyRef& r, int src)
 __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint32_t v, int sub)
 {
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
-  if (end - beg > 2 * kGroup) return eval_cvp(P, c, v);           // rare high-valence vertex: serial rule
+  if (end - beg > kCvpRounds * kGroup) return eval_cvp(P, c, v);   // rare high-valence vertex: serial rule
   const bool infl = P.seed_mask != nullptr;
   const bool mute = infl && P.seed_mask[v] == kInflMute;
-  CornerItem it[2];
+  CornerItem it[kCvpRounds];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < kCvpRounds; ++r) {
     const uint32_t i = beg + sub + r * kGroup;
     it[r].fk = key_ref_of(key_inf(), inf_f(), 0); it[r].trig = kNone; it[r].valid = false;
     it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone; it[r].first = false;
@@ -197,10 +204,10 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
   for (uint32_t pass_no = 0;; ++pass_no) {
     if (pass_no == max_pass) { raise_flag(P, kFlagWalkLimit); break; }
     // next trigger pop strictly after the last one: smallest `hi` first, the tree decides among equals
-    bool el[2];
+    bool el[kCvpRounds];
     unsigned long long mh = kNoKey;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < kCvpRounds; ++r) {
       el[r] = it[r].valid && (first || key_less(P, last, it[r].fk));
       if (el[r] && it[r].fk.k.hi < mh) mh = it[r].fk.k.hi;
     }
@@ -209,7 +216,7 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
     if (mh == kNoKey) break;
     KeyRef m = last; uint32_t m_trig = kNone;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < kCvpRounds; ++r) {
       unsigned gm = (unsigned)((__ballot(el[r] && it[r].fk.k.hi == mh) >> gbase) & 0xFFull);
       while (gm) {
         const int src = __ffs((int)gm) - 1;
@@ -224,9 +231,9 @@ __device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint
     bool any = false;
     float ins_d = 0.0f;
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) {                               // trigger's circulator order: flagged face first
-      const int r = pr & 1;
-      const bool want_first = pr < 2;
+    for (int pr = 0; pr < 2 * kCvpRounds; ++pr) {                  // trigger's circulator order: flagged face first
+      const int r = pr % kCvpRounds;
+      const bool want_first = pr < kCvpRounds;
       unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].trig == m_trig && it[r].first == want_first) >> gbase) & 0xFFull);
       while (gm) {
         const int src = __ffs((int)gm) - 1;
