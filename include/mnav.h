@@ -242,9 +242,10 @@ int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out);
 int mnav_set_band_width(mnav_ctx* ctx, float delta);
 /* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round,
  * lowest latency for a single plan), 1 = the distance-band gather steps that the CVP planner uses,
- * 2 = persistent per-plan workgroups walking the tiles best-first (highest throughput for large
- * batches), 3 = automatic (default: 2 for batches of >= 128 plans, else 0), 4 = one wave per plan on a finer
- * tiling (experimental, slower than 2 at 1M vertices).  All give identical results. */
+ * 2 = persistent per-plan workgroups walking the tiles best-first (medium batches),
+ * 3 = automatic (default: 5 for paths-only batches of >= 256 plans, 2 for batches of >= 128 plans, else 0),
+ * 5 = tile-batch: one wave per (tile, up to 64 plans), one plan per lane, the tile's graph as scalar data
+ * (highest throughput for large batches; paths-only calls).  All give identical results. */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
 /* Outputs that stay on the device.  mnav_set_resident_outputs(ctx, 1): every plan also computes its vector map
  * (computeVectorMap, dijkstra :189-209 / cvp :204-239) and leaves it in HBM even when no host buffer is passed.
@@ -255,7 +256,10 @@ int mnav_set_resident_outputs(mnav_ctx* ctx, int on);
 int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out);
 int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const float bary[3], float out[3]);
 /* Device pointers of the last plan's resident outputs (slot = plan index in a batch):
- * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available. */
+ * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available -- in particular dist / pred after a
+ * paths-only Dijkstra call (no dist_out / pred_out / vector map asked for): such a call runs no finalize pass, values
+ * beyond goal_dist would be engine-tentative.  mnav_download_output additionally takes what = 5, the POPPED potential of
+ * a Dijkstra plan: the reference's value wherever it popped the vertex (dist <= goal_dist), +inf elsewhere. */
 const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what);
 /* Algorithmic bytes of the last call per SURVEY.md §8(d): SSSP 24*V' + 24*E', CVP 32*V' + 68*F'
  * with V' = settled vertices and E'/F' their incident edges/faces scaled from the full mesh. */

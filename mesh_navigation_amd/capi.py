@@ -246,13 +246,13 @@ class MnavContext:
 
     def set_dijkstra_engine(self, engine: str):
         """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
-        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4}[engine])
+        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4, "tile_batch": 5}[engine])
 
     def set_resident_outputs(self, on: bool = True):
         self._L.mnav_set_resident_outputs(self._h, 1 if on else 0)
 
     def download_output(self, what: str, slot: int = 0) -> np.ndarray:
-        code = {"dist": 0, "pred": 1, "direction": 2, "cutface": 3, "vecmap": 4}[what]
+        code = {"dist": 0, "pred": 1, "direction": 2, "cutface": 3, "vecmap": 4, "popped": 5}[what]
         out = np.empty((self.V, 3) if code == 4 else self.V, np.uint32 if code in (1, 3) else np.float32)
         if self._L.mnav_download_output(self._h, int(slot), code, _p(out)) != 0:
             raise RuntimeError(f"mnav_download_output failed: {self._err()}")

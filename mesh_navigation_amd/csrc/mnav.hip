@@ -2147,6 +2147,10 @@ __global__ __launch_bounds__(kBlock) void k_combine_resident_ids(uint32_t n, con
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+}  // namespace
+#include "mnav_tb.h"
+namespace {
+
 struct Slot {
   float *dist = nullptr, *dirn = nullptr, *vecmap = nullptr;
   PopKey* tkey = nullptr;
@@ -2180,6 +2184,8 @@ struct mnav_ctx {
   // host copies needed for seeding
   uint32_t V = 0, F = 0, E = 0;
   std::vector<float> h_xyz, h_cost;
+  std::vector<uint32_t> h_row_ptr, h_nbr_u;   // gather CSR (host copy): the tile-batch engine builds its streams from it on first use
+  TbState tb; tb::Args tb_args{};             // tile-batch SSSP engine (mnav_tb.h); arguments of the last batch
   bool want_vec = false;               // the running call asked for vector maps (lazy 12 B/vertex/plan)
   bool resident_vecmap = false;        // mnav_set_resident_outputs: always compute the vector map, leave it on the device
   std::vector<uint32_t> caller_slot;   // plan index of the caller's batch -> device slot of the last call (kNone: never ran)
@@ -2261,6 +2267,7 @@ struct mnav_ctx {
   bool use_graph = true;
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
+  std::vector<uint32_t> last_target; double last_offset = 0.0;   // Dijkstra: robot vertex per device slot, goal_dist_offset of the last call
   mnav_stats stats{};
   uint64_t algo_bytes = 0;
   hipEvent_t ev[8]{};
@@ -2323,6 +2330,8 @@ void drop_graphs(mnav_ctx* ctx)
   ctx->graphs.clear();
 }
 
+int ensure_plan_tables(mnav_ctx* ctx, uint32_t n);
+
 int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp, bool band, bool vec)
 {
   const size_t V = ctx->V ? ctx->V : 1;
@@ -2358,6 +2367,12 @@ int ensure_slots(mnav_ctx* ctx, uint32_t n, bool cvp, bool band, bool vec)
     ctx->ctl_pool_cap = n;
   }
   for (uint32_t i = 0; i < n; ++i) ctx->slots[i].ctl = ctx->d_ctl_pool + 2 * i;
+  return ensure_plan_tables(ctx, n);
+}
+
+// per-plan tables shared by all engines (plan descriptors, results)
+int ensure_plan_tables(mnav_ctx* ctx, uint32_t n)
+{
   if (ctx->plans_cap < n) {
     if (ctx->d_plans) (void)hipFree(ctx->d_plans);
     if (ctx->d_res) (void)hipFree(ctx->d_res);
@@ -2452,7 +2467,7 @@ int materialize(mnav_ctx* ctx, bool cvp, double cost_limit)
     hipLaunchKernelGGL(k_build_nbr, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, V, ctx->d_row_ptr, ctx->d_nbr_u,
                        ctx->d_nbr_e, ctx->d_w, ctx->d_cost, ctx->d_invalid, cost_limit, ctx->d_nbr);
     HIPCHK(hipGetLastError());
-    ctx->nbr_limit = cost_limit; ctx->nbr_valid = true; ctx->tw_valid = false; ctx->wt.tw_valid = false;
+    ctx->nbr_limit = cost_limit; ctx->nbr_valid = true; ctx->tw_valid = false; ctx->wt.tw_valid = false; ctx->tb.w_valid = false;
   } else {
     if (ctx->crn_valid && ctx->crn_limit == cost_limit) return 0;
     if (!ctx->d_crn) HIPCHK(hipMalloc((void**)&ctx->d_crn, sizeof(Corner) * (size_t)(ctx->F ? 3 * (size_t)ctx->F : 1)));
@@ -2919,6 +2934,8 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   return 0;
 }
 
+#include "mnav_tb_host.h"
+
 float ev_ms(hipEvent_t a, hipEvent_t b)
 {
   float ms = 0.f;
@@ -3006,6 +3023,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   drop_graphs(ctx);
+  tb_free(ctx);
   for (auto& s : ctx->slots) free_slot(s);
   drop_layers(ctx);
   (void)hipFree(ctx->d_row_ptr); (void)hipFree(ctx->d_nbr_u); (void)hipFree(ctx->d_nbr_e); (void)hipFree(ctx->d_crn_ptr);
@@ -3091,6 +3109,8 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   }
   ctx->h_xyz.assign(xyz, xyz + 3 * (size_t)V);
   ctx->h_faces.assign(face_vtx, face_vtx + 3 * (size_t)F);
+  ctx->h_row_ptr = t.row_ptr; ctx->h_nbr_u = t.nbr_u;
+  tb_free(ctx);
   if (dev_upload(ctx, &ctx->d_row_ptr, t.row_ptr.data(), t.row_ptr.size())) return -1;
   if (dev_upload(ctx, &ctx->d_nbr_u, t.nbr_u.data(), t.nbr_u.size())) return -1;
   if (dev_upload(ctx, &ctx->d_nbr_e, t.nbr_e.data(), t.nbr_e.size())) return -1;
@@ -3693,6 +3713,28 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   // vertex, i.e. with the squared seed-target distance.  Workgroups are dispatched in plan order, so when a
   // batch holds more plans than the device runs at once the short ones back-fill behind the long ones
   // instead of leaving a tail (results are mapped back through `map`).
+  // engine: 0 = tiled rounds, 1 = band steps, 2 = persistent per-plan, 3 = auto, 5 = tile-batch (plan-vectorised, large batches)
+  int engine = ctx->dij_engine;
+  // paths only (nothing V-sized asked for, nothing kept resident): no finalize pass, predecessors along the path only
+  ctx->lazy_paths = ctx->allow_lazy_paths && !dist_out && !pred_out && !want_vecmap && !ctx->resident_vecmap;
+  {
+    const uint32_t m0 = (uint32_t)in.size();
+    // auto: one wave per (tile, 64 plans) for large batches, one workgroup per plan for medium ones, tile rounds otherwise
+    if (engine == 3) engine = (ctx->lazy_paths && m0 >= ctx->tb.min_batch && m0 <= 65535u) ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
+    if (engine == 5 && (!ctx->lazy_paths || m0 > 65535u)) engine = 2;
+  }
+  if (engine == 5 && in.size() > 1) {
+    // plans whose waves start close to each other are neighbours in the batch: their slices of a tile are adjacent in memory
+    // and they tend to have work on the same tiles at the same time
+    if (tb_build(ctx)) return MNAV_INTERNAL_ERROR;
+    std::vector<uint32_t> ord(in.size());
+    std::iota(ord.begin(), ord.end(), 0u);
+    const std::vector<uint32_t>& vt = ctx->tb.vert_tile;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return vt[in[x].seed[0]] < vt[in[y].seed[0]]; });
+    std::vector<PlanIn> in2(in.size()); std::vector<uint32_t> map2(in.size());
+    for (size_t i = 0; i < in.size(); ++i) { in2[i] = in[ord[i]]; map2[i] = map[ord[i]]; }
+    in.swap(in2); map.swap(map2);
+  } else
   if (in.size() > 1 && ctx->h_xyz.size() == 3 * (size_t)V) {
     std::vector<uint32_t> ord(in.size());
     std::iota(ord.begin(), ord.end(), 0u);
@@ -3712,18 +3754,15 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   const uint32_t m = (uint32_t)in.size();
   ctx->last_planner = kPlannerDijkstra; ctx->last_n = m;
+  ctx->last_target.resize(m); for (uint32_t k = 0; k < m; ++k) ctx->last_target[k] = in[k].target[0];
+  ctx->last_offset = offset;
   if (m) {
     if (materialize(ctx, false, cost_limit)) return MNAV_INTERNAL_ERROR;
     const bool want_path = true;
-    // engine: 0 = tiled rounds, 1 = band steps, 2 = persistent per-plan, 3 = auto (persistent for large batches)
-    int engine = ctx->dij_engine;
-    // paths only (nothing V-sized asked for, nothing kept resident): no finalize pass, predecessors along the path only
-    ctx->lazy_paths = ctx->allow_lazy_paths && !dist_out && !pred_out && !want_vecmap && !ctx->resident_vecmap;
-    // auto: one workgroup per plan for batches; the wave-per-plan engine (4) is opt-in -- measured slower at C2
-    if (engine == 3) engine = (ctx->wave_min_batch && m >= ctx->wave_min_batch) ? 4 : (m >= ctx->persistent_min_batch) ? 2 : 0;
     const int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
                  : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
                  : (engine == 4) ? run_dijkstra_wave(ctx, m, in, offset)
+                 : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
                                  : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
     ctx->last_engine = engine;
     MTRACE("engine returned");
@@ -3731,7 +3770,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
     if (engine == 1) ctx->lazy_paths = false;                         // the band steps keep their predecessors as they go
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
-    if (ctx->lazy_paths) {
+    if (engine == 5) {
+      hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
+      hipLaunchKernelGGL(k_tb_count, dim3(ctx->tb.ntiles ? ctx->tb.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, ctx->tb_args, ctx->tb.T, ctx->d_res);
+    } else if (ctx->lazy_paths) {
       hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
       hipLaunchKernelGGL(k_count_goal, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
     } else
@@ -3750,7 +3792,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       if (overflow) {                                               // a path longer than the default rows: rows of V ids
         std::vector<PlanResult> keep(ctx->h_res, ctx->h_res + m);   // settled / evals were accumulated by other kernels
         if (ensure_paths(ctx, m, V)) return MNAV_INTERNAL_ERROR;
-        if (ctx->lazy_paths) hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
+        if (engine == 5) hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
+        else if (ctx->lazy_paths) hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
         else hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
         if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
@@ -4183,7 +4226,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta)
 
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 {
-  if (!ctx || engine < 0 || engine > 4) return -1;
+  if (!ctx || engine < 0 || engine > 5) return -1;
   ctx->dij_engine = engine;
   return 0;
 }
@@ -4194,9 +4237,12 @@ const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
   if (slot < ctx->caller_slot.size()) slot = ctx->caller_slot[slot];      // caller's plan index -> device slot (kNone: never ran / overwritten)
   if (slot >= ctx->slots.size()) return nullptr;
   const Slot& s = ctx->slots[slot];
+  // a paths-only Dijkstra call finalized nothing: values beyond goal_dist are engine-tentative, predecessors were derived
+  // along the path only (mnav_download_output what = 5 returns the popped potential of such a call)
+  const bool lazy = ctx->lazy_paths && ctx->last_planner == kPlannerDijkstra;
   switch (what) {
-    case 0: return s.dist;
-    case 1: return (ctx->lazy_paths && ctx->last_planner == kPlannerDijkstra) ? nullptr : s.pred;   // a paths-only call derived no predecessor array
+    case 0: return lazy ? nullptr : s.dist;
+    case 1: return lazy ? nullptr : s.pred;
     case 2: return s.dirn;
     case 3: return s.cutf;
     case 4: return s.vecmap;
@@ -4214,6 +4260,22 @@ int mnav_set_resident_outputs(mnav_ctx* ctx, int on)
 int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out)
 {
   if (!ctx || !host_out) return -1;
+  if (what == 5) {                                                   // popped potential (Dijkstra): exact wherever dist <= goal_dist, +inf elsewhere
+    if (ctx->last_planner != kPlannerDijkstra) { ctx->err = "popped potential: the last call was not a Dijkstra plan"; return -1; }
+    if (slot < ctx->caller_slot.size()) slot = ctx->caller_slot[slot];
+    if (slot >= ctx->last_n) { ctx->err = "output not resident"; return -1; }
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, 4 * (size_t)(ctx->V ? ctx->V : 1)));
+    const uint32_t g = std::min<uint32_t>((ctx->V + kBlock - 1) / kBlock + 1, 4096);
+    if (ctx->last_engine == 5) hipLaunchKernelGGL(k_tb_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->tb_args, slot, ctx->V, tmp);
+    else hipLaunchKernelGGL(k_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->slots[slot].dist, ctx->last_target[slot], ctx->last_offset, ctx->V, tmp);
+    const hipError_t e1 = hipMemcpyAsync(host_out, tmp, 4 * (size_t)ctx->V, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e1 != hipSuccess || e2 != hipSuccess) { ctx->err = "popped potential: copy failed"; return -1; }
+    return 0;
+  }
   const void* src = mnav_device_output(ctx, slot, what);
   if (!src) { ctx->err = "output not resident"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;

@@ -1,0 +1,493 @@
+// mnav_tb.h -- TILE-BATCH SSSP engine: many Dijkstra wavefronts (dijkstra_mesh_planner.cpp:287-348, one per plan of a
+// batch) advanced together, tile-major and plan-vectorised.  Included by mnav.hip (device kernels + host driver).
+//
+// Why: with one workgroup per plan (k_plan_persistent) every tile activation re-stages the tile's graph and runs a
+// latency-bound chain of LDS queue sweeps for ONE plan.  Here a 64-lane wave takes one tile and up to 64 plans that
+// have work on it, one plan per lane.  All lanes execute the same edge sequence, so the graph is SCALAR data (s_load
+// from the constant address space, weights as SGPR operands), the distances of the tile's vertices live in LDS as
+// [vertex][lane] (a lane only ever touches its own column: no bank conflicts, no barriers, no atomics), and the
+// relaxation is a plain Gauss-Seidel sweep over the tile's vertices in one of four diagonal orders until a sweep
+// changes nothing in any lane -- the tile-local fixed point of  d[v] = min_u fl(d[u] + w(u,v)),  which is the
+// reference's float32 relaxation (dijkstra :331) and has a unique fixed point, so any schedule reproduces it bit
+// for bit.
+//
+// Schedule (level-synchronous over all plans, a few launches per iteration, replayed from a hipGraph):
+//   k_tb_plan    per plan: band threshold thr = (smallest pending wake-up) + band, bound = dist[target] + offset
+//   k_tb_filter  per pending (tile, plan) pair: wake-up < thr -> the tile's bucket; > bound -> dropped; else carried
+//   k_tb_items   per tile: the bucket is cut into work items of <= 64 plans
+//   k_tb_solve   per item: load the plans' slices, fold the ghost values in, sweep, write back what changed, wake the
+//                neighbouring tiles whose vertices were undercut, export changed boundary values to their ghost slots
+// Data written during an iteration is consumed in the next one (kernel boundary), so there is no intra-kernel
+// producer/consumer protocol; wake-ups use atomicMin on the pair's wake-up value, the first waker appends the pair.
+#pragma once
+
+#include "mnav_tb_build.h"
+
+namespace {
+
+namespace tb {
+
+// Streams and tile headers are read through the constant address space: uniform addresses there are always scalar
+// loads (s_load_dwordx8 / x16), whatever the compiler can or cannot prove about aliasing stores.
+#define MNAV_CONST __attribute__((address_space(4)))
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));     // a 4-record block: word 2k = record k .a, word 2k+1 = .b
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));   // an 8-record block / 4 export records / a tile header
+typedef const MNAV_CONST u32x8* cblk4_t;
+typedef const MNAV_CONST u32x16* cblk8_t;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32_t;
+// word indices of a TbTile read as u32x16
+enum { kTwSoff = 0, kTwSl = 1, kTwNv = 2, kTwNh = 3, kTwSweepOff = 4, kTwSweepBlocks = 5, kTwPreOff = 6, kTwPreBlocks = 7,
+       kTwPostOff = 8, kTwPostBlocks = 9, kTwExpOff = 10, kTwExpN = 11 };
+static_assert(offsetof(TbTile, exp_n) == 4 * kTwExpN && offsetof(TbTile, sweep_off) == 4 * kTwSweepOff, "TbTile layout");
+
+struct Ctl {
+  uint32_t n_cand[2];        // pending (tile, plan) pairs: list read / list written, by iteration parity
+  uint32_t n_items, next_item;
+  uint32_t err;              // 1: sweep cap hit
+  uint32_t iters;
+  unsigned long long acts;   // (tile, plan) activations
+  unsigned long long sweeps; // wave sweeps
+  unsigned long long items;  // work items (waves of <= 64 plans)
+  unsigned long long wakes;
+};
+
+struct Args {
+  const TbTile* tiles; const TbRec* recs; const TbExp* exps;
+  float* D; uint32_t* pend; uint32_t NP, ntiles;
+  uint16_t* bucket; uint32_t* bcnt; uint2* items; Ctl* ctl;
+  uint2* cand[2]; uint32_t* marr[2];
+  float* thr; float* bnd;
+  const uint32_t* seed; const uint32_t* target;                        // per plan: wave source / robot vertex
+  const uint2* vaddr; const uint32_t* vert_tile;                      // per vertex: {soff, sl << 8 | local}, tile
+  double offset; float band;
+};
+
+__device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_t p)
+{
+  return (size_t)va.x * NP + (size_t)p * (va.y >> 8) + (va.y & 255u);
+}
+
+__device__ __forceinline__ uint32_t ldsr(uint32_t off) { return *(lds_u32_t)(uintptr_t)off; }
+__device__ __forceinline__ void ldsw(uint32_t off, uint32_t v) { *(lds_u32_t)(uintptr_t)off = v; }
+__device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// wave-aggregated append of the pair (t, p) of every lane with `want`
+__device__ __forceinline__ void append_pair(bool want, uint32_t t, uint32_t p, uint2* list, uint32_t* count, int lane)
+{
+  const unsigned long long m = __ballot(want);
+  if (m == 0ull) return;
+  const int leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(t, p);
+}
+
+}  // namespace tb
+
+__global__ __launch_bounds__(kBlock) void k_tb_weights(uint32_t n, const uint32_t* __restrict__ wsrc, const Nbr* __restrict__ nbr, TbRec* __restrict__ recs)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = wsrc[i];
+  if (s != kNone) recs[i].b = f2u(nbr[s].w);
+}
+
+__global__ __launch_bounds__(kBlock) void k_tb_fill(u32x4* __restrict__ p, size_t n16, uint32_t v)
+{
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  const u32x4 x = { v, v, v, v };
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) __builtin_nontemporal_store(x, p + i);
+}
+
+// seeds: distance 0 at the wave source (dijkstra :272-277), exported to the ghost slots that mirror it, its tile pending
+__global__ __launch_bounds__(kBlock) void k_tb_seed(tb::Args A)
+{
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= A.NP) return;
+  const uint32_t s = A.seed[p];
+  const uint2 va = A.vaddr[s];
+  A.D[tb::slot_addr(va, A.NP, p)] = 0.0f;
+  const uint32_t t = A.vert_tile[s];
+  const TbTile W = A.tiles[t];
+  const uint32_t row = (va.y & 255u) * 256u;
+  for (uint32_t k = 0; k < W.exp_n; ++k) {
+    const TbExp e = A.exps[W.exp_off + k];
+    if (e.u == row) A.D[(size_t)e.soff * A.NP + (size_t)p * e.sl + e.off] = 0.0f;
+  }
+  A.pend[(size_t)t * A.NP + p] = 0u;
+  A.marr[0][p] = 0u;
+  const uint32_t i = atomicAdd(&A.ctl->n_cand[0], 1u);
+  A.cand[0][i] = make_uint2(t, p);
+}
+
+// per plan and iteration: band threshold and goal bound
+__global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
+{
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p == 0) { A.ctl->n_cand[par ^ 1] = 0u; A.ctl->next_item = 0u; A.ctl->iters += 1u; }
+  if (p >= A.NP) return;
+  const uint32_t mb = A.marr[par][p];
+  A.marr[par ^ 1][p] = kTbInfBits;
+  const float m = u2f(mb);
+  const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
+  const float bound = (float)((double)dt + A.offset);               // >= the final goal_dist (dijkstra :296)
+  const bool done = !(m < inf_f()) || m > bound;
+  float thr = m + A.band;
+  if (!(thr > m)) thr = next_up(m);
+  A.thr[p] = done ? 0.0f : thr;                                     // wake-up values are >= 0: nothing is below 0
+  A.bnd[p] = bound;
+}
+
+// per pending pair: ready (into the tile's bucket), dropped (beyond the goal bound) or carried to the next iteration
+__global__ __launch_bounds__(kBlock) void k_tb_filter(tb::Args A, int par)
+{
+  const uint32_t n = A.ctl->n_cand[par];
+  const uint2* in = A.cand[par];
+  const int lane = threadIdx.x & 63;
+  const uint32_t stride = gridDim.x * kBlock;
+  const uint32_t n_pad = (n + 63u) & ~63u;                          // whole waves stay together for the aggregated append
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
+    bool carry = false;
+    uint2 e = make_uint2(0u, 0u);
+    if (i < n) {
+      e = in[i];
+      const size_t pi = (size_t)e.x * A.NP + e.y;
+      const uint32_t pb = A.pend[pi];
+      const float pv = u2f(pb);
+      if (pv > A.bnd[e.y]) A.pend[pi] = kTbInfBits;                 // can never propagate any more (the bound only shrinks)
+      else if (pv < A.thr[e.y]) {
+        A.pend[pi] = kTbInfBits;
+        const uint32_t slot = atomicAdd(&A.bcnt[e.x], 1u);
+        A.bucket[(size_t)e.x * A.NP + slot] = (uint16_t)e.y;
+      } else {
+        carry = true;
+        atomicMin(&A.marr[par ^ 1][e.y], pb);
+      }
+    }
+    tb::append_pair(carry, e.x, e.y, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
+  }
+}
+
+// per tile: cut the bucket into items of <= 64 plans (one workgroup, a few dozen tiles per thread)
+__global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
+{
+  __shared__ uint32_t s_base;
+  __shared__ uint32_t s_wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_base = 0u;
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < A.ntiles; t0 += 1024) {
+    const uint32_t t = t0 + tid;
+    uint32_t c = 0;
+    if (t < A.ntiles) { c = A.bcnt[t]; if (c) A.bcnt[t] = 0u; }
+    const uint32_t k = (c + 63u) >> 6;
+    uint32_t incl = k;                                               // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += s_wsum[w];
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) tot += s_wsum[w];
+    const uint32_t base = s_base + woff + incl - k;
+    for (uint32_t q = 0; q < k; ++q) A.items[base + q] = make_uint2(t, (q * 64u) | (min(64u, c - q * 64u) << 16));
+    __syncthreads();
+    if (tid == 0) s_base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) A.ctl->n_items = s_base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The solve: one wave per work item (tile, <= 64 plans).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ unsigned long long tb_sweep(tb::cblk8_t B, uint32_t nblk, uint32_t lane4)
+{
+  unsigned long long any = 0ull;
+  for (uint32_t b = 0; b < nblk; ++b) {
+    const tb::u32x16 K = B[b];
+    const uint32_t ya = K[0] + lane4;
+    const uint32_t acc0 = tb::ldsr(ya) & 0x7fffffffu;
+    uint32_t t[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) t[k] = f2u(fabsf(u2f(tb::ldsr(K[2 + 2 * k] + lane4))) + u2f(K[3 + 2 * k]));   // dijkstra :331
+    uint32_t acc = min(min(acc0, t[0]), t[1]);
+    acc = min(min(acc, t[2]), t[3]); acc = min(min(acc, t[4]), t[5]); acc = min(acc, t[6]);
+    const bool ch = acc < acc0;
+    any |= __ballot(ch);
+    if (ch) tb::ldsw(ya, acc | kTbDirty);
+  }
+  return any;
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
+{
+  __shared__ uint32_t lds[T * 64];
+  const int lane = threadIdx.x;
+  const uint32_t lane4 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * lane;
+  const uint32_t NP = A.NP;
+  const tb::cblk8_t tiles = (tb::cblk8_t)(uintptr_t)A.tiles;
+  const uint32_t n_items = A.ctl->n_items;
+  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0;
+  for (;;) {
+    uint32_t it = 0;
+    if (lane == 0) it = atomicAdd(&A.ctl->next_item, 1u);
+    it = tb::rfl(it);
+    if (it >= n_items) break;
+    const uint2 item = A.items[it];
+    const uint32_t t = tb::rfl(item.x), start = tb::rfl(item.y) & 0xFFFFu, count = tb::rfl(item.y) >> 16;
+    const tb::u32x16 Wv = tiles[t];
+    TbTile W;
+    W.soff = Wv[tb::kTwSoff]; W.sl = Wv[tb::kTwSl]; W.nv = Wv[tb::kTwNv]; W.nh = Wv[tb::kTwNh];
+    W.sweep_off = Wv[tb::kTwSweepOff]; W.sweep_blocks = Wv[tb::kTwSweepBlocks]; W.pre_off = Wv[tb::kTwPreOff]; W.pre_blocks = Wv[tb::kTwPreBlocks];
+    W.post_off = Wv[tb::kTwPostOff]; W.post_blocks = Wv[tb::kTwPostBlocks]; W.exp_off = Wv[tb::kTwExpOff]; W.exp_n = Wv[tb::kTwExpN];
+    ++my_items; my_acts += count;
+    if ((uint32_t)lane < count) {
+      const uint32_t p = A.bucket[(size_t)t * NP + start + lane];
+      MNAV_GLOBAL float* sl = as_global(A.D) + ((size_t)W.soff * NP + (size_t)p * W.sl);
+      // ---- load the owned slots: LDS[row][lane]
+      {
+        MNAV_GLOBAL const u32x4* s4 = (MNAV_GLOBAL const u32x4*)sl;
+        u32x4 v[T / 4];
+#pragma unroll
+        for (int c = 0; c < T / 4; ++c) v[c] = s4[c];
+#pragma unroll
+        for (int c = 0; c < T / 4; ++c) {
+          tb::ldsw(lane4 + (4 * c + 0) * 256, v[c].x); tb::ldsw(lane4 + (4 * c + 1) * 256, v[c].y);
+          tb::ldsw(lane4 + (4 * c + 2) * 256, v[c].z); tb::ldsw(lane4 + (4 * c + 3) * 256, v[c].w);
+        }
+      }
+      MNAV_GLOBAL const u32x4* g4p = (MNAV_GLOBAL const u32x4*)(sl + T);
+      // ---- ghosts -> owned (the ghosts are constant during the activation)
+      {
+        const tb::cblk4_t B = (tb::cblk4_t)(uintptr_t)(A.recs + W.pre_off);
+        uint32_t b = 0, g4 = 0;
+        while (b < W.pre_blocks) {
+          const u32x4 G = g4p[g4++];
+          uint32_t fl;
+          do {
+            const tb::u32x8 K = B[b++];
+            fl = K[0];
+            const uint32_t j = fl & 3u, n = K[1];
+            const float g = u2f(j == 0 ? G.x : j == 1 ? G.y : j == 2 ? G.z : G.w);
+#pragma unroll
+            for (int k = 1; k <= 3; ++k) {
+              if ((uint32_t)k <= n) {
+                const uint32_t a = K[2 * k] + lane4;
+                const uint32_t nd = f2u(g + u2f(K[2 * k + 1]));
+                if (nd < (tb::ldsr(a) & 0x7fffffffu)) tb::ldsw(a, nd | kTbDirty);
+              }
+            }
+          } while (!(fl & kTbGroupEnd));
+        }
+      }
+      // ---- Gauss-Seidel sweeps to the tile-local fixed point
+      uint32_t sweep = 0;
+      for (;;) {
+        const tb::cblk8_t B = (tb::cblk8_t)(uintptr_t)(A.recs + W.sweep_off + (size_t)(sweep & 3u) * W.sweep_blocks * 8u);
+        const unsigned long long any = tb_sweep<T>(B, W.sweep_blocks, lane4);
+        ++sweep;
+        if (any == 0ull) break;
+        if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
+      }
+      my_sweeps += sweep;
+      // ---- write back the 16-byte chunks that hold a lowered value
+      {
+        MNAV_GLOBAL u32x4* s4 = (MNAV_GLOBAL u32x4*)sl;
+#pragma unroll
+        for (int c = 0; c < T / 4; ++c) {
+          u32x4 x;
+          x.x = tb::ldsr(lane4 + (4 * c + 0) * 256); x.y = tb::ldsr(lane4 + (4 * c + 1) * 256);
+          x.z = tb::ldsr(lane4 + (4 * c + 2) * 256); x.w = tb::ldsr(lane4 + (4 * c + 3) * 256);
+          if ((x.x | x.y | x.z | x.w) & kTbDirty) {
+            x.x &= 0x7fffffffu; x.y &= 0x7fffffffu; x.z &= 0x7fffffffu; x.w &= 0x7fffffffu;
+            s4[c] = x;
+          }
+        }
+      }
+      // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex
+      {
+        const tb::cblk4_t B = (tb::cblk4_t)(uintptr_t)(A.recs + W.post_off);
+        uint32_t b = 0, g4 = 0;
+        uint32_t cand = kTbInfBits, best = kTbInfBits;
+        while (b < W.post_blocks) {
+          const u32x4 G = g4p[g4++];
+          uint32_t fl;
+          do {
+            const tb::u32x8 K = B[b++];
+            fl = K[0];
+            const uint32_t n = (fl >> 8) & 3u;
+#pragma unroll
+            for (int k = 1; k <= 3; ++k)
+              if ((uint32_t)k <= n) cand = min(cand, f2u(fabsf(u2f(tb::ldsr(K[2 * k] + lane4))) + u2f(K[2 * k + 1])));
+            if (fl & kTbGhostEnd) {
+              const uint32_t j = fl & 3u;
+              const uint32_t g = j == 0 ? G.x : j == 1 ? G.y : j == 2 ? G.z : G.w;
+              if (cand < g) best = min(best, cand);
+              cand = kTbInfBits;
+            }
+            if (fl & kTbTileEnd) {
+              const uint32_t t2 = K[1];
+              bool first = false;
+              if (best != kTbInfBits) {
+                const uint32_t old = atomicMin(&A.pend[(size_t)t2 * NP + p], best);
+                if (best < old) atomicMin(&A.marr[par ^ 1][p], best);
+                first = old == kTbInfBits;
+                ++my_wakes;
+              }
+              tb::append_pair(first, t2, p, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
+              best = kTbInfBits;
+            }
+          } while (!(fl & kTbGroupEnd));
+        }
+      }
+      // ---- export the lowered boundary values to the ghost slots that mirror them
+      {
+        const tb::cblk8_t X4 = (tb::cblk8_t)(uintptr_t)(A.exps + W.exp_off);
+        for (uint32_t k4 = 0; k4 * 4u < W.exp_n; ++k4) {
+          const tb::u32x16 X = X4[k4];                                  // 4 records {u, soff, sl, off}
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (k4 * 4u + q < W.exp_n) {
+              const uint32_t v = tb::ldsr(X[4 * q] + lane4);
+              if (v & kTbDirty) as_global(A.D)[(size_t)X[4 * q + 1] * NP + ((size_t)p * X[4 * q + 2] + X[4 * q + 3])] = u2f(v & 0x7fffffffu);
+            }
+          }
+        }
+      }
+    }
+  }
+  // statistics: one set of atomics per wave
+  my_wakes = wave_sum(my_wakes);
+  if (lane == 0 && my_items) {
+    atomicAdd(&A.ctl->items, (unsigned long long)my_items); atomicAdd(&A.ctl->acts, (unsigned long long)my_acts);
+    atomicAdd(&A.ctl->sweeps, (unsigned long long)my_sweeps); atomicAdd(&A.ctl->wakes, (unsigned long long)my_wakes);
+  }
+}
+
+// vertex path of a plan from the blocked distances: the walk of k_path_lazy (predecessor = argmin (dist[u] + w, dist[u], u)
+// over the expanded neighbours, the minimum must BE the vertex's distance), dijkstra :358-373
+__global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* __restrict__ row_ptr, const Nbr* __restrict__ nbr, uint32_t V,
+                                                   PlanResult* __restrict__ res, uint32_t* __restrict__ paths, uint32_t path_stride,
+                                                   uint32_t* __restrict__ mismatch)
+{
+  const uint32_t p = blockIdx.x;
+  const int lane = threadIdx.x;
+  PlanResult& R = res[p];
+  const uint32_t seed = A.seed[p], target = A.target[p];
+  const float dt = A.D[tb::slot_addr(A.vaddr[target], A.NP, p)];
+  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+  uint32_t code = kSuccess, n = 0, bad = 0;
+  if (A.ctl->err || A.ctl->n_cand[0] || A.ctl->n_cand[1]) code = kInternalError;   // sweep cap hit / not finished
+  else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
+  else {
+    uint32_t* path = paths + (size_t)p * path_stride;                 // written target-side first
+    uint32_t v = target;
+    float dv = dt;
+    while (v != seed && n < path_stride) {
+      float best_s = inf_f(), best_du = inf_f();
+      uint32_t best_u = v;
+      const uint32_t beg = row_ptr[v], end = row_ptr[v + 1];
+      for (uint32_t i = beg + lane; i < end; i += kWave) {
+        const Nbr nb = nbr[i];
+        const float du = A.D[tb::slot_addr(A.vaddr[nb.u], A.NP, p)];
+        if (du > goal_dist) continue;                                 // never expanded (dijkstra :299)
+        const float sm = du + nb.w;                                   // :331
+        if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
+      }
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const float os = __shfl_xor(best_s, o), odu = __shfl_xor(best_du, o);
+        const uint32_t ou = __shfl_xor(best_u, o);
+        if (os < best_s || (os == best_s && os < inf_f() && (odu < best_du || (odu == best_du && ou < best_u)))) { best_s = os; best_du = odu; best_u = ou; }
+      }
+      if (f2u(best_s) != f2u(dv) || best_u == v) { bad = 1; break; }  // not a fixed point here: reported, never returned
+      v = best_u; dv = best_du;
+      if (lane == 0) path[n] = v;
+      ++n;
+    }
+    if (!bad && v != seed) code = (path_stride < V) ? kPathOverflow : kInternalError;
+    if (bad) code = kInternalError;
+  }
+  if (lane == 0) {
+    R.code = code; R.path_len = (code == kSuccess) ? n : 0;
+    R.steps = A.ctl->iters; R.bands = 0; R.armed = (dt < inf_f()) ? 1u : 0u; R.overflow = A.ctl->err;
+    R.goal_dist = goal_dist; R.evals = 0; R.shrinks = 0;
+    if (bad) atomicAdd(mismatch, 1u);
+  }
+}
+
+// settled vertices per plan (the popped ones: dist <= goal_dist), for the algorithmic-bytes figure: one wave per slice
+__global__ __launch_bounds__(kBlock) void k_tb_count(tb::Args A, uint32_t T, PlanResult* __restrict__ res)
+{
+  const uint32_t t = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const TbTile W = A.tiles[t];
+  for (uint32_t p = blockIdx.y * (kBlock / 64) + wid; p < A.NP; p += gridDim.y * (kBlock / 64)) {
+    const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
+    const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+    const float* sl = A.D + ((size_t)W.soff * A.NP + (size_t)p * W.sl);
+    uint32_t c = 0;
+    for (uint32_t i = lane; i < W.nv; i += 64) { const float d = sl[i]; c += (d < inf_f() && d <= goal_dist) ? 1u : 0u; }
+    c = wave_sum(c);
+    if (lane == 0 && c) atomicAdd(&res[p].settled, (unsigned long long)c);
+  }
+}
+
+// popped potential of one plan in vertex order: the reference's value wherever it popped the vertex (dist <= goal_dist),
+// +inf elsewhere (mnav_download_output what = 5)
+__global__ __launch_bounds__(kBlock) void k_tb_popped(tb::Args A, uint32_t p, uint32_t V, float* __restrict__ out)
+{
+  const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
+  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) {
+    const float d = A.D[tb::slot_addr(A.vaddr[v], A.NP, p)];
+    out[v] = (d <= goal_dist) ? d : inf_f();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dist, uint32_t target, double offset, uint32_t V, float* __restrict__ out)
+{
+  const float dt = dist[target];
+  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + offset) : inf_f();
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) { const float d = dist[v]; out[v] = (d <= goal_dist) ? d : inf_f(); }
+}
+
+// blocked distances -> vertex order (callers that want the V-sized fields: finalize pass, vector map)
+__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, uint32_t V, float* const* __restrict__ dist_ptrs)
+{
+  const uint32_t p = blockIdx.y;
+  float* out = dist_ptrs[p];
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) out[v] = A.D[tb::slot_addr(A.vaddr[v], A.NP, p)];
+}
+
+// host-side state of the engine (device arrays of the mesh-dependent streams, and of the running batch)
+struct TbState {
+  bool built = false, w_valid = false;
+  uint32_t T = 128, ntiles = 0, max_nh = 0;
+  uint64_t S = 0;                       // words per plan
+  size_t nrec = 0, nexp = 0;
+  std::vector<uint32_t> vert_tile;      // host copy: plans are ordered by the tile of their wave source
+  TbTile* d_tiles = nullptr; TbRec* d_recs = nullptr; uint32_t* d_wsrc = nullptr; TbExp* d_exps = nullptr;
+  uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
+  // batch state, sized for cap_np plans
+  uint32_t cap_np = 0;
+  float* D = nullptr; uint32_t* pend = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;
+  tb::Ctl* ctl = nullptr; tb::Ctl* h_ctl = nullptr;
+  uint2* cand[2] = { nullptr, nullptr }; uint32_t* marr[2] = { nullptr, nullptr };
+  float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;
+  uint32_t min_batch = 256;             // batches of at least this many plans take this engine (MNAV_TB_MIN_BATCH)
+  float band_mult = 1.0f;               // band = band_mult * mean edge weight * sqrt(T)
+  int iters_per_replay = 16, waves_per_cu = 0;
+  hipGraphExec_t graph = nullptr; tb::Args graph_args{};
+  tb::Ctl last{};                       // counters of the last batch
+};
+
+}  // namespace

@@ -1,0 +1,211 @@
+// mnav_tb_host.h -- host driver of the tile-batch SSSP engine (mnav_tb.h).  Included by mnav.hip inside its anonymous
+// namespace, after mnav_ctx and the helpers (HIPCHK, dev_upload, ev_ms, PlanIn) are defined.
+#pragma once
+
+void tb_free_batch(mnav_ctx* ctx)
+{
+  TbState& S = ctx->tb;
+  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
+  (void)hipFree(S.cand[0]); (void)hipFree(S.cand[1]); (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
+  (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target);
+  if (S.h_ctl) (void)hipHostFree(S.h_ctl);
+  if (S.graph) (void)hipGraphExecDestroy(S.graph);
+  S.D = nullptr; S.pend = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
+  S.cand[0] = S.cand[1] = nullptr; S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
+  S.graph = nullptr; S.cap_np = 0;
+}
+
+void tb_free(mnav_ctx* ctx)
+{
+  TbState& S = ctx->tb;
+  tb_free_batch(ctx);
+  for (void* p : { (void*)S.d_tiles, (void*)S.d_recs, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile })
+    if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
+  S.d_tiles = nullptr; S.d_recs = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr;
+  S.built = false; S.w_valid = false; S.vert_tile.clear();
+}
+
+// mesh-dependent streams: built on the first batch that takes this engine (a few seconds of host work at 1M vertices)
+int tb_build(mnav_ctx* ctx)
+{
+  TbState& S = ctx->tb;
+  if (S.built) return 0;
+  if (const char* e = getenv("MNAV_TB_TILE")) S.T = (uint32_t)atoi(e);
+  if (S.T != 64 && S.T != 128) S.T = 128;
+  HostTopology t;
+  t.V = ctx->V; t.E = ctx->E; t.F = ctx->F;
+  t.row_ptr = ctx->h_row_ptr; t.nbr_u = ctx->h_nbr_u;
+  HostTb H;
+  try { H = build_tb(t, ctx->h_xyz.data(), S.T); }
+  catch (const std::exception& ex) { ctx->err = ex.what(); return -1; }
+  std::vector<uint2> vaddr(ctx->V);
+  for (uint32_t v = 0; v < ctx->V; ++v) {
+    const TbTile& W = H.tiles[H.vert_tile[v]];
+    if (W.sl >= (1u << 24)) { ctx->err = "tile-batch engine: a tile has too many ghosts"; return -1; }
+    vaddr[v] = make_uint2(W.soff, (W.sl << 8) | H.vert_local[v]);
+  }
+  if (dev_upload(ctx, &S.d_tiles, H.tiles.data(), H.tiles.size())) return -1;
+  if (dev_upload(ctx, &S.d_recs, H.recs.data(), H.recs.size())) return -1;
+  if (dev_upload(ctx, &S.d_wsrc, H.wsrc.data(), H.wsrc.size())) return -1;
+  if (dev_upload(ctx, &S.d_exps, H.exps.data(), H.exps.size())) return -1;
+  if (dev_upload(ctx, &S.d_vaddr, vaddr.data(), vaddr.size())) return -1;
+  if (dev_upload(ctx, &S.d_vert_tile, H.vert_tile.data(), H.vert_tile.size())) return -1;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.recs.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
+  S.vert_tile = std::move(H.vert_tile);
+  S.built = true; S.w_valid = false;
+  if (getenv("MNAV_VERBOSE"))
+    fprintf(stderr, "[mnav] tile-batch engine: T %u, %u tiles, %.2f slots per vertex, max ghosts %u, %.1f MB of streams\n", S.T, S.ntiles,
+            ctx->V ? (double)S.S / ctx->V : 0.0, S.max_nh, (8.0 * S.nrec + 16.0 * S.nexp) / 1e6);
+  return 0;
+}
+
+int tb_weights(mnav_ctx* ctx)
+{
+  TbState& S = ctx->tb;
+  if (S.w_valid) return 0;
+  const uint32_t n = (uint32_t)S.nrec;
+  hipLaunchKernelGGL(k_tb_weights, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, S.d_wsrc, ctx->d_nbr, S.d_recs);
+  HIPCHK(hipGetLastError());
+  S.w_valid = true;
+  return 0;
+}
+
+int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
+{
+  TbState& S = ctx->tb;
+  if (np <= S.cap_np) return 0;
+  tb_free_batch(ctx);
+  const size_t nt = S.ntiles ? S.ntiles : 1, pairs = nt * (size_t)np;
+  HIPCHK(hipMalloc((void**)&S.D, 4 * (size_t)S.S * np + 64));
+  HIPCHK(hipMalloc((void**)&S.pend, 4 * pairs + 64));
+  HIPCHK(hipMalloc((void**)&S.bucket, 2 * pairs + 64));
+  HIPCHK(hipMalloc((void**)&S.bcnt, 4 * nt));
+  HIPCHK(hipMalloc((void**)&S.items, 8 * (nt + pairs / 64 + 64)));
+  HIPCHK(hipMalloc((void**)&S.ctl, sizeof(tb::Ctl)));
+  HIPCHK(hipHostMalloc((void**)&S.h_ctl, sizeof(tb::Ctl), hipHostMallocDefault));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(hipMalloc((void**)&S.cand[k], 8 * pairs + 64));
+    HIPCHK(hipMalloc((void**)&S.marr[k], 4 * (size_t)np));
+  }
+  HIPCHK(hipMalloc((void**)&S.thr, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.bnd, 4 * (size_t)np));
+  HIPCHK(hipMalloc((void**)&S.seed, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.target, 4 * (size_t)np));
+  S.cap_np = np;
+  return 0;
+}
+
+int tb_fill(mnav_ctx* ctx, void* p, size_t bytes, uint32_t v)
+{
+  const size_t n16 = (bytes + 15) / 16;                               // the buffers carry 64 bytes of slack
+  uint32_t g = (uint32_t)std::min<size_t>((n16 + kBlock - 1) / kBlock, 256 * 32);
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_tb_fill, dim3(g), dim3(kBlock), 0, ctx->stream, (u32x4*)p, n16, v);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t waves)
+{
+  const uint32_t gp = (A.NP + kBlock - 1) / kBlock;
+  for (int j = 0; j < count; ++j) {
+    const int par = j & 1;
+    hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
+    hipLaunchKernelGGL(k_tb_filter, dim3(1024), dim3(kBlock), 0, ctx->stream, A, par);
+    hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
+    if (ctx->tb.T == 64) hipLaunchKernelGGL(k_tb_solve<64>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else hipLaunchKernelGGL(k_tb_solve<128>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Dijkstra batches through the tile-batch engine (paths-only calls).  Returns 0, -1 (error) or 1 (cancelled).
+int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
+{
+  TbState& S = ctx->tb;
+  if (tb_build(ctx)) return -1;
+  if (tb_weights(ctx)) return -1;
+  if (n > 65535u) { ctx->err = "tile-batch engine: more than 65535 plans in one batch"; return -1; }
+  if (tb_ensure_batch(ctx, n)) return -1;
+  if (ensure_plan_tables(ctx, n)) return -1;
+  if (ensure_paths(ctx, n)) return -1;
+  if (!ctx->d_mismatch) HIPCHK(hipMalloc((void**)&ctx->d_mismatch, 4));
+  std::vector<uint32_t> seeds(n), targets(n);
+  for (uint32_t i = 0; i < n; ++i) { seeds[i] = in[i].seed[0]; targets[i] = in[i].target[0]; }
+  HIPCHK(hipMemcpyAsync(S.seed, seeds.data(), 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(S.target, targets.data(), 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
+  tb::Args A{};
+  A.tiles = S.d_tiles; A.recs = S.d_recs; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.NP = n; A.ntiles = S.ntiles;
+  A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl;
+  A.cand[0] = S.cand[0]; A.cand[1] = S.cand[1]; A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
+  A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
+  A.offset = offset;
+  {
+    float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * S.band_mult;   // potential across one tile
+    if (const char* e = getenv("MNAV_TB_BAND_MULT")) band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * (float)atof(e);
+    if (ctx->tile_band_user > 0.f) band = ctx->tile_band_user;
+    A.band = band;
+  }
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  if (tb_fill(ctx, S.D, 4 * (size_t)S.S * n, kTbInfBits)) return -1;
+  if (tb_fill(ctx, S.pend, 4 * (size_t)S.ntiles * n, kTbInfBits)) return -1;
+  if (tb_fill(ctx, S.marr[0], 4 * (size_t)n, kTbInfBits)) return -1;
+  if (tb_fill(ctx, S.marr[1], 4 * (size_t)n, kTbInfBits)) return -1;
+  HIPCHK(hipMemsetAsync(S.ctl, 0, sizeof(tb::Ctl), ctx->stream));
+  HIPCHK(hipMemsetAsync(S.bcnt, 0, 4 * (size_t)(S.ntiles ? S.ntiles : 1), ctx->stream));
+  hipLaunchKernelGGL(k_tb_seed, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  uint32_t per_cu = S.T == 64 ? 10u : 5u;                            // LDS: T x 256 bytes per wave, 160 KB per CU
+  if (S.waves_per_cu > 0) per_cu = (uint32_t)S.waves_per_cu;
+  const uint32_t waves = per_cu * (uint32_t)ncu;
+  const int chunk = S.iters_per_replay & ~1;
+  // graph of `chunk` iterations, re-captured when the kernel arguments change
+  const bool same = S.graph && memcmp(&S.graph_args, &A, sizeof(A)) == 0;
+  if (ctx->use_graph && !same) {
+    if (S.graph) { (void)hipGraphExecDestroy(S.graph); S.graph = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = tb_launch_iterations(ctx, A, chunk, waves);
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
+    HIPCHK(hipGraphInstantiate(&S.graph, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    memcpy(&S.graph_args, &A, sizeof(A));
+  }
+  int rc = 0;
+  uint32_t iters = 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
+  for (;;) {
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
+      ctx->err = "tile-batch iterations exceeded the wall-clock guard"; return -1;
+    }
+    if (ctx->use_graph) HIPCHK(hipGraphLaunch(S.graph, ctx->stream));
+    else if (tb_launch_iterations(ctx, A, chunk, waves)) return -1;
+    iters += (uint32_t)chunk;
+    HIPCHK(hipMemcpyAsync(S.h_ctl, S.ctl, sizeof(tb::Ctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (S.h_ctl->err) { ctx->err = "tile-batch engine: sweep cap hit"; return -1; }
+    if (S.h_ctl->n_cand[0] == 0u) break;                             // the chunk ends on odd parity: its output list is list 0
+    if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
+    if (iters > ctx->max_steps) { ctx->err = "tile-batch engine: iteration cap hit"; return -1; }
+  }
+  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  HIPCHK(hipEventSynchronize(ctx->evc[1]));
+  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
+  S.last = *S.h_ctl;
+  ctx->stats.launches = 1;                                           // one engine run per batch (iterations: stats.steps)
+  ctx->tb_args = A;
+  if (getenv("MNAV_TRACE"))
+    fprintf(stderr, "[mnav] tile-batch: %u iterations, %llu activations (%.1f per item), %llu items, %.2f sweeps per item, %llu wakes\n", S.h_ctl->iters,
+            S.h_ctl->acts, S.h_ctl->items ? (double)S.h_ctl->acts / S.h_ctl->items : 0.0, S.h_ctl->items,
+            S.h_ctl->items ? (double)S.h_ctl->sweeps / S.h_ctl->items : 0.0, S.h_ctl->wakes);
+  return rc;
+}

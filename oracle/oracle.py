@@ -404,8 +404,30 @@ def model_lib():
         L.sm_infl_candidate.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_int)]
         L.sm_run_inflation.restype = u32
         L.sm_run_inflation.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_int, u32, vp, vp, vp, vp, vp, vp]
+        L.tbm_run.restype = u32
+        L.tbm_run.argtypes = [u32, u32, u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, C.c_double, C.c_double, C.c_float, C.c_int, vp, vp]
         _model = L
     return _model
+
+
+def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targets, offset=0.3, cost_limit=1.0, tile=128,
+                     band=None, jacobi=1, invalid=None):
+    """The tile-batch SSSP engine (mnav_tb.h) on the CPU model (oracle/tb_model.cpp): potentials of a batch of plans."""
+    faces, edges = _u32(faces), _u32(edges)
+    w, vc, pos = _f32(edge_weights), _f32(vertex_costs), _f32(xyz)
+    V, F, E = vc.shape[0], faces.shape[0], edges.shape[0]
+    inv = None if invalid is None else _u8(invalid)
+    sd, tg = _u32(seeds), _u32(targets)
+    n = sd.shape[0]
+    if band is None:
+        fin = w[np.isfinite(w)]
+        band = float(fin.mean() * np.sqrt(tile)) if fin.size else 1.0
+    dist = np.empty((n, V), np.float32)
+    stats = np.zeros(8, np.uint64)
+    code = model_lib().tbm_run(V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(pos), int(tile), n, _p(sd), _p(tg),
+                               float(offset), float(cost_limit), float(band), int(jacobi), _p(dist), _p(stats))
+    return dict(code=code, dist=dist, iterations=int(stats[0]), activations=int(stats[1]), sweeps=int(stats[2]), wakes=int(stats[3]),
+                max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]))
 
 
 def product_inflation_update(u1, u2, a, b, c, max_distance):

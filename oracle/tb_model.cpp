@@ -1,0 +1,171 @@
+// tb_model.cpp -- CPU model of the tile-batch SSSP engine (mesh_navigation_amd/csrc/mnav_tb.h).
+//
+// TEST INFRASTRUCTURE ONLY (lives under oracle/): it interprets the very same record streams the HIP kernel reads
+// (mnav_tb_build.h), lane by lane, and runs the same level-synchronous schedule (k_tb_plan / k_tb_filter / k_tb_items /
+// k_tb_solve) serially on the host, so that tests without a GPU can check the stream builder and the schedule against
+// the sequential oracle (mnav_oracle.c).  Never linked into, loaded by, or reachable from the product library.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../mesh_navigation_amd/csrc/mnav_tb_build.h"
+
+using namespace mnav;
+
+namespace {
+inline uint32_t fabs_bits_add(uint32_t v, uint32_t w) { return f2u(std::fabs(u2f(v)) + u2f(w)); }
+}
+
+extern "C" {
+
+// jacobi: 1 = every activation of an iteration sees the slices as they were when the iteration started (what concurrent
+// waves may see at worst), 0 = in place, in item order.
+// stats_out: [0] iterations, [1] (tile, plan) activations, [2] sweeps summed over activations, [3] wake-ups, [4] max sweeps of
+// one activation, [5] tiles, [6] slots per plan
+uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx, const float* edge_weights,
+                 const float* vertex_costs, const uint8_t* invalid, const float* xyz, uint32_t T, uint32_t n, const uint32_t* seeds,
+                 const uint32_t* targets, double offset, double cost_limit, float band, int jacobi, float* dist_out, uint64_t* stats_out)
+{
+  HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
+  std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
+  materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
+  HostTb H = build_tb(topo, xyz, T);
+  for (size_t i = 0; i < H.recs.size(); ++i) if (H.wsrc[i] != kNone) H.recs[i].b = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
+  const uint32_t NP = n, nt = H.ntiles;
+  auto slot = [&](uint32_t t, uint32_t p, uint32_t i) { return (size_t)H.tiles[t].soff * NP + (size_t)p * H.tiles[t].sl + i; };
+  std::vector<uint32_t> D((size_t)H.S * NP, kTbInfBits), Dsnap;
+  std::vector<uint32_t> pend((size_t)nt * NP, kTbInfBits);
+  std::vector<uint32_t> marr[2] = { std::vector<uint32_t>(NP, kTbInfBits), std::vector<uint32_t>(NP, kTbInfBits) };
+  std::vector<std::pair<uint32_t, uint32_t>> cand[2];
+  std::vector<float> thr(NP), bnd(NP);
+  // k_tb_seed
+  for (uint32_t p = 0; p < NP; ++p) {
+    const uint32_t s = seeds[p], t = H.vert_tile[s], loc = H.vert_local[s];
+    D[slot(t, p, loc)] = 0u;
+    const TbTile& W = H.tiles[t];
+    for (uint32_t k = 0; k < W.exp_n; ++k) { const TbExp& e = H.exps[W.exp_off + k]; if (e.u == loc * 256u) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off] = 0u; }
+    pend[(size_t)t * NP + p] = 0u; marr[0][p] = 0u; cand[0].push_back({ t, p });
+  }
+  uint64_t iters = 0, acts = 0, sweeps_tot = 0, wakes = 0, max_sweeps = 0;
+  std::vector<std::vector<uint16_t>> bucket(nt);
+  std::vector<uint32_t> lds(256 * 64 / 64);   // one lane's column: row offset / 256 -> value
+  for (int par = 0;; par ^= 1) {
+    if (cand[par].empty()) break;
+    ++iters;
+    // k_tb_plan
+    for (uint32_t p = 0; p < NP; ++p) {
+      const float m = u2f(marr[par][p]);
+      marr[par ^ 1][p] = kTbInfBits;
+      const uint32_t tg = targets[p];
+      const float dt = u2f(D[slot(H.vert_tile[tg], p, H.vert_local[tg])]);
+      const float bound = (float)((double)dt + offset);
+      const bool done = !(m < INFINITY) || m > bound;
+      float th = m + band; if (!(th > m)) th = next_up(m);
+      thr[p] = done ? 0.0f : th; bnd[p] = bound;
+    }
+    // k_tb_filter
+    cand[par ^ 1].clear();
+    for (auto& e : cand[par]) {
+      const size_t pi = (size_t)e.first * NP + e.second;
+      const uint32_t pb = pend[pi]; const float pv = u2f(pb);
+      if (pv > bnd[e.second]) pend[pi] = kTbInfBits;
+      else if (pv < thr[e.second]) { pend[pi] = kTbInfBits; bucket[e.first].push_back((uint16_t)e.second); }
+      else { cand[par ^ 1].push_back(e); marr[par ^ 1][e.second] = std::min(marr[par ^ 1][e.second], pb); }
+    }
+    if (jacobi) Dsnap = D;
+    const std::vector<uint32_t>& Din = jacobi ? Dsnap : D;
+    // k_tb_items + k_tb_solve, one lane at a time
+    for (uint32_t t = 0; t < nt; ++t) {
+      const TbTile& W = H.tiles[t];
+      for (uint16_t p16 : bucket[t]) {
+        const uint32_t p = p16;
+        ++acts;
+        const size_t sl = slot(t, p, 0);
+        for (uint32_t r = 0; r < T; ++r) lds[r] = Din[sl + r];
+        const size_t gs = sl + T;
+        // pre
+        {
+          uint32_t b = 0, g4 = 0;
+          while (b < W.pre_blocks) {
+            const uint32_t* G = &Din[gs + 4 * (size_t)g4++];
+            uint32_t fl;
+            do {
+              const TbRec* K = &H.recs[W.pre_off + 4 * (size_t)b++];
+              fl = K[0].a;
+              const uint32_t j = fl & 3u, cnt = K[0].b;
+              const float g = u2f(G[j]);
+              for (uint32_t k = 1; k <= 3; ++k) if (k <= cnt) {
+                const uint32_t row = K[k].a / 256u;
+                const uint32_t nd = f2u(g + u2f(K[k].b));
+                if (nd < (lds[row] & 0x7fffffffu)) lds[row] = nd | kTbDirty;
+              }
+            } while (!(fl & kTbGroupEnd));
+          }
+        }
+        // sweeps
+        uint32_t sweep = 0;
+        for (;;) {
+          const TbRec* B = &H.recs[W.sweep_off + (size_t)(sweep & 3u) * W.sweep_blocks * 8u];
+          bool any = false;
+          for (uint32_t b = 0; b < W.sweep_blocks; ++b) {
+            const TbRec* K = B + 8 * (size_t)b;
+            const uint32_t y = K[0].a / 256u;
+            const uint32_t acc0 = lds[y] & 0x7fffffffu;
+            uint32_t acc = acc0;
+            for (int k = 1; k <= 7; ++k) acc = std::min(acc, fabs_bits_add(lds[K[k].a / 256u], K[k].b));
+            if (acc < acc0) { lds[y] = acc | kTbDirty; any = true; }
+          }
+          ++sweep;
+          if (!any) break;
+          if (sweep >= 16u * T) return 60;
+        }
+        sweeps_tot += sweep; max_sweeps = std::max<uint64_t>(max_sweeps, sweep);
+        // write back
+        for (uint32_t r = 0; r < T; ++r) if (lds[r] & kTbDirty) D[sl + r] = lds[r] & 0x7fffffffu;
+        // post
+        {
+          uint32_t b = 0, g4 = 0, cnd = kTbInfBits, best = kTbInfBits;
+          while (b < W.post_blocks) {
+            const uint32_t* G = &Din[gs + 4 * (size_t)g4++];
+            uint32_t fl;
+            do {
+              const TbRec* K = &H.recs[W.post_off + 4 * (size_t)b++];
+              fl = K[0].a;
+              const uint32_t cnt = (fl >> 8) & 3u;
+              for (uint32_t k = 1; k <= 3; ++k) if (k <= cnt) cnd = std::min(cnd, fabs_bits_add(lds[K[k].a / 256u], K[k].b));
+              if (fl & kTbGhostEnd) { if (cnd < G[fl & 3u]) best = std::min(best, cnd); cnd = kTbInfBits; }
+              if (fl & kTbTileEnd) {
+                if (best != kTbInfBits) {
+                  const size_t pi = (size_t)K[0].b * NP + p;
+                  const uint32_t old = pend[pi];
+                  if (best < old) { pend[pi] = best; marr[par ^ 1][p] = std::min(marr[par ^ 1][p], best); }
+                  if (old == kTbInfBits) cand[par ^ 1].push_back({ K[0].b, p });
+                  ++wakes;
+                }
+                best = kTbInfBits;
+              }
+            } while (!(fl & kTbGroupEnd));
+          }
+        }
+        // export
+        for (uint32_t k = 0; k < W.exp_n; ++k) {
+          const TbExp& e = H.exps[W.exp_off + k];
+          const uint32_t v = lds[e.u / 256u];
+          if (v & kTbDirty) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off] = v & 0x7fffffffu;
+        }
+      }
+      bucket[t].clear();
+    }
+    if (iters > 1000000) return 61;
+  }
+  for (uint32_t p = 0; p < NP; ++p)
+    for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(D[slot(H.vert_tile[v], p, H.vert_local[v])]);
+  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; }
+  return 0;
+}
+
+}  // extern "C"
