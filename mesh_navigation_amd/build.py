@@ -30,7 +30,7 @@ def hipcc() -> str:
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, f) for f in ("mnav.hip", "mnav_eval.h", "mnav_build.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "mnav.h"))
     if force or _stale(LIB, srcs):
         cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB, os.path.join(CSRC, "mnav.hip")]

@@ -27,17 +27,16 @@ namespace {
 
 namespace tb {
 
-// Streams and tile headers are read through the constant address space: uniform addresses there are always scalar
-// loads (s_load_dwordx8 / x16), whatever the compiler can or cannot prove about aliasing stores.
+// Tile headers and export records are read through the constant address space (uniform addresses there are always
+// scalar loads); the edge streams come in 256-byte chunks through the vector memory path, one dword per lane, and are
+// picked apart with v_readlane (mnav_tb_build.h).
 #define MNAV_CONST __attribute__((address_space(4)))
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));     // a 4-record block: word 2k = record k .a, word 2k+1 = .b
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));   // an 8-record block / 4 export records / a tile header
-typedef const MNAV_CONST u32x8* cblk4_t;
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));   // 4 export records / a tile header
 typedef const MNAV_CONST u32x16* cblk8_t;
 typedef __attribute__((address_space(3))) uint32_t* lds_u32_t;
 // word indices of a TbTile read as u32x16
-enum { kTwSoff = 0, kTwSl = 1, kTwNv = 2, kTwNh = 3, kTwSweepOff = 4, kTwSweepBlocks = 5, kTwPreOff = 6, kTwPreBlocks = 7,
-       kTwPostOff = 8, kTwPostBlocks = 9, kTwExpOff = 10, kTwExpN = 11 };
+enum { kTwSoff = 0, kTwSl = 1, kTwNv = 2, kTwNh = 3, kTwSweepOff = 4, kTwSweepChunks = 5, kTwPreOff = 6, kTwPreChunks = 7,
+       kTwPostOff = 8, kTwPostChunks = 9, kTwExpOff = 10, kTwExpN = 11 };
 static_assert(offsetof(TbTile, exp_n) == 4 * kTwExpN && offsetof(TbTile, sweep_off) == 4 * kTwSweepOff, "TbTile layout");
 
 struct Ctl {
@@ -52,7 +51,7 @@ struct Ctl {
 };
 
 struct Args {
-  const TbTile* tiles; const TbRec* recs; const TbExp* exps;
+  const TbTile* tiles; const uint32_t* stream; const TbExp* exps;
   float* D; uint32_t* pend; uint32_t NP, ntiles;
   uint16_t* bucket; uint32_t* bcnt; uint2* items; Ctl* ctl;
   uint2* cand[2]; uint32_t* marr[2];
@@ -70,6 +69,7 @@ __device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_
 __device__ __forceinline__ uint32_t ldsr(uint32_t off) { return *(lds_u32_t)(uintptr_t)off; }
 __device__ __forceinline__ void ldsw(uint32_t off, uint32_t v) { *(lds_u32_t)(uintptr_t)off = v; }
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+#define TB_RL(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (i)))   // dword i of the chunk held in v (one dword per lane)
 
 // wave-aggregated append of the pair (t, p) of every lane with `want`
 __device__ __forceinline__ void append_pair(bool want, uint32_t t, uint32_t p, uint2* list, uint32_t* count, int lane)
@@ -85,12 +85,13 @@ __device__ __forceinline__ void append_pair(bool want, uint32_t t, uint32_t p, u
 
 }  // namespace tb
 
-__global__ __launch_bounds__(kBlock) void k_tb_weights(uint32_t n, const uint32_t* __restrict__ wsrc, const Nbr* __restrict__ nbr, TbRec* __restrict__ recs)
+__global__ __launch_bounds__(kBlock) void k_tb_weights(size_t n, const uint32_t* __restrict__ wsrc, const Nbr* __restrict__ nbr, uint32_t* __restrict__ stream)
 {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t s = wsrc[i];
-  if (s != kNone) recs[i].b = f2u(nbr[s].w);
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint32_t s = wsrc[i];
+    if (s != kNone) stream[i] = f2u(nbr[s].w);
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_tb_fill(u32x4* __restrict__ p, size_t n16, uint32_t v)
@@ -203,29 +204,76 @@ __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
 // ---------------------------------------------------------------------------------------------
 // The solve: one wave per work item (tile, <= 64 plans).
 // ---------------------------------------------------------------------------------------------
+// One Gauss-Seidel sweep: every block relaxes its target row from up to 7 source rows (dijkstra :331), in stream order.
+// Software pipeline: the LDS reads of block j+1 are issued before block j's result is written, so a block that reads
+// its predecessor's target sees the value of the previous sweep -- legal (any relaxation order reaches the same fixed
+// point), and the LDS latency of one block hides behind the arithmetic of the other.  No branch in the loop body: the
+// target row is rewritten unconditionally (old bits when nothing improved).
+struct TbBlk { uint32_t ya, raw, v[7], w[7]; };
+__device__ __forceinline__ TbBlk tb_issue(uint32_t cur, int o, uint32_t lane4)
+{
+  TbBlk B;
+  const uint32_t a0 = TB_RL(cur, o), a1 = TB_RL(cur, o + 1), a2 = TB_RL(cur, o + 2), a3 = TB_RL(cur, o + 3);
+  B.ya = (a0 & 0xFFFFu) + lane4;
+  B.raw = tb::ldsr(B.ya);
+  B.v[0] = tb::ldsr((a0 >> 16) + lane4); B.v[1] = tb::ldsr((a1 & 0xFFFFu) + lane4); B.v[2] = tb::ldsr((a1 >> 16) + lane4);
+  B.v[3] = tb::ldsr((a2 & 0xFFFFu) + lane4); B.v[4] = tb::ldsr((a2 >> 16) + lane4); B.v[5] = tb::ldsr((a3 & 0xFFFFu) + lane4);
+  B.v[6] = tb::ldsr((a3 >> 16) + lane4);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) B.w[k] = TB_RL(cur, o + 4 + k);
+  return B;
+}
+__device__ __forceinline__ bool tb_retire(const TbBlk& B)
+{
+  const uint32_t acc0 = B.raw & 0x7fffffffu;
+  uint32_t t[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) t[k] = f2u(fabsf(u2f(B.v[k])) + u2f(B.w[k]));
+  uint32_t acc = min(min(acc0, t[0]), t[1]);
+  acc = min(min(acc, t[2]), t[3]); acc = min(min(acc, t[4]), t[5]); acc = min(acc, t[6]);
+  const bool ch = acc < acc0;
+  tb::ldsw(B.ya, ch ? (acc | kTbDirty) : B.raw);
+  return ch;
+}
+
 template <int T>
-__device__ __forceinline__ unsigned long long tb_sweep(tb::cblk8_t B, uint32_t nblk, uint32_t lane4)
+__device__ __forceinline__ unsigned long long tb_sweep(MNAV_GLOBAL const uint32_t* st, uint32_t nch, uint32_t lane, uint32_t lane4)
 {
   unsigned long long any = 0ull;
-  for (uint32_t b = 0; b < nblk; ++b) {
-    const tb::u32x16 K = B[b];
-    const uint32_t ya = K[0] + lane4;
-    const uint32_t acc0 = tb::ldsr(ya) & 0x7fffffffu;
-    uint32_t t[7];
+  uint32_t c0 = st[lane], c1 = st[kTbChunk + lane];                 // two chunks in flight behind vmcnt
+  for (uint32_t c = 0; c < nch; ++c) {
+    const uint32_t cur = c0;
+    c0 = c1; c1 = st[(size_t)(c + 2) * kTbChunk + lane];
+#ifdef MNAV_TB_NO_PIPELINE
 #pragma unroll
-    for (int k = 0; k < 7; ++k) t[k] = f2u(fabsf(u2f(tb::ldsr(K[2 + 2 * k] + lane4))) + u2f(K[3 + 2 * k]));   // dijkstra :331
-    uint32_t acc = min(min(acc0, t[0]), t[1]);
-    acc = min(min(acc, t[2]), t[3]); acc = min(min(acc, t[4]), t[5]); acc = min(acc, t[6]);
-    const bool ch = acc < acc0;
-    any |= __ballot(ch);
-    if (ch) tb::ldsw(ya, acc | kTbDirty);
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) { const TbBlk B = tb_issue(cur, (int)kTbBlock * j, lane4); any |= __ballot(tb_retire(B)); }
+#else
+    TbBlk A = tb_issue(cur, 0, lane4);
+#pragma unroll
+    for (int j = 1; j < (int)kTbBlocksPerChunk; ++j) {
+      const TbBlk B = tb_issue(cur, (int)kTbBlock * j, lane4);
+      any |= __ballot(tb_retire(A));
+      A = B;
+    }
+    any |= __ballot(tb_retire(A));
+#endif
   }
   return any;
 }
 
+#ifdef MNAV_TB_TIMING                      // debugging aid: cycles per phase of k_tb_solve, summed over all waves
+__device__ unsigned long long g_tb_timing[8];
+#define TB_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tt[k] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define TB_STAMP(k) do { } while (0)
+#endif
+
 template <int T>
 __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
 {
+#ifdef MNAV_TB_TIMING
+  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
+#endif
   __shared__ uint32_t lds[T * 64];
   const int lane = threadIdx.x;
   const uint32_t lane4 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * lane;
@@ -243,11 +291,15 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
     const tb::u32x16 Wv = tiles[t];
     TbTile W;
     W.soff = Wv[tb::kTwSoff]; W.sl = Wv[tb::kTwSl]; W.nv = Wv[tb::kTwNv]; W.nh = Wv[tb::kTwNh];
-    W.sweep_off = Wv[tb::kTwSweepOff]; W.sweep_blocks = Wv[tb::kTwSweepBlocks]; W.pre_off = Wv[tb::kTwPreOff]; W.pre_blocks = Wv[tb::kTwPreBlocks];
-    W.post_off = Wv[tb::kTwPostOff]; W.post_blocks = Wv[tb::kTwPostBlocks]; W.exp_off = Wv[tb::kTwExpOff]; W.exp_n = Wv[tb::kTwExpN];
+    W.sweep_off = Wv[tb::kTwSweepOff]; W.sweep_chunks = Wv[tb::kTwSweepChunks]; W.pre_off = Wv[tb::kTwPreOff]; W.pre_chunks = Wv[tb::kTwPreChunks];
+    W.post_off = Wv[tb::kTwPostOff]; W.post_chunks = Wv[tb::kTwPostChunks]; W.exp_off = Wv[tb::kTwExpOff]; W.exp_n = Wv[tb::kTwExpN];
     ++my_items; my_acts += count;
-    if ((uint32_t)lane < count) {
-      const uint32_t p = A.bucket[(size_t)t * NP + start + lane];
+    TB_STAMP(0);
+    {
+      // Every lane runs the whole item: the stream chunks are held one dword per lane, so all 64 lanes must execute the
+      // loads.  Lanes beyond `count` shadow the last plan of the item and store nothing.
+      const bool active = (uint32_t)lane < count;
+      const uint32_t p = A.bucket[(size_t)t * NP + start + min((uint32_t)lane, count - 1u)];
       MNAV_GLOBAL float* sl = as_global(A.D) + ((size_t)W.soff * NP + (size_t)p * W.sl);
       // ---- load the owned slots: LDS[row][lane]
       {
@@ -262,39 +314,50 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
         }
       }
       MNAV_GLOBAL const u32x4* g4p = (MNAV_GLOBAL const u32x4*)(sl + T);
+      TB_STAMP(1);
       // ---- ghosts -> owned (the ghosts are constant during the activation)
-      {
-        const tb::cblk4_t B = (tb::cblk4_t)(uintptr_t)(A.recs + W.pre_off);
-        uint32_t b = 0, g4 = 0;
-        while (b < W.pre_blocks) {
-          const u32x4 G = g4p[g4++];
-          uint32_t fl;
-          do {
-            const tb::u32x8 K = B[b++];
-            fl = K[0];
-            const uint32_t j = fl & 3u, n = K[1];
-            const float g = u2f(j == 0 ? G.x : j == 1 ? G.y : j == 2 ? G.z : G.w);
+      if (W.pre_chunks) {
+        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + (size_t)W.pre_off * kTbChunk;
+        uint32_t c0 = st[lane], c1 = st[kTbChunk + lane];
+        u32x4 G = g4p[TB_RL(c0, 60)];
+        for (uint32_t c = 0; c < W.pre_chunks; ++c) {
+          const uint32_t cur = c0;
+          c0 = c1; c1 = st[(size_t)(c + 2) * kTbChunk + lane];
+          const u32x4 Gn = g4p[TB_RL(cur, 61)];                       // the next chunk's ghost values (group 0 after the last one)
 #pragma unroll
-            for (int k = 1; k <= 3; ++k) {
-              if ((uint32_t)k <= n) {
-                const uint32_t a = K[2 * k] + lane4;
-                const uint32_t nd = f2u(g + u2f(K[2 * k + 1]));
-                if (nd < (tb::ldsr(a) & 0x7fffffffu)) tb::ldsw(a, nd | kTbDirty);
+          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+            const int o = (int)kTbBlock * j;
+            const uint32_t hd = TB_RL(cur, o), n = (hd >> 8) & 7u;
+            if (n) {
+              const uint32_t jj = hd & 3u;
+              const float g = u2f(jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w);
+#pragma unroll
+              for (int k = 0; k < (int)kTbGhostEdges; ++k) {
+                if ((uint32_t)k < n) {
+                  const uint32_t pr = TB_RL(cur, o + 1 + k / 2);
+                  const uint32_t a = ((k & 1) ? (pr >> 16) : (pr & 0xFFFFu)) + lane4;
+                  const uint32_t nd = f2u(g + u2f(TB_RL(cur, o + 4 + k)));
+                  const uint32_t raw = tb::ldsr(a);
+                  tb::ldsw(a, nd < (raw & 0x7fffffffu) ? (nd | kTbDirty) : raw);
+                }
               }
             }
-          } while (!(fl & kTbGroupEnd));
+          }
+          G = Gn;
         }
       }
+      TB_STAMP(2);
       // ---- Gauss-Seidel sweeps to the tile-local fixed point
       uint32_t sweep = 0;
       for (;;) {
-        const tb::cblk8_t B = (tb::cblk8_t)(uintptr_t)(A.recs + W.sweep_off + (size_t)(sweep & 3u) * W.sweep_blocks * 8u);
-        const unsigned long long any = tb_sweep<T>(B, W.sweep_blocks, lane4);
+        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + ((size_t)W.sweep_off + (size_t)(sweep & 3u) * W.sweep_chunks) * kTbChunk;
+        const unsigned long long any = tb_sweep<T>(st, W.sweep_chunks, (uint32_t)lane, lane4);
         ++sweep;
         if (any == 0ull) break;
         if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
       }
       my_sweeps += sweep;
+      TB_STAMP(3);
       // ---- write back the 16-byte chunks that hold a lowered value
       {
         MNAV_GLOBAL u32x4* s4 = (MNAV_GLOBAL u32x4*)sl;
@@ -303,48 +366,60 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
           u32x4 x;
           x.x = tb::ldsr(lane4 + (4 * c + 0) * 256); x.y = tb::ldsr(lane4 + (4 * c + 1) * 256);
           x.z = tb::ldsr(lane4 + (4 * c + 2) * 256); x.w = tb::ldsr(lane4 + (4 * c + 3) * 256);
-          if ((x.x | x.y | x.z | x.w) & kTbDirty) {
+          if (active && ((x.x | x.y | x.z | x.w) & kTbDirty)) {
             x.x &= 0x7fffffffu; x.y &= 0x7fffffffu; x.z &= 0x7fffffffu; x.w &= 0x7fffffffu;
             s4[c] = x;
           }
         }
       }
+      TB_STAMP(4);
       // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex
-      {
-        const tb::cblk4_t B = (tb::cblk4_t)(uintptr_t)(A.recs + W.post_off);
-        uint32_t b = 0, g4 = 0;
+      if (W.post_chunks) {
+        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + (size_t)W.post_off * kTbChunk;
+        uint32_t c0 = st[lane], c1 = st[kTbChunk + lane];
+        u32x4 G = g4p[TB_RL(c0, 60)];
         uint32_t cand = kTbInfBits, best = kTbInfBits;
-        while (b < W.post_blocks) {
-          const u32x4 G = g4p[g4++];
-          uint32_t fl;
-          do {
-            const tb::u32x8 K = B[b++];
-            fl = K[0];
-            const uint32_t n = (fl >> 8) & 3u;
+        for (uint32_t c = 0; c < W.post_chunks; ++c) {
+          const uint32_t cur = c0;
+          c0 = c1; c1 = st[(size_t)(c + 2) * kTbChunk + lane];
+          const u32x4 Gn = g4p[TB_RL(cur, 61)];
 #pragma unroll
-            for (int k = 1; k <= 3; ++k)
-              if ((uint32_t)k <= n) cand = min(cand, f2u(fabsf(u2f(tb::ldsr(K[2 * k] + lane4))) + u2f(K[2 * k + 1])));
-            if (fl & kTbGhostEnd) {
-              const uint32_t j = fl & 3u;
-              const uint32_t g = j == 0 ? G.x : j == 1 ? G.y : j == 2 ? G.z : G.w;
-              if (cand < g) best = min(best, cand);
-              cand = kTbInfBits;
-            }
-            if (fl & kTbTileEnd) {
-              const uint32_t t2 = K[1];
-              bool first = false;
-              if (best != kTbInfBits) {
-                const uint32_t old = atomicMin(&A.pend[(size_t)t2 * NP + p], best);
-                if (best < old) atomicMin(&A.marr[par ^ 1][p], best);
-                first = old == kTbInfBits;
-                ++my_wakes;
+          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+            const int o = (int)kTbBlock * j;
+            const uint32_t hd = TB_RL(cur, o), n = (hd >> 8) & 7u;
+            if (n) {
+#pragma unroll
+              for (int k = 0; k < (int)kTbGhostEdges; ++k) {
+                if ((uint32_t)k < n) {
+                  const uint32_t pr = TB_RL(cur, o + 1 + k / 2);
+                  const uint32_t a = ((k & 1) ? (pr >> 16) : (pr & 0xFFFFu)) + lane4;
+                  cand = min(cand, f2u(fabsf(u2f(tb::ldsr(a))) + u2f(TB_RL(cur, o + 4 + k))));
+                }
               }
-              tb::append_pair(first, t2, p, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
-              best = kTbInfBits;
+              if (hd & kTbGhostEnd) {
+                const uint32_t jj = hd & 3u;
+                const uint32_t g = jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w;
+                if (cand < g) best = min(best, cand);
+                cand = kTbInfBits;
+              }
+              if (hd & kTbTileEnd) {
+                const uint32_t t2 = TB_RL(cur, o + 9);
+                bool first = false;
+                if (active && best != kTbInfBits) {
+                  const uint32_t old = atomicMin(&A.pend[(size_t)t2 * NP + p], best);
+                  if (best < old) atomicMin(&A.marr[par ^ 1][p], best);
+                  first = old == kTbInfBits;
+                  ++my_wakes;
+                }
+                tb::append_pair(first, t2, p, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
+                best = kTbInfBits;
+              }
             }
-          } while (!(fl & kTbGroupEnd));
+          }
+          G = Gn;
         }
       }
+      TB_STAMP(5);
       // ---- export the lowered boundary values to the ghost slots that mirror them
       {
         const tb::cblk8_t X4 = (tb::cblk8_t)(uintptr_t)(A.exps + W.exp_off);
@@ -354,13 +429,17 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
           for (int q = 0; q < 4; ++q) {
             if (k4 * 4u + q < W.exp_n) {
               const uint32_t v = tb::ldsr(X[4 * q] + lane4);
-              if (v & kTbDirty) as_global(A.D)[(size_t)X[4 * q + 1] * NP + ((size_t)p * X[4 * q + 2] + X[4 * q + 3])] = u2f(v & 0x7fffffffu);
+              if (active && (v & kTbDirty)) as_global(A.D)[(size_t)X[4 * q + 1] * NP + ((size_t)p * X[4 * q + 2] + X[4 * q + 3])] = u2f(v & 0x7fffffffu);
             }
           }
         }
       }
+      TB_STAMP(6);
     }
   }
+#ifdef MNAV_TB_TIMING
+  if (lane == 0) for (int k = 0; k < 8; ++k) if (tt[k]) atomicAdd(&g_tb_timing[k], tt[k]);
+#endif
   // statistics: one set of atomics per wave
   my_wakes = wave_sum(my_wakes);
   if (lane == 0 && my_items) {
@@ -382,7 +461,7 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
   const float dt = A.D[tb::slot_addr(A.vaddr[target], A.NP, p)];
   const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
   uint32_t code = kSuccess, n = 0, bad = 0;
-  if (A.ctl->err || A.ctl->n_cand[0] || A.ctl->n_cand[1]) code = kInternalError;   // sweep cap hit / not finished
+  if (A.ctl->err || A.ctl->n_cand[0]) code = kInternalError;          // sweep cap hit / pairs still pending (the host stops after an odd iteration: list 0 is its output)
   else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
   else {
     uint32_t* path = paths + (size_t)p * path_stride;                 // written target-side first
@@ -475,7 +554,7 @@ struct TbState {
   uint64_t S = 0;                       // words per plan
   size_t nrec = 0, nexp = 0;
   std::vector<uint32_t> vert_tile;      // host copy: plans are ordered by the tile of their wave source
-  TbTile* d_tiles = nullptr; TbRec* d_recs = nullptr; uint32_t* d_wsrc = nullptr; TbExp* d_exps = nullptr;
+  TbTile* d_tiles = nullptr; uint32_t* d_stream = nullptr; uint32_t* d_wsrc = nullptr; TbExp* d_exps = nullptr;
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // batch state, sized for cap_np plans
   uint32_t cap_np = 0;
@@ -491,3 +570,12 @@ struct TbState {
 };
 
 }  // namespace
+
+#ifdef MNAV_TB_TIMING
+extern "C" int mnav_debug_tb_timing(unsigned long long* out)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tb_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tb_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

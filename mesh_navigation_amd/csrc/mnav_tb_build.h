@@ -25,36 +25,42 @@
 
 namespace mnav {
 
-struct TbRec { uint32_t a, b; };           // 8 bytes; meaning depends on the stream, see below
 struct TbExp { uint32_t u, soff, sl, off; };   // boundary vertex `u` (LDS byte offset of its row) is a ghost of another tile:
                                                // its value goes to D[soff * NP + plan * sl + off]
 
-// One 64-byte header per tile (read with scalar loads).
+// One 64-byte header per tile (read with one scalar load).
 struct TbTile {
   uint32_t soff;          // start of the tile's region, in words PER PLAN (prefix sum of sl)
   uint32_t sl;            // slice length in words: T owned slots + ghosts, padded to a multiple of 4
   uint32_t nv;            // owned vertices (<= T; the slots nv..T-1 stay +inf)
   uint32_t nh;            // ghosts
-  uint32_t sweep_off;     // first record of sweep order 0; order k starts at sweep_off + k * sweep_blocks * 8
-  uint32_t sweep_blocks;  // 8-record blocks per order
-  uint32_t pre_off, pre_blocks;     // 4-record blocks, ghost -> owned edges, grouped by ghost
-  uint32_t post_off, post_blocks;   // 4-record blocks, owned -> ghost edges, grouped by ghost
+  uint32_t sweep_off;     // first chunk of sweep order 0; order k starts at chunk sweep_off + k * sweep_chunks
+  uint32_t sweep_chunks;  // chunks per order
+  uint32_t pre_off, pre_chunks;     // ghost -> owned edges
+  uint32_t post_off, post_chunks;   // owned -> ghost edges
   uint32_t exp_off, exp_n;          // TbExp records
   uint32_t v0;            // position of the first owned vertex in `verts`
   uint32_t pad[3];
 };
 static_assert(sizeof(TbTile) == 64, "TbTile is read as one 64-byte scalar load");
 
-// Record streams.  A "row" is a local vertex; records carry the row's LDS byte offset (row * 256: 64 lanes x 4 B).
-//   sweep block (8 records):  [0] = {target row offset, edge count}   [1..7] = {source row offset, weight bits}
-//                             unused slots: {target row offset, +inf}
-//   pre block (4 records):    [0] = {flags | j, edge count}           [1..3] = {target row offset, weight bits}
-//                             ghost -> owned edges of ghost 4 * group + j
-//   post block (4 records):   [0] = {flags | j | count << 8, owner tile}   [1..3] = {source row offset, weight bits}
-//                             owned -> ghost edges of ghost 4 * group + j
-// flags of pre / post headers:
-constexpr uint32_t kTbGhostEnd = 1u << 4;   // last block of this ghost
-constexpr uint32_t kTbGroupEnd = 1u << 5;   // last block of this group of 4 ghosts (the next block needs the next 16-byte load)
+// Streams.  The graph of a tile is stored as CHUNKS of 64 dwords (256 bytes): a wave reads a chunk with ONE coalesced
+// vector load (lane l holds dword l; the next chunks are prefetched behind the vector-memory counter, which -- unlike
+// scalar loads -- does not share a wait counter with the LDS), and picks the dwords out with v_readlane into SGPRs.
+// A chunk holds 5 BLOCKS of 12 dwords; dwords 60..63 are chunk-level fields.  A "row" is a local vertex; offsets are
+// the row's LDS byte offset (row * 256: 64 lanes x 4 B), 16 bits each, two per dword (lo | hi << 16).
+//   sweep block:  d0 = target | src0 << 16, d1 = src1 | src2 << 16, d2 = src3 | src4 << 16, d3 = src5 | src6 << 16,
+//                 d4..d10 = weight bits of src0..src6 (unused slots: src = target, weight = +inf), d11 = 0
+//   pre block:    d0 = flags | j | n << 8 (n = edges, 0 = empty block), d1 = tgt0 | tgt1 << 16, d2 = tgt2 | tgt3 << 16,
+//                 d3 = tgt4, d4..d8 = weight bits: the ghost -> owned edges of ghost 4 * group + j
+//   post block:   as pre with source rows (owned -> ghost edges), d9 = owner tile of the ghost
+//   pre / post chunk fields: d60 = this chunk's ghost group (which 16-byte quad of the slice's ghost part), d61 = the
+//                 NEXT chunk's group (prefetch)
+constexpr uint32_t kTbChunk = 64;           // dwords per chunk
+constexpr uint32_t kTbBlock = 12;           // dwords per block
+constexpr uint32_t kTbBlocksPerChunk = 5;
+constexpr uint32_t kTbGhostEdges = 5;       // edges per pre / post block
+constexpr uint32_t kTbGhostEnd = 1u << 4;   // last block of this ghost (post: compare the candidate with the ghost value)
 constexpr uint32_t kTbTileEnd = 1u << 6;    // last ghost owned by this neighbour tile (post: emit the wake-up)
 constexpr uint32_t kTbInfBits = 0x7f800000u;
 constexpr uint32_t kTbDirty = 0x80000000u;  // sign bit of an LDS value: lowered during this activation
@@ -64,33 +70,69 @@ struct HostTb {
   uint64_t S = 0;                     // words per plan (sum of the slice lengths)
   uint32_t max_nh = 0, max_sl = 0;
   std::vector<TbTile> tiles;
-  std::vector<TbRec> recs;
-  std::vector<uint32_t> wsrc;         // per record: index into the gather CSR (Nbr) its weight comes from, kNone otherwise
+  std::vector<uint32_t> stream;       // chunks
+  std::vector<uint32_t> wsrc;         // per stream dword: index into the gather CSR (Nbr) its weight comes from, kNone otherwise
   std::vector<TbExp> exps;
   std::vector<uint32_t> verts;        // tile order -> vertex id
   std::vector<uint32_t> vert_tile, vert_local;   // V
 };
 
 namespace detail {
-// recursive coordinate bisection: compact, balanced tiles of <= T vertices in an order that keeps neighbours close
-inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, const float* xyz, uint32_t T, std::vector<uint32_t>& cuts)
+// Recursive coordinate bisection of a vertex set into `k` compact tiles of <= T vertices, in an order that keeps
+// neighbours close.  The cut is placed in the LARGEST GAP of the coordinate near the proportional split position: on a
+// scanned / gridded surface a cut through the middle of a row of vertices would deal that row to the two sides at
+// random (a zigzag boundary that wavefronts cross back and forth: twice the tile activations on the 1M terrain);
+// cuts between rows give straight boundaries.  The leaf budget leaves ~10 % slack so that such a cut usually exists
+// within the positions that keep both sides within their budgets.
+inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k, const float* xyz, uint32_t T, std::vector<uint32_t>& cuts)
 {
   const size_t n = hi - lo;
-  if (n <= T) { cuts.push_back((uint32_t)hi); return; }
+  if (k <= 1) { cuts.push_back((uint32_t)hi); return; }
   float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
   for (size_t i = lo; i < hi; ++i)
-    for (int k = 0; k < 3; ++k) { const float x = xyz[3 * (size_t)ids[i] + k]; mn[k] = std::min(mn[k], x); mx[k] = std::max(mx[k], x); }
+    for (int q = 0; q < 3; ++q) { const float x = xyz[3 * (size_t)ids[i] + q]; mn[q] = std::min(mn[q], x); mx[q] = std::max(mx[q], x); }
   int ax = 0;
-  for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
-  // leaves as full as possible: the left half gets a multiple of T when that keeps the halves balanced
-  const size_t leaves = (n + T - 1) / T;
-  const size_t left = std::min(n - 1, std::max<size_t>(1, (leaves / 2) * (size_t)T));
-  std::nth_element(ids.begin() + lo, ids.begin() + lo + left, ids.begin() + hi, [&](uint32_t a, uint32_t b) {
+  for (int q = 1; q < 3; ++q) if (mx[q] - mn[q] > mx[ax] - mn[ax]) ax = q;
+  auto less = [&](uint32_t a, uint32_t b) {
     const float xa = xyz[3 * (size_t)a + ax], xb = xyz[3 * (size_t)b + ax];
     return xa < xb || (xa == xb && a < b);
-  });
-  tb_bisect(ids, lo, lo + left, xyz, T, cuts);
-  tb_bisect(ids, lo + left, hi, xyz, T, cuts);
+  };
+  int ax2 = (ax + 1) % 3;                                            // second widest axis
+  { const int o = (ax + 2) % 3; if (mx[o] - mn[o] > mx[ax2] - mn[ax2]) ax2 = o; }
+  const size_t kl = k / 2, kr = k - kl;
+  const size_t target = (size_t)((double)n * (double)kl / (double)k);
+  // positions c (vertices on the left) that keep both sides within their budgets
+  const size_t f_lo = std::max<size_t>(n > kr * (size_t)T ? n - kr * (size_t)T : 1, 1), f_hi = std::min(kl * (size_t)T, n - 1);
+  // sorted window of order statistics around the target: about two rows of a square patch of n vertices on each side
+  const size_t w = (size_t)(2.0 * std::sqrt((double)n)) + 8;
+  const size_t a = target > w ? target - w : 0, b = std::min(target + w, n - 1);   // positions a..b are sorted
+  if (a > 0) std::nth_element(ids.begin() + lo, ids.begin() + lo + a, ids.begin() + hi, less);
+  if (b + 1 < n) std::nth_element(ids.begin() + lo + a, ids.begin() + lo + b, ids.begin() + hi, less);
+  std::sort(ids.begin() + lo + a, ids.begin() + lo + b + 1, less);
+  auto gap_at = [&](size_t c) { return xyz[3 * (size_t)ids[lo + c] + ax] - xyz[3 * (size_t)ids[lo + c - 1] + ax]; };   // between c-1 and c
+  float maxgap = 0.f;
+  for (size_t c = a + 1; c <= b; ++c) maxgap = std::max(maxgap, gap_at(c));
+  const size_t c_lo = std::min(std::max(f_lo, a + 1), b), c_hi = std::max(std::min(f_hi, b), c_lo);
+  size_t cut = std::min(std::max(target, c_lo), c_hi); float best = -1.f;
+  for (size_t c = c_lo; c <= c_hi; ++c) {
+    const float gap = gap_at(c);
+    const size_t dc = c > target ? c - target : target - c, db = cut > target ? cut - target : target - cut;
+    if (gap > best * 1.0001f + 1e-12f || (gap >= best && dc < db)) { best = gap; cut = c; }
+  }
+  if (best < 0.5f * maxgap) {
+    // no cut between two rows fits the budgets: cut through a row, but deal its vertices to the two sides in the order of the
+    // second axis (an L-shaped, contiguous boundary) instead of by their jitter along the first one
+    cut = std::min(std::max(target, c_lo), c_hi);
+    size_t rl = a, rr = b + 1;
+    for (size_t c = cut; c > a; --c) if (gap_at(c) >= 0.5f * maxgap) { rl = c; break; }
+    for (size_t c = cut + 1; c <= b; ++c) if (gap_at(c) >= 0.5f * maxgap) { rr = c; break; }
+    std::sort(ids.begin() + lo + rl, ids.begin() + lo + rr, [&](uint32_t p, uint32_t q) {
+      const float xp = xyz[3 * (size_t)p + ax2], xq = xyz[3 * (size_t)q + ax2];
+      return xp < xq || (xp == xq && p < q);
+    });
+  }
+  tb_bisect(ids, lo, lo + cut, kl, xyz, T, cuts);
+  tb_bisect(ids, lo + cut, hi, kr, xyz, T, cuts);
 }
 }  // namespace detail
 
@@ -103,7 +145,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
   H.verts.resize(V);
   std::iota(H.verts.begin(), H.verts.end(), 0u);
   std::vector<uint32_t> cuts;
-  if (V) detail::tb_bisect(H.verts, 0, V, xyz, T, cuts);
+  if (V) detail::tb_bisect(H.verts, 0, V, std::max<size_t>(1, (size_t)std::ceil((double)V / (0.9 * T))), xyz, T, cuts);
   H.ntiles = (uint32_t)cuts.size();
   H.vert_tile.assign(V, 0); H.vert_local.assign(V, 0);
   H.tiles.assign(H.ntiles, TbTile{});
@@ -143,7 +185,33 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     return (uint32_t)(it - g.begin());
   };
   const uint32_t kRow = 256;   // bytes per LDS row
-  auto push = [&](uint32_t a, uint32_t b, uint32_t src) { H.recs.push_back(TbRec{ a, b }); H.wsrc.push_back(src); };
+  // chunk writer: blocks are appended to the open chunk, a full (or closed) chunk is padded to 64 dwords
+  uint32_t in_chunk = 0;
+  // Every sweep block rewrites its target row (with the bits it read when nothing improved), and the kernel may have the
+  // reads of block j+1 in flight before block j's result is written (MNAV_TB_PIPELINE).  Two ADJACENT blocks of a chunk
+  // must therefore never have the same target.  `last_target` = target row of the previous block of the open chunk.
+  uint32_t last_target = kNone;
+  auto open_block = [&]() -> size_t {                                // returns the dword index of the new block
+    if (in_chunk == kTbBlocksPerChunk) { H.stream.resize(H.stream.size() + 4, 0u); H.wsrc.resize(H.wsrc.size() + 4, kNone); in_chunk = 0; last_target = kNone; }
+    const size_t at = H.stream.size();
+    H.stream.resize(at + kTbBlock, 0u); H.wsrc.resize(at + kTbBlock, kNone);
+    ++in_chunk;
+    return at;
+  };
+  auto noop_sweep_block = [&]() {                                    // all weights +inf, on a row the previous block did not target
+    const uint32_t row = (last_target == 0u) ? 1u : 0u;
+    const size_t at = open_block();
+    const uint32_t yo = row * kRow;
+    H.stream[at] = H.stream[at + 1] = H.stream[at + 2] = H.stream[at + 3] = yo | (yo << 16);
+    for (int q = 4; q <= 10; ++q) H.stream[at + q] = kTbInfBits;
+    last_target = row;
+  };
+  auto close_chunk = [&](bool sweep) {                               // pad the open chunk
+    if (in_chunk == 0) return;
+    while (in_chunk < kTbBlocksPerChunk) { if (sweep) noop_sweep_block(); else open_block(); }
+    H.stream.resize(H.stream.size() + 4, 0u); H.wsrc.resize(H.wsrc.size() + 4, kNone);
+    in_chunk = 0; last_target = kNone;
+  };
   std::vector<uint16_t> order;
   std::vector<uint32_t> ts;
   for (uint32_t tl = 0; tl < H.ntiles; ++tl) {
@@ -159,7 +227,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
       std::sort(idx, idx + 3, [&](int x, int y) { return (mx[x] - mn[x]) > (mx[y] - mn[y]) || ((mx[x] - mn[x]) == (mx[y] - mn[y]) && x < y); });
       a0 = std::min(idx[0], idx[1]); a1 = std::max(idx[0], idx[1]);
     }
-    W.sweep_off = (uint32_t)H.recs.size();
+    W.sweep_off = (uint32_t)(H.stream.size() / kTbChunk);
     static const float dirs[4][2] = { { 1, 1 }, { -1, 1 }, { -1, -1 }, { 1, -1 } };
     for (int o = 0; o < 4; ++o) {
       order.resize(W.nv);
@@ -168,30 +236,47 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
         const float* px = &xyz[3 * (size_t)H.verts[W.v0 + x]]; const float* py = &xyz[3 * (size_t)H.verts[W.v0 + y]];
         return dirs[o][0] * px[a0] + dirs[o][1] * px[a1] < dirs[o][0] * py[a0] + dirs[o][1] * py[a1];
       });
-      uint32_t blocks = 0;
+      const size_t first = H.stream.size() / kTbChunk;
       for (uint32_t i = 0; i < W.nv; ++i) {
         const uint32_t y = order[i], v = H.verts[W.v0 + y];
-        uint32_t in_block = 0, hdr = 0;
+        uint32_t n = 0; size_t at = 0;
         for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
           const uint32_t u = t.nbr_u[k];
           if (H.vert_tile[u] != tl) continue;
-          if (in_block == 0) { hdr = (uint32_t)H.recs.size(); push(y * kRow, 0, kNone); ++blocks; }
-          push(H.vert_local[u] * kRow, kTbInfBits, k);
-          if (++in_block == 7) { H.recs[hdr].b = 7; in_block = 0; }
+          if (n == 0) {                                              // new block: every slot "target, +inf" until filled
+            if (in_chunk != kTbBlocksPerChunk && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
+            at = open_block();
+            last_target = y;
+            const uint32_t yo = y * kRow;
+            H.stream[at] = yo | (yo << 16); H.stream[at + 1] = H.stream[at + 2] = H.stream[at + 3] = yo | (yo << 16);
+            for (int q = 4; q <= 10; ++q) H.stream[at + q] = kTbInfBits;
+          }
+          const uint32_t so = H.vert_local[u] * kRow;
+          const uint32_t slot = n + 1;                               // offsets: slot 0 = target, 1..7 = sources
+          uint32_t& d = H.stream[at + slot / 2];
+          d = (slot & 1u) ? ((d & 0x0000FFFFu) | (so << 16)) : ((d & 0xFFFF0000u) | so);
+          H.wsrc[at + 4 + n] = k;
+          if (++n == 7) n = 0;
         }
-        if (in_block) { H.recs[hdr].b = in_block; for (; in_block < 7; ++in_block) push(y * kRow, kTbInfBits, kNone); }
       }
-      if (o == 0) W.sweep_blocks = blocks;
-      else if (blocks != W.sweep_blocks) throw std::logic_error("tile-batch engine: sweep orders differ in size");
+      close_chunk(true);
+      const uint32_t chunks = (uint32_t)(H.stream.size() / kTbChunk - first);
+      if (o == 0) W.sweep_chunks = chunks;
+      else if (chunks != W.sweep_chunks) throw std::logic_error("tile-batch engine: sweep orders differ in size");
     }
-    // --- pre stream: ghost -> owned
+    // --- pre / post streams: one chunk per group of 4 ghosts (more when a group needs more than 5 blocks)
     auto emit_ghost_stream = [&](bool post) {
-      const uint32_t off = (uint32_t)H.recs.size();
-      uint32_t blocks = 0;
+      const size_t first = H.stream.size() / kTbChunk;
+      std::vector<size_t> chunk_at;                                  // dword index of every chunk of this stream
+      std::vector<uint32_t> chunk_group;
+      auto begin_chunk = [&](uint32_t group) {
+        close_chunk(false);
+        chunk_at.push_back(H.stream.size()); chunk_group.push_back(group);
+      };
       for (uint32_t h = 0; h < W.nh; ++h) {
         const uint32_t gv = g[h];
         const uint32_t owner = H.vert_tile[gv];
-        // edges between ghost gv and the owned vertices of this tile
+        if ((h & 3u) == 0u) begin_chunk(h / 4);
         struct E { uint32_t row, k; };
         std::vector<E> es;
         if (!post) {                                 // gv -> owned y: weight in row y
@@ -204,22 +289,32 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
           for (uint32_t k = t.row_ptr[gv]; k < t.row_ptr[gv + 1]; ++k) if (H.vert_tile[t.nbr_u[k]] == tl) es.push_back(E{ H.vert_local[t.nbr_u[k]], k });
         }
         const bool tile_end = (h + 1 == W.nh) || H.vert_tile[g[h + 1]] != owner;
-        const bool group_end = (h + 1 == W.nh) || ((h & 3u) == 3u);
         size_t i = 0;
         do {
-          const uint32_t n = (uint32_t)std::min<size_t>(3, es.size() - i);
+          if (in_chunk == kTbBlocksPerChunk) begin_chunk(h / 4);     // continuation chunk of the same group
+          const uint32_t n = (uint32_t)std::min<size_t>(kTbGhostEdges, es.size() - i);
           const bool last = i + n >= es.size();
-          uint32_t fl = h & 3u;
-          if (last) fl |= kTbGhostEnd | (group_end ? kTbGroupEnd : 0u) | (tile_end ? kTbTileEnd : 0u);
-          if (!post) push(fl, n, kNone); else push(fl | (n << 8), owner, kNone);
-          for (uint32_t q = 0; q < 3; ++q) {
-            if (q < n) push(es[i + q].row * kRow, kTbInfBits, es[i + q].k);
-            else push(0, kTbInfBits, kNone);
+          const size_t at = open_block();
+          uint32_t fl = (h & 3u) | (n << 8);
+          if (last) fl |= kTbGhostEnd | (tile_end ? kTbTileEnd : 0u);
+          H.stream[at] = fl;
+          for (uint32_t q = 0; q < n; ++q) {
+            const uint32_t ro = es[i + q].row * kRow;
+            uint32_t& d = H.stream[at + 1 + q / 2];
+            d = (q & 1u) ? (d | (ro << 16)) : (d | ro);
+            H.stream[at + 4 + q] = kTbInfBits; H.wsrc[at + 4 + q] = es[i + q].k;
           }
-          ++blocks; i += n;
+          if (post) H.stream[at + 9] = owner;
+          i += n;
         } while (i < es.size());
       }
-      if (!post) { W.pre_off = off; W.pre_blocks = blocks; } else { W.post_off = off; W.post_blocks = blocks; }
+      close_chunk(false);
+      for (size_t c = 0; c < chunk_at.size(); ++c) {
+        H.stream[chunk_at[c] + 60] = chunk_group[c];
+        H.stream[chunk_at[c] + 61] = c + 1 < chunk_at.size() ? chunk_group[c + 1] : 0u;
+      }
+      const uint32_t chunks = (uint32_t)(H.stream.size() / kTbChunk - first);
+      if (!post) { W.pre_off = (uint32_t)first; W.pre_chunks = chunks; } else { W.post_off = (uint32_t)first; W.post_chunks = chunks; }
     };
     emit_ghost_stream(false);
     emit_ghost_stream(true);
@@ -234,10 +329,10 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     }
     W.exp_n = (uint32_t)H.exps.size() - W.exp_off;
     while (H.exps.size() % 4) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // groups of 4 records = one 64-byte scalar load
-    while (H.recs.size() % 8) push(0, kTbInfBits, kNone);
   }
-  for (int k = 0; k < 16; ++k) push(0, kTbInfBits, kNone);            // tail slack for the block prefetch
+  H.stream.resize(H.stream.size() + 4 * kTbChunk, 0u); H.wsrc.resize(H.wsrc.size() + 4 * kTbChunk, kNone);   // tail slack for the chunk prefetch
   for (int k = 0; k < 4; ++k) H.exps.push_back(TbExp{ 0, 0, 0, 0 });
+  if (H.stream.size() / kTbChunk > 0xFFFFFFF0ull) throw std::invalid_argument("tile-batch engine: stream too large");
   return H;
 }
 

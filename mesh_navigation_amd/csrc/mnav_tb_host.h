@@ -19,9 +19,9 @@ void tb_free(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
   tb_free_batch(ctx);
-  for (void* p : { (void*)S.d_tiles, (void*)S.d_recs, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile })
+  for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile })
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
-  S.d_tiles = nullptr; S.d_recs = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr;
+  S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
 }
 
@@ -45,18 +45,18 @@ int tb_build(mnav_ctx* ctx)
     vaddr[v] = make_uint2(W.soff, (W.sl << 8) | H.vert_local[v]);
   }
   if (dev_upload(ctx, &S.d_tiles, H.tiles.data(), H.tiles.size())) return -1;
-  if (dev_upload(ctx, &S.d_recs, H.recs.data(), H.recs.size())) return -1;
+  if (dev_upload(ctx, &S.d_stream, H.stream.data(), H.stream.size())) return -1;
   if (dev_upload(ctx, &S.d_wsrc, H.wsrc.data(), H.wsrc.size())) return -1;
   if (dev_upload(ctx, &S.d_exps, H.exps.data(), H.exps.size())) return -1;
   if (dev_upload(ctx, &S.d_vaddr, vaddr.data(), vaddr.size())) return -1;
   if (dev_upload(ctx, &S.d_vert_tile, H.vert_tile.data(), H.vert_tile.size())) return -1;
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.recs.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
+  S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.stream.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
   S.vert_tile = std::move(H.vert_tile);
   S.built = true; S.w_valid = false;
   if (getenv("MNAV_VERBOSE"))
     fprintf(stderr, "[mnav] tile-batch engine: T %u, %u tiles, %.2f slots per vertex, max ghosts %u, %.1f MB of streams\n", S.T, S.ntiles,
-            ctx->V ? (double)S.S / ctx->V : 0.0, S.max_nh, (8.0 * S.nrec + 16.0 * S.nexp) / 1e6);
+            ctx->V ? (double)S.S / ctx->V : 0.0, S.max_nh, (4.0 * S.nrec + 16.0 * S.nexp) / 1e6);
   return 0;
 }
 
@@ -64,8 +64,7 @@ int tb_weights(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
   if (S.w_valid) return 0;
-  const uint32_t n = (uint32_t)S.nrec;
-  hipLaunchKernelGGL(k_tb_weights, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, S.d_wsrc, ctx->d_nbr, S.d_recs);
+  hipLaunchKernelGGL(k_tb_weights, dim3(4096), dim3(kBlock), 0, ctx->stream, S.nrec, S.d_wsrc, ctx->d_nbr, S.d_stream);
   HIPCHK(hipGetLastError());
   S.w_valid = true;
   return 0;
@@ -137,7 +136,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
   tb::Args A{};
-  A.tiles = S.d_tiles; A.recs = S.d_recs; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.NP = n; A.ntiles = S.ntiles;
+  A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.NP = n; A.ntiles = S.ntiles;
   A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl;
   A.cand[0] = S.cand[0]; A.cand[1] = S.cand[1]; A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
@@ -162,6 +161,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
   uint32_t per_cu = S.T == 64 ? 10u : 5u;                            // LDS: T x 256 bytes per wave, 160 KB per CU
+  if (const char* e = getenv("MNAV_TB_WAVES_PER_CU")) S.waves_per_cu = atoi(e);
   if (S.waves_per_cu > 0) per_cu = (uint32_t)S.waves_per_cu;
   const uint32_t waves = per_cu * (uint32_t)ncu;
   const int chunk = S.iters_per_replay & ~1;

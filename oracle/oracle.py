@@ -423,11 +423,12 @@ def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
         fin = w[np.isfinite(w)]
         band = float(fin.mean() * np.sqrt(tile)) if fin.size else 1.0
     dist = np.empty((n, V), np.float32)
-    stats = np.zeros(8, np.uint64)
+    stats = np.zeros(12, np.uint64)
     code = model_lib().tbm_run(V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(pos), int(tile), n, _p(sd), _p(tg),
                                float(offset), float(cost_limit), float(band), int(jacobi), _p(dist), _p(stats))
     return dict(code=code, dist=dist, iterations=int(stats[0]), activations=int(stats[1]), sweeps=int(stats[2]), wakes=int(stats[3]),
-                max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]))
+                max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]), items=int(stats[7]),
+                blocks_total=int(stats[8]), blocks_evaluated=int(stats[9]))
 
 
 def product_inflation_update(u1, u2, a, b, c, max_distance):

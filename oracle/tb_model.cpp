@@ -25,7 +25,8 @@ extern "C" {
 // jacobi: 1 = every activation of an iteration sees the slices as they were when the iteration started (what concurrent
 // waves may see at worst), 0 = in place, in item order.
 // stats_out: [0] iterations, [1] (tile, plan) activations, [2] sweeps summed over activations, [3] wake-ups, [4] max sweeps of
-// one activation, [5] tiles, [6] slots per plan
+// one item, [5] tiles, [6] slots per plan, [7] items (waves of <= 64 plans), [8] sweep blocks visited, [9] sweep blocks evaluated;
+// [2] counts sweeps per ITEM (the lanes of an item sweep in lockstep until no lane changes)
 uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx, const float* edge_weights,
                  const float* vertex_costs, const uint8_t* invalid, const float* xyz, uint32_t T, uint32_t n, const uint32_t* seeds,
                  const uint32_t* targets, double offset, double cost_limit, float band, int jacobi, float* dist_out, uint64_t* stats_out)
@@ -34,7 +35,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
   HostTb H = build_tb(topo, xyz, T);
-  for (size_t i = 0; i < H.recs.size(); ++i) if (H.wsrc[i] != kNone) H.recs[i].b = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
+  for (size_t i = 0; i < H.stream.size(); ++i) if (H.wsrc[i] != kNone) H.stream[i] = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
   const uint32_t NP = n, nt = H.ntiles;
   auto slot = [&](uint32_t t, uint32_t p, uint32_t i) { return (size_t)H.tiles[t].soff * NP + (size_t)p * H.tiles[t].sl + i; };
   std::vector<uint32_t> D((size_t)H.S * NP, kTbInfBits), Dsnap;
@@ -50,9 +51,9 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     for (uint32_t k = 0; k < W.exp_n; ++k) { const TbExp& e = H.exps[W.exp_off + k]; if (e.u == loc * 256u) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off] = 0u; }
     pend[(size_t)t * NP + p] = 0u; marr[0][p] = 0u; cand[0].push_back({ t, p });
   }
-  uint64_t iters = 0, acts = 0, sweeps_tot = 0, wakes = 0, max_sweeps = 0;
+  uint64_t iters = 0, acts = 0, sweeps_tot = 0, wakes = 0, max_sweeps = 0, items = 0, blocks_total = 0, blocks_eval = 0;
   std::vector<std::vector<uint16_t>> bucket(nt);
-  std::vector<uint32_t> lds(256 * 64 / 64);   // one lane's column: row offset / 256 -> value
+  std::vector<std::vector<uint32_t>> ldsv(64, std::vector<uint32_t>(256));   // per lane: row -> value
   for (int par = 0;; par ^= 1) {
     if (cand[par].empty()) break;
     ++iters;
@@ -78,84 +79,96 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     }
     if (jacobi) Dsnap = D;
     const std::vector<uint32_t>& Din = jacobi ? Dsnap : D;
-    // k_tb_items + k_tb_solve, one lane at a time
+    // k_tb_items + k_tb_solve: items of <= 64 plans of one tile, one plan per lane, the lanes in lockstep
     for (uint32_t t = 0; t < nt; ++t) {
       const TbTile& W = H.tiles[t];
-      for (uint16_t p16 : bucket[t]) {
-        const uint32_t p = p16;
-        ++acts;
-        const size_t sl = slot(t, p, 0);
-        for (uint32_t r = 0; r < T; ++r) lds[r] = Din[sl + r];
-        const size_t gs = sl + T;
-        // pre
-        {
-          uint32_t b = 0, g4 = 0;
-          while (b < W.pre_blocks) {
-            const uint32_t* G = &Din[gs + 4 * (size_t)g4++];
-            uint32_t fl;
-            do {
-              const TbRec* K = &H.recs[W.pre_off + 4 * (size_t)b++];
-              fl = K[0].a;
-              const uint32_t j = fl & 3u, cnt = K[0].b;
-              const float g = u2f(G[j]);
-              for (uint32_t k = 1; k <= 3; ++k) if (k <= cnt) {
-                const uint32_t row = K[k].a / 256u;
-                const uint32_t nd = f2u(g + u2f(K[k].b));
+      for (size_t start = 0; start < bucket[t].size(); start += 64) {
+        const uint32_t cnt_l = (uint32_t)std::min<size_t>(64, bucket[t].size() - start);
+        ++items; acts += cnt_l;
+        auto half = [](uint32_t pr, uint32_t k) { return (k & 1u) ? (pr >> 16) : (pr & 0xFFFFu); };
+        for (uint32_t l = 0; l < cnt_l; ++l) {
+          const uint32_t p = bucket[t][start + l];
+          uint32_t* lds = ldsv[l].data();
+          const size_t sl = slot(t, p, 0), gs = sl + T;
+          for (uint32_t r = 0; r < T; ++r) lds[r] = Din[sl + r];
+          // pre
+          for (uint32_t c = 0; c < W.pre_chunks; ++c) {
+            const uint32_t* cur = &H.stream[((size_t)W.pre_off + c) * kTbChunk];
+            const uint32_t* G = &Din[gs + 4 * (size_t)cur[60]];
+            for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+              const uint32_t* K = cur + kTbBlock * j;
+              const uint32_t hd = K[0], cnt = (hd >> 8) & 7u;
+              if (!cnt) continue;
+              const float g = u2f(G[hd & 3u]);
+              for (uint32_t k = 0; k < kTbGhostEdges; ++k) if (k < cnt) {
+                const uint32_t row = half(K[1 + k / 2], k) / 256u;
+                const uint32_t nd = f2u(g + u2f(K[4 + k]));
                 if (nd < (lds[row] & 0x7fffffffu)) lds[row] = nd | kTbDirty;
               }
-            } while (!(fl & kTbGroupEnd));
+            }
           }
         }
-        // sweeps
+        // sweeps, all lanes in lockstep until a sweep changes nothing in any of them
         uint32_t sweep = 0;
         for (;;) {
-          const TbRec* B = &H.recs[W.sweep_off + (size_t)(sweep & 3u) * W.sweep_blocks * 8u];
-          bool any = false;
-          for (uint32_t b = 0; b < W.sweep_blocks; ++b) {
-            const TbRec* K = B + 8 * (size_t)b;
-            const uint32_t y = K[0].a / 256u;
-            const uint32_t acc0 = lds[y] & 0x7fffffffu;
-            uint32_t acc = acc0;
-            for (int k = 1; k <= 7; ++k) acc = std::min(acc, fabs_bits_add(lds[K[k].a / 256u], K[k].b));
-            if (acc < acc0) { lds[y] = acc | kTbDirty; any = true; }
+          const uint32_t* B = &H.stream[((size_t)W.sweep_off + (size_t)(sweep & 3u) * W.sweep_chunks) * kTbChunk];
+          uint32_t chg_cur = 0;
+          for (uint32_t c = 0; c < W.sweep_chunks; ++c) {
+            const uint32_t* C = B + (size_t)c * kTbChunk;
+            blocks_total += kTbBlocksPerChunk;
+            for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+              const uint32_t* K = C + kTbBlock * j;
+              ++blocks_eval;
+              const uint32_t y = (K[0] & 0xFFFFu) / 256u;
+              for (uint32_t l = 0; l < cnt_l; ++l) {
+                uint32_t* lds = ldsv[l].data();
+                const uint32_t acc0 = lds[y] & 0x7fffffffu;
+                uint32_t acc = acc0;
+                for (uint32_t k = 0; k < 7; ++k) acc = std::min(acc, fabs_bits_add(lds[half(K[(k + 1) / 2], k + 1) / 256u], K[4 + k]));
+                if (acc < acc0) { lds[y] = acc | kTbDirty; chg_cur |= 1u << (y * 32u / T); }
+              }
+            }
           }
           ++sweep;
-          if (!any) break;
+          if (!chg_cur) break;
           if (sweep >= 16u * T) return 60;
         }
         sweeps_tot += sweep; max_sweeps = std::max<uint64_t>(max_sweeps, sweep);
-        // write back
-        for (uint32_t r = 0; r < T; ++r) if (lds[r] & kTbDirty) D[sl + r] = lds[r] & 0x7fffffffu;
-        // post
-        {
-          uint32_t b = 0, g4 = 0, cnd = kTbInfBits, best = kTbInfBits;
-          while (b < W.post_blocks) {
-            const uint32_t* G = &Din[gs + 4 * (size_t)g4++];
-            uint32_t fl;
-            do {
-              const TbRec* K = &H.recs[W.post_off + 4 * (size_t)b++];
-              fl = K[0].a;
-              const uint32_t cnt = (fl >> 8) & 3u;
-              for (uint32_t k = 1; k <= 3; ++k) if (k <= cnt) cnd = std::min(cnd, fabs_bits_add(lds[K[k].a / 256u], K[k].b));
-              if (fl & kTbGhostEnd) { if (cnd < G[fl & 3u]) best = std::min(best, cnd); cnd = kTbInfBits; }
-              if (fl & kTbTileEnd) {
+        for (uint32_t l = 0; l < cnt_l; ++l) {
+          const uint32_t p = bucket[t][start + l];
+          uint32_t* lds = ldsv[l].data();
+          const size_t sl = slot(t, p, 0), gs = sl + T;
+          // write back
+          for (uint32_t r = 0; r < T; ++r) if (lds[r] & kTbDirty) D[sl + r] = lds[r] & 0x7fffffffu;
+          // post
+          uint32_t cnd = kTbInfBits, best = kTbInfBits;
+          for (uint32_t c = 0; c < W.post_chunks; ++c) {
+            const uint32_t* cur = &H.stream[((size_t)W.post_off + c) * kTbChunk];
+            const uint32_t* G = &Din[gs + 4 * (size_t)cur[60]];
+            for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+              const uint32_t* K = cur + kTbBlock * j;
+              const uint32_t hd = K[0], cnt = (hd >> 8) & 7u;
+              if (!cnt) continue;
+              for (uint32_t k = 0; k < kTbGhostEdges; ++k) if (k < cnt) cnd = std::min(cnd, fabs_bits_add(lds[half(K[1 + k / 2], k) / 256u], K[4 + k]));
+              if (hd & kTbGhostEnd) { if (cnd < G[hd & 3u]) best = std::min(best, cnd); cnd = kTbInfBits; }
+              if (hd & kTbTileEnd) {
                 if (best != kTbInfBits) {
-                  const size_t pi = (size_t)K[0].b * NP + p;
+                  const size_t pi = (size_t)K[9] * NP + p;
                   const uint32_t old = pend[pi];
                   if (best < old) { pend[pi] = best; marr[par ^ 1][p] = std::min(marr[par ^ 1][p], best); }
-                  if (old == kTbInfBits) cand[par ^ 1].push_back({ K[0].b, p });
+                  if (old == kTbInfBits) cand[par ^ 1].push_back({ K[9], p });
                   ++wakes;
                 }
                 best = kTbInfBits;
               }
-            } while (!(fl & kTbGroupEnd));
+            }
           }
-        }
-        // export
-        for (uint32_t k = 0; k < W.exp_n; ++k) {
-          const TbExp& e = H.exps[W.exp_off + k];
-          const uint32_t v = lds[e.u / 256u];
-          if (v & kTbDirty) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off] = v & 0x7fffffffu;
+          // export
+          for (uint32_t k = 0; k < W.exp_n; ++k) {
+            const TbExp& e = H.exps[W.exp_off + k];
+            const uint32_t v = lds[e.u / 256u];
+            if (v & kTbDirty) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off] = v & 0x7fffffffu;
+          }
         }
       }
       bucket[t].clear();
@@ -164,7 +177,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   }
   for (uint32_t p = 0; p < NP; ++p)
     for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(D[slot(H.vert_tile[v], p, H.vert_local[v])]);
-  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; }
+  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; stats_out[7] = items; stats_out[8] = blocks_total; stats_out[9] = blocks_eval; }
   return 0;
 }
 

@@ -36,6 +36,14 @@ def main():
             if r:
                 res.append(dict(wall_ms=dt * 1e3, prop_ms=st["ms_propagation"], init_ms=st["ms_init"], path_ms=st["ms_path"], total_ms=st["ms_total"],
                                 kern_ms=st["ms_step_kernels"], settled=st["settled"], algo=st["algorithmic_bytes"]))
+        L = capi.load()
+        if hasattr(L, "mnav_debug_tb_timing"):
+            import ctypes
+            tt = (ctypes.c_ulonglong * 8)()
+            L.mnav_debug_tb_timing(tt)
+            tot = float(sum(tt)) or 1.0
+            names = ["fetch", "load", "pre", "sweeps", "writeback", "post", "export", "-"]
+            print("phase cycles:", {n: "%.1f%%" % (100.0 * tt[i] / tot) for i, n in enumerate(names)}, "total Gcycles %.2f" % (tot / 1e9), file=sys.stderr)
         best = min(res, key=lambda x: x["wall_ms"])
         best["plans_per_s"] = B / best["wall_ms"] * 1e3
         best["gbps_prop"] = best["algo"] / best["prop_ms"] / 1e6
