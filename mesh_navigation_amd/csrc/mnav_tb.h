@@ -28,8 +28,8 @@ namespace {
 namespace tb {
 
 // Tile headers and export records are read through the constant address space (uniform addresses there are always
-// scalar loads); the edge streams come in 256-byte chunks through the vector memory path, one dword per lane, and are
-// picked apart with v_readlane (mnav_tb_build.h).
+// scalar loads); the edge streams come in 256-byte chunks through the vector memory path, one dword per lane, are parked
+// in an LDS staging buffer and read back with uniform-address (broadcast) ds_read_b128 (mnav_tb_build.h).
 #define MNAV_CONST __attribute__((address_space(4)))
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));   // 4 export records / a tile header
 typedef const MNAV_CONST u32x16* cblk8_t;
@@ -68,8 +68,31 @@ __device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_
 
 __device__ __forceinline__ uint32_t ldsr(uint32_t off) { return *(lds_u32_t)(uintptr_t)off; }
 __device__ __forceinline__ void ldsw(uint32_t off, uint32_t v) { *(lds_u32_t)(uintptr_t)off = v; }
+typedef __attribute__((address_space(3))) u32x4* lds_u32x4_t;
+__device__ __forceinline__ u32x4 ldsr4(uint32_t off) { return *(lds_u32x4_t)(uintptr_t)off; }   // uniform address: broadcast
+
+// Stream reader: chunk c of a stream lives in staging buffer (c & 1); the chunk after next is in flight from memory.
+struct Stream {
+  MNAV_GLOBAL const uint32_t* st; uint32_t stage, lane4s, c1; uint32_t c;
+  // stage = LDS byte address of the two 256-byte staging buffers, lane4s = stage + 4 * lane
+  __device__ __forceinline__ void begin(MNAV_GLOBAL const uint32_t* s, uint32_t stage_, uint32_t lane)
+  {
+    st = s; stage = stage_; lane4s = stage_ + 4u * lane; c = 0;
+    ldsw(lane4s, st[lane]);                                          // chunk 0 -> buffer 0
+    c1 = st[kTbChunk + lane];                                        // chunk 1 in flight
+  }
+  // makes chunk c readable at the returned LDS address and moves on (call once per chunk, in order)
+  __device__ __forceinline__ uint32_t next(uint32_t lane)
+  {
+    const uint32_t nxt = c1;
+    c1 = st[(size_t)(c + 2) * kTbChunk + lane];
+    ldsw(lane4s + (((c + 1) & 1u) << 8), nxt);                       // LDS executes in order: the buffer's last readers are done
+    const uint32_t at = stage + ((c & 1u) << 8);
+    ++c;
+    return at;
+  }
+};
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-#define TB_RL(v, i) ((uint32_t)__builtin_amdgcn_readlane((int)(v), (i)))   // dword i of the chunk held in v (one dword per lane)
 
 // wave-aggregated append of the pair (t, p) of every lane with `want`
 __device__ __forceinline__ void append_pair(bool want, uint32_t t, uint32_t p, uint2* list, uint32_t* count, int lane)
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_filter(tb::Args A, int par)
         A.bucket[(size_t)e.x * A.NP + slot] = (uint16_t)e.y;
       } else {
         carry = true;
-        atomicMin(&A.marr[par ^ 1][e.y], pb);
+        if (pb < A.marr[par ^ 1][e.y]) atomicMin(&A.marr[par ^ 1][e.y], pb);   // plain look first (see k_tb_solve)
       }
     }
     tb::append_pair(carry, e.x, e.y, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
@@ -205,53 +228,67 @@ __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
 // The solve: one wave per work item (tile, <= 64 plans).
 // ---------------------------------------------------------------------------------------------
 // One Gauss-Seidel sweep: every block relaxes its target row from up to 7 source rows (dijkstra :331), in stream order.
-// Software pipeline: the LDS reads of block j+1 are issued before block j's result is written, so a block that reads
-// its predecessor's target sees the value of the previous sweep -- legal (any relaxation order reaches the same fixed
-// point), and the LDS latency of one block hides behind the arithmetic of the other.  No branch in the loop body: the
-// target row is rewritten unconditionally (old bits when nothing improved).
-struct TbBlk { uint32_t ya, raw, v[7], w[7]; };
-__device__ __forceinline__ TbBlk tb_issue(uint32_t cur, int o, uint32_t lane4)
+// No branch in the loop body: the target row is rewritten unconditionally (old bits when nothing improved).
+// MNAV_TB_PIPELINE (tried, off): the LDS reads of block j+1 issued before block j's result is written, so that one
+// block's LDS latency hides behind the other's arithmetic -- legal (any relaxation order reaches the same fixed point;
+// the builder never puts the same target into adjacent blocks), but a block that reads its predecessor's target then
+// sees the value of the previous sweep: +24 % sweeps, 303 vs 266 ms per 5120-plan batch on C2.
+struct TbBlk { uint32_t ya, raw, v[7]; u32x4 w0, w1; };
+__device__ __forceinline__ TbBlk tb_issue(uint32_t at, uint32_t lane4)
 {
   TbBlk B;
-  const uint32_t a0 = TB_RL(cur, o), a1 = TB_RL(cur, o + 1), a2 = TB_RL(cur, o + 2), a3 = TB_RL(cur, o + 3);
-  B.ya = (a0 & 0xFFFFu) + lane4;
+  const u32x4 o0 = tb::ldsr4(at), o1 = tb::ldsr4(at + 16);
+  B.w0 = tb::ldsr4(at + 32); B.w1 = tb::ldsr4(at + 48);
+  B.ya = o0.x + lane4;
   B.raw = tb::ldsr(B.ya);
-  B.v[0] = tb::ldsr((a0 >> 16) + lane4); B.v[1] = tb::ldsr((a1 & 0xFFFFu) + lane4); B.v[2] = tb::ldsr((a1 >> 16) + lane4);
-  B.v[3] = tb::ldsr((a2 & 0xFFFFu) + lane4); B.v[4] = tb::ldsr((a2 >> 16) + lane4); B.v[5] = tb::ldsr((a3 & 0xFFFFu) + lane4);
-  B.v[6] = tb::ldsr((a3 >> 16) + lane4);
-#pragma unroll
-  for (int k = 0; k < 7; ++k) B.w[k] = TB_RL(cur, o + 4 + k);
+  B.v[0] = tb::ldsr(o0.y + lane4); B.v[1] = tb::ldsr(o0.z + lane4); B.v[2] = tb::ldsr(o0.w + lane4);
+  B.v[3] = tb::ldsr(o1.x + lane4); B.v[4] = tb::ldsr(o1.y + lane4); B.v[5] = tb::ldsr(o1.z + lane4); B.v[6] = tb::ldsr(o1.w + lane4);
   return B;
 }
 __device__ __forceinline__ bool tb_retire(const TbBlk& B)
 {
   const uint32_t acc0 = B.raw & 0x7fffffffu;
-  uint32_t t[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) t[k] = f2u(fabsf(u2f(B.v[k])) + u2f(B.w[k]));
-  uint32_t acc = min(min(acc0, t[0]), t[1]);
-  acc = min(min(acc, t[2]), t[3]); acc = min(min(acc, t[4]), t[5]); acc = min(acc, t[6]);
+  const uint32_t t0 = f2u(fabsf(u2f(B.v[0])) + u2f(B.w0.x)), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(B.w0.y));
+  const uint32_t t2 = f2u(fabsf(u2f(B.v[2])) + u2f(B.w0.z)), t3 = f2u(fabsf(u2f(B.v[3])) + u2f(B.w0.w));
+  const uint32_t t4 = f2u(fabsf(u2f(B.v[4])) + u2f(B.w1.x)), t5 = f2u(fabsf(u2f(B.v[5])) + u2f(B.w1.y));
+  const uint32_t t6 = f2u(fabsf(u2f(B.v[6])) + u2f(B.w1.z));
+  uint32_t acc = min(min(acc0, t0), t1);
+  acc = min(min(acc, t2), t3); acc = min(min(acc, t4), t5); acc = min(acc, t6);
   const bool ch = acc < acc0;
   tb::ldsw(B.ya, ch ? (acc | kTbDirty) : B.raw);
   return ch;
 }
 
 template <int T>
-__device__ __forceinline__ unsigned long long tb_sweep(MNAV_GLOBAL const uint32_t* st, uint32_t nch, uint32_t lane, uint32_t lane4)
+__device__ __forceinline__ unsigned long long tb_sweep(MNAV_GLOBAL const uint32_t* st, uint32_t nch, uint32_t stage, uint32_t lane, uint32_t lane4)
 {
   unsigned long long any = 0ull;
-  uint32_t c0 = st[lane], c1 = st[kTbChunk + lane];                 // two chunks in flight behind vmcnt
+  tb::Stream S; S.begin(st, stage, lane);
   for (uint32_t c = 0; c < nch; ++c) {
-    const uint32_t cur = c0;
-    c0 = c1; c1 = st[(size_t)(c + 2) * kTbChunk + lane];
-#ifdef MNAV_TB_NO_PIPELINE
+    const uint32_t at = S.next(lane);
+#ifndef MNAV_TB_PIPELINE
+    // all 16 descriptor reads of the chunk first: one LDS round trip per chunk instead of one per block
+    u32x4 d[kTbBlocksPerChunk][4];
 #pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) { const TbBlk B = tb_issue(cur, (int)kTbBlock * j, lane4); any |= __ballot(tb_retire(B)); }
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(at + 64 * j + 16 * q);
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+      TbBlk B;
+      B.w0 = d[j][2]; B.w1 = d[j][3];
+      B.ya = d[j][0].x + lane4;
+      B.raw = tb::ldsr(B.ya);
+      B.v[0] = tb::ldsr(d[j][0].y + lane4); B.v[1] = tb::ldsr(d[j][0].z + lane4); B.v[2] = tb::ldsr(d[j][0].w + lane4);
+      B.v[3] = tb::ldsr(d[j][1].x + lane4); B.v[4] = tb::ldsr(d[j][1].y + lane4); B.v[5] = tb::ldsr(d[j][1].z + lane4);
+      B.v[6] = tb::ldsr(d[j][1].w + lane4);
+      any |= __ballot(tb_retire(B));
+    }
 #else
-    TbBlk A = tb_issue(cur, 0, lane4);
+    TbBlk A = tb_issue(at, lane4);
 #pragma unroll
     for (int j = 1; j < (int)kTbBlocksPerChunk; ++j) {
-      const TbBlk B = tb_issue(cur, (int)kTbBlock * j, lane4);
+      const TbBlk B = tb_issue(at + 64 * j, lane4);
       any |= __ballot(tb_retire(A));
       A = B;
     }
@@ -274,9 +311,10 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
 #ifdef MNAV_TB_TIMING
   unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
 #endif
-  __shared__ uint32_t lds[T * 64];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + 2 * kTbChunk];   // [row][lane] + two stream staging buffers
   const int lane = threadIdx.x;
   const uint32_t lane4 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * lane;
+  const uint32_t stage = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * (T * 64);
   const uint32_t NP = A.NP;
   const tb::cblk8_t tiles = (tb::cblk8_t)(uintptr_t)A.tiles;
   const uint32_t n_items = A.ctl->n_items;
@@ -317,26 +355,29 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
       TB_STAMP(1);
       // ---- ghosts -> owned (the ghosts are constant during the activation)
       if (W.pre_chunks) {
-        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + (size_t)W.pre_off * kTbChunk;
-        uint32_t c0 = st[lane], c1 = st[kTbChunk + lane];
-        u32x4 G = g4p[TB_RL(c0, 60)];
+        tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.pre_off * kTbChunk, stage, (uint32_t)lane);
+        u32x4 G = { 0u, 0u, 0u, 0u };
         for (uint32_t c = 0; c < W.pre_chunks; ++c) {
-          const uint32_t cur = c0;
-          c0 = c1; c1 = st[(size_t)(c + 2) * kTbChunk + lane];
-          const u32x4 Gn = g4p[TB_RL(cur, 61)];                       // the next chunk's ghost values (group 0 after the last one)
+          const uint32_t cur_at = S.next((uint32_t)lane);             // chunk c readable, chunk c + 1 staged behind it
+          const u32x4 hd0 = tb::ldsr4(cur_at), q3 = tb::ldsr4(cur_at + 48);   // block 0: header + chunk fields (d12 group, d13 next group)
+          if (c == 0) G = g4p[q3.x];
+          const u32x4 Gn = g4p[q3.y];                                 // the next chunk's ghost values (group 0 after the last one)
 #pragma unroll
           for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-            const int o = (int)kTbBlock * j;
-            const uint32_t hd = TB_RL(cur, o), n = (hd >> 8) & 7u;
+            const uint32_t b = cur_at + 64 * j;
+            const u32x4 h = (j == 0) ? hd0 : tb::ldsr4(b);
+            const uint32_t n = (h.x >> 8) & 7u;
             if (n) {
-              const uint32_t jj = hd & 3u;
+              const uint32_t jj = h.x & 3u;
               const float g = u2f(jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w);
+              const u32x4 o1 = tb::ldsr4(b + 16), w2 = tb::ldsr4(b + 32);   // d4..d7, d8..d11
+              const uint32_t offs[5] = { h.y, h.z, h.w, o1.x, o1.y };
+              const uint32_t ws[5] = { o1.z, o1.w, w2.x, w2.y, w2.z };
 #pragma unroll
               for (int k = 0; k < (int)kTbGhostEdges; ++k) {
                 if ((uint32_t)k < n) {
-                  const uint32_t pr = TB_RL(cur, o + 1 + k / 2);
-                  const uint32_t a = ((k & 1) ? (pr >> 16) : (pr & 0xFFFFu)) + lane4;
-                  const uint32_t nd = f2u(g + u2f(TB_RL(cur, o + 4 + k)));
+                  const uint32_t a = offs[k] + lane4;
+                  const uint32_t nd = f2u(g + u2f(ws[k]));
                   const uint32_t raw = tb::ldsr(a);
                   tb::ldsw(a, nd < (raw & 0x7fffffffu) ? (nd | kTbDirty) : raw);
                 }
@@ -351,7 +392,7 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
       uint32_t sweep = 0;
       for (;;) {
         MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + ((size_t)W.sweep_off + (size_t)(sweep & 3u) * W.sweep_chunks) * kTbChunk;
-        const unsigned long long any = tb_sweep<T>(st, W.sweep_chunks, (uint32_t)lane, lane4);
+        const unsigned long long any = tb_sweep<T>(st, W.sweep_chunks, stage, (uint32_t)lane, lane4);
         ++sweep;
         if (any == 0ull) break;
         if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
@@ -375,27 +416,26 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
       TB_STAMP(4);
       // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex
       if (W.post_chunks) {
-        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + (size_t)W.post_off * kTbChunk;
-        uint32_t c0 = st[lane], c1 = st[kTbChunk + lane];
-        u32x4 G = g4p[TB_RL(c0, 60)];
+        tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.post_off * kTbChunk, stage, (uint32_t)lane);
+        u32x4 G = { 0u, 0u, 0u, 0u };
         uint32_t cand = kTbInfBits, best = kTbInfBits;
         for (uint32_t c = 0; c < W.post_chunks; ++c) {
-          const uint32_t cur = c0;
-          c0 = c1; c1 = st[(size_t)(c + 2) * kTbChunk + lane];
-          const u32x4 Gn = g4p[TB_RL(cur, 61)];
+          const uint32_t cur_at = S.next((uint32_t)lane);
+          const u32x4 hd0 = tb::ldsr4(cur_at), q3 = tb::ldsr4(cur_at + 48);
+          if (c == 0) G = g4p[q3.x];
+          const u32x4 Gn = g4p[q3.y];
 #pragma unroll
           for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-            const int o = (int)kTbBlock * j;
-            const uint32_t hd = TB_RL(cur, o), n = (hd >> 8) & 7u;
+            const uint32_t b = cur_at + 64 * j;
+            const u32x4 h = (j == 0) ? hd0 : tb::ldsr4(b);
+            const uint32_t hd = h.x, n = (hd >> 8) & 7u;
             if (n) {
+              const u32x4 o1 = tb::ldsr4(b + 16), w2 = tb::ldsr4(b + 32);
+              const uint32_t offs[5] = { h.y, h.z, h.w, o1.x, o1.y };
+              const uint32_t ws[5] = { o1.z, o1.w, w2.x, w2.y, w2.z };
 #pragma unroll
-              for (int k = 0; k < (int)kTbGhostEdges; ++k) {
-                if ((uint32_t)k < n) {
-                  const uint32_t pr = TB_RL(cur, o + 1 + k / 2);
-                  const uint32_t a = ((k & 1) ? (pr >> 16) : (pr & 0xFFFFu)) + lane4;
-                  cand = min(cand, f2u(fabsf(u2f(tb::ldsr(a))) + u2f(TB_RL(cur, o + 4 + k))));
-                }
-              }
+              for (int k = 0; k < (int)kTbGhostEdges; ++k)
+                if ((uint32_t)k < n) cand = min(cand, f2u(fabsf(u2f(tb::ldsr(offs[k] + lane4))) + u2f(ws[k])));
               if (hd & kTbGhostEnd) {
                 const uint32_t jj = hd & 3u;
                 const uint32_t g = jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w;
@@ -403,13 +443,19 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
                 cand = kTbInfBits;
               }
               if (hd & kTbTileEnd) {
-                const uint32_t t2 = TB_RL(cur, o + 9);
+                const uint32_t t2 = tb::rfl(w2.w);                    // d11: owner tile (uniform)
                 bool first = false;
                 if (active && best != kTbInfBits) {
-                  const uint32_t old = atomicMin(&A.pend[(size_t)t2 * NP + p], best);
-                  if (best < old) atomicMin(&A.marr[par ^ 1][p], best);
-                  first = old == kTbInfBits;
-                  ++my_wakes;
+                  // Look before asking: within this launch a wake-up value only ever decreases, so a (possibly stale) plain load
+                  // is an upper bound of the true value: if it already is <= ours the wake-up changes nothing.
+                  MNAV_GLOBAL uint32_t* pw = as_global(A.pend) + ((size_t)t2 * NP + p);
+                  if (best < *pw) {
+                    const uint32_t old = atomicMin((uint32_t*)pw, best);
+                    first = old == kTbInfBits;
+                    MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
+                    if (best < old && best < *pm) atomicMin((uint32_t*)pm, best);
+                    ++my_wakes;
+                  }
                 }
                 tb::append_pair(first, t2, p, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
                 best = kTbInfBits;

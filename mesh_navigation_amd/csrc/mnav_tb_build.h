@@ -44,21 +44,23 @@ struct TbTile {
 };
 static_assert(sizeof(TbTile) == 64, "TbTile is read as one 64-byte scalar load");
 
-// Streams.  The graph of a tile is stored as CHUNKS of 64 dwords (256 bytes): a wave reads a chunk with ONE coalesced
-// vector load (lane l holds dword l; the next chunks are prefetched behind the vector-memory counter, which -- unlike
-// scalar loads -- does not share a wait counter with the LDS), and picks the dwords out with v_readlane into SGPRs.
-// A chunk holds 5 BLOCKS of 12 dwords; dwords 60..63 are chunk-level fields.  A "row" is a local vertex; offsets are
-// the row's LDS byte offset (row * 256: 64 lanes x 4 B), 16 bits each, two per dword (lo | hi << 16).
-//   sweep block:  d0 = target | src0 << 16, d1 = src1 | src2 << 16, d2 = src3 | src4 << 16, d3 = src5 | src6 << 16,
-//                 d4..d10 = weight bits of src0..src6 (unused slots: src = target, weight = +inf), d11 = 0
-//   pre block:    d0 = flags | j | n << 8 (n = edges, 0 = empty block), d1 = tgt0 | tgt1 << 16, d2 = tgt2 | tgt3 << 16,
-//                 d3 = tgt4, d4..d8 = weight bits: the ghost -> owned edges of ghost 4 * group + j
-//   post block:   as pre with source rows (owned -> ghost edges), d9 = owner tile of the ghost
-//   pre / post chunk fields: d60 = this chunk's ghost group (which 16-byte quad of the slice's ghost part), d61 = the
-//                 NEXT chunk's group (prefetch)
+// Streams.  The graph of a tile is stored as CHUNKS of 64 dwords (256 bytes).  A wave reads a chunk with ONE coalesced
+// vector load (lane l holds dword l; the next chunks are prefetched behind the vector-memory counter), parks it in a
+// 256-byte LDS staging buffer, and every lane then reads the dwords it needs back with uniform-address ds_read_b128:
+// an LDS broadcast delivers a wave-uniform value to all lanes at a quarter of the cost of a v_readlane -> SGPR hop
+// (measured: ~30 cycles per readlane'd value against ~8 per broadcast dword), and scalar loads would share the LDS's
+// wait counter and miss the scalar cache on every block (each order's stream is read once per sweep).
+// A chunk holds 4 BLOCKS of 16 dwords.  A "row" is a local vertex; offsets are the row's LDS byte offset (row * 256:
+// 64 lanes x 4 B).
+//   sweep block:  d0 = target offset, d1..d7 = source offsets, d8..d14 = weight bits of the sources (unused slots:
+//                 source = target, weight = +inf), d15 = 0
+//   pre block:    d0 = flags | j | n << 8 (n = edges, 0 = empty block), d1..d5 = target offsets, d6..d10 = weight bits:
+//                 the ghost -> owned edges of ghost 4 * group + j;  in block 0 of a chunk d12 = the chunk's ghost group
+//                 (which 16-byte quad of the slice's ghost part), d13 = the NEXT chunk's group (prefetch)
+//   post block:   as pre with source offsets (owned -> ghost edges), d11 = owner tile of the ghost
 constexpr uint32_t kTbChunk = 64;           // dwords per chunk
-constexpr uint32_t kTbBlock = 12;           // dwords per block
-constexpr uint32_t kTbBlocksPerChunk = 5;
+constexpr uint32_t kTbBlock = 16;           // dwords per block
+constexpr uint32_t kTbBlocksPerChunk = 4;
 constexpr uint32_t kTbGhostEdges = 5;       // edges per pre / post block
 constexpr uint32_t kTbGhostEnd = 1u << 4;   // last block of this ghost (post: compare the candidate with the ghost value)
 constexpr uint32_t kTbTileEnd = 1u << 6;    // last ghost owned by this neighbour tile (post: emit the wake-up)
@@ -185,31 +187,31 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     return (uint32_t)(it - g.begin());
   };
   const uint32_t kRow = 256;   // bytes per LDS row
-  // chunk writer: blocks are appended to the open chunk, a full (or closed) chunk is padded to 64 dwords
+  // chunk writer: blocks are appended to the open chunk, a closed chunk is padded with empty blocks
   uint32_t in_chunk = 0;
   // Every sweep block rewrites its target row (with the bits it read when nothing improved), and the kernel may have the
   // reads of block j+1 in flight before block j's result is written (MNAV_TB_PIPELINE).  Two ADJACENT blocks of a chunk
   // must therefore never have the same target.  `last_target` = target row of the previous block of the open chunk.
   uint32_t last_target = kNone;
   auto open_block = [&]() -> size_t {                                // returns the dword index of the new block
-    if (in_chunk == kTbBlocksPerChunk) { H.stream.resize(H.stream.size() + 4, 0u); H.wsrc.resize(H.wsrc.size() + 4, kNone); in_chunk = 0; last_target = kNone; }
+    if (in_chunk == kTbBlocksPerChunk) { in_chunk = 0; last_target = kNone; }
     const size_t at = H.stream.size();
     H.stream.resize(at + kTbBlock, 0u); H.wsrc.resize(at + kTbBlock, kNone);
     ++in_chunk;
     return at;
   };
+  auto init_sweep_block = [&](size_t at, uint32_t row) {             // every slot "target, +inf" until filled
+    for (int q = 0; q <= 7; ++q) H.stream[at + q] = row * kRow;
+    for (int q = 8; q <= 14; ++q) H.stream[at + q] = kTbInfBits;
+  };
   auto noop_sweep_block = [&]() {                                    // all weights +inf, on a row the previous block did not target
     const uint32_t row = (last_target == 0u) ? 1u : 0u;
-    const size_t at = open_block();
-    const uint32_t yo = row * kRow;
-    H.stream[at] = H.stream[at + 1] = H.stream[at + 2] = H.stream[at + 3] = yo | (yo << 16);
-    for (int q = 4; q <= 10; ++q) H.stream[at + q] = kTbInfBits;
+    init_sweep_block(open_block(), row);
     last_target = row;
   };
   auto close_chunk = [&](bool sweep) {                               // pad the open chunk
     if (in_chunk == 0) return;
     while (in_chunk < kTbBlocksPerChunk) { if (sweep) noop_sweep_block(); else open_block(); }
-    H.stream.resize(H.stream.size() + 4, 0u); H.wsrc.resize(H.wsrc.size() + 4, kNone);
     in_chunk = 0; last_target = kNone;
   };
   std::vector<uint16_t> order;
@@ -229,6 +231,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     }
     W.sweep_off = (uint32_t)(H.stream.size() / kTbChunk);
     static const float dirs[4][2] = { { 1, 1 }, { -1, 1 }, { -1, -1 }, { 1, -1 } };
+    uint32_t order_chunks[4] = { 0, 0, 0, 0 };
     for (int o = 0; o < 4; ++o) {
       order.resize(W.nv);
       for (uint32_t i = 0; i < W.nv; ++i) order[i] = (uint16_t)i;
@@ -243,26 +246,41 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
         for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
           const uint32_t u = t.nbr_u[k];
           if (H.vert_tile[u] != tl) continue;
-          if (n == 0) {                                              // new block: every slot "target, +inf" until filled
-            if (in_chunk != kTbBlocksPerChunk && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
+          if (n == 0) {
+            if (in_chunk != kTbBlocksPerChunk && in_chunk != 0 && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
             at = open_block();
             last_target = y;
-            const uint32_t yo = y * kRow;
-            H.stream[at] = yo | (yo << 16); H.stream[at + 1] = H.stream[at + 2] = H.stream[at + 3] = yo | (yo << 16);
-            for (int q = 4; q <= 10; ++q) H.stream[at + q] = kTbInfBits;
+            init_sweep_block(at, y);
           }
-          const uint32_t so = H.vert_local[u] * kRow;
-          const uint32_t slot = n + 1;                               // offsets: slot 0 = target, 1..7 = sources
-          uint32_t& d = H.stream[at + slot / 2];
-          d = (slot & 1u) ? ((d & 0x0000FFFFu) | (so << 16)) : ((d & 0xFFFF0000u) | so);
-          H.wsrc[at + 4 + n] = k;
+          H.stream[at + 1 + n] = H.vert_local[u] * kRow;
+          H.wsrc[at + 8 + n] = k;
           if (++n == 7) n = 0;
         }
       }
       close_chunk(true);
-      const uint32_t chunks = (uint32_t)(H.stream.size() / kTbChunk - first);
-      if (o == 0) W.sweep_chunks = chunks;
-      else if (chunks != W.sweep_chunks) throw std::logic_error("tile-batch engine: sweep orders differ in size");
+      order_chunks[o] = (uint32_t)(H.stream.size() / kTbChunk - first);
+    }
+    // the four orders hold the same edges but may differ by a few separator blocks: all are padded to the longest one
+    // (chunks of do-nothing blocks), so that order k starts at sweep_off + k * sweep_chunks
+    W.sweep_chunks = std::max(std::max(order_chunks[0], order_chunks[1]), std::max(order_chunks[2], order_chunks[3]));
+    {
+      std::vector<uint32_t> st2, ws2;
+      size_t src = (size_t)W.sweep_off * kTbChunk;
+      for (int o = 0; o < 4; ++o) {
+        const size_t len = (size_t)order_chunks[o] * kTbChunk;
+        st2.insert(st2.end(), H.stream.begin() + src, H.stream.begin() + src + len);
+        ws2.insert(ws2.end(), H.wsrc.begin() + src, H.wsrc.begin() + src + len);
+        src += len;
+        for (uint32_t c = order_chunks[o]; c < W.sweep_chunks; ++c)
+          for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+            const size_t at = st2.size();
+            st2.resize(at + kTbBlock, 0u); ws2.resize(at + kTbBlock, kNone);
+            for (int q = 0; q <= 7; ++q) st2[at + q] = (j & 1u) * kRow;
+            for (int q = 8; q <= 14; ++q) st2[at + q] = kTbInfBits;
+          }
+      }
+      H.stream.resize((size_t)W.sweep_off * kTbChunk); H.wsrc.resize((size_t)W.sweep_off * kTbChunk);
+      H.stream.insert(H.stream.end(), st2.begin(), st2.end()); H.wsrc.insert(H.wsrc.end(), ws2.begin(), ws2.end());
     }
     // --- pre / post streams: one chunk per group of 4 ghosts (more when a group needs more than 5 blocks)
     auto emit_ghost_stream = [&](bool post) {
@@ -299,19 +317,17 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
           if (last) fl |= kTbGhostEnd | (tile_end ? kTbTileEnd : 0u);
           H.stream[at] = fl;
           for (uint32_t q = 0; q < n; ++q) {
-            const uint32_t ro = es[i + q].row * kRow;
-            uint32_t& d = H.stream[at + 1 + q / 2];
-            d = (q & 1u) ? (d | (ro << 16)) : (d | ro);
-            H.stream[at + 4 + q] = kTbInfBits; H.wsrc[at + 4 + q] = es[i + q].k;
+            H.stream[at + 1 + q] = es[i + q].row * kRow;
+            H.stream[at + 6 + q] = kTbInfBits; H.wsrc[at + 6 + q] = es[i + q].k;
           }
-          if (post) H.stream[at + 9] = owner;
+          if (post) H.stream[at + 11] = owner;
           i += n;
         } while (i < es.size());
       }
       close_chunk(false);
       for (size_t c = 0; c < chunk_at.size(); ++c) {
-        H.stream[chunk_at[c] + 60] = chunk_group[c];
-        H.stream[chunk_at[c] + 61] = c + 1 < chunk_at.size() ? chunk_group[c + 1] : 0u;
+        H.stream[chunk_at[c] + 12] = chunk_group[c];
+        H.stream[chunk_at[c] + 13] = c + 1 < chunk_at.size() ? chunk_group[c + 1] : 0u;
       }
       const uint32_t chunks = (uint32_t)(H.stream.size() / kTbChunk - first);
       if (!post) { W.pre_off = (uint32_t)first; W.pre_chunks = chunks; } else { W.post_off = (uint32_t)first; W.post_chunks = chunks; }

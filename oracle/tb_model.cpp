@@ -85,7 +85,6 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
       for (size_t start = 0; start < bucket[t].size(); start += 64) {
         const uint32_t cnt_l = (uint32_t)std::min<size_t>(64, bucket[t].size() - start);
         ++items; acts += cnt_l;
-        auto half = [](uint32_t pr, uint32_t k) { return (k & 1u) ? (pr >> 16) : (pr & 0xFFFFu); };
         for (uint32_t l = 0; l < cnt_l; ++l) {
           const uint32_t p = bucket[t][start + l];
           uint32_t* lds = ldsv[l].data();
@@ -94,15 +93,15 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
           // pre
           for (uint32_t c = 0; c < W.pre_chunks; ++c) {
             const uint32_t* cur = &H.stream[((size_t)W.pre_off + c) * kTbChunk];
-            const uint32_t* G = &Din[gs + 4 * (size_t)cur[60]];
+            const uint32_t* G = &Din[gs + 4 * (size_t)cur[12]];
             for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
               const uint32_t* K = cur + kTbBlock * j;
               const uint32_t hd = K[0], cnt = (hd >> 8) & 7u;
               if (!cnt) continue;
               const float g = u2f(G[hd & 3u]);
               for (uint32_t k = 0; k < kTbGhostEdges; ++k) if (k < cnt) {
-                const uint32_t row = half(K[1 + k / 2], k) / 256u;
-                const uint32_t nd = f2u(g + u2f(K[4 + k]));
+                const uint32_t row = K[1 + k] / 256u;
+                const uint32_t nd = f2u(g + u2f(K[6 + k]));
                 if (nd < (lds[row] & 0x7fffffffu)) lds[row] = nd | kTbDirty;
               }
             }
@@ -119,12 +118,12 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
             for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
               const uint32_t* K = C + kTbBlock * j;
               ++blocks_eval;
-              const uint32_t y = (K[0] & 0xFFFFu) / 256u;
+              const uint32_t y = K[0] / 256u;
               for (uint32_t l = 0; l < cnt_l; ++l) {
                 uint32_t* lds = ldsv[l].data();
                 const uint32_t acc0 = lds[y] & 0x7fffffffu;
                 uint32_t acc = acc0;
-                for (uint32_t k = 0; k < 7; ++k) acc = std::min(acc, fabs_bits_add(lds[half(K[(k + 1) / 2], k + 1) / 256u], K[4 + k]));
+                for (uint32_t k = 0; k < 7; ++k) acc = std::min(acc, fabs_bits_add(lds[K[1 + k] / 256u], K[8 + k]));
                 if (acc < acc0) { lds[y] = acc | kTbDirty; chg_cur |= 1u << (y * 32u / T); }
               }
             }
@@ -144,19 +143,19 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
           uint32_t cnd = kTbInfBits, best = kTbInfBits;
           for (uint32_t c = 0; c < W.post_chunks; ++c) {
             const uint32_t* cur = &H.stream[((size_t)W.post_off + c) * kTbChunk];
-            const uint32_t* G = &Din[gs + 4 * (size_t)cur[60]];
+            const uint32_t* G = &Din[gs + 4 * (size_t)cur[12]];
             for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
               const uint32_t* K = cur + kTbBlock * j;
               const uint32_t hd = K[0], cnt = (hd >> 8) & 7u;
               if (!cnt) continue;
-              for (uint32_t k = 0; k < kTbGhostEdges; ++k) if (k < cnt) cnd = std::min(cnd, fabs_bits_add(lds[half(K[1 + k / 2], k) / 256u], K[4 + k]));
+              for (uint32_t k = 0; k < kTbGhostEdges; ++k) if (k < cnt) cnd = std::min(cnd, fabs_bits_add(lds[K[1 + k] / 256u], K[6 + k]));
               if (hd & kTbGhostEnd) { if (cnd < G[hd & 3u]) best = std::min(best, cnd); cnd = kTbInfBits; }
               if (hd & kTbTileEnd) {
                 if (best != kTbInfBits) {
-                  const size_t pi = (size_t)K[9] * NP + p;
+                  const size_t pi = (size_t)K[11] * NP + p;
                   const uint32_t old = pend[pi];
                   if (best < old) { pend[pi] = best; marr[par ^ 1][p] = std::min(marr[par ^ 1][p], best); }
-                  if (old == kTbInfBits) cand[par ^ 1].push_back({ K[9], p });
+                  if (old == kTbInfBits) cand[par ^ 1].push_back({ K[11], p });
                   ++wakes;
                 }
                 best = kTbInfBits;
