@@ -3720,8 +3720,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   {
     const uint32_t m0 = (uint32_t)in.size();
     // auto: one wave per (tile, 64 plans) for large batches, one workgroup per plan for medium ones, tile rounds otherwise
-    if (engine == 3) engine = (ctx->lazy_paths && m0 >= ctx->tb.min_batch && m0 <= 65535u) ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
-    if (engine == 5 && (!ctx->lazy_paths || m0 > 65535u)) engine = 2;
+    if (engine == 3) engine = (m0 >= ctx->tb.min_batch && m0 <= 65535u) ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
+    if (engine == 5 && m0 > 65535u) engine = 2;
   }
   if (engine == 5 && in.size() > 1) {
     // plans whose waves start close to each other are neighbours in the batch: their slices of a tile are adjacent in memory
@@ -3770,7 +3770,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
     if (engine == 1) ctx->lazy_paths = false;                         // the band steps keep their predecessors as they go
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
-    if (engine == 5) {
+    if (engine == 5 && ctx->lazy_paths) {
       hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
       hipLaunchKernelGGL(k_tb_count, dim3(ctx->tb.ntiles ? ctx->tb.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, ctx->tb_args, ctx->tb.T, ctx->d_res);
     } else if (ctx->lazy_paths) {
@@ -3792,7 +3792,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       if (overflow) {                                               // a path longer than the default rows: rows of V ids
         std::vector<PlanResult> keep(ctx->h_res, ctx->h_res + m);   // settled / evals were accumulated by other kernels
         if (ensure_paths(ctx, m, V)) return MNAV_INTERNAL_ERROR;
-        if (engine == 5) hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
+        if (engine == 5 && ctx->lazy_paths) hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
         else if (ctx->lazy_paths) hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
         else hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
         if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -4268,7 +4268,7 @@ int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out)
     float* tmp = nullptr;
     HIPCHK(hipMalloc((void**)&tmp, 4 * (size_t)(ctx->V ? ctx->V : 1)));
     const uint32_t g = std::min<uint32_t>((ctx->V + kBlock - 1) / kBlock + 1, 4096);
-    if (ctx->last_engine == 5) hipLaunchKernelGGL(k_tb_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->tb_args, slot, ctx->V, tmp);
+    if (ctx->last_engine == 5 && ctx->lazy_paths) hipLaunchKernelGGL(k_tb_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->tb_args, slot, ctx->V, tmp);
     else hipLaunchKernelGGL(k_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->slots[slot].dist, ctx->last_target[slot], ctx->last_offset, ctx->V, tmp);
     const hipError_t e1 = hipMemcpyAsync(host_out, tmp, 4 * (size_t)ctx->V, hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);

@@ -584,22 +584,38 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) { const float d = dist[v]; out[v] = (d <= goal_dist) ? d : inf_f(); }
 }
 
-// blocked distances -> vertex order (callers that want the V-sized fields: finalize pass, vector map)
-__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, uint32_t V, float* const* __restrict__ dist_ptrs)
+// blocked distances -> vertex order, for callers that want the V-sized fields: dist / pred of every plan are initialised
+// (k_init's job) and the tile marks that k_dij_finalize reads say "visit every tile"; one workgroup per (tile, plans)
+__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, const uint32_t* __restrict__ verts, const Plan* __restrict__ plans,
+                                                        const TilePlan* __restrict__ tplans, uint32_t n_ftiles)
 {
-  const uint32_t p = blockIdx.y;
-  float* out = dist_ptrs[p];
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) out[v] = A.D[tb::slot_addr(A.vaddr[v], A.NP, p)];
+  const uint32_t t = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const TbTile W = A.tiles[t];
+  for (uint32_t p = blockIdx.y * (kBlock / 64) + wid; p < A.NP; p += gridDim.y * (kBlock / 64)) {
+    const float* sl = A.D + ((size_t)W.soff * A.NP + (size_t)p * W.sl);
+    float* dist = plans[p].dist; uint32_t* pred = plans[p].pred;
+    for (uint32_t i = lane; i < W.nv; i += 64) { const uint32_t v = verts[W.v0 + i]; dist[v] = sl[i]; pred[v] = v; }
+    if (t == 0) {                                                    // marks of the finalize pass: every tile visited, plan converged
+      const TilePlan& T = tplans[p];
+      for (uint32_t k = lane; k < n_ftiles; k += 64) { T.tlast[k] = 0.0f; T.pend[0][k] = kInfBits; if (T.pend[1] != T.pend[0]) T.pend[1][k] = kInfBits; }
+      if (lane == 0) {
+        TCtl c; memset(&c, 0, sizeof(c));
+        c.it = (int32_t)A.ctl->iters; c.done = 1u; c.acts = 0; c.sweeps = 0; c.pad[0] = A.ctl->err || A.ctl->n_cand[0];
+        T.ctl[0] = c; T.ctl[1] = c;
+      }
+    }
+  }
 }
 
 // host-side state of the engine (device arrays of the mesh-dependent streams, and of the running batch)
 struct TbState {
   bool built = false, w_valid = false;
-  uint32_t T = 128, ntiles = 0, max_nh = 0;
+  uint32_t T = 120, ntiles = 0, max_nh = 0;   // 120 rows x 256 B + staging = 31 232 B of LDS: five waves per CU (128 rows: four)
   uint64_t S = 0;                       // words per plan
   size_t nrec = 0, nexp = 0;
   std::vector<uint32_t> vert_tile;      // host copy: plans are ordered by the tile of their wave source
+  uint32_t* d_verts = nullptr;          // tile order -> vertex id
   TbTile* d_tiles = nullptr; uint32_t* d_stream = nullptr; uint32_t* d_wsrc = nullptr; TbExp* d_exps = nullptr;
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // batch state, sized for cap_np plans
@@ -609,7 +625,7 @@ struct TbState {
   uint2* cand[2] = { nullptr, nullptr }; uint32_t* marr[2] = { nullptr, nullptr };
   float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;
   uint32_t min_batch = 256;             // batches of at least this many plans take this engine (MNAV_TB_MIN_BATCH)
-  float band_mult = 1.0f;               // band = band_mult * mean edge weight * sqrt(T)
+  float band_mult = 2.0f;               // band = band_mult * mean edge weight * sqrt(T)  (measured on C2: 1 -> 236 ms, 2 -> 218 ms per 5120 plans)
   int iters_per_replay = 16, waves_per_cu = 0;
   hipGraphExec_t graph = nullptr; tb::Args graph_args{};
   tb::Ctl last{};                       // counters of the last batch

@@ -19,9 +19,9 @@ void tb_free(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
   tb_free_batch(ctx);
-  for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile })
+  for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile, (void*)S.d_verts })
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
-  S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr;
+  S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr; S.d_verts = nullptr;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
 }
 
@@ -31,7 +31,7 @@ int tb_build(mnav_ctx* ctx)
   TbState& S = ctx->tb;
   if (S.built) return 0;
   if (const char* e = getenv("MNAV_TB_TILE")) S.T = (uint32_t)atoi(e);
-  if (S.T != 64 && S.T != 128) S.T = 128;
+  if (S.T != 64 && S.T != 96 && S.T != 120 && S.T != 128) S.T = 120;
   HostTopology t;
   t.V = ctx->V; t.E = ctx->E; t.F = ctx->F;
   t.row_ptr = ctx->h_row_ptr; t.nbr_u = ctx->h_nbr_u;
@@ -50,6 +50,7 @@ int tb_build(mnav_ctx* ctx)
   if (dev_upload(ctx, &S.d_exps, H.exps.data(), H.exps.size())) return -1;
   if (dev_upload(ctx, &S.d_vaddr, vaddr.data(), vaddr.size())) return -1;
   if (dev_upload(ctx, &S.d_vert_tile, H.vert_tile.data(), H.vert_tile.size())) return -1;
+  if (dev_upload(ctx, &S.d_verts, H.verts.data(), H.verts.size())) return -1;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.stream.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
   S.vert_tile = std::move(H.vert_tile);
@@ -112,13 +113,56 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     hipLaunchKernelGGL(k_tb_filter, dim3(1024), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
     if (ctx->tb.T == 64) hipLaunchKernelGGL(k_tb_solve<64>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else if (ctx->tb.T == 96) hipLaunchKernelGGL(k_tb_solve<96>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else if (ctx->tb.T == 120) hipLaunchKernelGGL(k_tb_solve<120>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else hipLaunchKernelGGL(k_tb_solve<128>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-// Dijkstra batches through the tile-batch engine (paths-only calls).  Returns 0, -1 (error) or 1 (cancelled).
+// per-plan arrays in vertex order + the finalize pass, for calls that want V-sized outputs
+int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, const tb::Args& A)
+{
+  TbState& S = ctx->tb;
+  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
+  if (ensure_tile_state(ctx, n)) return -1;
+  if (tile_weights(ctx)) return -1;
+  const HostTiles& M = ctx->tiles_meta;
+  std::vector<Plan> hp(n);
+  std::vector<TilePlan> tp(n);
+  std::vector<float*> vecs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Slot& s = ctx->slots[i];
+    Plan& P = hp[i];
+    memset(&P, 0, sizeof(P));
+    P.planner = kPlannerDijkstra; P.V = ctx->V;
+    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+    P.dist = s.dist; P.pred = s.pred; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.offset = offset; P.max_steps = ctx->max_steps;
+    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
+    P.seed_face = kNone;
+    vecs[i] = s.vecmap;
+    TilePlan& T = tp[i];
+    memset(&T, 0, sizeof(T));
+    T.V = ctx->V; T.ntiles = M.ntiles;
+    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
+    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
+    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
+    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));                          // hp / tp / vecs go out of scope
+  hipLaunchKernelGGL(k_tb_unblock, dim3(S.ntiles ? S.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, A, S.d_verts, ctx->d_plans, ctx->d_tplans, M.ntiles);
+  launch_finalize(ctx, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Dijkstra batches through the tile-batch engine.  Returns 0, -1 (error) or 1 (cancelled).
 int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
   TbState& S = ctx->tb;
@@ -160,7 +204,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
 
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  uint32_t per_cu = S.T == 64 ? 10u : 5u;                            // LDS: T x 256 bytes per wave, 160 KB per CU
+  uint32_t per_cu = (uint32_t)((160u * 1024u) / (S.T * 256u + 512u));   // LDS: T x 256 bytes + staging per wave, 160 KB per CU
   if (const char* e = getenv("MNAV_TB_WAVES_PER_CU")) S.waves_per_cu = atoi(e);
   if (S.waves_per_cu > 0) per_cu = (uint32_t)S.waves_per_cu;
   const uint32_t waves = per_cu * (uint32_t)ncu;
@@ -197,6 +241,12 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     if (iters > ctx->max_steps) { ctx->err = "tile-batch engine: iteration cap hit"; return -1; }
   }
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
+  if (rc == 0 && !ctx->lazy_paths) {
+    // V-sized outputs wanted (potential, predecessors, vector map): the blocked distances go to the per-plan arrays in vertex
+    // order and the finalize pass of the tile engines derives the reference's exact cut-off semantics and predecessors from
+    // them (k_dij_finalize; every tile visited)
+    if (tb_fields(ctx, n, in, offset, A)) return -1;
+  }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   HIPCHK(hipEventSynchronize(ctx->evc[1]));
   ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);

@@ -265,7 +265,7 @@ def test_batch_equals_single_plans(c1):
     goals[3] = goals[0]                                               # duplicate goal
     targets = np.full(12, m.vertex_at(0.9, 0.9), np.uint32)
     goals[5] = targets[5]                                             # seed == target inside a batch
-    for engine in ("tiled", "persistent", "wave"):
+    for engine in ("tiled", "persistent", "wave", "tile_batch"):
         ctx.set_dijkstra_engine(engine)
         b = ctx.plan_dijkstra_batch(goals, targets, want_fields=True)
         check_batch(case, b, goals, targets)

@@ -55,6 +55,28 @@ def test_c1_batch_paths_and_popped_potential(gpu_ctx_factory, tile, monkeypatch)
     ctx.close()
 
 
+def test_fields_through_the_finalize_pass(gpu_ctx_factory):
+    """Calls that want the V-sized outputs: blocked distances -> vertex order -> k_dij_finalize; potential (incl. the
+    tentative values beyond goal_dist), predecessors and paths bit-equal to the oracle."""
+    case = terrain_case(224, 1)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    ctx.set_dijkstra_engine("tile_batch")
+    m = case.mesh
+    rng = np.random.default_rng(23)
+    n = 40
+    seeds = rng.choice(m.V, n, replace=False).astype(np.uint32)
+    targets = rng.choice(m.V, n, replace=False).astype(np.uint32)
+    b = ctx.plan_dijkstra_batch(seeds, targets, want_fields=True)
+    for k in range(n):
+        ref = case.om.dijkstra(case.weights, case.costs, int(seeds[k]), int(targets[k]))
+        assert b["codes"][k] == ref.code
+        assert np.array_equal(b["paths"][k], ref.path)
+        assert np.array_equal(b["dist"][k].view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(b["pred"][k], ref.pred)
+    ctx.close()
+
+
 def test_costs_limit_invalid_unreachable(gpu_ctx_factory):
     mesh = meshgen.terrain(160, 0.1, 11)
     rng = np.random.default_rng(5)
