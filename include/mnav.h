@@ -236,6 +236,10 @@ void mnav_cancel(mnav_ctx* ctx);
 
 /* -- introspection / tuning -------------------------------------------------------------- */
 int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out);
+/* The same without the settled-vertex count when that has not been taken yet: after a paths-only batch of the tile-batch
+ * engine the count (instrumentation for mnav_algorithmic_bytes) is made by the first mnav_get_stats / mnav_algorithmic_bytes
+ * call, from the resident distances -- mnav_get_timing never triggers it and reports settled = 0 until then. */
+int mnav_get_timing(const mnav_ctx* ctx, mnav_stats* out);
 /* Band width of the wavefront engine in potential units; <= 0 selects the default
  * (3 x mean finite edge weight for the Dijkstra band steps, 12 x for CVP, recomputed on every cost
  * upload).  Results do not depend on it. */

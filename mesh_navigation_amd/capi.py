@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -20,12 +21,32 @@ SUCCESS, CANCELED, INVALID_START, INVALID_GOAL, NO_PATH_FOUND, INTERNAL_ERROR = 
 SYMBOLS = [
     "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_set_face_circulation", "mnav_upload_mesh", "mnav_upload_costs",
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
-    "mnav_cancel", "mnav_get_stats", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
+    "mnav_cancel", "mnav_get_stats", "mnav_get_timing", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
 ]
+
+
+class _PathRows:
+    """The vertex paths of a batch, row k copied out when it is asked for (valid until the context's next batch call)."""
+
+    def __init__(self, buf, lens, cap):
+        self._buf, self._lens, self._cap = buf, lens, cap
+
+    def __len__(self):
+        return self._lens.shape[0]
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        return self._buf[k, : min(int(self._lens[k]), self._cap)].copy()
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class Stats(C.Structure):
@@ -80,6 +101,8 @@ def load(path: str | None = None):
     L.mnav_cancel.argtypes = [vp]
     L.mnav_get_stats.restype = C.c_int
     L.mnav_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.mnav_get_timing.restype = C.c_int
+    L.mnav_get_timing.argtypes = [vp, C.POINTER(Stats)]
     L.mnav_set_band_width.restype = C.c_int
     L.mnav_set_band_width.argtypes = [vp, C.c_float]
     L.mnav_set_dijkstra_engine.restype = C.c_int
@@ -375,6 +398,12 @@ class MnavContext:
         d["algorithmic_bytes"] = int(self._L.mnav_algorithmic_bytes(self._h))
         return d
 
+    def timing(self) -> dict:
+        """Event timings of the last call; never triggers the (lazy) settled-vertex count of a tile-batch call."""
+        s = Stats()
+        self._L.mnav_get_timing(self._h, C.byref(s))
+        return s.as_dict()
+
     def cancel(self):
         self._L.mnav_cancel(self._h)
 
@@ -397,7 +426,7 @@ class MnavContext:
         return DijkstraOut(code, dist, pred, path[: n.value].copy(), vm, self.stats())
 
     def plan_dijkstra_batch(self, seeds, targets, goal_dist_offset: float = 0.3, cost_limit: float = 1.0,
-                            want_fields: bool = False, path_cap: int | None = None):
+                            want_fields: bool = False, path_cap: int | None = None, want_stats: bool = True):
         seeds, targets = _u32(seeds), _u32(targets)
         n = seeds.shape[0]
         V = self.V
@@ -405,15 +434,19 @@ class MnavContext:
         codes = np.empty(n, np.uint32)
         dist = np.empty((n, V), np.float32) if want_fields else None
         pred = np.empty((n, V), np.uint32) if want_fields else None
-        paths = np.empty((n, max(cap, 1)), np.uint32)
+        # the rows of the path buffer are only touched where a path lands: keep the (mostly untouched) buffer between calls
+        # (only while no earlier result still refers to it)
+        key = (n, max(cap, 1))
+        if getattr(self, "_path_buf_key", None) != key or sys.getrefcount(self._path_buf) > 2:
+            self._path_buf, self._path_buf_key = np.empty(key, np.uint32), key
+        paths = self._path_buf
         lens = np.zeros(n, np.uint32)
         rc = self._L.mnav_plan_dijkstra_batch(self._h, n, _p(seeds), _p(targets), float(goal_dist_offset),
                                               float(cost_limit), _p(codes), _p(dist), _p(pred), _p(paths), cap, _p(lens))
         if rc == INTERNAL_ERROR:
             raise RuntimeError(f"mnav_plan_dijkstra_batch internal error: {self._err()}")
-        return dict(rc=rc, codes=codes, dist=dist, pred=pred,
-                    paths=[paths[i, : min(int(lens[i]), cap)].copy() for i in range(n)], path_len=lens,
-                    stats=self.stats())
+        return dict(rc=rc, codes=codes, dist=dist, pred=pred, paths=_PathRows(paths, lens, cap), path_len=lens,
+                    stats=self.stats() if want_stats else self.timing())
 
     def plan_cvp_batch(self, seed_pos, seed_faces, target_faces, goal_dist_offset: float = 0.3, cost_limit: float = 1.0,
                        want_fields: bool = False, want_vecmap: bool = False):

@@ -3753,6 +3753,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   const uint32_t m = (uint32_t)in.size();
+  ctx->tb.count_pending = false;
   ctx->last_planner = kPlannerDijkstra; ctx->last_n = m;
   ctx->last_target.resize(m); for (uint32_t k = 0; k < m; ++k) ctx->last_target[k] = in[k].target[0];
   ctx->last_offset = offset;
@@ -3772,7 +3773,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
     if (engine == 5 && ctx->lazy_paths) {
       hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
-      hipLaunchKernelGGL(k_tb_count, dim3(ctx->tb.ntiles ? ctx->tb.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, ctx->tb_args, ctx->tb.T, ctx->d_res);
+      ctx->tb.count_pending = true;                                  // settled vertices (a statistic): counted when somebody asks, mnav_get_stats
     } else if (ctx->lazy_paths) {
       hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
       hipLaunchKernelGGL(k_count_goal, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
@@ -4210,10 +4211,33 @@ void mnav_cancel(mnav_ctx* ctx)
   if (ctx->d_cancel && ctx->h_one) (void)hipMemcpyAsync(ctx->d_cancel, ctx->h_one, 4, hipMemcpyHostToDevice, ctx->cancel_stream);
 }
 
+// The settled-vertex count of a paths-only tile-batch call is instrumentation (it only feeds mnav_stats.settled and
+// mnav_algorithmic_bytes): it is taken from the resident distances on the first query after the call, not inside it.
+static void settle_stats(mnav_ctx* ctx)
+{
+  if (!ctx->tb.count_pending) return;
+  ctx->tb.count_pending = false;
+  const uint32_t m = ctx->last_n;
+  if (!m || hipSetDevice(ctx->device) != hipSuccess) return;
+  hipLaunchKernelGGL(k_tb_count, dim3(ctx->tb.ntiles ? ctx->tb.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, ctx->tb_args, ctx->tb.T, ctx->d_res);
+  if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) return;
+  finish_stats(ctx, m, false);
+}
+
 int mnav_get_stats(const mnav_ctx* ctx, mnav_stats* out)
 {
   if (!ctx || !out) return -1;
+  settle_stats(const_cast<mnav_ctx*>(ctx));
   *out = ctx->stats;
+  return 0;
+}
+
+int mnav_get_timing(const mnav_ctx* ctx, mnav_stats* out)
+{
+  if (!ctx || !out) return -1;
+  *out = ctx->stats;
+  if (ctx->tb.count_pending) out->settled = 0;
   return 0;
 }
 
@@ -4313,7 +4337,12 @@ int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const flo
   return 1;
 }
 
-uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx) { return ctx ? ctx->algo_bytes : 0; }
+uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx)
+{
+  if (!ctx) return 0;
+  settle_stats(const_cast<mnav_ctx*>(ctx));
+  return ctx->algo_bytes;
+}
 
 #ifdef MNAV_TILE_TIMING
 int mnav_debug_tile_timing(unsigned long long* out, unsigned int cap)

@@ -585,9 +585,11 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
 }
 
 // blocked distances -> vertex order, for callers that want the V-sized fields: dist / pred of every plan are initialised
-// (k_init's job) and the tile marks that k_dij_finalize reads say "visit every tile"; one workgroup per (tile, plans)
-__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, const uint32_t* __restrict__ verts, const Plan* __restrict__ plans,
-                                                        const TilePlan* __restrict__ tplans, uint32_t n_ftiles)
+// (k_init's job), the LDS tiles of the finalize pass that hold a reached vertex are marked "visited" (k_tile_init cleared
+// the marks), and the plan is flagged converged; one wave per (tile, plan) slice
+__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, const uint32_t* __restrict__ verts, const uint32_t* __restrict__ fin_tile,
+                                                        const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ nbr_u,
+                                                        const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans)
 {
   const uint32_t t = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -595,15 +597,20 @@ __global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, const uint32_
   for (uint32_t p = blockIdx.y * (kBlock / 64) + wid; p < A.NP; p += gridDim.y * (kBlock / 64)) {
     const float* sl = A.D + ((size_t)W.soff * A.NP + (size_t)p * W.sl);
     float* dist = plans[p].dist; uint32_t* pred = plans[p].pred;
-    for (uint32_t i = lane; i < W.nv; i += 64) { const uint32_t v = verts[W.v0 + i]; dist[v] = sl[i]; pred[v] = v; }
-    if (t == 0) {                                                    // marks of the finalize pass: every tile visited, plan converged
-      const TilePlan& T = tplans[p];
-      for (uint32_t k = lane; k < n_ftiles; k += 64) { T.tlast[k] = 0.0f; T.pend[0][k] = kInfBits; if (T.pend[1] != T.pend[0]) T.pend[1][k] = kInfBits; }
-      if (lane == 0) {
-        TCtl c; memset(&c, 0, sizeof(c));
-        c.it = (int32_t)A.ctl->iters; c.done = 1u; c.acts = 0; c.sweeps = 0; c.pad[0] = A.ctl->err || A.ctl->n_cand[0];
-        T.ctl[0] = c; T.ctl[1] = c;
+    const TilePlan& T = tplans[p];
+    for (uint32_t i = lane; i < W.nv; i += 64) {
+      const uint32_t v = verts[W.v0 + i];
+      const float d = sl[i];
+      dist[v] = d; pred[v] = v;
+      if (d < inf_f()) {                                             // its tile and its neighbours' tiles (they may owe it a tentative value)
+        T.tlast[fin_tile[v]] = 0.0f;                                 // same value from every writer
+        for (uint32_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) { const uint32_t ft = fin_tile[nbr_u[k]]; if (!(T.tlast[ft] == 0.0f)) T.tlast[ft] = 0.0f; }
       }
+    }
+    if (t == 0 && lane == 0) {
+      TCtl c; memset(&c, 0, sizeof(c));
+      c.it = (int32_t)A.ctl->iters; c.done = 1u; c.pad[0] = (A.ctl->err || A.ctl->n_cand[0]) ? 1u : 0u;
+      T.ctl[0] = c; T.ctl[1] = c;
     }
   }
 }
@@ -627,8 +634,12 @@ struct TbState {
   uint32_t min_batch = 256;             // batches of at least this many plans take this engine (MNAV_TB_MIN_BATCH)
   float band_mult = 2.0f;               // band = band_mult * mean edge weight * sqrt(T)  (measured on C2: 1 -> 236 ms, 2 -> 218 ms per 5120 plans)
   int iters_per_replay = 16, waves_per_cu = 0;
-  hipGraphExec_t graph = nullptr; tb::Args graph_args{};
+  hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
+  // second distance buffer, filled with +inf on its own stream behind the previous call (the fill of 6 B x slots x plans is
+  // otherwise 2 % of a batch); only when both fit comfortably
+  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr;
   tb::Ctl last{};                       // counters of the last batch
+  bool count_pending = false;           // the settled-vertex count of the last (paths-only) batch has not been taken yet
 };
 
 }  // namespace

@@ -9,10 +9,12 @@ void tb_free_batch(mnav_ctx* ctx)
   (void)hipFree(S.cand[0]); (void)hipFree(S.cand[1]); (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
   (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target);
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
-  if (S.graph) (void)hipGraphExecDestroy(S.graph);
+  for (int k = 0; k < 2; ++k) { if (S.graph[k]) (void)hipGraphExecDestroy(S.graph[k]); S.graph[k] = nullptr; }
+  if (S.fill_stream) (void)hipStreamSynchronize(S.fill_stream);
+  (void)hipFree(S.D2); S.D2 = nullptr; S.d2_clean = false;
   S.D = nullptr; S.pend = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
   S.cand[0] = S.cand[1] = nullptr; S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
-  S.graph = nullptr; S.cap_np = 0;
+  S.cap_np = 0;
 }
 
 void tb_free(mnav_ctx* ctx)
@@ -78,6 +80,10 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   tb_free_batch(ctx);
   const size_t nt = S.ntiles ? S.ntiles : 1, pairs = nt * (size_t)np;
   HIPCHK(hipMalloc((void**)&S.D, 4 * (size_t)S.S * np + 64));
+  if (8 * (size_t)S.S * np <= ((size_t)96 << 30) && !getenv("MNAV_TB_NO_PREFILL")) {
+    if (hipMalloc((void**)&S.D2, 4 * (size_t)S.S * np + 64) != hipSuccess) { S.D2 = nullptr; (void)hipGetLastError(); }
+    if (S.D2 && !S.fill_stream) { HIPCHK(hipStreamCreateWithFlags(&S.fill_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&S.fill_done, hipEventDisableTiming)); }
+  }
   HIPCHK(hipMalloc((void**)&S.pend, 4 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.bucket, 2 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.bcnt, 4 * nt));
@@ -156,7 +162,12 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));                          // hp / tp / vecs go out of scope
-  hipLaunchKernelGGL(k_tb_unblock, dim3(S.ntiles ? S.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, A, S.d_verts, ctx->d_plans, ctx->d_tplans, M.ntiles);
+  {
+    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
+    if (gt < 1) gt = 1;
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);   // tile marks cleared
+  }
+  hipLaunchKernelGGL(k_tb_unblock, dim3(S.ntiles ? S.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, A, S.d_verts, ctx->d_vert_tile, ctx->d_row_ptr, ctx->d_nbr_u, ctx->d_plans, ctx->d_tplans);
   launch_finalize(ctx, n);
   HIPCHK(hipGetLastError());
   return 0;
@@ -192,7 +203,14 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     A.band = band;
   }
   HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  if (tb_fill(ctx, S.D, 4 * (size_t)S.S * n, kTbInfBits)) return -1;
+  bool prefilled = false;
+  if (S.D2 && S.d2_clean && S.d2_clean_np >= n) {                     // a clean buffer was prepared behind the previous call
+    std::swap(S.D, S.D2); A.D = S.D;
+    HIPCHK(hipStreamWaitEvent(ctx->stream, S.fill_done, 0));
+    prefilled = true;
+  }
+  S.d2_clean = false;
+  if (!prefilled && tb_fill(ctx, S.D, 4 * (size_t)S.S * n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.pend, 4 * (size_t)S.ntiles * n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.marr[0], 4 * (size_t)n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.marr[1], 4 * (size_t)n, kTbInfBits)) return -1;
@@ -210,18 +228,20 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   const uint32_t waves = per_cu * (uint32_t)ncu;
   const int chunk = S.iters_per_replay & ~1;
   // graph of `chunk` iterations, re-captured when the kernel arguments change
-  const bool same = S.graph && memcmp(&S.graph_args, &A, sizeof(A)) == 0;
-  if (ctx->use_graph && !same) {
-    if (S.graph) { (void)hipGraphExecDestroy(S.graph); S.graph = nullptr; }
+  int gi = 0;                                                         // graph slot: the one captured with these arguments, else the older one
+  for (int k = 0; k < 2; ++k) if (S.graph[k] && memcmp(&S.graph_args[k], &A, sizeof(A)) == 0) gi = k + 2;
+  if (ctx->use_graph && gi < 2) {
+    gi = (S.graph[0] && S.graph_args[0].D != A.D) ? 1 : 0;
+    if (S.graph[gi]) { (void)hipGraphExecDestroy(S.graph[gi]); S.graph[gi] = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     const int rc = tb_launch_iterations(ctx, A, chunk, waves);
     const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
     if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
-    HIPCHK(hipGraphInstantiate(&S.graph, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphInstantiate(&S.graph[gi], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    memcpy(&S.graph_args, &A, sizeof(A));
-  }
+    memcpy(&S.graph_args[gi], &A, sizeof(A));
+  } else gi -= 2;
   int rc = 0;
   uint32_t iters = 0;
   const auto t_start = std::chrono::steady_clock::now();
@@ -230,7 +250,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
       ctx->err = "tile-batch iterations exceeded the wall-clock guard"; return -1;
     }
-    if (ctx->use_graph) HIPCHK(hipGraphLaunch(S.graph, ctx->stream));
+    if (ctx->use_graph) HIPCHK(hipGraphLaunch(S.graph[gi], ctx->stream));
     else if (tb_launch_iterations(ctx, A, chunk, waves)) return -1;
     iters += (uint32_t)chunk;
     HIPCHK(hipMemcpyAsync(S.h_ctl, S.ctl, sizeof(tb::Ctl), hipMemcpyDeviceToHost, ctx->stream));
@@ -241,6 +261,12 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     if (iters > ctx->max_steps) { ctx->err = "tile-batch engine: iteration cap hit"; return -1; }
   }
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
+  if (S.D2) {                                                         // the other buffer (the previous call's distances, dead by now) is cleaned for the next call
+    const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
+    hipLaunchKernelGGL(k_tb_fill, dim3(256 * 8), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
+    HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
+    S.d2_clean = true; S.d2_clean_np = n;
+  }
   if (rc == 0 && !ctx->lazy_paths) {
     // V-sized outputs wanted (potential, predecessors, vector map): the blocked distances go to the per-plan arrays in vertex
     // order and the finalize pass of the tile engines derives the reference's exact cut-off semantics and predecessors from
