@@ -75,7 +75,8 @@ private:
   std::string name_, map_frame_;
   rclcpp::Node::SharedPtr node_;
   std::atomic_bool cancel_planning_{ false };
-  struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; } config_;
+  struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0;
+           bool sync_vector_map = true; } config_;   // sync_vector_map: MeshMap::setVectorMap after every plan, like the reference (:208)
   std::unique_ptr<DeviceMap> dev_;
 };
 

@@ -115,6 +115,7 @@ bool GpuDijkstraMeshPlanner::initialize(const std::string& plugin_name, const st
   mesh_map_ = mesh_map_ptr; name_ = plugin_name; node_ = node;
   map_frame_ = mesh_map_->mapFrame();
   config_.publish_vector_field = node_->declare_parameter(name_ + ".publish_vector_field", config_.publish_vector_field);
+  config_.sync_vector_map = node_->declare_parameter(name_ + ".sync_vector_map", config_.sync_vector_map);
   config_.publish_face_vectors = node_->declare_parameter(name_ + ".publish_face_vectors", config_.publish_face_vectors);
   config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);
   config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
@@ -154,11 +155,15 @@ uint32_t GpuDijkstraMeshPlanner::plan(const mesh_map::Vector& wave_seed, const m
                                            config_.cost_limit, nullptr, nullptr, ids.data(), V, &n, nullptr);
   if (code != Result::SUCCESS) return code;
   for (uint32_t i = 0; i < n; ++i) path.push_back(lvr2::VertexHandle(ids[i]));
-  if (config_.publish_vector_field) exportVectorMap();
+  // computeVectorMap ends with mesh_map_->setVectorMap(vector_map_) (:208): the controller copies the map's field in
+  // setPlan (mesh_controller.cpp:182), so a drop-in has to leave it there after every successful plan.  16 bytes per
+  // vertex cross PCIe for it; a deployment whose controller samples the resident field instead (mnav_vector_at) turns
+  // `sync_vector_map` off.
+  if (config_.sync_vector_map || config_.publish_vector_field) exportVectorMap();
   return Result::SUCCESS;
 }
 
-// computeVectorMap's side effect, MeshMap::setVectorMap (:189-209): only when somebody wants the field on the host
+// computeVectorMap's side effect, MeshMap::setVectorMap (:189-209)
 void GpuDijkstraMeshPlanner::exportVectorMap()
 {
   const uint32_t V = dev_->numVertices();

@@ -269,7 +269,7 @@ class MnavContext:
 
     def set_dijkstra_engine(self, engine: str):
         """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
-        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "wave": 4, "tile_batch": 5}[engine])
+        self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "tile_batch": 5}[engine])
 
     def set_resident_outputs(self, on: bool = True):
         self._L.mnav_set_resident_outputs(self._h, 1 if on else 0)

@@ -531,7 +531,6 @@ struct TilePlan {
   uint32_t max_rounds;
   uint32_t max_nv, max_nh, max_ne;
   const uint32_t* cancel;  // device word set by mnav_cancel (polled by the persistent kernels), may be null
-  const uint32_t* thdr;    // k_plan_wave: 8 words per tile {v0, nv, h0, nh, e0, ne, r0, 0}
   uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
 };
 
@@ -655,27 +654,10 @@ __device__ __forceinline__ uint32_t tile_sweeps(const TileLds& L, uint32_t nv, f
         const uint32_t c = L.lcol[e];
         const uint32_t ndb = f2u(di + L.lw[e]);
         const uint32_t old = atomicMin(&L.ldu[c], ndb);
-#ifdef MNAV_SWEEP_BALLOT                  // tried: one queue-slot atomic per wave instead of one per pushing lane -- 453 vs 411 ms
-                                          // per launch on C2 (the extra ballot / shuffle instructions cost more than the atomics)
-        bool want = false;
-        if (ndb < old && c < nv) {
-          const uint32_t bit = 1u << (c & 31);
-          want = !(atomicOr(&mk[c >> 5], bit) & bit);
-        }
-        const unsigned long long wm = __ballot(want);
-        if (wm) {
-          const int leader = __ffsll((long long)wm) - 1, lane = tid & 63;
-          uint32_t base = 0;
-          if (lane == leader) base = atomicAdd(nqb, (uint32_t)__popcll(wm));
-          base = __shfl(base, leader);
-          if (want) qb[base + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull))] = (uint16_t)c;
-        }
-#else
         if (ndb < old && c < nv) {
           const uint32_t bit = 1u << (c & 31);
           if (!(atomicOr(&mk[c >> 5], bit) & bit)) qb[atomicAdd(nqb, 1u)] = (uint16_t)c;
         }
-#endif
       }
     }
     ++sweep;
@@ -1050,281 +1032,6 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// One WAVE per plan (large batches).  k_plan_persistent spends its time waiting: every sweep of the
-// tile solve is a chain of dependent LDS round trips with only a wave-front segment of a tile's vertices
-// active, and at 30 KB of LDS per plan only 5 plans fit a CU (profiles/r01_pmc_shader_core.md: no unit
-// above 23 %).  Here a plan is owned by a single 64-lane wave: small tiles (<= ~128 vertices, 5-8 KB LDS
-// image), no workgroup barrier anywhere -- the lanes of a wave run in lockstep and LDS operations of a
-// wave complete in order -- and up to 32 plans per CU (4 independent waves per 256-thread workgroup,
-// 8 workgroups per CU at <= 64 VGPRs).  Waves fetch plans from a global counter, so a batch of any size
-// runs as one launch without a tail.  Schedule per plan: scan the wake-up values of all tiles, collect
-// the tiles below the band threshold (up to kReadyCap) in LDS, solve them one after the other (same LDS
-// queue sweeps as tile_sweeps, 8 lanes per active vertex), rescan; when nothing is below the threshold
-// the band advances to the smallest wake-up value + band.  Label-correcting, so the order of the solves
-// does not change the fixed point (k_dij_finalize verifies it).
-// Memory: everything the wave re-reads after writing it (dist, wake-ups, tlast) is private to the plan,
-// i.e. to this wave; those loads/stores are relaxed agent-scope atomics (sc1: served by the L2, never by
-// a stale L1 line), the wake-up minima are L2 atomics.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kReadyCap = 128;
-#define MNAV_LDS __attribute__((address_space(3)))
-// (pointers typed as LDS: a generic `char*` through the out-of-line call would turn every access into a flat_*
-//  instruction with an aperture check instead of ds_*)
-struct WaveLds {
-  MNAV_LDS float* lw; MNAV_LDS uint16_t* lcol; MNAV_LDS uint32_t* ldu; MNAV_LDS uint32_t* l0; MNAV_LDS uint16_t* lrow;
-  MNAV_LDS uint16_t *q0, *q1; MNAV_LDS uint32_t* mask; MNAV_LDS uint32_t* ready; MNAV_LDS uint32_t* nq;
-  uint32_t mw;
-};
-__device__ __forceinline__ uint32_t lds_min(MNAV_LDS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t lds_or(MNAV_LDS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t lds_add(MNAV_LDS uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__host__ __device__ inline size_t wave_lds_bytes(uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
-{
-  const uint32_t nl = max_nv + max_nh;
-  const size_t b = 6 * (size_t)pad_to(max_ne, 8) + 2 * 4 * (size_t)pad_to(nl, 4) + 2 * (size_t)pad_to(nl + 1, 8) +
-                   2 * 2 * (size_t)pad_to(nl, 8) + 4 * (size_t)pad_to(3 * tile_mask_words(max_nv), 4) + 4 * (size_t)kReadyCap + 16;
-  return (b + 15) / 16 * 16;
-}
-__device__ __forceinline__ WaveLds wave_lds_layout(MNAV_LDS char* base, uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
-{
-  const uint32_t nl = max_nv + max_nh;
-  WaveLds L;
-  L.lw = (MNAV_LDS float*)base;
-  L.lcol = (MNAV_LDS uint16_t*)(L.lw + pad_to(max_ne, 8));
-  L.ldu = (MNAV_LDS uint32_t*)(L.lcol + pad_to(max_ne, 8));
-  L.l0 = L.ldu + pad_to(nl, 4);
-  L.mw = tile_mask_words(max_nv);
-  L.mask = L.l0 + pad_to(nl, 4);
-  L.ready = L.mask + pad_to(3 * L.mw, 4);
-  L.nq = L.ready + kReadyCap;
-  L.lrow = (MNAV_LDS uint16_t*)(L.nq + 4);
-  L.q0 = L.lrow + pad_to(nl + 1, 8);
-  L.q1 = L.q0 + pad_to(nl, 8);
-  return L;
-}
-
-__device__ __forceinline__ uint32_t ald_u32(MNAV_GLOBAL const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ald_f32(MNAV_GLOBAL const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ast_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ast_f32(MNAV_GLOBAL float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t gmin_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ uint32_t rdl(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = min(x, (uint32_t)__shfl_xor((int)x, o));
-  return x;
-}
-// LDS traffic of one wave is ordered by the hardware; what has to be stopped is the COMPILER moving or caching LDS
-// accesses across a phase boundary (the staging stores are 16-byte vectors, the reads u16 / f32: type-based alias
-// analysis would let it).  A wavefront-scope fence alone proved too weak in practice (the kernel hung without the
-// compiler barrier); lgkmcnt(0) is what the next phase needs anyway.
-__device__ __forceinline__ void wave_lds_fence()
-{
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// One plan, start to convergence, on the calling wave (kept out of line: the kernel around it is then a plain
-// fetch loop, and the structurizer sees this control flow on its own).
-__device__ __noinline__ void wave_run_plan(const TilePlan& P, MNAV_LDS char* base, int lane)
-{
-  const int sub = lane & (kGroup - 1);
-  const WaveLds L = wave_lds_layout(base, P.max_nv, P.max_nh, P.max_ne);
-  MNAV_GLOBAL uint32_t* pend = as_global(P.pend[0]);
-  MNAV_GLOBAL const uint32_t* g_thdr = as_global(P.thdr);
-  MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
-  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
-  MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
-  MNAV_GLOBAL float* g_dist = as_global(P.dist);
-  MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
-  const uint32_t nt = P.ntiles;
-  const double offset = P.offset;
-  const float band = P.band;
-  uint32_t acts = 0, sweeps_total = 0, status = 0, rounds = 0;
-  uint32_t thr_bits = 0u;                                           // band threshold (float bits; all values >= 0)
-  for (;;) {
-    if (++rounds > 64u * nt + 4096u) { status = 4; break; }          // safety net: never spin (reported as an internal error)
-    // ---- scan: tiles below the threshold -> ready list; smallest wake-up value of the rest ----
-    // (values that are the same in every lane are moved to scalar registers: scalar branches, no fake divergence)
-    const float dt = u2f(rfl(f2u(ald_f32(g_dist + P.target))));
-    const float bound = (float)((double)dt + offset);                // >= the final goal_dist (dijkstra :296)
-    const uint32_t bound_bits = f2u(bound);
-    uint32_t mn = kInfBits, nready = 0;
-    for (uint32_t t0 = 0; t0 < nt; t0 += 4 * kWave) {
-      uint32_t pv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const uint32_t t = t0 + u * kWave + lane; pv[u] = (t < nt) ? ald_u32(pend + t) : kInfBits; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool rdy = pv[u] < thr_bits && pv[u] <= bound_bits;
-        const unsigned long long bm = __ballot(rdy);
-        const uint32_t idx = nready + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-        const bool take = rdy && idx < kReadyCap;
-        if (take) L.ready[idx] = t0 + u * kWave + lane;
-        if (!take && pv[u] <= bound_bits) mn = min(mn, pv[u]);       // (a wake-up above the bound can never propagate)
-        nready += (uint32_t)__popcll(bm);
-      }
-    }
-    mn = rfl(wave_min_u32(mn));
-    if (nready == 0) {
-      if (mn == kInfBits) break;                                     // nothing left that may propagate: converged
-      const float m = u2f(mn);
-      float thr = m + band;
-      if (!(thr > m)) thr = next_up(m);
-      thr_bits = f2u(thr);
-      continue;
-    }
-    if (nready > kReadyCap) nready = kReadyCap;
-    wave_lds_fence();
-    const float thr = u2f(thr_bits);
-    for (uint32_t r = 0; r < nready; ++r) {
-      const uint32_t t = rfl(L.ready[r]);
-      // ---- tile header, wake-up reset ----
-      uint32_t hw = 0;
-      if (lane < 7) hw = g_thdr[8 * (size_t)t + lane];
-      if (lane == 7) hw = f2u(ald_f32(g_tlast + t));
-      if (lane == 8) { ast_u32(pend + t, kInfBits); L.nq[0] = 0; L.nq[1] = 0; L.nq[2] = 0; }
-      const uint32_t v0 = rdl(hw, 0), nv = rdl(hw, 1), h0 = rdl(hw, 2), nh = rdl(hw, 3), e0 = rdl(hw, 4), ne = rdl(hw, 5), r0 = rdl(hw, 6);
-      const float tl = u2f(rdl(hw, 7));
-      const uint32_t nl = nv + nh;
-      // ---- stage the push graph: 16-byte loads, a few in flight per lane ----
-      {
-        MNAV_GLOBAL const u32x4* sw = (MNAV_GLOBAL const u32x4*)(P.tw + e0);
-        MNAV_GLOBAL const u32x4* sc = (MNAV_GLOBAL const u32x4*)(P.col + e0);
-        MNAV_GLOBAL const u32x4* sr = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);
-        MNAV_LDS u32x4* dw = (MNAV_LDS u32x4*)L.lw;
-        MNAV_LDS u32x4* dc = (MNAV_LDS u32x4*)L.lcol;
-        MNAV_LDS u32x4* dr = (MNAV_LDS u32x4*)L.lrow;
-        const uint32_t nw16 = ne / 4, nc16 = ne / 8, nr16 = (nl + 1 + 7) / 8;
-        for (uint32_t i0 = 0; i0 < nw16; i0 += 4 * kWave) {
-          u32x4 a[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kWave + lane; a[u] = sw[i < nw16 ? i : 0]; }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * kWave + lane; if (i < nw16) dw[i] = a[u]; }
-        }
-        for (uint32_t i0 = 0; i0 < nc16; i0 += 2 * kWave) {
-          u32x4 a[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) { const uint32_t i = i0 + u * kWave + lane; a[u] = sc[i < nc16 ? i : 0]; }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) { const uint32_t i = i0 + u * kWave + lane; if (i < nc16) dc[i] = a[u]; }
-        }
-        for (uint32_t i = lane; i < nr16; i += kWave) dr[i] = sr[i];
-        for (uint32_t i = lane; i < 3 * L.mw; i += kWave) L.mask[i] = 0u;
-      }
-      wave_lds_fence();
-      // ---- distances of the owned vertices and of the halo; initial queue ----
-      for (uint32_t i0 = 0; i0 < nl; i0 += 2 * kWave) {
-        uint32_t g[2]; float d[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t i = i0 + u * kWave + lane;
-          g[u] = (i < nv) ? g_verts[v0 + i] : ((i < nl) ? g_halo_verts[h0 + i - nv] : 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { const uint32_t i = i0 + u * kWave + lane; d[u] = (i < nl) ? ald_f32(g_dist + g[u]) : inf_f(); }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t i = i0 + u * kWave + lane;
-          if (i < nl) {
-            const uint32_t b = f2u(d[u]);
-            L.ldu[i] = b; L.l0[i] = b;
-            const bool src = d[u] < thr && d[u] <= bound && (i >= nv || !(d[u] < tl));   // owned sources in [tlast, thr), halo sources below thr
-            if (src) L.q0[lds_add(&L.nq[0], 1u)] = (uint16_t)i;
-          }
-        }
-      }
-      wave_lds_fence();
-      // ---- sweeps over the active queue (spec: tile_sweeps) ----
-      uint32_t sweep = 0;
-      for (;;) {
-        const uint32_t nq = rfl(L.nq[sweep % 3]);
-        if (nq == 0) break;
-        if (lane == 0) L.nq[(sweep + 2) % 3] = 0;
-        for (uint32_t i = lane; i < L.mw; i += kWave) L.mask[((sweep + 2) % 3) * L.mw + i] = 0u;
-        MNAV_LDS const uint16_t* qa = (sweep & 1) ? L.q1 : L.q0;
-        MNAV_LDS uint16_t* qb = (sweep & 1) ? L.q0 : L.q1;
-        MNAV_LDS uint32_t* nqb = &L.nq[(sweep + 1) % 3];
-        MNAV_LDS uint32_t* mk = L.mask + ((sweep + 1) % 3) * L.mw;
-        for (uint32_t idx = (uint32_t)lane >> 3; idx < nq; idx += kWave / kGroup) {
-          const uint32_t x = qa[idx];
-          const uint32_t dib = L.ldu[x];
-          const uint32_t eb = L.lrow[x], ee = L.lrow[x + 1];
-          const float di = u2f(dib);
-          if (!(di < thr) || !(di <= bound)) continue;
-          for (uint32_t e = eb + sub; e < ee; e += kGroup) {
-            const uint32_t c = L.lcol[e];
-            const uint32_t ndb = f2u(di + L.lw[e]);                 // the float add of dijkstra :331
-            const uint32_t old = lds_min(&L.ldu[c], ndb);
-            if (ndb < old && c < nv) {
-              const uint32_t bit = 1u << (c & 31);
-              if (!(lds_or(&mk[c >> 5], bit) & bit)) qb[lds_add(nqb, 1u)] = (uint16_t)c;
-            }
-          }
-        }
-        ++sweep;
-        wave_lds_fence();
-        if (sweep > 8u * (nl + 8u)) { status = 5; break; }            // safety net (a tile needs at most ~nl sweeps)
-      }
-      // ---- wake the owners of undercut halo vertices, write back, own left-over ----
-      for (uint32_t i = lane; i < nh; i += kWave) {
-        const uint32_t b = L.ldu[nv + i];
-        if (b < L.l0[nv + i]) gmin_u32(pend + g_halo_tile[h0 + i], b);
-      }
-      uint32_t own_left = kInfBits;
-      for (uint32_t i = lane; i < nv; i += kWave) {
-        const uint32_t db = L.ldu[i];
-        if (db != L.l0[i]) ast_f32(g_dist + g_verts[v0 + i], u2f(db));
-        const float d = u2f(db);
-        if (!(d < thr) && d <= bound) own_left = min(own_left, db);
-      }
-      own_left = rfl(wave_min_u32(own_left));
-      if (lane == 0) {
-        if (own_left != kInfBits) gmin_u32(pend + t, own_left);
-        ast_f32(g_tlast + t, thr);
-      }
-      ++acts; sweeps_total += sweep;
-      // the next tile of this round may stage vertices this one just wrote (its halo): the stores have to be
-      // performed at the L2 first
-      __builtin_amdgcn_s_waitcnt(0);
-      wave_lds_fence();
-    }
-    if (acts >= P.max_rounds) { status = 2; break; }
-    // mnav_cancel: one agent-scope load per scan round
-    uint32_t stop = 0;
-    if (lane == 0 && P.cancel) stop = __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (rfl(stop)) { status = 3; break; }
-    // every atomic / store of this round has to be performed at the L2 before the next scan reads the wake-ups
-    __builtin_amdgcn_s_waitcnt(0);
-  }
-  if (lane == 0) {
-    TCtl c; memset(&c, 0, sizeof(c));
-    c.it = (int32_t)acts; c.done = 1; c.acts = acts; c.sweeps = sweeps_total; c.pad[0] = status; c.pad[1] = rounds;
-    P.ctl[0] = c; P.ctl[1] = c;
-  }
-}
-
-__global__ __launch_bounds__(kTileBlock, 4) void k_plan_wave(const TilePlan* __restrict__ plans, uint32_t n_plans,
-                                                            uint32_t* __restrict__ next_plan, uint32_t slice_bytes)
-{
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  MNAV_LDS char* base = (MNAV_LDS char*)smem + (threadIdx.x >> 6) * slice_bytes;
-  for (;;) {
-    uint32_t pi = 0;
-    if (lane == 0) pi = atomicAdd(next_plan, 1u);
-    pi = rfl(pi);
-    if (pi >= n_plans) break;
-    wave_run_plan(plans[pi], base, lane);
-  }
-}
-
-// per-plan initialisation of the tile state (dist/pred are set by k_init)
 __global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile)
 {
   const TilePlan& P = plans[blockIdx.y];
@@ -1984,7 +1691,7 @@ __global__ __launch_bounds__(kBlock) void k_steepness(uint32_t V, const float* _
 {
   const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
   if (v >= V) return;
-  const float st = acosf(nrm[3 * (size_t)v + 2]);                  // :165 (float overload of acos)
+  const float st = acosf_ref(nrm[3 * (size_t)v + 2]);              // :165 (float overload of acos; the host libm's bits, mnav_eval.h)
   cost[v] = st;
   lethal[v] = ((double)st > threshold) ? 1 : 0;                    // :88
 }
@@ -2165,10 +1872,6 @@ struct Slot {
   TCtl* tctl = nullptr;
   TCnt* tcnt = nullptr;
   bool tile_ready = false;
-  // wave engine (finer tiling)
-  uint32_t* wpend = nullptr;
-  float* wtlast = nullptr;
-  bool wave_ready = false;
 };
 
 }  // namespace
@@ -2233,14 +1936,6 @@ struct mnav_ctx {
            *d_t_eptr = nullptr, *d_t_src = nullptr, *d_vert_tile = nullptr, *d_mismatch = nullptr;
   uint16_t *d_t_rowptr = nullptr, *d_t_col = nullptr;
   float* d_t_tw = nullptr; bool tw_valid = false; uint32_t t_nnz = 0;
-  // second, finer tiling for the wave-per-plan engine (k_plan_wave): same arrays, plus the packed tile headers
-  struct WaveTiles {
-    HostTiles meta; uint32_t tile_size = 128, nnz = 0; bool tw_valid = false; size_t slice = 0, fin_lds = 0; float band_auto = 1.f;
-    uint32_t *vptr = nullptr, *verts = nullptr, *hptr = nullptr, *halo_verts = nullptr, *halo_tile = nullptr, *eptr = nullptr,
-             *rptr = nullptr, *src = nullptr, *vert_tile = nullptr, *thdr = nullptr;
-    uint16_t *rowptr = nullptr, *col = nullptr;
-    float* tw = nullptr;
-  } wt;
   // sharded single plan (mnav_shard_*)
   struct Shard {
     bool ready = false, active = false;
@@ -2259,8 +1954,6 @@ struct mnav_ctx {
   uint8_t *d_infl_mask = nullptr, *d_zero_u8 = nullptr;
   float* d_infl_keyd = nullptr;
   uint32_t infl_steps = 0, infl_bands = 0; uint64_t infl_evals = 0; float infl_ms = 0.f, infl_ms_wave = 0.f;   // last inflation wave
-  uint32_t* d_next_plan = nullptr;
-  uint32_t wave_min_batch = 0;                                     // auto engine: 0 = never pick k_plan_wave (MNAV_WAVE_MIN_BATCH to opt in)
   TilePlan* d_tplans = nullptr; uint32_t tplans_cap = 0;
   TCtl* h_tctl = nullptr;
   size_t tile_lds = 0, fin_lds = 0;
@@ -2320,7 +2013,6 @@ void free_slot(Slot& s)
   (void)hipFree(s.wlist0); (void)hipFree(s.wlist1); (void)hipFree(s.wstamp);
   (void)hipFree(s.cnt);
   (void)hipFree(s.tpend0); (void)hipFree(s.tpend1); (void)hipFree(s.tlast); (void)hipFree(s.tcnt);
-  (void)hipFree(s.wpend); (void)hipFree(s.wtlast);
   s = Slot{};
 }
 
@@ -2467,7 +2159,7 @@ int materialize(mnav_ctx* ctx, bool cvp, double cost_limit)
     hipLaunchKernelGGL(k_build_nbr, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, V, ctx->d_row_ptr, ctx->d_nbr_u,
                        ctx->d_nbr_e, ctx->d_w, ctx->d_cost, ctx->d_invalid, cost_limit, ctx->d_nbr);
     HIPCHK(hipGetLastError());
-    ctx->nbr_limit = cost_limit; ctx->nbr_valid = true; ctx->tw_valid = false; ctx->wt.tw_valid = false; ctx->tb.w_valid = false;
+    ctx->nbr_limit = cost_limit; ctx->nbr_valid = true; ctx->tw_valid = false; ctx->tb.w_valid = false;
   } else {
     if (ctx->crn_valid && ctx->crn_limit == cost_limit) return 0;
     if (!ctx->d_crn) HIPCHK(hipMalloc((void**)&ctx->d_crn, sizeof(Corner) * (size_t)(ctx->F ? 3 * (size_t)ctx->F : 1)));
@@ -2766,106 +2458,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   return rc;
 }
 
-// Dijkstra batches through the persistent per-plan kernel.  Returns 0 or -1.
-int wave_tile_weights(mnav_ctx* ctx)
-{
-  if (ctx->wt.tw_valid) return 0;
-  const uint32_t n = ctx->wt.nnz;
-  const uint32_t gb = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_tile_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, n, ctx->wt.src, ctx->wt.col, ctx->d_nbr, ctx->wt.tw);
-  HIPCHK(hipGetLastError());
-  ctx->wt.tw_valid = true;
-  return 0;
-}
-
-// Dijkstra batches through k_plan_wave (one wave per plan, fine tiling).  Returns 0, -1 (error) or 1 (cancelled).
-int run_dijkstra_wave(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
-{
-  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_paths(ctx, n)) return -1;
-  if (ensure_tile_state(ctx, n)) return -1;                          // TCtl / TCnt pools, d_tplans, d_mismatch
-  const HostTiles& M = ctx->wt.meta;
-  const size_t nt = M.ntiles ? M.ntiles : 1;
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    if (!s.wave_ready) {
-      HIPCHK(hipMalloc((void**)&s.wpend, 4 * nt)); HIPCHK(hipMalloc((void**)&s.wtlast, 4 * nt));
-      s.wave_ready = true;
-    }
-  }
-  if (!ctx->d_next_plan) HIPCHK(hipMalloc((void**)&ctx->d_next_plan, 256));
-  if (wave_tile_weights(ctx)) return -1;
-  std::vector<Plan> hp(n);
-  std::vector<TilePlan> tp(n);
-  std::vector<float*> vecs(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    Plan& P = hp[i];
-    memset(&P, 0, sizeof(P));
-    P.planner = kPlannerDijkstra; P.V = ctx->V;
-    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
-    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
-    P.seed_face = kNone;
-    vecs[i] = s.vecmap;
-    TilePlan& T = tp[i];
-    memset(&T, 0, sizeof(T));
-    T.V = ctx->V; T.ntiles = M.ntiles;
-    T.vptr = ctx->wt.vptr; T.verts = ctx->wt.verts; T.hptr = ctx->wt.hptr; T.halo_verts = ctx->wt.halo_verts;
-    T.halo_tile = ctx->wt.halo_tile; T.eptr = ctx->wt.eptr; T.rptr = ctx->wt.rptr; T.rowptr = ctx->wt.rowptr; T.col = ctx->wt.col; T.tw = ctx->wt.tw;
-    T.thdr = ctx->wt.thdr;
-    T.dist = s.dist; T.pend[0] = s.wpend; T.pend[1] = s.wpend; T.tlast = s.wtlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
-    T.max_rounds = 64u * (M.ntiles ? M.ntiles : 1u) + 1024u;          // activation cap per plan
-    T.cancel = ctx->d_cancel;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->wt.band_auto;
-    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
-  }
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_next_plan, 0, 256, ctx->stream));
-  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  {
-    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-    if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->wt.vert_tile);
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-  ctx->ms_chunks = 0.0;
-  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-  {
-    // 4 plans (waves) per workgroup; at most what the chip holds at once, the waves fetch the remaining plans themselves
-    const size_t per_wg = 4 * ctx->wt.slice;
-    uint32_t wg_per_cu = (uint32_t)std::min<size_t>(8, (160 * 1024) / (per_wg ? per_wg : 1));
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    uint32_t grid = std::min<uint32_t>((n + 3) / 4, wg_per_cu * (uint32_t)ncu);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_plan_wave, dim3(grid), dim3(kTileBlock), per_wg, ctx->stream, ctx->d_tplans, n, ctx->d_next_plan, (uint32_t)ctx->wt.slice);
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  if (!ctx->lazy_paths) launch_finalize(ctx, n, M.ntiles, ctx->wt.fin_lds);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
-  ctx->stats.launches = 1;
-  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;
-  return 0;
-}
-
+// Dijkstra batches through the persistent per-plan kernel.  Returns 0, -1 (error) or 1 (cancelled).
 int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
   if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
@@ -3013,7 +2606,6 @@ mnav_ctx* mnav_create(int device)
     else ctx->dij_engine = 3;
   }
   if (const char* e = getenv("MNAV_PERSISTENT_MIN_BATCH")) ctx->persistent_min_batch = (uint32_t)atoi(e);
-  if (const char* e = getenv("MNAV_WAVE_MIN_BATCH")) ctx->wave_min_batch = (uint32_t)atoi(e);
   return ctx;
 }
 
@@ -3034,10 +2626,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_t_vptr); (void)hipFree(ctx->d_t_verts); (void)hipFree(ctx->d_t_hptr); (void)hipFree(ctx->d_t_halo_verts);
   (void)hipFree(ctx->d_t_halo_tile); (void)hipFree(ctx->d_t_eptr); (void)hipFree(ctx->d_t_src); (void)hipFree(ctx->d_vert_tile);
   (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
-  (void)hipFree(ctx->d_tplans); (void)hipFree(ctx->d_next_plan);
-  (void)hipFree(ctx->wt.vptr); (void)hipFree(ctx->wt.verts); (void)hipFree(ctx->wt.hptr); (void)hipFree(ctx->wt.halo_verts);
-  (void)hipFree(ctx->wt.halo_tile); (void)hipFree(ctx->wt.eptr); (void)hipFree(ctx->wt.rptr); (void)hipFree(ctx->wt.src);
-  (void)hipFree(ctx->wt.vert_tile); (void)hipFree(ctx->wt.thdr); (void)hipFree(ctx->wt.rowptr); (void)hipFree(ctx->wt.col); (void)hipFree(ctx->wt.tw);
+  (void)hipFree(ctx->d_tplans);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
   (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
@@ -3172,54 +2761,6 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     ctx->tiles_meta = std::move(T);
     ctx->shard.ready = false;
   }
-  // the finer tiling of the wave-per-plan engine
-  {
-    auto& W = ctx->wt;
-    if (const char* e = getenv("MNAV_WAVE_TILE")) W.tile_size = (uint32_t)atoi(e);
-    if (W.tile_size < 32) W.tile_size = 32;
-    HostTiles T;
-    for (;;) {
-      try { T = build_tiles(t, xyz, W.tile_size); }
-      catch (const std::exception& ex) { ctx->err = ex.what(); return -2; }
-      W.slice = wave_lds_bytes(T.max_nv, T.max_nh, T.max_ne);
-      W.fin_lds = finalize_lds_bytes(T.max_nv, T.max_nh, T.max_ne);
-      if (4 * W.slice <= 64 * 1024 || W.tile_size <= 32) break;   // 4 waves per workgroup within the default 64 KiB
-      W.tile_size /= 2;
-    }
-    if (4 * W.slice > 160 * 1024) { ctx->err = "mesh valence too high for the wave tile engine"; return -2; }
-    if (4 * W.slice > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)k_plan_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * W.slice)));
-    if (W.fin_lds > ctx->fin_lds && W.fin_lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)k_dij_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W.fin_lds));
-    if (getenv("MNAV_VERBOSE"))
-      fprintf(stderr, "[mnav] wave tiles: size %u, %u tiles, max owned %u, halo %u, edges %u -> LDS %zu B per wave\n",
-              W.tile_size, T.ntiles, T.max_nv, T.max_nh, T.max_ne, W.slice);
-    std::vector<uint32_t> thdr(8 * (size_t)(T.ntiles ? T.ntiles : 1), 0u);
-    for (uint32_t k = 0; k < T.ntiles; ++k) {
-      uint32_t* h = &thdr[8 * (size_t)k];
-      h[0] = T.vptr[k]; h[1] = T.vptr[k + 1] - T.vptr[k]; h[2] = T.hptr[k]; h[3] = T.hptr[k + 1] - T.hptr[k];
-      h[4] = T.eptr[k]; h[5] = T.eptr[k + 1] - T.eptr[k]; h[6] = T.rptr[k];
-    }
-    W.nnz = (uint32_t)T.col.size(); W.tw_valid = false;
-    if (dev_upload(ctx, &W.vptr, T.vptr.data(), T.vptr.size())) return -1;
-    if (dev_upload(ctx, &W.verts, T.verts.data(), T.verts.size())) return -1;
-    if (dev_upload(ctx, &W.hptr, T.hptr.data(), T.hptr.size())) return -1;
-    if (dev_upload(ctx, &W.halo_verts, T.halo_verts.data(), T.halo_verts.size())) return -1;
-    if (dev_upload(ctx, &W.halo_tile, T.halo_tile.data(), T.halo_tile.size())) return -1;
-    if (dev_upload(ctx, &W.eptr, T.eptr.data(), T.eptr.size())) return -1;
-    if (dev_upload(ctx, &W.rptr, T.rptr.data(), T.rptr.size())) return -1;
-    if (dev_upload(ctx, &W.rowptr, T.rowptr.data(), T.rowptr.size())) return -1;
-    if (dev_upload(ctx, &W.col, T.col.data(), T.col.size())) return -1;
-    if (dev_upload(ctx, &W.src, T.src.data(), T.src.size())) return -1;
-    if (dev_upload(ctx, &W.vert_tile, T.vert_tile.data(), T.vert_tile.size())) return -1;
-    if (dev_upload(ctx, &W.thdr, thdr.data(), thdr.size())) return -1;
-    if (dev_upload(ctx, &W.tw, (const float*)nullptr, T.col.size())) return -1;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    T.verts.clear(); T.verts.shrink_to_fit(); T.halo_verts.clear(); T.halo_verts.shrink_to_fit();
-    T.halo_tile.clear(); T.halo_tile.shrink_to_fit(); T.rowptr.clear(); T.rowptr.shrink_to_fit();
-    T.col.clear(); T.col.shrink_to_fit(); T.src.clear(); T.src.shrink_to_fit(); T.vert_tile.clear(); T.vert_tile.shrink_to_fit();
-    W.meta = std::move(T);
-  }
   HIPCHK(hipStreamSynchronize(ctx->stream));   // host vectors go out of scope
   ctx->have_mesh = true;
   return 0;
@@ -3233,8 +2774,6 @@ static void auto_delta(mnav_ctx* ctx, const float* w, uint32_t E)
   if (!(ctx->delta_auto > 0.f)) ctx->delta_auto = 1.0f;
   // tile band ~ the potential difference across one tile (sqrt(tile_size) mean edges)
   ctx->tile_band_auto = (ctx->delta_auto / 3.0f) * std::sqrt((float)ctx->tile_size);
-  ctx->wt.band_auto = (ctx->delta_auto / 3.0f) * std::sqrt((float)ctx->wt.tile_size);
-  if (const char* e = getenv("MNAV_WAVE_BAND_MULT")) ctx->wt.band_auto *= (float)atof(e);
   if (const char* e = getenv("MNAV_TILE_BAND")) ctx->tile_band_user = (float)atof(e);
   if (const char* e = getenv("MNAV_ROUNDS_BAND_MULT")) ctx->rounds_band_mult = (float)atof(e);
 }
@@ -3720,7 +3259,14 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   {
     const uint32_t m0 = (uint32_t)in.size();
     // auto: one wave per (tile, 64 plans) for large batches, one workgroup per plan for medium ones, tile rounds otherwise
-    if (engine == 3) engine = (m0 >= ctx->tb.min_batch && m0 <= 65535u) ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
+    if (engine == 3) {
+      // The tile-batch engine fills a wave with the plans that have work on ONE tile in ONE iteration: about
+      // 0.64 * plans / sqrt(tiles) of them (measured on C2: 34 lanes at 5120 plans / 9260 tiles).  Below ~12 lanes per wave
+      // the per-plan engine is faster (10M-vertex mesh with 1536 plans: 3 lanes per wave, 504 against 831 plans/s).
+      const double tiles = std::max(1.0, (double)V / (0.9 * ctx->tb.T));
+      const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && 0.64 * m0 >= ctx->tb.min_lanes * std::sqrt(tiles);
+      engine = fills ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
+    }
     if (engine == 5 && m0 > 65535u) engine = 2;
   }
   if (engine == 5 && in.size() > 1) {
@@ -3762,7 +3308,6 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     const bool want_path = true;
     const int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
                  : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
-                 : (engine == 4) ? run_dijkstra_wave(ctx, m, in, offset)
                  : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
                                  : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
     ctx->last_engine = engine;
@@ -4250,7 +3795,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta)
 
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 {
-  if (!ctx || engine < 0 || engine > 5) return -1;
+  if (!ctx || engine < 0 || engine > 5 || engine == 4) return -1;   // 4 was the one-wave-per-plan experiment (removed)
   ctx->dij_engine = engine;
   return 0;
 }

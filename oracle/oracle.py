@@ -400,6 +400,8 @@ def model_lib():
         L.sm_run.restype = u32
         L.sm_run.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, u32, vp, C.c_double, C.c_double,
                              C.c_float, C.c_int, u32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+        L.sm_acosf_ref.restype = C.c_float
+        L.sm_acosf_ref.argtypes = [C.c_float]
         L.sm_infl_candidate.restype = C.c_float
         L.sm_infl_candidate.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_int)]
         L.sm_run_inflation.restype = u32
@@ -429,6 +431,11 @@ def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
     return dict(code=code, dist=dist, iterations=int(stats[0]), activations=int(stats[1]), sweeps=int(stats[2]), wakes=int(stats[3]),
                 max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]), items=int(stats[7]),
                 blocks_total=int(stats[8]), blocks_evaluated=int(stats[9]))
+
+
+def product_acosf(x) -> float:
+    """mnav_eval.h acosf_ref: the device's restatement of the host libm's acosf (SteepnessLayer)."""
+    return float(model_lib().sm_acosf_ref(float(x)))
 
 
 def product_inflation_update(u1, u2, a, b, c, max_distance):

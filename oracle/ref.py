@@ -118,6 +118,8 @@ def lib():
         L.ref_dijkstra.restype = u32
         L.ref_dijkstra.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32)]
         L.ref_dijkstra_fields.argtypes = [vp, vp, vp, vp, vp]
+        if hasattr(L, "ref_map_vector_map"):
+            L.ref_map_vector_map.argtypes = [vp, vp, vp]
         L.ref_dijkstra_make_plan.restype = u32
         L.ref_dijkstra_make_plan.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(f64)]
         L.ref_dijkstra_cancel.argtypes = [vp]
@@ -369,6 +371,13 @@ class RefMap:
             hv = np.zeros(self.V, np.uint8)
             lib().ref_dijkstra_fields(self._h, _p(dist), _p(pred), _p(vm), _p(hv))
         return RefDijkstra(code, dist, pred, path[: n.value].copy(), vm, hv)
+
+    def map_vector_map(self):
+        """MeshMap::getVectorMap() (mesh_map.h:268): (vectors[V,3], has[V]) -- what the last planner's setVectorMap left in the map."""
+        vm = np.zeros((self.V, 3), np.float32)
+        hv = np.zeros(self.V, np.uint8)
+        lib().ref_map_vector_map(self._h, _p(vm), _p(hv))
+        return vm, hv
 
     def dijkstra_make_plan(self, start_pose7, goal_pose7, goal_dist_offset=0.3, cost_limit=1.0):
         self._init_dij(goal_dist_offset, cost_limit)

@@ -357,6 +357,18 @@ void ref_dijkstra_fields(void* h, float* dist, uint32_t* pred, float* vecmap, ui
     }
   }
 }
+// the field the MAP holds (MeshMap::getVectorMap, mesh_map.h:268): what a planner's setVectorMap left for the controller
+void ref_map_vector_map(void* h, float* vecmap, uint8_t* has_vec)
+{
+  auto* r = static_cast<Ref*>(h);
+  const uint32_t V = r->map->mesh()->numVertices();
+  const auto& vm = r->map->getVectorMap();
+  for (uint32_t v = 0; v < V; ++v) {
+    const auto m = vm.get(lvr2::VertexHandle(v));
+    has_vec[v] = m ? 1 : 0;
+    vecmap[3 * v] = m ? m->x : 0; vecmap[3 * v + 1] = m ? m->y : 0; vecmap[3 * v + 2] = m ? m->z : 0;
+  }
+}
 uint32_t ref_dijkstra_make_plan(void* h, const double start7[7], const double goal7[7], double* poses, uint32_t cap, uint32_t* n_poses, double* cost)
 {
   auto* r = static_cast<Ref*>(h);

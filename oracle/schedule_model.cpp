@@ -354,6 +354,9 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
 
 // the product's waveFrontUpdate arithmetic on plain numbers (mnav_eval.h infl_candidate): value offered to the free
 // vertex, or NaN when it is not finite; *requeue = the :311 condition
+// mnav_eval.h acosf_ref (the device's SteepnessLayer arithmetic) for the host-side check against libm
+float sm_acosf_ref(float x) { return acosf_ref(x); }
+
 float sm_infl_candidate(float u1, float u2, float a, float b, float c, float max_distance, int* requeue)
 {
   const InflCand k = infl_candidate(u1, u2, a, b, c, max_distance);

@@ -10,7 +10,7 @@ from tests.common import Case
 from tests.test_gpu_planners import assert_cvp_close, assert_dijkstra_equal
 
 pytestmark = pytest.mark.gpu
-ENGINES = ("tiled", "band", "persistent", "wave")
+ENGINES = ("tiled", "band", "persistent", "tile_batch")
 
 
 def face_of(mesh, v):

@@ -32,9 +32,13 @@ def world():
 def test_gpu_dijkstra_plugin_equals_the_reference_planner_on_the_reference_map(world):
     m, rm, robot, goal = world
     code_r, plan_r, cost_r = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    vm_r, has_r = rm.map_vector_map()                            # what the reference planner left in the MAP (setVectorMap, :208)
+    assert has_r.any()
     assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra")
     code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal))
     assert code == code_r == 0
+    vm, has = rm.map_vector_map()                                # ... and what the GPU plugin leaves there: the controller reads this
+    assert np.array_equal(has, has_r) and np.array_equal(vm.view(np.uint32), vm_r.view(np.uint32))
     assert plan.shape == plan_r.shape and len(plan) > 20
     assert np.array_equal(plan, plan_r)                          # every pose, position and quaternion, bit for bit
     assert cost == cost_r
@@ -43,6 +47,11 @@ def test_gpu_dijkstra_plugin_equals_the_reference_planner_on_the_reference_map(w
     c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal2))
     cr, pr, kr = rm.dijkstra_make_plan(pose(robot), pose(goal2))
     assert c2 == cr == 0 and np.array_equal(p2, pr, equal_nan=True) and k2 == kr     # (goal ON a vertex: the reference's last pose has a NaN quaternion, so has ours)
+    vm_r2, has_r2 = rm.map_vector_map()                          # the reference ran last: its field is in the map now
+    rm.plugin_make_plan(pose(robot), pose(goal2))
+    vm2, has2 = rm.map_vector_map()
+    assert np.array_equal(has2, has_r2) and np.array_equal(vm2.view(np.uint32), vm_r2.view(np.uint32))
+    assert not np.array_equal(has2, has)                         # a different wave than the first plan's
     rm.plugin_release()
 
 

@@ -171,3 +171,18 @@ def test_seed_lookup_and_pose():
     assert length == 1.0 and np.allclose(pose, [0, 0, 0, 0, 0, 0, 1])      # identity orientation
     pose, _ = O.pose_from_position([0, 0, 0], [0, 2, 0], [0, 0, 1])
     assert np.allclose(pose[3:], [0, 0, np.sqrt(0.5), np.sqrt(0.5)])       # +90 deg about z
+
+
+def test_device_acosf_is_the_host_libm_acosf():
+    """SteepnessLayer (steepness_layer.cpp:165) takes acos of a float on the host; the device restates glibc's float
+    routine (mnav_eval.h acosf_ref).  Exhaustively equal on [-1, 1] (2.1e9 arguments, checked once with a C loop); here
+    a sample incl. the branch boundaries."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.acosf.restype = ctypes.c_float
+    libm.acosf.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-1, 1, 20000), np.cos(rng.uniform(0, 1.2, 20000)), [0.0, -0.0, 0.5, -0.5, 1.0, -1.0, 1e-20, 0.49999997, 0.50000006, 0.99999994]]).astype(np.float32)
+    for x in xs:
+        a, b = np.float32(O.product_acosf(x)), np.float32(libm.acosf(float(x)))
+        assert a.view(np.uint32) == b.view(np.uint32), float(x)
