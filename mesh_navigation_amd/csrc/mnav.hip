@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile)
+__global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile, float tlast0)
 {
   const TilePlan& P = plans[blockIdx.y];
   const uint32_t stride = gridDim.x * kBlock;
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict
   for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) {
     if (P.pend[1] != P.pend[0]) P.pend[1][t] = kInfBits;            // (the per-plan engines use a single buffer)
     P.pend[0][t] = (t == st) ? 0u : kInfBits;                       // the seed's tile wakes at 0
-    P.tlast[t] = -inf_f();
+    P.tlast[t] = tlast0;                                            // -inf: never solved (the finalize pass skips the tile unless it was woken)
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     P.dist[P.seed] = 0.0f;                                          // dijkstra :276
@@ -1215,6 +1215,15 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
     uint32_t db[kFinVpt];
 #pragma unroll
     for (int k = 0; k < kFinVpt; ++k) db[k] = f2u(g_dist[g[k]]);
+    {
+      // no reached vertex among the tile's own and halo vertices: nothing to derive here (dist = inf, pred = itself stay)
+      int reached = 0;
+#pragma unroll
+      for (int k = 0; k < kFinVpt; ++k) reached |= ((uint32_t)(tid + k * kTileBlock) < nl && db[k] != kInfBits) ? 1 : 0;
+      for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock)
+        reached |= (g_dist[(i < nv) ? g_verts[v0 + i] : g_halo_verts[h0 + i - nv]] < inf_f()) ? 1 : 0;
+      if (!__syncthreads_or(reached)) continue;                     // uniform over the workgroup
+    }
     int cut = 0;                                                   // owned vertices above goal_dist: their value is re-derived
 #pragma unroll
     for (int k = 0; k < kFinVpt; ++k) {
@@ -2413,7 +2422,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   {
     uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
     if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -2506,7 +2515,7 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   {
     uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
     if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
@@ -3676,7 +3685,7 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
   uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
   if (gt < 1) gt = 1;
-  hipLaunchKernelGGL(k_tile_init, dim3(gt, 1), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);
+  hipLaunchKernelGGL(k_tile_init, dim3(gt, 1), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   S.j = 0; S.seed = seed_vertex; S.target = target_vertex; S.offset = goal_dist_offset; S.active = true;

@@ -584,34 +584,27 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) { const float d = dist[v]; out[v] = (d <= goal_dist) ? d : inf_f(); }
 }
 
-// blocked distances -> vertex order, for callers that want the V-sized fields: dist / pred of every plan are initialised
-// (k_init's job), the LDS tiles of the finalize pass that hold a reached vertex are marked "visited" (k_tile_init cleared
-// the marks), and the plan is flagged converged; one wave per (tile, plan) slice
-__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, const uint32_t* __restrict__ verts, const uint32_t* __restrict__ fin_tile,
-                                                        const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ nbr_u,
-                                                        const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans)
+// blocked distances -> vertex order, for callers that want the V-sized fields: dist / pred of every plan are written in
+// vertex order (coalesced stores; the reads gather 4-byte words, neighbouring vertices mostly from the same slice), and
+// the plan is flagged converged.  k_dij_finalize then looks at every LDS tile and skips those without a reached vertex.
+__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, uint32_t V, const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans)
 {
-  const uint32_t t = blockIdx.x;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const TbTile W = A.tiles[t];
-  for (uint32_t p = blockIdx.y * (kBlock / 64) + wid; p < A.NP; p += gridDim.y * (kBlock / 64)) {
-    const float* sl = A.D + ((size_t)W.soff * A.NP + (size_t)p * W.sl);
-    float* dist = plans[p].dist; uint32_t* pred = plans[p].pred;
+  const uint32_t p = blockIdx.y;
+  const Plan& P = plans[p];
+  MNAV_GLOBAL float* dist = as_global(P.dist); MNAV_GLOBAL uint32_t* pred = as_global(P.pred);
+  MNAV_GLOBAL const u32x2* va = (MNAV_GLOBAL const u32x2*)A.vaddr;
+  MNAV_GLOBAL const float* D = as_global(A.D);
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) {
+    const u32x2 a = va[v];
+    dist[v] = D[(size_t)a.x * A.NP + (size_t)p * (a.y >> 8) + (a.y & 255u)];
+    pred[v] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     const TilePlan& T = tplans[p];
-    for (uint32_t i = lane; i < W.nv; i += 64) {
-      const uint32_t v = verts[W.v0 + i];
-      const float d = sl[i];
-      dist[v] = d; pred[v] = v;
-      if (d < inf_f()) {                                             // its tile and its neighbours' tiles (they may owe it a tentative value)
-        T.tlast[fin_tile[v]] = 0.0f;                                 // same value from every writer
-        for (uint32_t k = row_ptr[v]; k < row_ptr[v + 1]; ++k) { const uint32_t ft = fin_tile[nbr_u[k]]; if (!(T.tlast[ft] == 0.0f)) T.tlast[ft] = 0.0f; }
-      }
-    }
-    if (t == 0 && lane == 0) {
-      TCtl c; memset(&c, 0, sizeof(c));
-      c.it = (int32_t)A.ctl->iters; c.done = 1u; c.pad[0] = (A.ctl->err || A.ctl->n_cand[0]) ? 1u : 0u;
-      T.ctl[0] = c; T.ctl[1] = c;
-    }
+    TCtl c; memset(&c, 0, sizeof(c));
+    c.it = (int32_t)A.ctl->iters; c.done = 1u; c.pad[0] = (A.ctl->err || A.ctl->n_cand[0]) ? 1u : 0u;
+    T.ctl[0] = c; T.ctl[1] = c;
   }
 }
 

@@ -165,9 +165,14 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   {
     uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
     if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile);   // tile marks cleared
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, 0.0f);   // marks: every tile is looked at
   }
-  hipLaunchKernelGGL(k_tb_unblock, dim3(S.ntiles ? S.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, A, S.d_verts, ctx->d_vert_tile, ctx->d_row_ptr, ctx->d_nbr_u, ctx->d_plans, ctx->d_tplans);
+  {
+    uint32_t gv = (ctx->V + kBlock * 8 - 1) / (kBlock * 8);
+    if (gv < 1) gv = 1;
+    if (gv > 512) gv = 512;
+    hipLaunchKernelGGL(k_tb_unblock, dim3(gv, n), dim3(kBlock), 0, ctx->stream, A, ctx->V, ctx->d_plans, ctx->d_tplans);
+  }
   launch_finalize(ctx, n);
   HIPCHK(hipGetLastError());
   return 0;
