@@ -1372,14 +1372,23 @@ __global__ void k_seed(const Plan* __restrict__ plans)
 // result assembly: code + vertex path (dijkstra :358-373) / reachability (cvp :902-918), stats
 // ---------------------------------------------------------------------------------------------
 
-constexpr uint32_t kPathOverflow = 0xFFFFFFF0u;   // internal: the path row was too short, the host retries with rows of V ids
+constexpr uint32_t kPathOverflow = 0xFFFFFFF0u;   // internal: the path row was too short; path_len then holds the FULL length and
+                                                  // the host walks the overflowed plans again into exact-size rows
+// Where the vertex path of plan k goes: rows of `stride` ids, or -- second pass, for the plans whose path did not fit --
+// rows of exactly the needed size in a packed buffer (off / cap per plan, cap 0 = plan not part of this pass).
+struct PathRows {
+  uint32_t* base; uint32_t stride;
+  const unsigned long long* off; const uint32_t* cap;
+  __device__ __forceinline__ uint32_t* row(uint32_t k) const { return base + (off ? (size_t)off[k] : (size_t)k * stride); }
+  __device__ __forceinline__ uint32_t capacity(uint32_t k) const { return cap ? cap[k] : stride; }
+  __device__ __forceinline__ bool skip(uint32_t k) const { return cap && cap[k] == 0u; }
+};
 
 template <uint32_t PLANNER>
-__global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict__ res,
-                         uint32_t* __restrict__ paths, uint32_t path_stride)
+__global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict__ res, PathRows rows)
 {
   const Plan& P = plans[blockIdx.x];
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0 || rows.skip(blockIdx.x)) return;
   PlanResult& R = res[blockIdx.x];
   const Ctl a = P.ctl[0], b = P.ctl[1];
   const Ctl last = (a.it > b.it) ? a : b;
@@ -1397,10 +1406,12 @@ __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict_
     const uint32_t seed = P.seed[0], target = P.target[0];
     if (P.pred[target] == target) code = kNoPathFound;             // dijkstra :358
     else {
-      uint32_t* path = paths + (size_t)blockIdx.x * path_stride;   // written target-side first
+      uint32_t* path = rows.row(blockIdx.x);                       // written target-side first
+      const uint32_t cap = rows.capacity(blockIdx.x);
       uint32_t n = 0, v = target;
-      while (v != seed && n < path_stride) { v = P.pred[v]; path[n++] = v; }   // :369-373
-      if (v != seed) code = (path_stride < P.V) ? kPathOverflow : kInternalError;   // row too short: the host retries with V ids
+      while (v != seed && n <= P.V) { v = P.pred[v]; if (n < cap) path[n] = v; ++n; }   // :369-373; the full length is counted
+      if (v != seed) code = kInternalError;                         // a predecessor cycle
+      else if (n > cap) code = kPathOverflow;                       // row too short: the host walks this plan again into an exact row
       R.path_len = n;
     }
   } else {
@@ -1420,8 +1431,9 @@ __global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict_
 // computed here on the fly along the walk (one wave per plan, one neighbour per lane).  Every hop also checks that the
 // minimum IS the vertex's distance (the fixed-point property k_dij_finalize verifies everywhere; here along the path).
 __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans, PlanResult* __restrict__ res,
-                                                     uint32_t* __restrict__ paths, uint32_t path_stride, uint32_t* __restrict__ mismatch)
+                                                     PathRows rows, uint32_t* __restrict__ mismatch)
 {
+  if (rows.skip(blockIdx.x)) return;
   const Plan& P = plans[blockIdx.x];
   const TilePlan& T = tplans[blockIdx.x];
   const int lane = threadIdx.x;
@@ -1435,9 +1447,10 @@ __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ pl
   if (last.pad[0] || !last.done) code = kInternalError;               // activation cap hit / not finished
   else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
   else {
-    uint32_t* path = paths + (size_t)blockIdx.x * path_stride;        // written target-side first
+    uint32_t* path = rows.row(blockIdx.x);                            // written target-side first
+    const uint32_t cap = rows.capacity(blockIdx.x);
     uint32_t v = target;
-    while (v != seed && n < path_stride) {
+    while (v != seed && n <= P.V) {
       const float dv = P.dist[v];
       float best_s = inf_f(), best_du = inf_f();
       uint32_t best_u = v;
@@ -1457,14 +1470,14 @@ __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ pl
       }
       if (f2u(best_s) != f2u(dv) || best_u == v) { bad = 1; break; }  // not a fixed point here: reported, never returned
       v = best_u;
-      if (lane == 0) path[n] = v;
+      if (lane == 0 && n < cap) path[n] = v;
       ++n;
     }
-    if (!bad && v != seed) code = (path_stride < P.V) ? kPathOverflow : kInternalError;
-    if (bad) code = kInternalError;
+    if (bad || v != seed) code = kInternalError;
+    else if (n > cap) code = kPathOverflow;
   }
   if (lane == 0) {
-    R.code = code; R.path_len = (code == kSuccess) ? n : 0;
+    R.code = code; R.path_len = (code == kSuccess || code == kPathOverflow) ? n : 0;
     R.steps = (uint32_t)(last.it < 0 ? 0 : last.it); R.bands = last.sweeps; R.armed = (dt < inf_f()) ? 1u : 0u; R.overflow = last.pad[0];
     R.goal_dist = goal_dist; R.evals = last.acts; R.shrinks = 0;
     if (bad) atomicAdd(mismatch, 1u);
@@ -1473,11 +1486,11 @@ __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ pl
 
 // vertex paths of a batch, packed back to back and turned into the reference's list order (seed ... pred[target]) on the
 // device: ONE dense copy to a pinned buffer instead of a strided 2-D copy of n rows
-__global__ __launch_bounds__(kBlock) void k_pack_paths(const uint32_t* __restrict__ paths, uint32_t path_stride, const uint32_t* __restrict__ offs,
+__global__ __launch_bounds__(kBlock) void k_pack_paths(PathRows rows, PathRows over, const uint32_t* __restrict__ offs,
                                                        const uint32_t* __restrict__ lens, uint32_t* __restrict__ out)
 {
   const uint32_t k = blockIdx.x, len = lens[k];
-  const uint32_t* src = paths + (size_t)k * path_stride;
+  const uint32_t* src = (over.cap && over.cap[k]) ? over.row(k) : rows.row(k);   // second-pass rows where the first ones were too short
   uint32_t* dst = out + offs[k];
   for (uint32_t q = threadIdx.x; q < len; q += kBlock) dst[q] = src[len - 1 - q];
 }
@@ -1923,6 +1936,7 @@ struct mnav_ctx {
   PlanResult* d_res = nullptr; PlanResult* h_res = nullptr;
   float** d_vecptrs = nullptr;
   uint32_t* d_paths = nullptr; size_t paths_words = 0; uint32_t path_stride = 0;   // n plans x path_stride vertex ids
+  uint32_t* d_over = nullptr; unsigned long long* d_over_off = nullptr; uint32_t* d_over_cap = nullptr;   // exact rows of the paths that did not fit
   uint32_t *d_pack = nullptr, *h_pack = nullptr, *d_pack_meta = nullptr; size_t pack_words = 0, pack_meta_n = 0;   // packed paths (device, pinned host), offsets + lengths
   std::unordered_map<void*, size_t> alloc_bytes;                   // sizes of the dev_upload buffers (re-used when unchanged)
   Ctl* h_ctl = nullptr;       // pinned, 2 per plan
@@ -2094,7 +2108,8 @@ int ensure_plan_tables(mnav_ctx* ctx, uint32_t n)
 
 // Vertex paths of a batch: n rows of `stride` ids.  A path has ~1.4 sqrt(V) hops on a terrain, so rows of
 // 16 sqrt(V) + 1024 ids hold it with a wide margin (84 MB instead of 20 GB for 5120 plans on the 1M mesh); a path
-// that does not fit makes k_finish report kPathOverflow and the batch is finished again with rows of V ids.
+// that does not fit makes the path kernels report kPathOverflow with the full length, and only those plans are walked
+// again into rows of exactly that size.
 uint32_t default_path_stride(const mnav_ctx* ctx)
 {
   const double s = 16.0 * std::sqrt((double)ctx->V) + 1024.0;
@@ -2639,6 +2654,7 @@ void mnav_destroy(mnav_ctx* ctx)
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
   (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
+  (void)hipFree(ctx->d_over); (void)hipFree(ctx->d_over_off); (void)hipFree(ctx->d_over_cap);
   (void)hipFree(ctx->d_pack); (void)hipFree(ctx->d_pack_meta); if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
@@ -3324,15 +3340,17 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
     if (engine == 1) ctx->lazy_paths = false;                         // the band steps keep their predecessors as they go
+    const PathRows rows1{ ctx->d_paths, ctx->path_stride, nullptr, nullptr };
+    PathRows rows2{ nullptr, 0u, nullptr, nullptr };
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
     if (engine == 5 && ctx->lazy_paths) {
-      hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
+      hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, rows1, ctx->d_mismatch);
       ctx->tb.count_pending = true;                                  // settled vertices (a statistic): counted when somebody asks, mnav_get_stats
     } else if (ctx->lazy_paths) {
-      hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, ctx->path_stride, ctx->d_mismatch);
+      hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, rows1, ctx->d_mismatch);
       hipLaunchKernelGGL(k_count_goal, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
     } else
-    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, ctx->path_stride);
+    hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, rows1);
     if (engine == 1)   // the tile engines count the settled vertices in k_dij_finalize
       hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
     (void)hipEventRecord(ctx->ev[4], ctx->stream);
@@ -3342,14 +3360,25 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
     {
-      bool overflow = false;
-      for (uint32_t k = 0; k < m; ++k) overflow = overflow || ctx->h_res[k].code == kPathOverflow;
-      if (overflow) {                                               // a path longer than the default rows: rows of V ids
+      // paths longer than the default rows (corridors, mazes): ONLY those plans are walked again, into rows of exactly their
+      // length (the first walk counted it) in one packed buffer
+      size_t over_words = 0;
+      std::vector<unsigned long long> ooff(m, 0ull); std::vector<uint32_t> ocap(m, 0u);
+      for (uint32_t k = 0; k < m; ++k)
+        if (ctx->h_res[k].code == kPathOverflow) { ooff[k] = over_words; ocap[k] = ctx->h_res[k].path_len; over_words += ctx->h_res[k].path_len; }
+      if (over_words) {
         std::vector<PlanResult> keep(ctx->h_res, ctx->h_res + m);   // settled / evals were accumulated by other kernels
-        if (ensure_paths(ctx, m, V)) return MNAV_INTERNAL_ERROR;
-        if (engine == 5 && ctx->lazy_paths) hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
-        else if (ctx->lazy_paths) hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, ctx->d_paths, V, ctx->d_mismatch);
-        else hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, ctx->d_paths, V);
+        (void)hipFree(ctx->d_over); (void)hipFree(ctx->d_over_off); (void)hipFree(ctx->d_over_cap);
+        ctx->d_over = nullptr; ctx->d_over_off = nullptr; ctx->d_over_cap = nullptr;
+        if (hipMalloc((void**)&ctx->d_over, 4 * over_words) != hipSuccess || hipMalloc((void**)&ctx->d_over_off, 8 * (size_t)m) != hipSuccess ||
+            hipMalloc((void**)&ctx->d_over_cap, 4 * (size_t)m) != hipSuccess ||
+            hipMemcpyAsync(ctx->d_over_off, ooff.data(), 8 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(ctx->d_over_cap, ocap.data(), 4 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+          { ctx->err = "path buffers: out of memory"; return MNAV_INTERNAL_ERROR; }
+        rows2 = PathRows{ ctx->d_over, 0u, ctx->d_over_off, ctx->d_over_cap };
+        if (engine == 5 && ctx->lazy_paths) hipLaunchKernelGGL(k_tb_path, dim3(m), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, V, ctx->d_res, rows2, ctx->d_mismatch);
+        else if (ctx->lazy_paths) hipLaunchKernelGGL(k_path_lazy, dim3(m), dim3(kWave), 0, ctx->stream, ctx->d_plans, ctx->d_tplans, ctx->d_res, rows2, ctx->d_mismatch);
+        else hipLaunchKernelGGL(k_finish<kPlannerDijkstra>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, rows2);
         if (hipMemcpyAsync(ctx->h_res, ctx->d_res, sizeof(PlanResult) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "result download failed"; return MNAV_INTERNAL_ERROR; }
         for (uint32_t k = 0; k < m; ++k) ctx->h_res[k].settled = keep[k].settled;
@@ -3389,7 +3418,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       if (hipMemcpyAsync(ctx->d_pack_meta, offs.data(), 4 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
           hipMemcpyAsync(ctx->d_pack_meta + m, lens.data(), 4 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
-      hipLaunchKernelGGL(k_pack_paths, dim3(m), dim3(kBlock), 0, ctx->stream, ctx->d_paths, ctx->path_stride, ctx->d_pack_meta, ctx->d_pack_meta + m, ctx->d_pack);
+      hipLaunchKernelGGL(k_pack_paths, dim3(m), dim3(kBlock), 0, ctx->stream, rows1, rows2, ctx->d_pack_meta, ctx->d_pack_meta + m, ctx->d_pack);
       if (hipMemcpyAsync(ctx->h_pack, ctx->d_pack, 4 * total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "path download failed"; return MNAV_INTERNAL_ERROR; }
     }
@@ -3506,7 +3535,7 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
     const int rc = run_plans<kPlannerCvp>(ctx, m, in, goal_dist_offset, false);
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { if (codes_out) for (uint32_t i = 0; i < n; ++i) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // cvp :888-892
-    hipLaunchKernelGGL(k_finish<kPlannerCvp>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, (uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(k_finish<kPlannerCvp>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, PathRows{ nullptr, 0u, nullptr, nullptr });
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
     hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
     (void)hipEventRecord(ctx->ev[4], ctx->stream);

@@ -497,10 +497,10 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
 // vertex path of a plan from the blocked distances: the walk of k_path_lazy (predecessor = argmin (dist[u] + w, dist[u], u)
 // over the expanded neighbours, the minimum must BE the vertex's distance), dijkstra :358-373
 __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* __restrict__ row_ptr, const Nbr* __restrict__ nbr, uint32_t V,
-                                                   PlanResult* __restrict__ res, uint32_t* __restrict__ paths, uint32_t path_stride,
-                                                   uint32_t* __restrict__ mismatch)
+                                                   PlanResult* __restrict__ res, PathRows rows, uint32_t* __restrict__ mismatch)
 {
   const uint32_t p = blockIdx.x;
+  if (rows.skip(p)) return;
   const int lane = threadIdx.x;
   PlanResult& R = res[p];
   const uint32_t seed = A.seed[p], target = A.target[p];
@@ -510,10 +510,11 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
   if (A.ctl->err || A.ctl->n_cand[0]) code = kInternalError;          // sweep cap hit / pairs still pending (the host stops after an odd iteration: list 0 is its output)
   else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
   else {
-    uint32_t* path = paths + (size_t)p * path_stride;                 // written target-side first
+    uint32_t* path = rows.row(p);                                     // written target-side first
+    const uint32_t cap = rows.capacity(p);
     uint32_t v = target;
     float dv = dt;
-    while (v != seed && n < path_stride) {
+    while (v != seed && n <= V) {
       float best_s = inf_f(), best_du = inf_f();
       uint32_t best_u = v;
       const uint32_t beg = row_ptr[v], end = row_ptr[v + 1];
@@ -532,14 +533,14 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
       }
       if (f2u(best_s) != f2u(dv) || best_u == v) { bad = 1; break; }  // not a fixed point here: reported, never returned
       v = best_u; dv = best_du;
-      if (lane == 0) path[n] = v;
+      if (lane == 0 && n < cap) path[n] = v;
       ++n;
     }
-    if (!bad && v != seed) code = (path_stride < V) ? kPathOverflow : kInternalError;
-    if (bad) code = kInternalError;
+    if (bad || v != seed) code = kInternalError;
+    else if (n > cap) code = kPathOverflow;                           // the host walks this plan again into a row of n ids
   }
   if (lane == 0) {
-    R.code = code; R.path_len = (code == kSuccess) ? n : 0;
+    R.code = code; R.path_len = (code == kSuccess || code == kPathOverflow) ? n : 0;
     R.steps = A.ctl->iters; R.bands = 0; R.armed = (dt < inf_f()) ? 1u : 0u; R.overflow = A.ctl->err;
     R.goal_dist = goal_dist; R.evals = 0; R.shrinks = 0;
     if (bad) atomicAdd(mismatch, 1u);

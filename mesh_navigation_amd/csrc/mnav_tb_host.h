@@ -130,7 +130,6 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
 // per-plan arrays in vertex order + the finalize pass, for calls that want V-sized outputs
 int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, const tb::Args& A)
 {
-  TbState& S = ctx->tb;
   if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
   if (ensure_tile_state(ctx, n)) return -1;
   if (tile_weights(ctx)) return -1;

@@ -179,3 +179,39 @@ def test_walk_bound_hit_returns_internal_error_instead_of_a_reordered_plan(gpu_c
     case.upload(cut)                                  # the bounds are read here
     with pytest.raises(RuntimeError, match="internal error"):
         cut.plan_cvp(sp, sf, tf)
+
+
+def test_paths_longer_than_the_default_rows_are_walked_again_into_exact_rows(gpu_ctx_factory):
+    """A corridor mesh (4 x 9000 vertices): end-to-end paths have ~9000 vertices, the default path rows hold
+    16 sqrt(V) + 1024 = 4060.  Only the plans whose path did not fit are walked a second time, into rows of exactly their
+    length (no V ids per plan for the whole batch); short and long plans share a batch, every engine, lazy and finalized."""
+    W, L, h = 4, 9000, 0.1
+    rng = np.random.default_rng(8)
+    ii, jj = np.meshgrid(np.arange(W), np.arange(L), indexing="xy")
+    xyz = np.stack([ii.ravel() * h + rng.uniform(-0.02, 0.02, W * L), jj.ravel() * h + rng.uniform(-0.02, 0.02, W * L),
+                    0.05 * np.sin(jj.ravel() * 0.01)], axis=1).astype(np.float32)
+    f = []
+    for j in range(L - 1):
+        for i in range(W - 1):
+            a = j * W + i
+            f.append((a, a + 1, a + W + 1)); f.append((a, a + W + 1, a + W))
+    mesh = meshgen.from_faces(xyz, np.array(f, np.uint32))
+    case = Case(mesh)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    n = 24
+    seeds = rng.integers(0, 4 * 200, n).astype(np.uint32)              # near one end
+    targets = (mesh.V - 1 - rng.integers(0, 4 * 200, n)).astype(np.uint32)   # near the other end: long paths ...
+    targets[::3] = seeds[::3] + 4 * 50                                 # ... and every third plan a short one
+    refs = [case.om.dijkstra(case.weights, case.costs, int(s), int(t)) for s, t in zip(seeds, targets)]
+    assert max(len(r.path) for r in refs) > 8000 and min(len(r.path) for r in refs) < 200
+    for engine in ("tiled", "persistent", "tile_batch"):
+        ctx.set_dijkstra_engine(engine)
+        for fields in (False, True):
+            b = ctx.plan_dijkstra_batch(seeds, targets, want_fields=fields)
+            for k in range(n):
+                assert b["codes"][k] == refs[k].code == 0
+                assert np.array_equal(b["paths"][k], refs[k].path), (engine, fields, k)
+    o = ctx.plan_dijkstra(int(seeds[1]), int(targets[1]), want_fields=False)
+    assert np.array_equal(o.path, refs[1].path)
+    ctx.set_dijkstra_engine("auto")
