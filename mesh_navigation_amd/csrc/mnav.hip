@@ -2005,6 +2005,18 @@ namespace {
     }                                                                                              \
   } while (0)
 
+// temporary device buffer of one call: freed on every way out (the HIPCHK early returns included)
+template <class T>
+struct DevTmp {
+  T* p = nullptr;
+  DevTmp() = default;
+  DevTmp(const DevTmp&) = delete;
+  DevTmp& operator=(const DevTmp&) = delete;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  operator T*() const { return p; }
+  void** out() { return (void**)&p; }
+};
+
 template <class T>
 int dev_upload(mnav_ctx* ctx, T** dptr, const T* host, size_t n)
 {
@@ -2877,9 +2889,9 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
   if ((n_layers && !layer_costs) || (mode == 1 && n_layers && !weights) || (ctx->E && !edge_distances && !ctx->d_edge_dist)) { ctx->err = "null input array"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   const uint32_t V = ctx->V;
-  float *d_layers = nullptr, *d_wts = nullptr;
-  HIPCHK(hipMalloc((void**)&d_layers, sizeof(float) * ((size_t)n_layers * V + 1)));
-  HIPCHK(hipMalloc((void**)&d_wts, sizeof(float) * (n_layers + 1)));
+  DevTmp<float> d_layers, d_wts;
+  HIPCHK(hipMalloc(d_layers.out(), sizeof(float) * ((size_t)n_layers * V + 1)));
+  HIPCHK(hipMalloc(d_wts.out(), sizeof(float) * (n_layers + 1)));
   int rc = 0;
   for (uint32_t l = 0; l < n_layers && rc == 0; ++l) {
     if (!layer_costs[l]) { ctx->err = "null layer"; rc = -1; break; }
@@ -2897,7 +2909,6 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
   // the combined costs never leave the device: the edge-weight pass reads them where they are
   if (rc == 0) rc = edge_weight_pass(ctx, edge_cost_factor, invalid, vertex_costs_out, edge_weights_out);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_layers); (void)hipFree(d_wts);
   return rc;
 }
 
@@ -2910,9 +2921,9 @@ int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, con
   if (!vertex_ids || !values) { ctx->err = "null input array"; return -1; }
   for (uint32_t i = 0; i < n; ++i) if (vertex_ids[i] >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
-  uint32_t* d_ids = nullptr; float* d_vals = nullptr;
-  HIPCHK(hipMalloc((void**)&d_ids, sizeof(uint32_t) * n));
-  HIPCHK(hipMalloc((void**)&d_vals, sizeof(float) * n));
+  DevTmp<uint32_t> d_ids; DevTmp<float> d_vals;
+  HIPCHK(hipMalloc(d_ids.out(), sizeof(uint32_t) * n));
+  HIPCHK(hipMalloc(d_vals.out(), sizeof(float) * n));
   int rc = 0;
   if (hipMemcpyAsync(d_ids, vertex_ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(d_vals, values, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "upload failed"; rc = -1; }
@@ -2927,7 +2938,6 @@ int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, con
     if (rc == 0 && hipGetLastError() != hipSuccess) { ctx->err = "cost update failed"; rc = -1; }
   }
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_ids); (void)hipFree(d_vals);
   if (rc) return rc;
   for (uint32_t i = 0; i < n; ++i) ctx->h_cost[vertex_ids[i]] = values[i];
   ctx->nbr_valid = ctx->crn_valid = false;                          // the cost-limit folded copies are rebuilt on the next plan
@@ -3023,8 +3033,8 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   if (!ctx->d_infl_mask) HIPCHK(hipMalloc((void**)&ctx->d_infl_mask, Vn));
   if (!ctx->d_zero_u8) { HIPCHK(hipMalloc((void**)&ctx->d_zero_u8, Vn)); HIPCHK(hipMemsetAsync(ctx->d_zero_u8, 0, Vn, ctx->stream)); }
   if (!ctx->d_infl_keyd) HIPCHK(hipMalloc((void**)&ctx->d_infl_keyd, 4 * Vn));
-  uint8_t* d_inv = nullptr;
-  if (invalid) { HIPCHK(hipMalloc((void**)&d_inv, Vn)); HIPCHK(hipMemcpyAsync(d_inv, invalid, V, hipMemcpyHostToDevice, ctx->stream)); }
+  DevTmp<uint8_t> d_inv;
+  if (invalid) { HIPCHK(hipMalloc(d_inv.out(), Vn)); HIPCHK(hipMemcpyAsync(d_inv, invalid, V, hipMemcpyHostToDevice, ctx->stream)); }
   mnav_ctx::Layer& L = ctx->layers[layer];
   mnav_ctx::Layer& In = ctx->layers[input_layer];
   hipLaunchKernelGGL(k_infl_mask, dim3(gb), dim3(kBlock), 0, ctx->stream, V, In.lethal, d_inv, ctx->d_infl_mask);
@@ -3060,9 +3070,9 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   Ctl last{};
   for (;;) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
-      ctx->err = "inflation wave exceeded the wall-clock guard"; if (d_inv) (void)hipFree(d_inv); return -1;
+      ctx->err = "inflation wave exceeded the wall-clock guard"; return -1;
     }
-    if (run_chunk<kPlannerCvp>(ctx, 1, G)) { if (d_inv) (void)hipFree(d_inv); return -1; }
+    if (run_chunk<kPlannerCvp>(ctx, 1, G)) return -1;
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
@@ -3073,7 +3083,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   }
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
   // verification: every vertex must be a fixed point of the replay rule on the converged state (k_cvp_verify)
-  if (verify_sweeps(ctx, 1)) { if (d_inv) (void)hipFree(d_inv); return -1; }
+  if (verify_sweeps(ctx, 1)) return -1;
   hipLaunchKernelGGL(k_infl_cost, dim3(gb), dim3(kBlock), 0, ctx->stream, V, L.dist, inflation_radius, inscribed_radius, inscribed_value,
                      lethal_value, cost_scaling_factor, L.cost);
   HIPCHK(hipGetLastError());
@@ -3106,7 +3116,6 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   Cnt flags{};
   HIPCHK(hipMemcpyAsync(&flags, s.cnt + 3, sizeof(Cnt), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (d_inv) (void)hipFree(d_inv);
   ctx->infl_steps = (uint32_t)(last.it < 0 ? 0 : last.it); ctx->infl_bands = last.bands; ctx->infl_evals = last.evals;
   ctx->infl_ms = ev_ms(ctx->ev[1], ctx->ev[3]); ctx->infl_ms_wave = ev_ms(ctx->ev[1], ctx->ev[2]);
   if (last.overflow) { ctx->err = "inflation wave did not converge (work-list overflow or step limit)"; return -1; }
@@ -3179,9 +3188,9 @@ int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32
     ptrs[l] = ctx->layers[layers[l]].cost;
   }
   if (ensure_edge_distances(ctx)) return -1;
-  const float** d_ptrs = nullptr; float* d_wts = nullptr;
-  HIPCHK(hipMalloc((void**)&d_ptrs, sizeof(float*) * (n_layers + 1)));
-  HIPCHK(hipMalloc((void**)&d_wts, sizeof(float) * (n_layers + 1)));
+  DevTmp<const float*> d_ptrs; DevTmp<float> d_wts;
+  HIPCHK(hipMalloc(d_ptrs.out(), sizeof(float*) * (n_layers + 1)));
+  HIPCHK(hipMalloc(d_wts.out(), sizeof(float) * (n_layers + 1)));
   int rc = 0;
   if (n_layers && hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float*) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
   if (rc == 0 && mode == 1 && n_layers && hipMemcpyAsync(d_wts, weights, sizeof(float) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
@@ -3194,7 +3203,6 @@ int mnav_combine_layers(mnav_ctx* ctx, int mode, uint32_t n_layers, const uint32
   if (rc != 0 && ctx->err.empty()) ctx->err = "layer combination failed";
   if (rc == 0) rc = edge_weight_pass(ctx, edge_cost_factor, invalid, nullptr, nullptr);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_ptrs); (void)hipFree(d_wts);
   return rc;
 }
 
@@ -3218,11 +3226,11 @@ int mnav_combine_layers_update(mnav_ctx* ctx, int mode, uint32_t n_layers, const
     if (layers[l] >= ctx->layers.size() || !ctx->layers[layers[l]].ready) { ctx->err = "layer is not resident"; return -1; }
     ptrs[l] = ctx->layers[layers[l]].cost;
   }
-  const float** d_ptrs = nullptr; float *d_wts = nullptr, *d_vals = nullptr; uint32_t* d_ids = nullptr;
-  HIPCHK(hipMalloc((void**)&d_ptrs, sizeof(float*) * (n_layers + 1)));
-  HIPCHK(hipMalloc((void**)&d_wts, sizeof(float) * (n_layers + 1)));
-  HIPCHK(hipMalloc((void**)&d_vals, sizeof(float) * n));
-  HIPCHK(hipMalloc((void**)&d_ids, sizeof(uint32_t) * n));
+  DevTmp<const float*> d_ptrs; DevTmp<float> d_wts, d_vals; DevTmp<uint32_t> d_ids;
+  HIPCHK(hipMalloc(d_ptrs.out(), sizeof(float*) * (n_layers + 1)));
+  HIPCHK(hipMalloc(d_wts.out(), sizeof(float) * (n_layers + 1)));
+  HIPCHK(hipMalloc(d_vals.out(), sizeof(float) * n));
+  HIPCHK(hipMalloc(d_ids.out(), sizeof(uint32_t) * n));
   std::vector<float> vals(n);
   int rc = 0;
   if (n_layers && hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(float*) * n_layers, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = -1;
@@ -3238,7 +3246,6 @@ int mnav_combine_layers_update(mnav_ctx* ctx, int mode, uint32_t n_layers, const
   }
   if (rc == 0 && hipMemcpyAsync(vals.data(), d_vals, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = -1;
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_ptrs); (void)hipFree(d_wts); (void)hipFree(d_vals); (void)hipFree(d_ids);
   if (rc != 0) { if (ctx->err.empty()) ctx->err = "incremental combination failed"; return rc; }
   for (uint32_t i = 0; i < n; ++i) ctx->h_cost[vertex_ids[i]] = vals[i];
   ctx->nbr_valid = ctx->crn_valid = false;                          // the cost-limit folded copies are rebuilt on the next plan
@@ -3251,6 +3258,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
 {
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
+  // goal_dist = dist[target] + offset cuts the wave off BEHIND the robot (dijkstra :296).  With a negative offset the
+  // reference stops expanding vertices it popped before the target; the engines prune with the running bound and would
+  // return a tentative target value as final -- refused rather than answered wrongly (the parameter's default is 0.3).
+  if (!(offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return MNAV_INTERNAL_ERROR; }
   ctx->cancel.store(0);                                               // dijkstra :238
   if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   want_vecmap = want_vecmap || ctx->resident_vecmap;
@@ -3486,6 +3497,7 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
 {
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
+  if (!(goal_dist_offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return MNAV_INTERNAL_ERROR; }   // see dijkstra_impl
   ctx->cancel.store(0);                                               // cvp :679
   if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }
@@ -3674,6 +3686,7 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   if (check_ready(ctx)) return -1;
   if (!ctx->shard.ready) { ctx->err = "mnav_shard_setup has not been called"; return -1; }
   if (seed_vertex >= ctx->V || target_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (!(goal_dist_offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   ctx->err.clear();
   ctx->cancel.store(0);

@@ -27,7 +27,7 @@ from typing import Callable, Sequence
 
 import numpy as np
 
-SUCCESS, CANCELED, NO_PATH_FOUND = 0, 51, 54
+SUCCESS, CANCELED, NO_PATH_FOUND, INTERNAL_ERROR = 0, 51, 54, 60
 
 
 @dataclass
@@ -59,7 +59,14 @@ def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, go
     or a numpy array, the engine decides) -- the only communication there is."""
     engine.begin(seed, target, goal_dist_offset)
     exchanges = rounds = 0
-    ctl = engine.control_buffer()                                     # 2 floats: [smallest pending wake-up, dist[target]]
+    # 3 floats: [smallest pending wake-up, dist[target], -status].  The status of every rank (0 ok, 1 cancelled, 2 error) rides
+    # on the termination reduce, so that a rank-local cancel or failure ends the plan on ALL ranks in the same exchange
+    # instead of leaving the others blocked in the next collective.
+    ctl = engine.control_buffer()
+
+    def agreed_status() -> int:
+        return int(round(-float(ctl[2])))
+
     while True:
         buf = engine.rounds(rounds_per_exchange)
         rounds += rounds_per_exchange
@@ -67,14 +74,21 @@ def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, go
         local_min, target_dist = engine.apply(buf)
         ctl[0] = local_min
         ctl[1] = target_dist
-        allreduce_min(ctl)                                            # termination: 8 bytes
+        ctl[2] = -float(getattr(engine, "status", 0))
+        allreduce_min(ctl)                                            # termination + status: 12 bytes
         exchanges += 1
+        if agreed_status():
+            return ShardedResult(CANCELED if agreed_status() == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
         gmin, gtarget = float(ctl[0]), float(ctl[1])
         if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
             break                                                     # nothing left that may still propagate
         if exchanges >= max_exchanges:
-            raise RuntimeError("sharded plan did not terminate")
-    dist_buf, pred_buf = engine.finalize()
+            raise RuntimeError("sharded plan did not terminate")      # (the count is the same on every rank)
+    dist_buf, pred_buf = engine.finalize()                            # a failing fixed-point check sets engine.status, it does not raise
+    ctl[2] = -float(getattr(engine, "status", 0))
+    allreduce_min(ctl)
+    if agreed_status():
+        return ShardedResult(CANCELED if agreed_status() == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
     if not gather:
         return ShardedResult(SUCCESS, None, None, np.zeros(0, np.uint32), exchanges, rounds)
     allreduce_min(dist_buf)                                           # every vertex has exactly one owner
@@ -97,13 +111,15 @@ class GpuShardEngine:
         self.info = ctx.shard_info()
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.buf = torch.empty(self.n, dtype=torch.float32, device=dev)
-        self.ctl = torch.empty(2, dtype=torch.float32, device=dev)
+        self.ctl = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.status = 0                                                # 0 ok, 1 cancelled, 2 error: agreed on by all ranks in run_sharded_plan
         self.dist = torch.empty(ctx.V, dtype=torch.float32, device=dev)
         # predecessors travel as int32 bit patterns (RCCL has no uint32 MIN in torch): ids < 2^31 keep their order,
         # and the neutral element 0xFFFFFFFF is -1, which MIN would prefer -> flip the sign bit around the collective
         self.pred = torch.empty(ctx.V, dtype=torch.int32, device=dev)
 
     def begin(self, seed, target, offset):
+        self.status = 0
         self.ctx.shard_begin(seed, target, offset, self.cost_limit)
 
     def control_buffer(self):
@@ -111,7 +127,11 @@ class GpuShardEngine:
 
     def rounds(self, r):
         self.torch.cuda.synchronize()
-        self.ctx.shard_rounds(r, self.buf.data_ptr())
+        try:
+            if self.ctx.shard_rounds(r, self.buf.data_ptr()) == 1:     # mnav_cancel arrived on this rank
+                self.status = max(self.status, 1)
+        except RuntimeError:
+            self.status = 2
         return self.buf
 
     def apply(self, buf):
@@ -120,7 +140,10 @@ class GpuShardEngine:
 
     def finalize(self):
         self.torch.cuda.synchronize()
-        self.ctx.shard_finalize(self.dist.data_ptr(), self.pred.data_ptr())
+        try:
+            self.ctx.shard_finalize(self.dist.data_ptr(), self.pred.data_ptr())
+        except RuntimeError:                                           # fixed-point check failed on this rank: all ranks stop together
+            self.status = 2
         self.pred ^= -2147483648            # uint32 order -> int32 order (0xFFFFFFFF becomes INT32_MAX: neutral for MIN)
         return self.dist, self.pred
 
@@ -167,8 +190,12 @@ def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offs
             lm, td = e.apply(b)
             c[0] = lm
             c[1] = td
+            c[2] = -float(getattr(e, "status", 0))
         reduce_min(ctls)
         exchanges += 1
+        if int(round(-float(ctls[0][2]))):
+            st = int(round(-float(ctls[0][2])))
+            return ShardedResult(CANCELED if st == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
         gmin, gtarget = float(ctls[0][0]), float(ctls[0][1])
         if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
             break

@@ -31,7 +31,8 @@ class ModelShardEngine:
         self.dist = np.full(self.V, np.inf, np.float32)
         self.dist[seed] = 0.0
         self.pending = True                                           # something may still propagate locally
-        self.ctl = np.zeros(2, np.float32)
+        self.ctl = np.zeros(3, np.float32)                             # [min pending, dist[target], -status]
+        self.status = 0
 
     def control_buffer(self):
         return self.ctl

@@ -6,7 +6,7 @@ import pytest
 
 from mesh_navigation_amd import capi, meshgen
 from oracle import oracle as O
-from tests.common import Case
+from tests.common import Case, terrain_case
 from tests.test_gpu_planners import assert_cvp_close, assert_dijkstra_equal
 
 pytestmark = pytest.mark.gpu
@@ -215,3 +215,14 @@ def test_paths_longer_than_the_default_rows_are_walked_again_into_exact_rows(gpu
     o = ctx.plan_dijkstra(int(seeds[1]), int(targets[1]), want_fields=False)
     assert np.array_equal(o.path, refs[1].path)
     ctx.set_dijkstra_engine("auto")
+
+
+def test_negative_goal_dist_offset_is_refused(gpu_ctx_factory):
+    case = terrain_case(64, 3)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    with pytest.raises(RuntimeError, match="goal_dist_offset"):
+        ctx.plan_dijkstra(3, 900, goal_dist_offset=-0.1)
+    with pytest.raises(RuntimeError, match="goal_dist_offset"):
+        ctx.plan_dijkstra_batch(np.array([3, 4], np.uint32), np.array([900, 901], np.uint32), goal_dist_offset=float("nan"))
+    assert ctx.plan_dijkstra(3, 900, goal_dist_offset=0.0).code == 0

@@ -90,3 +90,25 @@ def test_virtual_ranks_in_one_process_and_unreachable_target():
     res2 = sharded.plan_virtual_ranks(engines, seed, target)
     assert res2.code == ref2.code == sharded.NO_PATH_FOUND
     assert np.array_equal(res2.dist.view(np.uint32), ref2.dist.view(np.uint32))
+
+
+def test_rank_local_cancel_ends_the_plan_on_all_virtual_ranks():
+    """a status raised on ONE rank (cancel = 1, error = 2) travels with the termination reduce: every rank returns the same
+    code in the same exchange (no rank is left waiting in a collective)"""
+    from mesh_navigation_amd import meshgen, sharded
+    from tests.shard_model import ModelShardEngine
+    from tests.common import Case
+    case = Case(meshgen.terrain(48, 0.1, 5))
+    engines = [ModelShardEngine(case.mesh, case.weights, case.costs, r, 3) for r in range(3)]
+    orig = engines[1].rounds
+    calls = {"n": 0}
+
+    def cancelling_rounds(r):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            engines[1].status = 1                                       # what GpuShardEngine does when mnav_shard_rounds returns CANCELED
+        return orig(r)
+
+    engines[1].rounds = cancelling_rounds
+    res = sharded.plan_virtual_ranks(engines, case.mesh.vertex_at(0.1, 0.1), case.mesh.vertex_at(0.9, 0.9), rounds_per_exchange=2)
+    assert res.code == sharded.CANCELED and res.exchanges == 3
