@@ -71,12 +71,18 @@ public:
 private:
   uint32_t plan(const mesh_map::Vector& wave_seed, const mesh_map::Vector& wave_target, std::list<lvr2::VertexHandle>& path);
   void exportVectorMap();
+  rcl_interfaces::msg::SetParametersResult reconfigureCallback(std::vector<rclcpp::Parameter> parameters);   // dijkstra_mesh_planner.h:154
+  rclcpp::Publisher<nav_msgs::msg::Path>::SharedPtr path_pub_;                                                  // :166
+  rclcpp::node_interfaces::OnSetParametersCallbackHandle::SharedPtr reconfiguration_callback_handle_;          // :176
+  lvr2::DenseVertexMap<mesh_map::Vector> vector_map_;                                                          // :174 (host copy of the last field)
   std::shared_ptr<mesh_map::MeshMap> mesh_map_;
   std::string name_, map_frame_;
   rclcpp::Node::SharedPtr node_;
   std::atomic_bool cancel_planning_{ false };
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0;
-           bool sync_vector_map = true; } config_;   // sync_vector_map: MeshMap::setVectorMap after every plan, like the reference (:208)
+           bool sync_vector_map = true; bool publish_potential = true; } config_;
+  // sync_vector_map: MeshMap::setVectorMap after every plan, like the reference (:208); publish_potential: the "Potential"
+  // cost layer after every plan (:124).  Both cross PCIe with V-sized arrays; switched off, a plan costs the host O(path).
   std::unique_ptr<DeviceMap> dev_;
 };
 
@@ -95,11 +101,16 @@ public:
 private:
   uint32_t plan(const mesh_map::Vector& wave_seed, const mesh_map::Vector& wave_target,
                 std::list<std::pair<mesh_map::Vector, lvr2::FaceHandle>>& path, std::string& message);
+  rcl_interfaces::msg::SetParametersResult reconfigureCallback(std::vector<rclcpp::Parameter> parameters);   // cvp_mesh_planner.h:184
+  rclcpp::Publisher<nav_msgs::msg::Path>::SharedPtr path_pub_;
+  rclcpp::node_interfaces::OnSetParametersCallbackHandle::SharedPtr reconfiguration_callback_handle_;
+  lvr2::DenseVertexMap<mesh_map::Vector> vector_map_;
   std::shared_ptr<mesh_map::MeshMap> mesh_map_;
   std::string name_, map_frame_;
   rclcpp::Node::SharedPtr node_;
   std::atomic_bool cancel_planning_{ false };
-  struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; double step_width = 0.4; } config_;
+  struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; double step_width = 0.4;
+           bool publish_potential = true; } config_;
   std::unique_ptr<DeviceMap> dev_;
 };
 }  // namespace mesh_gpu_planners

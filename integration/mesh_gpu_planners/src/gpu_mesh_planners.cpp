@@ -119,6 +119,7 @@ bool GpuDijkstraMeshPlanner::initialize(const std::string& plugin_name, const st
   config_.publish_face_vectors = node_->declare_parameter(name_ + ".publish_face_vectors", config_.publish_face_vectors);
   config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);
   config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
+  config_.publish_potential = node_->declare_parameter(name_ + ".publish_potential", config_.publish_potential);
   const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
   dev_ = std::make_unique<DeviceMap>(device);
   std::string err;
@@ -126,7 +127,20 @@ bool GpuDijkstraMeshPlanner::initialize(const std::string& plugin_name, const st
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
     return false;
   }
+  path_pub_ = node_->create_publisher<nav_msgs::msg::Path>("~/path", rclcpp::QoS(1).transient_local());     // :158
+  reconfiguration_callback_handle_ = node_->add_on_set_parameters_callback(                                    // :161-162
+      std::bind(&GpuDijkstraMeshPlanner::reconfigureCallback, this, std::placeholders::_1));
   return true;
+}
+
+// dynamic reconfigure (:172-187): the cost limit; it is an argument of every device plan, nothing is re-uploaded
+rcl_interfaces::msg::SetParametersResult GpuDijkstraMeshPlanner::reconfigureCallback(std::vector<rclcpp::Parameter> parameters)
+{
+  rcl_interfaces::msg::SetParametersResult result;
+  for (const auto& parameter : parameters)
+    if (parameter.get_name() == name_ + ".cost_limit") config_.cost_limit = parameter.as_double();
+  result.successful = true;
+  return result;
 }
 
 bool GpuDijkstraMeshPlanner::cancel()                                                              // :136-140
@@ -170,10 +184,10 @@ void GpuDijkstraMeshPlanner::exportVectorMap()
   std::vector<float> vm((size_t)V * 3);
   std::vector<uint32_t> pred(V);
   if (mnav_download_output(dev_->ctx(), 0, 4, vm.data()) != 0 || mnav_download_output(dev_->ctx(), 0, 1, pred.data()) != 0) return;
-  lvr2::DenseVertexMap<mesh_map::Vector> field;
+  vector_map_.clear();
   for (uint32_t v = 0; v < V; ++v)
-    if (pred[v] != v) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(vm[3 * (size_t)v], vm[3 * (size_t)v + 1], vm[3 * (size_t)v + 2]));   // :197
-  mesh_map_->setVectorMap(field);                                                                  // :208
+    if (pred[v] != v) vector_map_.insert(lvr2::VertexHandle(v), mesh_map::Vector(vm[3 * (size_t)v], vm[3 * (size_t)v + 1], vm[3 * (size_t)v + 2]));   // :197
+  mesh_map_->setVectorMap(vector_map_);                                                            // :208
 }
 
 bool GpuDijkstraMeshPlanner::potential(std::vector<float>& out)
@@ -222,7 +236,21 @@ uint32_t GpuDijkstraMeshPlanner::makePlan(const PoseStamped& start, const PoseSt
     cost += step;
     plan_out.push_back(pose);
   }
-  // publishing of the path / potential / vector field (:118-131) is ROS I/O of the hosting node and not done here
+  // :119-131: the path, the potential as a vertex-cost layer, the vector field on request
+  nav_msgs::msg::Path path_msg;
+  path_msg.poses = plan_out;
+  path_msg.header = header;
+  path_pub_->publish(path_msg);
+  if (config_.publish_potential) {                                 // 4 bytes per vertex cross PCIe for it; off = O(path) host work per plan
+    std::vector<float> pot;
+    if (outcome == Result::SUCCESS && potential(pot)) {
+      lvr2::DenseVertexMap<float> potential_map;
+      for (uint32_t v = 0; v < pot.size(); ++v) potential_map.insert(lvr2::VertexHandle(v), pot[v]);
+      mesh_map_->publishVertexCosts(potential_map, "Potential", node_->now());
+    }
+  }
+  if (config_.publish_vector_field && outcome == Result::SUCCESS)
+    mesh_map_->publishVectorField("vector_field", vector_map_, config_.publish_face_vectors);
   return outcome;
 }
 
@@ -239,6 +267,7 @@ bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::sh
   config_.goal_dist_offset = node_->declare_parameter(name_ + ".goal_dist_offset", config_.goal_dist_offset);
   config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
   config_.step_width = node_->declare_parameter(name_ + ".step_width", config_.step_width);
+  config_.publish_potential = node_->declare_parameter(name_ + ".publish_potential", config_.publish_potential);
   const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
   dev_ = std::make_unique<DeviceMap>(device);
   std::string err;
@@ -246,7 +275,22 @@ bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::sh
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
     return false;
   }
+  path_pub_ = node_->create_publisher<nav_msgs::msg::Path>("~/path", rclcpp::QoS(1).transient_local());     // cvp :176
+  reconfiguration_callback_handle_ = node_->add_on_set_parameters_callback(                                    // :181-182
+      std::bind(&GpuCVPMeshPlanner::reconfigureCallback, this, std::placeholders::_1));
   return true;
+}
+
+// dynamic reconfigure (cvp :187-202): cost limit and back-tracking step width
+rcl_interfaces::msg::SetParametersResult GpuCVPMeshPlanner::reconfigureCallback(std::vector<rclcpp::Parameter> parameters)
+{
+  rcl_interfaces::msg::SetParametersResult result;
+  for (const auto& parameter : parameters) {
+    if (parameter.get_name() == name_ + ".cost_limit") config_.cost_limit = parameter.as_double();
+    else if (parameter.get_name() == name_ + ".step_width") config_.step_width = parameter.as_double();
+  }
+  result.successful = true;
+  return result;
 }
 
 bool GpuCVPMeshPlanner::cancel()                                                                   // :142-146
@@ -287,7 +331,8 @@ uint32_t GpuCVPMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_m
   if (code == Result::INTERNAL_ERROR) { message = mnav_last_error(dev_->ctx()); return code; }
   // MeshMap::setVectorMap (:238): the field the map's meshAhead walks on.  Present for the three seed vertices (their
   // offset from the seed position, :722-724) and for every vertex the wave updated; the device writes zeros elsewhere.
-  lvr2::DenseVertexMap<mesh_map::Vector> field;
+  lvr2::DenseVertexMap<mesh_map::Vector>& field = vector_map_;
+  field.clear();
   const auto mesh = mesh_map_->mesh();
   for (uint32_t v = 0; v < V; ++v) {
     const float* q = &vm[3 * (size_t)v];
@@ -357,6 +402,20 @@ uint32_t GpuCVPMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped
     pose.pose = goal_in_map.pose;                                  // the goal pose itself closes the plan
     plan_out.push_back(pose);
   }
+  // :125-137: the path, the potential as a vertex-cost layer, the vector field on request
+  nav_msgs::msg::Path path_msg;
+  path_msg.poses = plan_out;
+  path_msg.header = header;
+  path_pub_->publish(path_msg);
+  if (config_.publish_potential) {
+    std::vector<float> pot;
+    if ((outcome == Result::SUCCESS || outcome == Result::NO_PATH_FOUND) && potential(pot)) {
+      lvr2::DenseVertexMap<float> potential_map;
+      for (uint32_t v = 0; v < pot.size(); ++v) potential_map.insert(lvr2::VertexHandle(v), pot[v]);
+      mesh_map_->publishVertexCosts(potential_map, "Potential", header.stamp);
+    }
+  }
+  if (config_.publish_vector_field) mesh_map_->publishVectorField("vector_field", vector_map_, config_.publish_face_vectors);
   return outcome;
 }
 }  // namespace mesh_gpu_planners

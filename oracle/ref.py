@@ -120,6 +120,11 @@ def lib():
         L.ref_dijkstra_fields.argtypes = [vp, vp, vp, vp, vp]
         if hasattr(L, "ref_map_vector_map"):
             L.ref_map_vector_map.argtypes = [vp, vp, vp]
+        if hasattr(L, "ref_pub_count"):
+            L.ref_pub_count.restype = C.c_long
+            L.ref_pub_count.argtypes = [C.c_char_p]
+            L.ref_pub_last_path.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+            L.ref_pub_last_costs.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         L.ref_dijkstra_make_plan.restype = u32
         L.ref_dijkstra_make_plan.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(f64)]
         L.ref_dijkstra_cancel.argtypes = [vp]
@@ -371,6 +376,29 @@ class RefMap:
             hv = np.zeros(self.V, np.uint8)
             lib().ref_dijkstra_fields(self._h, _p(dist), _p(pred), _p(vm), _p(hv))
         return RefDijkstra(code, dist, pred, path[: n.value].copy(), vm, hv)
+
+    @staticmethod
+    def published_count(topic: str) -> int:
+        """messages the (stub) node has published on `topic` so far; -1 = no such publisher"""
+        return int(lib().ref_pub_count(topic.encode()))
+
+    def published_path(self, topic: str = "~/path"):
+        poses = np.zeros((self.V + 2, 7), np.float64)
+        n = C.c_uint32(0)
+        if not lib().ref_pub_last_path(topic.encode(), _p(poses), poses.shape[0], C.byref(n)):
+            return None
+        return poses[: n.value].copy()
+
+    def published_costs(self, name: str = "Potential"):
+        vals = np.zeros(self.V, np.float32)
+        n = C.c_uint32(0)
+        if not lib().ref_pub_last_costs(name.encode(), _p(vals), vals.shape[0], C.byref(n)):
+            return None
+        return vals[: n.value].copy()
+
+    def set_param(self, name: str, value: float) -> bool:
+        """`ros2 param set`: stores the value and fires the node's on-set-parameters callbacks"""
+        return bool(lib().ref_set_param_double(self._h, name.encode(), float(value)))
 
     def map_vector_map(self):
         """MeshMap::getVectorMap() (mesh_map.h:268): (vectors[V,3], has[V]) -- what the last planner's setVectorMap left in the map."""

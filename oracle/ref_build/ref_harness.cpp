@@ -404,6 +404,43 @@ uint32_t ref_plugin_make_plan(void* h, const double start7[7], const double goal
   for (uint32_t i = 0; i < plan.size() && i < cap; ++i) pose_to(plan[i].pose, poses + 7 * i);
   return code;
 }
+// ---- what was published (the stub publishers keep the last message per topic) ----------------------------------
+long ref_pub_count(const char* topic)
+{
+  const auto* p = rclcpp::stub_find_publisher(topic);
+  return p ? (long)p->count_ : -1;
+}
+// last nav_msgs::Path on `topic`: poses as 7 doubles each
+int ref_pub_last_path(const char* topic, double* poses, uint32_t cap, uint32_t* n)
+{
+  auto* p = dynamic_cast<rclcpp::Publisher<nav_msgs::msg::Path>*>(rclcpp::stub_find_publisher(topic));
+  if (!p || p->count_ == 0) return 0;
+  const auto& msg = p->last();
+  *n = (uint32_t)msg.poses.size();
+  for (uint32_t i = 0; i < msg.poses.size() && i < cap; ++i) {
+    const auto& q = msg.poses[i].pose;
+    double* o = poses + 7 * (size_t)i;
+    o[0] = q.position.x; o[1] = q.position.y; o[2] = q.position.z;
+    o[3] = q.orientation.x; o[4] = q.orientation.y; o[5] = q.orientation.z; o[6] = q.orientation.w;
+  }
+  return 1;
+}
+// last mesh_msgs::MeshVertexCostsStamped of ANY topic whose layer name (`type`) is `name`: the values per vertex
+int ref_pub_last_costs(const char* name, float* values, uint32_t cap, uint32_t* n)
+{
+  rclcpp::Publisher<mesh_msgs::msg::MeshVertexCostsStamped>* best = nullptr;
+  for (auto* b : rclcpp::stub_publishers()) {
+    auto* p = dynamic_cast<rclcpp::Publisher<mesh_msgs::msg::MeshVertexCostsStamped>*>(b);
+    if (!p || p->count_ == 0 || p->last().type != name) continue;
+    if (!best || p->seq_ > best->seq_) best = p;
+  }
+  if (!best) return 0;
+  const auto& c = best->last().mesh_vertex_costs.costs;
+  *n = (uint32_t)c.size();
+  for (uint32_t i = 0; i < c.size() && i < cap; ++i) values[i] = c[i];
+  return 1;
+}
+
 void ref_plugin_cancel(void* h) { auto* r = static_cast<Ref*>(h); if (r->plugin) r->plugin->cancel(); }
 void ref_plugin_release(void* h) { static_cast<Ref*>(h)->plugin.reset(); }
 

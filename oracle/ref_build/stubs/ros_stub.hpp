@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <functional>
 #include <iostream>
 #include <list>
@@ -99,7 +100,8 @@ struct MeshGeometry { };
 struct MeshGeometryStamped { std_msgs::msg::Header header; std::string uuid; MeshGeometry mesh_geometry; };
 struct MeshVertexColors { std::vector<std_msgs::msg::ColorRGBA> vertex_colors; };
 struct MeshVertexColorsStamped { std_msgs::msg::Header header; std::string uuid; MeshVertexColors mesh_vertex_colors; };
-struct MeshVertexCostsStamped { std_msgs::msg::Header header; std::string uuid; std::string type; };
+struct MeshVertexCosts { std::vector<float> costs; };
+struct MeshVertexCostsStamped { std_msgs::msg::Header header; std::string uuid; std::string type; MeshVertexCosts mesh_vertex_costs; };
 struct MeshVertexCostsSparseStamped { std_msgs::msg::Header header; std::string uuid; std::string type; };
 }
 namespace std_srvs::srv { struct Trigger { struct Request { }; struct Response { bool success = false; std::string message; }; }; }
@@ -207,19 +209,38 @@ public:
   QoS& transient_local() { return *this; }
 };
 
+// STUB publishers RECORD: the last message and a count, so that a test can look at what a planner published.  Several
+// publishers may exist for one topic (the reference planner's and a plugin's `~/path`): a look-up returns the one that
+// published last.
+struct PublisherBase
+{
+  virtual ~PublisherBase() = default;
+  std::string topic_;
+  std::size_t count_ = 0;
+  unsigned long long seq_ = 0;          // global sequence number of its last publish()
+};
+inline std::vector<PublisherBase*>& stub_publishers() { static std::vector<PublisherBase*> v; return v; }
+inline unsigned long long& stub_publish_seq() { static unsigned long long s = 0; return s; }
+inline PublisherBase* stub_find_publisher(const std::string& topic)
+{
+  PublisherBase* best = nullptr;
+  for (PublisherBase* p : stub_publishers()) if (p->topic_ == topic && (!best || p->seq_ >= best->seq_)) best = p;
+  return best;
+}
 template <typename MsgT>
-class Publisher
+class Publisher : public PublisherBase
 {
 public:
   using SharedPtr = std::shared_ptr<Publisher<MsgT>>;
-  explicit Publisher(std::string topic) : topic_(std::move(topic)) { }
-  void publish(const MsgT&) { ++count_; }
+  explicit Publisher(std::string topic) { topic_ = std::move(topic); stub_publishers().push_back(this); }
+  ~Publisher() override { auto& v = stub_publishers(); v.erase(std::remove(v.begin(), v.end(), static_cast<PublisherBase*>(this)), v.end()); }
+  void publish(const MsgT& msg) { ++count_; seq_ = ++stub_publish_seq(); last_ = msg; }
   std::size_t get_subscription_count() const { return 0; }
   std::size_t get_intra_process_subscription_count() const { return 0; }
   const char* get_topic_name() const { return topic_.c_str(); }
+  const MsgT& last() const { return last_; }
 private:
-  std::string topic_;
-  std::size_t count_ = 0;
+  MsgT last_{};
 };
 template <typename SrvT> class Service { public: using SharedPtr = std::shared_ptr<Service<SrvT>>; };
 class TimerBase { public: using SharedPtr = std::shared_ptr<TimerBase>; };

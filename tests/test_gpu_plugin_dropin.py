@@ -80,3 +80,43 @@ def test_gpu_cvp_plugin_equals_the_reference_planner_on_the_reference_map(world)
 def test_unknown_plugin_name_is_reported(world):
     _, rm, _, _ = world
     assert not rm.plugin_init("mesh_gpu_planners/NoSuchPlanner", "x")
+
+
+def test_gpu_plugins_publish_what_the_reference_publishes_and_follow_parameter_changes(world):
+    """f4: `~/path`, the "Potential" vertex-cost layer (dijkstra_mesh_planner.cpp:119-124, cvp :125-131) and the dynamic
+    cost_limit parameter (:165-187) -- through the stub node, whose publishers keep the last message."""
+    m, rm, robot, goal = world
+    # reference planner first: what it publishes for this plan
+    code_r, plan_r, _ = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    path_r = rm.published_path()
+    pot_r = rm.published_costs("Potential")
+    assert code_r == 0 and path_r is not None and pot_r is not None and len(path_r) == len(plan_r)
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra_pub")
+    code, plan, cost, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert code == 0
+    assert rm.published_count("~/path") == 1                     # the plugin's own publisher (it published last), first message
+    path = rm.published_path()
+    assert np.array_equal(path, plan) and np.array_equal(path, path_r)
+    pot = rm.published_costs("Potential")
+    assert pot is not None and pot.shape == pot_r.shape
+    fin = np.isfinite(pot_r)
+    assert np.array_equal(np.isfinite(pot), fin) and np.array_equal(pot[fin].view(np.uint32), pot_r[fin].view(np.uint32))
+    # dynamic parameter: a cost limit below the cheapest vertex makes every vertex a wall -> the plan changes to NO_PATH_FOUND
+    assert rm.set_param("gpu_dijkstra_pub.cost_limit", 1e-6)
+    code2, plan2, _, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert code2 == 54 and len(plan2) == 0
+    assert rm.set_param("gpu_dijkstra_pub.cost_limit", 1.0)
+    code3, plan3, _, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert code3 == 0 and np.array_equal(plan3, plan)
+    rm.plugin_release()
+    # CVP: path + potential published, step_width follows the parameter
+    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_pub", step_width=0.3)
+    gq = (0, 0, np.sin(0.3), np.cos(0.3))
+    c, p, k, msg = rm.plugin_make_plan(pose(robot), pose(goal, gq))
+    assert c == 0, msg
+    assert np.array_equal(rm.published_path(), p)
+    assert rm.published_costs("Potential") is not None
+    assert rm.set_param("gpu_cvp_pub.step_width", 0.15)
+    c2, p2, _, _ = rm.plugin_make_plan(pose(robot), pose(goal, gq))
+    assert c2 == 0 and len(p2) > 1.5 * len(p)                       # half the step width: about twice the poses
+    rm.plugin_release()
