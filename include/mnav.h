@@ -262,6 +262,23 @@ int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
 int mnav_set_resident_outputs(mnav_ctx* ctx, int on);
 int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out);
 int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const float bary[3], float out[3]);
+/* CVPMeshPlanner's back-tracking over the vector field (cvp_mesh_planner.cpp:920-951: MeshMap::meshAhead mesh_map.cpp
+ * :1070-1108 with projectedBarycentricCoords util.cpp:320-347, searchNeighbourFaces mesh_map.cpp:999-1068,
+ * directionAtPosition :625-650 and InflationLayer::vectorAt inflation_layer.cpp:493-521) on the vector maps the last
+ * mnav_plan_cvp(_batch) call left resident (mnav_set_resident_outputs, or a vecmap_out buffer): plan i walks from
+ * target_pos/target_face (the robot) until it is within step_width of seed_pos/seed_face (the goal).  inflation_layer: a
+ * layer computed by mnav_layer_inflation whose repulsive field is added to every step, or -1.  Row i of positions_out
+ * (cap*3 floats) / faces_out (cap) receives n_out[i] entries in the reference's list order (seed first); status_out[i] =
+ * 1 reached the seed, 0 no path (the walk left the field or the mesh, or ran into `cap`), -1 a face of the walk has a
+ * vertex without an inflation entry (lvr2 panics there), -2 internal list overflow.  The same float32 operations in the
+ * same order as the host: positions are bit-identical.  Returns 0, or -1 with mnav_last_error set (then nothing was
+ * walked).  The single-plan form returns the status; -1 with a non-empty mnav_last_error is an argument/device error. */
+int mnav_backtrack_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const uint32_t* seed_faces, const float* target_pos,
+                             const uint32_t* target_faces, double step_width, int32_t inflation_layer, uint32_t cap,
+                             float* positions_out, uint32_t* faces_out, uint32_t* n_out, int32_t* status_out);
+int mnav_backtrack_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_face, const float target_pos[3], uint32_t target_face,
+                       double step_width, int32_t inflation_layer, uint32_t cap, float* positions_out, uint32_t* faces_out,
+                       uint32_t* n_out);
 /* Device pointers of the last plan's resident outputs (slot = plan index in a batch):
  * what = 0 dist, 1 pred, 2 direction, 3 cutface, 4 vecmap.  NULL if not available -- in particular dist / pred after a
  * paths-only Dijkstra call (no dist_out / pred_out / vector map asked for): such a call runs no finalize pass, values

@@ -110,7 +110,9 @@ private:
   rclcpp::Node::SharedPtr node_;
   std::atomic_bool cancel_planning_{ false };
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; double step_width = 0.4;
-           bool publish_potential = true; } config_;
+           bool publish_potential = true; bool sync_vector_map = true; bool device_backtracking = false; int device_inflation_layer = -1; } config_;
+  // device_backtracking: the walk over the vector field (cvp :920-951) runs on the device (mnav_backtrack_cvp); with
+  // sync_vector_map and publish_vector_field off as well, nothing V-sized crosses PCIe per plan.
   std::unique_ptr<DeviceMap> dev_;
 };
 }  // namespace mesh_gpu_planners

@@ -268,6 +268,9 @@ bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::sh
   config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
   config_.step_width = node_->declare_parameter(name_ + ".step_width", config_.step_width);
   config_.publish_potential = node_->declare_parameter(name_ + ".publish_potential", config_.publish_potential);
+  config_.sync_vector_map = node_->declare_parameter(name_ + ".sync_vector_map", config_.sync_vector_map);
+  config_.device_backtracking = node_->declare_parameter(name_ + ".device_backtracking", config_.device_backtracking);
+  config_.device_inflation_layer = (int)node_->declare_parameter(name_ + ".device_inflation_layer", config_.device_inflation_layer);
   const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
   dev_ = std::make_unique<DeviceMap>(device);
   std::string err;
@@ -275,6 +278,7 @@ bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::sh
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
     return false;
   }
+  if (config_.device_backtracking) mnav_set_resident_outputs(dev_->ctx(), 1);   // the field stays in HBM for mnav_backtrack_cvp
   path_pub_ = node_->create_publisher<nav_msgs::msg::Path>("~/path", rclcpp::QoS(1).transient_local());     // cvp :176
   reconfiguration_callback_handle_ = node_->add_on_set_parameters_callback(                                    // :181-182
       std::bind(&GpuCVPMeshPlanner::reconfigureCallback, this, std::placeholders::_1));
@@ -323,27 +327,52 @@ uint32_t GpuCVPMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_m
   std::string err;
   if (!dev_->syncCosts(*mesh_map_, err)) { message = err; return Result::INTERNAL_ERROR; }
   const uint32_t V = dev_->numVertices();
-  std::vector<float> vm((size_t)V * 3);
+  // the V-sized field crosses PCIe only when someone on the host reads it: the map (setVectorMap, the controller's
+  // directionAtPosition), the vector-field publisher, or the host back-tracking below
+  const bool field_to_host = config_.sync_vector_map || config_.publish_vector_field || !config_.device_backtracking;
+  std::vector<float> vm(field_to_host ? (size_t)V * 3 : 0);
   const float seed_pos[3] = { seed.x, seed.y, seed.z };
   const uint32_t code = mnav_plan_cvp(dev_->ctx(), seed_pos, seed_face.idx(), target_face.idx(), config_.goal_dist_offset, config_.cost_limit,
-                                      nullptr, nullptr, nullptr, nullptr, vm.data());              // only the vector map comes back
+                                      nullptr, nullptr, nullptr, nullptr, field_to_host ? vm.data() : nullptr);   // only the vector map comes back
   if (code == Result::CANCELED) return code;
   if (code == Result::INTERNAL_ERROR) { message = mnav_last_error(dev_->ctx()); return code; }
-  // MeshMap::setVectorMap (:238): the field the map's meshAhead walks on.  Present for the three seed vertices (their
-  // offset from the seed position, :722-724) and for every vertex the wave updated; the device writes zeros elsewhere.
-  lvr2::DenseVertexMap<mesh_map::Vector>& field = vector_map_;
-  field.clear();
-  const auto mesh = mesh_map_->mesh();
-  for (uint32_t v = 0; v < V; ++v) {
-    const float* q = &vm[3 * (size_t)v];
-    if (q[0] != 0.f || q[1] != 0.f || q[2] != 0.f) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(q[0], q[1], q[2]));
+  if (field_to_host) {
+    // MeshMap::setVectorMap (:238): the field the map's meshAhead walks on.  Present for the three seed vertices (their
+    // offset from the seed position, :722-724) and for every vertex the wave updated; the device writes zeros elsewhere.
+    lvr2::DenseVertexMap<mesh_map::Vector>& field = vector_map_;
+    field.clear();
+    const auto mesh = mesh_map_->mesh();
+    for (uint32_t v = 0; v < V; ++v) {
+      const float* q = &vm[3 * (size_t)v];
+      if (q[0] != 0.f || q[1] != 0.f || q[2] != 0.f) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(q[0], q[1], q[2]));
+    }
+    for (const auto vH : mesh->getVerticesOfFace(seed_face)) {
+      const float* q = &vm[3 * (size_t)vH.idx()];
+      field.insert(vH, mesh_map::Vector(q[0], q[1], q[2]));
+    }
+    mesh_map_->setVectorMap(field);
   }
-  for (const auto vH : mesh->getVerticesOfFace(seed_face)) {
-    const float* q = &vm[3 * (size_t)vH.idx()];
-    field.insert(vH, mesh_map::Vector(q[0], q[1], q[2]));
-  }
-  mesh_map_->setVectorMap(field);
   if (code == Result::NO_PATH_FOUND) { message = "Predecessor of the goal is not set! No path found!"; return code; }   // :912-918
+  if (config_.device_backtracking) {
+    // :920-951 on the device (mnav_backtrack_cvp): the same float32 walk over the field resident in HBM, O(path) bytes
+    // back.  The layers' vectorAt (mesh_map.cpp:1099-1102) is the device's own inflation layer (device_inflation_layer,
+    // computed by mnav_layer_inflation) or none: a host-side layer plugin's private field is not reachable from here.
+    const uint32_t cap = 1u << 16;
+    std::vector<float> pp((size_t)cap * 3);
+    std::vector<uint32_t> pf(cap);
+    uint32_t n = 0;
+    const float target_pos[3] = { target.x, target.y, target.z };
+    const int st = mnav_backtrack_cvp(dev_->ctx(), seed_pos, seed_face.idx(), target_pos, target_face.idx(), config_.step_width,
+                                      config_.device_inflation_layer, cap, pp.data(), pf.data(), &n);
+    const char* derr = mnav_last_error(dev_->ctx());
+    if (st < 0 && derr && *derr) { message = derr; return Result::INTERNAL_ERROR; }
+    for (uint32_t i = n; i-- > 0;)                                    // rows come seed first; push_front from the robot's end
+      path.push_front(std::make_pair(mesh_map::Vector(pp[3 * (size_t)i], pp[3 * (size_t)i + 1], pp[3 * (size_t)i + 2]), lvr2::FaceHandle(pf[i])));
+    if (st == -1) { message = "Could not find a valid path, while back-tracking from the goal: HalfEdgeMesh panicked!"; return Result::NO_PATH_FOUND; }
+    if (st != 1) { message = "Could not find a valid path, while back-tracking from the goal"; return Result::NO_PATH_FOUND; }
+    if (cancel_planning_) return Result::CANCELED;
+    return Result::SUCCESS;
+  }
   lvr2::FaceHandle face = target_face;                                                             // :920-951
   mesh_map::Vector pos = target;
   path.push_front(std::make_pair(pos, face));

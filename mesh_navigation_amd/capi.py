@@ -24,7 +24,7 @@ SYMBOLS = [
     "mnav_cancel", "mnav_get_stats", "mnav_get_timing", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
-    "mnav_vector_at", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
+    "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
 ]
 
@@ -113,6 +113,10 @@ def load(path: str | None = None):
     L.mnav_set_resident_outputs.argtypes = [vp, C.c_int]
     L.mnav_download_output.restype = C.c_int
     L.mnav_download_output.argtypes = [vp, u32, C.c_int, vp]
+    L.mnav_backtrack_cvp_batch.restype = C.c_int
+    L.mnav_backtrack_cvp_batch.argtypes = [vp, u32, vp, vp, vp, vp, C.c_double, C.c_int32, u32, vp, vp, vp, vp]
+    L.mnav_backtrack_cvp.restype = C.c_int
+    L.mnav_backtrack_cvp.argtypes = [vp, vp, u32, vp, u32, C.c_double, C.c_int32, u32, vp, vp, vp]
     L.mnav_vector_at.restype = C.c_int
     L.mnav_vector_at.argtypes = [vp, u32, vp, vp, vp]
     L.mnav_update_costs.restype = C.c_int
@@ -287,6 +291,26 @@ class MnavContext:
         if rc < 0:
             raise RuntimeError(f"mnav_vector_at failed: {self._err()}")
         return out if rc == 1 else None
+
+    def backtrack_cvp_batch(self, seed_pos, seed_faces, target_pos, target_faces, step_width: float = 0.4, inflation_layer: int = -1,
+                            cap: int = 4096):
+        """CVPMeshPlanner's back-tracking (cvp_mesh_planner.cpp:920-951) on the resident vector maps of the last CVP call:
+        list of (status, positions[n,3], faces[n]) per plan, reference list order (seed first); status 1 = reached."""
+        sp, tp = _f32(seed_pos).reshape(-1, 3), _f32(target_pos).reshape(-1, 3)
+        sf, tf = _u32(seed_faces).reshape(-1), _u32(target_faces).reshape(-1)
+        n = sf.shape[0]
+        pos = np.empty((n, cap, 3), np.float32)
+        face = np.empty((n, cap), np.uint32)
+        cnt = np.zeros(n, np.uint32)
+        st = np.zeros(n, np.int32)
+        rc = self._L.mnav_backtrack_cvp_batch(self._h, n, _p(sp), _p(sf), _p(tp), _p(tf), float(step_width), int(inflation_layer), int(cap),
+                                              _p(pos), _p(face), _p(cnt), _p(st))
+        if rc != 0:
+            raise RuntimeError(f"mnav_backtrack_cvp_batch failed ({rc}): {self._err()}")
+        return [(int(st[i]), pos[i, : cnt[i]].copy(), face[i, : cnt[i]].copy()) for i in range(n)]
+
+    def backtrack_cvp(self, seed_pos, seed_face, target_pos, target_face, step_width: float = 0.4, inflation_layer: int = -1, cap: int = 4096):
+        return self.backtrack_cvp_batch([seed_pos], [seed_face], [target_pos], [target_face], step_width, inflation_layer, cap)[0]
 
     def update_costs(self, vertex_ids, values):
         """Incremental cost change (layerChanged + updateEdgeWeights(changed)) on the device."""

@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(kBlock) void k_vecmap_cvp(const Plan* __restrict__ 
       const float nx = nrm[3 * (size_t)v], ny = nrm[3 * (size_t)v + 1], nz = nrm[3 * (size_t)v + 2];
       // rotated(normal, direction) :234 -- Rodrigues (CONVENTION, lvr2 un-vendored; see oracle)
       const float ang = P.dirn[v];
-      const float c = cosf(ang), s = sinf(ang);
+      const float c = cosf_ref(ang), s = sinf_ref(ang);   // the host libm's bits (mnav_eval.h): the field is the reference's bit for bit
       const float cx = ny * dz - nz * dy, cy = nz * dx - nx * dz, cz = nx * dy - ny * dx;
       const float ndv = nx * dx + ny * dy + nz * dz;
       const float k = ndv * (1.0f - c);
@@ -1878,6 +1878,29 @@ __global__ __launch_bounds__(kBlock) void k_combine_resident_ids(uint32_t n, con
 // ---------------------------------------------------------------------------------------------
 }  // namespace
 #include "mnav_tb.h"
+#include "mnav_walk.h"
+
+// One back-tracking job: the plan's resident vector map and the two ends of the walk.
+struct WalkJob { const float* vecmap; float seed[3]; uint32_t seed_face; float target[3]; uint32_t target_face; };
+
+// CVPMeshPlanner's back-tracking (cvp_mesh_planner.cpp:920-951) on the resident vector map: one workgroup per plan, its
+// first lane walks (the loop is a dependent chain: each step needs the position the previous one produced), the face list
+// of searchNeighbourFaces lives in LDS.  ctl[2*j] = walk status, ctl[2*j+1] = entries written (walk order, target first).
+__global__ __launch_bounds__(64) void k_backtrack(WalkMesh M, WalkInflation L, const WalkJob* __restrict__ jobs, double step_width, uint32_t cap,
+                                                  float* __restrict__ pos_out, uint32_t* __restrict__ face_out, int32_t* __restrict__ ctl)
+{
+  __shared__ uint32_t list[kWalkListCap];
+  if (threadIdx.x != 0) return;
+  const uint32_t j = blockIdx.x;
+  const WalkJob J = jobs[j];
+  WalkField Fd;
+  Fd.vecmap = J.vecmap;
+  for (int k = 0; k < 3; ++k) Fd.seed_vs[k] = M.faces[3 * (size_t)J.seed_face + k];
+  uint32_t n = 0;
+  const int st = walk_backtrack(M, Fd, L, w3(J.seed[0], J.seed[1], J.seed[2]), J.seed_face, w3(J.target[0], J.target[1], J.target[2]), J.target_face,
+                                step_width, cap, pos_out + 3 * (size_t)cap * j, face_out + (size_t)cap * j, &n, list);
+  ctl[2 * j] = st; ctl[2 * j + 1] = (int32_t)n;
+}
 namespace {
 
 struct Slot {
@@ -1915,6 +1938,10 @@ struct mnav_ctx {
   bool resident_vecmap = false;        // mnav_set_resident_outputs: always compute the vector map, leave it on the device
   std::vector<uint32_t> caller_slot;   // plan index of the caller's batch -> device slot of the last call (kNone: never ran)
   std::vector<uint32_t> h_faces;
+  std::vector<uint32_t> h_vf_ptr, h_vf;    // getFacesOfVertex rows (host copy; uploaded on the first device back-tracking call)
+  uint32_t *d_faces = nullptr, *d_vf_ptr = nullptr, *d_vf = nullptr; bool walk_mesh_valid = false;
+  float* d_walk_pos = nullptr; uint32_t* d_walk_face = nullptr; size_t walk_cap = 0;   // k_backtrack outputs: rows of `cap` entries
+  struct WalkJob* d_walk_jobs = nullptr; int32_t* d_walk_ctl = nullptr; uint32_t walk_jobs_cap = 0;
   std::vector<uint8_t> h_invalid;
   bool have_mesh = false, have_costs = false, have_normals = false;
   // device mesh
@@ -1971,7 +1998,8 @@ struct mnav_ctx {
   double edge_cost_factor = 0.0;                                   // factor of the resident edge weights (mnav_update_costs)
   // layers computed / kept on the device (mnav_layer_*)
   struct Layer { float* cost = nullptr; uint8_t* lethal = nullptr; float* dist = nullptr; float* vec = nullptr; uint8_t* vstate = nullptr;   // vstate: 3 x V (two state arrays + the accumulate flags)
-                 bool ready = false, have_vec = false; };
+                 bool ready = false, have_vec = false;
+                 double inflation_radius = 0, inscribed_radius = 0, inscribed_value = 0, lethal_value = 0; };   // InflationLayer config (vectorAt reads it)
   std::vector<Layer> layers;
   Corner* d_crn_infl = nullptr; bool crn_infl_valid = false;       // corners over the edge distances (inflation wave)
   uint8_t *d_infl_mask = nullptr, *d_zero_u8 = nullptr;
@@ -2674,6 +2702,8 @@ void mnav_destroy(mnav_ctx* ctx)
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->evc) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_ctl_pool); (void)hipFree(ctx->d_tctl_pool);
+  (void)hipFree(ctx->d_faces); (void)hipFree(ctx->d_vf_ptr); (void)hipFree(ctx->d_vf); (void)hipFree(ctx->d_walk_pos); (void)hipFree(ctx->d_walk_face);
+  (void)hipFree(ctx->d_walk_jobs); (void)hipFree(ctx->d_walk_ctl);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -2736,6 +2766,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   ctx->h_xyz.assign(xyz, xyz + 3 * (size_t)V);
   ctx->h_faces.assign(face_vtx, face_vtx + 3 * (size_t)F);
   ctx->h_row_ptr = t.row_ptr; ctx->h_nbr_u = t.nbr_u;
+  ctx->h_vf_ptr = std::move(t.vf_ptr); ctx->h_vf = std::move(t.vf); ctx->walk_mesh_valid = false;
   tb_free(ctx);
   if (dev_upload(ctx, &ctx->d_row_ptr, t.row_ptr.data(), t.row_ptr.size())) return -1;
   if (dev_upload(ctx, &ctx->d_nbr_u, t.nbr_u.data(), t.nbr_u.size())) return -1;
@@ -3037,6 +3068,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   if (invalid) { HIPCHK(hipMalloc(d_inv.out(), Vn)); HIPCHK(hipMemcpyAsync(d_inv, invalid, V, hipMemcpyHostToDevice, ctx->stream)); }
   mnav_ctx::Layer& L = ctx->layers[layer];
   mnav_ctx::Layer& In = ctx->layers[input_layer];
+  L.inflation_radius = inflation_radius; L.inscribed_radius = inscribed_radius; L.inscribed_value = inscribed_value; L.lethal_value = lethal_value;
   hipLaunchKernelGGL(k_infl_mask, dim3(gb), dim3(kBlock), 0, ctx->stream, V, In.lethal, d_inv, ctx->d_infl_mask);
   HIPCHK(hipMemcpyAsync(L.lethal, In.lethal, V, hipMemcpyDeviceToDevice, ctx->stream));    // lethal_vertices_ = input->lethals() :170,:584
   if (ensure_slots(ctx, 1, true, true, false)) return -1;
@@ -3931,6 +3963,91 @@ int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const flo
   if (!any || !(std::isfinite(acc[0]) && std::isfinite(acc[1]) && std::isfinite(acc[2]))) return 0;   // :639-646
   out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
   return 1;
+}
+
+// f3 of SURVEY.md section 8: the consumer of the CVP vector field on the device.  Plan i of the last mnav_plan_cvp(_batch)
+// call is walked from its target (the robot) back to its seed (the goal) over the vector map resident in HBM; what
+// crosses PCIe is the path, not the 12 B/vertex field.
+int mnav_backtrack_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const uint32_t* seed_faces, const float* target_pos,
+                             const uint32_t* target_faces, double step_width, int32_t inflation_layer, uint32_t cap, float* positions_out,
+                             uint32_t* faces_out, uint32_t* n_out, int32_t* status_out)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!n) return 0;
+  if (!seed_pos || !seed_faces || !target_pos || !target_faces || !positions_out || !faces_out || !n_out || !status_out) { ctx->err = "null argument"; return -1; }
+  if (cap < 2 || (uint64_t)cap * n > (1ull << 28)) { ctx->err = "path capacity out of range"; return -1; }
+  if (!(step_width > 0.0)) { ctx->err = "step_width must be positive"; return -1; }   // a zero step never leaves the start
+  if (ctx->last_planner != kPlannerCvp) { ctx->err = "back-tracking: the last call was not a CVP plan"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  std::vector<WalkJob> jobs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* vm = static_cast<const float*>(mnav_device_output(ctx, i, 4));
+    if (!vm) { ctx->err = "vector map not resident (mnav_set_resident_outputs, or pass vecmap_out to the plan call)"; return -1; }
+    if (seed_faces[i] >= ctx->F || target_faces[i] >= ctx->F) { ctx->err = "face id out of range"; return -1; }
+    jobs[i].vecmap = vm; jobs[i].seed_face = seed_faces[i]; jobs[i].target_face = target_faces[i];
+    for (int k = 0; k < 3; ++k) { jobs[i].seed[k] = seed_pos[3 * (size_t)i + k]; jobs[i].target[k] = target_pos[3 * (size_t)i + k]; }
+  }
+  WalkInflation L{};
+  if (inflation_layer >= 0) {
+    if ((size_t)inflation_layer >= ctx->layers.size() || !ctx->layers[inflation_layer].ready || !ctx->layers[inflation_layer].dist || !ctx->layers[inflation_layer].have_vec) {
+      ctx->err = "back-tracking: not a resident inflation layer with a vector field"; return -1;
+    }
+    const mnav_ctx::Layer& Ly = ctx->layers[inflation_layer];
+    L.distances = Ly.dist; L.vectors = Ly.vec; L.has_vector = Ly.vstate;
+    L.inflation_radius = Ly.inflation_radius; L.inscribed_radius = Ly.inscribed_radius; L.inscribed_value = Ly.inscribed_value; L.lethal_value = Ly.lethal_value;
+    L.repulsive_field = 1;
+  }
+  if (!ctx->walk_mesh_valid) {
+    if (dev_upload(ctx, &ctx->d_faces, ctx->h_faces.data(), ctx->h_faces.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_vf_ptr, ctx->h_vf_ptr.data(), ctx->h_vf_ptr.size())) return -1;
+    if (dev_upload(ctx, &ctx->d_vf, ctx->h_vf.data(), ctx->h_vf.size())) return -1;
+    ctx->walk_mesh_valid = true;
+  }
+  const size_t need = (size_t)cap * n;
+  if (need > ctx->walk_cap) {
+    (void)hipFree(ctx->d_walk_pos); (void)hipFree(ctx->d_walk_face); ctx->d_walk_pos = nullptr; ctx->d_walk_face = nullptr; ctx->walk_cap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_walk_pos, 12 * need)); HIPCHK(hipMalloc((void**)&ctx->d_walk_face, 4 * need));
+    ctx->walk_cap = need;
+  }
+  if (n > ctx->walk_jobs_cap) {
+    (void)hipFree(ctx->d_walk_jobs); (void)hipFree(ctx->d_walk_ctl); ctx->d_walk_jobs = nullptr; ctx->d_walk_ctl = nullptr; ctx->walk_jobs_cap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_walk_jobs, sizeof(WalkJob) * (size_t)n)); HIPCHK(hipMalloc((void**)&ctx->d_walk_ctl, 8 * (size_t)n));
+    ctx->walk_jobs_cap = n;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_walk_jobs, jobs.data(), sizeof(WalkJob) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  WalkMesh M{ ctx->d_xyz, ctx->d_faces, ctx->d_vf_ptr, ctx->d_vf, ctx->V, ctx->F };
+  hipLaunchKernelGGL(k_backtrack, dim3(n), dim3(64), 0, ctx->stream, M, L, ctx->d_walk_jobs, step_width, cap, ctx->d_walk_pos, ctx->d_walk_face, ctx->d_walk_ctl);
+  HIPCHK(hipGetLastError());
+  std::vector<int32_t> ctl(2 * (size_t)n);
+  HIPCHK(hipMemcpyAsync(ctl.data(), ctx->d_walk_ctl, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = 0; i < n; ++i) {                                  // the walked entries only: O(path) bytes per plan
+    const uint32_t m = (uint32_t)ctl[2 * (size_t)i + 1];
+    if (m) {
+      HIPCHK(hipMemcpyAsync(positions_out + 3 * (size_t)cap * i, ctx->d_walk_pos + 3 * (size_t)cap * i, 12 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(faces_out + (size_t)cap * i, ctx->d_walk_face + (size_t)cap * i, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t m = (uint32_t)ctl[2 * (size_t)i + 1];
+    float* pp = positions_out + 3 * (size_t)cap * i; uint32_t* pf = faces_out + (size_t)cap * i;
+    for (uint32_t a = 0, b = m ? m - 1 : 0; a < b; ++a, --b) {        // the reference push_front()s: list order is seed first
+      for (int k = 0; k < 3; ++k) std::swap(pp[3 * (size_t)a + k], pp[3 * (size_t)b + k]);
+      std::swap(pf[a], pf[b]);
+    }
+    n_out[i] = m; status_out[i] = ctl[2 * (size_t)i];
+  }
+  return 0;
+}
+
+int mnav_backtrack_cvp(mnav_ctx* ctx, const float seed_pos[3], uint32_t seed_face, const float target_pos[3], uint32_t target_face, double step_width,
+                       int32_t inflation_layer, uint32_t cap, float* positions_out, uint32_t* faces_out, uint32_t* n_out)
+{
+  int32_t status = 0;
+  const int rc = mnav_backtrack_cvp_batch(ctx, 1, seed_pos, &seed_face, target_pos, &target_face, step_width, inflation_layer, cap, positions_out, faces_out, n_out, &status);
+  return rc < 0 ? rc : status;
 }
 
 uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx)

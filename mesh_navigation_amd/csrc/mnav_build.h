@@ -33,6 +33,9 @@ struct HostTopology {
   // face comes up twice): 6 x 5 bits {v1: first, second; v2: first, second; the row's own vertex: first, second};
   // kWalkUnknown when a vertex has too many neighbours for 5 bits (the repulsive field is then not computed there)
   std::vector<uint32_t> crn_walk;
+  // getFacesOfVertex rows the corner flags were derived from (the caller's or the half-edge replay): the order
+  // MeshMap::searchNeighbourFaces expands faces in (mesh_map.cpp:1048-1049), read by the device back-tracking
+  std::vector<uint32_t> vf_ptr, vf;   // V+1, 3F
 };
 constexpr uint32_t kWalkUnknown = 0xFFFFFFFFu;
 inline uint32_t walk_pos(uint32_t walk, int slot) { return (walk >> (5 * slot)) & 31u; }   // slot 0..5
@@ -378,6 +381,8 @@ inline HostTopology build_topology(uint32_t V, uint32_t F, uint32_t E, const uin
       }
     }
   }
+  if (circ == &own) { t.vf_ptr = std::move(own.ptr); t.vf = std::move(own.faces); }
+  else { t.vf_ptr = circ->ptr; t.vf = circ->faces; }
   return t;
 }
 

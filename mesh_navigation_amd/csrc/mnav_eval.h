@@ -105,6 +105,62 @@ MNAV_HD float acosf_ref(float x)
   const float w = r * s + c;
   return 2.0f * (df + w);
 }
+// cosf as the reference's host computes it (InflationLayer::vectorAt, inflation_layer.cpp:509: `cos(alpha)` on a float,
+// read by MeshMap::meshAhead while the CVP planner walks its path).  glibc 2.35's routine (sysdeps/ieee754/flt-32/s_cosf.c
+// with s_sincosf.h: quadrant reduction and two degree-8 polynomials in double, the x86-64 build with fused multiply-adds)
+// restated operation by operation.  Checked against this host's libm on every float of [0, 120): identical bits; the
+// variant without fused operations (a host without FMA) differs on 11 arguments, all beyond 17 rad -- outside what
+// vectorAt can produce (alpha <= (sqrt(inflation_radius) - inscribed_radius) / (inflation_radius - inscribed_radius) * pi).
+// |x| >= 120, infinities and NaNs are not restated (the caller never produces them): they return NaN.
+namespace sincosf_ref_detail {
+// s_sincosf.h: sinf_poly (n even: sine of x, odd: cosine; `flip` = the second table entry, whose cosine coefficients are negated)
+MNAV_HD float poly(double x, double x2, int n, double flip)
+{
+  const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+  const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+  if ((n & 1) == 0) {
+    const double x3 = x * x2, t1 = fma(x2, s3, s2), x7 = x3 * x2, s = fma(x3, s1, x);
+    return (float)fma(x7, t1, s);
+  }
+  const double x4 = x2 * x2, q2 = fma(x2, flip * c4, flip * c3), q1 = fma(x2, flip * c1, flip * c0), x6 = x4 * x2, c = fma(x4, flip * c2, q1);
+  return (float)fma(x6, q2, c);
+}
+// reduce_fast + the sign / table selection of s_sinf.c / s_cosf.c; `odd` = 1 for the cosine (n ^ 1)
+MNAV_HD float reduced(double x, int odd)
+{
+  const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+  const double r = x * hpi_inv;
+  const int n = ((int32_t)r + 0x800000) >> 24;                      // quadrant, rounded to nearest
+  x = fma(-(double)n, hpi, x);
+  const double sgn = (((n & 3) == 1) || ((n & 3) == 2)) ? -1.0 : 1.0;   // sign table {1, -1, -1, 1}
+  return poly(x * sgn, x * x, n ^ odd, (n & 2) ? -1.0 : 1.0);
+}
+}  // namespace sincosf_ref_detail
+
+MNAV_HD float cosf_ref(float y)
+{
+  const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
+  const double x = (double)y;
+  if (top < ((0x3f490fdbu >> 20) & 0x7ffu)) {                       // |y| below pi/4 (compared on the top 12 bits, as s_cosf.c does)
+    if (top < ((0x39800000u >> 20) & 0x7ffu)) return 1.0f;          // |y| < 2^-12
+    return sincosf_ref_detail::poly(x, x * x, 1, 1.0);
+  }
+  if (!(top < ((0x42f00000u >> 20) & 0x7ffu))) return u2f(0x7fc00000u);
+  return sincosf_ref_detail::reduced(x, 1);
+}
+// sinf likewise (s_sinf.c; CVPMeshPlanner's vector map rotates by the cut-face angle, cvp_mesh_planner.cpp:234): identical
+// bits to this host's libm on every float of (-120, 120), checked the same way.
+MNAV_HD float sinf_ref(float y)
+{
+  const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
+  const double x = (double)y;
+  if (top < ((0x3f490fdbu >> 20) & 0x7ffu)) {
+    if (top < ((0x39800000u >> 20) & 0x7ffu)) return y;
+    return sincosf_ref_detail::poly(x, x * x, 0, 1.0);
+  }
+  if (!(top < ((0x42f00000u >> 20) & 0x7ffu))) return u2f(0x7fc00000u);
+  return sincosf_ref_detail::reduced(x, 0);
+}
 MNAV_HD float inf_f() { return u2f(0x7f800000u); }
 MNAV_HD float next_up(float x) { return (x >= 0.0f) ? u2f(f2u(x) + 1u) : u2f(f2u(x) - 1u); }  // finite x
 

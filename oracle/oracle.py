@@ -402,6 +402,12 @@ def model_lib():
                              C.c_float, C.c_int, u32, vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
         L.sm_acosf_ref.restype = C.c_float
         L.sm_acosf_ref.argtypes = [C.c_float]
+        L.sm_cosf_ref.restype = C.c_float
+        L.sm_cosf_ref.argtypes = [C.c_float]
+        L.sm_sinf_ref.restype = C.c_float
+        L.sm_sinf_ref.argtypes = [C.c_float]
+        L.sm_backtrack.restype = C.c_int
+        L.sm_backtrack.argtypes = [u32, u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, C.c_double, u32, vp, vp, vp, C.c_int, vp, vp, C.POINTER(u32)]
         L.sm_infl_candidate.restype = C.c_float
         L.sm_infl_candidate.argtypes = [C.c_float] * 6 + [C.POINTER(C.c_int)]
         L.sm_run_inflation.restype = u32
@@ -436,6 +442,38 @@ def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
 def product_acosf(x) -> float:
     """mnav_eval.h acosf_ref: the device's restatement of the host libm's acosf (SteepnessLayer)."""
     return float(model_lib().sm_acosf_ref(float(x)))
+
+
+def product_cosf(x) -> float:
+    """mnav_eval.h cosf_ref: the device's restatement of the host libm's cosf (InflationLayer::vectorAt)."""
+    return float(model_lib().sm_cosf_ref(float(x)))
+
+
+def product_sinf(x) -> float:
+    """mnav_eval.h sinf_ref (CVP vector map rotation, cvp_mesh_planner.cpp:234)."""
+    return float(model_lib().sm_sinf_ref(float(x)))
+
+
+def product_backtrack(xyz, faces, vf_ptr, vf, vecmap, seed_pos, seed_face, target_pos, target_face, step_width=0.4,
+                      inflation_field=None, cap=100000):
+    """mnav_walk.h (the arithmetic of the device kernel k_backtrack) on host arrays: (status, positions, faces) in the
+    reference's list order (seed first), like MeshOracle.cvp_backtrack."""
+    xyz, vm = _f32(xyz), _f32(vecmap)
+    faces, vf_ptr, vf = _u32(faces), _u32(vf_ptr), _u32(vf)
+    pos = np.empty((cap, 3), dtype=np.float32)
+    face = np.empty(cap, dtype=np.uint32)
+    n = C.c_uint32(0)
+    d = v = cfg = None
+    rep = 0
+    if inflation_field is not None:
+        d0, v0, c, rep = inflation_field
+        d, v = _f32(d0), _f32(v0)
+        cfg = np.array([c.inflation_radius, c.inscribed_radius, c.inscribed_value, c.lethal_value], dtype=np.float64)
+    st = model_lib().sm_backtrack(xyz.shape[0], faces.shape[0], _p(xyz), _p(faces), _p(vf_ptr), _p(vf), _p(vm), _p(_f32(seed_pos)),
+                                  int(seed_face), _p(_f32(target_pos)), int(target_face), float(step_width), cap,
+                                  _p(d) if d is not None else None, _p(v) if v is not None else None,
+                                  _p(cfg) if cfg is not None else None, int(rep), _p(pos), _p(face), C.byref(n))
+    return st, pos[: n.value][::-1].copy(), face[: n.value][::-1].copy()
 
 
 def product_inflation_update(u1, u2, a, b, c, max_distance):

@@ -450,7 +450,12 @@ class RefMap:
         """Loads a MeshPlanner plugin by its pluginlib lookup name (like mbf_mesh_nav does) and initializes it on THIS
         map; `params` are set as ROS parameters `<name>.<key>` first."""
         for k, v in params.items():
-            lib().ref_param_double(self._h, f"{name}.{k}".encode(), float(v))
+            if isinstance(v, bool):
+                lib().ref_param_bool(self._h, f"{name}.{k}".encode(), int(v))
+            elif isinstance(v, int):
+                lib().ref_param_int(self._h, f"{name}.{k}".encode(), int(v))
+            else:
+                lib().ref_param_double(self._h, f"{name}.{k}".encode(), float(v))
         return bool(lib().ref_plugin_init(self._h, lookup_name.encode(), name.encode()))
 
     def plugin_make_plan(self, start_pose7, goal_pose7):

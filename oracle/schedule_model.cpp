@@ -14,6 +14,7 @@
 
 #include "../mesh_navigation_amd/csrc/mnav_build.h"
 #include "../mesh_navigation_amd/csrc/mnav_eval.h"
+#include "../mesh_navigation_amd/csrc/mnav_walk.h"
 
 using namespace mnav;
 
@@ -356,6 +357,21 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
 // vertex, or NaN when it is not finite; *requeue = the :311 condition
 // mnav_eval.h acosf_ref (the device's SteepnessLayer arithmetic) for the host-side check against libm
 float sm_acosf_ref(float x) { return acosf_ref(x); }
+float sm_cosf_ref(float x) { return cosf_ref(x); }
+float sm_sinf_ref(float x) { return sinf_ref(x); }
+
+// mnav_walk.h (what k_backtrack runs, one thread) on host arrays: the product's back-tracking arithmetic for the CPU
+// parity test against mo_cvp_backtrack.  Returns the walk status; positions / faces in walk order (target first).
+int sm_backtrack(uint32_t V, uint32_t F, const float* xyz, const uint32_t* faces, const uint32_t* vf_ptr, const uint32_t* vf, const float* vecmap,
+                 const float* seed_pos, uint32_t seed_face, const float* target_pos, uint32_t target_face, double step_width, uint32_t cap,
+                 const float* infl_dist, const float* infl_vec, const double* infl_cfg, int repulsive, float* pos_out, uint32_t* face_out, uint32_t* n_out)
+{
+  WalkMesh M{ xyz, faces, vf_ptr, vf, V, F };
+  WalkField Fd{ vecmap, { faces[3 * (size_t)seed_face], faces[3 * (size_t)seed_face + 1], faces[3 * (size_t)seed_face + 2] } };
+  WalkInflation L{ infl_dist, infl_vec, nullptr, infl_cfg ? infl_cfg[0] : 0.0, infl_cfg ? infl_cfg[1] : 0.0, infl_cfg ? infl_cfg[2] : 0.0, infl_cfg ? infl_cfg[3] : 0.0, repulsive };
+  std::vector<uint32_t> list(kWalkListCap);
+  return walk_backtrack(M, Fd, L, w3_load(seed_pos), seed_face, w3_load(target_pos), target_face, step_width, cap, pos_out, face_out, n_out, list.data());
+}
 
 float sm_infl_candidate(float u1, float u2, float a, float b, float c, float max_distance, int* requeue)
 {

@@ -120,3 +120,33 @@ def test_gpu_plugins_publish_what_the_reference_publishes_and_follow_parameter_c
     c2, p2, _, _ = rm.plugin_make_plan(pose(robot), pose(goal, gq))
     assert c2 == 0 and len(p2) > 1.5 * len(p)                       # half the step width: about twice the poses
     rm.plugin_release()
+
+
+def test_gpu_cvp_plugin_with_device_backtracking_equals_the_reference_planner(world):
+    """f3: `device_backtracking` moves the walk over the vector field (cvp_mesh_planner.cpp:920-951, the map's meshAhead)
+    onto the device; with `sync_vector_map` off as well no V-sized array crosses PCIe.  The plan is the reference
+    planner's: every pose bit for bit (the device field carries the host libm's sin / cos bits)."""
+    m, rm, robot, goal = world
+    gq = (0, 0, np.sin(0.3), np.cos(0.3))
+    for sw in (0.3, 0.12):
+        code_r, plan_r, cost_r, msg_r = rm.cvp_make_plan(pose(robot), pose(goal, gq), step_width=sw)
+        name = f"gpu_cvp_dev_{int(sw * 100)}"
+        assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", name, step_width=sw, device_backtracking=True, sync_vector_map=False,
+                              publish_potential=False)
+        code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal, gq))
+        assert code == code_r == 0, (msg, msg_r)
+        assert plan.shape == plan_r.shape and len(plan) > 10
+        assert np.array_equal(plan, plan_r) and cost == cost_r
+        rm.plugin_release()
+        # the host walk on the downloaded field gives the same plan (the field itself is bit-identical now)
+        assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", name + "_host", step_width=sw)
+        code_h, plan_h, cost_h, _ = rm.plugin_make_plan(pose(robot), pose(goal, gq))
+        assert code_h == 0 and np.array_equal(plan_h, plan_r) and cost_h == cost_r
+        rm.plugin_release()
+    # the walk that loses the surface (default step width on this 0.1 m terrain): same outcome and message from the device
+    rm2 = R.RefMap(m.xyz, m.faces)
+    cr, pr, kr, mr = rm2.cvp_make_plan(pose(robot), pose(goal))
+    assert rm2.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_dev_default", device_backtracking=True)
+    c, p, k, mm = rm2.plugin_make_plan(pose(robot), pose(goal))
+    assert c == cr and mm == mr and len(p) == len(pr)
+    rm2.plugin_release()

@@ -186,3 +186,24 @@ def test_device_acosf_is_the_host_libm_acosf():
     for x in xs:
         a, b = np.float32(O.product_acosf(x)), np.float32(libm.acosf(float(x)))
         assert a.view(np.uint32) == b.view(np.uint32), float(x)
+
+
+def test_device_cosf_sinf_are_the_host_libm_functions():
+    """InflationLayer::vectorAt (inflation_layer.cpp:509) and the CVP vector map's rotation (cvp_mesh_planner.cpp:234) take
+    cos / sin of a float on the host; the device restates glibc's float routines (mnav_eval.h cosf_ref / sinf_ref).
+    Exhaustively equal on (-120, 120) (2.2e9 arguments each, checked once with a C loop); here a sample incl. the
+    branch boundaries (2^-12, pi/4 on the top 12 bits, the quadrant changes)."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    for f in (libm.cosf, libm.sinf):
+        f.restype = ctypes.c_float
+        f.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(2)
+    edges = np.array([0.0, -0.0, 2.0 ** -12, 2.4e-4, 0.78125, 0.785398, 0.7853982, 0.8125, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi, 17.28, 23.55, 119.99], np.float32)
+    xs = np.concatenate([rng.uniform(-np.pi, np.pi, 30000), rng.uniform(-119, 119, 10000), rng.uniform(-1e-3, 1e-3, 2000), edges, -edges,
+                         np.nextafter(edges, np.float32(200)), np.nextafter(edges, np.float32(-200))]).astype(np.float32)
+    for x in xs:
+        a, b = np.float32(O.product_cosf(x)), np.float32(libm.cosf(float(x)))
+        assert a.view(np.uint32) == b.view(np.uint32), ("cos", float(x))
+        a, b = np.float32(O.product_sinf(x)), np.float32(libm.sinf(float(x)))
+        assert a.view(np.uint32) == b.view(np.uint32), ("sin", float(x))
