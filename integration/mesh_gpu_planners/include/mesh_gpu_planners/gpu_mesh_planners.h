@@ -45,8 +45,12 @@ public:
   bool ok() const { return ctx_ != nullptr; }
   uint32_t numVertices() const { return V_; }
   bool uploadMesh(mesh_map::MeshMap& map, std::string& err);
-  bool syncCosts(mesh_map::MeshMap& map, std::string& err);
+  // true: the device copy is current.  One signing pass over the map's arrays per call, an upload only when they
+  // changed; with setStaticCosts(true) not even that unless `force`
+  bool syncCosts(mesh_map::MeshMap& map, std::string& err, bool force = false);
+  void setStaticCosts(bool on) { static_costs_ = on; }
 private:
+  bool static_costs_ = false;
   mnav_ctx* ctx_ = nullptr;
   uint32_t V_ = 0, F_ = 0, E_ = 0;
   uint64_t cost_hash_ = 0;
@@ -78,7 +82,7 @@ private:
   std::shared_ptr<mesh_map::MeshMap> mesh_map_;
   std::string name_, map_frame_;
   rclcpp::Node::SharedPtr node_;
-  std::atomic_bool cancel_planning_{ false };
+  std::atomic_bool cancel_planning_{ false }, reload_costs_{ false };   // reload_costs_: parameter `<name>.reload_costs` was set (static_costs maps)
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0;
            bool sync_vector_map = true; bool publish_potential = true; } config_;
   // sync_vector_map: MeshMap::setVectorMap after every plan, like the reference (:208); publish_potential: the "Potential"
@@ -108,7 +112,7 @@ private:
   std::shared_ptr<mesh_map::MeshMap> mesh_map_;
   std::string name_, map_frame_;
   rclcpp::Node::SharedPtr node_;
-  std::atomic_bool cancel_planning_{ false };
+  std::atomic_bool cancel_planning_{ false }, reload_costs_{ false };
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; double step_width = 0.4;
            bool publish_potential = true; bool sync_vector_map = true; bool device_backtracking = false; int device_inflation_layer = -1; } config_;
   // device_backtracking: the walk over the vector field (cvp :920-951) runs on the device (mnav_backtrack_cvp); with

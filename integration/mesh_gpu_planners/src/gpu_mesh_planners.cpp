@@ -17,23 +17,6 @@ namespace mesh_gpu_planners
 using Result = mbf_msgs::action::GetPath::Result;
 using geometry_msgs::msg::PoseStamped;
 
-namespace
-{
-uint64_t mix_words(const void* data, size_t bytes, uint64_t h)
-{
-  const unsigned char* p = static_cast<const unsigned char*>(data);
-  size_t i = 0;
-  for (; i + 8 <= bytes; i += 8) {
-    uint64_t w;
-    std::memcpy(&w, p + i, 8);
-    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-    h ^= h >> 29;
-  }
-  for (; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
-  return h;
-}
-}  // namespace
-
 // ------------------------------------------------------------------------------------------------------------------
 DeviceMap::DeviceMap(int device) : ctx_(mnav_create(device)) {}
 DeviceMap::~DeviceMap() { if (ctx_) mnav_destroy(ctx_); }
@@ -82,10 +65,34 @@ bool DeviceMap::uploadMesh(mesh_map::MeshMap& map, std::string& err)
 }
 
 // vertexCosts() / edgeWeights() / invalid, re-read like the reference does on every plan; uploaded when they changed.
-bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err)
+// The reference re-reads the map's cost arrays by const reference on every plan (dijkstra_mesh_planner.cpp:214-215); the
+// device keeps a copy, so each makePlan has to find out whether the map's layers changed it.  MeshMap offers no change
+// counter, so the arrays are signed in ONE pass straight out of the map (no staging copy); only a changed signature
+// stages and uploads.  `static_costs` (the planners' parameter) skips even that pass: the copy taken at initialize
+// stays until the parameter `<name>.reload_costs` is set.
+bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
 {
+  if (static_costs_ && have_costs_ && !force) return true;
   const auto& vc = map.vertexCosts();
   const auto& ew = map.edgeWeights();
+  uint64_t h = 0xCBF29CE484222325ull;
+  auto mix = [&h](uint32_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
+  for (uint32_t v = 0; v < V_; ++v) {
+    const lvr2::VertexHandle vH(v);
+    const auto c = std::as_const(vc).get(vH);
+    const float f = c ? *c : 0.f;
+    uint32_t w;
+    std::memcpy(&w, &f, 4);
+    mix(w ^ (map.invalid[vH] ? 0x80000001u : 0u));
+  }
+  for (uint32_t e = 0; e < E_; ++e) {
+    const auto wgt = std::as_const(ew).get(lvr2::EdgeHandle(e));
+    const float f = wgt ? *wgt : std::numeric_limits<float>::infinity();
+    uint32_t w;
+    std::memcpy(&w, &f, 4);
+    mix(w);
+  }
+  if (have_costs_ && h == cost_hash_) return true;
   costs_.resize(V_); weights_.resize(E_); invalid_.resize(V_);
   for (uint32_t v = 0; v < V_; ++v) {
     const lvr2::VertexHandle vH(v);
@@ -97,10 +104,6 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err)
     const auto w = std::as_const(ew).get(lvr2::EdgeHandle(e));
     weights_[e] = w ? *w : std::numeric_limits<float>::infinity();
   }
-  uint64_t h = mix_words(costs_.data(), sizeof(float) * V_, 0xCBF29CE484222325ull);
-  h = mix_words(weights_.data(), sizeof(float) * E_, h);
-  h = mix_words(invalid_.data(), V_, h);
-  if (have_costs_ && h == cost_hash_) return true;
   if (mnav_upload_costs(ctx_, costs_.data(), weights_.data(), invalid_.data()) != 0) { err = mnav_last_error(ctx_); return false; }
   cost_hash_ = h; have_costs_ = true;
   return true;
@@ -121,7 +124,10 @@ bool GpuDijkstraMeshPlanner::initialize(const std::string& plugin_name, const st
   config_.cost_limit = node_->declare_parameter(name_ + ".cost_limit", config_.cost_limit);
   config_.publish_potential = node_->declare_parameter(name_ + ".publish_potential", config_.publish_potential);
   const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
+  const bool static_costs = node_->declare_parameter(name_ + ".static_costs", false);
+  node_->declare_parameter(name_ + ".reload_costs", false);
   dev_ = std::make_unique<DeviceMap>(device);
+  dev_->setStaticCosts(static_costs);
   std::string err;
   if (!dev_->uploadMesh(*mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
@@ -138,7 +144,8 @@ rcl_interfaces::msg::SetParametersResult GpuDijkstraMeshPlanner::reconfigureCall
 {
   rcl_interfaces::msg::SetParametersResult result;
   for (const auto& parameter : parameters)
-    if (parameter.get_name() == name_ + ".cost_limit") config_.cost_limit = parameter.as_double();
+    if (parameter.get_name() == name_ + ".reload_costs") { if (parameter.as_bool()) reload_costs_ = true; }
+    else if (parameter.get_name() == name_ + ".cost_limit") config_.cost_limit = parameter.as_double();
   result.successful = true;
   return result;
 }
@@ -161,7 +168,7 @@ uint32_t GpuDijkstraMeshPlanner::plan(const mesh_map::Vector& wave_seed, const m
   if (!target_opt) return Result::INVALID_GOAL;                                                    // :242
   path.clear();
   std::string err;
-  if (!dev_->syncCosts(*mesh_map_, err)) { RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err); return Result::INTERNAL_ERROR; }
+  if (!dev_->syncCosts(*mesh_map_, err, reload_costs_.exchange(false))) { RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err); return Result::INTERNAL_ERROR; }
   const uint32_t V = dev_->numVertices();
   std::vector<uint32_t> ids(V ? V : 1);
   uint32_t n = 0;
@@ -272,7 +279,10 @@ bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::sh
   config_.device_backtracking = node_->declare_parameter(name_ + ".device_backtracking", config_.device_backtracking);
   config_.device_inflation_layer = (int)node_->declare_parameter(name_ + ".device_inflation_layer", config_.device_inflation_layer);
   const int device = (int)node_->declare_parameter(name_ + ".gpu_device", 0);
+  const bool static_costs = node_->declare_parameter(name_ + ".static_costs", false);
+  node_->declare_parameter(name_ + ".reload_costs", false);
   dev_ = std::make_unique<DeviceMap>(device);
+  dev_->setStaticCosts(static_costs);
   std::string err;
   if (!dev_->uploadMesh(*mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
@@ -290,7 +300,8 @@ rcl_interfaces::msg::SetParametersResult GpuCVPMeshPlanner::reconfigureCallback(
 {
   rcl_interfaces::msg::SetParametersResult result;
   for (const auto& parameter : parameters) {
-    if (parameter.get_name() == name_ + ".cost_limit") config_.cost_limit = parameter.as_double();
+    if (parameter.get_name() == name_ + ".reload_costs") { if (parameter.as_bool()) reload_costs_ = true; }
+    else if (parameter.get_name() == name_ + ".cost_limit") config_.cost_limit = parameter.as_double();
     else if (parameter.get_name() == name_ + ".step_width") config_.step_width = parameter.as_double();
   }
   result.successful = true;
@@ -325,7 +336,7 @@ uint32_t GpuCVPMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_m
   const lvr2::FaceHandle seed_face = seed_opt.unwrap(), target_face = target_opt.unwrap();
   path.clear();
   std::string err;
-  if (!dev_->syncCosts(*mesh_map_, err)) { message = err; return Result::INTERNAL_ERROR; }
+  if (!dev_->syncCosts(*mesh_map_, err, reload_costs_.exchange(false))) { message = err; return Result::INTERNAL_ERROR; }
   const uint32_t V = dev_->numVertices();
   // the V-sized field crosses PCIe only when someone on the host reads it: the map (setVectorMap, the controller's
   // directionAtPosition), the vector-field publisher, or the host back-tracking below

@@ -75,6 +75,8 @@ def lib():
         L.ref_param_int.argtypes = [vp, cp, C.c_int64]
         L.ref_param_string.argtypes = [vp, cp, cp]
         L.ref_param_string_array.argtypes = [vp, cp, cp]
+        L.ref_set_param_bool.restype = C.c_int
+        L.ref_set_param_bool.argtypes = [vp, cp, C.c_int]
         L.ref_set_param_double.restype = C.c_int
         L.ref_set_param_double.argtypes = [vp, cp, f64]
         L.ref_set_mesh.argtypes = [vp, u32, u32, vp, vp]
@@ -333,9 +335,6 @@ class RefMap:
                                           None if lethal is None else _p(_u8(lethal)))
         assert ok
 
-    def set_param(self, name, value):
-        return bool(lib().ref_set_param_double(self._h, name.encode(), float(value)))
-
     # ---- lookups ----
     def nearest_vertex(self, p):
         return int(lib().ref_nearest_vertex(self._h, _p(_f32(p))))
@@ -398,6 +397,8 @@ class RefMap:
 
     def set_param(self, name: str, value: float) -> bool:
         """`ros2 param set`: stores the value and fires the node's on-set-parameters callbacks"""
+        if isinstance(value, bool):
+            return bool(lib().ref_set_param_bool(self._h, name.encode(), int(value)))
         return bool(lib().ref_set_param_double(self._h, name.encode(), float(value)))
 
     def map_vector_map(self):

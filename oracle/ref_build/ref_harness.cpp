@@ -142,6 +142,7 @@ void ref_param_string_array(void* h, const char* name, const char* csv)
   }
   static_cast<Ref*>(h)->node->stub_set_override(name, rclcpp::ParameterValue(out));
 }
+int ref_set_param_bool(void* h, const char* name, int v) { return static_cast<Ref*>(h)->node->stub_set_parameter(name, rclcpp::ParameterValue(v != 0)) ? 1 : 0; }
 int ref_set_param_double(void* h, const char* name, double v) { return static_cast<Ref*>(h)->node->stub_set_parameter(name, rclcpp::ParameterValue(v)) ? 1 : 0; }
 
 // ---- the "map file" ----

@@ -151,3 +151,35 @@ def test_gpu_cvp_plugin_with_device_backtracking_equals_the_reference_planner(wo
     c, p, k, mm = rm2.plugin_make_plan(pose(robot), pose(goal))
     assert c == cr and mm == mr and len(p) == len(pr)
     rm2.plugin_release()
+
+
+def test_gpu_plugin_follows_cost_changes_of_the_map(world):
+    """The reference reads the map's costs by reference on every plan; the plugin's device copy follows the map: by a
+    signature pass per plan (default), or -- `static_costs` -- only when `<name>.reload_costs` is set."""
+    m, _, robot, goal = world
+    rm = R.RefMap(m.xyz, m.faces, vertex_costs=np.zeros(m.V, np.float32), edge_cost_factor=1.0)
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_follow")
+    c0, p0, k0, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    cr0, pr0, kr0 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
+    # a costly band across the straight line: the map's layer changes, both planners detour alike
+    N = m.N
+    band = (np.arange(N // 4, 3 * N // 4)[:, None] * N + np.arange(N // 2 - 2, N // 2 + 2)[None, :]).ravel().astype(np.uint32)
+    rm.update_array_layer(band, np.full(band.shape[0], 0.9, np.float32))
+    cr1, pr1, kr1 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    c1, p1, k1, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c1 == cr1 == 0 and np.array_equal(p1, pr1) and k1 == kr1
+    assert not np.array_equal(p1, p0) if len(p1) == len(p0) else True
+    rm.plugin_release()
+    # static_costs: the copy taken at initialize stays ...
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_static", static_costs=True)
+    c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c2 == 0 and np.array_equal(p2, pr1)
+    rm.update_array_layer(band, np.zeros(band.shape[0], np.float32))       # the band is free again
+    cr3, pr3, kr3 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    c3, p3, k3, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert np.array_equal(pr3, pr0) and np.array_equal(p3, pr1)            # ... the plugin still plans on the old costs
+    assert rm.set_param("gpu_dij_static.reload_costs", True)               # ... until told to reload
+    c4, p4, k4, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c4 == 0 and np.array_equal(p4, pr0) and k4 == kr3
+    rm.plugin_release()
