@@ -1883,14 +1883,14 @@ __global__ __launch_bounds__(kBlock) void k_combine_resident_ids(uint32_t n, con
 // One back-tracking job: the plan's resident vector map and the two ends of the walk.
 struct WalkJob { const float* vecmap; float seed[3]; uint32_t seed_face; float target[3]; uint32_t target_face; };
 
-// CVPMeshPlanner's back-tracking (cvp_mesh_planner.cpp:920-951) on the resident vector map: one workgroup per plan, its
-// first lane walks (the loop is a dependent chain: each step needs the position the previous one produced), the face list
-// of searchNeighbourFaces lives in LDS.  ctl[2*j] = walk status, ctl[2*j+1] = entries written (walk order, target first).
+// CVPMeshPlanner's back-tracking (cvp_mesh_planner.cpp:920-951) on the resident vector map: one wave per plan.  The loop
+// is a dependent chain (each step needs the position the previous one produced), so all 64 lanes walk in lockstep on the
+// same data (uniform loads, uniform branches) and divide only the scan of searchNeighbourFaces' face list, which lives in
+// LDS.  ctl[2*j] = walk status, ctl[2*j+1] = entries written (walk order, target first).
 __global__ __launch_bounds__(64) void k_backtrack(WalkMesh M, WalkInflation L, const WalkJob* __restrict__ jobs, double step_width, uint32_t cap,
                                                   float* __restrict__ pos_out, uint32_t* __restrict__ face_out, int32_t* __restrict__ ctl)
 {
-  __shared__ uint32_t list[kWalkListCap];
-  if (threadIdx.x != 0) return;
+  __shared__ uint32_t list[kWalkScratchWords];
   const uint32_t j = blockIdx.x;
   const WalkJob J = jobs[j];
   WalkField Fd;

@@ -68,11 +68,8 @@ MNAV_HD bool walk_bary(const WalkMesh& M, W3 p, uint32_t f, float bary[3], float
 // mesh_map.cpp:999-1068: breadth-first over the faces around `face` within max_radius (+ the face's own extent); the
 // reference's SparseFaceMap "already listed" test is a linear scan of the (short) list here.  kNone: nothing found;
 // *status = kWalkListFull when the list capacity ended the search.
-MNAV_HD uint32_t walk_search_faces(const WalkMesh& M, W3 pos, uint32_t face, float max_radius, float max_dist, float bary_out[3],
-                                   uint32_t* list, int* status)
+MNAV_HD void walk_search_setup(const WalkMesh& M, uint32_t face, float max_radius, W3* center_out, float* max_radius_sq)
 {
-  int n = 0, it = 0;
-  list[n++] = face;
   W3 center = w3(0, 0, 0);
   for (int k = 0; k < 3; ++k) center = w3_add(center, w3_load(M.xyz + 3 * (size_t)M.faces[3 * (size_t)face + k]));   // :1010-1013
   center = w3_div(center, 3);                                           // :1014
@@ -80,7 +77,101 @@ MNAV_HD uint32_t walk_search_faces(const WalkMesh& M, W3 pos, uint32_t face, flo
   for (int k = 0; k < 3; ++k)
     vertex_center_max = fmaxf(vertex_center_max, sqrtf(w3_distance2(w3_load(M.xyz + 3 * (size_t)M.faces[3 * (size_t)face + k]), center)));   // :1017-1020
   const float ext_radius = max_radius + vertex_center_max;              // :1022
-  const float max_radius_sq = ext_radius * ext_radius;                  // :1023
+  *max_radius_sq = ext_radius * ext_radius;                             // :1023
+  *center_out = center;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr int kWalkCand = 32;                                           // candidate slots per listed face (3 vertex rows; valence 6 -> 18)
+constexpr int kWalkScratchWords = kWalkListCap + 64 * kWalkCand + 64;   // list | candidates of the 64 faces of a round | their counts
+
+// "is nn in list[0..n)": the 64 lanes of the wave divide the scan
+__device__ __forceinline__ bool walk_listed(const uint32_t* list, int n, uint32_t nn)
+{
+  bool hit = false;
+  for (int q = (int)(threadIdx.x & 63u); q < n; q += 64) hit |= list[q] == nn;
+  return __any(hit);
+}
+
+// The wave version of the search (k_backtrack: 64 lanes in lockstep on one plan).  The sequential loop tests list[it],
+// expands it, tests list[it+1], ...: the LIST ORDER does not depend on the tests, only where the loop stops does.  So a
+// round takes the next <= 64 listed faces, one per lane: every lane tests its face and gathers the faces around its
+// three vertices (the dependent global loads of 64 faces in flight at once); the first lane whose test passes is the
+// sequential loop's answer.  If none passes, the gathered candidates are appended in the sequential order (face by face,
+// vertex by vertex, row order), each after a lane-parallel "already listed" scan.
+__device__ inline uint32_t walk_search_faces(const WalkMesh& M, W3 pos, uint32_t face, float max_radius, float max_dist, float bary_out[3],
+                                             uint32_t* list, int* status)
+{
+  const int lane = (int)(threadIdx.x & 63u);
+  uint32_t* cand = list + kWalkListCap;
+  uint32_t* cnt = cand + 64 * kWalkCand;
+  int n = 0, it = 0;
+  list[n++] = face;
+  W3 center; float max_radius_sq;
+  walk_search_setup(M, face, max_radius, &center, &max_radius_sq);
+  while (it < n) {
+    const int m = n - it < 64 ? n - it : 64;
+    float bary[3] = { 0.f, 0.f, 0.f }, dist = 0.f;
+    bool pass = false;
+    if (lane < m) {
+      const uint32_t f = list[it + lane];
+      pass = walk_bary(M, pos, f, bary, &dist) && fabsf(dist) < max_dist;   // :1035
+      uint32_t c = 0; bool over = false;
+      for (int k = 0; k < 3; ++k) {                                     // :1042
+        const uint32_t vertex = M.faces[3 * (size_t)f + k];
+        if (w3_distance2(center, w3_load(M.xyz + 3 * (size_t)vertex)) < max_radius_sq)   // :1044
+          for (uint32_t i = M.vf_ptr[vertex]; i < M.vf_ptr[vertex + 1]; ++i) {           // :1048-1049
+            if (c < (uint32_t)kWalkCand) cand[lane * kWalkCand + c++] = M.vf[i]; else over = true;
+          }
+      }
+      cnt[lane] = over ? 0xFFFFFFFFu : c;
+    }
+    __syncthreads();                                                    // (one wave per workgroup: orders the LDS traffic of the round)
+    const unsigned long long mask = __ballot(pass);
+    if (mask) {
+      const int first = __ffsll((long long)mask) - 1;
+      for (int k = 0; k < 3; ++k) bary_out[k] = __shfl(bary[k], first);
+      return list[it + first];
+    }
+    for (int j = 0; j < m; ++j) {                                       // append in the sequential order
+      const uint32_t c = cnt[j];
+      if (c != 0xFFFFFFFFu) {
+        for (uint32_t t = 0; t < c; ++t) {
+          const uint32_t nn = cand[j * kWalkCand + t];
+          if (!walk_listed(list, n, nn)) {                              // :1051-1055
+            if (n >= kWalkListCap) { *status = kWalkListFull; return kNone; }
+            list[n++] = nn;
+          }
+        }
+      } else {                                                          // a vertex row longer than the slots: straight from memory
+        const uint32_t f = list[it + j];
+        for (int k = 0; k < 3; ++k) {
+          const uint32_t vertex = M.faces[3 * (size_t)f + k];
+          if (w3_distance2(center, w3_load(M.xyz + 3 * (size_t)vertex)) < max_radius_sq)
+            for (uint32_t i = M.vf_ptr[vertex]; i < M.vf_ptr[vertex + 1]; ++i) {
+              const uint32_t nn = M.vf[i];
+              if (!walk_listed(list, n, nn)) {
+                if (n >= kWalkListCap) { *status = kWalkListFull; return kNone; }
+                list[n++] = nn;
+              }
+            }
+        }
+      }
+    }
+    __syncthreads();
+    it += m;                                                            // :1063
+  }
+  return kNone;
+}
+#else
+constexpr int kWalkScratchWords = kWalkListCap;
+inline uint32_t walk_search_faces(const WalkMesh& M, W3 pos, uint32_t face, float max_radius, float max_dist, float bary_out[3],
+                                  uint32_t* list, int* status)
+{
+  int n = 0, it = 0;
+  list[n++] = face;
+  W3 center; float max_radius_sq;
+  walk_search_setup(M, face, max_radius, &center, &max_radius_sq);
   while (it < n) {                                                      // :1031
     const uint32_t f = list[it];
     float bary[3], dist;
@@ -106,6 +197,7 @@ MNAV_HD uint32_t walk_search_faces(const WalkMesh& M, W3 pos, uint32_t face, flo
   }
   return kNone;
 }
+#endif
 
 // inflation_layer.cpp:493-521; *panic where lvr2's attribute maps would throw (a vertex without an entry, :499 / :503)
 MNAV_HD W3 walk_inflation_vector(const WalkInflation& L, const uint32_t vs[3], const float bary[3], bool* panic)

@@ -1,0 +1,61 @@
+"""Per-call cost of the real plugin (integration/mesh_gpu_planners, loaded through pluginlib on the reference's MeshMap,
+oracle/_ref) next to the reference planner on the same map: wall time of makePlan at C2 scale (1M vertices).
+Test infrastructure (needs oracle/_ref); prints one JSON line."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from mesh_navigation_amd import meshgen  # noqa: E402
+from oracle import ref as R  # noqa: E402
+
+
+def pose(p, q=(0, 0, 0, 1)):
+    return np.array([p[0], p[1], p[2], *q], np.float64)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    t0 = time.time()
+    m = meshgen.terrain(n, 0.1, 21)
+    rng = np.random.default_rng(3)
+    costs = rng.uniform(0.0, 0.6, m.V).astype(np.float32)
+    rm = R.RefMap(m.xyz, m.faces, vertex_costs=costs, edge_cost_factor=1.0)
+    t_map = time.time() - t0
+    robot = m.xyz[m.vertex_at(0.85, 0.8)] + np.array([0.031, 0.017, 0.0], np.float32)
+    goals = [m.xyz[m.vertex_at(0.12 + 0.05 * k, 0.2 + 0.03 * k)] + np.array([0.023, 0.011, 0.0], np.float32) for k in range(5)]
+    out = dict(V=int(m.V), map_s=round(t_map, 1))
+
+    def timed(fn, reps):
+        ts = []
+        for k in range(reps):
+            t = time.perf_counter()
+            r = fn(goals[k % len(goals)])
+            ts.append((time.perf_counter() - t) * 1e3)
+            assert r[0] == 0, r[0]
+        return round(float(np.median(ts)), 3), len(r[1])
+
+    if R.gpu_plugins_linked() and "--no-gpu" not in sys.argv:
+        for label, params in () if "--cvp-only" in sys.argv else (("default", {}),
+                              ("no_sync", dict(sync_vector_map=False, publish_potential=False)),
+                              ("no_sync_static", dict(sync_vector_map=False, publish_potential=False, static_costs=True))):
+            assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "t_dij_" + label, **params)
+            rm.plugin_make_plan(pose(robot), pose(goals[0]))            # warm: tables, graphs
+            out["gpu_dijkstra_ms_" + label], out["dijkstra_poses"] = timed(lambda g: rm.plugin_make_plan(pose(robot), pose(g)), 10)
+            rm.plugin_release()
+        for label, params in (("default", {}),
+                              ("device_walk", dict(sync_vector_map=False, publish_potential=False, static_costs=True, device_backtracking=True))):
+            assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "t_cvp_" + label, step_width=0.25, **params)
+            rm.plugin_make_plan(pose(robot), pose(goals[0]))
+            out["gpu_cvp_ms_" + label], out["cvp_poses"] = timed(lambda g: rm.plugin_make_plan(pose(robot), pose(g)), 5)
+            rm.plugin_release()
+    if "--no-ref" not in sys.argv:
+        out["ref_dijkstra_ms"], _ = timed(lambda g: rm.dijkstra_make_plan(pose(robot), pose(g)), 3)
+        out["ref_cvp_ms"], _ = timed(lambda g: rm.cvp_make_plan(pose(robot), pose(g), step_width=0.25), 2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
