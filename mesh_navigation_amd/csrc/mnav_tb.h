@@ -585,30 +585,6 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) { const float d = dist[v]; out[v] = (d <= goal_dist) ? d : inf_f(); }
 }
 
-// blocked distances -> vertex order, for callers that want the V-sized fields: dist / pred of every plan are written in
-// vertex order (coalesced stores; the reads gather 4-byte words, neighbouring vertices mostly from the same slice), and
-// the plan is flagged converged.  k_dij_finalize then looks at every LDS tile and skips those without a reached vertex.
-__global__ __launch_bounds__(kBlock) void k_tb_unblock(tb::Args A, uint32_t V, const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans)
-{
-  const uint32_t p = blockIdx.y;
-  const Plan& P = plans[p];
-  MNAV_GLOBAL float* dist = as_global(P.dist); MNAV_GLOBAL uint32_t* pred = as_global(P.pred);
-  MNAV_GLOBAL const u32x2* va = (MNAV_GLOBAL const u32x2*)A.vaddr;
-  MNAV_GLOBAL const float* D = as_global(A.D);
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) {
-    const u32x2 a = va[v];
-    dist[v] = D[(size_t)a.x * A.NP + (size_t)p * (a.y >> 8) + (a.y & 255u)];
-    pred[v] = v;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const TilePlan& T = tplans[p];
-    TCtl c; memset(&c, 0, sizeof(c));
-    c.it = (int32_t)A.ctl->iters; c.done = 1u; c.pad[0] = (A.ctl->err || A.ctl->n_cand[0]) ? 1u : 0u;
-    T.ctl[0] = c; T.ctl[1] = c;
-  }
-}
-
 // host-side state of the engine (device arrays of the mesh-dependent streams, and of the running batch)
 struct TbState {
   bool built = false, w_valid = false;

@@ -131,11 +131,10 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
 int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, const tb::Args& A)
 {
   if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_tile_state(ctx, n)) return -1;
+  if (ensure_tile_state(ctx, 1)) return -1;                          // one TilePlan record: the LDS tiles' mesh tables
   if (tile_weights(ctx)) return -1;
   const HostTiles& M = ctx->tiles_meta;
   std::vector<Plan> hp(n);
-  std::vector<TilePlan> tp(n);
   std::vector<float*> vecs(n);
   for (uint32_t i = 0; i < n; ++i) {
     Slot& s = ctx->slots[i];
@@ -148,31 +147,25 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
     P.seed_face = kNone;
     vecs[i] = s.vecmap;
-    TilePlan& T = tp[i];
-    memset(&T, 0, sizeof(T));
-    T.V = ctx->V; T.ntiles = M.ntiles;
-    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
-    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
+  TilePlan T;
+  memset(&T, 0, sizeof(T));
+  T.V = ctx->V; T.ntiles = M.ntiles;
+  T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+  T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
+  T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, &T, sizeof(TilePlan), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));                          // hp / tp / vecs go out of scope
-  {
-    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-    if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, 0.0f);   // marks: every tile is looked at
-  }
-  {
-    uint32_t gv = (ctx->V + kBlock * 8 - 1) / (kBlock * 8);
-    if (gv < 1) gv = 1;
-    if (gv > 512) gv = 512;
-    hipLaunchKernelGGL(k_tb_unblock, dim3(gv, n), dim3(kBlock), 0, ctx->stream, A, ctx->V, ctx->d_plans, ctx->d_tplans);
-  }
-  launch_finalize(ctx, n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));                          // hp / T / vecs go out of scope
+  // potential (with the reference's tentative values beyond goal_dist) and predecessors of every plan, in vertex order,
+  // straight from the blocked distances: k_dij_finalize gathers them per LDS tile, eight plans per staged tile graph
+  FinBlocked B{};
+  B.D = A.D; B.vaddr = A.vaddr; B.NP = A.NP; B.xyz = ctx->d_xyz; B.vecmaps = ctx->want_vec ? ctx->d_vecptrs : nullptr;
+  B.iters = (const uint32_t*)((const char*)A.ctl + offsetof(tb::Ctl, iters));
+  B.err = (const uint32_t*)((const char*)A.ctl + offsetof(tb::Ctl, err));
+  B.n_cand = (const uint32_t*)((const char*)A.ctl + offsetof(tb::Ctl, n_cand));
+  launch_finalize_blocked(ctx, n, B);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -272,9 +265,8 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     S.d2_clean = true; S.d2_clean_np = n;
   }
   if (rc == 0 && !ctx->lazy_paths) {
-    // V-sized outputs wanted (potential, predecessors, vector map): the blocked distances go to the per-plan arrays in vertex
-    // order and the finalize pass of the tile engines derives the reference's exact cut-off semantics and predecessors from
-    // them (k_dij_finalize; every tile visited)
+    // V-sized outputs wanted (potential, predecessors, vector map): the finalize pass of the tile engines derives the
+    // reference's exact cut-off semantics and predecessors straight from the blocked distances (k_dij_finalize<8, true>)
     if (tb_fields(ctx, n, in, offset, A)) return -1;
   }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
