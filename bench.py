@@ -67,7 +67,7 @@ def main() -> None:
     ap.add_argument("--no-configs", action="store_true", help="skip the C3/C4/C5 legs (profiling the headline kernel)")
     ap.add_argument("--skip-c4", action="store_true", help="skip the 10M-vertex leg")
     ap.add_argument("--c4-grid", type=int, default=int(os.environ.get("MNAV_BENCH_C4_N", "3163")))
-    ap.add_argument("--c4-batch", type=int, default=int(os.environ.get("MNAV_BENCH_C4_BATCH", "1536")))   # one workgroup per plan: 1536 are resident at once (123 GB of per-plan state at 10M)
+    ap.add_argument("--c4-batch", type=int, default=int(os.environ.get("MNAV_BENCH_C4_BATCH", "4096")))   # tile-batch engine: 52 MB of blocked distances per plan at 10M = 213 GB (1536 plans on the per-plan engine: 831 plans/s; 4096 here: 1132)
     args = ap.parse_args()
     if args.cpu_all_cores_child:
         return cpu_all_cores_child(args)

@@ -3431,8 +3431,9 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     // auto: one wave per (tile, 64 plans) for large batches, one workgroup per plan for medium ones, tile rounds otherwise
     if (engine == 3) {
       // The tile-batch engine fills a wave with the plans that have work on ONE tile in ONE iteration: about
-      // 0.64 * plans / sqrt(tiles) of them (measured on C2: 34 lanes at 5120 plans / 9260 tiles).  Below ~12 lanes per wave
-      // the per-plan engine is faster (10M-vertex mesh with 1536 plans: 3 lanes per wave, 504 against 831 plans/s).
+      // 0.64 * plans / sqrt(tiles) of them by this estimate (C2, 5120 plans / 9260 tiles: 34; the measured fill is a little
+      // higher, 41).  Below ~7 estimated lanes per wave the per-plan engine is faster: on the 10M-vertex mesh 1536 plans
+      // (estimate 3.2) run at 504 against 831 plans/s, 4096 plans (estimate 8.6, measured 15.5) at 1132 against 831.
       const double tiles = std::max(1.0, (double)V / (0.9 * ctx->tb.T));
       const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && 0.64 * m0 >= ctx->tb.min_lanes * std::sqrt(tiles);
       engine = fills ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;

@@ -602,7 +602,7 @@ struct TbState {
   uint2* cand[2] = { nullptr, nullptr }; uint32_t* marr[2] = { nullptr, nullptr };
   float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;
   uint32_t min_batch = 256;             // auto engine: batches of at least this many plans ...
-  double min_lanes = 12.0;              // ... that are expected to fill at least this many lanes of a wave (mnav.hip dijkstra_impl)
+  double min_lanes = 7.0;               // ... that are expected to fill at least this many lanes of a wave (mnav.hip dijkstra_impl)
   float band_mult = 2.0f;               // band = band_mult * mean edge weight * sqrt(T)  (measured on C2: 1 -> 236 ms, 2 -> 218 ms per 5120 plans)
   int iters_per_replay = 16, waves_per_cu = 0;
   hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
