@@ -557,14 +557,15 @@ def sharded_c4(args, torch, dist, rank, local_rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
+    dev_loop = os.environ.get("MNAV_SHARD_HOST_LOOP") is None         # default: the exchange loop stays on the device
     res = None
     for k in range(args.warmup):
-        res = sharded.run_sharded_plan(eng, red, int(goals[k]), robot, args.offset, max_exchanges=200000)
+        res = sharded.run_sharded_plan(eng, red, int(goals[k]), robot, args.offset, max_exchanges=200000, device_loop=dev_loop)
     barrier()
     t0 = time.perf_counter()
     exch = 0
     for k in range(args.steps):
-        res = sharded.run_sharded_plan(eng, red, int(goals[args.warmup + k]), robot, args.offset, max_exchanges=200000)
+        res = sharded.run_sharded_plan(eng, red, int(goals[args.warmup + k]), robot, args.offset, max_exchanges=200000, device_loop=dev_loop)
         assert res.code == 0
         exch += res.exchanges
     barrier()
@@ -579,7 +580,8 @@ def sharded_c4(args, torch, dist, rank, local_rank, world):
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"C4 sharded: {N}x{N} terrain = {mesh.V} vertices, tiles range-partitioned over {world} GPU(s), "
                                       f"min-allreduce of {eng.n} interface floats per exchange", "exchanges_per_plan": exch / args.steps,
-                          "path_len": int(len(res.path))},
+                          "path_len": int(len(res.path)),
+                          "exchange_loop": "device-resident (termination words read every 8 exchanges)" if dev_loop else "host-checked every exchange"},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     ctx.close()

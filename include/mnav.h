@@ -230,6 +230,13 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
 int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev);
 int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out);
 int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev);
+/* The two steps of an exchange without a host round trip.  `caller_stream` (a hipStream_t) is the stream the caller's
+ * collectives are ordered on; the library links its own stream to it with events in both directions, nothing waits on the
+ * host.  mnav_shard_apply_async writes {smallest pending wake-up, dist[target], -1 if mnav_cancel arrived else 0} to the
+ * DEVICE words ctl_dev[0..2]; the caller min-allreduces them and reads them back once every few exchanges -- an exchange
+ * after convergence changes nothing, so checking late is safe. */
+int mnav_shard_rounds_async(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev, void* caller_stream);
+int mnav_shard_apply_async(mnav_ctx* ctx, const float* iface_buf_dev, float* ctl_dev, void* caller_stream);
 
 /* Replaces MeshPlanner::cancel(), mesh_planner.h:80 (dijkstra_mesh_planner.cpp:136-140):
  * async-signal/thread safe, only sets a flag that the running plan polls between step

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_set_face_circulation", "mnav_upload_mesh", "mnav_upload_costs",
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_get_timing", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
-    "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply",
+    "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply", "mnav_shard_rounds_async", "mnav_shard_apply_async",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
@@ -147,6 +147,10 @@ def load(path: str | None = None):
     L.mnav_shard_begin.argtypes = [vp, u32, u32, f64, f64]
     L.mnav_shard_rounds.restype = C.c_int
     L.mnav_shard_rounds.argtypes = [vp, u32, vp]
+    L.mnav_shard_rounds_async.restype = C.c_int
+    L.mnav_shard_rounds_async.argtypes = [vp, u32, vp, vp]
+    L.mnav_shard_apply_async.restype = C.c_int
+    L.mnav_shard_apply_async.argtypes = [vp, vp, vp, vp]
     L.mnav_shard_apply.restype = C.c_int
     L.mnav_shard_apply.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.mnav_shard_finalize.restype = C.c_int
@@ -409,6 +413,14 @@ class MnavContext:
         if self._L.mnav_shard_apply(self._h, C.c_void_p(buf_ptr), C.byref(lm), C.byref(td)) != 0:
             raise RuntimeError(f"mnav_shard_apply failed: {self._err()}")
         return lm.value, td.value
+
+    def shard_rounds_async(self, rounds: int, buf_ptr: int, stream: int):
+        if self._L.mnav_shard_rounds_async(self._h, int(rounds), C.c_void_p(buf_ptr), C.c_void_p(stream)) != 0:
+            raise RuntimeError(f"mnav_shard_rounds_async failed: {self._err()}")
+
+    def shard_apply_async(self, buf_ptr: int, ctl_ptr: int, stream: int):
+        if self._L.mnav_shard_apply_async(self._h, C.c_void_p(buf_ptr), C.c_void_p(ctl_ptr), C.c_void_p(stream)) != 0:
+            raise RuntimeError(f"mnav_shard_apply_async failed: {self._err()}")
 
     def shard_finalize(self, dist_ptr: int, pred_ptr: int):
         rc = self._L.mnav_shard_finalize(self._h, C.c_void_p(dist_ptr), C.c_void_p(pred_ptr))

@@ -1127,6 +1127,17 @@ __global__ __launch_bounds__(kBlock) void k_shard_minpend(const TilePlan* __rest
   if ((threadIdx.x & 63) == 0 && m != kInfBits) atomicMin(out, m);
 }
 
+// the termination words of one exchange, written on the device: {smallest pending wake-up, dist[target], -status}
+__global__ void k_shard_ctl(const uint32_t* __restrict__ minpend, const float* __restrict__ dist, uint32_t target, const uint32_t* __restrict__ cancel,
+                            float* __restrict__ ctl)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  const uint32_t mp = *minpend;
+  ctl[0] = (mp >= kInfBits) ? inf_f() : u2f(mp);
+  ctl[1] = dist[target];
+  ctl[2] = (cancel && __atomic_load_n(cancel, __ATOMIC_RELAXED)) ? -1.0f : 0.0f;
+}
+
 // final gather buffers: owned entries, neutral elements elsewhere (min-allreduce over dist, pred)
 __global__ __launch_bounds__(kBlock) void k_shard_owned(uint32_t V, const uint32_t* __restrict__ vert_tile, uint32_t t_lo, uint32_t t_hi,
                                                         const float* __restrict__ dist, const uint32_t* __restrict__ pred,
@@ -2027,6 +2038,7 @@ struct mnav_ctx {
   std::vector<uint32_t> h_vf_ptr, h_vf;    // getFacesOfVertex rows (host copy; uploaded on the first device back-tracking call)
   uint32_t *d_faces = nullptr, *d_vf_ptr = nullptr, *d_vf = nullptr; bool walk_mesh_valid = false;
   float* d_walk_pos = nullptr; uint32_t* d_walk_face = nullptr; size_t walk_cap = 0;   // k_backtrack outputs: rows of `cap` entries
+  hipEvent_t ev_link[2]{};                 // stream links of the asynchronous shard calls (caller's stream <-> ours)
   struct WalkJob* d_walk_jobs = nullptr; int32_t* d_walk_ctl = nullptr; uint32_t walk_jobs_cap = 0;
   std::vector<uint8_t> h_invalid;
   bool have_mesh = false, have_costs = false, have_normals = false;
@@ -2802,6 +2814,7 @@ void mnav_destroy(mnav_ctx* ctx)
   if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->evc) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_link) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->d_ctl_pool); (void)hipFree(ctx->d_tctl_pool);
   (void)hipFree(ctx->d_faces); (void)hipFree(ctx->d_vf_ptr); (void)hipFree(ctx->d_vf); (void)hipFree(ctx->d_walk_pos); (void)hipFree(ctx->d_walk_face);
   (void)hipFree(ctx->d_walk_jobs); (void)hipFree(ctx->d_walk_ctl);
@@ -3907,6 +3920,57 @@ int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min
   if (local_min_out) *local_min_out = (mp >= 0x7f800000u) ? INFINITY : u2f(mp);
   if (target_dist_out) *target_dist_out = td;
   return 0;
+}
+
+// The same two steps without a host round trip, for an exchange loop that stays on the device (mesh_navigation_amd/sharded.py):
+// the library's stream is linked to `caller_stream` (the stream the caller's collectives are ordered on, e.g. torch's
+// current stream) by events -- our kernels start after what the caller enqueued so far, the caller's next operation after
+// ours.  mnav_shard_apply_async leaves {smallest pending wake-up, dist[target], -cancelled} in ctl_dev[0..2]: the caller
+// reduces those three floats over the ranks and looks at them once every few exchanges (an exchange after convergence
+// changes nothing).
+static int shard_link(mnav_ctx* ctx, hipStream_t caller, bool in)
+{
+  hipEvent_t& e = ctx->ev_link[in ? 0 : 1];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->err = "event creation failed"; return -1; }
+  if (in) { HIPCHK(hipEventRecord(e, caller)); HIPCHK(hipStreamWaitEvent(ctx->stream, e, 0)); }
+  else { HIPCHK(hipEventRecord(e, ctx->stream)); HIPCHK(hipStreamWaitEvent(caller, e, 0)); }
+  return 0;
+}
+
+int mnav_shard_rounds_async(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev, void* caller_stream)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
+  const uint32_t own = S.t_hi - S.t_lo;
+  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
+  if (G > own) G = own ? own : 1;
+  for (uint32_t r = 0; r < rounds; ++r, ++S.j)
+    hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)(S.j % 6));
+  if (iface_buf_dev)
+    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->slots[0].dist, iface_buf_dev);
+  HIPCHK(hipGetLastError());
+  return shard_link(ctx, (hipStream_t)caller_stream, false);
+}
+
+int mnav_shard_apply_async(mnav_ctx* ctx, const float* iface_buf_dev, float* ctl_dev, void* caller_stream)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (!iface_buf_dev || !ctl_dev) { ctx->err = "null buffer"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
+  HIPCHK(hipMemsetAsync(S.d_changed, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)S.d_minpend, (int)kInfBits, 1, ctx->stream));   // +inf: "nothing pending"
+  const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
+  const uint32_t own = S.t_hi - S.t_lo;
+  const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
+  hipLaunchKernelGGL(k_shard_ctl, dim3(1), dim3(64), 0, ctx->stream, S.d_minpend, ctx->slots[0].dist, S.target, ctx->d_cancel, ctl_dev);
+  HIPCHK(hipGetLastError());
+  return shard_link(ctx, (hipStream_t)caller_stream, false);
 }
 
 int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev)

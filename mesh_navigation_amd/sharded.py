@@ -3,12 +3,18 @@
 One process per GPU.  Every process holds the whole (read-only) mesh description but OWNS a contiguous range of
 the Morton-ordered LDS tiles and, with them, their vertices: only the owner relaxes into a vertex.  The loop is
 
-    repeat:  R local tile rounds on the own tiles                      (k_tile_round, mnav_shard_rounds)
+    repeat:  R local tile rounds on the own tiles                      (k_tile_round, mnav_shard_rounds[_async])
              ONE min-allreduce of the interface buffer                 (RCCL over xGMI: halo-vertex distances
                                                                         + the robot vertex, a few 10^4 floats)
-             ghost values that dropped wake the tiles around them      (mnav_shard_apply)
-             ONE 2-float min-allreduce: smallest pending wake-up, dist[robot]
+             ghost values that dropped wake the tiles around them      (mnav_shard_apply[_async])
+             ONE 3-float min-allreduce: smallest pending wake-up, dist[robot], -status
     until nothing that may still propagate is pending anywhere
+
+With an engine that offers the asynchronous steps (GpuShardEngine) the loop stays on the device: kernels and collectives
+are ordered by stream events, the termination words are written by a kernel, and the host reads them back only once
+every `check_every` exchanges -- an exchange after convergence changes nothing (values only ever decrease, and the finalize
+pass derives everything beyond goal_dist from the popped vertices), so looking late costs a few idle exchanges, not
+correctness.
     finalize the own tiles (cut-off semantics + predecessors), min-allreduce dist / pred once
 
 The schedule is label-correcting, so the potential is the unique fixed point of the reference's float32
@@ -53,8 +59,10 @@ def walk_path(pred: np.ndarray, seed: int, target: int) -> tuple[int, np.ndarray
 
 
 def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, goal_dist_offset: float = 0.3,
-                     rounds_per_exchange: int = 8, max_exchanges: int = 100_000, gather: bool = True) -> ShardedResult:
-    """The loop above for ONE rank.  `engine`: begin/rounds/apply/finalize (see GpuShardEngine).
+                     rounds_per_exchange: int = 8, max_exchanges: int = 100_000, gather: bool = True, check_every: int = 8,
+                     device_loop: bool | None = None) -> ShardedResult:
+    """The loop above for ONE rank.  `engine`: begin/rounds/apply/finalize (see GpuShardEngine), optionally
+    rounds_async/apply_async/read_control for the device-resident loop.
     `allreduce_min(x)`: in-place elementwise MIN over all ranks of a buffer the engine handed out (a torch tensor
     or a numpy array, the engine decides) -- the only communication there is."""
     engine.begin(seed, target, goal_dist_offset)
@@ -63,27 +71,43 @@ def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, go
     # on the termination reduce, so that a rank-local cancel or failure ends the plan on ALL ranks in the same exchange
     # instead of leaving the others blocked in the next collective.
     ctl = engine.control_buffer()
+    if device_loop is None:
+        device_loop = hasattr(engine, "apply_async")
 
-    def agreed_status() -> int:
-        return int(round(-float(ctl[2])))
+    def failed(st: int) -> ShardedResult:
+        return ShardedResult(CANCELED if st == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
 
     while True:
-        buf = engine.rounds(rounds_per_exchange)
-        rounds += rounds_per_exchange
-        allreduce_min(buf)                                            # halo-vertex distances (+ robot vertex)
-        local_min, target_dist = engine.apply(buf)
-        ctl[0] = local_min
-        ctl[1] = target_dist
-        ctl[2] = -float(getattr(engine, "status", 0))
-        allreduce_min(ctl)                                            # termination + status: 12 bytes
-        exchanges += 1
-        if agreed_status():
-            return ShardedResult(CANCELED if agreed_status() == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
-        gmin, gtarget = float(ctl[0]), float(ctl[1])
+        if device_loop:
+            for _ in range(max(1, check_every)):                      # nothing in here waits on the host
+                buf = engine.rounds_async(rounds_per_exchange)
+                rounds += rounds_per_exchange
+                allreduce_min(buf)
+                engine.apply_async(buf, ctl)
+                allreduce_min(ctl)
+                exchanges += 1
+            gmin, gtarget, st = engine.read_control(ctl)              # ONE read-back per block of exchanges
+        else:
+            buf = engine.rounds(rounds_per_exchange)
+            rounds += rounds_per_exchange
+            allreduce_min(buf)                                        # halo-vertex distances (+ robot vertex)
+            local_min, target_dist = engine.apply(buf)
+            ctl[0] = local_min
+            ctl[1] = target_dist
+            ctl[2] = -float(getattr(engine, "status", 0))
+            allreduce_min(ctl)                                        # termination + status: 12 bytes
+            exchanges += 1
+            gmin, gtarget, st = float(ctl[0]), float(ctl[1]), int(round(-float(ctl[2])))
+        if st:
+            return failed(st)
         if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
             break                                                     # nothing left that may still propagate
         if exchanges >= max_exchanges:
             raise RuntimeError("sharded plan did not terminate")      # (the count is the same on every rank)
+
+    def agreed_status() -> int:
+        return int(round(-float(ctl[2])))
+
     dist_buf, pred_buf = engine.finalize()                            # a failing fixed-point check sets engine.status, it does not raise
     ctl[2] = -float(getattr(engine, "status", 0))
     allreduce_min(ctl)
@@ -138,6 +162,29 @@ class GpuShardEngine:
         self.torch.cuda.synchronize()
         return self.ctx.shard_apply(buf.data_ptr())
 
+    # -- the device-resident loop: kernels linked to torch's current stream by events, no host synchronisation
+    def _stream(self) -> int:
+        return int(self.torch.cuda.current_stream().cuda_stream)
+
+    def rounds_async(self, r):
+        try:
+            self.ctx.shard_rounds_async(r, self.buf.data_ptr(), self._stream())
+        except RuntimeError:
+            self.status = 2
+        return self.buf
+
+    def apply_async(self, buf, ctl):
+        try:
+            self.ctx.shard_apply_async(buf.data_ptr(), ctl.data_ptr(), self._stream())
+        except RuntimeError:
+            self.status = 2
+        if self.status:                                                # a host-side failure of this rank rides on the same reduce
+            ctl[2] = -float(self.status)
+
+    def read_control(self, ctl):
+        c = ctl.cpu().numpy()                                          # the one synchronising copy per block of exchanges
+        return float(c[0]), float(c[1]), int(round(-float(c[2])))
+
     def finalize(self):
         self.torch.cuda.synchronize()
         try:
@@ -167,12 +214,16 @@ def torch_allreduce_min(dist):
 
 
 def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offset: float = 0.3,
-                       rounds_per_exchange: int = 8, max_exchanges: int = 100_000) -> ShardedResult:
+                       rounds_per_exchange: int = 8, max_exchanges: int = 100_000, check_every: int = 8,
+                       device_loop: bool | None = None) -> ShardedResult:
     """`world` engines inside ONE process (one GPU standing in for several): the same protocol, the collective
-    replaced by an elementwise minimum over the engines' buffers.  Lock-step version of run_sharded_plan."""
+    replaced by an elementwise minimum over the engines' buffers.  Lock-step version of run_sharded_plan (both of its
+    loops: engines with the asynchronous steps run the device-resident one)."""
     for e in engines:
         e.begin(seed, target, goal_dist_offset)
     ctls = [e.control_buffer() for e in engines]
+    if device_loop is None:
+        device_loop = all(hasattr(e, "apply_async") for e in engines)
 
     def reduce_min(bufs):
         m = bufs[0].clone() if hasattr(bufs[0], "clone") else bufs[0].copy()
@@ -183,20 +234,30 @@ def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offs
 
     exchanges = rounds = 0
     while True:
-        bufs = [e.rounds(rounds_per_exchange) for e in engines]
-        rounds += rounds_per_exchange
-        reduce_min(bufs)
-        for e, b, c in zip(engines, bufs, ctls):
-            lm, td = e.apply(b)
-            c[0] = lm
-            c[1] = td
-            c[2] = -float(getattr(e, "status", 0))
-        reduce_min(ctls)
-        exchanges += 1
-        if int(round(-float(ctls[0][2]))):
-            st = int(round(-float(ctls[0][2])))
+        if device_loop:
+            for _ in range(max(1, check_every)):
+                bufs = [e.rounds_async(rounds_per_exchange) for e in engines]
+                rounds += rounds_per_exchange
+                reduce_min(bufs)
+                for e, b, c in zip(engines, bufs, ctls):
+                    e.apply_async(b, c)
+                reduce_min(ctls)
+                exchanges += 1
+            gmin, gtarget, st = engines[0].read_control(ctls[0])
+        else:
+            bufs = [e.rounds(rounds_per_exchange) for e in engines]
+            rounds += rounds_per_exchange
+            reduce_min(bufs)
+            for e, b, c in zip(engines, bufs, ctls):
+                lm, td = e.apply(b)
+                c[0] = lm
+                c[1] = td
+                c[2] = -float(getattr(e, "status", 0))
+            reduce_min(ctls)
+            exchanges += 1
+            gmin, gtarget, st = float(ctls[0][0]), float(ctls[0][1]), int(round(-float(ctls[0][2])))
+        if st:
             return ShardedResult(CANCELED if st == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
-        gmin, gtarget = float(ctls[0][0]), float(ctls[0][1])
         if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
             break
         if exchanges >= max_exchanges:

@@ -106,3 +106,21 @@ class ModelShardEngine:
         if x is self._pred:
             return (x.view(np.uint32) ^ np.uint32(0x80000000))
         return x
+
+
+class AsyncModelShardEngine(ModelShardEngine):
+    """The same engine behind the asynchronous step protocol of the device-resident loop (rounds_async / apply_async /
+    read_control): on the CPU the steps are of course synchronous -- what the tests exercise is the LOOP: termination words
+    written by the engine, read back only every `check_every` exchanges, exchanges after convergence being harmless."""
+
+    def rounds_async(self, r):
+        return self.rounds(r)
+
+    def apply_async(self, buf, ctl):
+        lm, td = self.apply(buf)
+        ctl[0] = lm
+        ctl[1] = td
+        ctl[2] = -float(self.status)
+
+    def read_control(self, ctl):
+        return float(ctl[0]), float(ctl[1]), int(round(-float(ctl[2])))

@@ -20,8 +20,9 @@ def engines(case, world, gpu_ctx_factory, cost_limit=1.0):
     return out
 
 
-@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0)])
-def test_sharded_plan_c1_bit_exact(gpu_ctx_factory, world, offset):
+@pytest.mark.parametrize("device_loop", [True, False])             # exchange loop resident on the device (stream events, termination
+@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0)])   # words read every 8 exchanges) / host-checked
+def test_sharded_plan_c1_bit_exact(gpu_ctx_factory, world, offset, device_loop):
     case = terrain_case(224, 1)
     m = case.mesh
     seed, target = m.vertex_at(0.1, 0.1), m.vertex_at(0.9, 0.9)
@@ -30,8 +31,8 @@ def test_sharded_plan_c1_bit_exact(gpu_ctx_factory, world, offset):
     infos = [e.info for e in eng]
     assert infos[0]["t_lo"] == 0 and infos[-1]["t_hi"] == infos[0]["ntiles"]
     assert all(a["t_hi"] == b["t_lo"] for a, b in zip(infos, infos[1:]))
-    res = sharded.plan_virtual_ranks(eng, seed, target, offset, rounds_per_exchange=4, max_exchanges=5000)
-    assert res.code == ref.code == 0 and res.exchanges > 2
+    res = sharded.plan_virtual_ranks(eng, seed, target, offset, rounds_per_exchange=4, max_exchanges=5000, device_loop=device_loop)
+    assert res.code == ref.code == 0 and res.exchanges > 2 and (not device_loop or res.exchanges % 8 == 0)
     assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32))
     assert np.array_equal(res.pred, ref.pred) and np.array_equal(res.path, ref.path)
 

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from mesh_navigation_amd import meshgen, sharded
 from tests.common import Case
-from tests.shard_model import ModelShardEngine
+from tests.shard_model import AsyncModelShardEngine, ModelShardEngine
 
 
 def _free_port():
@@ -31,13 +31,15 @@ def _case():
     return Case(mesh, costs, 0.5)
 
 
-def _worker(rank, world, port, seed, target, offset, rpe, q):
+def _worker(rank, world, port, seed, target, offset, rpe, q, check_every=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     case = _case()
-    eng = ModelShardEngine(case.mesh, case.weights, case.costs, rank, world)
-    res = sharded.run_sharded_plan(eng, sharded.torch_allreduce_min(dist), seed, target, offset, rounds_per_exchange=rpe)
+    # check_every > 0: the device-resident loop (termination words read back once per block of exchanges)
+    eng = (AsyncModelShardEngine if check_every else ModelShardEngine)(case.mesh, case.weights, case.costs, rank, world)
+    res = sharded.run_sharded_plan(eng, sharded.torch_allreduce_min(dist), seed, target, offset, rounds_per_exchange=rpe,
+                                   check_every=max(1, check_every))
     if rank == 0:
         q.put((res.code, res.dist.tobytes(), res.pred.tobytes(), res.path.tolist(), res.exchanges))
     dist.barrier()
@@ -45,8 +47,8 @@ def _worker(rank, world, port, seed, target, offset, rpe, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,offset,rpe", [(2, 0.3, 4), (3, float("inf"), 2), (2, 0.0, 16)])
-def test_sharded_single_plan_matches_oracle(world, offset, rpe):
+@pytest.mark.parametrize("world,offset,rpe,check_every", [(2, 0.3, 4, 0), (3, float("inf"), 2, 0), (2, 0.0, 16, 0), (2, 0.3, 4, 5), (3, 0.3, 2, 8)])
+def test_sharded_single_plan_matches_oracle(world, offset, rpe, check_every):
     case = _case()
     m = case.mesh
     seed, target = m.vertex_at(0.1, 0.15), m.vertex_at(0.9, 0.85)       # the path crosses every strip
@@ -54,7 +56,7 @@ def test_sharded_single_plan_matches_oracle(world, offset, rpe):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, target, offset, rpe, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, target, offset, rpe, q, check_every)) for r in range(world)]
     for p in procs:
         p.start()
     code, dbytes, pbytes, path, exchanges = q.get(timeout=240)
@@ -64,6 +66,8 @@ def test_sharded_single_plan_matches_oracle(world, offset, rpe):
     d = np.frombuffer(dbytes, np.float32)
     pr = np.frombuffer(pbytes, np.uint32)
     assert code == ref.code == 0 and exchanges > 2
+    if check_every:
+        assert exchanges % check_every == 0                          # whole blocks: the loop only looks at the words between them
     assert np.array_equal(d.view(np.uint32), ref.dist.view(np.uint32))
     assert np.array_equal(pr, ref.pred) and path == ref.path.tolist()
 
@@ -74,11 +78,12 @@ def test_virtual_ranks_in_one_process_and_unreachable_target():
     m = case.mesh
     seed, target = m.vertex_at(0.2, 0.2), m.vertex_at(0.8, 0.7)
     ref = case.om.dijkstra(case.weights, case.costs, seed, target)
-    engines = [ModelShardEngine(m, case.weights, case.costs, r, 4) for r in range(4)]
-    res = sharded.plan_virtual_ranks(engines, seed, target, rounds_per_exchange=3)
-    assert res.code == ref.code == 0
-    assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(res.pred, ref.pred)
-    assert np.array_equal(res.path, ref.path)
+    for cls, every in ((ModelShardEngine, 1), (AsyncModelShardEngine, 6)):      # host-checked loop / device-resident loop
+        engines = [cls(m, case.weights, case.costs, r, 4) for r in range(4)]
+        res = sharded.plan_virtual_ranks(engines, seed, target, rounds_per_exchange=3, check_every=every)
+        assert res.code == ref.code == 0
+        assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(res.pred, ref.pred)
+        assert np.array_equal(res.path, ref.path)
     # a target nobody reaches: invalid ring around it
     inv = np.zeros(m.V, np.uint8)
     ring = np.unique(m.edges[(m.edges == target).any(1)].ravel())
