@@ -276,7 +276,7 @@ class MnavContext:
         self._L.mnav_set_band_width(self._h, float(delta))
 
     def set_dijkstra_engine(self, engine: str):
-        """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'wave' (one wave per plan)."""
+        """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan) or 'tile_batch' (large batches: one plan per lane)."""
         self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "tile_batch": 5}[engine])
 
     def set_resident_outputs(self, on: bool = True):
