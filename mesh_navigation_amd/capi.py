@@ -470,12 +470,21 @@ class MnavContext:
         codes = np.empty(n, np.uint32)
         dist = np.empty((n, V), np.float32) if want_fields else None
         pred = np.empty((n, V), np.uint32) if want_fields else None
-        # the rows of the path buffer are only touched where a path lands: keep the (mostly untouched) buffer between calls
-        # (only while no earlier result still refers to it)
+        # the rows of the path buffer are only touched where a path lands: keep the (mostly untouched) buffers between calls --
+        # a fresh 335 MB buffer per call costs one page fault per row (12 ms per 5120-plan batch).  A small pool, because the
+        # caller usually still holds the previous call's result (which refers to its buffer) while the next call runs.
         key = (n, max(cap, 1))
-        if getattr(self, "_path_buf_key", None) != key or sys.getrefcount(self._path_buf) > 2:
-            self._path_buf, self._path_buf_key = np.empty(key, np.uint32), key
-        paths = self._path_buf
+        if getattr(self, "_path_buf_key", None) != key:
+            self._path_pool, self._path_buf_key = [], key
+        paths = None
+        for buf in self._path_pool:
+            if sys.getrefcount(buf) <= 3:                             # the pool, the loop variable, getrefcount's argument
+                paths = buf
+                break
+        if paths is None:
+            paths = np.empty(key, np.uint32)
+            if len(self._path_pool) < 3:
+                self._path_pool.append(paths)
         lens = np.zeros(n, np.uint32)
         rc = self._L.mnav_plan_dijkstra_batch(self._h, n, _p(seeds), _p(targets), float(goal_dist_offset),
                                               float(cost_limit), _p(codes), _p(dist), _p(pred), _p(paths), cap, _p(lens))

@@ -2121,7 +2121,7 @@ struct mnav_ctx {
 
 namespace {
 
-#define MTRACE(msg) do { if (getenv("MNAV_TRACE")) { fprintf(stderr, "[mnav] %s:%d %s\n", __func__, __LINE__, msg); fflush(stderr); } } while (0)
+#define MTRACE(msg) do { if (getenv("MNAV_TRACE")) { fprintf(stderr, "[mnav] %9.3f ms %s:%d %s\n", 1e-3 * (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(), __func__, __LINE__, msg); fflush(stderr); } } while (0)
 #define HIPCHK(call)                                                                               \
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
@@ -3598,6 +3598,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       if (vecmap_out && want_vecmap && hipMemcpyAsync(vecmap_out + (size_t)i * 3 * V, ctx->slots[k].vecmap, 12 * (size_t)V, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         { ctx->err = "vecmap download failed"; return MNAV_INTERNAL_ERROR; }
     }
+    MTRACE("paths copied out");
     (void)hipEventRecord(ctx->ev[6], ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "sync failed"; return MNAV_INTERNAL_ERROR; }
     finish_stats(ctx, m, false);

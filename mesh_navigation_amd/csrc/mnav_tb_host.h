@@ -216,6 +216,16 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   hipLaunchKernelGGL(k_tb_seed, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+  if (S.D2) {
+    // the other buffer (the previous call's distances: superseded the moment this call began) is cleaned for the NEXT call
+    // now, on its own stream, next to the solve -- which is latency bound and leaves the HBM write bandwidth idle; behind the
+    // engine run the fill would compete with the finalize pass's output writes and, in back-to-back batches, still be
+    // running when the next call wants the buffer
+    const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
+    hipLaunchKernelGGL(k_tb_fill, dim3(256 * 2), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
+    HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
+    S.d2_clean = true; S.d2_clean_np = n;
+  }
 
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -258,12 +268,6 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     if (iters > ctx->max_steps) { ctx->err = "tile-batch engine: iteration cap hit"; return -1; }
   }
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  if (S.D2) {                                                         // the other buffer (the previous call's distances, dead by now) is cleaned for the next call
-    const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
-    hipLaunchKernelGGL(k_tb_fill, dim3(256 * 8), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
-    HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
-    S.d2_clean = true; S.d2_clean_np = n;
-  }
   if (rc == 0 && !ctx->lazy_paths) {
     // V-sized outputs wanted (potential, predecessors, vector map): the finalize pass of the tile engines derives the
     // reference's exact cut-off semantics and predecessors straight from the blocked distances (k_dij_finalize<8, true>)
