@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- plans/sec of the MI355X wavefront planner on BASELINE config C2.
 
-One "step" = one batch of B (default 5120) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex synthetic
+One "step" = one batch of B (default 7168: 234 GB of the 288 GB with the V-sized outputs of every plan resident) independent Dijkstra (delta-stepping SSSP) plans on the 1M-vertex synthetic
 terrain (N=1000, h=0.1 m, seed 2, edge_cost_factor 0, reference default cut-offs goal_dist_offset 0.3 /
 cost_limit 1.0), B goal vertices drawn per step, common robot vertex (the concurrent-goals shape of BASELINE config 5).
 Every plan does what the reference's dijkstra() does (dijkstra_mesh_planner.cpp:217-398): the wave, the cut-off
@@ -56,7 +56,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "5120")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MNAV_BENCH_BATCH", "7168")))
     ap.add_argument("--grid", type=int, default=int(os.environ.get("MNAV_BENCH_N", "1000")))
     ap.add_argument("--offset", type=float, default=float(os.environ.get("MNAV_BENCH_OFFSET", "0.3")),
                     help="goal_dist_offset (reference default 0.3; inf = full-field variant of SURVEY.md 8d)")
@@ -246,7 +246,7 @@ def main() -> None:
             for name, leg in (("C2_paths_only", lambda: leg_paths_only(ctx, mesh, robot, rng, args)),
                               ("C5", lambda: leg_c5(ctx, mesh, edge_w, costs, robot, args))):
                 cfgs[name] = run_leg(leg)
-            ctx.close(); ctx = None                                   # free the 5120 plan slots before the other meshes
+            ctx.close(); ctx = None                                   # free the plan slots before the other meshes
             cfgs["C2_adapter_inclusive"] = run_leg(lambda: leg_adapter(mesh, vnrm, fnrm, edge_w, costs, first, robot))
             cfgs["C3"] = run_leg(lambda: leg_c3(local_rank, args))
             if not args.skip_c4:

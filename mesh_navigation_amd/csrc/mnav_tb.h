@@ -352,11 +352,14 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
         }
       }
       MNAV_GLOBAL const u32x4* g4p = (MNAV_GLOBAL const u32x4*)(sl + T);
+      uint32_t first_order = 0;                                       // sweep order of the first sweep (wave-uniform)
       TB_STAMP(1);
       // ---- ghosts -> owned (the ghosts are constant during the activation)
       if (W.pre_chunks) {
         tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.pre_off * kTbChunk, stage, (uint32_t)lane);
         u32x4 G = { 0u, 0u, 0u, 0u };
+        float gmin = inf_f();                                         // smallest ghost value that lowered one of this lane's vertices ...
+        uint32_t gord = 0;                                            // ... and the sweep order that runs with a wave entering there
         for (uint32_t c = 0; c < W.pre_chunks; ++c) {
           const uint32_t cur_at = S.next((uint32_t)lane);             // chunk c readable, chunk c + 1 staged behind it
           const u32x4 hd0 = tb::ldsr4(cur_at), q3 = tb::ldsr4(cur_at + 48);   // block 0: header + chunk fields (d12 group, d13 next group)
@@ -373,25 +376,37 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
               const u32x4 o1 = tb::ldsr4(b + 16), w2 = tb::ldsr4(b + 32);   // d4..d7, d8..d11
               const uint32_t offs[5] = { h.y, h.z, h.w, o1.x, o1.y };
               const uint32_t ws[5] = { o1.z, o1.w, w2.x, w2.y, w2.z };
+              bool lowered = false;
 #pragma unroll
               for (int k = 0; k < (int)kTbGhostEdges; ++k) {
                 if ((uint32_t)k < n) {
                   const uint32_t a = offs[k] + lane4;
                   const uint32_t nd = f2u(g + u2f(ws[k]));
                   const uint32_t raw = tb::ldsr(a);
-                  tb::ldsw(a, nd < (raw & 0x7fffffffu) ? (nd | kTbDirty) : raw);
+                  const bool low = nd < (raw & 0x7fffffffu);
+                  lowered |= low;
+                  tb::ldsw(a, low ? (nd | kTbDirty) : raw);
                 }
               }
+              if (lowered && g < gmin) { gmin = g; gord = (h.x >> kTbOrderShift) & 3u; }
             }
           }
           G = Gn;
+        }
+        // the order most lanes ask for (lanes whose ghosts lowered nothing do not vote; no votes: order 0)
+        const bool votes = active && gmin < inf_f();
+        uint32_t bestc = 0;
+#pragma unroll
+        for (uint32_t o = 0; o < 4; ++o) {
+          const uint32_t cn = (uint32_t)__popcll(__ballot(votes && gord == o));
+          if (cn > bestc) { bestc = cn; first_order = o; }
         }
       }
       TB_STAMP(2);
       // ---- Gauss-Seidel sweeps to the tile-local fixed point
       uint32_t sweep = 0;
       for (;;) {
-        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + ((size_t)W.sweep_off + (size_t)(sweep & 3u) * W.sweep_chunks) * kTbChunk;
+        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + ((size_t)W.sweep_off + (size_t)((sweep + first_order) & 3u) * W.sweep_chunks) * kTbChunk;
         const unsigned long long any = tb_sweep<T>(st, W.sweep_chunks, stage, (uint32_t)lane, lane4);
         ++sweep;
         if (any == 0ull) break;

@@ -64,6 +64,7 @@ constexpr uint32_t kTbBlocksPerChunk = 4;
 constexpr uint32_t kTbGhostEdges = 5;       // edges per pre / post block
 constexpr uint32_t kTbGhostEnd = 1u << 4;   // last block of this ghost (post: compare the candidate with the ghost value)
 constexpr uint32_t kTbTileEnd = 1u << 6;    // last ghost owned by this neighbour tile (post: emit the wake-up)
+constexpr uint32_t kTbOrderShift = 12;      // pre blocks, 2 bits: the sweep order that runs with a wave entering through this ghost
 constexpr uint32_t kTbInfBits = 0x7f800000u;
 constexpr uint32_t kTbDirty = 0x80000000u;  // sign bit of an LDS value: lowered during this activation
 
@@ -282,6 +283,17 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
       H.stream.resize((size_t)W.sweep_off * kTbChunk); H.wsrc.resize((size_t)W.sweep_off * kTbChunk);
       H.stream.insert(H.stream.end(), st2.begin(), st2.end()); H.wsrc.insert(H.wsrc.end(), ws2.begin(), ws2.end());
     }
+    // which of the four sweep orders runs WITH a wave that enters through ghost gv: the one whose direction has the largest
+    // component along (tile centroid - ghost position).  The solve starts its sweeps with the order most lanes ask for.
+    float cen[2] = { 0.f, 0.f };
+    for (uint32_t i = 0; i < W.nv; ++i) { const float* q = &xyz[3 * (size_t)H.verts[W.v0 + i]]; cen[0] += q[a0]; cen[1] += q[a1]; }
+    if (W.nv) { cen[0] /= (float)W.nv; cen[1] /= (float)W.nv; }
+    auto ghost_order = [&](uint32_t gv) -> uint32_t {
+      const float d0 = cen[0] - xyz[3 * (size_t)gv + a0], d1 = cen[1] - xyz[3 * (size_t)gv + a1];
+      uint32_t best = 0; float bv = -INFINITY;
+      for (uint32_t o = 0; o < 4; ++o) { const float sc = dirs[o][0] * d0 + dirs[o][1] * d1; if (sc > bv) { bv = sc; best = o; } }
+      return best;
+    };
     // --- pre / post streams: one chunk per group of 4 ghosts (more when a group needs more than 5 blocks)
     auto emit_ghost_stream = [&](bool post) {
       const size_t first = H.stream.size() / kTbChunk;
@@ -315,6 +327,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
           const size_t at = open_block();
           uint32_t fl = (h & 3u) | (n << 8);
           if (last) fl |= kTbGhostEnd | (tile_end ? kTbTileEnd : 0u);
+          if (!post) fl |= ghost_order(gv) << kTbOrderShift;
           H.stream[at] = fl;
           for (uint32_t q = 0; q < n; ++q) {
             H.stream[at + 1 + q] = es[i + q].row * kRow;

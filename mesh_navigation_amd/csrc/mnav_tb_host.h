@@ -221,8 +221,10 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     // now, on its own stream, next to the solve -- which is latency bound and leaves the HBM write bandwidth idle; behind the
     // engine run the fill would compete with the finalize pass's output writes and, in back-to-back batches, still be
     // running when the next call wants the buffer
+    // ... with few workgroups: at full width the fill saturates the HBM write queues and the small kernels of the first
+    // iterations crawl behind it (k_tb_seed / k_tb_plan took 6-7 ms each); 192 workgroups move ~0.4 TB/s, done well within the run
     const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
-    hipLaunchKernelGGL(k_tb_fill, dim3(256 * 2), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
+    hipLaunchKernelGGL(k_tb_fill, dim3(192), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
     HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
     S.d2_clean = true; S.d2_clean_np = n;
   }
