@@ -305,16 +305,19 @@ __device__ unsigned long long g_tb_timing[8];
 #define TB_STAMP(k) do { } while (0)
 #endif
 
+constexpr uint32_t kTbWakeRecs = 32;        // neighbour tiles whose first wake-ups one list append covers
+
 template <int T>
 __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
 {
 #ifdef MNAV_TB_TIMING
   unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
 #endif
-  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + 2 * kTbChunk];   // [row][lane] + two stream staging buffers
+  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + 2 * kTbChunk + 3 * kTbWakeRecs];   // [row][lane] + two stream staging buffers + first-wake-up records
   const int lane = threadIdx.x;
   const uint32_t lane4 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * lane;
   const uint32_t stage = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * (T * 64);
+  const uint32_t wake_rec = stage + 4u * (2 * kTbChunk);             // {neighbour tile, lane mask lo, hi} per neighbour tile with first wake-ups
   const uint32_t NP = A.NP;
   const tb::cblk8_t tiles = (tb::cblk8_t)(uintptr_t)A.tiles;
   const uint32_t n_items = A.ctl->n_items;
@@ -429,11 +432,60 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
         }
       }
       TB_STAMP(4);
-      // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex
+      // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex.
+      // A wake-up is three dependent memory operations (look at the pending value, atomicMin it, learn from the old value
+      // whether this is the pair's first wake-up) and the list append a fourth: done one after the other per neighbour tile
+      // they were a third of an item's time.  They are pipelined over the neighbour tiles instead -- at tile end k the look
+      // for tile k is issued, the atomic for tile k-1 (whose look has arrived), and the old value of tile k-2 is consumed --
+      // and the first wake-ups of the whole item are appended to the pending list with ONE counter atomic at the end.
       if (W.post_chunks) {
         tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.post_off * kTbChunk, stage, (uint32_t)lane);
         u32x4 G = { 0u, 0u, 0u, 0u };
         uint32_t cand = kTbInfBits, best = kTbInfBits;
+        MNAV_GLOBAL uint32_t* const pend_p = as_global(A.pend) + p;
+        MNAV_GLOBAL uint32_t* const pm = as_global(A.marr[par ^ 1]) + p;
+        // stage 1: looked at, stage 2: atomic in flight (t2 uniform, the rest per lane)
+        uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, t2_2 = 0, best_2 = kTbInfBits, old_2 = 0;
+        bool want_1 = false, did_2 = false;
+        uint32_t n_first = 0, n_rec = 0;                                // first wake-ups of this item so far / (tile, lane mask) records in LDS
+        auto flush = [&]() {                                            // append the recorded first wake-ups: one counter atomic
+          if (n_first) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
+            base = tb::rfl(base);
+            uint2* list = A.cand[par ^ 1];
+            for (uint32_t r = 0; r < n_rec; ++r) {
+              const uint32_t tt = tb::ldsr(wake_rec + 12u * r), lo = tb::ldsr(wake_rec + 12u * r + 4u), hi = tb::ldsr(wake_rec + 12u * r + 8u);
+              const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+              if ((m >> lane) & 1ull) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(tt, p);
+              base += (uint32_t)__popcll(m);
+            }
+          }
+          n_first = 0; n_rec = 0;
+        };
+        auto advance = [&](uint32_t t2_new, uint32_t best_new, bool want_new) {
+          // stage 3: the old value of the atomic issued one tile end ago
+          bool first = false;
+          if (did_2) {
+            first = old_2 == kTbInfBits;
+            if (best_2 < old_2) atomicMin((uint32_t*)pm, best_2);       // the plan's smallest pending value of the next iteration
+            ++my_wakes;
+          }
+          const unsigned long long fm = __ballot(first);
+          if (fm) {
+            if (n_rec == kTbWakeRecs) flush();
+            if (lane == 0) { tb::ldsw(wake_rec + 12u * n_rec, t2_2); tb::ldsw(wake_rec + 12u * n_rec + 4u, (uint32_t)fm); tb::ldsw(wake_rec + 12u * n_rec + 8u, (uint32_t)(fm >> 32)); }
+            ++n_rec; n_first += (uint32_t)__popcll(fm);
+          }
+          // stage 2: the look has arrived -- within this launch a wake-up value only ever decreases, so a (possibly stale) plain
+          // load is an upper bound of the true value: if it already is <= ours the wake-up changes nothing
+          did_2 = want_1 && best_1 < cur_1;
+          t2_2 = t2_1; best_2 = best_1;
+          if (did_2) old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1);
+          // stage 1: look
+          want_1 = want_new; t2_1 = t2_new; best_1 = best_new;
+          if (want_new) cur_1 = pend_p[(size_t)t2_new * NP];
+        };
         for (uint32_t c = 0; c < W.post_chunks; ++c) {
           const uint32_t cur_at = S.next((uint32_t)lane);
           const u32x4 hd0 = tb::ldsr4(cur_at), q3 = tb::ldsr4(cur_at + 48);
@@ -458,27 +510,16 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
                 cand = kTbInfBits;
               }
               if (hd & kTbTileEnd) {
-                const uint32_t t2 = tb::rfl(w2.w);                    // d11: owner tile (uniform)
-                bool first = false;
-                if (active && best != kTbInfBits) {
-                  // Look before asking: within this launch a wake-up value only ever decreases, so a (possibly stale) plain load
-                  // is an upper bound of the true value: if it already is <= ours the wake-up changes nothing.
-                  MNAV_GLOBAL uint32_t* pw = as_global(A.pend) + ((size_t)t2 * NP + p);
-                  if (best < *pw) {
-                    const uint32_t old = atomicMin((uint32_t*)pw, best);
-                    first = old == kTbInfBits;
-                    MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
-                    if (best < old && best < *pm) atomicMin((uint32_t*)pm, best);
-                    ++my_wakes;
-                  }
-                }
-                tb::append_pair(first, t2, p, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
+                advance(tb::rfl(w2.w), best, active && best != kTbInfBits);   // d11: owner tile (uniform)
                 best = kTbInfBits;
               }
             }
           }
           G = Gn;
         }
+        advance(0u, kTbInfBits, false);                                // drain the two stages in flight
+        advance(0u, kTbInfBits, false);
+        flush();
       }
       TB_STAMP(5);
       // ---- export the lowered boundary values to the ghost slots that mirror them
