@@ -120,6 +120,11 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def first_of(g, t, r):
+        # what the legs outside the timed region need of the first batch: its goals and the codes / paths of its first plans
+        k = min(B, 512)
+        return g, t, {"codes": r["codes"][:k].copy(), "paths": [r["paths"][i] for i in range(k)]}
+
     # every plan leaves potential, predecessors and vector map behind, like the reference's dijkstra() (:380): resident in HBM
     ctx.set_resident_outputs(True)
     first = None
@@ -127,7 +132,8 @@ def main() -> None:
         g, t = batch_goals()
         r = ctx.plan_dijkstra_batch(g, t, goal_dist_offset=args.offset, want_fields=False, path_cap=16384)
         if first is None:
-            first = (g, t, r)
+            first = first_of(g, t, r)
+    r = None                                                            # (a result keeps its path buffer of the binding's pool busy)
     prop_ms = kern_ms = launches = algo = vec_ms = 0.0
     settled = 0
     barrier()
@@ -140,7 +146,7 @@ def main() -> None:
         prop_ms += st["ms_propagation"]; kern_ms += st["ms_step_kernels"]; launches += st["launches"]; vec_ms += st["ms_vector_map"]
         algo += st["algorithmic_bytes"]; settled += st["settled"]
         if first is None:
-            first = (g, t, r)
+            first = first_of(g, t, r)
     barrier()
     elapsed = time.perf_counter() - t0
     from mesh_navigation_amd import multi
