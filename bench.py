@@ -199,7 +199,7 @@ def main() -> None:
         # roofline of the dominant kernel: algorithmic bytes per launch (24 B per settled vertex + 24 B per
         # incident edge, summed over the batch) divided by the average launch duration, measured live with HIP events that
         # the library records on ITS OWN stream around the engine's launches.  Batches of >= 256 plans run on the tile-batch
-        # engine: ONE engine run per batch = a few hundred iterations of k_tb_plan / k_tb_filter / k_tb_items / k_tb_solve
+        # engine: ONE engine run per batch = a few hundred iterations of k_tb_plan / k_tb_scan / k_tb_items / k_tb_solve
         # replayed from a hipGraph (k_tb_solve is > 90 % of it, profiles/r03_bench_kernel_stats.md); the events bracket the
         # whole run, so `achieved` prices the scheduling kernels too.  HBM traffic per run from the PMC passes committed
         # under profiles/ (tools/prof_pmc.sh: FETCH_SIZE / WRITE_SIZE summed over the engine's kernels of one batch) -- only
@@ -238,7 +238,7 @@ def main() -> None:
             "cvp_planner_same_mesh": cvp,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_tb_solve (tile-batch engine run: plan/filter/items/solve iterations)" if launches <= args.steps else "k_tile_round",
+                         "kernel": "k_tb_solve (tile-batch engine run: plan/scan/items/solve iterations)" if launches <= args.steps else "k_tile_round",
                          "launches_per_step": launches / args.steps, "vector_map_ms_per_step": vec_ms / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
                          "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,

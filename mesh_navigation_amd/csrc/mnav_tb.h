@@ -13,12 +13,12 @@
 //
 // Schedule (level-synchronous over all plans, a few launches per iteration, replayed from a hipGraph):
 //   k_tb_plan    per plan: band threshold thr = (smallest pending wake-up) + band, bound = dist[target] + offset
-//   k_tb_filter  per pending (tile, plan) pair: wake-up < thr -> the tile's bucket; > bound -> dropped; else carried
+//   k_tb_scan    every pending value pend[tile][plan]: < thr -> the tile's bucket; > bound -> dropped; else carried (counted)
 //   k_tb_items   per tile: the bucket is cut into work items of <= 64 plans
 //   k_tb_solve   per item: load the plans' slices, fold the ghost values in, sweep, write back what changed, wake the
 //                neighbouring tiles whose vertices were undercut, export changed boundary values to their ghost slots
 // Data written during an iteration is consumed in the next one (kernel boundary), so there is no intra-kernel
-// producer/consumer protocol; wake-ups use atomicMin on the pair's wake-up value, the first waker appends the pair.
+// producer/consumer protocol; wake-ups use atomicMin on the pair's wake-up value, the first waker counts the pair.
 #pragma once
 
 #include "mnav_tb_build.h"
@@ -40,7 +40,7 @@ enum { kTwSoff = 0, kTwSl = 1, kTwNv = 2, kTwNh = 3, kTwSweepOff = 4, kTwSweepCh
 static_assert(offsetof(TbTile, exp_n) == 4 * kTwExpN && offsetof(TbTile, sweep_off) == 4 * kTwSweepOff, "TbTile layout");
 
 struct Ctl {
-  uint32_t n_cand[2];        // pending (tile, plan) pairs: list read / list written, by iteration parity
+  uint32_t n_cand[2];        // pending (tile, plan) pairs after / during an iteration, by iteration parity (0 at the end: converged)
   uint32_t n_items, next_item;
   uint32_t err;              // 1: sweep cap hit
   uint32_t iters;
@@ -54,7 +54,7 @@ struct Args {
   const TbTile* tiles; const uint32_t* stream; const TbExp* exps;
   float* D; uint32_t* pend; uint32_t NP, ntiles;
   uint16_t* bucket; uint32_t* bcnt; uint2* items; Ctl* ctl;
-  uint2* cand[2]; uint32_t* marr[2];
+  uint32_t* marr[2];
   float* thr; float* bnd;
   const uint32_t* seed; const uint32_t* target;                        // per plan: wave source / robot vertex
   const uint2* vaddr; const uint32_t* vert_tile;                      // per vertex: {soff, sl << 8 | local}, tile
@@ -94,18 +94,6 @@ struct Stream {
 };
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// wave-aggregated append of the pair (t, p) of every lane with `want`
-__device__ __forceinline__ void append_pair(bool want, uint32_t t, uint32_t p, uint2* list, uint32_t* count, int lane)
-{
-  const unsigned long long m = __ballot(want);
-  if (m == 0ull) return;
-  const int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(t, p);
-}
-
 }  // namespace tb
 
 __global__ __launch_bounds__(kBlock) void k_tb_weights(size_t n, const uint32_t* __restrict__ wsrc, const Nbr* __restrict__ nbr, uint32_t* __restrict__ stream)
@@ -141,8 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_seed(tb::Args A)
   }
   A.pend[(size_t)t * A.NP + p] = 0u;
   A.marr[0][p] = 0u;
-  const uint32_t i = atomicAdd(&A.ctl->n_cand[0], 1u);
-  A.cand[0][i] = make_uint2(t, p);
+  atomicAdd(&A.ctl->n_cand[0], 1u);
 }
 
 // per plan and iteration: band threshold and goal bound
@@ -163,34 +150,54 @@ __global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
   A.bnd[p] = bound;
 }
 
-// per pending pair: ready (into the tile's bucket), dropped (beyond the goal bound) or carried to the next iteration
-__global__ __launch_bounds__(kBlock) void k_tb_filter(tb::Args A, int par)
+// The pending values pend[tile][plan] (+inf: none), all of them, once per iteration: an entry below its plan's band threshold
+// is READY (cleared, the plan goes into the tile's bucket), one beyond the goal bound is dropped (it can never propagate any
+// more: the bound only shrinks), the rest is CARRIED (counted, and its smallest value per plan is next iteration's band
+// start).  Dense on purpose: the matrix is 4 B x tiles x plans (265 MB for 7168 plans on the 1M mesh, ~65 us at HBM speed),
+// which is less than walking lists of pending pairs cost (random 4-byte reads, an atomic per ready pair and per list append:
+// 165 us).  A thread owns one plan and walks a range of tiles (coalesced along the plans): threshold, bound and the running
+// minimum stay in registers; a wave that finds ready plans for a tile takes its bucket slots with ONE atomic, whose answer is
+// picked up an iteration of the loop later.
+constexpr uint32_t kTbScanTiles = 64;       // tiles per workgroup of k_tb_scan
+__global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
 {
-  const uint32_t n = A.ctl->n_cand[par];
-  const uint2* in = A.cand[par];
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const uint32_t stride = gridDim.x * kBlock;
-  const uint32_t n_pad = (n + 63u) & ~63u;                          // whole waves stay together for the aggregated append
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_pad; i += stride) {
-    bool carry = false;
-    uint2 e = make_uint2(0u, 0u);
-    if (i < n) {
-      e = in[i];
-      const size_t pi = (size_t)e.x * A.NP + e.y;
-      const uint32_t pb = A.pend[pi];
-      const float pv = u2f(pb);
-      if (pv > A.bnd[e.y]) A.pend[pi] = kTbInfBits;                 // can never propagate any more (the bound only shrinks)
-      else if (pv < A.thr[e.y]) {
-        A.pend[pi] = kTbInfBits;
-        const uint32_t slot = atomicAdd(&A.bcnt[e.x], 1u);
-        A.bucket[(size_t)e.x * A.NP + slot] = (uint16_t)e.y;
-      } else {
-        carry = true;
-        if (pb < A.marr[par ^ 1][e.y]) atomicMin(&A.marr[par ^ 1][e.y], pb);   // plain look first (see k_tb_solve)
-      }
+  const bool live = p < A.NP;
+  const uint32_t pc = live ? p : A.NP - 1u;
+  const float thr = A.thr[pc], bnd = A.bnd[pc];
+  const uint32_t t0 = blockIdx.y * kTbScanTiles, t1 = min(t0 + kTbScanTiles, A.ntiles);
+  MNAV_GLOBAL uint32_t* pend = as_global(A.pend) + pc;
+  uint32_t mn = kTbInfBits, carried = 0;
+  // one tile behind: the bucket slots asked for in the previous loop iteration
+  uint32_t base_prev = 0, t_prev = 0; unsigned long long m_prev = 0ull;
+  auto place = [&]() {
+    if (m_prev) {
+      const uint32_t base = tb::rfl(base_prev);
+      if ((m_prev >> lane) & 1ull) A.bucket[(size_t)t_prev * A.NP + base + (uint32_t)__popcll(m_prev & ((1ull << lane) - 1ull))] = (uint16_t)p;
     }
-    tb::append_pair(carry, e.x, e.y, A.cand[par ^ 1], &A.ctl->n_cand[par ^ 1], lane);
+  };
+  for (uint32_t t = t0; t < t1; ++t) {
+    const uint32_t pb = live ? pend[(size_t)t * A.NP] : kTbInfBits;
+    const float pv = u2f(pb);
+    bool ready = false;
+    if (pb != kTbInfBits) {
+      if (pv > bnd) pend[(size_t)t * A.NP] = kTbInfBits;
+      else if (pv < thr) { pend[(size_t)t * A.NP] = kTbInfBits; ready = true; }
+      else { ++carried; mn = min(mn, pb); }
+    }
+    const unsigned long long m = __ballot(ready);
+    place();
+    m_prev = m; t_prev = t;
+    if (m && lane == 0) base_prev = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));
   }
+  place();
+  if (live && mn != kTbInfBits) {
+    MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
+    if (mn < *pm) atomicMin((uint32_t*)pm, mn);                        // plain look first (see k_tb_solve)
+  }
+  carried = wave_sum(carried);
+  if (lane == 0 && carried) atomicAdd(&A.ctl->n_cand[par ^ 1], carried);
 }
 
 // per tile: cut the bucket into items of <= 64 plans (one workgroup, a few dozen tiles per thread)
@@ -305,19 +312,16 @@ __device__ unsigned long long g_tb_timing[8];
 #define TB_STAMP(k) do { } while (0)
 #endif
 
-constexpr uint32_t kTbWakeRecs = 32;        // neighbour tiles whose first wake-ups one list append covers
-
 template <int T>
 __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
 {
 #ifdef MNAV_TB_TIMING
   unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
 #endif
-  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + 2 * kTbChunk + 3 * kTbWakeRecs];   // [row][lane] + two stream staging buffers + first-wake-up records
+  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + 2 * kTbChunk ];   // [row][lane] + two stream staging buffers
   const int lane = threadIdx.x;
   const uint32_t lane4 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * lane;
   const uint32_t stage = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * (T * 64);
-  const uint32_t wake_rec = stage + 4u * (2 * kTbChunk);             // {neighbour tile, lane mask lo, hi} per neighbour tile with first wake-ups
   const uint32_t NP = A.NP;
   const tb::cblk8_t tiles = (tb::cblk8_t)(uintptr_t)A.tiles;
   const uint32_t n_items = A.ctl->n_items;
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
       // whether this is the pair's first wake-up) and the list append a fourth: done one after the other per neighbour tile
       // they were a third of an item's time.  They are pipelined over the neighbour tiles instead -- at tile end k the look
       // for tile k is issued, the atomic for tile k-1 (whose look has arrived), and the old value of tile k-2 is consumed --
-      // and the first wake-ups of the whole item are appended to the pending list with ONE counter atomic at the end.
+      // and the first wake-ups of the whole item (pairs that were not pending before) are counted with ONE atomic at the end.
       if (W.post_chunks) {
         tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.post_off * kTbChunk, stage, (uint32_t)lane);
         u32x4 G = { 0u, 0u, 0u, 0u };
@@ -445,24 +449,9 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
         MNAV_GLOBAL uint32_t* const pend_p = as_global(A.pend) + p;
         MNAV_GLOBAL uint32_t* const pm = as_global(A.marr[par ^ 1]) + p;
         // stage 1: looked at, stage 2: atomic in flight (t2 uniform, the rest per lane)
-        uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, t2_2 = 0, best_2 = kTbInfBits, old_2 = 0;
+        uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, best_2 = kTbInfBits, old_2 = 0;
         bool want_1 = false, did_2 = false;
-        uint32_t n_first = 0, n_rec = 0;                                // first wake-ups of this item so far / (tile, lane mask) records in LDS
-        auto flush = [&]() {                                            // append the recorded first wake-ups: one counter atomic
-          if (n_first) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
-            base = tb::rfl(base);
-            uint2* list = A.cand[par ^ 1];
-            for (uint32_t r = 0; r < n_rec; ++r) {
-              const uint32_t tt = tb::ldsr(wake_rec + 12u * r), lo = tb::ldsr(wake_rec + 12u * r + 4u), hi = tb::ldsr(wake_rec + 12u * r + 8u);
-              const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-              if ((m >> lane) & 1ull) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(tt, p);
-              base += (uint32_t)__popcll(m);
-            }
-          }
-          n_first = 0; n_rec = 0;
-        };
+        uint32_t n_first = 0;                                           // first wake-ups of this item (pairs that were not pending)
         auto advance = [&](uint32_t t2_new, uint32_t best_new, bool want_new) {
           // stage 3: the old value of the atomic issued one tile end ago
           bool first = false;
@@ -471,16 +460,11 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
             if (best_2 < old_2) atomicMin((uint32_t*)pm, best_2);       // the plan's smallest pending value of the next iteration
             ++my_wakes;
           }
-          const unsigned long long fm = __ballot(first);
-          if (fm) {
-            if (n_rec == kTbWakeRecs) flush();
-            if (lane == 0) { tb::ldsw(wake_rec + 12u * n_rec, t2_2); tb::ldsw(wake_rec + 12u * n_rec + 4u, (uint32_t)fm); tb::ldsw(wake_rec + 12u * n_rec + 8u, (uint32_t)(fm >> 32)); }
-            ++n_rec; n_first += (uint32_t)__popcll(fm);
-          }
+          n_first += first ? 1u : 0u;
           // stage 2: the look has arrived -- within this launch a wake-up value only ever decreases, so a (possibly stale) plain
           // load is an upper bound of the true value: if it already is <= ours the wake-up changes nothing
           did_2 = want_1 && best_1 < cur_1;
-          t2_2 = t2_1; best_2 = best_1;
+          best_2 = best_1;
           if (did_2) old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1);
           // stage 1: look
           want_1 = want_new; t2_1 = t2_new; best_1 = best_new;
@@ -519,7 +503,8 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
         }
         advance(0u, kTbInfBits, false);                                // drain the two stages in flight
         advance(0u, kTbInfBits, false);
-        flush();
+        n_first = wave_sum(n_first);                                   // the pending-pair count of the next iteration: one atomic per item
+        if (lane == 0 && n_first) atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
       }
       TB_STAMP(5);
       // ---- export the lowered boundary values to the ghost slots that mirror them
@@ -655,7 +640,7 @@ struct TbState {
   uint32_t cap_np = 0;
   float* D = nullptr; uint32_t* pend = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;
   tb::Ctl* ctl = nullptr; tb::Ctl* h_ctl = nullptr;
-  uint2* cand[2] = { nullptr, nullptr }; uint32_t* marr[2] = { nullptr, nullptr };
+  uint32_t* marr[2] = { nullptr, nullptr };
   float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;
   uint32_t min_batch = 256;             // auto engine: batches of at least this many plans ...
   double min_lanes = 7.0;               // ... that are expected to fill at least this many lanes of a wave (mnav.hip dijkstra_impl)

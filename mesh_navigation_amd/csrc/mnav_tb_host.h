@@ -6,14 +6,14 @@ void tb_free_batch(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
   (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
-  (void)hipFree(S.cand[0]); (void)hipFree(S.cand[1]); (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
+  (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
   (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target);
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
   for (int k = 0; k < 2; ++k) { if (S.graph[k]) (void)hipGraphExecDestroy(S.graph[k]); S.graph[k] = nullptr; }
   if (S.fill_stream) (void)hipStreamSynchronize(S.fill_stream);
   (void)hipFree(S.D2); S.D2 = nullptr; S.d2_clean = false;
   S.D = nullptr; S.pend = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
-  S.cand[0] = S.cand[1] = nullptr; S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
+  S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
   S.cap_np = 0;
 }
 
@@ -91,7 +91,6 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   HIPCHK(hipMalloc((void**)&S.ctl, sizeof(tb::Ctl)));
   HIPCHK(hipHostMalloc((void**)&S.h_ctl, sizeof(tb::Ctl), hipHostMallocDefault));
   for (int k = 0; k < 2; ++k) {
-    HIPCHK(hipMalloc((void**)&S.cand[k], 8 * pairs + 64));
     HIPCHK(hipMalloc((void**)&S.marr[k], 4 * (size_t)np));
   }
   HIPCHK(hipMalloc((void**)&S.thr, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.bnd, 4 * (size_t)np));
@@ -116,7 +115,7 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
   for (int j = 0; j < count; ++j) {
     const int par = j & 1;
     hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
-    hipLaunchKernelGGL(k_tb_filter, dim3(1024), dim3(kBlock), 0, ctx->stream, A, par);
+    hipLaunchKernelGGL(k_tb_scan, dim3(gp, (A.ntiles + kTbScanTiles - 1) / kTbScanTiles), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
     if (ctx->tb.T == 64) hipLaunchKernelGGL(k_tb_solve<64>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 96) hipLaunchKernelGGL(k_tb_solve<96>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
@@ -190,7 +189,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   tb::Args A{};
   A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.NP = n; A.ntiles = S.ntiles;
   A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl;
-  A.cand[0] = S.cand[0]; A.cand[1] = S.cand[1]; A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
+  A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
   A.offset = offset;
   {

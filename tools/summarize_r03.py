@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out", "prof_r03")
 P = os.path.join(ROOT, "profiles")
 TAG = "r03"
-ENGINE = ("k_tb_plan", "k_tb_filter", "k_tb_items", "k_tb_solve")
+ENGINE = ("k_tb_plan", "k_tb_scan", "k_tb_items", "k_tb_solve")
 
 
 def short(name):
@@ -66,7 +66,7 @@ with open(os.path.join(P, f"{TAG}_bench_kernel_stats.md"), "w") as f:
     f.write("MI355X (gfx950). Command (tools/prof_r03.sh): `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv "
             "-d gpurun_out/prof_r03/trace -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu --no-latency --no-configs`.\n")
     f.write(f"Raw CSV: `profiles/{TAG}_bench_kernel_stats.csv`. Workload: {line['config']['workload']}; {steps_profiled} batches (1 warm-up + 3 timed). "
-            "One batch = ONE run of the tile-batch engine = a few hundred iterations of k_tb_plan / k_tb_filter / k_tb_items / k_tb_solve replayed "
+            "One batch = ONE run of the tile-batch engine = a few hundred iterations of k_tb_plan / k_tb_scan / k_tb_items / k_tb_solve replayed "
             "from a hipGraph, then k_tb_unblock + k_dij_finalize + k_vecmap_dijkstra + k_finish for the V-sized outputs.\n\n")
     f.write("| kernel | calls | total ms | avg µs | min µs | max µs | % |\n|---|---|---|---|---|---|---|\n")
     for r in rows[:14]:
