@@ -684,6 +684,35 @@ def cpu_baseline(mesh, edge_w, costs, first, B, offset=0.3):
             reference_code = {"value": nr / t_ref, "unit": "plans/s", "cores": 1, "ms_per_plan": t_ref / nr * 1e3,
                               "sample": f"first {nr} plans of the first batch through DijkstraMeshPlanner::dijkstra of oracle/_ref (wall clock incl. nearest-vertex lookup)",
                               "map_build_s": t_build, "gpu_paths_match_reference_code": bool(same)}
+            if R.gpu_plugins_linked():
+                # the REAL plugin (integration/mesh_gpu_planners, loaded by pluginlib lookup name) on the reference's own MeshMap,
+                # next to the reference planner's makePlan on the same map: wall time per makePlan, plans compared pose by pose
+                def pose(pt):
+                    return np.array([pt[0], pt[1], pt[2], 0, 0, 0, 1], np.float64)
+                ref_ms, ref_plans = [], []
+                for k in range(nr):
+                    t1 = time.perf_counter()
+                    code, plan, _ = rm.dijkstra_make_plan(pose(mesh.xyz[int(t[k])]), pose(mesh.xyz[int(g[k])]), goal_dist_offset=offset)
+                    ref_ms.append((time.perf_counter() - t1) * 1e3)
+                    ref_plans.append((code, plan))
+                plug, match = {}, True
+                for label, params in (("reference_side_effects", {}),
+                                      ("no_vsized_syncs_static_costs", dict(sync_vector_map=False, publish_potential=False, static_costs=True))):
+                    if not rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "bench_" + label, goal_dist_offset=float(offset), **params):
+                        plug[label] = None
+                        continue
+                    rm.plugin_make_plan(pose(mesh.xyz[int(t[0])]), pose(mesh.xyz[int(g[0])]))      # tables, graphs
+                    ms = []
+                    for k in range(nr):
+                        t1 = time.perf_counter()
+                        code, plan, _, _ = rm.plugin_make_plan(pose(mesh.xyz[int(t[k])]), pose(mesh.xyz[int(g[k])]))
+                        ms.append((time.perf_counter() - t1) * 1e3)
+                        match = match and code == ref_plans[k][0] and np.array_equal(plan, ref_plans[k][1], equal_nan=True)
+                    plug[label] = float(np.median(ms))
+                    rm.plugin_release()
+                reference_code["make_plan"] = {"reference_planner_ms": float(np.median(ref_ms)), "gpu_plugin_ms": plug,
+                                               "plugin_plans_equal_reference_plans": bool(match),
+                                               "sample": f"{nr} makePlan calls each, median wall time, same MeshMap object"}
     except Exception as e:                                               # noqa: BLE001 -- the port figure stands on its own
         reference_code = {"error": repr(e)[:200]}
     return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "reference_code": reference_code, "all_host_cores": all_cores,
