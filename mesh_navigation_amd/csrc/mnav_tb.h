@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
   const float dt = A.D[tb::slot_addr(A.vaddr[target], A.NP, p)];
   const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
   uint32_t code = kSuccess, n = 0, bad = 0;
-  if (A.ctl->err || A.ctl->n_cand[0]) code = kInternalError;          // sweep cap hit / pairs still pending (the host stops after an odd iteration: list 0 is its output)
+  if (A.ctl->err || A.ctl->n_cand[0]) code = kInternalError;          // sweep cap hit / pairs still pending (the host stops after an odd iteration: counter 0 is its count)
   else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
   else {
     uint32_t* path = rows.row(p);                                     // written target-side first

@@ -264,7 +264,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     HIPCHK(hipMemcpyAsync(S.h_ctl, S.ctl, sizeof(tb::Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (S.h_ctl->err) { ctx->err = "tile-batch engine: sweep cap hit"; return -1; }
-    if (S.h_ctl->n_cand[0] == 0u) break;                             // the chunk ends on odd parity: its output list is list 0
+    if (S.h_ctl->n_cand[0] == 0u) break;                             // the chunk ends on odd parity: its pending count is counter 0
     if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
     if (iters > ctx->max_steps) { ctx->err = "tile-batch engine: iteration cap hit"; return -1; }
   }
