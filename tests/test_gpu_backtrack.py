@@ -126,3 +126,39 @@ def test_walk_with_the_device_built_inflation_layer():
     rc0, ppos0, pface0 = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, sf, robot, tf, step_width=0.2)
     assert st0 == 1 and np.array_equal(face0, pface0) and np.array_equal(pos0.view(np.uint32), ppos0.view(np.uint32))
     assert not np.array_equal(pos0, pos) if len(pos0) == len(pos) else True
+
+
+def test_walk_over_a_high_valence_hub_and_holes():
+    """a valence-40 hub: the rows of getFacesOfVertex exceed the 32 candidate slots a lane gathers per listed face, the wave
+    search then reads the rows from memory -- same list order as the sequential search; holes: the search runs dry alike"""
+    for mesh in (meshgen.fan_field(spokes=40, rings=6, seed=1), meshgen.punched(72, 0.1, 4, drop=0.12)):
+        case = Case(mesh)
+        m = case.mesh
+        deg = np.bincount(m.faces.ravel(), minlength=m.V)
+        okv = np.flatnonzero(deg > 0)
+        rng = np.random.default_rng(7)
+        with capi.MnavContext(0) as ctx:
+            ctx.upload_mesh(m.xyz, m.faces, m.edges, case.vn)
+            ctx.upload_costs(case.costs, case.weights)
+            ctx.set_resident_outputs(True)
+            done = 0
+            for _ in range(10):
+                a, b = rng.choice(okv, 2, replace=False)
+                goal = m.xyz[a] + np.array([0.011, 0.007, 0.0], np.float32)
+                robot = m.xyz[b] + np.array([0.009, 0.013, 0.0], np.float32)
+                sf, _ = case.om.containing_face(goal)
+                tf, _ = case.om.containing_face(robot)
+                if not (0 <= sf < m.F and 0 <= tf < m.F):
+                    continue
+                ref = case.om.cvp(case.weights, case.costs, case.vn, goal, int(sf), int(tf))
+                out = ctx.plan_cvp(goal, int(sf), int(tf), want_fields=False, want_vecmap=False)
+                assert out.code == ref.code
+                if ref.code not in (0, 54):
+                    continue
+                for sw in (0.3, 0.08):
+                    rc, ppos, pface = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, goal, int(sf), robot, int(tf), step_width=sw)
+                    st, pos, face = ctx.backtrack_cvp(goal, int(sf), robot, int(tf), step_width=sw, cap=8192)
+                    assert (st == 1) == (rc == 0)
+                    assert np.array_equal(face, pface) and np.array_equal(pos.view(np.uint32), ppos.view(np.uint32))
+                    done += 1
+            assert done >= 6

@@ -63,3 +63,29 @@ def test_walk_with_the_inflation_layers_repulsive_field():
     rc0, ppos0, _ = case2.om.cvp_backtrack(vm, hv, goal, sf, robot, tf, step_width=0.2)
     rc1, ppos1, _ = case2.om.cvp_backtrack(vm, hv, goal, sf, robot, tf, step_width=0.2, inflation_field=field)
     assert len(ppos0) != len(ppos1) or not np.array_equal(ppos0, ppos1)               # the layer's field does bend the path
+
+
+def test_walk_on_a_mesh_with_holes_and_a_high_valence_hub():
+    """holes: searchNeighbourFaces runs out of faces where the reference's does; a valence-40 hub: vertex rows longer than
+    the device's 32 candidate slots per listed face (the wave search falls back to the rows in memory -- same list order)"""
+    for mesh in (meshgen.punched(72, 0.1, 4, drop=0.12), meshgen.fan_field(spokes=40, rings=6, seed=1)):
+        case = Case(mesh)
+        m = case.mesh
+        deg = np.bincount(m.faces.ravel(), minlength=m.V)
+        ok = np.flatnonzero(deg > 0)
+        rng = np.random.default_rng(7)
+        done = 0
+        for _ in range(12):
+            a, b = rng.choice(ok, 2, replace=False)
+            goal = m.xyz[a] + np.array([0.011, 0.007, 0.0], np.float32)
+            robot = m.xyz[b] + np.array([0.009, 0.013, 0.0], np.float32)
+            sf, _ = case.om.containing_face(goal)
+            tf, _ = case.om.containing_face(robot)
+            if sf >= m.F or tf >= m.F or sf < 0 or tf < 0:
+                continue
+            ref = case.om.cvp(case.weights, case.costs, case.vn, goal, int(sf), int(tf))
+            vm, hv = np.ascontiguousarray(ref.vecmap), np.ascontiguousarray(ref.has_vec)
+            for sw in (0.3, 0.08):
+                walk_both(case, vm, hv, goal, int(sf), robot, int(tf), sw)
+                done += 1
+        assert done >= 8
