@@ -158,7 +158,10 @@ __global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
 // 165 us).  A thread owns one plan and walks a range of tiles (coalesced along the plans): threshold, bound and the running
 // minimum stay in registers; a wave that finds ready plans for a tile takes its bucket slots with ONE atomic, whose answer is
 // picked up an iteration of the loop later.
-constexpr uint32_t kTbScanTiles = 64;       // tiles per workgroup of k_tb_scan
+#ifndef MNAV_TB_SCAN_TILES
+#define MNAV_TB_SCAN_TILES 16          // measured on C2: 4 -> 217, 8 -> 200, 16 -> 191, 64 -> 193, 128 -> 197, 512 -> 251 ms per 5120-plan engine run
+#endif
+constexpr uint32_t kTbScanTiles = MNAV_TB_SCAN_TILES;   // tiles per workgroup of k_tb_scan
 __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
 {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
