@@ -117,3 +117,43 @@ def test_rank_local_cancel_ends_the_plan_on_all_virtual_ranks():
     engines[1].rounds = cancelling_rounds
     res = sharded.plan_virtual_ranks(engines, case.mesh.vertex_at(0.1, 0.1), case.mesh.vertex_at(0.9, 0.9), rounds_per_exchange=2)
     assert res.code == sharded.CANCELED and res.exchanges == 3
+
+
+def test_rank_local_cancel_in_the_device_resident_loop():
+    """the same with the loop that only looks at the termination words once per block of exchanges: the status rides on the
+    reduced words of every exchange (MIN over -status keeps it), so the block that contains the cancel ends the plan on
+    every rank -- at the block's end, never later"""
+    case = Case(meshgen.terrain(48, 0.1, 5))
+    engines = [AsyncModelShardEngine(case.mesh, case.weights, case.costs, r, 3) for r in range(3)]
+    orig = engines[2].rounds
+    calls = {"n": 0}
+
+    def cancelling_rounds(r):
+        calls["n"] += 1
+        if calls["n"] == 6:
+            engines[2].status = 1
+        return orig(r)
+
+    engines[2].rounds = cancelling_rounds
+    res = sharded.plan_virtual_ranks(engines, case.mesh.vertex_at(0.1, 0.1), case.mesh.vertex_at(0.9, 0.9), rounds_per_exchange=2, check_every=4)
+    assert res.code == sharded.CANCELED and res.exchanges == 8          # cancel in exchange 6, seen at the end of the block 5..8
+    # a failure (status 2) wins over a cancel (status 1) when both happen in one block
+    engines = [AsyncModelShardEngine(case.mesh, case.weights, case.costs, r, 2) for r in range(2)]
+    o0, o1 = engines[0].rounds, engines[1].rounds
+    n = {"a": 0, "b": 0}
+
+    def r0(r):
+        n["a"] += 1
+        if n["a"] == 2:
+            engines[0].status = 1
+        return o0(r)
+
+    def r1(r):
+        n["b"] += 1
+        if n["b"] == 3:
+            engines[1].status = 2
+        return o1(r)
+
+    engines[0].rounds, engines[1].rounds = r0, r1
+    res = sharded.plan_virtual_ranks(engines, case.mesh.vertex_at(0.1, 0.1), case.mesh.vertex_at(0.9, 0.9), rounds_per_exchange=2, check_every=4)
+    assert res.code == sharded.INTERNAL_ERROR and res.exchanges == 4
