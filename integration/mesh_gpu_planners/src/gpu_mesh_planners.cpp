@@ -83,7 +83,7 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
     const float f = c ? *c : 0.f;
     uint32_t w;
     std::memcpy(&w, &f, 4);
-    mix(w ^ (map.invalid[vH] ? 0x80000001u : 0u));
+    mix(w); mix(map.invalid[vH] ? 1u : 0u);                            // the flag as its own word: no cost bit pattern can mask a flip
   }
   for (uint32_t e = 0; e < E_; ++e) {
     const auto wgt = std::as_const(ew).get(lvr2::EdgeHandle(e));
@@ -250,7 +250,9 @@ uint32_t GpuDijkstraMeshPlanner::makePlan(const PoseStamped& start, const PoseSt
   path_pub_->publish(path_msg);
   if (config_.publish_potential) {                                 // 4 bytes per vertex cross PCIe for it; off = O(path) host work per plan
     std::vector<float> pot;
-    if (outcome == Result::SUCCESS && potential(pot)) {
+    // like the reference (:124) after EVERY plan the wave ran for, NO_PATH_FOUND included; a plan that never reached the
+    // device (invalid start / goal, error, cancel) left no potential behind and publishes nothing
+    if (potential(pot)) {
       lvr2::DenseVertexMap<float> potential_map;
       for (uint32_t v = 0; v < pot.size(); ++v) potential_map.insert(lvr2::VertexHandle(v), pot[v]);
       mesh_map_->publishVertexCosts(potential_map, "Potential", node_->now());

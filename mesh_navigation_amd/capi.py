@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import sys
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -476,21 +477,28 @@ class MnavContext:
         key = (n, max(cap, 1))
         if getattr(self, "_path_buf_key", None) != key:
             self._path_pool, self._path_buf_key = [], key
+        # a pooled buffer is free when no result that was handed out still refers to it: every _PathRows takes a LEASE on its
+        # buffer (a weak reference to the rows object kept next to the buffer), released when the rows object dies
         paths = None
-        for buf in self._path_pool:
-            if sys.getrefcount(buf) <= 3:                             # the pool, the loop variable, getrefcount's argument
-                paths = buf
+        for entry in self._path_pool:
+            entry[1] = [r for r in entry[1] if r() is not None]
+            if not entry[1]:
+                paths = entry[0]
+                lease = entry[1]
                 break
         if paths is None:
             paths = np.empty(key, np.uint32)
+            lease = []
             if len(self._path_pool) < 3:
-                self._path_pool.append(paths)
+                self._path_pool.append([paths, lease])
         lens = np.zeros(n, np.uint32)
         rc = self._L.mnav_plan_dijkstra_batch(self._h, n, _p(seeds), _p(targets), float(goal_dist_offset),
                                               float(cost_limit), _p(codes), _p(dist), _p(pred), _p(paths), cap, _p(lens))
         if rc == INTERNAL_ERROR:
             raise RuntimeError(f"mnav_plan_dijkstra_batch internal error: {self._err()}")
-        return dict(rc=rc, codes=codes, dist=dist, pred=pred, paths=_PathRows(paths, lens, cap), path_len=lens,
+        rows = _PathRows(paths, lens, cap)
+        lease.append(weakref.ref(rows))
+        return dict(rc=rc, codes=codes, dist=dist, pred=pred, paths=rows, path_len=lens,
                     stats=self.stats() if want_stats else self.timing())
 
     def plan_cvp_batch(self, seed_pos, seed_faces, target_faces, goal_dist_offset: float = 0.3, cost_limit: float = 1.0,

@@ -1990,6 +1990,7 @@ __global__ __launch_bounds__(64) void k_backtrack(WalkMesh M, WalkInflation L, c
   __shared__ uint32_t list[kWalkScratchWords];
   const uint32_t j = blockIdx.x;
   const WalkJob J = jobs[j];
+  if (!J.vecmap) { if (threadIdx.x == 0) { ctl[2 * j] = 0; ctl[2 * j + 1] = 0; } return; }   // no plan behind this row
   WalkField Fd;
   Fd.vecmap = J.vecmap;
   for (int k = 0; k < 3; ++k) Fd.seed_vs[k] = M.faces[3 * (size_t)J.seed_face + k];
@@ -2031,6 +2032,7 @@ struct mnav_ctx {
   std::vector<float> h_xyz, h_cost;
   std::vector<uint32_t> h_row_ptr, h_nbr_u;   // gather CSR (host copy): the tile-batch engine builds its streams from it on first use
   TbState tb; tb::Args tb_args{};             // tile-batch SSSP engine (mnav_tb.h); arguments of the last batch
+  bool tb_args_valid = false;                 // ... which still describe live device memory (last tile-batch call succeeded, nothing freed since)
   bool want_vec = false;               // the running call asked for vector maps (lazy 12 B/vertex/plan)
   bool resident_vecmap = false;        // mnav_set_resident_outputs: always compute the vector map, leave it on the device
   std::vector<uint32_t> caller_slot;   // plan index of the caller's batch -> device slot of the last call (kNone: never ran)
@@ -3483,8 +3485,8 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   const uint32_t m = (uint32_t)in.size();
-  ctx->tb.count_pending = false;
-  ctx->last_planner = kPlannerDijkstra; ctx->last_n = m;
+  ctx->tb.count_pending = false; ctx->tb_args_valid = false;
+  ctx->last_planner = kPlannerDijkstra; ctx->last_n = 0;            // outputs of the previous call are gone; this call's count once its engine succeeded
   ctx->last_target.resize(m); for (uint32_t k = 0; k < m; ++k) ctx->last_target[k] = in[k].target[0];
   ctx->last_offset = offset;
   if (m) {
@@ -3494,10 +3496,11 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
                  : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
                  : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
                                  : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
-    ctx->last_engine = engine;
     MTRACE("engine returned");
+    if (rc != 0) (void)hipStreamSynchronize(ctx->stream);             // nothing of a failed / cancelled call stays in flight
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { for (uint32_t i = 0; i < n; ++i) if (codes_out) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // :350-354
+    ctx->last_engine = engine; ctx->last_n = m;                       // only a call whose engine succeeded leaves outputs behind
     if (engine == 1) ctx->lazy_paths = false;                         // the band steps keep their predecessors as they go
     const PathRows rows1{ ctx->d_paths, ctx->path_stride, nullptr, nullptr };
     PathRows rows2{ nullptr, 0u, nullptr, nullptr };
@@ -3682,7 +3685,8 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
   ctx->caller_slot.assign(n, kNone);
   for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
-  ctx->last_planner = kPlannerCvp; ctx->last_n = m;
+  ctx->tb.count_pending = false; ctx->tb_args_valid = false;         // (a lazy settled-vertex count of an earlier Dijkstra batch is void now)
+  ctx->last_planner = kPlannerCvp; ctx->last_n = 0; ctx->last_engine = 1;
   uint32_t worst = MNAV_SUCCESS;
   if (m) {
     if (materialize(ctx, true, cost_limit)) return MNAV_INTERNAL_ERROR;
@@ -3694,8 +3698,10 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
     if (hipMemcpyAsync(ctx->d_seed_pos, sp.data(), 12 * (size_t)m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
       { ctx->err = "seed upload failed"; return MNAV_INTERNAL_ERROR; }
     const int rc = run_plans<kPlannerCvp>(ctx, m, in, goal_dist_offset, false);
+    if (rc != 0) (void)hipStreamSynchronize(ctx->stream);
     if (rc < 0) return MNAV_INTERNAL_ERROR;
     if (rc == 1) { if (codes_out) for (uint32_t i = 0; i < n; ++i) codes_out[i] = MNAV_CANCELED; return MNAV_CANCELED; }   // cvp :888-892
+    ctx->last_n = m;
     hipLaunchKernelGGL(k_finish<kPlannerCvp>, dim3(m), dim3(64), 0, ctx->stream, ctx->d_plans, ctx->d_res, PathRows{ nullptr, 0u, nullptr, nullptr });
     const uint32_t gc = (V + kBlock * 4 - 1) / (kBlock * 4);
     hipLaunchKernelGGL(k_count, dim3(gc ? gc : 1, m), dim3(kBlock), 0, ctx->stream, ctx->d_plans, ctx->d_res);
@@ -3841,6 +3847,8 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   ctx->cancel.store(0);
   if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   ctx->want_vec = false;
+  ctx->tb.count_pending = false; ctx->tb_args_valid = false;         // slot 0 and d_res are taken over by the sharded plan
+  ctx->last_planner = kPlannerDijkstra; ctx->last_engine = 0; ctx->last_n = 0; ctx->caller_slot.clear();
   if (materialize(ctx, false, cost_limit)) return -1;
   if (ensure_slots(ctx, 1, false, false, false)) return -1;
   if (ensure_paths(ctx, 1)) return -1;
@@ -4013,6 +4021,8 @@ static void settle_stats(mnav_ctx* ctx)
 {
   if (!ctx->tb.count_pending) return;
   ctx->tb.count_pending = false;
+  // only the arguments of a tile-batch call that succeeded and whose buffers are still allocated may be dereferenced
+  if (!ctx->tb_args_valid || ctx->last_planner != kPlannerDijkstra || ctx->last_engine != 5 || !ctx->tb.built) return;
   const uint32_t m = ctx->last_n;
   if (!m || hipSetDevice(ctx->device) != hipSuccess) return;
   hipLaunchKernelGGL(k_tb_count, dim3(ctx->tb.ntiles ? ctx->tb.ntiles : 1, 16), dim3(kBlock), 0, ctx->stream, ctx->tb_args, ctx->tb.T, ctx->d_res);
@@ -4054,8 +4064,9 @@ int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
 {
   if (!ctx) return nullptr;
-  if (slot < ctx->caller_slot.size()) slot = ctx->caller_slot[slot];      // caller's plan index -> device slot (kNone: never ran / overwritten)
-  if (slot >= ctx->slots.size()) return nullptr;
+  if (slot >= ctx->caller_slot.size()) return nullptr;                    // not a plan of the last call (a stale slot of an earlier, larger batch is never handed out)
+  slot = ctx->caller_slot[slot];                                          // caller's plan index -> device slot (kNone: never reached the device)
+  if (slot >= ctx->last_n || slot >= ctx->slots.size()) return nullptr;   // last_n == 0: the last call failed or was cancelled
   const Slot& s = ctx->slots[slot];
   // a paths-only Dijkstra call finalized nothing: values beyond goal_dist are engine-tentative, predecessors were derived
   // along the path only (mnav_download_output what = 5 returns the popped potential of such a call)
@@ -4088,6 +4099,7 @@ int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out)
     float* tmp = nullptr;
     HIPCHK(hipMalloc((void**)&tmp, 4 * (size_t)(ctx->V ? ctx->V : 1)));
     const uint32_t g = std::min<uint32_t>((ctx->V + kBlock - 1) / kBlock + 1, 4096);
+    if (ctx->last_engine == 5 && ctx->lazy_paths && !ctx->tb_args_valid) { (void)hipFree(tmp); ctx->err = "output not resident"; return -1; }
     if (ctx->last_engine == 5 && ctx->lazy_paths) hipLaunchKernelGGL(k_tb_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->tb_args, slot, ctx->V, tmp);
     else hipLaunchKernelGGL(k_popped, dim3(g), dim3(kBlock), 0, ctx->stream, ctx->slots[slot].dist, ctx->last_target[slot], ctx->last_offset, ctx->V, tmp);
     const hipError_t e1 = hipMemcpyAsync(host_out, tmp, 4 * (size_t)ctx->V, hipMemcpyDeviceToHost, ctx->stream);
@@ -4148,9 +4160,12 @@ int mnav_backtrack_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
   if (!(step_width > 0.0)) { ctx->err = "step_width must be positive"; return -1; }   // a zero step never leaves the start
   if (ctx->last_planner != kPlannerCvp) { ctx->err = "back-tracking: the last call was not a CVP plan"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  if (n != ctx->caller_slot.size()) { ctx->err = "back-tracking: n differs from the last mnav_plan_cvp(_batch) call"; return -1; }
   std::vector<WalkJob> jobs(n);
   for (uint32_t i = 0; i < n; ++i) {
     const float* vm = static_cast<const float*>(mnav_device_output(ctx, i, 4));
+    jobs[i].vecmap = nullptr;
+    if (ctx->caller_slot[i] == kNone) continue;                       // a plan rejected before it reached the device (INVALID_START / _GOAL): status 0, no entries
     if (!vm) { ctx->err = "vector map not resident (mnav_set_resident_outputs, or pass vecmap_out to the plan call)"; return -1; }
     if (seed_faces[i] >= ctx->F || target_faces[i] >= ctx->F) { ctx->err = "face id out of range"; return -1; }
     jobs[i].vecmap = vm; jobs[i].seed_face = seed_faces[i]; jobs[i].target_face = target_faces[i];

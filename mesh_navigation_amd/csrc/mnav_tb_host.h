@@ -15,6 +15,7 @@ void tb_free_batch(mnav_ctx* ctx)
   S.D = nullptr; S.pend = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
   S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
   S.cap_np = 0;
+  S.count_pending = false; ctx->tb_args_valid = false;               // the last batch's arguments point into freed memory now
 }
 
 void tb_free(mnav_ctx* ctx)
@@ -25,6 +26,7 @@ void tb_free(mnav_ctx* ctx)
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
   S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr; S.d_verts = nullptr;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
+  S.count_pending = false; ctx->tb_args_valid = false;
 }
 
 // mesh-dependent streams: built on the first batch that takes this engine (a few seconds of host work at 1M vertices)
@@ -279,7 +281,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
   S.last = *S.h_ctl;
   ctx->stats.launches = 1;                                           // one engine run per batch (iterations: stats.steps)
-  ctx->tb_args = A;
+  ctx->tb_args = A; ctx->tb_args_valid = (rc == 0);
   if (getenv("MNAV_TRACE"))
     fprintf(stderr, "[mnav] tile-batch: %u iterations, %llu activations (%.1f per item), %llu items, %.2f sweeps per item, %llu wakes\n", S.h_ctl->iters,
             S.h_ctl->acts, S.h_ctl->items ? (double)S.h_ctl->acts / S.h_ctl->items : 0.0, S.h_ctl->items,

@@ -75,6 +75,8 @@ def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, go
         device_loop = hasattr(engine, "apply_async")
 
     def failed(st: int) -> ShardedResult:
+        if hasattr(engine, "drain"):
+            engine.drain()                                            # kernels / collectives queued behind the failure finish before the next plan starts
         return ShardedResult(CANCELED if st == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
 
     while True:
@@ -112,7 +114,7 @@ def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, go
     ctl[2] = -float(getattr(engine, "status", 0))
     allreduce_min(ctl)
     if agreed_status():
-        return ShardedResult(CANCELED if agreed_status() == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
+        return failed(agreed_status())
     if not gather:
         return ShardedResult(SUCCESS, None, None, np.zeros(0, np.uint32), exchanges, rounds)
     allreduce_min(dist_buf)                                           # every vertex has exactly one owner
@@ -160,7 +162,14 @@ class GpuShardEngine:
 
     def apply(self, buf):
         self.torch.cuda.synchronize()
-        return self.ctx.shard_apply(buf.data_ptr())
+        try:
+            return self.ctx.shard_apply(buf.data_ptr())
+        except RuntimeError:                                           # rank-local failure: reported through the status word, the
+            self.status = 2                                            # other ranks must not be left waiting in the next all-reduce
+            return float("inf"), float("inf")
+
+    def drain(self):
+        self.torch.cuda.synchronize()
 
     # -- the device-resident loop: kernels linked to torch's current stream by events, no host synchronisation
     def _stream(self) -> int:
