@@ -226,6 +226,20 @@ int mnav_layer_stats(const mnav_ctx* ctx, uint32_t* steps, uint32_t* bands, uint
  * fixed point matters.  Returns 0, <0 on error, 1 if cancelled. */
 int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world);
 int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_t* ntiles, uint32_t* n_exchange);
+/* The same loop on a mesh whose DATA is partitioned (north_star: "the mesh is range-partitioned across the 8 GPUs ...
+ * allreduce of halo-vertex distances only"): the mesh uploaded to this context is ONE PART -- the vertices this process
+ * owns plus their 1-ring halo (the neighbours owned elsewhere), renumbered in ascending global id, with every edge that has
+ * an owned endpoint.  `exchange_vertex[i]` (i < n_exchange, the same global list of interface vertices on every process:
+ * the vertices that have a neighbour owned by another process) is the LOCAL id of interface vertex i, or 0xFFFFFFFF when
+ * this process does not hold it; `owned[v]` (one byte per local vertex) is 1 for owned vertices, 0 for halo copies.
+ * The exchange buffer has n_exchange + 1 floats (last: the robot vertex, passed to mnav_shard_begin as a local id).  All
+ * local tiles run; every held copy of an interface vertex is packed (a value reached along real edges is an upper bound of
+ * the true distance) and takes the reduced minimum; mnav_shard_finalize returns dist / pred of the LOCAL vertices (the
+ * owned ones are final, predecessors are local ids), sized by the part, not by the mesh.  Returns n_exchange + 1. */
+int mnav_shard_setup_partition(mnav_ctx* ctx, uint32_t n_exchange, const uint32_t* exchange_vertex, const uint8_t* owned);
+/* Device memory this context holds for mesh tables and per-plan state, in bytes (the partitioned plan's footprint test). */
+uint64_t mnav_device_bytes(const mnav_ctx* ctx);
+
 int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit);
 int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev);
 int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out);

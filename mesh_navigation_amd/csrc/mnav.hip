@@ -532,6 +532,8 @@ struct TilePlan {
   uint32_t max_nv, max_nh, max_ne;
   const uint32_t* cancel;  // device word set by mnav_cancel (polled by the persistent kernels), may be null
   uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
+  const uint8_t* owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
+                           // neighbourhood is incomplete here (its value arrives through the exchange); null: every vertex is owned
 };
 
 constexpr int kTileBlock = 256;
@@ -1075,6 +1077,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_weights(uint32_t n, const uint3
 // ---------------------------------------------------------------------------------------------
 struct ShardDev {
   uint32_t n_iface, rank, target;
+  uint32_t partition;            // 1: partitioned mesh -- iface_vert holds LOCAL ids (kNone: vertex not held here), every held copy is
+                                 // packed (a valid upper bound) and every held copy takes a smaller reduced value
   const uint32_t* iface_vert;    // n_iface vertex ids, the same list on every process
   const uint8_t* iface_owner;    // n_iface owning process
   const uint32_t* wake_ptr;      // n_iface+1 -> wake_tile: local tiles that hold the vertex in their halo
@@ -1085,7 +1089,10 @@ struct ShardDev {
 __global__ __launch_bounds__(kBlock) void k_shard_pack(ShardDev S, const float* __restrict__ dist, float* __restrict__ buf)
 {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < S.n_iface) buf[i] = (S.iface_owner[i] == S.rank) ? dist[S.iface_vert[i]] : inf_f();
+  if (i < S.n_iface) {
+    const uint32_t v = S.iface_vert[i];
+    buf[i] = (v != kNone && (S.partition || S.iface_owner[i] == S.rank)) ? dist[v] : inf_f();
+  }
   if (i == S.n_iface) buf[i] = dist[S.target];      // last slot: the robot vertex (bound / goal_dist need it everywhere); stale copies are larger
 }
 
@@ -1102,8 +1109,9 @@ __global__ __launch_bounds__(kBlock) void k_shard_apply(ShardDev S, const TilePl
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i == 0) { P.ctl[0].done = 0; P.ctl[1].done = 0; }
   if (i == S.n_iface) { if (buf[i] < P.dist[S.target]) P.dist[S.target] = buf[i]; return; }
-  if (i >= S.n_iface || S.iface_owner[i] == S.rank) return;
+  if (i >= S.n_iface) return;
   const uint32_t v = S.iface_vert[i];
+  if (v == kNone || (!S.partition && S.iface_owner[i] == S.rank)) return;
   const float nv = buf[i];
   if (!(nv < P.dist[v])) return;
   P.dist[v] = nv;
@@ -1363,7 +1371,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
         }
         const uint32_t sb = lsum[i], ob = L.ldu[i];
         const unsigned long long key = lkey[i];
-        if (sb != kInfBits && key == ~0ull) ++bad;                    // a finite value no expanded neighbour supports
+        if (sb != kInfBits && key == ~0ull && (!T.owned || T.owned[gg])) ++bad;   // a finite value no expanded neighbour supports (a halo copy's support may live on another process)
         const uint32_t pv = (sb != kInfBits) ? (uint32_t)key : gg;
         g_pred[gg] = pv;
         if (BLOCKED || sb != ob) g_dist[gg] = u2f(sb);                // (else only above goal_dist: tentative value, dijkstra :337-343)
@@ -2094,6 +2102,7 @@ struct mnav_ctx {
     uint32_t *d_iface_vert = nullptr, *d_wake_ptr = nullptr, *d_wake_tile = nullptr, *d_changed = nullptr, *d_minpend = nullptr;
     uint8_t* d_iface_owner = nullptr;
     std::vector<uint32_t> iface_vert;
+    bool partition = false; uint8_t* d_owned = nullptr;              // mnav_shard_setup_partition
   } shard;
   double edge_cost_factor = 0.0;                                   // factor of the resident edge weights (mnav_update_costs)
   // layers computed / kept on the device (mnav_layer_*)
@@ -2806,6 +2815,8 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_t_halo_tile); (void)hipFree(ctx->d_t_eptr); (void)hipFree(ctx->d_t_src); (void)hipFree(ctx->d_vert_tile);
   (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
   (void)hipFree(ctx->d_tplans);
+  (void)hipFree(ctx->shard.d_iface_vert); (void)hipFree(ctx->shard.d_iface_owner); (void)hipFree(ctx->shard.d_wake_ptr); (void)hipFree(ctx->shard.d_wake_tile);
+  (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
   (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
@@ -3773,7 +3784,7 @@ int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world)
   if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
   if (M.ntiles < world) { ctx->err = "fewer tiles than processes"; return -1; }
   auto& S = ctx->shard;
-  S.rank = rank; S.world = world;
+  S.rank = rank; S.world = world; S.partition = false;
   auto lo = [&](uint32_t r) { return (uint32_t)(((uint64_t)M.ntiles * r) / world); };
   S.t_lo = lo(rank); S.t_hi = lo(rank + 1);
   std::vector<uint32_t> bound(world + 1);
@@ -3818,6 +3829,77 @@ int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world)
   return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
 }
 
+// The mesh of this context is ONE PART of a partitioned mesh (owned vertices + their 1-ring halo, local ids in ascending
+// global id so that every (value, id) tie breaks as on the whole mesh): all local tiles run, every held copy of an
+// interface vertex is packed (any value reached along real edges is an upper bound of the true distance) and takes the
+// reduced minimum, and the finalize pass does not ask a halo copy for a local predecessor.
+int mnav_shard_setup_partition(mnav_ctx* ctx, uint32_t n_exchange, const uint32_t* exchange_vertex, const uint8_t* owned)
+{
+  if (!ctx || !ctx->have_mesh || (n_exchange && !exchange_vertex) || !owned) { if (ctx) ctx->err = "mnav_shard_setup_partition: bad arguments or no mesh"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  const HostTiles& M = ctx->tiles_meta;
+  if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
+  auto& S = ctx->shard;
+  S.rank = 0; S.world = 1; S.partition = true; S.t_lo = 0; S.t_hi = M.ntiles;
+  S.iface_vert.assign(exchange_vertex, exchange_vertex + n_exchange);
+  S.n_iface = n_exchange;
+  std::vector<uint32_t> idx_of(ctx->V, kNone);
+  for (uint32_t i = 0; i < n_exchange; ++i) {
+    const uint32_t v = exchange_vertex[i];
+    if (v == kNone) continue;
+    if (v >= ctx->V || idx_of[v] != kNone) { ctx->err = "mnav_shard_setup_partition: exchange vertex out of range or listed twice"; return -1; }
+    idx_of[v] = i;
+  }
+  // tiles to wake when an exchanged value drops: the vertex's own tile and the tiles that hold it in their halo
+  std::vector<uint32_t> wptr((size_t)n_exchange + 1, 0), wtile;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<uint32_t> fill((size_t)n_exchange + 1, 0);
+    for (uint32_t i = 0; i < n_exchange; ++i) {
+      const uint32_t v = exchange_vertex[i];
+      if (v == kNone) continue;
+      if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = M.vert_tile[v];
+    }
+    for (uint32_t t = 0; t < M.ntiles; ++t)
+      for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
+        const uint32_t i = idx_of[M.halo_verts[k]];
+        if (i == kNone) continue;
+        if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = t;
+      }
+    if (pass == 0) { for (uint32_t i = 0; i < n_exchange; ++i) wptr[i + 1] += wptr[i]; wtile.assign(wptr[n_exchange] ? wptr[n_exchange] : 1, 0); }
+  }
+  std::vector<uint8_t> zero(n_exchange ? n_exchange : 1, 0);
+  if (dev_upload(ctx, &S.d_iface_vert, S.iface_vert.data(), S.iface_vert.size())) return -1;
+  if (dev_upload(ctx, &S.d_iface_owner, zero.data(), n_exchange)) return -1;
+  if (dev_upload(ctx, &S.d_wake_ptr, wptr.data(), wptr.size())) return -1;
+  if (dev_upload(ctx, &S.d_wake_tile, wtile.data(), wtile.size())) return -1;
+  if (dev_upload(ctx, &S.d_owned, owned, (size_t)ctx->V)) return -1;
+  if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
+  if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.ready = true; S.active = false;
+  return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
+}
+
+uint64_t mnav_device_bytes(const mnav_ctx* ctx)
+{
+  if (!ctx) return 0;
+  uint64_t n = 0;
+  for (const auto& kv : ctx->alloc_bytes) n += kv.second;             // mesh tables, tiles, costs, shard lists (dev_upload)
+  const uint64_t V = ctx->V ? ctx->V : 1;
+  for (const Slot& s : ctx->slots) {                                  // per-plan state (ensure_slots, ensure_tile_state)
+    n += 8 * V;
+    if (s.band_ready) n += 28 * V;
+    if (s.vecmap) n += 12 * V;
+    if (s.cvp_ready) n += (sizeof(PopKey) + 8) * V;
+    if (s.tpend0) n += 12ull * (ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1);
+  }
+  if (ctx->d_nbr) n += 8ull * 2 * ctx->E;
+  if (ctx->d_crn) n += 24ull * 3 * ctx->F;
+  if (ctx->d_blocked) n += V;
+  n += 4ull * ctx->paths_words;
+  return n;
+}
+
 int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_t* ntiles, uint32_t* n_iface)
 {
   if (!ctx || !ctx->shard.ready) return -1;
@@ -3831,7 +3913,7 @@ int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_
 static ShardDev shard_dev(const mnav_ctx* ctx)
 {
   ShardDev D;
-  D.n_iface = ctx->shard.n_iface; D.rank = ctx->shard.rank; D.target = ctx->shard.target; D.iface_vert = ctx->shard.d_iface_vert; D.iface_owner = ctx->shard.d_iface_owner;
+  D.n_iface = ctx->shard.n_iface; D.rank = ctx->shard.rank; D.target = ctx->shard.target; D.partition = ctx->shard.partition ? 1u : 0u; D.iface_vert = ctx->shard.d_iface_vert; D.iface_owner = ctx->shard.d_iface_owner;
   D.wake_ptr = ctx->shard.d_wake_ptr; D.wake_tile = ctx->shard.d_wake_tile;
   return D;
 }
@@ -3874,6 +3956,7 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
   T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   T.t_lo = S.t_lo; T.t_hi = S.t_hi;
+  T.owned = S.partition ? S.d_owned : nullptr;
   HIPCHK(hipMemcpyAsync(ctx->d_plans, &P, sizeof(Plan), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_tplans, &T, sizeof(TilePlan), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult), ctx->stream));

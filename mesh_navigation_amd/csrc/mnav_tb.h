@@ -59,6 +59,7 @@ struct Args {
   const uint32_t* seed; const uint32_t* target;                        // per plan: wave source / robot vertex
   const uint2* vaddr; const uint32_t* vert_tile;                      // per vertex: {soff, sl << 8 | local}, tile
   double offset; float band;
+  uint32_t gran;                                                     // plans per work item: 16 (quarter-wave solve) or 64 (one tile per wave)
 };
 
 __device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_t p)
@@ -203,19 +204,20 @@ __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
   if (lane == 0 && carried) atomicAdd(&A.ctl->n_cand[par ^ 1], carried);
 }
 
-// per tile: cut the bucket into items of <= 64 plans (one workgroup, a few dozen tiles per thread)
+// per tile: cut the bucket into items of <= `gran` plans (one workgroup, a few dozen tiles per thread)
 __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
 {
   __shared__ uint32_t s_base;
   __shared__ uint32_t s_wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t gran = A.gran;
   if (tid == 0) s_base = 0u;
   __syncthreads();
   for (uint32_t t0 = 0; t0 < A.ntiles; t0 += 1024) {
     const uint32_t t = t0 + tid;
     uint32_t c = 0;
     if (t < A.ntiles) { c = A.bcnt[t]; if (c) A.bcnt[t] = 0u; }
-    const uint32_t k = (c + 63u) >> 6;
+    const uint32_t k = (c + gran - 1u) / gran;
     uint32_t incl = k;                                               // inclusive scan over the wave, then over the 16 waves
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
     uint32_t tot = 0;
     for (int w = 0; w < 16; ++w) tot += s_wsum[w];
     const uint32_t base = s_base + woff + incl - k;
-    for (uint32_t q = 0; q < k; ++q) A.items[base + q] = make_uint2(t, (q * 64u) | (min(64u, c - q * 64u) << 16));
+    for (uint32_t q = 0; q < k; ++q) A.items[base + q] = make_uint2(t, (q * gran) | (min(gran, c - q * gran) << 16));
     __syncthreads();
     if (tid == 0) s_base += tot;
     __syncthreads();
@@ -538,6 +540,317 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The quarter-wave solve: one wave per FOUR work items of <= 16 plans, one item per 16-lane quarter.
+// ---------------------------------------------------------------------------------------------
+// k_tb_solve above fills a wave with the plans that have work on ONE tile in one iteration: 42-50 of 64 lanes on the 1M
+// mesh, 15 of 64 on the 10M mesh, where the batch cannot grow any further (the blocked distances fill the HBM).  Here the
+// buckets are cut into items of <= 16 plans and a wave takes four of them -- of the same tile or of four different
+// ones.  Everything that was wave-uniform becomes uniform per QUARTER: the tile header sits in VGPRs, each quarter
+// parks its own tile's stream chunk in its own 256-byte staging area (lane l loads the 16 bytes (l & 15) of its
+// quarter's chunk: still one vector load per lane and chunk) and reads the descriptors back with ds_read_b128 at a
+// per-quarter address (the 16 lanes of a quarter read one address: a broadcast per 8-lane pass, like the uniform read).
+// Streams of different length run to the longest one: a quarter past the end of its sweep stream re-runs its last
+// chunk (a relaxation applied twice changes nothing), past the end of a ghost stream it idles.  The staging is
+// single-buffered: all descriptor reads of a chunk are issued before the next chunk is written over it (the LDS
+// executes in order), which keeps a wave at 31.8 KB of LDS -- five waves per CU as before.
+constexpr uint32_t kTbQStride = 272;      // bytes between the quarters' staging areas: 256 + 16, so that they start in different banks
+
+namespace tb {
+__device__ __forceinline__ void ldsw4(uint32_t off, u32x4 v) { *(lds_u32x4_t)(uintptr_t)off = v; }
+__device__ __forceinline__ uint32_t wmax4(uint32_t x)                // max over the four quarters (x uniform per quarter), wave-uniform
+{
+  x = max(x, (uint32_t)__shfl_xor((int)x, 16));
+  x = max(x, (uint32_t)__shfl_xor((int)x, 32));
+  return rfl(x);
+}
+// Per-quarter stream reader.  The staging area holds chunk c; chunk c + 1 waits in a register, chunk c + 2 is in flight.
+struct QStream {
+  MNAV_GLOBAL const u32x4* st;   // this lane's 16 bytes of chunk 0
+  uint32_t last, wr, c; u32x4 c1;
+  // `first`: the 16-byte unit 0 of chunk 0
+  __device__ __forceinline__ void begin_at(MNAV_GLOBAL const u32x4* first, uint32_t nch, uint32_t stage_q, uint32_t l16)
+  {
+    st = first + l16;
+    last = nch ? nch - 1u : 0u; wr = stage_q + 16u * l16; c = 0;
+    ldsw4(wr, st[0]);
+    c1 = st[(size_t)min(1u, last) * 16u];
+  }
+  __device__ __forceinline__ void begin(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t stage_q, uint32_t l16)
+  {
+    begin_at((MNAV_GLOBAL const u32x4*)(stream + (size_t)chunk_off * kTbChunk), nch, stage_q, l16);
+  }
+  // call when every LDS read of chunk c has been issued
+  __device__ __forceinline__ void advance()
+  {
+    ldsw4(wr, c1);
+    c1 = st[(size_t)min(c + 2u, last) * 16u];
+    ++c;
+  }
+};
+}  // namespace tb
+
+template <int T>
+__device__ __forceinline__ unsigned long long tbq_sweep(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t max_nch,
+                                                        uint32_t stage_q, uint32_t l16, uint32_t lane4)
+{
+  unsigned long long any = 0ull;
+  tb::QStream S; S.begin(stream, chunk_off, nch, stage_q, l16);
+  for (uint32_t c = 0; c < max_nch; ++c) {
+    u32x4 d[kTbBlocksPerChunk][4];
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(stage_q + 64 * j + 16 * q);
+    S.advance();
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+      TbBlk B;
+      B.w0 = d[j][2]; B.w1 = d[j][3];
+      B.ya = d[j][0].x + lane4;
+      B.raw = tb::ldsr(B.ya);
+      B.v[0] = tb::ldsr(d[j][0].y + lane4); B.v[1] = tb::ldsr(d[j][0].z + lane4); B.v[2] = tb::ldsr(d[j][0].w + lane4);
+      B.v[3] = tb::ldsr(d[j][1].x + lane4); B.v[4] = tb::ldsr(d[j][1].y + lane4); B.v[5] = tb::ldsr(d[j][1].z + lane4);
+      B.v[6] = tb::ldsr(d[j][1].w + lane4);
+      any |= __ballot(tb_retire(B));
+    }
+  }
+  return any;
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
+{
+#ifdef MNAV_TB_TIMING
+  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
+#endif
+  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + kTbQStride];   // [row][lane] + four staging areas of 272 bytes
+  const int lane = threadIdx.x;
+  const uint32_t q = (uint32_t)lane >> 4, l16 = (uint32_t)lane & 15u;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds;
+  const uint32_t lane4 = lds0 + 4u * lane;
+  const uint32_t stage_q = lds0 + 4u * (T * 64) + q * kTbQStride;
+  const unsigned long long qmask = 0xFFFFull << (16u * q);
+  const uint32_t NP = A.NP;
+  const uint32_t n_items = A.ctl->n_items;
+  MNAV_GLOBAL const uint32_t* const stream = as_global(A.stream);
+  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0;
+  for (;;) {
+    uint32_t it0 = 0;
+    if (lane == 0) it0 = atomicAdd(&A.ctl->next_item, 4u);
+    it0 = tb::rfl(it0);
+    if (it0 >= n_items) break;
+    // a quarter beyond the last item shadows it and stores nothing
+    const u32x2 item = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[min(it0 + q, n_items - 1u)];
+    const uint32_t t = item.x, start = item.y & 0xFFFFu, count = (it0 + q < n_items) ? (item.y >> 16) : 0u;
+    TbTile W;
+    {
+      MNAV_GLOBAL const u32x4* hp = (MNAV_GLOBAL const u32x4*)as_global(A.tiles) + 4u * (size_t)t;
+      const u32x4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+      W.soff = h0.x; W.sl = h0.y; W.nv = h0.z; W.nh = h0.w;
+      W.sweep_off = h1.x; W.sweep_chunks = h1.y; W.pre_off = h1.z; W.pre_chunks = h1.w;
+      W.post_off = h2.x; W.post_chunks = h2.y; W.exp_off = h2.z; W.exp_n = h2.w;
+    }
+    const uint32_t max_sweep = tb::wmax4(W.sweep_chunks), max_pre = tb::wmax4(W.pre_chunks), max_post = tb::wmax4(W.post_chunks),
+                   max_exp = tb::wmax4(W.exp_n);
+    ++my_items; my_acts += (l16 == 0u) ? count : 0u;
+    TB_STAMP(0);
+    {
+      // Every lane runs the whole item (the stream chunks are loaded 16 bytes per lane).  Lanes beyond `count` shadow the
+      // last plan of their quarter's item and store nothing.
+      const bool active = l16 < count;
+      const uint32_t p = A.bucket[(size_t)t * NP + start + min(l16, max(count, 1u) - 1u)];
+      MNAV_GLOBAL float* sl = as_global(A.D) + ((size_t)W.soff * NP + (size_t)p * W.sl);
+      // ---- load the owned slots: LDS[row][lane]
+      {
+        MNAV_GLOBAL const u32x4* s4 = (MNAV_GLOBAL const u32x4*)sl;
+        u32x4 v[T / 4];
+#pragma unroll
+        for (int c = 0; c < T / 4; ++c) v[c] = s4[c];
+#pragma unroll
+        for (int c = 0; c < T / 4; ++c) {
+          tb::ldsw(lane4 + (4 * c + 0) * 256, v[c].x); tb::ldsw(lane4 + (4 * c + 1) * 256, v[c].y);
+          tb::ldsw(lane4 + (4 * c + 2) * 256, v[c].z); tb::ldsw(lane4 + (4 * c + 3) * 256, v[c].w);
+        }
+      }
+      MNAV_GLOBAL const u32x4* g4p = (MNAV_GLOBAL const u32x4*)(sl + T);
+      uint32_t first_order = 0;                                       // sweep order of the first sweep (uniform per quarter)
+      TB_STAMP(1);
+      // ---- ghosts -> owned (the ghosts are constant during the activation)
+      if (max_pre) {
+        tb::QStream S; S.begin(stream, W.pre_off, W.pre_chunks, stage_q, l16);
+        u32x4 G = { 0u, 0u, 0u, 0u };
+        float gmin = inf_f();                                         // smallest ghost value that lowered one of this lane's vertices ...
+        uint32_t gord = 0;                                            // ... and the sweep order that runs with a wave entering there
+        for (uint32_t c = 0; c < max_pre; ++c) {
+          const bool live = c < W.pre_chunks;
+          u32x4 h[kTbBlocksPerChunk], o1[kTbBlocksPerChunk], w2[kTbBlocksPerChunk];
+#pragma unroll
+          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+            h[j] = tb::ldsr4(stage_q + 64 * j); o1[j] = tb::ldsr4(stage_q + 64 * j + 16); w2[j] = tb::ldsr4(stage_q + 64 * j + 32);
+          }
+          const u32x4 q3 = tb::ldsr4(stage_q + 48);                   // block 0: d12 = the chunk's ghost group, d13 = the next chunk's
+          S.advance();
+          if (c == 0) G = g4p[live ? q3.x : 0u];
+          const u32x4 Gn = g4p[(c + 1u < W.pre_chunks) ? q3.y : 0u];  // the next chunk's ghost values
+#pragma unroll
+          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+            const uint32_t n = live ? ((h[j].x >> 8) & 7u) : 0u;
+            if (n) {
+              const uint32_t jj = h[j].x & 3u;
+              const float g = u2f(jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w);
+              const uint32_t offs[5] = { h[j].y, h[j].z, h[j].w, o1[j].x, o1[j].y };
+              const uint32_t ws[5] = { o1[j].z, o1[j].w, w2[j].x, w2[j].y, w2[j].z };
+              bool lowered = false;
+#pragma unroll
+              for (int k = 0; k < (int)kTbGhostEdges; ++k) {
+                if ((uint32_t)k < n) {
+                  const uint32_t a = offs[k] + lane4;
+                  const uint32_t nd = f2u(g + u2f(ws[k]));
+                  const uint32_t raw = tb::ldsr(a);
+                  const bool low = nd < (raw & 0x7fffffffu);
+                  lowered |= low;
+                  tb::ldsw(a, low ? (nd | kTbDirty) : raw);
+                }
+              }
+              if (lowered && g < gmin) { gmin = g; gord = (h[j].x >> kTbOrderShift) & 3u; }
+            }
+          }
+          G = Gn;
+        }
+        // the order most lanes of the quarter ask for (lanes whose ghosts lowered nothing do not vote; no votes: order 0)
+        const bool votes = active && gmin < inf_f();
+        uint32_t bestc = 0;
+#pragma unroll
+        for (uint32_t o = 0; o < 4; ++o) {
+          const uint32_t cn = (uint32_t)__popcll(__ballot(votes && gord == o) & qmask);
+          if (cn > bestc) { bestc = cn; first_order = o; }
+        }
+      }
+      TB_STAMP(2);
+      // ---- Gauss-Seidel sweeps to the tile-local fixed point of every quarter (a converged quarter changes nothing any more)
+      uint32_t sweep = 0;
+      for (;;) {
+        const uint32_t off = W.sweep_off + ((sweep + first_order) & 3u) * W.sweep_chunks;
+        const unsigned long long any = tbq_sweep<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4);
+        ++sweep;
+        if (any == 0ull) break;
+        if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
+      }
+      my_sweeps += sweep;
+      TB_STAMP(3);
+      // ---- write back the 16-byte chunks that hold a lowered value
+      {
+        MNAV_GLOBAL u32x4* s4 = (MNAV_GLOBAL u32x4*)sl;
+#pragma unroll
+        for (int c = 0; c < T / 4; ++c) {
+          u32x4 x;
+          x.x = tb::ldsr(lane4 + (4 * c + 0) * 256); x.y = tb::ldsr(lane4 + (4 * c + 1) * 256);
+          x.z = tb::ldsr(lane4 + (4 * c + 2) * 256); x.w = tb::ldsr(lane4 + (4 * c + 3) * 256);
+          if (active && ((x.x | x.y | x.z | x.w) & kTbDirty)) {
+            x.x &= 0x7fffffffu; x.y &= 0x7fffffffu; x.z &= 0x7fffffffu; x.w &= 0x7fffffffu;
+            s4[c] = x;
+          }
+        }
+      }
+      TB_STAMP(4);
+      // ---- owned -> ghosts: wake-ups, pipelined over the neighbour tiles as in k_tb_solve (every stage is per lane here:
+      // the neighbour tile differs between the quarters)
+      if (max_post) {
+        tb::QStream S; S.begin(stream, W.post_off, W.post_chunks, stage_q, l16);
+        u32x4 G = { 0u, 0u, 0u, 0u };
+        uint32_t cand = kTbInfBits, best = kTbInfBits;
+        MNAV_GLOBAL uint32_t* const pend_p = as_global(A.pend) + p;
+        MNAV_GLOBAL uint32_t* const pm = as_global(A.marr[par ^ 1]) + p;
+        uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, best_2 = kTbInfBits, old_2 = 0;
+        bool want_1 = false, did_2 = false;
+        uint32_t n_first = 0;
+        auto advance = [&](uint32_t t2_new, uint32_t best_new, bool want_new) {
+          bool first = false;
+          if (did_2) {
+            first = old_2 == kTbInfBits;
+            if (best_2 < old_2) atomicMin((uint32_t*)pm, best_2);
+            ++my_wakes;
+          }
+          n_first += first ? 1u : 0u;
+          did_2 = want_1 && best_1 < cur_1;
+          best_2 = best_1;
+          if (did_2) old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1);
+          want_1 = want_new; t2_1 = t2_new; best_1 = best_new;
+          if (want_new) cur_1 = pend_p[(size_t)t2_new * NP];
+        };
+        for (uint32_t c = 0; c < max_post; ++c) {
+          const bool live = c < W.post_chunks;
+          u32x4 h[kTbBlocksPerChunk], o1[kTbBlocksPerChunk], w2[kTbBlocksPerChunk];
+#pragma unroll
+          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+            h[j] = tb::ldsr4(stage_q + 64 * j); o1[j] = tb::ldsr4(stage_q + 64 * j + 16); w2[j] = tb::ldsr4(stage_q + 64 * j + 32);
+          }
+          const u32x4 q3 = tb::ldsr4(stage_q + 48);
+          S.advance();
+          if (c == 0) G = g4p[live ? q3.x : 0u];
+          const u32x4 Gn = g4p[(c + 1u < W.post_chunks) ? q3.y : 0u];
+#pragma unroll
+          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+            const uint32_t hd = live ? h[j].x : 0u, n = (hd >> 8) & 7u;
+            if (n) {
+              const uint32_t offs[5] = { h[j].y, h[j].z, h[j].w, o1[j].x, o1[j].y };
+              const uint32_t ws[5] = { o1[j].z, o1[j].w, w2[j].x, w2[j].y, w2[j].z };
+#pragma unroll
+              for (int k = 0; k < (int)kTbGhostEdges; ++k)
+                if ((uint32_t)k < n) cand = min(cand, f2u(fabsf(u2f(tb::ldsr(offs[k] + lane4))) + u2f(ws[k])));
+              if (hd & kTbGhostEnd) {
+                const uint32_t jj = hd & 3u;
+                const uint32_t g = jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w;
+                if (cand < g) best = min(best, cand);
+                cand = kTbInfBits;
+              }
+              if (hd & kTbTileEnd) {
+                advance(w2[j].w, best, active && best != kTbInfBits);   // d11: owner tile of the ghosts just closed
+                best = kTbInfBits;
+              }
+            }
+          }
+          G = Gn;
+        }
+        advance(0u, kTbInfBits, false);                                // drain the two stages in flight
+        advance(0u, kTbInfBits, false);
+        n_first = wave_sum(n_first);
+        if (lane == 0 && n_first) atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
+      }
+      TB_STAMP(5);
+      // ---- export the lowered boundary values to the ghost slots that mirror them.  The records {row, soff, sl, off} are read
+      // like a stream: 16 of them are one 256-byte chunk (a per-lane load of the records one after the other was a chain of
+      // dependent global loads: +70 % on this phase)
+      if (max_exp) {
+        tb::QStream S; S.begin_at((MNAV_GLOBAL const u32x4*)as_global(A.exps) + W.exp_off, (W.exp_n + 15u) >> 4, stage_q, l16);
+        for (uint32_t k0 = 0; k0 < max_exp; k0 += 16u) {
+          u32x4 x[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = tb::ldsr4(stage_q + 16 * r);
+          S.advance();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (k0 + r < W.exp_n) {
+              const uint32_t v = tb::ldsr(x[r].x + lane4);
+              if (active && (v & kTbDirty)) as_global(A.D)[(size_t)x[r].y * NP + ((size_t)p * x[r].z + x[r].w)] = u2f(v & 0x7fffffffu);
+            }
+          }
+        }
+      }
+      TB_STAMP(6);
+    }
+  }
+#ifdef MNAV_TB_TIMING
+  if (lane == 0) for (int k = 0; k < 8; ++k) if (tt[k]) atomicAdd(&g_tb_timing[k], tt[k]);
+#endif
+  my_wakes = wave_sum(my_wakes); my_acts = wave_sum(my_acts);
+  if (lane == 0 && my_items) {
+    atomicAdd(&A.ctl->items, (unsigned long long)my_items); atomicAdd(&A.ctl->acts, (unsigned long long)my_acts);
+    atomicAdd(&A.ctl->sweeps, (unsigned long long)my_sweeps); atomicAdd(&A.ctl->wakes, (unsigned long long)my_wakes);
+  }
+}
+
 // vertex path of a plan from the blocked distances: the walk of k_path_lazy (predecessor = argmin (dist[u] + w, dist[u], u)
 // over the expanded neighbours, the minimum must BE the vertex's distance), dijkstra :358-373
 __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* __restrict__ row_ptr, const Nbr* __restrict__ nbr, uint32_t V,
@@ -649,6 +962,7 @@ struct TbState {
   double min_lanes = 7.0;               // ... that are expected to fill at least this many lanes of a wave (mnav.hip dijkstra_impl)
   float band_mult = 2.0f;               // band = band_mult * mean edge weight * sqrt(T)  (measured on C2: 1 -> 236 ms, 2 -> 218 ms per 5120 plans)
   int iters_per_replay = 16, waves_per_cu = 0;
+  uint32_t gran = 16;                   // plans per work item (tb::Args::gran)
   hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
   // second distance buffer, filled with +inf on its own stream behind the previous call (the fill of 6 B x slots x plans is
   // otherwise 2 % of a batch); only when both fit comfortably

@@ -360,7 +360,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     while (H.exps.size() % 4) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // groups of 4 records = one 64-byte scalar load
   }
   H.stream.resize(H.stream.size() + 4 * kTbChunk, 0u); H.wsrc.resize(H.wsrc.size() + 4 * kTbChunk, kNone);   // tail slack for the chunk prefetch
-  for (int k = 0; k < 4; ++k) H.exps.push_back(TbExp{ 0, 0, 0, 0 });
+  for (int k = 0; k < 48; ++k) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // tail slack: the quarter-wave solve reads the records in chunks of 16, two chunks ahead
   if (H.stream.size() / kTbChunk > 0xFFFFFFF0ull) throw std::invalid_argument("tile-batch engine: stream too large");
   return H;
 }

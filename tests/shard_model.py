@@ -124,3 +124,109 @@ class AsyncModelShardEngine(ModelShardEngine):
 
     def read_control(self, ctl):
         return float(ctl[0]), float(ctl[1]), int(round(-float(ctl[2])))
+
+
+class PartModelEngine:
+    """CPU model of one rank of the PARTITIONED plan (sharded.MeshPart): the engine only sees its part -- owned vertices, their
+    1-ring halo, the edges with an owned endpoint, local ids -- relaxes along every local edge (a halo copy's local value is an
+    upper bound of its true distance), packs every held copy of an interface vertex and lets every held copy take the reduced
+    minimum.  What mnav_shard_setup_partition does on the device."""
+
+    def __init__(self, part, weights_local, costs_local, cost_limit=1.0, invalid_local=None, asynchronous=False):
+        self.part = part
+        self.n = part.n_local
+        e = part.edges.astype(np.int64)
+        self.src = np.concatenate([e[:, 0], e[:, 1]])
+        self.dst = np.concatenate([e[:, 1], e[:, 0]])
+        w = np.concatenate([weights_local, weights_local]).astype(np.float32)
+        inv = np.zeros(self.n, bool) if invalid_local is None else np.asarray(invalid_local, bool)
+        self.w = np.where(inv[self.dst] | (np.asarray(costs_local, np.float64)[self.src] > cost_limit), np.float32(np.inf), w)
+        self.held = part.exchange_vertex != 0xFFFFFFFF
+        self.ex = part.exchange_vertex[self.held].astype(np.int64)
+        self.status = 0
+        if asynchronous:                                               # the device-resident loop's protocol (see AsyncModelShardEngine)
+            self.rounds_async = self.rounds
+            self.apply_async = self._apply_async
+            self.read_control = lambda ctl: (float(ctl[0]), float(ctl[1]), int(round(-float(ctl[2]))))
+
+    def begin(self, seed, target, offset):
+        n0 = self.part.gid.shape[0]
+        ls, lt = self.part.local_of(seed), self.part.local_of(target)
+        self.seed, self.target, self.offset = (ls if ls >= 0 else n0), (lt if lt >= 0 else n0 + 1), offset
+        self.dist = np.full(self.n, np.inf, np.float32)
+        self.dist[self.seed] = 0.0
+        self.ctl = np.zeros(3, np.float32)
+        self.status = 0
+
+    def control_buffer(self):
+        return self.ctl
+
+    def _bound(self):
+        return np.float32(np.float64(self.dist[self.target]) + self.offset)
+
+    def rounds(self, r):
+        d = self.dist
+        self.moved = np.zeros(self.n, bool)
+        for _ in range(r):
+            ok = d[self.src] <= self._bound()
+            cand = (d[self.src] + self.w).astype(np.float32)
+            new = d.copy()
+            np.minimum.at(new, self.dst[ok], cand[ok])
+            ch = new < d
+            if not ch.any():
+                break
+            self.moved |= ch
+            d = new
+        self.dist = d
+        buf = np.full(self.part.exchange_vertex.shape[0] + 1, np.inf, np.float32)
+        buf[:-1][self.held] = d[self.ex]
+        buf[-1] = d[self.target]
+        return buf
+
+    def apply(self, buf):
+        got = buf[:-1][self.held]
+        drop = got < self.dist[self.ex]
+        self.dist[self.ex[drop]] = got[drop]
+        if buf[-1] < self.dist[self.target]:
+            self.dist[self.target] = buf[-1]
+        cand = np.concatenate([self.dist[self.moved], self.dist[self.ex[drop]]])
+        cand = cand[cand <= self._bound()]
+        local_min = np.float32(cand.min()) if cand.size else np.float32(np.inf)
+        return float(local_min), float(self.dist[self.target])
+
+    def _apply_async(self, buf, ctl):
+        lm, td = self.apply(buf)
+        ctl[0], ctl[1], ctl[2] = lm, td, -float(self.status)
+
+    def finalize(self):
+        d = self.dist
+        goal = np.float32(np.float64(d[self.target]) + self.offset) if np.isfinite(d[self.target]) else np.float32(np.inf)
+        expanded = np.isfinite(d) & (d <= goal)
+        ok = expanded[self.src]
+        cand = (d[self.src] + self.w).astype(np.float32)
+        best = np.full(self.n, np.inf, np.float32)
+        np.minimum.at(best, self.dst[ok], cand[ok])
+        out = d.copy()
+        above = ~(d <= goal)
+        out[above] = best[above]
+        out[self.seed] = 0.0
+        pred = np.arange(self.n, dtype=np.int64)
+        att = ok & (cand == out[self.dst]) & np.isfinite(cand)
+        key = np.full(self.n, np.iinfo(np.int64).max, np.int64)
+        k = (d[self.src].view(np.uint32).astype(np.int64) << 32) | self.src      # local ids ascend with the global ids: same ties
+        np.minimum.at(key, self.dst[att], k[att])
+        has = key != np.iinfo(np.int64).max
+        pred[has] = key[has] & 0xFFFFFFFF
+        pred[self.seed] = self.seed
+        self._dist, self._pred = out.astype(np.float32), pred.astype(np.uint32)
+        return self._dist, self._pred
+
+    def local_result(self):
+        return self._dist, self._pred
+
+    @staticmethod
+    def reduce_int64(host, allreduce_min):
+        allreduce_min(host)
+        return host
+
+    reduce_float32 = reduce_int64
