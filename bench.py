@@ -550,9 +550,16 @@ def sharded_c4(args, torch, dist, rank, local_rank, world):
     edge_w = meshgen.edge_lengths(mesh)
     costs = np.zeros(mesh.V, np.float32)
     ctx = capi.MnavContext(local_rank)
-    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
-    ctx.upload_costs(costs, edge_w)
-    eng = sharded.GpuShardEngine(ctx, rank, world)
+    replicated = os.environ.get("MNAV_SHARD_REPLICATED") is not None
+    if replicated:                                                    # every rank holds the whole mesh, ownership of the tiles is partitioned
+        ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
+        ctx.upload_costs(costs, edge_w)
+        eng = sharded.GpuShardEngine(ctx, rank, world)
+    else:                                                             # default: the DATA is partitioned -- a rank uploads its part only
+        owner = sharded.partition_vertices(mesh.xyz, world)
+        part = sharded.extract_part(mesh.xyz, mesh.edges, owner, rank, world)
+        sharded.PartitionedShardEngine.upload_part(ctx, part, costs, edge_w)
+        eng = sharded.PartitionedShardEngine(ctx, part)
     red = sharded.torch_allreduce_min(dist) if dist is not None else (lambda x: None)
     robot = mesh.vertex_at(0.9, 0.9)
     goals = np.random.default_rng(5).choice(mesh.V, size=args.steps + args.warmup, replace=False)
@@ -566,12 +573,12 @@ def sharded_c4(args, torch, dist, rank, local_rank, world):
     dev_loop = os.environ.get("MNAV_SHARD_HOST_LOOP") is None         # default: the exchange loop stays on the device
     res = None
     for k in range(args.warmup):
-        res = sharded.run_sharded_plan(eng, red, int(goals[k]), robot, args.offset, max_exchanges=200000, device_loop=dev_loop)
+        res = sharded.run_sharded_plan(eng, red, int(goals[k]), robot, args.offset, max_exchanges=200000, device_loop=dev_loop, gather=replicated)
     barrier()
     t0 = time.perf_counter()
     exch = 0
     for k in range(args.steps):
-        res = sharded.run_sharded_plan(eng, red, int(goals[args.warmup + k]), robot, args.offset, max_exchanges=200000, device_loop=dev_loop)
+        res = sharded.run_sharded_plan(eng, red, int(goals[args.warmup + k]), robot, args.offset, max_exchanges=200000, device_loop=dev_loop, gather=replicated)
         assert res.code == 0
         exch += res.exchanges
     barrier()
@@ -584,8 +591,10 @@ def sharded_c4(args, torch, dist, rank, local_rank, world):
         out = {"metric": "plans/sec (one Dijkstra plan range-partitioned over the GPUs, 10M-vertex mesh)", "value": args.steps / elapsed,
                "unit": "plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"C4 sharded: {N}x{N} terrain = {mesh.V} vertices, tiles range-partitioned over {world} GPU(s), "
-                                      f"min-allreduce of {eng.n} interface floats per exchange", "exchanges_per_plan": exch / args.steps,
+               "config": {"workload": f"C4 sharded: {N}x{N} terrain = {mesh.V} vertices, "
+                                      + ("mesh replicated, tiles range-partitioned" if replicated else "mesh DATA partitioned (a rank holds its part + 1-ring halo)")
+                                      + f" over {world} GPU(s), min-allreduce of {eng.n} interface floats per exchange", "exchanges_per_plan": exch / args.steps,
+                          "vertices_on_rank0": int(ctx.V), "device_bytes_rank0": int(ctx.device_bytes()),
                           "path_len": int(len(res.path)),
                           "exchange_loop": "device-resident (termination words read every 8 exchanges)" if dev_loop else "host-checked every exchange"},
                "roofline": None, "cpu_baseline": None}

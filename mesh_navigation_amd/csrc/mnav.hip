@@ -1116,6 +1116,10 @@ __global__ __launch_bounds__(kBlock) void k_shard_apply(ShardDev S, const TilePl
   if (!(nv < P.dist[v])) return;
   P.dist[v] = nv;
   const uint32_t bits = f2u(nv);
+  // Partitioned mesh: v sits INSIDE a local tile (first entry of its wake list).  A tile only re-queues its own vertices
+  // from the threshold of its last solve upwards (k_tile_round: sources in [tlast, thr)), so a value that arrives from
+  // outside below that threshold pulls it down.  Signed min on the float bits: the negative marks (-inf: never solved) stay.
+  if (S.partition) atomicMin((int*)&P.tlast[S.wake_tile[S.wake_ptr[i]]], (int)bits);
   for (uint32_t k = S.wake_ptr[i]; k < S.wake_ptr[i + 1]; ++k) atomicMin(&pn[S.wake_tile[k]], bits);
   if (S.wake_ptr[i + 1] > S.wake_ptr[i]) { atomicMin(&cnt->minpend, bits); atomicOr(changed, 1u); }
 }

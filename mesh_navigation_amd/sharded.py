@@ -153,6 +153,7 @@ class GpuShardEngine:
         self.buf = torch.empty(self.n, dtype=torch.float32, device=dev)
         self.ctl = torch.zeros(3, dtype=torch.float32, device=dev)
         self.status = 0                                                # 0 ok, 1 cancelled, 2 error: agreed on by all ranks in run_sharded_plan
+        self.error = ""                                                # the library's message behind status 2
         self.dist = torch.empty(ctx.V, dtype=torch.float32, device=dev)
         # predecessors travel as int32 bit patterns (RCCL has no uint32 MIN in torch): ids < 2^31 keep their order,
         # and the neutral element 0xFFFFFFFF is -1, which MIN would prefer -> flip the sign bit around the collective
@@ -170,16 +171,16 @@ class GpuShardEngine:
         try:
             if self.ctx.shard_rounds(r, self.buf.data_ptr()) == 1:     # mnav_cancel arrived on this rank
                 self.status = max(self.status, 1)
-        except RuntimeError:
-            self.status = 2
+        except RuntimeError as ex:
+            self.status, self.error = 2, str(ex)
         return self.buf
 
     def apply(self, buf):
         self.torch.cuda.synchronize()
         try:
             return self.ctx.shard_apply(buf.data_ptr())
-        except RuntimeError:                                           # rank-local failure: reported through the status word, the
-            self.status = 2                                            # other ranks must not be left waiting in the next all-reduce
+        except RuntimeError as ex:                                     # rank-local failure: reported through the status word, the
+            self.status, self.error = 2, str(ex)                       # other ranks must not be left waiting in the next all-reduce
             return float("inf"), float("inf")
 
     def drain(self):
@@ -192,15 +193,15 @@ class GpuShardEngine:
     def rounds_async(self, r):
         try:
             self.ctx.shard_rounds_async(r, self.buf.data_ptr(), self._stream())
-        except RuntimeError:
-            self.status = 2
+        except RuntimeError as ex:
+            self.status, self.error = 2, str(ex)
         return self.buf
 
     def apply_async(self, buf, ctl):
         try:
             self.ctx.shard_apply_async(buf.data_ptr(), ctl.data_ptr(), self._stream())
-        except RuntimeError:
-            self.status = 2
+        except RuntimeError as ex:
+            self.status, self.error = 2, str(ex)
         if self.status:                                                # a host-side failure of this rank rides on the same reduce
             ctl[2] = -float(self.status)
 
@@ -212,8 +213,8 @@ class GpuShardEngine:
         self.torch.cuda.synchronize()
         try:
             self.ctx.shard_finalize(self.dist.data_ptr(), self.pred.data_ptr())
-        except RuntimeError:                                           # fixed-point check failed on this rank: all ranks stop together
-            self.status = 2
+        except RuntimeError as ex:                                     # fixed-point check failed on this rank: all ranks stop together
+            self.status, self.error = 2, str(ex)
         self.pred ^= -2147483648            # uint32 order -> int32 order (0xFFFFFFFF becomes INT32_MAX: neutral for MIN)
         return self.dist, self.pred
 
@@ -408,6 +409,7 @@ class PartitionedShardEngine(GpuShardEngine):
         self.buf = torch.empty(self.n, dtype=torch.float32, device=dev)
         self.ctl = torch.zeros(3, dtype=torch.float32, device=dev)
         self.status = 0
+        self.error = ""
         self.dist = torch.empty(ctx.V, dtype=torch.float32, device=dev)   # sized by the PART
         self.pred = torch.empty(ctx.V, dtype=torch.int32, device=dev)
 
@@ -426,8 +428,8 @@ class PartitionedShardEngine(GpuShardEngine):
         self.torch.cuda.synchronize()
         try:
             self.ctx.shard_finalize(self.dist.data_ptr(), self.pred.data_ptr())
-        except RuntimeError:
-            self.status = 2
+        except RuntimeError as ex:
+            self.status, self.error = 2, str(ex)
         return self.dist, self.pred
 
     def local_result(self):
