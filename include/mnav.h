@@ -237,6 +237,12 @@ int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_
  * the true distance) and takes the reduced minimum; mnav_shard_finalize returns dist / pred of the LOCAL vertices (the
  * owned ones are final, predecessors are local ids), sized by the part, not by the mesh.  Returns n_exchange + 1. */
 int mnav_shard_setup_partition(mnav_ctx* ctx, uint32_t n_exchange, const uint32_t* exchange_vertex, const uint8_t* owned);
+/* After mnav_shard_finalize: one segment of the vertex path (dijkstra_mesh_planner.cpp:358-373) inside this process's part.
+ * Predecessors are followed from `start_vertex` (local id) while the vertex is owned here, at most `cap` hops:
+ * out_host[0] = hops, out_host[1] = the vertex the walk stopped at (the seed, or a halo copy: its owner continues),
+ * out_host[2] = 1 if a vertex without predecessor was met (the wave never reached it), out_host[3..] = the predecessors
+ * visited (local ids).  `out_host` holds cap + 3 words.  The potential / predecessor arrays never leave the device. */
+int mnav_shard_walk(mnav_ctx* ctx, uint32_t start_vertex, uint32_t seed_vertex, uint32_t cap, uint32_t* out_host);
 /* Device memory this context holds for mesh tables and per-plan state, in bytes (the partitioned plan's footprint test). */
 uint64_t mnav_device_bytes(const mnav_ctx* ctx);
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mnav_create", "mnav_destroy", "mnav_last_error", "mnav_set_face_circulation", "mnav_upload_mesh", "mnav_upload_costs",
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_get_timing", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
-    "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_setup_partition", "mnav_device_bytes", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply", "mnav_shard_rounds_async", "mnav_shard_apply_async",
+    "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_setup_partition", "mnav_shard_walk", "mnav_device_bytes", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply", "mnav_shard_rounds_async", "mnav_shard_apply_async",
     "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
@@ -144,6 +144,8 @@ def load(path: str | None = None):
     L.mnav_shard_setup.argtypes = [vp, u32, u32]
     L.mnav_shard_setup_partition.restype = C.c_int
     L.mnav_shard_setup_partition.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(C.c_uint8)]
+    L.mnav_shard_walk.restype = C.c_int
+    L.mnav_shard_walk.argtypes = [vp, u32, u32, u32, C.POINTER(u32)]
     L.mnav_device_bytes.restype = C.c_uint64
     L.mnav_device_bytes.argtypes = [vp]
     L.mnav_shard_info.restype = C.c_int
@@ -408,6 +410,13 @@ class MnavContext:
         if n < 0:
             raise RuntimeError(f"mnav_shard_setup_partition failed: {self._err()}")
         return n
+
+    def shard_walk(self, start: int, seed: int, cap: int = 4096) -> np.ndarray:
+        """One path segment inside this part (include/mnav.h): [hops, stop vertex, status, local ids...]."""
+        out = np.zeros(cap + 3, np.uint32)
+        if self._L.mnav_shard_walk(self._h, int(start), int(seed), int(cap), out.ctypes.data_as(C.POINTER(C.c_uint32))) != 0:
+            raise RuntimeError(f"mnav_shard_walk failed: {self._err()}")
+        return out
 
     def device_bytes(self) -> int:
         return int(self._L.mnav_device_bytes(self._h))

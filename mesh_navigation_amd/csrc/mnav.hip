@@ -19,12 +19,14 @@
 // This file never computes a plan on the CPU: every entry point fails when no GPU is usable.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -1086,14 +1088,17 @@ struct ShardDev {
 };
 
 // pack: own interface values, +inf for the others (the min-allreduce then delivers every owner's value)
-__global__ __launch_bounds__(kBlock) void k_shard_pack(ShardDev S, const float* __restrict__ dist, float* __restrict__ buf)
+__global__ __launch_bounds__(kBlock) void k_shard_pack(ShardDev S, const TilePlan* __restrict__ plans, float* __restrict__ buf,
+                                                       uint32_t* __restrict__ changed, uint32_t* __restrict__ minpend)
 {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *changed = 0u; *minpend = kInfBits; }   // the words the apply step accumulates into ("nothing pending")
+  const float* dist = plans[0].dist;                                  // (the robot vertex comes from the plan record too: the captured
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;               //  exchange graphs hold nothing that changes from plan to plan)
   if (i < S.n_iface) {
     const uint32_t v = S.iface_vert[i];
     buf[i] = (v != kNone && (S.partition || S.iface_owner[i] == S.rank)) ? dist[v] : inf_f();
   }
-  if (i == S.n_iface) buf[i] = dist[S.target];      // last slot: the robot vertex (bound / goal_dist need it everywhere); stale copies are larger
+  if (i == S.n_iface) buf[i] = dist[plans[0].target];   // last slot: the robot vertex (bound / goal_dist need it everywhere); stale copies are larger
 }
 
 // apply: ghost values that dropped are stored and wake the local tiles around them for the next round;
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void k_shard_apply(ShardDev S, const TilePl
   TCnt* cnt = &P.cnt[((j % 3) + 3) % 3];                             // ... and the counters it reads as "previous"
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i == 0) { P.ctl[0].done = 0; P.ctl[1].done = 0; }
-  if (i == S.n_iface) { if (buf[i] < P.dist[S.target]) P.dist[S.target] = buf[i]; return; }
+  if (i == S.n_iface) { if (buf[i] < P.dist[P.target]) P.dist[P.target] = buf[i]; return; }
   if (i >= S.n_iface) return;
   const uint32_t v = S.iface_vert[i];
   if (v == kNone || (!S.partition && S.iface_owner[i] == S.rank)) return;
@@ -1140,14 +1145,31 @@ __global__ __launch_bounds__(kBlock) void k_shard_minpend(const TilePlan* __rest
 }
 
 // the termination words of one exchange, written on the device: {smallest pending wake-up, dist[target], -status}
-__global__ void k_shard_ctl(const uint32_t* __restrict__ minpend, const float* __restrict__ dist, uint32_t target, const uint32_t* __restrict__ cancel,
+__global__ void k_shard_ctl(const uint32_t* __restrict__ minpend, const TilePlan* __restrict__ plans, const uint32_t* __restrict__ cancel,
                             float* __restrict__ ctl)
 {
   if (threadIdx.x || blockIdx.x) return;
+  const float* dist = plans[0].dist; const uint32_t target = plans[0].target;
   const uint32_t mp = *minpend;
   ctl[0] = (mp >= kInfBits) ? inf_f() : u2f(mp);
   ctl[1] = dist[target];
   ctl[2] = (cancel && __atomic_load_n(cancel, __ATOMIC_RELAXED)) ? -1.0f : 0.0f;
+}
+
+// One segment of the vertex path (dijkstra :358-373) inside this process's part: predecessors are followed from `start` while
+// the vertex is owned here; out = {count, vertex the walk stopped at, status (1: a vertex without predecessor), ids...}
+__global__ void k_shard_walk(const uint32_t* __restrict__ pred, const uint8_t* __restrict__ owned, uint32_t start, uint32_t seed, uint32_t cap,
+                             uint32_t* __restrict__ out)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t v = start, n = 0, status = 0;
+  while (v != seed && (!owned || owned[v]) && n < cap) {
+    const uint32_t p = pred[v];
+    if (p == v) { status = 1; break; }
+    out[3 + n++] = p;
+    v = p;
+  }
+  out[0] = n; out[1] = v; out[2] = status;
 }
 
 // final gather buffers: owned entries, neutral elements elsewhere (min-allreduce over dist, pred)
@@ -2107,6 +2129,8 @@ struct mnav_ctx {
     uint8_t* d_iface_owner = nullptr;
     std::vector<uint32_t> iface_vert;
     bool partition = false; uint8_t* d_owned = nullptr;              // mnav_shard_setup_partition
+    uint32_t* d_walk = nullptr; uint32_t walk_cap = 0;               // mnav_shard_walk
+    std::map<std::array<uint64_t, 3>, hipGraphExec_t> graphs;        // captured exchange sequences (shard_replay)
   } shard;
   double edge_cost_factor = 0.0;                                   // factor of the resident edge weights (mnav_update_costs)
   // layers computed / kept on the device (mnav_layer_*)
@@ -2196,6 +2220,8 @@ void drop_graphs(mnav_ctx* ctx)
 {
   for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
   ctx->graphs.clear();
+  for (auto& kv : ctx->shard.graphs) (void)hipGraphExecDestroy(kv.second);
+  ctx->shard.graphs.clear();
 }
 
 int ensure_plan_tables(mnav_ctx* ctx, uint32_t n);
@@ -2820,7 +2846,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
   (void)hipFree(ctx->d_tplans);
   (void)hipFree(ctx->shard.d_iface_vert); (void)hipFree(ctx->shard.d_iface_owner); (void)hipFree(ctx->shard.d_wake_ptr); (void)hipFree(ctx->shard.d_wake_tile);
-  (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend);
+  (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend); (void)hipFree(ctx->shard.d_walk);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
   (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
@@ -3829,6 +3855,8 @@ int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world)
   if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
   if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : S.graphs) (void)hipGraphExecDestroy(kv.second);   // the captured exchanges hold the old lists
+  S.graphs.clear();
   S.ready = true; S.active = false;
   return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
 }
@@ -3880,6 +3908,8 @@ int mnav_shard_setup_partition(mnav_ctx* ctx, uint32_t n_exchange, const uint32_
   if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
   if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : S.graphs) (void)hipGraphExecDestroy(kv.second);   // the captured exchanges hold the old lists
+  S.graphs.clear();
   S.ready = true; S.active = false;
   return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
 }
@@ -3989,7 +4019,7 @@ int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev)
   for (uint32_t r = 0; r < rounds; ++r, ++S.j)
     hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)(S.j % 6));
   if (iface_buf_dev)
-    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->slots[0].dist, iface_buf_dev);
+    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, ctx->shard.d_changed, ctx->shard.d_minpend);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->cancel.load(std::memory_order_relaxed)) return 1;
@@ -4033,6 +4063,32 @@ static int shard_link(mnav_ctx* ctx, hipStream_t caller, bool in)
   return 0;
 }
 
+// One exchange is two fixed sequences of small launches (R rounds + pack; apply + min + control words): each is captured into a
+// hipGraph once per (R, round parity, buffers) and replayed -- the launches of a 10M-vertex plan are ~80 exchanges x 12.
+// KERNELS ONLY: with hipMemsetAsync / hipMemsetD32Async nodes at the head of the second graph (ROCm 7.2) a plan that started
+// right after another one read a wake-up word of the previous plan now and then (a stale "3" instead of +inf; gone with either
+// graph alone, with a device synchronisation at the start of the plan, or -- the fix -- with the two words cleared by the
+// pack kernel of the first sequence): memset nodes do not seem to be ordered like the kernels around them.
+static int shard_replay(mnav_ctx* ctx, const std::array<uint64_t, 3>& key, const std::function<int()>& enqueue)
+{
+  if (!ctx->use_graph) return enqueue();
+  auto& S = ctx->shard;
+  auto it = S.graphs.find(key);
+  if (it == S.graphs.end()) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue();
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = S.graphs.emplace(key, ge).first;
+  }
+  HIPCHK(hipGraphLaunch(it->second, ctx->stream));
+  return 0;
+}
+
 int mnav_shard_rounds_async(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev, void* caller_stream)
 {
   if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
@@ -4042,11 +4098,17 @@ int mnav_shard_rounds_async(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev
   const uint32_t own = S.t_hi - S.t_lo;
   uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
   if (G > own) G = own ? own : 1;
-  for (uint32_t r = 0; r < rounds; ++r, ++S.j)
-    hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)(S.j % 6));
-  if (iface_buf_dev)
-    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->slots[0].dist, iface_buf_dev);
-  HIPCHK(hipGetLastError());
+  const uint32_t j0 = S.j % 6u;
+  const int rc = shard_replay(ctx, { ((uint64_t)rounds << 8) | j0, (uint64_t)(uintptr_t)iface_buf_dev, 1ull }, [&]() {
+    for (uint32_t r = 0; r < rounds; ++r)
+      hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)((j0 + r) % 6u));
+    if (iface_buf_dev)
+      hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, ctx->shard.d_changed, ctx->shard.d_minpend);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  S.j += rounds;
   return shard_link(ctx, (hipStream_t)caller_stream, false);
 }
 
@@ -4057,15 +4119,17 @@ int mnav_shard_apply_async(mnav_ctx* ctx, const float* iface_buf_dev, float* ctl
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
   auto& S = ctx->shard;
   if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
-  HIPCHK(hipMemsetAsync(S.d_changed, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)S.d_minpend, (int)kInfBits, 1, ctx->stream));   // +inf: "nothing pending"
-  const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
-  const uint32_t own = S.t_hi - S.t_lo;
-  const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
-  hipLaunchKernelGGL(k_shard_ctl, dim3(1), dim3(64), 0, ctx->stream, S.d_minpend, ctx->slots[0].dist, S.target, ctx->d_cancel, ctl_dev);
-  HIPCHK(hipGetLastError());
+  const int rc = shard_replay(ctx, { (uint64_t)(uintptr_t)iface_buf_dev, (uint64_t)(uintptr_t)ctl_dev, 2ull }, [&]() {
+    const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;          // (k_shard_pack cleared the two accumulator words: kernels only in the graph)
+    hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
+    const uint32_t own = S.t_hi - S.t_lo;
+    const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
+    hipLaunchKernelGGL(k_shard_ctl, dim3(1), dim3(64), 0, ctx->stream, S.d_minpend, ctx->d_tplans, ctx->d_cancel, ctl_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
   return shard_link(ctx, (hipStream_t)caller_stream, false);
 }
 
@@ -4091,6 +4155,26 @@ int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_d
   HIPCHK(hipStreamSynchronize(ctx->stream));
   S.active = false;
   if (mism) { ctx->err = "sharded SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)"; return -2; }
+  return 0;
+}
+
+int mnav_shard_walk(mnav_ctx* ctx, uint32_t start_vertex, uint32_t seed_vertex, uint32_t cap, uint32_t* out_host)
+{
+  if (!ctx || !ctx->shard.ready || !out_host || ctx->slots.empty()) { if (ctx) ctx->err = "mnav_shard_walk: no sharded plan"; return -1; }
+  if (start_vertex >= ctx->V || seed_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  if (S.walk_cap < cap + 3u) {
+    (void)hipFree(S.d_walk); S.d_walk = nullptr;
+    HIPCHK(hipMalloc((void**)&S.d_walk, 4 * (size_t)(cap + 3u)));
+    S.walk_cap = cap + 3u;
+  }
+  hipLaunchKernelGGL(k_shard_walk, dim3(1), dim3(64), 0, ctx->stream, ctx->slots[0].pred, S.partition ? S.d_owned : nullptr, start_vertex, seed_vertex, cap, S.d_walk);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_host, S.d_walk, 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint32_t n = out_host[0];
+  if (n) HIPCHK(hipMemcpy(out_host + 3, S.d_walk + 3, 4 * (size_t)n, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -319,15 +319,26 @@ def extract_part(xyz: np.ndarray, edges: np.ndarray, owner: np.ndarray, rank: in
 _BIG = np.iinfo(np.int64).max
 
 
-def _segment_of(part: MeshPart, pred_l: np.ndarray, cur: int, seed: int, first: bool, segment: int) -> np.ndarray:
+def _segment_of(part: MeshPart, pred_l, cur: int, seed: int, first: bool, segment: int) -> np.ndarray:
     """This process's contribution to one hop of the path walk: [count, next vertex, status, ids...] if it owns `cur`, the
-    neutral element of the int64 MIN otherwise."""
+    neutral element of the int64 MIN otherwise.  `pred_l`: the local predecessor array, or a callable (start, seed, cap) ->
+    [hops, stop, status, local ids...] that walks on the device (mnav_shard_walk)."""
     seg = np.full(segment + 3, _BIG, np.int64)
     if not part.owns(cur):
         return seg
+    n0 = part.gid.shape[0]
+    if callable(pred_l):
+        ls = part.local_of(seed)
+        w = pred_l(part.local_of(cur), ls if ls >= 0 else n0, segment)
+        n, stop, status = int(w[0]), int(w[1]), int(w[2])
+        ids_l = w[3:3 + n].astype(np.int64)
+        if status or (n and int(ids_l.max()) >= n0) or stop >= n0:        # no predecessor / a phantom on the path
+            status = 1 if (first and n == 0) else 2
+        seg[0], seg[1], seg[2] = n, (int(part.gid[stop]) if stop < n0 else cur), status
+        seg[3:3 + n] = part.gid[np.minimum(ids_l, n0 - 1)]
+        return seg
     ids: list[int] = []
     v, status = cur, 0
-    n0 = part.gid.shape[0]
     while v != seed and part.owns(v) and len(ids) < segment:
         lv = part.local_of(v)
         lp = int(pred_l[lv])
@@ -381,7 +392,10 @@ def collect_partitioned(engine, allreduce_min: Callable, seed: int, target: int,
     the V-sized potential / predecessor arrays are assembled as well (validation only: the one place where something
     mesh-sized exists per process)."""
     part: MeshPart = engine.part
-    dist_l, pred_l = engine.local_result()                             # local arrays; predecessors are local ids
+    if not gather and hasattr(engine, "walker"):
+        dist_l, pred_l = None, engine.walker()                         # the arrays stay on the device, segments are walked there
+    else:
+        dist_l, pred_l = engine.local_result()                         # local arrays; predecessors are local ids
     code, path = _walk_segments(lambda cur, first: engine.reduce_int64(_segment_of(part, pred_l, cur, seed, first, segment), allreduce_min),
                                 seed, target, part.V_global)
     dist = pred = None
@@ -435,6 +449,9 @@ class PartitionedShardEngine(GpuShardEngine):
     def local_result(self):
         return self.dist.cpu().numpy(), self.pred.cpu().numpy().view(np.uint32)
 
+    def walker(self):
+        return lambda start, seed, cap: self.ctx.shard_walk(start, seed, cap)
+
     def _reduce(self, host: np.ndarray, allreduce_min):
         t = self.torch.from_numpy(host).to(self.dev)
         allreduce_min(t)
@@ -462,7 +479,7 @@ def torch_allreduce_min(dist):
 
 def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offset: float = 0.3,
                        rounds_per_exchange: int = 8, max_exchanges: int = 100_000, check_every: int = 8,
-                       device_loop: bool | None = None) -> ShardedResult:
+                       device_loop: bool | None = None, gather: bool = True) -> ShardedResult:
     """`world` engines inside ONE process (one GPU standing in for several): the same protocol, the collective
     replaced by an elementwise minimum over the engines' buffers.  Lock-step version of run_sharded_plan (both of its
     loops: engines with the asynchronous steps run the device-resident one)."""
@@ -513,6 +530,11 @@ def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offs
     if any(getattr(e, "status", 0) for e in engines):
         return ShardedResult(INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
     if hasattr(engines[0], "part"):                                   # partitioned data: the same collection, the collectives done by hand
+        if not gather and all(hasattr(e, "walker") for e in engines):  # nothing V-sized leaves the devices: segments are walked there
+            walkers = [e.walker() for e in engines]
+            code, path = _walk_segments(lambda cur, first: np.minimum.reduce([_segment_of(e.part, w, cur, seed, first, 4096) for e, w in zip(engines, walkers)]),
+                                        seed, target, engines[0].part.V_global)
+            return ShardedResult(code, None, None, path, exchanges, rounds)
         loc = [e.local_result() for e in engines]
         code, path = _walk_segments(lambda cur, first: np.minimum.reduce([_segment_of(e.part, l[1], cur, seed, first, 4096) for e, l in zip(engines, loc)]),
                                     seed, target, engines[0].part.V_global)

@@ -120,9 +120,11 @@ def test_partitioned_plan_with_costs_invalid_and_unreachable(gpu_ctx_factory):
     assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(res.pred, ref.pred)
     assert np.array_equal(res.path, ref.path)
     ref2 = case.om.dijkstra(case.weights, case.costs, s, t, invalid=invalid, cost_limit=-1.0)
-    res2 = sharded.plan_virtual_ranks(part_engines(case, 2, gpu_ctx_factory, cost_limit=-1.0), s, t, max_exchanges=5000)
+    eng2 = part_engines(case, 2, gpu_ctx_factory, cost_limit=-1.0)
+    res2 = sharded.plan_virtual_ranks(eng2, s, t, max_exchanges=5000)
     assert res2.code == ref2.code == sharded.NO_PATH_FOUND
     assert np.array_equal(res2.dist.view(np.uint32), ref2.dist.view(np.uint32))
+    assert sharded.plan_virtual_ranks(eng2, s, t, max_exchanges=5000, gather=False).code == sharded.NO_PATH_FOUND   # device walk: same verdict
 
 
 def test_partitioned_plan_1m_four_ranks_and_device_footprint(gpu_ctx_factory):
@@ -138,6 +140,13 @@ def test_partitioned_plan_1m_four_ranks_and_device_footprint(gpu_ctx_factory):
     assert res.code == ref.code == 0
     assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32))
     assert np.array_equal(res.pred, ref.pred) and np.array_equal(res.path, ref.path)
+    # the path again with nothing mesh-sized leaving the devices: every part walks its segments itself (mnav_shard_walk)
+    res_w = sharded.plan_virtual_ranks(eng, seed, target, rounds_per_exchange=8, max_exchanges=5000, gather=False)
+    assert res_w.code == 0 and res_w.dist is None and np.array_equal(res_w.path, ref.path)
+    far = m.vertex_at(0.5, 0.03)                                     # another robot vertex: the path crosses other interfaces
+    ref_f = case.om.dijkstra(case.weights, case.costs, seed, far)
+    res_f = sharded.plan_virtual_ranks(eng, seed, far, rounds_per_exchange=8, max_exchanges=5000, gather=False)
+    assert res_f.code == ref_f.code == 0 and np.array_equal(res_f.path, ref_f.path)
     full = part_engines(case, 1, gpu_ctx_factory)                   # the same upload (no faces, two phantoms) of the whole mesh
     r1 = sharded.plan_virtual_ranks(full, seed, target, rounds_per_exchange=8, max_exchanges=5000)
     assert np.array_equal(r1.path, ref.path) and np.array_equal(r1.pred, ref.pred)
