@@ -378,14 +378,241 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
   return x;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide CVP step (batches): a wave takes 64 work-list entries per round instead of 8.
+// The 8-lane replay above spends most of its instructions on in-group shuffles and serves 8 vertices per wave instruction.
+// Here the evaluation is cut where its data dependence allows (mnav_eval.h: make_cvp_item / eval_cvp_items):
+//   phase A, one lane per incident FACE of the 64 vertices (~384 faces = 6 passes of 64 lanes): fire event and float64
+//            candidate, neither depends on the vertex's own state -> a 48-byte item in LDS;
+//   phase B, one lane per VERTEX: the replay over its own items, serially, without a single shuffle;
+//   pushes,  one lane per face again (wave-aggregated list appends as before).
+// Same functions, same decisions as eval_cvp (held against it in the CPU model on every evaluation); which vertices are
+// evaluated concurrently differs, which the fixed-point iteration does not care about.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kWideSlots = 416;          // items per wave and round: 64 vertices x 6.5 faces (20 KB of LDS; with the table below: seven waves per CU)
+constexpr uint32_t kWideSeen = 512;           // direct-mapped table of vertices this wave has pushed in this launch (see push_many)
+constexpr uint32_t kWideMaxFaces = 32;        // faces of one vertex that go through the items; beyond: the serial rule (eval_cvp)
+// items field-major: phase A stores a field of 64 consecutive slots at a time, phase B lanes read only the fields they look at
+// (an array of 48-byte structs costs an 8-way bank conflict per read there: the lanes' items lie 6 x 48 bytes apart)
+struct WideLds {
+  unsigned long long hi[kWideSlots], own[kWideSlots];
+  double u3tmp[kWideSlots], cand[kWideSlots];
+  uint32_t up[kWideSlots], lvl[kWideSlots], meta[kWideSlots];
+  float dir[kWideSlots];
+  uint8_t owner[kWideSlots];
+  uint32_t seen[kWideSeen];
+};
+struct WideItems {
+  const WideLds* L; uint32_t off;
+  __device__ __forceinline__ unsigned long long hi(uint32_t k) const { return L->hi[off + k]; }
+  __device__ __forceinline__ uint32_t up(uint32_t k) const { return L->up[off + k]; }
+  __device__ __forceinline__ uint32_t lvl(uint32_t k) const { return L->lvl[off + k]; }
+  __device__ __forceinline__ unsigned long long own(uint32_t k) const { return L->own[off + k]; }
+  __device__ __forceinline__ double u3tmp(uint32_t k) const { return L->u3tmp[off + k]; }
+  __device__ __forceinline__ double cand(uint32_t k) const { return L->cand[off + k]; }
+  __device__ __forceinline__ float dir(uint32_t k) const { return L->dir[off + k]; }
+  __device__ __forceinline__ uint32_t meta(uint32_t k) const { return L->meta[off + k]; }
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, o));
+  return x;
+}
+
+// dedup'd, wave-aggregated append of up to N vertices per lane (kNone: none) to the next work list: the stamp looks, the
+// exchanges and the ONE counter atomic of the whole batch are each in flight together (push_agg per vertex is a chain of three
+// dependent round trips)
+// Neighbouring vertices share most of their neighbours, and a wave's 64 work-list entries are neighbours: most candidates of a
+// batch are duplicates of each other.  They are filtered in LDS first -- `seen` is a direct-mapped table of the vertices this
+// wave has handed on during this launch (one step of one plan: the global stamp of such a vertex is set already, so dropping a
+// repeat is exactly what the stamp would do; a slot taken over by another vertex only lets a repeat through) -- which leaves
+// a third of the global look / exchange pairs.
+template <int N>
+__device__ __forceinline__ void push_many(StepCtx& S, uint32_t (&u)[N], uint32_t* seen, int lane)
+{
+  uint32_t st[N];
+  bool ok[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (u[k] != kNone) { const uint32_t old = atomicExch(&seen[u[k] & (kWideSeen - 1u)], u[k]); if (old == u[k]) u[k] = kNone; }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) { st[k] = S.sv; if (u[k] != kNone) { S.P->dirty[u[k]] = S.sv; st[k] = S.P->stamp[u[k]]; } }
+#pragma unroll
+  for (int k = 0; k < N; ++k) { uint32_t o = S.sv; if (st[k] != S.sv) o = atomicExch(&S.P->stamp[u[k]], S.sv); st[k] = o; }
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) { ok[k] = st[k] != S.sv; mine += ok[k] ? 1u : 0u; }
+  uint32_t incl = mine;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+  const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+  if (total == 0u) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&S.cnt->n_next, total);
+  uint32_t idx = (uint32_t)__shfl((int)base, 0) + incl - mine;
+#pragma unroll
+  for (int k = 0; k < N; ++k) if (ok[k]) { if (idx < S.P->cap) S.next[idx] = u[k]; ++idx; }
+}
+
+constexpr int kWidePassesPerBatch = 4;        // face passes whose loads are in flight together (4 x 64 faces)
+
+#ifdef MNAV_WIDE_TIMING                   // debugging aid: cycles per phase of wide_round, summed over all waves
+__device__ unsigned long long g_wide_timing[8];
+#define WD_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); wt[k] += now_ - w_last; w_last = now_; } while (0)
+#else
+#define WD_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl& c, WideLds& L, bool active, uint32_t v, int lane)
+{
+#ifdef MNAV_WIDE_TIMING
+  unsigned long long wt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, w_last = __builtin_readcyclecounter();
+#endif
+  // ---- per vertex: does it have to be evaluated?  (spec: process_entry)
+  bool evaluate = false, retain = false, push_nb = false, self_again = false;
+  float old_d = inf_f(), old_t = inf_f(), t_new = inf_f(), old_dir = 0.0f;
+  uint32_t old_pred = kNone, old_cut = kNone, beg = 0, nf = 0;
+  PopKey old_key = key_inf();
+  if (active && !is_seed(P, v)) {
+    old_d = P.dist[v]; old_key = P.tkey[v];
+    const uint8_t blk = P.blocked[v];
+    const uint32_t dirty = P.dirty[v];
+    const uint32_t b0 = P.crn_ptr[v], b1 = P.crn_ptr[v + 1];
+    old_pred = P.pred[v]; old_cut = P.cutf[v]; old_dir = P.dirn[v];  // (all of the vertex's state in flight together)
+    old_t = key_time(old_key);
+    const bool go = !(old_t < c.thr_fixed) && !blk;
+    const bool parked = go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && dirty != (uint32_t)c.it;
+    if (parked) { retain = true; t_new = old_t; }
+    else if (go) { evaluate = true; beg = b0; nf = b1 - b0; }
+  }
+  // ---- item slots: prefix sum of the face counts.  A vertex of very high valence, and whatever does not fit, takes the serial rule
+  const uint32_t want = (nf <= kWideMaxFaces) ? nf : 0u;
+  uint32_t incl = want;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+  const bool slots = want > 0u && incl <= kWideSlots;
+  const uint32_t off = incl - want;
+  const uint32_t T = wave_max_u32(slots ? incl : 0u);
+  __syncthreads();                                                     // the previous round's readers of the LDS image are done
+  if (slots) for (uint32_t k = 0; k < nf; ++k) L.owner[off + k] = (uint8_t)lane;
+  __syncthreads();
+  WD_STAMP(0);
+  // ---- phase A: one lane per face; the records of a batch of passes are loaded before the first face is looked at
+  for (uint32_t q00 = 0; q00 < T; q00 += kWidePassesPerBatch * kWave) {
+    Corner ck[kWidePassesPerBatch];
+    uint32_t vs[kWidePassesPerBatch];
+#pragma unroll
+    for (int p = 0; p < kWidePassesPerBatch; ++p) {
+      const uint32_t q = q00 + p * kWave + (uint32_t)lane;
+      ck[p].v1 = kNone; ck[p].v2 = kNone; ck[p].a = 0.f; ck[p].b = 0.f; ck[p].c = 0.f; ck[p].face = 0u; vs[p] = 0u;
+      if (q00 + p * kWave < T) {                                       // (wave-uniform)
+        const int s = L.owner[q < T ? q : T - 1u];
+        vs[p] = (uint32_t)__shfl((int)v, s);
+        const uint32_t bs = (uint32_t)__shfl((int)beg, s), os = (uint32_t)__shfl((int)off, s);
+        if (q < T) ck[p] = P.crn[bs + (q - os)];
+      }
+    }
+    PopKey t1[kWidePassesPerBatch], t2[kWidePassesPerBatch];
+    float d1[kWidePassesPerBatch], d2[kWidePassesPerBatch];
+#pragma unroll
+    for (int p = 0; p < kWidePassesPerBatch; ++p) {
+      t1[p] = key_inf(); t2[p] = key_inf(); d1[p] = inf_f(); d2[p] = inf_f();
+      if (ck[p].v1 != kNone) { t1[p] = P.tkey[ck[p].v1]; t2[p] = P.tkey[ck[p].v2]; d1[p] = P.dist[ck[p].v1]; d2[p] = P.dist[ck[p].v2]; }
+    }
+#ifdef MNAV_WIDE_TIMING
+    { float z = 0.f; for (int p = 0; p < kWidePassesPerBatch; ++p) z += d1[p] + d2[p]; asm volatile("" :: "v"(z)); }   // wait for the loads
+#endif
+    WD_STAMP(1);
+#pragma unroll
+    for (int p = 0; p < kWidePassesPerBatch; ++p) {
+      const uint32_t q = q00 + p * kWave + (uint32_t)lane;
+      if (q < T) {
+        const CvpItem it = make_cvp_item_pre(P, c, vs[p], ck[p], t1[p], t2[p], d1[p], d2[p]);
+        L.hi[q] = it.hi; L.own[q] = it.own; L.u3tmp[q] = it.u3tmp; L.cand[q] = it.cand;
+        L.up[q] = it.up; L.lvl[q] = it.lvl; L.meta[q] = it.meta; L.dir[q] = it.dir;
+      }
+    }
+    WD_STAMP(2);
+  }
+  __syncthreads();
+  // ---- phase B: one lane per vertex
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
+  if (slots) {
+    uint32_t win; int sel;
+    WideItems mine; mine.L = &L; mine.off = off;
+    e = eval_cvp_items_any(P, v, nf, mine, win, sel);
+    if (win != kNone) { const Corner k = P.crn[beg + win]; e.pred = (sel == 1) ? k.v1 : k.v2; e.cut = corner_face(k); }
+  } else if (evaluate) {
+    e = eval_cvp(P, c, v);                                             // no faces / too many / no room left in this round
+  }
+  WD_STAMP(3);
+  if (evaluate) {
+    ++S.levals;
+    const bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != old_pred) || (e.key != old_key) ||
+                         (e.cut != old_cut) || (f2u(e.dir) != f2u(old_dir));
+    if (changed) { P.dist[v] = e.d; P.pred[v] = e.pred; P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
+    t_new = e.t;
+    const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
+    push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
+    retain = !now_in && e.t < inf_f();
+    self_again = (e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key;   // spec: process_entry
+  }
+  if (push_nb || self_again) {
+    S.lchanged = true;
+    if (push_nb && ((old_t < c.thr) != (t_new < c.thr))) S.lcut = fminf(S.lcut, fminf(old_t, t_new));   // crossed the bound (spec: note_cut)
+  }
+  // ---- pushes: one lane per face of the vertices that moved, the vertex itself when its cascade key moved
+  {
+    constexpr int kPasses = (int)(kWideSlots / kWave);
+    uint32_t u[2 * kPasses + 1];
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+      u[2 * p] = kNone; u[2 * p + 1] = kNone;
+      if ((uint32_t)(p * kWave) < T) {                                  // (wave-uniform)
+        const uint32_t q = p * kWave + (uint32_t)lane;
+        const int s = L.owner[q < T ? q : T - 1u];
+        const bool w = __shfl((int)push_nb, s) != 0 && q < T;
+        const uint32_t bs = (uint32_t)__shfl((int)beg, s), os = (uint32_t)__shfl((int)off, s);
+        if (w) { const Corner k = P.crn[bs + (q - os)]; if (k.v1 != kNone) { u[2 * p] = k.v1; u[2 * p + 1] = k.v2; } }
+      }
+    }
+    u[2 * kPasses] = self_again ? v : kNone;
+    WD_STAMP(4);
+    push_many(S, u, L.seen, lane);
+  }
+  WD_STAMP(5);
+  unsigned long long sm = __ballot(push_nb && !slots);                 // vertices that took the serial rule: the wave walks their faces
+  while (sm) {
+    const int src = __ffsll((long long)sm) - 1;
+    sm &= sm - 1ull;
+    const uint32_t vb = (uint32_t)__shfl((int)beg, src), vn = (uint32_t)__shfl((int)nf, src);
+    for (uint32_t i0 = 0; i0 < vn; i0 += kWave) {
+      const uint32_t i = i0 + (uint32_t)lane;
+      uint32_t a = kNone, b = kNone;
+      if (i < vn) { const Corner k = P.crn[vb + i]; if (k.v1 != kNone) { a = k.v1; b = k.v2; } }
+      push_agg<true>(S, a != kNone, a);
+      push_agg<true>(S, b != kNone, b);
+    }
+  }
+  park_agg(S, retain, v);
+  if (retain) S.lmin = fminf(S.lmin, t_new);
+  WD_STAMP(6);
+#ifdef MNAV_WIDE_TIMING
+  if (lane == 0) for (int k = 0; k < 8; ++k) if (wt[k]) atomicAdd(&g_wide_timing[k], wt[k]);
+#endif
+}
+
 // grid = (waves per plan, plans).  slot j (0..5) selects the ping-pong control block (j&1) and
 // the counter block (j%3).
 #ifndef MNAV_STEP_OCC                     // waves per SIMD the register allocator must reach: 3 (<= 168 VGPRs).  The CVP replay sits
 #define MNAV_STEP_OCC 3                   // right at that edge (159-170 VGPRs); at 2 waves a batch is 20 % slower, forcing 4 or 5
 #endif                                    // spills and is slower still (measured: 179 / 150 / 120 plans/s at 3 / 4 / 5)
 #define MNAV_STEP_BOUNDS __launch_bounds__(kWave, MNAV_STEP_OCC)
-template <uint32_t PLANNER>
-__global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
+template <uint32_t PLANNER, bool WIDE>
+__device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j)
 {
   const Plan& P = plans[blockIdx.y];
   const int lane = threadIdx.x;
@@ -409,6 +636,33 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
   const int sub = lane & (kGroup - 1), grp = lane >> 3;
   const uint32_t ngroups = gridDim.x * kGroupsPerWave;
   const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
+  if constexpr (WIDE && PLANNER == kPlannerCvp) {
+    if (cur.repair == 0 && P.seed_mask == nullptr) {                  // the ordinary step: 64 work-list entries per wave and round
+      __shared__ WideLds s_wide;
+      for (uint32_t k = (uint32_t)lane; k < kWideSeen; k += kWave) s_wide.seen[k] = kNone;   // (wide_round starts with a barrier)
+      const uint32_t* list = P.list[cur.it & 1];
+      const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
+      const uint32_t ntot = cur.n + cur.wread;
+      const uint32_t per = gridDim.x * kWave;
+      for (uint32_t base = blockIdx.x * kWave; base < ntot; base += per) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool active = i < ntot;
+        const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
+        wide_round(S, P, cur, s_wide, active, v, lane);
+      }
+      const float wmin = wave_min(S.lmin);
+      const float wcut = wave_min(S.lcut);
+      const uint32_t wev = wave_sum(S.levals);
+      const bool wch = __any(S.lchanged);
+      if (lane == 0) {
+        if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
+        if (wcut < inf_f()) atomicMin(&cnt->minchg, f2u(wcut));
+        if (wev) atomicAdd(&cnt->evals, wev);
+        if (wch) atomicOr(&cnt->changed, 1u);
+      }
+      return;
+    }
+  }
   if (cur.repair == 3) {                                             // spec: process_cut -- no evaluation
     const uint32_t nthreads = gridDim.x * kWave, tid = blockIdx.x * kWave + lane;
     const uint32_t* list = P.list[cur.it & 1];
@@ -463,6 +717,11 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j)
     if (wch) atomicOr(&cnt->changed, 1u);
   }
 }
+
+template <uint32_t PLANNER>
+__global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) { step_body<PLANNER, false>(plans, j); }
+// the wide variant is bounded by its LDS image (seven waves per CU), not by registers
+__global__ __launch_bounds__(kWave, 2) void k_step_wide(const Plan* __restrict__ plans, int j) { step_body<kPlannerCvp, true>(plans, j); }
 
 // CVP verification sweep, run once after the last step (the CVP counterpart of k_dij_finalize's fixed-point
 // check): every vertex is evaluated once more on the CONVERGED state.  (1) Its stored (potential, pop key,
@@ -2146,6 +2405,7 @@ struct mnav_ctx {
   TCtl* h_tctl = nullptr;
   size_t tile_lds = 0, fin_lds = 0;
   bool use_graph = true;
+  uint32_t cvp_wide_min_batch = 24;                                  // CVP batches of at least this many plans run k_step_wide
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
   std::vector<uint32_t> last_target; double last_offset = 0.0;   // Dijkstra: robot vertex per device slot, goal_dist_offset of the last call
@@ -2322,25 +2582,26 @@ uint32_t blocks_per_plan(const mnav_ctx* ctx)
 }
 
 template <uint32_t PLANNER>
-int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count)
+int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count, bool wide)
 {
   for (int j = 0; j < count; ++j) {
-    hipLaunchKernelGGL(k_step<PLANNER>, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
+    if (wide) hipLaunchKernelGGL(k_step_wide, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
+    else hipLaunchKernelGGL(k_step<PLANNER>, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 template <uint32_t PLANNER>
-int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G)
+int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G, bool wide)
 {
-  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, getenv("MNAV_DEBUG_CHUNK") ? atoi(getenv("MNAV_DEBUG_CHUNK")) : kChunk);   // debug: finer control-block trace
-  const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)n << 32) | G;
+  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, getenv("MNAV_DEBUG_CHUNK") ? atoi(getenv("MNAV_DEBUG_CHUNK")) : kChunk, wide);   // debug: finer control-block trace
+  const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)(wide ? 1u : 0u) << 59) | ((uint64_t)n << 32) | G;
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = launch_steps<PLANNER>(ctx, n, G, kChunk);
+    const int rc = launch_steps<PLANNER>(ctx, n, G, kChunk, wide);
     hipError_t e = hipStreamEndCapture(ctx->stream, &g);
     if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
     hipGraphExec_t ge = nullptr;
@@ -2447,7 +2708,16 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
 
-  const uint32_t G = blocks_per_plan(ctx);
+  // CVP batches: the wide step kernel (64 work-list entries per wave and round); single plans keep the 8-lane replay, whose
+  // many small waves finish a short work list sooner
+  bool wide = cvp && n >= ctx->cvp_wide_min_batch;
+  if (const char* e = getenv("MNAV_CVP_WIDE")) wide = cvp && atoi(e) != 0;
+  uint32_t G = blocks_per_plan(ctx);
+  if (wide) {
+    G = (G + 3u) / 4u;                                                // half the lanes of a round busy on average: measured best (1M mesh, 128 plans: 63 waves
+                                                                      // per plan 193 plans/s, 125 -> 219, 32 -> 147)
+    if (const char* e = getenv("MNAV_BLOCKS_PER_PLAN_WIDE")) G = (uint32_t)std::max(1, atoi(e));
+  }
   uint32_t launches = 0;
   int rc = 0;
   const auto t_start = std::chrono::steady_clock::now();
@@ -2457,7 +2727,7 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
       ctx->err = "wavefront steps exceeded the wall-clock guard"; return -1;
     }
     HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-    if (run_chunk<PLANNER>(ctx, n, G)) return -1;
+    if (run_chunk<PLANNER>(ctx, n, G, wide)) return -1;
     HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
     launches += kChunk;
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl) * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -3262,7 +3532,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
       ctx->err = "inflation wave exceeded the wall-clock guard"; return -1;
     }
-    if (run_chunk<kPlannerCvp>(ctx, 1, G)) return -1;
+    if (run_chunk<kPlannerCvp>(ctx, 1, G, false)) return -1;
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
@@ -4426,3 +4696,12 @@ int mnav_debug_tile_timing(unsigned long long* out, unsigned int cap)
 #endif
 
 }  // extern "C"
+
+#ifdef MNAV_WIDE_TIMING
+extern "C" int mnav_debug_wide_timing(unsigned long long* out)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

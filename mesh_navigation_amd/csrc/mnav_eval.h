@@ -16,13 +16,19 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#ifdef MNAV_CHECK_TWO_PART
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #if defined(__HIPCC__)
 #define MNAV_HD __host__ __device__ __forceinline__
 #define MNAV_HD_COLD __host__ __device__ __attribute__((noinline))   // rare paths: kept out of the callers' register budget
+#define MNAV_UNROLL _Pragma("unroll")
 #else
 #define MNAV_HD inline
 #define MNAV_HD_COLD inline
+#define MNAV_UNROLL
 #endif
 
 namespace mnav {
@@ -492,7 +498,8 @@ MNAV_HD_COLD bool key_less_walk(const Plan& P, KeyRef a, KeyRef b)
 MNAV_HD bool key_less(const Plan& P, const KeyRef& a, const KeyRef& b)
 {
   if (a.k.hi != b.k.hi) return a.k.hi < b.k.hi;                    // different main-front pops
-  return key_less_walk(P, a, b);
+  if (a.k.lvl == b.k.lvl && a.own == b.own) return false;          // the same node (key_less_walk's first test, without the call:
+  return key_less_walk(P, a, b);                                   //  two faces fired by one pop are compared all the time)
 }
 
 // key of vertex v whose value d was set by the pop `trig`
@@ -520,9 +527,8 @@ MNAV_HD PopKey key_for(const Plan& P, float d, uint32_t v, KeyRef trig)
 // after v, so it can never be a trigger FOR v; in a half-converged state it must not act as one either,
 // or the two would keep supporting each other (v set by its own child, the child by v, ...).
 constexpr int kDescendWalkMax = 64;
-MNAV_HD bool key_descends_from(const Plan& P, uint32_t t, uint32_t v)
+MNAV_HD bool key_descends_from_pre(const Plan& P, PopKey a, uint32_t v)   // a = tkey[t]
 {
-  PopKey a = P.tkey[t];                                            // (no shortcut through hi / lvl: both may be stale)
   int guard = 0;
   for (; guard < P.descend_max && a.lvl > 0u; ++guard) {
     if (a.up == v) return true;
@@ -532,6 +538,7 @@ MNAV_HD bool key_descends_from(const Plan& P, uint32_t t, uint32_t v)
   if (guard == P.descend_max && a.lvl > 0u) raise_flag(P, kFlagWalkLimit);
   return false;
 }
+MNAV_HD bool key_descends_from(const Plan& P, uint32_t t, uint32_t v) { return key_descends_from_pre(P, P.tkey[t], v); }   // (no shortcut through hi / lvl: both may be stale)
 
 // --- arming of goal_dist once the robot vertex / robot face is settled -----------------------
 // Dijkstra: goal_dist = dist[target] + offset when the target pops (dijkstra :293-297).
@@ -697,12 +704,13 @@ MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
 // earliest such pop; trig == kNone when the face cannot fire in this band.
 struct Fire { KeyRef key; uint32_t trig; };
 
-MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
+// (k1, k2: key_ref of the two supports, d1, d2: their potentials -- loaded by the caller, so that a kernel can have the loads of
+// many faces in flight before the first one is looked at)
+MNAV_HD Fire corner_fire_pre(const Plan& P, const Ctl& c, const Corner& k, const KeyRef& k1, const KeyRef& k2, float d1, float d2)
 {
   Fire f; f.key = key_ref_of(key_inf(), inf_f(), 0); f.trig = kNone;
   if (k.v1 == kNone) return f;
   const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
-  const KeyRef k1 = key_ref(P, k.v1), k2 = key_ref(P, k.v2);
   const float t1 = key_time(k1.k), t2 = key_time(k2.k);
   if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return f;         // both supports fixed by this band
   bool ex1 = true, ex2 = true;
@@ -715,11 +723,17 @@ MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
     if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
   }
   const bool one_first = key_less(P, k1, k2);                        // v1 pops before v2
-  const bool trig1 = t1 < c.thr && ex1 && !(P.dist[k.v1] > c.goal_dist) && (s2 || !one_first);
-  const bool trig2 = t2 < c.thr && ex2 && !(P.dist[k.v2] > c.goal_dist) && (s1 || one_first || k1.own == k2.own);
+  const bool trig1 = t1 < c.thr && ex1 && !(d1 > c.goal_dist) && (s2 || !one_first);
+  const bool trig2 = t2 < c.thr && ex2 && !(d2 > c.goal_dist) && (s1 || one_first || k1.own == k2.own);
   if (trig1) { f.key = k1; f.trig = k.v1; }
   if (trig2 && (!trig1 || key_less(P, k2, k1))) { f.key = k2; f.trig = k.v2; }
   return f;
+}
+
+MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
+{
+  if (k.v1 == kNone) { Fire f; f.key = key_ref_of(key_inf(), inf_f(), 0); f.trig = kNone; return f; }
+  return corner_fire_pre(P, c, k, key_ref(P, k.v1), key_ref(P, k.v2), P.dist[k.v1], P.dist[k.v2]);
 }
 
 // CVP: replay of the incident-face updates of vertex v in the order their trigger vertices
@@ -783,6 +797,180 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
 }
 
 // ---------------------------------------------------------------------------------------
+// eval_cvp in two parts, for the wide step kernel (k_step<cvp, true>, mnav.hip): what a vertex's incident faces
+// contribute does not depend on the vertex's own state, so it is prepared face by face (one lane per face: fire event +
+// float64 candidate, make_cvp_item) and the replay then runs per vertex over the prepared items (eval_cvp_items) -- the
+// same decisions in the same order as eval_cvp, which stays the specification (tests/test_schedule_model.py holds the two
+// against each other on every evaluation of the model).  CVP planner only (the inflation wave keeps eval_cvp).
+// ---------------------------------------------------------------------------------------
+struct CvpItem {
+  unsigned long long hi;    // pop key of the trigger: PopKey {hi, up, lvl} ...
+  uint32_t up, lvl;
+  unsigned long long own;   // ... and its own (value, id) pair; the trigger's id is pair_id(own)
+  double u3tmp, cand;       // CvpCand
+  float dir;
+  uint32_t meta;            // bit 0: the face can fire (and its trigger does not descend from the vertex), bits 1-2 sel, 3-4 kind,
+};                          // bit 5: the face comes first in the trigger's circulator (corner_first_for)
+static_assert(sizeof(CvpItem) == 48, "CvpItem: 48 bytes of LDS per incident face");
+constexpr uint32_t kItemValid = 1u, kItemFirst = 32u;
+
+// (t1, t2, d1, d2: pop keys and potentials of the face's two supports, loaded by the caller; CVP planner: keyd is not in use)
+MNAV_HD CvpItem make_cvp_item_pre(const Plan& P, const Ctl& c, uint32_t v, const Corner& k, const PopKey& t1, const PopKey& t2, float d1, float d2)
+{
+  CvpItem it;
+  it.hi = 0ull; it.up = kNone; it.lvl = 0u; it.own = 0ull; it.u3tmp = 0.0; it.cand = 0.0; it.dir = 0.0f; it.meta = 0u;
+  if (k.v1 == kNone) return it;
+  const Fire f = corner_fire_pre(P, c, k, key_ref_of(t1, d1, k.v1), key_ref_of(t2, d2, k.v2), d1, d2);
+  if (f.trig == kNone || key_descends_from_pre(P, f.trig == k.v1 ? t1 : t2, v)) return it;          // (spec: eval_cvp)
+  const CvpCand cd = cvp_candidate(d1, d2, k.a, k.b, k.c);
+  it.hi = f.key.k.hi; it.up = f.key.k.up; it.lvl = f.key.k.lvl; it.own = f.key.own;
+  it.u3tmp = cd.u3tmp; it.cand = cd.cand; it.dir = cd.dir;
+  it.meta = kItemValid | ((uint32_t)cd.sel << 1) | ((uint32_t)cd.kind << 3) | (corner_first_for(k, f.trig) ? kItemFirst : 0u);
+  return it;
+}
+
+MNAV_HD CvpItem make_cvp_item(const Plan& P, const Ctl& c, uint32_t v, const Corner& k)
+{
+  if (k.v1 == kNone) { const PopKey z = key_inf(); return make_cvp_item_pre(P, c, v, k, z, z, inf_f(), inf_f()); }
+  return make_cvp_item_pre(P, c, v, k, P.tkey[k.v1], P.tkey[k.v2], P.dist[k.v1], P.dist[k.v2]);
+}
+
+// Items: field accessors hi(k), up(k), lvl(k), own(k), u3tmp(k), cand(k), dir(k), meta(k) of the vertex's k-th corner -- an array of
+// CvpItem on the CPU (CvpItemArray), field-major arrays in LDS on the device (a lane then only reads the fields it looks at).
+struct CvpItemArray {
+  const CvpItem* p;
+  MNAV_HD unsigned long long hi(uint32_t k) const { return p[k].hi; }
+  MNAV_HD uint32_t up(uint32_t k) const { return p[k].up; }
+  MNAV_HD uint32_t lvl(uint32_t k) const { return p[k].lvl; }
+  MNAV_HD unsigned long long own(uint32_t k) const { return p[k].own; }
+  MNAV_HD double u3tmp(uint32_t k) const { return p[k].u3tmp; }
+  MNAV_HD double cand(uint32_t k) const { return p[k].cand; }
+  MNAV_HD float dir(uint32_t k) const { return p[k].dir; }
+  MNAV_HD uint32_t meta(uint32_t k) const { return p[k].meta; }
+};
+
+// The replay of eval_cvp over n prepared items.  `win` = index of the corner whose update set the returned value (kNone: none)
+// and `win_sel` which of its supports is the predecessor; the caller resolves them to vertex / face ids from the corner record.
+template <class Items>
+MNAV_HD Eval eval_cvp_items(const Plan& P, uint32_t v, uint32_t n, const Items& item, uint32_t& win, int& win_sel)
+{
+  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
+  win = kNone; win_sel = 0;
+  KeyRef last = key_ref_of(key_inf(), inf_f(), 0);
+  bool first = true, queued = false;
+  const uint32_t max_pass = 2u * n + 2u;
+  for (uint32_t pass_no = 0;; ++pass_no) {
+    if (pass_no == max_pass) { raise_flag(P, kFlagWalkLimit); break; }
+    KeyRef m = last; uint32_t m_trig = kNone;                         // next trigger pop strictly after the last one
+    for (uint32_t k = 0; k < n; ++k) {
+      if (!(item.meta(k) & kItemValid)) continue;
+      const unsigned long long hi = item.hi(k);
+      // decided by the main-front part of the key alone (the common case): no further field is read
+      if (!first && hi < last.k.hi) continue;
+      if (m_trig != kNone && hi > m.k.hi) continue;
+      KeyRef fk; fk.k.hi = hi; fk.k.up = item.up(k); fk.k.lvl = item.lvl(k); fk.own = item.own(k);
+      if (pair_id(fk.own) == m_trig) continue;                        // a second face of the current candidate's pop: the same key
+      if (!first && !key_less(P, last, fk)) continue;
+      if (m_trig == kNone || key_less(P, fk, m)) { m = fk; m_trig = pair_id(fk.own); }
+    }
+    if (m_trig == kNone) break;
+    if (queued && !key_less(P, m, key_ref_of(e.key, e.keyd, v))) break;   // v pops before this trigger
+    bool any = false;
+    float ins_d = 0.0f;
+    for (int pass = 0; pass < 2; ++pass)                              // faces of this pop, flagged face first
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t meta = item.meta(k);
+        if (!(meta & kItemValid) || ((meta & kItemFirst) != 0u) != (pass == 0) || item.hi(k) != m.k.hi || pair_id(item.own(k)) != m_trig) continue;
+        CvpCand cd; cd.u3tmp = item.u3tmp(k); cd.cand = item.cand(k); cd.dir = item.dir(k); cd.sel = (int)((meta >> 1) & 3u); cd.kind = (int)((meta >> 3) & 3u);
+        int sel = 0; float dir = 0.0f;
+        if (cvp_apply(cd, e.d, sel, dir)) { win = k; win_sel = sel; e.dir = dir; any = true; ins_d = e.d; }
+      }
+    if (any) { e.key = key_for(P, ins_d, v, m); e.keyd = ins_d; queued = true; }
+    last = m; first = false;
+  }
+  if (!queued) { e.key = key_inf(); e.keyd = inf_f(); win = kNone; }
+  e.t = key_time(e.key);
+  return e;
+}
+
+// The same replay for vertices with at most kFastItems faces (nearly all of them), with the fields the loops look at held in
+// registers: every loop is a fully unrolled, predicated sweep over eight slots, and LDS is only read where an update is applied.
+// Ties in the main-front part of the key between DIFFERENT triggers (cascades) need key_less's walk: the replay then starts over
+// on the general path.  Returns false in that case.
+constexpr uint32_t kFastItems = 8;
+template <class Items>
+MNAV_HD bool eval_cvp_items_fast(const Plan& P, uint32_t v, uint32_t n, const Items& item, Eval& e, uint32_t& win, int& win_sel)
+{
+  unsigned long long hi[kFastItems]; uint32_t trig[kFastItems], meta[kFastItems];
+MNAV_UNROLL
+  for (uint32_t k = 0; k < kFastItems; ++k) {
+    meta[k] = 0u; hi[k] = 0ull; trig[k] = kNone;
+    if (k < n) { meta[k] = item.meta(k); hi[k] = item.hi(k); trig[k] = pair_id(item.own(k)); }
+    if (!(meta[k] & kItemValid)) { meta[k] = 0u; trig[k] = kNone; }
+  }
+  e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
+  win = kNone; win_sel = 0;
+  unsigned long long last_hi = 0ull; uint32_t last_trig = kNone;
+  bool first = true, queued = false;
+  for (uint32_t pass_no = 0; pass_no <= kFastItems; ++pass_no) {       // (every pass consumes one trigger: at most n passes)
+    unsigned long long m_hi = ~0ull; uint32_t m_trig = kNone; uint32_t m_k = 0;
+    bool tie = false;
+MNAV_UNROLL
+    for (uint32_t k = 0; k < kFastItems; ++k) {
+      if (trig[k] == kNone || trig[k] == last_trig) continue;
+      if (!first && hi[k] < last_hi) continue;
+      if (!first && hi[k] == last_hi) { tie = true; continue; }        // another trigger inside the last one's cascade
+      if (m_trig != kNone && trig[k] == m_trig) continue;
+      if (m_trig != kNone && hi[k] == m_hi) { tie = true; continue; }
+      if (hi[k] < m_hi) { m_hi = hi[k]; m_trig = trig[k]; m_k = k; }
+    }
+    if (tie) return false;
+    if (m_trig == kNone) break;
+    KeyRef m; m.k.hi = m_hi; m.k.up = item.up(m_k); m.k.lvl = item.lvl(m_k); m.own = item.own(m_k);
+    if (queued && !key_less(P, m, key_ref_of(e.key, e.keyd, v))) break;   // v pops before this trigger
+    bool any = false;
+    float ins_d = 0.0f;
+MNAV_UNROLL
+    for (int pass = 0; pass < 2; ++pass)
+MNAV_UNROLL
+      for (uint32_t k = 0; k < kFastItems; ++k) {
+        if (trig[k] != m_trig || hi[k] != m_hi || ((meta[k] & kItemFirst) != 0u) != (pass == 0)) continue;
+        CvpCand cd; cd.u3tmp = item.u3tmp(k); cd.cand = item.cand(k); cd.dir = item.dir(k); cd.sel = (int)((meta[k] >> 1) & 3u); cd.kind = (int)((meta[k] >> 3) & 3u);
+        int sel = 0; float dir = 0.0f;
+        if (cvp_apply(cd, e.d, sel, dir)) { win = k; win_sel = sel; e.dir = dir; any = true; ins_d = e.d; }
+      }
+    if (any) { e.key = key_for(P, ins_d, v, m); e.keyd = ins_d; queued = true; }
+    last_hi = m_hi; last_trig = m_trig; first = false;
+  }
+  if (!queued) { e.key = key_inf(); e.keyd = inf_f(); win = kNone; }
+  e.t = key_time(e.key);
+  return true;
+}
+
+template <class Items>
+MNAV_HD Eval eval_cvp_items_any(const Plan& P, uint32_t v, uint32_t n, const Items& item, uint32_t& win, int& win_sel)
+{
+  Eval e;
+  if (n <= kFastItems && eval_cvp_items_fast(P, v, n, item, e, win, win_sel)) return e;
+  return eval_cvp_items(P, v, n, item, win, win_sel);
+}
+
+// the two parts put together on one thread (CPU model; the kernel's fall-back for vertices of very high valence is eval_cvp)
+constexpr uint32_t kCvpItemsMax = 64;
+MNAV_HD Eval eval_cvp_two_part(const Plan& P, const Ctl& c, uint32_t v)
+{
+  const uint32_t beg = P.crn_ptr[v], n = P.crn_ptr[v + 1] - beg;
+  if (n > kCvpItemsMax || P.seed_mask) return eval_cvp(P, c, v);
+  CvpItem items[kCvpItemsMax];
+  for (uint32_t k = 0; k < n; ++k) items[k] = make_cvp_item(P, c, v, P.crn[beg + k]);
+  uint32_t win; int sel;
+  CvpItemArray arr; arr.p = items;
+  Eval e = eval_cvp_items_any(P, v, n, arr, win, sel);
+  if (win != kNone) { const Corner k = P.crn[beg + win]; e.pred = (sel == 1) ? k.v1 : k.v2; e.cut = corner_face(k); }
+  return e;
+}
+
+// ---------------------------------------------------------------------------------------
 // One work-list entry.  `Ops` supplies: push(v) (dedup'd append to the next list), push_dirty(u)
 // (the same, and marks u as "a neighbour moved" for the next step),
 // note_changed(), note_cut(float) (pop time of an in-band vertex that moved), note_min(float), note_eval(), park(v, t) (dedup'd append to the waiting list + note_min(t)).
@@ -808,6 +996,16 @@ MNAV_HD void process_entry_rw(const Plan& P, const Plan& W, const Ctl& c, uint32
   ops.note_eval();
   Eval e;
   if constexpr (cvp) e = eval_cvp(P, c, v); else e = eval_dijkstra(P, c, v);
+#ifdef MNAV_CHECK_TWO_PART                // CPU model: the wide step kernel's two-part evaluation against the specification, on every evaluation
+  if constexpr (cvp) {
+    const Eval w = eval_cvp_two_part(P, c, v);
+    if (f2u(w.d) != f2u(e.d) || f2u(w.t) != f2u(e.t) || w.key != e.key || w.pred != e.pred || f2u(w.dir) != f2u(e.dir) || w.cut != e.cut ||
+        f2u(w.keyd) != f2u(e.keyd)) {
+      fprintf(stderr, "two-part CVP evaluation differs from eval_cvp at vertex %u: d %.9g / %.9g pred %u / %u cut %u / %u\n", v, w.d, e.d, w.pred, e.pred, w.cut, e.cut);
+      abort();
+    }
+  }
+#endif
   const float old_d = P.dist[v];
   bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t));
   if (cvp) changed = changed || (e.key != old_key) || (e.pred != P.pred[v]) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v])) ||

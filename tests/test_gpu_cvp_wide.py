@@ -1,0 +1,73 @@
+"""The wide CVP step kernel (k_step_wide: 64 work-list entries per wave and round; phase A one lane per incident face,
+phase B one lane per vertex over the prepared items; mnav_eval.h make_cvp_item / eval_cvp_items) against the oracle
+(cvp_mesh_planner.cpp:369-556, 651-918) and against the 8-lane replay: batches pick it from 24 plans on, MNAV_CVP_WIDE forces
+either.  Potential and predecessors bit for bit."""
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from tests.common import Case, layered_costs, terrain_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(case, n, seed):
+    m = case.mesh
+    free = np.where(case.costs < 0.5)[0]
+    rng = np.random.default_rng(seed)
+    verts = rng.choice(free, size=n, replace=False)
+    off = np.array([0.02, 0.015, 0.0], np.float32)
+    sps = np.stack([m.xyz[v] + off for v in verts]).astype(np.float32)
+    sfs = np.array([case.om.containing_face(p)[0] for p in sps], np.uint32)
+    t = int(free[((m.xyz[free, :2] - m.xyz[m.vertex_at(0.9, 0.9), :2]) ** 2).sum(1).argmin()])
+    tf, _ = case.om.containing_face(m.xyz[t] + off)
+    return sps, sfs, np.full(n, tf, np.uint32)
+
+
+def test_wide_batch_on_layered_costs_matches_oracle_and_the_8_lane_replay(gpu_ctx_factory, monkeypatch):
+    base = terrain_case(224, 1)
+    costs, _ = layered_costs(base, "avg")                             # Steepness + Inflation: cost-inflated triangles, cascades
+    case = Case(base.mesh, costs, 1.0)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    sps, sfs, tfs = _batch(case, 32, 11)
+    monkeypatch.delenv("MNAV_CVP_WIDE", raising=False)
+    wide = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)         # 32 >= 24 plans: the wide kernel
+    monkeypatch.setenv("MNAV_CVP_WIDE", "0")
+    narrow = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)
+    monkeypatch.delenv("MNAV_CVP_WIDE")
+    assert np.array_equal(wide["codes"], narrow["codes"])
+    assert np.array_equal(wide["dist"].view(np.uint32), narrow["dist"].view(np.uint32)) and np.array_equal(wide["pred"], narrow["pred"])
+    assert wide["stats"]["steps"] > 50
+    for k in (0, 7, 19, 31):
+        ref = case.om.cvp(case.weights, case.costs, case.vn, sps[k], int(sfs[k]), int(tfs[k]))
+        assert wide["codes"][k] == ref.code
+        assert np.array_equal(wide["dist"][k].view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(wide["pred"][k], ref.pred)
+
+
+def test_wide_kernel_on_irregular_valence_and_adversarial_costs(gpu_ctx_factory, monkeypatch):
+    """a valence-40 hub (more faces than a vertex gets item slots for: the serial rule inside the wide kernel) and random
+    per-vertex costs that break the triangle inequality on most faces (non-causal updates, cascades)"""
+    monkeypatch.setenv("MNAV_CVP_WIDE", "1")
+    mesh = meshgen.fan_field(40, 6, 1)
+    case = Case(mesh)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    for sv, tv in ((1 + 5 * 40 + 3, 1 + 5 * 40 + 23), (0, 1 + 5 * 40 + 23)):
+        sf = int(np.where((mesh.faces == sv).any(axis=1))[0][0]); tf = int(np.where((mesh.faces == tv).any(axis=1))[0][0])
+        sp = mesh.xyz[mesh.faces[sf]].mean(axis=0).astype(np.float32)
+        ref = case.om.cvp(case.weights, case.costs, case.vn, sp, sf, tf, goal_dist_offset=float("inf"))
+        out = ctx.plan_cvp(sp, sf, tf, goal_dist_offset=float("inf"))
+        assert out.code == ref.code
+        assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
+    m2 = meshgen.terrain(96, 0.1, 5)
+    rng = np.random.default_rng(2)
+    case2 = Case(m2, rng.uniform(0.0, 0.9, m2.V).astype(np.float32), 3.0)
+    ctx2 = gpu_ctx_factory()
+    case2.upload(ctx2)
+    sps, sfs, tfs = _batch(Case(m2, np.zeros(m2.V, np.float32)), 6, 3)
+    for k in range(6):
+        ref = case2.om.cvp(case2.weights, case2.costs, case2.vn, sps[k], int(sfs[k]), int(tfs[k]), goal_dist_offset=float("inf"))
+        out = ctx2.plan_cvp(sps[k], int(sfs[k]), int(tfs[k]), goal_dist_offset=float("inf"))
+        assert out.code == ref.code
+        assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
