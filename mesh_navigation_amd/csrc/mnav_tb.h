@@ -60,6 +60,7 @@ struct Args {
   const uint2* vaddr; const uint32_t* vert_tile;                      // per vertex: {soff, sl << 8 | local}, tile
   double offset; float band;
   uint32_t gran;                                                     // plans per work item: 16 (quarter-wave solve) or 64 (one tile per wave)
+  uint8_t* pflag; uint32_t nblk;                                     // per (tile, block of 64 plans): 1 = some pend[tile][plan] of the block may be set
 };
 
 __device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_t p)
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_seed(tb::Args A)
     if (e.u == row) A.D[(size_t)e.soff * A.NP + (size_t)p * e.sl + e.off] = 0.0f;
   }
   A.pend[(size_t)t * A.NP + p] = 0u;
+  A.pflag[(size_t)t * A.nblk + (p >> 6)] = 1;
   A.marr[0][p] = 0u;
   atomicAdd(&A.ctl->n_cand[0], 1u);
 }
@@ -181,14 +183,22 @@ __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
       if ((m_prev >> lane) & 1ull) A.bucket[(size_t)t_prev * A.NP + base + (uint32_t)__popcll(m_prev & ((1ull << lane) - 1ull))] = (uint16_t)p;
     }
   };
+  // the matrix is sparse (a plan's pending tiles are the ring around its front): a byte per (tile, 64 plans), set by whoever
+  // writes a pending value and cleared here when nothing of the block is carried over, lets a wave skip the 256-byte rows that
+  // hold nothing -- most of them (the plans of a block have neighbouring wave sources, hence similar rings)
+  MNAV_GLOBAL uint8_t* const pf = as_global(A.pflag) + (pc >> 6);
   for (uint32_t t = t0; t < t1; ++t) {
-    const uint32_t pb = live ? pend[(size_t)t * A.NP] : kTbInfBits;
-    const float pv = u2f(pb);
     bool ready = false;
-    if (pb != kTbInfBits) {
-      if (pv > bnd) pend[(size_t)t * A.NP] = kTbInfBits;
-      else if (pv < thr) { pend[(size_t)t * A.NP] = kTbInfBits; ready = true; }
-      else { ++carried; mn = min(mn, pb); }
+    if (tb::rfl((uint32_t)pf[(size_t)t * A.nblk])) {                  // (wave-uniform: a wave is one block of plans)
+      const uint32_t pb = live ? pend[(size_t)t * A.NP] : kTbInfBits;
+      const float pv = u2f(pb);
+      bool keep = false;
+      if (pb != kTbInfBits) {
+        if (pv > bnd) pend[(size_t)t * A.NP] = kTbInfBits;
+        else if (pv < thr) { pend[(size_t)t * A.NP] = kTbInfBits; ready = true; }
+        else { ++carried; mn = min(mn, pb); keep = true; }
+      }
+      if (!__any(keep) && lane == 0 && live) pf[(size_t)t * A.nblk] = 0;   // (lane 0 is live in every wave that holds plans)
     }
     const unsigned long long m = __ballot(ready);
     place();
@@ -452,6 +462,7 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
         u32x4 G = { 0u, 0u, 0u, 0u };
         uint32_t cand = kTbInfBits, best = kTbInfBits;
         MNAV_GLOBAL uint32_t* const pend_p = as_global(A.pend) + p;
+        MNAV_GLOBAL uint8_t* const pflag_p = as_global(A.pflag) + (p >> 6);
         MNAV_GLOBAL uint32_t* const pm = as_global(A.marr[par ^ 1]) + p;
         // stage 1: looked at, stage 2: atomic in flight (t2 uniform, the rest per lane)
         uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, best_2 = kTbInfBits, old_2 = 0;
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
           // load is an upper bound of the true value: if it already is <= ours the wake-up changes nothing
           did_2 = want_1 && best_1 < cur_1;
           best_2 = best_1;
-          if (did_2) old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1);
+          if (did_2) { old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1); pflag_p[(size_t)t2_1 * A.nblk] = 1; }
           // stage 1: look
           want_1 = want_new; t2_1 = t2_new; best_1 = best_new;
           if (want_new) cur_1 = pend_p[(size_t)t2_new * NP];
@@ -761,6 +772,7 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
         u32x4 G = { 0u, 0u, 0u, 0u };
         uint32_t cand = kTbInfBits, best = kTbInfBits;
         MNAV_GLOBAL uint32_t* const pend_p = as_global(A.pend) + p;
+        MNAV_GLOBAL uint8_t* const pflag_p = as_global(A.pflag) + (p >> 6);
         MNAV_GLOBAL uint32_t* const pm = as_global(A.marr[par ^ 1]) + p;
         uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, best_2 = kTbInfBits, old_2 = 0;
         bool want_1 = false, did_2 = false;
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
           n_first += first ? 1u : 0u;
           did_2 = want_1 && best_1 < cur_1;
           best_2 = best_1;
-          if (did_2) old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1);
+          if (did_2) { old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1); pflag_p[(size_t)t2_1 * A.nblk] = 1; }
           want_1 = want_new; t2_1 = t2_new; best_1 = best_new;
           if (want_new) cur_1 = pend_p[(size_t)t2_new * NP];
         };
@@ -954,7 +966,7 @@ struct TbState {
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // batch state, sized for cap_np plans
   uint32_t cap_np = 0;
-  float* D = nullptr; uint32_t* pend = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;
+  float* D = nullptr; uint32_t* pend = nullptr; uint8_t* pflag = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;
   tb::Ctl* ctl = nullptr; tb::Ctl* h_ctl = nullptr;
   uint32_t* marr[2] = { nullptr, nullptr };
   float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;

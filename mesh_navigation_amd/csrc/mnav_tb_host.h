@@ -5,14 +5,14 @@
 void tb_free_batch(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
-  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
+  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
   (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
   (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target);
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
   for (int k = 0; k < 2; ++k) { if (S.graph[k]) (void)hipGraphExecDestroy(S.graph[k]); S.graph[k] = nullptr; }
   if (S.fill_stream) (void)hipStreamSynchronize(S.fill_stream);
   (void)hipFree(S.D2); S.D2 = nullptr; S.d2_clean = false;
-  S.D = nullptr; S.pend = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
+  S.D = nullptr; S.pend = nullptr; S.pflag = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
   S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
   S.cap_np = 0;
   S.count_pending = false; ctx->tb_args_valid = false;               // the last batch's arguments point into freed memory now
@@ -87,6 +87,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
     if (S.D2 && !S.fill_stream) { HIPCHK(hipStreamCreateWithFlags(&S.fill_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&S.fill_done, hipEventDisableTiming)); }
   }
   HIPCHK(hipMalloc((void**)&S.pend, 4 * pairs + 64));
+  HIPCHK(hipMalloc((void**)&S.pflag, nt * (((size_t)np + 63) / 64) + 64));
   HIPCHK(hipMalloc((void**)&S.bucket, 2 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.bcnt, 4 * nt));
   HIPCHK(hipMalloc((void**)&S.items, 8 * (nt + pairs / 16 + 64)));
@@ -195,7 +196,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
   tb::Args A{};
-  A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.NP = n; A.ntiles = S.ntiles;
+  A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.pflag = S.pflag; A.nblk = (n + 63u) / 64u; A.NP = n; A.ntiles = S.ntiles;
   A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl;
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
@@ -218,6 +219,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   S.d2_clean = false;
   if (!prefilled && tb_fill(ctx, S.D, 4 * (size_t)S.S * n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.pend, 4 * (size_t)S.ntiles * n, kTbInfBits)) return -1;
+  HIPCHK(hipMemsetAsync(S.pflag, 0, (size_t)(S.ntiles ? S.ntiles : 1) * ((n + 63u) / 64u), ctx->stream));
   if (tb_fill(ctx, S.marr[0], 4 * (size_t)n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.marr[1], 4 * (size_t)n, kTbInfBits)) return -1;
   HIPCHK(hipMemsetAsync(S.ctl, 0, sizeof(tb::Ctl), ctx->stream));
