@@ -204,11 +204,16 @@ def main() -> None:
         # whole run, so `achieved` prices the scheduling kernels too.  HBM traffic per run from the PMC passes committed
         # under profiles/ (tools/prof_pmc.sh: FETCH_SIZE / WRITE_SIZE summed over the engine's kernels of one batch) -- only
         # quoted when it was measured on this very workload.
+        # `traffic` is null in this line: the PMC counters cannot be read inside a timed run (rocprofv3 collects them in its own
+        # passes).  The figure of those passes over this very command is quoted next to it, with its source, when the
+        # committed profile was taken on the same workload and kernel.
         traffic = None
+        traffic_profiled = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-            if pm.get("kernel") == "k_tb_solve" and B == pm.get("batch") and N == pm.get("grid"):
-                traffic = pm["traffic_bytes_per_launch"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            if pm.get("kernel") == "k_tb_solve_q" and B == pm.get("batch") and N == pm.get("grid"):
+                traffic_profiled = {"bytes_per_launch": pm["traffic_bytes_per_launch"], "bytes_per_launch_high": pm.get("traffic_bytes_per_launch_high"),
+                                    "source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"}
         except (OSError, ValueError, KeyError):
             pass
         per_launch_bytes = algo / max(launches, 1)
@@ -237,8 +242,8 @@ def main() -> None:
             "ms_per_plan_in_batch": ms_step / B,
             "cvp_planner_same_mesh": cvp,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_tb_solve (tile-batch engine run: plan/scan/items/solve iterations)" if launches <= args.steps else "k_tile_round",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profiled": traffic_profiled,
+                         "kernel": "k_tb_solve_q (tile-batch engine run: plan/scan/items/solve iterations)" if launches <= args.steps else "k_tile_round",
                          "launches_per_step": launches / args.steps, "vector_map_ms_per_step": vec_ms / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
                          "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,
@@ -337,7 +342,7 @@ def leg_c5(ctx, mesh, edge_w, costs, robot, args):
     st = r["stats"]
     out = {"workload": "C5: 64 concurrent goals, common robot vertex, 1M-vertex C2 mesh, one batch on one GPU",
            "plans_per_s": 64 / med, "ms_per_batch": med * 1e3, "ms_per_batch_p95": float(np.percentile(ts, 95)) * 1e3,
-           "roofline": roofline_of(st, "k_tile_round" if st["launches"] > 1 else "k_plan_persistent")}
+           "roofline": roofline_of(st, "k_tile_round" if st["launches"] > 1 else "k_tb_solve_q (tile-batch engine run)")}
     if not args.no_cpu:
         from oracle import oracle as O
         om = O.OracleMesh(mesh.xyz, mesh.faces)
@@ -523,7 +528,7 @@ def leg_c4(local_rank, args):
                "vertices": mesh.V, "edges": mesh.E, "mesh_generation_s": t_gen, "upload_and_tiling_s": t_up,
                "ms_per_makeplan_single": float(np.median(lat)), "ms_per_makeplan_single_p95": float(np.percentile(lat, 95)),
                "batch": B, "plans_per_s_batch": B / tb, "ms_per_batch": tb * 1e3,
-               "roofline": roofline_of(sb, "k_tb_solve (tile-batch engine run)" if sb["launches"] <= 1 else "k_tile_round"),
+               "roofline": roofline_of(sb, "k_tb_solve_q (tile-batch engine run)" if sb["launches"] <= 1 else "k_tile_round"),
                "roofline_single_plan": roofline_of(st, "k_tile_round")}
         if not args.no_cpu:
             from oracle import oracle as O

@@ -3756,12 +3756,13 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     const uint32_t m0 = (uint32_t)in.size();
     // auto: one wave per (tile, 64 plans) for large batches, one workgroup per plan for medium ones, tile rounds otherwise
     if (engine == 3) {
-      // The tile-batch engine fills a wave with the plans that have work on ONE tile in ONE iteration: about
-      // 0.64 * plans / sqrt(tiles) of them by this estimate (C2, 5120 plans / 9260 tiles: 34; the measured fill is a little
-      // higher, 41).  Below ~7 estimated lanes per wave the per-plan engine is faster: on the 10M-vertex mesh 1536 plans
-      // (estimate 3.2) run at 504 against 831 plans/s, 4096 plans (estimate 8.6, measured 15.5) at 1132 against 831.
+      // The tile-batch engine advances all plans tile by tile, 16 plans per quarter of a wave (k_tb_solve_q).  Its floor is one
+      // stream pass per iteration (~190 iterations x ~180 us on the 1M mesh, ~600 x 300 us at 10M), whatever the batch; above
+      // that it beats the per-plan engines at every size measured (round 4, plans/s, tiled / persistent / tile-batch --
+      // 1M: 64 plans 1084 / 496 / 1359, 256: 1879 / 1929 / 4392, 1024: 2223 / 7107 / 12871;
+      // 10M: 64 plans 196 / 41 / 189, 256: 252 / 163 / 409, 1024: 254 / 594 / 924).
       const double tiles = std::max(1.0, (double)V / (0.9 * ctx->tb.T));
-      const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && 0.64 * m0 >= ctx->tb.min_lanes * std::sqrt(tiles);
+      const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && (double)m0 >= tiles / 1000.0;
       engine = fills ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
     }
     if (engine == 5 && m0 > 65535u) engine = 2;

@@ -2,10 +2,11 @@
 // batch) advanced together, tile-major and plan-vectorised.  Included by mnav.hip (device kernels + host driver).
 //
 // Why: with one workgroup per plan (k_plan_persistent) every tile activation re-stages the tile's graph and runs a
-// latency-bound chain of LDS queue sweeps for ONE plan.  Here a 64-lane wave takes one tile and up to 64 plans that
-// have work on it, one plan per lane.  All lanes execute the same edge sequence, so the graph is SCALAR data (s_load
-// from the constant address space, weights as SGPR operands), the distances of the tile's vertices live in LDS as
-// [vertex][lane] (a lane only ever touches its own column: no bank conflicts, no barriers, no atomics), and the
+// latency-bound chain of LDS queue sweeps for ONE plan.  Here the lanes of a wave are PLANS that have work on the same tile:
+// 16 plans per quarter of a wave, the four quarters on the same tile or on four different ones (k_tb_solve_q).  The lanes of a
+// quarter execute the same edge sequence, so the tile's graph is uniform data per quarter: flat record streams, parked chunk
+// by chunk in a per-quarter LDS staging area and read back with broadcast ds_read_b128; the distances of the tile's vertices
+// live in LDS as [vertex][lane] (a lane only ever touches its own column: no bank conflicts, no barriers, no atomics), and the
 // relaxation is a plain Gauss-Seidel sweep over the tile's vertices in one of four diagonal orders until a sweep
 // changes nothing in any lane -- the tile-local fixed point of  d[v] = min_u fl(d[u] + w(u,v)),  which is the
 // reference's float32 relaxation (dijkstra :331) and has a unique fixed point, so any schedule reproduces it bit
@@ -14,8 +15,8 @@
 // Schedule (level-synchronous over all plans, a few launches per iteration, replayed from a hipGraph):
 //   k_tb_plan    per plan: band threshold thr = (smallest pending wake-up) + band, bound = dist[target] + offset
 //   k_tb_scan    every pending value pend[tile][plan]: < thr -> the tile's bucket; > bound -> dropped; else carried (counted)
-//   k_tb_items   per tile: the bucket is cut into work items of <= 64 plans
-//   k_tb_solve   per item: load the plans' slices, fold the ghost values in, sweep, write back what changed, wake the
+//   k_tb_items   per tile: the bucket is cut into work items of <= 16 plans
+//   k_tb_solve_q per item: load the plans' slices, fold the ghost values in, sweep, write back what changed, wake the
 //                neighbouring tiles whose vertices were undercut, export changed boundary values to their ghost slots
 // Data written during an iteration is consumed in the next one (kernel boundary), so there is no intra-kernel
 // producer/consumer protocol; wake-ups use atomicMin on the pair's wake-up value, the first waker counts the pair.
@@ -59,7 +60,6 @@ struct Args {
   const uint32_t* seed; const uint32_t* target;                        // per plan: wave source / robot vertex
   const uint2* vaddr; const uint32_t* vert_tile;                      // per vertex: {soff, sl << 8 | local}, tile
   double offset; float band;
-  uint32_t gran;                                                     // plans per work item: 16 (quarter-wave solve) or 64 (one tile per wave)
   uint8_t* pflag; uint32_t nblk;                                     // per (tile, block of 64 plans): 1 = some pend[tile][plan] of the block may be set
 };
 
@@ -73,27 +73,6 @@ __device__ __forceinline__ void ldsw(uint32_t off, uint32_t v) { *(lds_u32_t)(ui
 typedef __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 __device__ __forceinline__ u32x4 ldsr4(uint32_t off) { return *(lds_u32x4_t)(uintptr_t)off; }   // uniform address: broadcast
 
-// Stream reader: chunk c of a stream lives in staging buffer (c & 1); the chunk after next is in flight from memory.
-struct Stream {
-  MNAV_GLOBAL const uint32_t* st; uint32_t stage, lane4s, c1; uint32_t c;
-  // stage = LDS byte address of the two 256-byte staging buffers, lane4s = stage + 4 * lane
-  __device__ __forceinline__ void begin(MNAV_GLOBAL const uint32_t* s, uint32_t stage_, uint32_t lane)
-  {
-    st = s; stage = stage_; lane4s = stage_ + 4u * lane; c = 0;
-    ldsw(lane4s, st[lane]);                                          // chunk 0 -> buffer 0
-    c1 = st[kTbChunk + lane];                                        // chunk 1 in flight
-  }
-  // makes chunk c readable at the returned LDS address and moves on (call once per chunk, in order)
-  __device__ __forceinline__ uint32_t next(uint32_t lane)
-  {
-    const uint32_t nxt = c1;
-    c1 = st[(size_t)(c + 2) * kTbChunk + lane];
-    ldsw(lane4s + (((c + 1) & 1u) << 8), nxt);                       // LDS executes in order: the buffer's last readers are done
-    const uint32_t at = stage + ((c & 1u) << 8);
-    ++c;
-    return at;
-  }
-};
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
 }  // namespace tb
@@ -208,19 +187,20 @@ __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
   place();
   if (live && mn != kTbInfBits) {
     MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
-    if (mn < *pm) atomicMin((uint32_t*)pm, mn);                        // plain look first (see k_tb_solve)
+    if (mn < *pm) atomicMin((uint32_t*)pm, mn);                        // plain look first (see k_tb_solve_q)
   }
   carried = wave_sum(carried);
   if (lane == 0 && carried) atomicAdd(&A.ctl->n_cand[par ^ 1], carried);
 }
 
-// per tile: cut the bucket into items of <= `gran` plans (one workgroup, a few dozen tiles per thread)
+constexpr uint32_t kTbItemPlans = 16;     // plans per work item = lanes per quarter of a wave (k_tb_solve_q)
+// per tile: cut the bucket into items of <= kTbItemPlans plans (one workgroup, a few dozen tiles per thread)
 __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
 {
   __shared__ uint32_t s_base;
   __shared__ uint32_t s_wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t gran = A.gran;
+  constexpr uint32_t gran = kTbItemPlans;
   if (tid == 0) s_base = 0u;
   __syncthreads();
   for (uint32_t t0 = 0; t0 < A.ntiles; t0 += 1024) {
@@ -246,27 +226,9 @@ __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
   if (tid == 0) A.ctl->n_items = s_base;
 }
 
-// ---------------------------------------------------------------------------------------------
-// The solve: one wave per work item (tile, <= 64 plans).
-// ---------------------------------------------------------------------------------------------
-// One Gauss-Seidel sweep: every block relaxes its target row from up to 7 source rows (dijkstra :331), in stream order.
-// No branch in the loop body: the target row is rewritten unconditionally (old bits when nothing improved).
-// MNAV_TB_PIPELINE (tried, off): the LDS reads of block j+1 issued before block j's result is written, so that one
-// block's LDS latency hides behind the other's arithmetic -- legal (any relaxation order reaches the same fixed point;
-// the builder never puts the same target into adjacent blocks), but a block that reads its predecessor's target then
-// sees the value of the previous sweep: +24 % sweeps, 303 vs 266 ms per 5120-plan batch on C2.
+// One block of a Gauss-Seidel sweep: the target row is relaxed from up to 7 source rows (dijkstra :331).  No branch: the row is
+// rewritten unconditionally (old bits when nothing improved).
 struct TbBlk { uint32_t ya, raw, v[7]; u32x4 w0, w1; };
-__device__ __forceinline__ TbBlk tb_issue(uint32_t at, uint32_t lane4)
-{
-  TbBlk B;
-  const u32x4 o0 = tb::ldsr4(at), o1 = tb::ldsr4(at + 16);
-  B.w0 = tb::ldsr4(at + 32); B.w1 = tb::ldsr4(at + 48);
-  B.ya = o0.x + lane4;
-  B.raw = tb::ldsr(B.ya);
-  B.v[0] = tb::ldsr(o0.y + lane4); B.v[1] = tb::ldsr(o0.z + lane4); B.v[2] = tb::ldsr(o0.w + lane4);
-  B.v[3] = tb::ldsr(o1.x + lane4); B.v[4] = tb::ldsr(o1.y + lane4); B.v[5] = tb::ldsr(o1.z + lane4); B.v[6] = tb::ldsr(o1.w + lane4);
-  return B;
-}
 __device__ __forceinline__ bool tb_retire(const TbBlk& B)
 {
   const uint32_t acc0 = B.raw & 0x7fffffffu;
@@ -281,283 +243,21 @@ __device__ __forceinline__ bool tb_retire(const TbBlk& B)
   return ch;
 }
 
-template <int T>
-__device__ __forceinline__ unsigned long long tb_sweep(MNAV_GLOBAL const uint32_t* st, uint32_t nch, uint32_t stage, uint32_t lane, uint32_t lane4)
-{
-  unsigned long long any = 0ull;
-  tb::Stream S; S.begin(st, stage, lane);
-  for (uint32_t c = 0; c < nch; ++c) {
-    const uint32_t at = S.next(lane);
-#ifndef MNAV_TB_PIPELINE
-    // all 16 descriptor reads of the chunk first: one LDS round trip per chunk instead of one per block
-    u32x4 d[kTbBlocksPerChunk][4];
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(at + 64 * j + 16 * q);
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-      TbBlk B;
-      B.w0 = d[j][2]; B.w1 = d[j][3];
-      B.ya = d[j][0].x + lane4;
-      B.raw = tb::ldsr(B.ya);
-      B.v[0] = tb::ldsr(d[j][0].y + lane4); B.v[1] = tb::ldsr(d[j][0].z + lane4); B.v[2] = tb::ldsr(d[j][0].w + lane4);
-      B.v[3] = tb::ldsr(d[j][1].x + lane4); B.v[4] = tb::ldsr(d[j][1].y + lane4); B.v[5] = tb::ldsr(d[j][1].z + lane4);
-      B.v[6] = tb::ldsr(d[j][1].w + lane4);
-      any |= __ballot(tb_retire(B));
-    }
-#else
-    TbBlk A = tb_issue(at, lane4);
-#pragma unroll
-    for (int j = 1; j < (int)kTbBlocksPerChunk; ++j) {
-      const TbBlk B = tb_issue(at + 64 * j, lane4);
-      any |= __ballot(tb_retire(A));
-      A = B;
-    }
-    any |= __ballot(tb_retire(A));
-#endif
-  }
-  return any;
-}
-
-#ifdef MNAV_TB_TIMING                      // debugging aid: cycles per phase of k_tb_solve, summed over all waves
+#ifdef MNAV_TB_TIMING                      // debugging aid: cycles per phase of k_tb_solve_q, summed over all waves
 __device__ unsigned long long g_tb_timing[8];
 #define TB_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tt[k] += now_ - t_last; t_last = now_; } while (0)
 #else
 #define TB_STAMP(k) do { } while (0)
 #endif
 
-template <int T>
-__global__ __launch_bounds__(64) void k_tb_solve(tb::Args A, int par)
-{
-#ifdef MNAV_TB_TIMING
-  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
-#endif
-  __shared__ __attribute__((aligned(16))) uint32_t lds[T * 64 + 2 * kTbChunk ];   // [row][lane] + two stream staging buffers
-  const int lane = threadIdx.x;
-  const uint32_t lane4 = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * lane;
-  const uint32_t stage = (uint32_t)(uintptr_t)(tb::lds_u32_t)lds + 4u * (T * 64);
-  const uint32_t NP = A.NP;
-  const tb::cblk8_t tiles = (tb::cblk8_t)(uintptr_t)A.tiles;
-  const uint32_t n_items = A.ctl->n_items;
-  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0;
-  for (;;) {
-    uint32_t it = 0;
-    if (lane == 0) it = atomicAdd(&A.ctl->next_item, 1u);
-    it = tb::rfl(it);
-    if (it >= n_items) break;
-    const uint2 item = A.items[it];
-    const uint32_t t = tb::rfl(item.x), start = tb::rfl(item.y) & 0xFFFFu, count = tb::rfl(item.y) >> 16;
-    const tb::u32x16 Wv = tiles[t];
-    TbTile W;
-    W.soff = Wv[tb::kTwSoff]; W.sl = Wv[tb::kTwSl]; W.nv = Wv[tb::kTwNv]; W.nh = Wv[tb::kTwNh];
-    W.sweep_off = Wv[tb::kTwSweepOff]; W.sweep_chunks = Wv[tb::kTwSweepChunks]; W.pre_off = Wv[tb::kTwPreOff]; W.pre_chunks = Wv[tb::kTwPreChunks];
-    W.post_off = Wv[tb::kTwPostOff]; W.post_chunks = Wv[tb::kTwPostChunks]; W.exp_off = Wv[tb::kTwExpOff]; W.exp_n = Wv[tb::kTwExpN];
-    ++my_items; my_acts += count;
-    TB_STAMP(0);
-    {
-      // Every lane runs the whole item: the stream chunks are held one dword per lane, so all 64 lanes must execute the
-      // loads.  Lanes beyond `count` shadow the last plan of the item and store nothing.
-      const bool active = (uint32_t)lane < count;
-      const uint32_t p = A.bucket[(size_t)t * NP + start + min((uint32_t)lane, count - 1u)];
-      MNAV_GLOBAL float* sl = as_global(A.D) + ((size_t)W.soff * NP + (size_t)p * W.sl);
-      // ---- load the owned slots: LDS[row][lane]
-      {
-        MNAV_GLOBAL const u32x4* s4 = (MNAV_GLOBAL const u32x4*)sl;
-        u32x4 v[T / 4];
-#pragma unroll
-        for (int c = 0; c < T / 4; ++c) v[c] = s4[c];
-#pragma unroll
-        for (int c = 0; c < T / 4; ++c) {
-          tb::ldsw(lane4 + (4 * c + 0) * 256, v[c].x); tb::ldsw(lane4 + (4 * c + 1) * 256, v[c].y);
-          tb::ldsw(lane4 + (4 * c + 2) * 256, v[c].z); tb::ldsw(lane4 + (4 * c + 3) * 256, v[c].w);
-        }
-      }
-      MNAV_GLOBAL const u32x4* g4p = (MNAV_GLOBAL const u32x4*)(sl + T);
-      uint32_t first_order = 0;                                       // sweep order of the first sweep (wave-uniform)
-      TB_STAMP(1);
-      // ---- ghosts -> owned (the ghosts are constant during the activation)
-      if (W.pre_chunks) {
-        tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.pre_off * kTbChunk, stage, (uint32_t)lane);
-        u32x4 G = { 0u, 0u, 0u, 0u };
-        float gmin = inf_f();                                         // smallest ghost value that lowered one of this lane's vertices ...
-        uint32_t gord = 0;                                            // ... and the sweep order that runs with a wave entering there
-        for (uint32_t c = 0; c < W.pre_chunks; ++c) {
-          const uint32_t cur_at = S.next((uint32_t)lane);             // chunk c readable, chunk c + 1 staged behind it
-          const u32x4 hd0 = tb::ldsr4(cur_at), q3 = tb::ldsr4(cur_at + 48);   // block 0: header + chunk fields (d12 group, d13 next group)
-          if (c == 0) G = g4p[q3.x];
-          const u32x4 Gn = g4p[q3.y];                                 // the next chunk's ghost values (group 0 after the last one)
-#pragma unroll
-          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-            const uint32_t b = cur_at + 64 * j;
-            const u32x4 h = (j == 0) ? hd0 : tb::ldsr4(b);
-            const uint32_t n = (h.x >> 8) & 7u;
-            if (n) {
-              const uint32_t jj = h.x & 3u;
-              const float g = u2f(jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w);
-              const u32x4 o1 = tb::ldsr4(b + 16), w2 = tb::ldsr4(b + 32);   // d4..d7, d8..d11
-              const uint32_t offs[5] = { h.y, h.z, h.w, o1.x, o1.y };
-              const uint32_t ws[5] = { o1.z, o1.w, w2.x, w2.y, w2.z };
-              bool lowered = false;
-#pragma unroll
-              for (int k = 0; k < (int)kTbGhostEdges; ++k) {
-                if ((uint32_t)k < n) {
-                  const uint32_t a = offs[k] + lane4;
-                  const uint32_t nd = f2u(g + u2f(ws[k]));
-                  const uint32_t raw = tb::ldsr(a);
-                  const bool low = nd < (raw & 0x7fffffffu);
-                  lowered |= low;
-                  tb::ldsw(a, low ? (nd | kTbDirty) : raw);
-                }
-              }
-              if (lowered && g < gmin) { gmin = g; gord = (h.x >> kTbOrderShift) & 3u; }
-            }
-          }
-          G = Gn;
-        }
-        // the order most lanes ask for (lanes whose ghosts lowered nothing do not vote; no votes: order 0)
-        const bool votes = active && gmin < inf_f();
-        uint32_t bestc = 0;
-#pragma unroll
-        for (uint32_t o = 0; o < 4; ++o) {
-          const uint32_t cn = (uint32_t)__popcll(__ballot(votes && gord == o));
-          if (cn > bestc) { bestc = cn; first_order = o; }
-        }
-      }
-      TB_STAMP(2);
-      // ---- Gauss-Seidel sweeps to the tile-local fixed point
-      uint32_t sweep = 0;
-      for (;;) {
-        MNAV_GLOBAL const uint32_t* st = as_global(A.stream) + ((size_t)W.sweep_off + (size_t)((sweep + first_order) & 3u) * W.sweep_chunks) * kTbChunk;
-        const unsigned long long any = tb_sweep<T>(st, W.sweep_chunks, stage, (uint32_t)lane, lane4);
-        ++sweep;
-        if (any == 0ull) break;
-        if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
-      }
-      my_sweeps += sweep;
-      TB_STAMP(3);
-      // ---- write back the 16-byte chunks that hold a lowered value
-      {
-        MNAV_GLOBAL u32x4* s4 = (MNAV_GLOBAL u32x4*)sl;
-#pragma unroll
-        for (int c = 0; c < T / 4; ++c) {
-          u32x4 x;
-          x.x = tb::ldsr(lane4 + (4 * c + 0) * 256); x.y = tb::ldsr(lane4 + (4 * c + 1) * 256);
-          x.z = tb::ldsr(lane4 + (4 * c + 2) * 256); x.w = tb::ldsr(lane4 + (4 * c + 3) * 256);
-          if (active && ((x.x | x.y | x.z | x.w) & kTbDirty)) {
-            x.x &= 0x7fffffffu; x.y &= 0x7fffffffu; x.z &= 0x7fffffffu; x.w &= 0x7fffffffu;
-            s4[c] = x;
-          }
-        }
-      }
-      TB_STAMP(4);
-      // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex.
-      // A wake-up is three dependent memory operations (look at the pending value, atomicMin it, learn from the old value
-      // whether this is the pair's first wake-up) and the list append a fourth: done one after the other per neighbour tile
-      // they were a third of an item's time.  They are pipelined over the neighbour tiles instead -- at tile end k the look
-      // for tile k is issued, the atomic for tile k-1 (whose look has arrived), and the old value of tile k-2 is consumed --
-      // and the first wake-ups of the whole item (pairs that were not pending before) are counted with ONE atomic at the end.
-      if (W.post_chunks) {
-        tb::Stream S; S.begin(as_global(A.stream) + (size_t)W.post_off * kTbChunk, stage, (uint32_t)lane);
-        u32x4 G = { 0u, 0u, 0u, 0u };
-        uint32_t cand = kTbInfBits, best = kTbInfBits;
-        MNAV_GLOBAL uint32_t* const pend_p = as_global(A.pend) + p;
-        MNAV_GLOBAL uint8_t* const pflag_p = as_global(A.pflag) + (p >> 6);
-        MNAV_GLOBAL uint32_t* const pm = as_global(A.marr[par ^ 1]) + p;
-        // stage 1: looked at, stage 2: atomic in flight (t2 uniform, the rest per lane)
-        uint32_t t2_1 = 0, best_1 = kTbInfBits, cur_1 = 0, best_2 = kTbInfBits, old_2 = 0;
-        bool want_1 = false, did_2 = false;
-        uint32_t n_first = 0;                                           // first wake-ups of this item (pairs that were not pending)
-        auto advance = [&](uint32_t t2_new, uint32_t best_new, bool want_new) {
-          // stage 3: the old value of the atomic issued one tile end ago
-          bool first = false;
-          if (did_2) {
-            first = old_2 == kTbInfBits;
-            if (best_2 < old_2) atomicMin((uint32_t*)pm, best_2);       // the plan's smallest pending value of the next iteration
-            ++my_wakes;
-          }
-          n_first += first ? 1u : 0u;
-          // stage 2: the look has arrived -- within this launch a wake-up value only ever decreases, so a (possibly stale) plain
-          // load is an upper bound of the true value: if it already is <= ours the wake-up changes nothing
-          did_2 = want_1 && best_1 < cur_1;
-          best_2 = best_1;
-          if (did_2) { old_2 = atomicMin((uint32_t*)(pend_p + (size_t)t2_1 * NP), best_1); pflag_p[(size_t)t2_1 * A.nblk] = 1; }
-          // stage 1: look
-          want_1 = want_new; t2_1 = t2_new; best_1 = best_new;
-          if (want_new) cur_1 = pend_p[(size_t)t2_new * NP];
-        };
-        for (uint32_t c = 0; c < W.post_chunks; ++c) {
-          const uint32_t cur_at = S.next((uint32_t)lane);
-          const u32x4 hd0 = tb::ldsr4(cur_at), q3 = tb::ldsr4(cur_at + 48);
-          if (c == 0) G = g4p[q3.x];
-          const u32x4 Gn = g4p[q3.y];
-#pragma unroll
-          for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-            const uint32_t b = cur_at + 64 * j;
-            const u32x4 h = (j == 0) ? hd0 : tb::ldsr4(b);
-            const uint32_t hd = h.x, n = (hd >> 8) & 7u;
-            if (n) {
-              const u32x4 o1 = tb::ldsr4(b + 16), w2 = tb::ldsr4(b + 32);
-              const uint32_t offs[5] = { h.y, h.z, h.w, o1.x, o1.y };
-              const uint32_t ws[5] = { o1.z, o1.w, w2.x, w2.y, w2.z };
-#pragma unroll
-              for (int k = 0; k < (int)kTbGhostEdges; ++k)
-                if ((uint32_t)k < n) cand = min(cand, f2u(fabsf(u2f(tb::ldsr(offs[k] + lane4))) + u2f(ws[k])));
-              if (hd & kTbGhostEnd) {
-                const uint32_t jj = hd & 3u;
-                const uint32_t g = jj == 0 ? G.x : jj == 1 ? G.y : jj == 2 ? G.z : G.w;
-                if (cand < g) best = min(best, cand);
-                cand = kTbInfBits;
-              }
-              if (hd & kTbTileEnd) {
-                advance(tb::rfl(w2.w), best, active && best != kTbInfBits);   // d11: owner tile (uniform)
-                best = kTbInfBits;
-              }
-            }
-          }
-          G = Gn;
-        }
-        advance(0u, kTbInfBits, false);                                // drain the two stages in flight
-        advance(0u, kTbInfBits, false);
-        n_first = wave_sum(n_first);                                   // the pending-pair count of the next iteration: one atomic per item
-        if (lane == 0 && n_first) atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
-      }
-      TB_STAMP(5);
-      // ---- export the lowered boundary values to the ghost slots that mirror them
-      {
-        const tb::cblk8_t X4 = (tb::cblk8_t)(uintptr_t)(A.exps + W.exp_off);
-        for (uint32_t k4 = 0; k4 * 4u < W.exp_n; ++k4) {
-          const tb::u32x16 X = X4[k4];                                  // 4 records {u, soff, sl, off}
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (k4 * 4u + q < W.exp_n) {
-              const uint32_t v = tb::ldsr(X[4 * q] + lane4);
-              if (active && (v & kTbDirty)) as_global(A.D)[(size_t)X[4 * q + 1] * NP + ((size_t)p * X[4 * q + 2] + X[4 * q + 3])] = u2f(v & 0x7fffffffu);
-            }
-          }
-        }
-      }
-      TB_STAMP(6);
-    }
-  }
-#ifdef MNAV_TB_TIMING
-  if (lane == 0) for (int k = 0; k < 8; ++k) if (tt[k]) atomicAdd(&g_tb_timing[k], tt[k]);
-#endif
-  // statistics: one set of atomics per wave
-  my_wakes = wave_sum(my_wakes);
-  if (lane == 0 && my_items) {
-    atomicAdd(&A.ctl->items, (unsigned long long)my_items); atomicAdd(&A.ctl->acts, (unsigned long long)my_acts);
-    atomicAdd(&A.ctl->sweeps, (unsigned long long)my_sweeps); atomicAdd(&A.ctl->wakes, (unsigned long long)my_wakes);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // The quarter-wave solve: one wave per FOUR work items of <= 16 plans, one item per 16-lane quarter.
 // ---------------------------------------------------------------------------------------------
-// k_tb_solve above fills a wave with the plans that have work on ONE tile in one iteration: 42-50 of 64 lanes on the 1M
-// mesh, 15 of 64 on the 10M mesh, where the batch cannot grow any further (the blocked distances fill the HBM).  Here the
-// buckets are cut into items of <= 16 plans and a wave takes four of them -- of the same tile or of four different
-// ones.  Everything that was wave-uniform becomes uniform per QUARTER: the tile header sits in VGPRs, each quarter
+// One wave per (tile, <= 64 plans) -- round 3's solve -- fills a wave with the plans that have work on ONE tile in one iteration:
+// 42-50 of 64 lanes on the 1M mesh, 15 of 64 on the 10M mesh, where the batch cannot grow any further (the blocked distances
+// fill the HBM), 1-2 in small batches.  Here the buckets are cut into items of <= 16 plans and a wave takes four of them -- of
+// the same tile or of four different ones (measured against the old kernel: C4 batch 3555 -> 2184 ms, C2 234 -> 220 ms once the
+// export records were read as a stream too, 2048 plans 136 -> 110 ms; the old kernel is gone).  Everything that was wave-uniform becomes uniform per QUARTER: the tile header sits in VGPRs, each quarter
 // parks its own tile's stream chunk in its own 256-byte staging area (lane l loads the 16 bytes (l & 15) of its
 // quarter's chunk: still one vector load per lane and chunk) and reads the descriptors back with ds_read_b128 at a
 // per-quarter address (the 16 lanes of a quarter read one address: a broadcast per 8-lane pass, like the uniform read).
@@ -765,8 +465,11 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
         }
       }
       TB_STAMP(4);
-      // ---- owned -> ghosts: wake-ups, pipelined over the neighbour tiles as in k_tb_solve (every stage is per lane here:
-      // the neighbour tile differs between the quarters)
+      // ---- owned -> ghosts: a neighbour tile is woken when a candidate undercuts what we know of its vertex.  A wake-up is
+      // three dependent memory operations (look at the pending value, atomicMin it, learn from the old value whether this is the
+      // pair's first wake-up): they are pipelined over the neighbour tiles -- at tile end k the look for tile k is issued, the
+      // atomic for tile k-1 (whose look has arrived), and the old value of tile k-2 is consumed -- and the first wake-ups of the
+      // whole item are counted with ONE atomic at the end.  Every stage is per lane: the neighbour tile differs between the quarters.
       if (max_post) {
         tb::QStream S; S.begin(stream, W.post_off, W.post_chunks, stage_q, l16);
         u32x4 G = { 0u, 0u, 0u, 0u };
@@ -970,11 +673,9 @@ struct TbState {
   tb::Ctl* ctl = nullptr; tb::Ctl* h_ctl = nullptr;
   uint32_t* marr[2] = { nullptr, nullptr };
   float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;
-  uint32_t min_batch = 256;             // auto engine: batches of at least this many plans ...
-  double min_lanes = 7.0;               // ... that are expected to fill at least this many lanes of a wave (mnav.hip dijkstra_impl)
+  uint32_t min_batch = 48;              // auto engine: batches of at least this many plans (and of tiles / 1000: mnav.hip dijkstra_impl)
   float band_mult = 2.0f;               // band = band_mult * mean edge weight * sqrt(T)  (measured on C2: 1 -> 236 ms, 2 -> 218 ms per 5120 plans)
   int iters_per_replay = 16, waves_per_cu = 0;
-  uint32_t gran = 16;                   // plans per work item (tb::Args::gran)
   hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
   // second distance buffer, filled with +inf on its own stream behind the previous call (the fill of 6 B x slots x plans is
   // otherwise 2 % of a batch); only when both fit comfortably

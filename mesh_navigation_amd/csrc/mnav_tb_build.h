@@ -1,4 +1,4 @@
-// mnav_tb_build.h -- host-side construction of the TILE-BATCH SSSP engine's arrays (k_tb_solve in mnav_tb.h).
+// mnav_tb_build.h -- host-side construction of the TILE-BATCH SSSP engine's arrays (k_tb_solve_q in mnav_tb.h).
 // Host-only C++17, shared by the library (mnav.hip) and the CPU model of the schedule (oracle/tb_model.cpp).
 //
 // The engine runs many Dijkstra wavefronts (dijkstra_mesh_planner.cpp:287-348, one per plan) at once, TILE-major and
@@ -190,9 +190,9 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
   const uint32_t kRow = 256;   // bytes per LDS row
   // chunk writer: blocks are appended to the open chunk, a closed chunk is padded with empty blocks
   uint32_t in_chunk = 0;
-  // Every sweep block rewrites its target row (with the bits it read when nothing improved), and the kernel may have the
-  // reads of block j+1 in flight before block j's result is written (MNAV_TB_PIPELINE).  Two ADJACENT blocks of a chunk
-  // must therefore never have the same target.  `last_target` = target row of the previous block of the open chunk.
+  // Every sweep block rewrites its target row (with the bits it read when nothing improved); two ADJACENT blocks of a chunk
+  // never have the same target, so that a kernel may have the reads of block j+1 in flight before block j's result is
+  // written (tried and dropped: +24 % sweeps).  `last_target` = target row of the previous block of the open chunk.
   uint32_t last_target = kNone;
   auto open_block = [&]() -> size_t {                                // returns the dword index of the new block
     if (in_chunk == kTbBlocksPerChunk) { in_chunk = 0; last_target = kNone; }

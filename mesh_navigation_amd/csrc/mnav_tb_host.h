@@ -90,7 +90,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   HIPCHK(hipMalloc((void**)&S.pflag, nt * (((size_t)np + 63) / 64) + 64));
   HIPCHK(hipMalloc((void**)&S.bucket, 2 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.bcnt, 4 * nt));
-  HIPCHK(hipMalloc((void**)&S.items, 8 * (nt + pairs / 16 + 64)));
+  HIPCHK(hipMalloc((void**)&S.items, 8 * (nt + pairs / kTbItemPlans + 64)));
   HIPCHK(hipMalloc((void**)&S.ctl, sizeof(tb::Ctl)));
   HIPCHK(hipHostMalloc((void**)&S.h_ctl, sizeof(tb::Ctl), hipHostMallocDefault));
   for (int k = 0; k < 2; ++k) {
@@ -120,16 +120,10 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_scan, dim3(gp, (A.ntiles + kTbScanTiles - 1) / kTbScanTiles), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
-    if (A.gran == 16u) {
-      if (ctx->tb.T == 64) hipLaunchKernelGGL(k_tb_solve_q<64>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 96) hipLaunchKernelGGL(k_tb_solve_q<96>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 120) hipLaunchKernelGGL(k_tb_solve_q<120>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else hipLaunchKernelGGL(k_tb_solve_q<128>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    }
-    else if (ctx->tb.T == 64) hipLaunchKernelGGL(k_tb_solve<64>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    else if (ctx->tb.T == 96) hipLaunchKernelGGL(k_tb_solve<96>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    else if (ctx->tb.T == 120) hipLaunchKernelGGL(k_tb_solve<120>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    else hipLaunchKernelGGL(k_tb_solve<128>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    if (ctx->tb.T == 64) hipLaunchKernelGGL(k_tb_solve_q<64>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else if (ctx->tb.T == 96) hipLaunchKernelGGL(k_tb_solve_q<96>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else if (ctx->tb.T == 120) hipLaunchKernelGGL(k_tb_solve_q<120>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else hipLaunchKernelGGL(k_tb_solve_q<128>, dim3(waves), dim3(64), 0, ctx->stream, A, par);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -201,8 +195,6 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
   A.offset = offset;
-  A.gran = S.gran;
-  if (const char* e = getenv("MNAV_TB_GRAN")) A.gran = (atoi(e) == 64) ? 64u : 16u;
   {
     float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * S.band_mult;   // potential across one tile
     if (const char* e = getenv("MNAV_TB_BAND_MULT")) band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * (float)atof(e);
@@ -242,7 +234,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
 
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  uint32_t per_cu = (uint32_t)((160u * 1024u) / (S.T * 256u + (A.gran == 16u ? kTbQStride * 4u : 512u)));   // LDS: T x 256 bytes + staging per wave, 160 KB per CU
+  uint32_t per_cu = (uint32_t)((160u * 1024u) / (S.T * 256u + kTbQStride * 4u));   // LDS: T x 256 bytes + staging per wave, 160 KB per CU
   if (const char* e = getenv("MNAV_TB_WAVES_PER_CU")) S.waves_per_cu = atoi(e);
   if (S.waves_per_cu > 0) per_cu = (uint32_t)S.waves_per_cu;
   const uint32_t waves = per_cu * (uint32_t)ncu;
