@@ -433,7 +433,7 @@ def leg_c3(local_rank, args):
         robot = int(free[np.argmin(np.abs(mesh.xyz[free, 0] - 0.9 * N * 0.1) + np.abs(mesh.xyz[free, 1] - 0.9 * N * 0.1))])
         free = free[vc[free] < 0.5]                                       # goals well inside the traversable component
         tf = int(first_face[robot])
-        goals = rng.choice(free, size=160, replace=False)
+        goals = rng.choice(free, size=16 + 512, replace=False)
         lat, codes, st = [], [], None
         for k in range(13):
             sp, sf = wave_seed(int(goals[k]))
@@ -451,13 +451,18 @@ def leg_c3(local_rank, args):
             if k >= 2:
                 latv.append(o.stats["ms_total"])
         ctx.set_resident_outputs(False)
+        # batches run the wide step kernel (k_cvp_ctl + k_step_wide + k_step_repair per step); 128 plans as in the earlier rounds,
+        # and 512 (a step of 128 plans is ~1.3 rounds of the resident waves: a quarter of the time is the last, half-empty round)
+        def batch(nb):
+            seeds = [wave_seed(int(v)) for v in goals[16:16 + nb]]
+            sps = np.stack([x[0] for x in seeds]); sfs = np.array([x[1] for x in seeds], np.uint32)
+            ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
+            t0 = time.perf_counter()
+            r = ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
+            return r, time.perf_counter() - t0
         nb = 128
-        seeds = [wave_seed(int(v)) for v in goals[16:16 + nb]]
-        sps = np.stack([x[0] for x in seeds]); sfs = np.array([x[1] for x in seeds], np.uint32)
-        ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
-        tb = time.perf_counter()
-        rb = ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
-        tb = time.perf_counter() - tb
+        rb, tb = batch(nb)
+        rb512, tb512 = batch(512)
         # full-field variant (goal_dist_offset = +inf): the cleanest roofline denominator
         sp0, sf0 = wave_seed(int(goals[0]))
         ctx.plan_cvp(sp0, sf0, tf, goal_dist_offset=float("inf"), want_fields=False, want_vecmap=False)
@@ -471,7 +476,10 @@ def leg_c3(local_rank, args):
                "ms_per_plan_single_with_vector_map": float(np.median(latv)),
                "codes_single": sorted(set(codes)), "batch": nb, "plans_per_s_batch": nb / tb,
                "codes_batch": sorted(set(int(c) for c in rb["codes"])),
-               "roofline": roofline_of(rb["stats"], "k_step<cvp>"), "roofline_single_plan": roofline_of(st, "k_step<cvp>")}
+               "batch_512": {"plans_per_s": 512 / tb512, "ms_per_batch": tb512 * 1e3, "codes": sorted(set(int(c) for c in rb512["codes"])),
+                             "roofline": roofline_of(rb512["stats"], "k_step_wide (one step = k_cvp_ctl + k_step_wide + k_step_repair)")},
+               "roofline": roofline_of(rb["stats"], "k_step_wide (one step = k_cvp_ctl + k_step_wide + k_step_repair)"),
+               "roofline_single_plan": roofline_of(st, "k_step<cvp>")}
         if not args.no_cpu:
             from oracle import oracle as O
             om = O.OracleMesh(mesh.xyz, mesh.faces)

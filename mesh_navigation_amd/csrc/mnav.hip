@@ -460,7 +460,7 @@ __device__ __forceinline__ void push_many(StepCtx& S, uint32_t (&u)[N], uint32_t
 constexpr int kWidePassesPerBatch = 4;        // face passes whose loads are in flight together (4 x 64 faces)
 
 #ifdef MNAV_WIDE_TIMING                   // debugging aid: cycles per phase of wide_round, summed over all waves
-__device__ unsigned long long g_wide_timing[8];
+__device__ unsigned long long g_wide_timing[12];   // [0..6] cycles per phase, [8] rounds, [9] active entries, [10] evaluated, [11] serial-rule vertices
 #define WD_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); wt[k] += now_ - w_last; w_last = now_; } while (0)
 #else
 #define WD_STAMP(k) do { } while (0)
@@ -601,6 +601,10 @@ __device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl&
   if (retain) S.lmin = fminf(S.lmin, t_new);
   WD_STAMP(6);
 #ifdef MNAV_WIDE_TIMING
+  {
+    const unsigned long long ne = __popcll(__ballot(evaluate)), na = __popcll(__ballot(active)), ns = __popcll(__ballot(!slots && evaluate));
+    if (lane == 0) { atomicAdd(&g_wide_timing[8], 1ull); atomicAdd(&g_wide_timing[9], na); atomicAdd(&g_wide_timing[10], ne); atomicAdd(&g_wide_timing[11], ns); }
+  }
   if (lane == 0) for (int k = 0; k < 8; ++k) if (wt[k]) atomicAdd(&g_wide_timing[k], wt[k]);
 #endif
 }
@@ -611,58 +615,37 @@ __device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl&
 #define MNAV_STEP_OCC 3                   // right at that edge (159-170 VGPRs); at 2 waves a batch is 20 % slower, forcing 4 or 5
 #endif                                    // spills and is slower still (measured: 179 / 150 / 120 plans/s at 3 / 4 / 5)
 #define MNAV_STEP_BOUNDS __launch_bounds__(kWave, MNAV_STEP_OCC)
-template <uint32_t PLANNER, bool WIDE>
-__device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j)
+// PRECTL: the step's control block was computed by k_cvp_ctl (batches on the wide kernel); this kernel then only serves the plans
+// that are in a repair / rebuild / cut step, which sweep over all vertices with the 8-lane code below.
+template <uint32_t PLANNER, bool PRECTL>
+__device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j, uint32_t plan_index)
 {
-  const Plan& P = plans[blockIdx.y];
+  const Plan& P = plans[plan_index];
   const int lane = threadIdx.x;
   __shared__ Ctl s_ctl;
   if (lane == 0) {
-    const Ctl prev = P.ctl[(j + 1) & 1];
-    const Cnt cprev = P.cnt[(j + 2) % 3];
-    const Ctl cur = controller(P, prev, cprev);
-    s_ctl = cur;
-    if (blockIdx.x == 0) {
-      P.ctl[j & 1] = cur;
-      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
-      P.cnt[(j + 1) % 3] = z;
+    if constexpr (PRECTL) s_ctl = P.ctl[j & 1];
+    else {
+      const Ctl prev = P.ctl[(j + 1) & 1];
+      const Cnt cprev = P.cnt[(j + 2) % 3];
+      const Ctl cur = controller(P, prev, cprev);
+      s_ctl = cur;
+      if (blockIdx.x == 0) {
+        P.ctl[j & 1] = cur;
+        Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
+        P.cnt[(j + 1) % 3] = z;
+      }
     }
   }
   __syncthreads();
   const Ctl cur = s_ctl;
   if (cur.done) return;
+  if constexpr (PRECTL) { if (cur.repair == 0 && P.seed_mask == nullptr) return; }   // an ordinary step: k_step_wide's
   Cnt* cnt = &P.cnt[j % 3];
   StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
   const int sub = lane & (kGroup - 1), grp = lane >> 3;
   const uint32_t ngroups = gridDim.x * kGroupsPerWave;
   const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
-  if constexpr (WIDE && PLANNER == kPlannerCvp) {
-    if (cur.repair == 0 && P.seed_mask == nullptr) {                  // the ordinary step: 64 work-list entries per wave and round
-      __shared__ WideLds s_wide;
-      for (uint32_t k = (uint32_t)lane; k < kWideSeen; k += kWave) s_wide.seen[k] = kNone;   // (wide_round starts with a barrier)
-      const uint32_t* list = P.list[cur.it & 1];
-      const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
-      const uint32_t ntot = cur.n + cur.wread;
-      const uint32_t per = gridDim.x * kWave;
-      for (uint32_t base = blockIdx.x * kWave; base < ntot; base += per) {
-        const uint32_t i = base + (uint32_t)lane;
-        const bool active = i < ntot;
-        const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
-        wide_round(S, P, cur, s_wide, active, v, lane);
-      }
-      const float wmin = wave_min(S.lmin);
-      const float wcut = wave_min(S.lcut);
-      const uint32_t wev = wave_sum(S.levals);
-      const bool wch = __any(S.lchanged);
-      if (lane == 0) {
-        if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
-        if (wcut < inf_f()) atomicMin(&cnt->minchg, f2u(wcut));
-        if (wev) atomicAdd(&cnt->evals, wev);
-        if (wch) atomicOr(&cnt->changed, 1u);
-      }
-      return;
-    }
-  }
   if (cur.repair == 3) {                                             // spec: process_cut -- no evaluation
     const uint32_t nthreads = gridDim.x * kWave, tid = blockIdx.x * kWave + lane;
     const uint32_t* list = P.list[cur.it & 1];
@@ -719,9 +702,125 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j)
 }
 
 template <uint32_t PLANNER>
-__global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) { step_body<PLANNER, false>(plans, j); }
-// the wide variant is bounded by its LDS image (seven waves per CU), not by registers
-__global__ __launch_bounds__(kWave, 2) void k_step_wide(const Plan* __restrict__ plans, int j) { step_body<kPlannerCvp, true>(plans, j); }
+__global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) { step_body<PLANNER, false>(plans, j, blockIdx.y); }
+
+// ---- CVP batches: one launch of persistent waves per step, the work of ALL plans dealt out in chunks of 64 entries ------------
+// With a grid of (waves per plan, plans) most workgroups of a step find nothing to do -- a plan's work list is a few hundred to a
+// few ten thousand entries, the grid must cover the largest -- and for a kernel with a 22 KB LDS image every one of them holds
+// an LDS slot while it starts and exits: on the benched C3 configuration that kept the wide kernel at the 8-lane kernel's
+// throughput.  k_cvp_ctl evaluates every plan's controller once (what each workgroup of k_step does for itself), writes the
+// control blocks and the prefix sums of the plans' chunk counts; k_step_wide then runs exactly as many waves as stay resident,
+// each taking an equal, contiguous share of the step's chunks, whatever plans they belong to.
+struct WideSched { uint32_t total, n_repair, pad[2]; };
+constexpr uint32_t kRepairRows = 16;          // grid rows of k_step_repair: plans in a repair step are rare, a row takes several if there are more
+
+// the plans that k_cvp_ctl found in a repair / rebuild / cut step (rep_list = prefix + n + 1 ...): the 8-lane sweeps over all vertices
+__global__ MNAV_STEP_BOUNDS void k_step_repair(const Plan* __restrict__ plans, int j, const uint32_t* __restrict__ rep_list, const WideSched* __restrict__ sched)
+{
+  const uint32_t nr = sched->n_repair;
+  for (uint32_t r = blockIdx.y; r < nr; r += kRepairRows) {
+    step_body<kPlannerCvp, true>(plans, j, rep_list[r]);
+    __syncthreads();                                                   // (s_ctl of the next plan)
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cvp_ctl(const Plan* __restrict__ plans, uint32_t n, int j, uint32_t* __restrict__ prefix, WideSched* __restrict__ sched)
+{
+  __shared__ uint32_t s_base, s_rep;
+  __shared__ uint32_t s_wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) { s_base = 0u; s_rep = 0u; }
+  __syncthreads();
+  for (uint32_t p0 = 0; p0 < n; p0 += 256) {
+    const uint32_t p = p0 + tid;
+    uint32_t chunks = 0;
+    if (p < n) {
+      const Plan& P = plans[p];
+      const Ctl prev = P.ctl[(j + 1) & 1];
+      const Cnt cprev = P.cnt[(j + 2) % 3];
+      const Ctl cur = controller(P, prev, cprev);
+      P.ctl[j & 1] = cur;
+      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
+      P.cnt[(j + 1) % 3] = z;
+      if (!cur.done) {
+        if (cur.repair == 0 && P.seed_mask == nullptr) chunks = (cur.n + cur.wread + kWave - 1) / kWave;
+        else prefix[n + 1u + atomicAdd(&s_rep, 1u)] = p;              // (the list of plans for k_step_repair follows the prefix sums)
+      }
+    }
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wid) woff += s_wsum[w]; tot += s_wsum[w]; }
+    if (p < n) prefix[p] = s_base + woff + incl - chunks;
+    __syncthreads();
+    if (tid == 0) s_base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) { prefix[n] = s_base; sched->total = s_base; sched->n_repair = s_rep; }
+}
+
+// the plan that chunk c belongs to: the largest p with prefix[p] <= c (all lanes search together, 64 entries per look)
+__device__ __forceinline__ uint32_t wide_find_plan(const uint32_t* __restrict__ prefix, uint32_t n, uint32_t c, int lane)
+{
+  uint32_t lo = 0, len = n + 1u;                                       // the answer lies in [lo, lo + len)
+  while (len > 1u) {
+    const uint32_t step = (len + kWave - 1u) / kWave;
+    const uint32_t idx = lo + (uint32_t)lane * step;
+    const bool le = idx < lo + len && prefix[idx] <= c;
+    const uint32_t k = (uint32_t)__popcll(__ballot(le));                // samples are ascending: the first k of them are <= c (k >= 1)
+    const uint32_t nlo = lo + (k - 1u) * step;
+    len = min(step, lo + len - nlo);
+    lo = nlo;
+  }
+  return lo;
+}
+
+// bounded by its LDS image (seven waves per CU), not by registers
+__global__ __launch_bounds__(kWave, 2) void k_step_wide(const Plan* __restrict__ plans, uint32_t n, int j, const uint32_t* __restrict__ prefix,
+                                                        const WideSched* __restrict__ sched)
+{
+  __shared__ WideLds s_wide;
+  const int lane = threadIdx.x;
+  const uint32_t total = sched->total;
+  uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
+  const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1u)) / gridDim.x);
+  if (c0 >= c1) return;
+  uint32_t p = wide_find_plan(prefix, n, c0, lane);
+  while (c0 < c1) {
+    const uint32_t pb = prefix[p], pe = prefix[p + 1];
+    if (pe <= c0) { ++p; continue; }                                   // (a plan without chunks in this step)
+    const Plan& P = plans[p];
+    const Ctl cur = P.ctl[j & 1];
+    Cnt* cnt = &P.cnt[j % 3];
+    StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
+    __syncthreads();
+    for (uint32_t k = (uint32_t)lane; k < kWideSeen; k += kWave) s_wide.seen[k] = kNone;   // vertex ids of another plan (wide_round starts with a barrier)
+    const uint32_t* list = P.list[cur.it & 1];
+    const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
+    const uint32_t ntot = cur.n + cur.wread;
+    const uint32_t ce = min(c1, pe);
+    for (uint32_t c = c0; c < ce; ++c) {
+      const uint32_t i = (c - pb) * kWave + (uint32_t)lane;
+      const bool active = i < ntot;
+      const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
+      wide_round(S, P, cur, s_wide, active, v, lane);
+    }
+    const float wmin = wave_min(S.lmin);
+    const float wcut = wave_min(S.lcut);
+    const uint32_t wev = wave_sum(S.levals);
+    const bool wch = __any(S.lchanged);
+    if (lane == 0) {
+      if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
+      if (wcut < inf_f()) atomicMin(&cnt->minchg, f2u(wcut));
+      if (wev) atomicAdd(&cnt->evals, wev);
+      if (wch) atomicOr(&cnt->changed, 1u);
+    }
+    c0 = ce; ++p;
+  }
+}
 
 // CVP verification sweep, run once after the last step (the CVP counterpart of k_dij_finalize's fixed-point
 // check): every vertex is evaluated once more on the CONVERGED state.  (1) Its stored (potential, pop key,
@@ -2405,6 +2504,7 @@ struct mnav_ctx {
   TCtl* h_tctl = nullptr;
   size_t tile_lds = 0, fin_lds = 0;
   bool use_graph = true;
+  uint32_t* d_wide_prefix = nullptr; WideSched* d_wide_sched = nullptr; uint32_t wide_cap = 0;   // k_cvp_ctl -> k_step_wide
   uint32_t cvp_wide_min_batch = 24;                                  // CVP batches of at least this many plans run k_step_wide
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
@@ -2585,7 +2685,13 @@ template <uint32_t PLANNER>
 int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count, bool wide)
 {
   for (int j = 0; j < count; ++j) {
-    if (wide) hipLaunchKernelGGL(k_step_wide, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
+    if (wide) {
+      // controller + shares of all plans, the wide kernel with as many waves as stay resident (7 per CU: its LDS image), and the
+      // 8-lane kernel for the plans that are in a repair / rebuild / cut step (a sweep over all vertices: any grid will do)
+      hipLaunchKernelGGL(k_cvp_ctl, dim3(1), dim3(256), 0, ctx->stream, ctx->d_plans, n, j % 6, ctx->d_wide_prefix, ctx->d_wide_sched);
+      hipLaunchKernelGGL(k_step_wide, dim3(G), dim3(kWave), 0, ctx->stream, ctx->d_plans, n, j % 6, ctx->d_wide_prefix, ctx->d_wide_sched);
+      hipLaunchKernelGGL(k_step_repair, dim3(blocks_per_plan(ctx), kRepairRows), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6, ctx->d_wide_prefix + n + 1u, ctx->d_wide_sched);
+    }
     else hipLaunchKernelGGL(k_step<PLANNER>, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
   }
   HIPCHK(hipGetLastError());
@@ -2714,9 +2820,17 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   if (const char* e = getenv("MNAV_CVP_WIDE")) wide = cvp && atoi(e) != 0;
   uint32_t G = blocks_per_plan(ctx);
   if (wide) {
-    G = (G + 3u) / 4u;                                                // half the lanes of a round busy on average: measured best (1M mesh, 128 plans: 63 waves
-                                                                      // per plan 193 plans/s, 125 -> 219, 32 -> 147)
-    if (const char* e = getenv("MNAV_BLOCKS_PER_PLAN_WIDE")) G = (uint32_t)std::max(1, atoi(e));
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    G = 7u * (uint32_t)ncu;                                           // waves of the whole batch, not per plan: what stays resident
+    if (const char* e = getenv("MNAV_WIDE_WAVES")) G = (uint32_t)std::max(1, atoi(e));
+    if (ctx->wide_cap < n + 1u) {
+      (void)hipFree(ctx->d_wide_prefix); ctx->d_wide_prefix = nullptr;
+      HIPCHK(hipMalloc((void**)&ctx->d_wide_prefix, 4 * (size_t)(2u * n + 2u)));   // prefix sums [n + 1], then the repair list [n]
+      ctx->wide_cap = n + 1u;
+      drop_graphs(ctx);                                               // (captured with the old pointer)
+    }
+    if (!ctx->d_wide_sched) HIPCHK(hipMalloc((void**)&ctx->d_wide_sched, sizeof(WideSched)));
   }
   uint32_t launches = 0;
   int rc = 0;
@@ -3116,6 +3230,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
   (void)hipFree(ctx->d_tplans);
   (void)hipFree(ctx->shard.d_iface_vert); (void)hipFree(ctx->shard.d_iface_owner); (void)hipFree(ctx->shard.d_wake_ptr); (void)hipFree(ctx->shard.d_wake_tile);
+  (void)hipFree(ctx->d_wide_prefix); (void)hipFree(ctx->d_wide_sched);
   (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend); (void)hipFree(ctx->shard.d_walk);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
@@ -4701,8 +4816,8 @@ int mnav_debug_tile_timing(unsigned long long* out, unsigned int cap)
 #ifdef MNAV_WIDE_TIMING
 extern "C" int mnav_debug_wide_timing(unsigned long long* out)
 {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-  unsigned long long z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_timing), sizeof(unsigned long long) * 12) != hipSuccess) return -1;
+  unsigned long long z[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_timing), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif

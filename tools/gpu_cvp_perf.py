@@ -42,10 +42,12 @@ for nb in [int(x) for x in os.environ.get("PERF_BATCHES", "1,128,512").split(","
     Lb = capi.load()
     if hasattr(Lb, "mnav_debug_wide_timing"):
         import ctypes
-        tt = (ctypes.c_ulonglong * 8)()
+        tt = (ctypes.c_ulonglong * 12)()
         Lb.mnav_debug_wide_timing(tt)
         names = ["pre+slots", "A loads", "A compute", "B replay", "post", "push", "park", "-"]
-        print("   phase Gcycles:", {nm: round(tt[i] / 1e9, 2) for i, nm in enumerate(names)}, flush=True)
+        print("   phase Gcycles:", {nm: round(tt[i] / 1e9, 2) for i, nm in enumerate(names[:7])}, flush=True)
+        r = max(int(tt[8]), 1)
+        print("   rounds %d: active entries per round %.1f, evaluated %.1f, serial-rule %.3f" % (r, tt[9] / r, tt[10] / r, tt[11] / r), flush=True)
     print(json.dumps({"band_edges": os.environ.get("PERF_BAND_EDGES", "12"), "lib": tag, "batch": nb, "plans_per_s": nb / dt, "ms": dt * 1e3, "steps": st["steps"], "launches": st["launches"],
                       "evals_per_plan": st["evals"] / nb, "band_shrinks": st["band_shrinks"], "settled_per_plan": st["settled"] / nb, "ms_step_kernels": st["ms_step_kernels"],
                       "codes": sorted(set(int(c) for c in rb["codes"]))}), flush=True)

@@ -41,9 +41,11 @@ for B in [int(x) for x in os.environ.get("BS", "1,16,128").split(",")]:
             Lb = capi.load()
             if hasattr(Lb, "mnav_debug_wide_timing"):
                 import ctypes
-                tt = (ctypes.c_ulonglong * 8)()
+                tt = (ctypes.c_ulonglong * 12)()
                 Lb.mnav_debug_wide_timing(tt)
                 names = ["pre+slots", "A loads", "A compute", "B replay", "post", "push", "park", "-"]
-                print("   phase Gcycles:", {nm: round(tt[i] / 1e9, 2) for i, nm in enumerate(names)}, flush=True)
+                print("   phase Gcycles:", {nm: round(tt[i] / 1e9, 2) for i, nm in enumerate(names[:7])}, flush=True)
+                r = max(int(tt[8]), 1)
+                print("   rounds %d: active entries per round %.1f, evaluated %.1f, serial-rule %.3f" % (r, tt[9] / r, tt[10] / r, tt[11] / r), flush=True)
             print(dict(B=B, wide=wide, G=g, wall_ms=round(dt * 1e3, 1), plans_per_s=round(B / dt, 1), steps=st["steps"], ms_kern=round(st["ms_step_kernels"], 1),
                        evals=st.get("evals"), ok=int((b["codes"] == 0).sum()), equal_to_first=eq), flush=True)
