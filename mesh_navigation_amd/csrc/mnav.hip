@@ -466,6 +466,10 @@ __device__ unsigned long long g_wide_timing[12];   // [0..6] cycles per phase, [
 #define WD_STAMP(k) do { } while (0)
 #endif
 
+// mode 0: an ordinary step (spec: process_entry); 1: the repair sweep after goal_dist was armed (process_repair: every reached
+// vertex is looked at, those whose pop time lies above goal_dist are evaluated again under the final cut-off and stored, nothing is
+// pushed); 2: the rebuild after a band shrink (process_entry over every reached vertex, band_new == 1)
+template <int MODE>
 __device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl& c, WideLds& L, bool active, uint32_t v, int lane)
 {
 #ifdef MNAV_WIDE_TIMING
@@ -483,10 +487,17 @@ __device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl&
     const uint32_t b0 = P.crn_ptr[v], b1 = P.crn_ptr[v + 1];
     old_pred = P.pred[v]; old_cut = P.cutf[v]; old_dir = P.dirn[v];  // (all of the vertex's state in flight together)
     old_t = key_time(old_key);
-    const bool go = !(old_t < c.thr_fixed) && !blk;
-    const bool parked = go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && dirty != (uint32_t)c.it;
-    if (parked) { retain = true; t_new = old_t; }
-    else if (go) { evaluate = true; beg = b0; nf = b1 - b0; }
+    if constexpr (MODE == 1) {
+      if (old_d < inf_f()) {
+        if (old_t > c.goal_dist) { evaluate = true; beg = b0; nf = b1 - b0; }
+        else { t_new = old_t; retain = (t_new >= c.thr) && (t_new < inf_f()); }
+      }
+    } else {
+      const bool go = !(old_t < c.thr_fixed) && !blk && (MODE == 0 || old_d < inf_f());
+      const bool parked = go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && dirty != (uint32_t)c.it;
+      if (parked) { retain = true; t_new = old_t; }
+      else if (go) { evaluate = true; beg = b0; nf = b1 - b0; }
+    }
   }
   // ---- item slots: prefix sum of the face counts.  A vertex of very high valence, and whatever does not fit, takes the serial rule
   const uint32_t want = (nf <= kWideMaxFaces) ? nf : 0u;
@@ -555,10 +566,15 @@ __device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl&
                          (e.cut != old_cut) || (f2u(e.dir) != f2u(old_dir));
     if (changed) { P.dist[v] = e.d; P.pred[v] = e.pred; P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
     t_new = e.t;
-    const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
-    push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
-    retain = !now_in && e.t < inf_f();
-    self_again = (e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key;   // spec: process_entry
+    if constexpr (MODE == 1) {
+      if (f2u(e.d) != f2u(old_d) || e.key != old_key) S.lchanged = true;       // sweep again (spec: process_repair)
+      retain = (t_new >= c.thr) && (t_new < inf_f());
+    } else {
+      const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
+      push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
+      retain = !now_in && e.t < inf_f();
+      self_again = (e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key;   // spec: process_entry
+    }
   }
   if (push_nb || self_again) {
     S.lchanged = true;
@@ -640,7 +656,7 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
   __syncthreads();
   const Ctl cur = s_ctl;
   if (cur.done) return;
-  if constexpr (PRECTL) { if (cur.repair == 0 && P.seed_mask == nullptr) return; }   // an ordinary step: k_step_wide's
+  if constexpr (PRECTL) { if (cur.repair <= 2 && P.seed_mask == nullptr) return; }   // k_step_wide's
   Cnt* cnt = &P.cnt[j % 3];
   StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
   const int sub = lane & (kGroup - 1), grp = lane >> 3;
@@ -743,8 +759,9 @@ __global__ __launch_bounds__(256) void k_cvp_ctl(const Plan* __restrict__ plans,
       Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
       P.cnt[(j + 1) % 3] = z;
       if (!cur.done) {
-        if (cur.repair == 0 && P.seed_mask == nullptr) chunks = (cur.n + cur.wread + kWave - 1) / kWave;
-        else prefix[n + 1u + atomicAdd(&s_rep, 1u)] = p;              // (the list of plans for k_step_repair follows the prefix sums)
+        if (P.seed_mask == nullptr && cur.repair == 0) chunks = (cur.n + cur.wread + kWave - 1) / kWave;
+        else if (P.seed_mask == nullptr && cur.repair <= 2) chunks = (P.V + kWave - 1) / kWave;   // repair sweep / rebuild: over all vertices
+        else prefix[n + 1u + atomicAdd(&s_rep, 1u)] = p;              // band cut (no evaluation): k_step_repair; its list follows the prefix sums
       }
     }
     uint32_t incl = chunks;
@@ -802,11 +819,19 @@ __global__ __launch_bounds__(kWave, 2) void k_step_wide(const Plan* __restrict__
     const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
     const uint32_t ntot = cur.n + cur.wread;
     const uint32_t ce = min(c1, pe);
-    for (uint32_t c = c0; c < ce; ++c) {
-      const uint32_t i = (c - pb) * kWave + (uint32_t)lane;
-      const bool active = i < ntot;
-      const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
-      wide_round(S, P, cur, s_wide, active, v, lane);
+    if (cur.repair == 0) {
+      for (uint32_t c = c0; c < ce; ++c) {
+        const uint32_t i = (c - pb) * kWave + (uint32_t)lane;
+        const bool active = i < ntot;
+        const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
+        wide_round<0>(S, P, cur, s_wide, active, v, lane);
+      }
+    } else {
+      for (uint32_t c = c0; c < ce; ++c) {                             // a sweep over the vertices themselves
+        const uint32_t v = (c - pb) * kWave + (uint32_t)lane;
+        if (cur.repair == 1) wide_round<1>(S, P, cur, s_wide, v < P.V, v < P.V ? v : 0u, lane);
+        else wide_round<2>(S, P, cur, s_wide, v < P.V, v < P.V ? v : 0u, lane);
+      }
     }
     const float wmin = wave_min(S.lmin);
     const float wcut = wave_min(S.lcut);
