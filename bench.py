@@ -433,7 +433,8 @@ def leg_c3(local_rank, args):
         robot = int(free[np.argmin(np.abs(mesh.xyz[free, 0] - 0.9 * N * 0.1) + np.abs(mesh.xyz[free, 1] - 0.9 * N * 0.1))])
         free = free[vc[free] < 0.5]                                       # goals well inside the traversable component
         tf = int(first_face[robot])
-        goals = rng.choice(free, size=16 + 512, replace=False)
+        goals = rng.choice(free, size=160, replace=False)               # (the draw of the earlier rounds: same single plans, same batch of 128)
+        goals512 = rng.choice(free, size=512, replace=False)
         lat, codes, st = [], [], None
         for k in range(13):
             sp, sf = wave_seed(int(goals[k]))
@@ -454,7 +455,7 @@ def leg_c3(local_rank, args):
         # batches run the wide step kernel (k_cvp_ctl + k_step_wide + k_step_repair per step); 128 plans as in the earlier rounds,
         # and 512 (a step of 128 plans is ~1.3 rounds of the resident waves: a quarter of the time is the last, half-empty round)
         def batch(nb):
-            seeds = [wave_seed(int(v)) for v in goals[16:16 + nb]]
+            seeds = [wave_seed(int(v)) for v in (goals[16:16 + nb] if nb <= 128 else goals512[:nb])]
             sps = np.stack([x[0] for x in seeds]); sfs = np.array([x[1] for x in seeds], np.uint32)
             ctx.plan_cvp_batch(sps, sfs, np.full(nb, tf, np.uint32))
             t0 = time.perf_counter()
