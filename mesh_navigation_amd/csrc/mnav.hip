@@ -2530,6 +2530,7 @@ struct mnav_ctx {
   size_t tile_lds = 0, fin_lds = 0;
   bool use_graph = true;
   uint32_t* d_wide_prefix = nullptr; WideSched* d_wide_sched = nullptr; uint32_t wide_cap = 0;   // k_cvp_ctl -> k_step_wide
+  float* d_vec3 = nullptr;                                           // mnav_vector_at after a paths-only batch
   uint32_t cvp_wide_min_batch = 24;                                  // CVP batches of at least this many plans run k_step_wide
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
@@ -3255,7 +3256,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_t_rptr); (void)hipFree(ctx->d_mismatch); (void)hipFree(ctx->d_t_rowptr); (void)hipFree(ctx->d_t_col); (void)hipFree(ctx->d_t_tw);
   (void)hipFree(ctx->d_tplans);
   (void)hipFree(ctx->shard.d_iface_vert); (void)hipFree(ctx->shard.d_iface_owner); (void)hipFree(ctx->shard.d_wake_ptr); (void)hipFree(ctx->shard.d_wake_tile);
-  (void)hipFree(ctx->d_wide_prefix); (void)hipFree(ctx->d_wide_sched);
+  (void)hipFree(ctx->d_wide_prefix); (void)hipFree(ctx->d_wide_sched); (void)hipFree(ctx->d_vec3);
   (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend); (void)hipFree(ctx->shard.d_walk);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
@@ -4658,7 +4659,8 @@ const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)
     case 1: return lazy ? nullptr : s.pred;
     case 2: return s.dirn;
     case 3: return s.cutf;
-    case 4: return s.vecmap;
+    case 4: return (ctx->last_planner == kPlannerDijkstra && !ctx->want_vec) ? nullptr : s.vecmap;   // (a Dijkstra call that was not asked for vector maps
+                                                                                                       //  must not hand out an earlier call's)
     default: return nullptr;
   }
 }
@@ -4705,15 +4707,27 @@ int mnav_download_output(mnav_ctx* ctx, uint32_t slot, int what, void* host_out)
 int mnav_vector_at(mnav_ctx* ctx, uint32_t slot, const uint32_t vs[3], const float bary[3], float out[3])
 {
   if (!ctx || !vs || !bary || !out) return -1;
-  const float* vm = static_cast<const float*>(mnav_device_output(ctx, slot, 4));
-  if (!vm) { ctx->err = "vector map not resident"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  for (int k = 0; k < 3; ++k) if (vs[k] >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
   float v[3][3];
-  for (int k = 0; k < 3; ++k) {
-    if (vs[k] >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
-    HIPCHK(hipMemcpyAsync(v[k], vm + 3 * (size_t)vs[k], 12, hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->last_planner == kPlannerDijkstra && ctx->last_engine == 5 && ctx->lazy_paths && ctx->tb_args_valid) {
+    // paths-only batch of the tile-batch engine: no vector map was written -- the three entries are derived from the blocked distances
+    uint32_t p = slot;
+    if (p < ctx->caller_slot.size()) p = ctx->caller_slot[p];
+    if (p >= ctx->last_n) { ctx->err = "output not resident"; return -1; }
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    if (!ctx->d_vec3) HIPCHK(hipMalloc((void**)&ctx->d_vec3, 64));
+    hipLaunchKernelGGL(k_tb_vector3, dim3(3), dim3(kWave), 0, ctx->stream, ctx->tb_args, ctx->d_row_ptr, ctx->d_nbr, ctx->d_xyz, p,
+                       make_uint3(vs[0], vs[1], vs[2]), ctx->d_vec3);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&v[0][0], ctx->d_vec3, 36, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else {
+    const float* vm = static_cast<const float*>(mnav_device_output(ctx, slot, 4));
+    if (!vm) { ctx->err = "vector map not resident"; return -1; }
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+    for (int k = 0; k < 3; ++k) HIPCHK(hipMemcpyAsync(v[k], vm + 3 * (size_t)vs[k], 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   float acc[3] = { 0.f, 0.f, 0.f };
   bool any = false;
   for (int k = 0; k < 3; ++k) {

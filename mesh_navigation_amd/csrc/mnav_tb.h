@@ -619,6 +619,49 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
   }
 }
 
+// The vector-map entries (dijkstra :189-209) of three vertices of ONE plan, straight from the blocked distances: the predecessor
+// is derived like along the path (k_tb_path) -- the first-popped expanded neighbour attaining the smallest sum, which for a vertex
+// beyond goal_dist is the tentative value's predecessor of the reference -- and the vector is k_vecmap_dijkstra's arithmetic.
+// What mnav_vector_at samples after a paths-only batch: no finalize pass, no V-sized output.  One wave per vertex.
+__global__ __launch_bounds__(kWave) void k_tb_vector3(tb::Args A, const uint32_t* __restrict__ row_ptr, const Nbr* __restrict__ nbr,
+                                                      const float* __restrict__ xyz, uint32_t p, uint3 vs, float* __restrict__ out)
+{
+  const int lane = threadIdx.x;
+  const uint32_t v = blockIdx.x == 0 ? vs.x : blockIdx.x == 1 ? vs.y : vs.z;
+  const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
+  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+  float best_s = inf_f(), best_du = inf_f();
+  uint32_t best_u = v;
+  if (v != A.seed[p]) {
+    const uint32_t beg = row_ptr[v], end = row_ptr[v + 1];
+    for (uint32_t i = beg + lane; i < end; i += kWave) {
+      const Nbr nb = nbr[i];
+      const float du = A.D[tb::slot_addr(A.vaddr[nb.u], A.NP, p)];
+      if (du > goal_dist) continue;                                   // never expanded (dijkstra :299)
+      const float sm = du + nb.w;                                     // :331
+      if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
+    }
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const float os = __shfl_xor(best_s, o), odu = __shfl_xor(best_du, o);
+      const uint32_t ou = __shfl_xor(best_u, o);
+      if (os < best_s || (os == best_s && os < inf_f() && (odu < best_du || (odu == best_du && ou < best_u)))) { best_s = os; best_du = odu; best_u = ou; }
+    }
+    if (!(best_s < inf_f())) best_u = v;
+  }
+  if (lane == 0) {
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (best_u != v) {                                                // :197
+      x = xyz[3 * (size_t)best_u] - xyz[3 * (size_t)v];               // :204
+      y = xyz[3 * (size_t)best_u + 1] - xyz[3 * (size_t)v + 1];
+      z = xyz[3 * (size_t)best_u + 2] - xyz[3 * (size_t)v + 2];
+      const float len = sqrtf(x * x + y * y + z * z);                 // normalized(), :206
+      x = x / len; y = y / len; z = z / len;
+    }
+    out[3 * blockIdx.x] = x; out[3 * blockIdx.x + 1] = y; out[3 * blockIdx.x + 2] = z;
+  }
+}
+
 // settled vertices per plan (the popped ones: dist <= goal_dist), for the algorithmic-bytes figure: one wave per slice
 __global__ __launch_bounds__(kBlock) void k_tb_count(tb::Args A, uint32_t T, PlanResult* __restrict__ res)
 {

@@ -72,3 +72,51 @@ def test_paths_only_batches_equal_the_oracle_and_the_finalize_path(c2_costs, off
         assert fin["codes"][k] == results["tile_batch"][0][k]
         assert fin["paths"][k].tolist() == results["tile_batch"][1][k]
     ctx.set_dijkstra_engine("auto")
+
+
+def test_vector_at_after_a_paths_only_batch_equals_the_vector_map(c2_costs):
+    """mnav_vector_at (MeshMap::directionAtPosition, mesh_map.cpp:625-650) after a paths-only tile-batch batch: the three vector-map
+    entries (dijkstra :189-209) are derived from the blocked distances on demand (k_tb_vector3) -- the same numbers as sampling the
+    vector map that the finalize pass writes when V-sized outputs are asked for, at popped vertices, at tentative ones beyond
+    goal_dist, at unreached ones, at the wave source."""
+    case, ctx, seeds, targets = c2_costs
+    mesh = case.mesh
+    sub = np.arange(0, 64)
+    ctx.set_dijkstra_engine("tile_batch")
+    rng = np.random.default_rng(77)
+    faces = rng.choice(mesh.F, 40, replace=False)
+    bary = rng.dirichlet(np.ones(3), size=40).astype(np.float32)
+    plans = [0, 5, 17, 40, 48, 63]                                    # incl. NO_PATH_FOUND (48: the wave floods everything it can reach)
+    ctx.set_resident_outputs(True)
+    full = ctx.plan_dijkstra_batch(seeds[sub], targets[sub], goal_dist_offset=0.3, cost_limit=0.8, want_fields=True, path_cap=16384)   # vector maps resident
+    want = {}
+    for p in plans:
+        extra = [np.array([seeds[p]] * 3, np.uint32)]                  # the wave source itself: no vector
+        if full["codes"][p] == 0:
+            d = full["dist"][p]
+            far = np.nonzero(np.isfinite(d) & (d > d[targets[p]] + 0.3))[0]        # tentative values beyond goal_dist keep a predecessor
+            if far.size:
+                extra.append(np.array([far[0], far[far.size // 2], far[-1]], np.uint32))
+        tri = [mesh.faces[f].astype(np.uint32) for f in faces] + extra
+        br = [b for b in bary] + [np.array([0.2, 0.3, 0.5], np.float32)] * len(extra)
+        want[p] = [(t, b, ctx.vector_at(t, b, slot=int(p))) for t, b in zip(tri, br)]
+        vmap = ctx.download_output("vecmap", slot=int(p))
+        for t, b, got in want[p][:8]:                                  # the resident map is the finalize pass's: spot-check against its download
+            vm = vmap[t]
+            has = ~(vm == 0).all(axis=1)
+            exp = (vm[has] * b[has, None]).sum(axis=0) if has.any() else None
+            assert (got is None) == (exp is None) and (got is None or np.allclose(got, exp, rtol=0, atol=1e-6))
+    ctx.set_resident_outputs(False)
+    lazy = ctx.plan_dijkstra_batch(seeds[sub], targets[sub], goal_dist_offset=0.3, cost_limit=0.8, want_fields=False, path_cap=16384)
+    assert ctx.device_output(0, 4) == 0                                # no vector map anywhere
+    assert [int(c) for c in lazy["codes"]] == [int(c) for c in full["codes"]]
+    n_vec = 0
+    for p in plans:
+        for t, b, exp in want[p]:
+            got = ctx.vector_at(t, b, slot=int(p))
+            assert (got is None) == (exp is None), (p, t)
+            if got is not None:
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), (p, t)   # the same float operations: bit-equal
+                n_vec += 1
+    assert n_vec > 60
+    ctx.set_dijkstra_engine("auto")
