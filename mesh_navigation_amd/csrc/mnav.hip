@@ -389,7 +389,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 // Same functions, same decisions as eval_cvp (held against it in the CPU model on every evaluation); which vertices are
 // evaluated concurrently differs, which the fixed-point iteration does not care about.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kWideSlots = 416;          // items per wave and round: 64 vertices x 6.5 faces (20 KB of LDS; with the table below: seven waves per CU)
+#ifndef MNAV_WIDE_VERTS
+#define MNAV_WIDE_VERTS 32
+#endif
+constexpr uint32_t kWideVerts = MNAV_WIDE_VERTS;   // work-list entries per wave and round (64, or 32: half the LDS image and shorter rounds for more resident waves)
+constexpr uint32_t kWideSlots = (kWideVerts * 13u) / 2u;   // items per wave and round: 6.5 faces per vertex (64 vertices: 20 KB of LDS; with the table below seven waves per CU)
+constexpr int kWideOcc = kWideVerts == 64u ? 2 : 3;  // waves per SIMD the register allocator must reach
 constexpr uint32_t kWideSeen = 512;           // direct-mapped table of vertices this wave has pushed in this launch (see push_many)
 constexpr uint32_t kWideMaxFaces = 32;        // faces of one vertex that go through the items; beyond: the serial rule (eval_cvp)
 // items field-major: phase A stores a field of 64 consecutive slots at a time, phase B lanes read only the fields they look at
@@ -457,7 +462,7 @@ __device__ __forceinline__ void push_many(StepCtx& S, uint32_t (&u)[N], uint32_t
   for (int k = 0; k < N; ++k) if (ok[k]) { if (idx < S.P->cap) S.next[idx] = u[k]; ++idx; }
 }
 
-constexpr int kWidePassesPerBatch = 4;        // face passes whose loads are in flight together (4 x 64 faces)
+constexpr int kWidePassesPerBatch = kWideVerts == 64u ? 4 : 2;   // face passes whose loads are in flight together
 
 #ifdef MNAV_WIDE_TIMING                   // debugging aid: cycles per phase of wide_round, summed over all waves
 __device__ unsigned long long g_wide_timing[12];   // [0..6] cycles per phase, [8] rounds, [9] active entries, [10] evaluated, [11] serial-rule vertices
@@ -582,7 +587,7 @@ __device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl&
   }
   // ---- pushes: one lane per face of the vertices that moved, the vertex itself when its cascade key moved
   {
-    constexpr int kPasses = (int)(kWideSlots / kWave);
+    constexpr int kPasses = (int)((kWideSlots + kWave - 1) / kWave);
     uint32_t u[2 * kPasses + 1];
 #pragma unroll
     for (int p = 0; p < kPasses; ++p) {
@@ -759,8 +764,8 @@ __global__ __launch_bounds__(256) void k_cvp_ctl(const Plan* __restrict__ plans,
       Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
       P.cnt[(j + 1) % 3] = z;
       if (!cur.done) {
-        if (P.seed_mask == nullptr && cur.repair == 0) chunks = (cur.n + cur.wread + kWave - 1) / kWave;
-        else if (P.seed_mask == nullptr && cur.repair <= 2) chunks = (P.V + kWave - 1) / kWave;   // repair sweep / rebuild: over all vertices
+        if (P.seed_mask == nullptr && cur.repair == 0) chunks = (cur.n + cur.wread + kWideVerts - 1) / kWideVerts;
+        else if (P.seed_mask == nullptr && cur.repair <= 2) chunks = (P.V + kWideVerts - 1) / kWideVerts;   // repair sweep / rebuild: over all vertices
         else prefix[n + 1u + atomicAdd(&s_rep, 1u)] = p;              // band cut (no evaluation): k_step_repair; its list follows the prefix sums
       }
     }
@@ -796,7 +801,7 @@ __device__ __forceinline__ uint32_t wide_find_plan(const uint32_t* __restrict__ 
 }
 
 // bounded by its LDS image (seven waves per CU), not by registers
-__global__ __launch_bounds__(kWave, 2) void k_step_wide(const Plan* __restrict__ plans, uint32_t n, int j, const uint32_t* __restrict__ prefix,
+__global__ __launch_bounds__(kWave, kWideOcc) void k_step_wide(const Plan* __restrict__ plans, uint32_t n, int j, const uint32_t* __restrict__ prefix,
                                                         const WideSched* __restrict__ sched)
 {
   __shared__ WideLds s_wide;
@@ -821,16 +826,17 @@ __global__ __launch_bounds__(kWave, 2) void k_step_wide(const Plan* __restrict__
     const uint32_t ce = min(c1, pe);
     if (cur.repair == 0) {
       for (uint32_t c = c0; c < ce; ++c) {
-        const uint32_t i = (c - pb) * kWave + (uint32_t)lane;
-        const bool active = i < ntot;
+        const uint32_t i = (c - pb) * kWideVerts + (uint32_t)lane;
+        const bool active = (uint32_t)lane < kWideVerts && i < ntot;
         const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
         wide_round<0>(S, P, cur, s_wide, active, v, lane);
       }
     } else {
       for (uint32_t c = c0; c < ce; ++c) {                             // a sweep over the vertices themselves
-        const uint32_t v = (c - pb) * kWave + (uint32_t)lane;
-        if (cur.repair == 1) wide_round<1>(S, P, cur, s_wide, v < P.V, v < P.V ? v : 0u, lane);
-        else wide_round<2>(S, P, cur, s_wide, v < P.V, v < P.V ? v : 0u, lane);
+        const uint32_t v = (c - pb) * kWideVerts + (uint32_t)lane;
+        const bool act = (uint32_t)lane < kWideVerts && v < P.V;
+        if (cur.repair == 1) wide_round<1>(S, P, cur, s_wide, act, act ? v : 0u, lane);
+        else wide_round<2>(S, P, cur, s_wide, act, act ? v : 0u, lane);
       }
     }
     const float wmin = wave_min(S.lmin);
@@ -2848,7 +2854,7 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   if (wide) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    G = 7u * (uint32_t)ncu;                                           // waves of the whole batch, not per plan: what stays resident
+    G = (kWideVerts == 64u ? 7u : 12u) * (uint32_t)ncu;               // waves of the whole batch, not per plan: what stays resident
     if (const char* e = getenv("MNAV_WIDE_WAVES")) G = (uint32_t)std::max(1, atoi(e));
     if (ctx->wide_cap < n + 1u) {
       (void)hipFree(ctx->d_wide_prefix); ctx->d_wide_prefix = nullptr;
