@@ -733,6 +733,7 @@ __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) {
 // control blocks and the prefix sums of the plans' chunk counts; k_step_wide then runs exactly as many waves as stay resident,
 // each taking an equal, contiguous share of the step's chunks, whatever plans they belong to.
 struct WideSched { uint32_t total, n_repair, pad[2]; };
+constexpr uint32_t kWideGroupsMax = 8;        // groups of plans a CVP batch is stepped in, each on its own stream (branch of the captured graph)
 constexpr uint32_t kRepairRows = 16;          // grid rows of k_step_repair: plans in a repair step are rare, a row takes several if there are more
 
 // the plans that k_cvp_ctl found in a repair / rebuild / cut step (rep_list = prefix + n + 1 ...): the 8-lane sweeps over all vertices
@@ -2537,6 +2538,7 @@ struct mnav_ctx {
   bool use_graph = true;
   uint32_t* d_wide_prefix = nullptr; WideSched* d_wide_sched = nullptr; uint32_t wide_cap = 0;   // k_cvp_ctl -> k_step_wide
   float* d_vec3 = nullptr;                                           // mnav_vector_at after a paths-only batch
+  uint32_t wide_groups = 1; hipStream_t stream_g[kWideGroupsMax] = {}; hipEvent_t ev_fork[kWideGroupsMax] = {};   // CVP batches in groups on their own streams ([0] unused / fork event)
   uint32_t cvp_wide_min_batch = 24;                                  // CVP batches of at least this many plans run k_step_wide
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
@@ -2716,15 +2718,36 @@ uint32_t blocks_per_plan(const mnav_ctx* ctx)
 template <uint32_t PLANNER>
 int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count, bool wide)
 {
+  const bool fork = wide && ctx->wide_groups > 1;
+  if (fork) {                                                          // the other streams join (the capture of) the first
+    HIPCHK(hipEventRecord(ctx->ev_fork[0], ctx->stream));
+    for (uint32_t g = 1; g < ctx->wide_groups; ++g) HIPCHK(hipStreamWaitEvent(ctx->stream_g[g], ctx->ev_fork[0], 0));
+  }
   for (int j = 0; j < count; ++j) {
     if (wide) {
-      // controller + shares of all plans, the wide kernel with as many waves as stay resident (7 per CU: its LDS image), and the
-      // 8-lane kernel for the plans that are in a repair / rebuild / cut step (a sweep over all vertices: any grid will do)
-      hipLaunchKernelGGL(k_cvp_ctl, dim3(1), dim3(256), 0, ctx->stream, ctx->d_plans, n, j % 6, ctx->d_wide_prefix, ctx->d_wide_sched);
-      hipLaunchKernelGGL(k_step_wide, dim3(G), dim3(kWave), 0, ctx->stream, ctx->d_plans, n, j % 6, ctx->d_wide_prefix, ctx->d_wide_sched);
-      hipLaunchKernelGGL(k_step_repair, dim3(blocks_per_plan(ctx), kRepairRows), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6, ctx->d_wide_prefix + n + 1u, ctx->d_wide_sched);
+      // per group of plans: controller + shares, the wide kernel with as many waves as stay resident, and the 8-lane kernel for the
+      // plans in a band cut.  The groups run on two streams (two branches of the captured graph): a step of one group is ~0.6
+      // rounds of the resident waves, so where one group's last round leaves the machine half empty the other group's step fills it
+      uint32_t off = 0, poff = 0;
+      for (uint32_t g = 0; g < ctx->wide_groups; ++g) {
+        const uint32_t ng = (n * (g + 1u)) / ctx->wide_groups - off;
+        hipStream_t st = g == 0 ? ctx->stream : ctx->stream_g[g];
+        if (ng) {
+          hipLaunchKernelGGL(k_cvp_ctl, dim3(1), dim3(256), 0, st, ctx->d_plans + off, ng, j % 6, ctx->d_wide_prefix + poff, ctx->d_wide_sched + g);
+          hipLaunchKernelGGL(k_step_wide, dim3(G), dim3(kWave), 0, st, ctx->d_plans + off, ng, j % 6, ctx->d_wide_prefix + poff, ctx->d_wide_sched + g);
+          hipLaunchKernelGGL(k_step_repair, dim3(blocks_per_plan(ctx), kRepairRows), dim3(kWave), 0, st, ctx->d_plans + off, j % 6,
+                             ctx->d_wide_prefix + poff + ng + 1u, ctx->d_wide_sched + g);
+        }
+        off += ng; poff += 2u * ng + 2u;
+      }
     }
     else hipLaunchKernelGGL(k_step<PLANNER>, dim3(G, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, j % 6);
+  }
+  if (fork) {
+    for (uint32_t g = 1; g < ctx->wide_groups; ++g) {
+      HIPCHK(hipEventRecord(ctx->ev_fork[g], ctx->stream_g[g]));
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_fork[g], 0));
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -2734,7 +2757,7 @@ template <uint32_t PLANNER>
 int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G, bool wide)
 {
   if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, getenv("MNAV_DEBUG_CHUNK") ? atoi(getenv("MNAV_DEBUG_CHUNK")) : kChunk, wide);   // debug: finer control-block trace
-  const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)(wide ? 1u : 0u) << 59) | ((uint64_t)n << 32) | G;
+  const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)(wide ? ctx->wide_groups : 0u) << 57) | ((uint64_t)n << 32) | G;
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t g = nullptr;
@@ -2856,13 +2879,21 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     G = (kWideVerts == 64u ? 7u : 12u) * (uint32_t)ncu;               // waves of the whole batch, not per plan: what stays resident
     if (const char* e = getenv("MNAV_WIDE_WAVES")) G = (uint32_t)std::max(1, atoi(e));
+    ctx->wide_groups = std::min(4u, std::max(1u, n / 40u));            // measured on the benched C3 configuration, plans/s with 1 / 2 / 3 / 4 / 8 groups:
+                                                                      // 128 plans 277 / 315 / 320 / 320 / 221, 512 plans 330 / 425 / 463 / 468 / 422
+    if (const char* e = getenv("MNAV_CVP_GROUPS")) ctx->wide_groups = (uint32_t)std::min(std::max(1, atoi(e)), (int)kWideGroupsMax);
+    if (ctx->wide_groups > n) ctx->wide_groups = 1;
     if (ctx->wide_cap < n + 1u) {
       (void)hipFree(ctx->d_wide_prefix); ctx->d_wide_prefix = nullptr;
-      HIPCHK(hipMalloc((void**)&ctx->d_wide_prefix, 4 * (size_t)(2u * n + 2u)));   // prefix sums [n + 1], then the repair list [n]
+      HIPCHK(hipMalloc((void**)&ctx->d_wide_prefix, 4 * (size_t)(2u * n + 2u * kWideGroupsMax + 8u)));   // per group: prefix sums [ng + 1], then the list of plans in a band cut [ng]
       ctx->wide_cap = n + 1u;
       drop_graphs(ctx);                                               // (captured with the old pointer)
     }
-    if (!ctx->d_wide_sched) HIPCHK(hipMalloc((void**)&ctx->d_wide_sched, sizeof(WideSched)));
+    if (!ctx->d_wide_sched) HIPCHK(hipMalloc((void**)&ctx->d_wide_sched, kWideGroupsMax * sizeof(WideSched)));
+    if (!ctx->stream_g[1]) {
+      for (uint32_t g = 1; g < kWideGroupsMax; ++g) HIPCHK(hipStreamCreateWithFlags(&ctx->stream_g[g], hipStreamNonBlocking));
+      for (auto& e : ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
   }
   uint32_t launches = 0;
   int rc = 0;
@@ -3263,6 +3294,8 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->d_tplans);
   (void)hipFree(ctx->shard.d_iface_vert); (void)hipFree(ctx->shard.d_iface_owner); (void)hipFree(ctx->shard.d_wake_ptr); (void)hipFree(ctx->shard.d_wake_tile);
   (void)hipFree(ctx->d_wide_prefix); (void)hipFree(ctx->d_wide_sched); (void)hipFree(ctx->d_vec3);
+  for (auto& st : ctx->stream_g) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  for (auto& e : ctx->ev_fork) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend); (void)hipFree(ctx->shard.d_walk);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
