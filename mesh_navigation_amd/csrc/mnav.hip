@@ -2539,7 +2539,7 @@ struct mnav_ctx {
   uint32_t* d_wide_prefix = nullptr; WideSched* d_wide_sched = nullptr; uint32_t wide_cap = 0;   // k_cvp_ctl -> k_step_wide
   float* d_vec3 = nullptr;                                           // mnav_vector_at after a paths-only batch
   uint32_t wide_groups = 1; hipStream_t stream_g[kWideGroupsMax] = {}; hipEvent_t ev_fork[kWideGroupsMax] = {};   // CVP batches in groups on their own streams ([0] unused / fork event)
-  uint32_t cvp_wide_min_batch = 24;                                  // CVP batches of at least this many plans run k_step_wide
+  uint32_t cvp_wide_min_batch = 32;                                  // CVP batches of at least this many plans run k_step_wide
   float delta_user = 0.f, delta_auto = 0.f;
   uint32_t last_planner = 0, last_n = 0;
   std::vector<uint32_t> last_target; double last_offset = 0.0;   // Dijkstra: robot vertex per device slot, goal_dist_offset of the last call

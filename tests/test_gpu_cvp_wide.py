@@ -1,6 +1,6 @@
 """The wide CVP step kernel (k_step_wide: 64 work-list entries per wave and round; phase A one lane per incident face,
 phase B one lane per vertex over the prepared items; mnav_eval.h make_cvp_item / eval_cvp_items) against the oracle
-(cvp_mesh_planner.cpp:369-556, 651-918) and against the 8-lane replay: batches pick it from 24 plans on, MNAV_CVP_WIDE forces
+(cvp_mesh_planner.cpp:369-556, 651-918) and against the 8-lane replay: batches pick it from 32 plans on, MNAV_CVP_WIDE forces
 either.  Potential and predecessors bit for bit."""
 import numpy as np
 import pytest
@@ -32,7 +32,7 @@ def test_wide_batch_on_layered_costs_matches_oracle_and_the_8_lane_replay(gpu_ct
     case.upload(ctx)
     sps, sfs, tfs = _batch(case, 32, 11)
     monkeypatch.delenv("MNAV_CVP_WIDE", raising=False)
-    wide = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)         # 32 >= 24 plans: the wide kernel
+    wide = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)         # 32 plans: the wide kernel
     monkeypatch.setenv("MNAV_CVP_WIDE", "0")
     narrow = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)
     monkeypatch.delenv("MNAV_CVP_WIDE")
