@@ -20,5 +20,19 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" 
   MNAV_NO_GRAPH=1 PERF_BATCHES=128 timeout 600 rocprofv3 --pmc $grp --output-format csv -d $OUT/cvp_pmc_$i -o pmc -- python $R/tools/gpu_cvp_perf.py > $OUT/cvp_pmc_$i.log 2>&1
 done
 rm -f $OUT/trace/*kernel_trace.csv $OUT/cvp_trace/*kernel_trace.csv $OUT/*/*/*kernel_trace.csv       # tens of MB; the stats files are the summary
+# the per-dispatch counter files of the CVP passes are tens of MB (three kernels per step): keep the sums per (kernel, counter)
+python - <<'PY'
+import csv, glob, os, collections
+root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/prof_r04"
+for f in glob.glob(root + "/*pmc*/**/*counter_collection.csv", recursive=True):
+    agg = collections.defaultdict(float); disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"], r["Counter_Name"])
+        agg[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
+    with open(f, "w", newline="") as g:
+        w = csv.writer(g); w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value", "Dispatch_Id", "Launches"])
+        for (kn, cn), v in sorted(agg.items()):
+            w.writerow([kn, cn, repr(v), "sum", len(disp[(kn, cn)])])
+PY
 find $OUT -name "*.csv" | head -20
 du -sh $OUT

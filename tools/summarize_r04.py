@@ -103,7 +103,9 @@ nl = collections.defaultdict(set)
 for fcsv in glob.glob(os.path.join(G, "cvp_pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(fcsv)):
         k = short(r["Kernel_Name"])
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); nl[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r.get("Launches"): nl[(k, r["Counter_Name"])].update(range(int(r["Launches"])))     # (files reduced on the GPU box: sums + launch counts)
+        else: nl[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
 wide_ns = sum(float(r["TotalDurationNs"]) for r in crow if short(r["Name"]).startswith("k_step_wide"))
 with open(os.path.join(P, f"{TAG}_pmc_cvp.md"), "w") as f:
     f.write(f"# profiles/{TAG}_pmc_cvp.md -- shader-core counters of the CVP batch kernels\n\n")
@@ -117,10 +119,11 @@ with open(os.path.join(P, f"{TAG}_pmc_cvp.md"), "w") as f:
     w = agg.get("k_step_wide", {})
     if w and wide_ns > 0:
         cyc = wide_ns * 1e-9 * 2.4e9                                   # kernel time of the traced run in cycles at 2.4 GHz
-        f.write(f"\nReading for `k_step_wide` (kernel time in the traced run {wide_ns/1e6:.0f} ms = {cyc:.3g} cycles; 1024 SIMDs):\n")
+        f.write(f"\nReading for `k_step_wide` (sum of its kernel durations in the traced run {wide_ns/1e6:.0f} ms = {cyc:.3g} cycles; the batch is stepped in three groups on "
+                "their own streams, whose kernels overlap: the sum is an upper bound of the time the kernel was on the machine, so the two figures below are lower bounds; 1024 SIMDs):\n")
         if "SQ_WAVE_CYCLES" in w:
             f.write(f"* resident waves on average: SQ_WAVE_CYCLES x 4 / cycles = **{w['SQ_WAVE_CYCLES'] * 4 / cyc:.0f}** "
-                    f"(= {w['SQ_WAVE_CYCLES'] * 4 / cyc / 1024:.2f} per SIMD; the 22 KB LDS image allows 7 per CU = 1 792)\n")
+                    f"(= {w['SQ_WAVE_CYCLES'] * 4 / cyc / 1024:.2f} per SIMD; 12 KB of LDS and 168 VGPRs allow 12 per CU = 3 072)\n")
         if "SQ_ACTIVE_INST_VALU" in w:
             f.write(f"* VALU busy: SQ_ACTIVE_INST_VALU x 4 / (cycles x 1024 SIMDs) = **{w['SQ_ACTIVE_INST_VALU'] * 4 / (cyc * 1024) * 100:.0f} %**\n")
         if "SQ_INSTS_VALU" in w and "SQ_INSTS_VMEM_RD" in w and w["SQ_INSTS_VMEM_RD"]:
@@ -128,5 +131,5 @@ with open(os.path.join(P, f"{TAG}_pmc_cvp.md"), "w") as f:
         ev = cline.get("evals_per_plan", 0) * cline.get("batch", 0) * 2
         if ev and "SQ_INSTS_VALU" in w:
             f.write(f"* wave-level VALU instructions per vertex evaluation: {w['SQ_INSTS_VALU'] / ev:.1f} (two batches, {ev:.3g} evaluations; "
-                    f"the 8-lane kernel of round 2: 1.85e11 / 7.4e8 = 250)\n")
+                    f"the 8-lane kernel of round 2: 1.85e11 / 7.4e8 = 250; the 64-entry version of this kernel: 71 -- with 32 entries per round half the lanes idle in the per-vertex phases)\n")
 print("cvp:", {k: dict(v) for k, v in agg.items() if k.startswith("k_step_wide")})
