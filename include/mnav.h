@@ -163,6 +163,11 @@ uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
  * same mixed float/double expression (:606-610), otherwise only the vertex costs change ("edge_cost_factor is 0,
  * skipping edge cost update", :568-572).  Nothing but the n ids and values crosses PCIe.  Returns 0 / <0. */
 int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, const float* values);
+/* The caller's own incremental edge weights (MeshMap::updateEdgeWeights, mesh_map.cpp:563-618, already run on the host by
+ * MeshMap::layerChanged :454-493): `values[i]` replaces the weight of edge `edge_ids[i]`.  Together with mnav_update_costs on
+ * weights that were uploaded (mnav_upload_costs: then mnav_update_costs only touches the vertex costs) a cost change of the
+ * map costs O(changed) instead of a pass over all vertices and edges. */
+int mnav_update_edge_weights(mnav_ctx* ctx, uint32_t n, const uint32_t* edge_ids, const float* values);
 /* Copies of the resident vertex costs (V) and edge weights (E); either pointer may be NULL. */
 int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weights_out);
 

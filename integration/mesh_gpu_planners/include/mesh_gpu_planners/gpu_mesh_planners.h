@@ -29,6 +29,7 @@
 #include <rclcpp/rclcpp.hpp>
 
 #include "mnav.h"
+#include "mesh_gpu_planners/cost_observer_layer.h"
 
 namespace mesh_gpu_planners
 {
@@ -45,8 +46,9 @@ public:
   bool ok() const { return ctx_ != nullptr; }
   uint32_t numVertices() const { return V_; }
   bool uploadMesh(mesh_map::MeshMap& map, std::string& err);
-  // true: the device copy is current.  One signing pass over the map's arrays per call, an upload only when they
-  // changed; with setStaticCosts(true) not even that unless `force`
+  // true: the device copy is current.  With a CostObserverLayer in the map's layer graph: the vertices it filed since the
+  // last call and their edges are updated (O(changed)); without one: one signing pass over the map's arrays per call, an
+  // upload only when they changed; with setStaticCosts(true) not even that unless `force`
   bool syncCosts(mesh_map::MeshMap& map, std::string& err, bool force = false);
   void setStaticCosts(bool on) { static_costs_ = on; }
 private:
@@ -57,6 +59,8 @@ private:
   bool have_costs_ = false;
   std::vector<float> costs_, weights_;
   std::vector<uint8_t> invalid_;
+  std::shared_ptr<CostChangeLog> log_;       // the map's change log (cost_observer_layer.h) and this mirror's place in it
+  int log_id_ = -1;
 };
 
 class GpuDijkstraMeshPlanner : public mbf_mesh_core::MeshPlanner

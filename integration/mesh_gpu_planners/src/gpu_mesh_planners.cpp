@@ -3,6 +3,8 @@
 // reference each block stands in for.
 #include <mesh_gpu_planners/gpu_mesh_planners.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <limits>
 
@@ -18,8 +20,23 @@ using Result = mbf_msgs::action::GetPath::Result;
 using geometry_msgs::msg::PoseStamped;
 
 // ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+std::atomic<uint64_t> g_full_uploads{ 0 }, g_incremental_updates{ 0 }, g_signing_passes{ 0 };
+}
+extern "C" void mesh_gpu_planners_cost_sync_counts(uint64_t* full_uploads, uint64_t* incremental_updates, uint64_t* signing_passes)
+{
+  if (full_uploads) *full_uploads = g_full_uploads.load();
+  if (incremental_updates) *incremental_updates = g_incremental_updates.load();
+  if (signing_passes) *signing_passes = g_signing_passes.load();
+}
+
 DeviceMap::DeviceMap(int device) : ctx_(mnav_create(device)) {}
-DeviceMap::~DeviceMap() { if (ctx_) mnav_destroy(ctx_); }
+DeviceMap::~DeviceMap()
+{
+  if (log_ && log_id_ >= 0) log_->unsubscribe(log_id_);
+  if (ctx_) mnav_destroy(ctx_);
+}
 
 // The half-edge mesh as flat arrays, in the reference's own ids (handle indices), once per map.
 bool DeviceMap::uploadMesh(mesh_map::MeshMap& map, std::string& err)
@@ -61,6 +78,9 @@ bool DeviceMap::uploadMesh(mesh_map::MeshMap& map, std::string& err)
   }
   mnav_set_resident_outputs(ctx_, 1);            // potential / predecessors / vector map stay on the device until asked for
   have_costs_ = false;
+  if (log_ && log_id_ >= 0) log_->unsubscribe(log_id_);
+  log_ = CostChangeLog::of(&map);                // from now on every change an observer layer files is kept for this mirror
+  log_id_ = log_->subscribe();
   return true;
 }
 
@@ -75,6 +95,38 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
   if (static_costs_ && have_costs_ && !force) return true;
   const auto& vc = map.vertexCosts();
   const auto& ew = map.edgeWeights();
+  if (have_costs_ && !force && log_ && log_->attached()) {
+    // The change signal (cost_observer_layer.h): MeshMap::layerChanged (mesh_map.cpp:454-493) has updated vertex_costs and, through
+    // updateEdgeWeights(changed) (:563-618), the weights of the changed vertices' edges; exactly those go to the device.
+    // (`invalid` only changes when a planner trips over a broken vertex, dijkstra :312-321: picked up by `reload_costs`.)
+    const std::vector<uint32_t> ids = log_->take(log_id_);
+    if (ids.empty()) return true;
+    const auto mesh = map.mesh();
+    std::vector<float> vals(ids.size());
+    std::vector<uint32_t> eids;
+    std::vector<lvr2::EdgeHandle> edges;
+    for (size_t i = 0; i < ids.size(); ++i) {
+      const lvr2::VertexHandle vH(ids[i]);
+      const auto c = std::as_const(vc).get(vH);
+      vals[i] = c ? *c : 0.f;
+      edges.clear();
+      mesh->getEdgesOfVertex(vH, edges);
+      for (const auto eH : edges) eids.push_back((uint32_t)eH.idx());
+    }
+    std::sort(eids.begin(), eids.end());
+    eids.erase(std::unique(eids.begin(), eids.end()), eids.end());
+    std::vector<float> evals(eids.size());
+    for (size_t i = 0; i < eids.size(); ++i) {
+      const auto w = std::as_const(ew).get(lvr2::EdgeHandle((size_t)eids[i]));
+      evals[i] = w ? *w : std::numeric_limits<float>::infinity();
+    }
+    if (mnav_update_costs(ctx_, (uint32_t)ids.size(), ids.data(), vals.data()) != 0 ||
+        mnav_update_edge_weights(ctx_, (uint32_t)eids.size(), eids.data(), evals.data()) != 0) { err = mnav_last_error(ctx_); return false; }
+    ++g_incremental_updates;
+    return true;
+  }
+  ++g_signing_passes;
+  if (log_) (void)log_->take(log_id_);            // what was filed up to here is part of the full copy taken below; later changes stay pending
   uint64_t h = 0xCBF29CE484222325ull;
   auto mix = [&h](uint32_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; };
   for (uint32_t v = 0; v < V_; ++v) {
@@ -105,6 +157,7 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
     weights_[e] = w ? *w : std::numeric_limits<float>::infinity();
   }
   if (mnav_upload_costs(ctx_, costs_.data(), weights_.data(), invalid_.data()) != 0) { err = mnav_last_error(ctx_); return false; }
+  ++g_full_uploads;
   cost_hash_ = h; have_costs_ = true;
   return true;
 }

@@ -24,7 +24,7 @@ SYMBOLS = [
     "mnav_compute_edge_weights", "mnav_combine_costs", "mnav_plan_dijkstra", "mnav_plan_cvp", "mnav_plan_dijkstra_batch", "mnav_plan_cvp_batch",
     "mnav_cancel", "mnav_get_stats", "mnav_get_timing", "mnav_set_band_width", "mnav_set_dijkstra_engine", "mnav_device_output",
     "mnav_algorithmic_bytes", "mnav_shard_setup", "mnav_shard_setup_partition", "mnav_shard_walk", "mnav_device_bytes", "mnav_shard_info", "mnav_shard_begin", "mnav_shard_rounds", "mnav_shard_apply", "mnav_shard_rounds_async", "mnav_shard_apply_async",
-    "mnav_shard_finalize", "mnav_update_costs", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
+    "mnav_shard_finalize", "mnav_update_costs", "mnav_update_edge_weights", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
 ]
@@ -122,6 +122,8 @@ def load(path: str | None = None):
     L.mnav_vector_at.argtypes = [vp, u32, vp, vp, vp]
     L.mnav_update_costs.restype = C.c_int
     L.mnav_update_costs.argtypes = [vp, u32, vp, vp]
+    L.mnav_update_edge_weights.restype = C.c_int
+    L.mnav_update_edge_weights.argtypes = [vp, u32, vp, vp]
     L.mnav_download_costs.restype = C.c_int
     L.mnav_download_costs.argtypes = [vp, vp, vp]
     L.mnav_layer_upload.restype = C.c_int

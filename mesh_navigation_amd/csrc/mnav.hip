@@ -3583,6 +3583,31 @@ int mnav_update_costs(mnav_ctx* ctx, uint32_t n, const uint32_t* vertex_ids, con
   return 0;
 }
 
+int mnav_update_edge_weights(mnav_ctx* ctx, uint32_t n, const uint32_t* edge_ids, const float* values)
+{
+  if (!ctx) return -1;
+  ctx->err.clear();
+  if (!ctx->have_costs) { ctx->err = "no costs resident yet (mnav_upload_costs / mnav_compute_edge_weights / mnav_combine_costs first)"; return -1; }
+  if (n == 0) return 0;
+  if (!edge_ids || !values) { ctx->err = "null input array"; return -1; }
+  for (uint32_t i = 0; i < n; ++i) if (edge_ids[i] >= ctx->E) { ctx->err = "edge id out of range"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  DevTmp<uint32_t> d_ids; DevTmp<float> d_vals;
+  HIPCHK(hipMalloc(d_ids.out(), sizeof(uint32_t) * n));
+  HIPCHK(hipMalloc(d_vals.out(), sizeof(float) * n));
+  int rc = 0;
+  if (hipMemcpyAsync(d_ids, edge_ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(d_vals, values, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "upload failed"; rc = -1; }
+  if (rc == 0) {
+    hipLaunchKernelGGL(k_scatter_costs, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, n, d_ids, d_vals, ctx->d_w);   // (a scatter of floats by index)
+    if (hipGetLastError() != hipSuccess) { ctx->err = "edge weight update failed"; rc = -1; }
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  if (rc) return rc;
+  ctx->nbr_valid = ctx->crn_valid = false;                          // the cost-limit folded copies (and the tiles' weights behind them) are rebuilt on the next plan
+  return 0;
+}
+
 int mnav_download_costs(mnav_ctx* ctx, float* vertex_costs_out, float* edge_weights_out)
 {
   if (!ctx || !ctx->have_costs) { if (ctx) ctx->err = "no costs resident"; return -1; }

@@ -214,6 +214,16 @@ class RefMap:
             L.ref_param_string_array(self._h, ns + b"layers", b"costs")
             L.ref_param_string(self._h, ns + b"costs.type", b"ref_harness/ArrayLayer")
             L.ref_param_string(self._h, ns + b"default_layer", b"costs")
+        elif layers == "array+observer":
+            # the harness-served default layer plus the GPU planners' change observer (integration/mesh_gpu_planners:
+            # mesh_gpu_planners/CostObserverLayer, the default layer as its input)
+            vc = np.zeros(self.V, np.float32) if vertex_costs is None else _f32(vertex_costs)
+            L.ref_set_array_layer(self._h, b"costs", self.V, _p(vc), None if lethal is None else _p(_u8(lethal)))
+            L.ref_param_string_array(self._h, ns + b"layers", b"costs,gpu_cost_observer")
+            L.ref_param_string(self._h, ns + b"costs.type", b"ref_harness/ArrayLayer")
+            L.ref_param_string(self._h, ns + b"gpu_cost_observer.type", b"mesh_gpu_planners/CostObserverLayer")
+            L.ref_param_string_array(self._h, ns + b"gpu_cost_observer.inputs", b"costs")
+            L.ref_param_string(self._h, ns + b"default_layer", b"costs")
         elif layers == "array+inflation":
             # a harness-served layer with lethal flags feeding the reference's InflationLayer (the default layer)
             vc = np.zeros(self.V, np.float32) if vertex_costs is None else _f32(vertex_costs)
@@ -328,6 +338,13 @@ class RefMap:
         if not lib().ref_inflation_fields(self._h, name.encode(), _p(dist), _p(vec)):
             raise KeyError(name)
         return dist, vec
+
+    @staticmethod
+    def gpu_plugin_cost_sync_counts():
+        """(full uploads, incremental updates, signing passes) of the GPU planners' device mirrors in this process"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib().mesh_gpu_planners_cost_sync_counts(C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def update_array_layer(self, ids, values, lethal=None, name="costs"):
         ids, values = _u32(ids), _f32(values)

@@ -54,7 +54,9 @@ REPO="$HERE/../.."
 if [ -f "$REPO/mesh_navigation_amd/libmnav.so" ]; then
   $CXX $CXXFLAGS $INC -I"$REPO/integration/mesh_gpu_planners/include" -I"$REPO/include" \
     -c "$REPO/integration/mesh_gpu_planners/src/gpu_mesh_planners.cpp" -o "$OUT/obj/gpu_mesh_planners.o"
-  $CXX -shared -o "$OUT/libmnav_ref_gpu.so" $OBJS "$OUT/obj/ref_harness.o" "$OUT/obj/gpu_mesh_planners.o" \
+  $CXX $CXXFLAGS $INC -I"$REPO/integration/mesh_gpu_planners/include" -I"$REPO/include" \
+    -c "$REPO/integration/mesh_gpu_planners/src/cost_observer_layer.cpp" -o "$OUT/obj/cost_observer_layer.o"
+  $CXX -shared -o "$OUT/libmnav_ref_gpu.so" $OBJS "$OUT/obj/ref_harness.o" "$OUT/obj/gpu_mesh_planners.o" "$OUT/obj/cost_observer_layer.o" \
     -L"$REPO/mesh_navigation_amd" -lmnav -Wl,-rpath,'$ORIGIN/../../mesh_navigation_amd' -lpthread
   echo "built $OUT/libmnav_ref_gpu.so"
 fi

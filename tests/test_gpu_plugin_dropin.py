@@ -183,3 +183,42 @@ def test_gpu_plugin_follows_cost_changes_of_the_map(world):
     c4, p4, k4, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     assert c4 == 0 and np.array_equal(p4, pr0) and k4 == kr3
     rm.plugin_release()
+
+
+def test_gpu_plugin_with_the_cost_observer_layer_updates_only_what_changed(world):
+    """With mesh_gpu_planners/CostObserverLayer in the map's layer graph (the default layer as its input) the plugin learns the
+    changed vertices through the reference's own notification chain (layer -> LayerManager::layer_changed -> MeshMap::layerChanged
+    -> dependents' onInputChanged, layer_manager.cpp:229-261) and updates its device copy in O(changed): no signing pass over the
+    map's arrays, no full upload -- and plans like the reference planner on the changed map."""
+    m, _, robot, goal = world
+    rm = R.RefMap(m.xyz, m.faces, layers="array+observer", vertex_costs=np.zeros(m.V, np.float32), edge_cost_factor=1.0)
+    full0, inc0, sign0 = R.RefMap.gpu_plugin_cost_sync_counts()
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_observed")
+    c0, p0, k0, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    cr0, pr0, kr0 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
+    full1, inc1, sign1 = R.RefMap.gpu_plugin_cost_sync_counts()
+    assert (full1 - full0, inc1 - inc0) == (1, 0)                      # initialize takes the full copy
+    # nothing changed: neither a signing pass nor an upload
+    c0b, p0b, _, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert np.array_equal(p0b, p0) and R.RefMap.gpu_plugin_cost_sync_counts() == (full1, inc1, sign1)
+    N = m.N
+    band = (np.arange(N // 4, 3 * N // 4)[:, None] * N + np.arange(N // 2 - 2, N // 2 + 2)[None, :]).ravel().astype(np.uint32)
+    rm.update_array_layer(band, np.full(band.shape[0], 0.9, np.float32))            # a costly band across the straight line
+    cr1, pr1, kr1 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    c1, p1, k1, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c1 == cr1 == 0 and np.array_equal(p1, pr1) and k1 == kr1 and not np.array_equal(pr1, pr0)
+    full2, inc2, sign2 = R.RefMap.gpu_plugin_cost_sync_counts()
+    assert (full2 - full1, inc2 - inc1, sign2 - sign1) == (0, 1, 0)    # ... through ONE incremental update
+    rm.update_array_layer(band[::2], np.zeros(band[::2].shape[0], np.float32))      # two changes between two plans: both arrive
+    rm.update_array_layer(band[1::2], np.full(band[1::2].shape[0], 0.3, np.float32))
+    cr2, pr2, kr2 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c2 == cr2 == 0 and np.array_equal(p2, pr2) and k2 == kr2
+    assert R.RefMap.gpu_plugin_cost_sync_counts() == (full2, inc2 + 1, sign2)
+    # the CVP plugin on the same map has its own mirror and its own place in the log
+    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_observed")
+    cc, pc, kc, mc = rm.plugin_make_plan(pose(robot), pose(goal))
+    crc, prc, krc, mrc = rm.cvp_make_plan(pose(robot), pose(goal))
+    assert cc == crc and mc == mrc and len(pc) == len(prc) and (len(pc) == 0 or np.array_equal(pc, prc))
+    rm.plugin_release()

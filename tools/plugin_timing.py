@@ -22,11 +22,12 @@ def main():
     m = meshgen.terrain(n, 0.1, 21)
     rng = np.random.default_rng(3)
     costs = rng.uniform(0.0, 0.6, m.V).astype(np.float32)
-    rm = R.RefMap(m.xyz, m.faces, vertex_costs=costs, edge_cost_factor=1.0)
+    observer = "--observer" in sys.argv              # mesh_gpu_planners/CostObserverLayer in the map's layer graph: costs tracked by change signal
+    rm = R.RefMap(m.xyz, m.faces, layers="array+observer" if observer else "array", vertex_costs=costs, edge_cost_factor=1.0)
     t_map = time.time() - t0
     robot = m.xyz[m.vertex_at(0.85, 0.8)] + np.array([0.031, 0.017, 0.0], np.float32)
     goals = [m.xyz[m.vertex_at(0.12 + 0.05 * k, 0.2 + 0.03 * k)] + np.array([0.023, 0.011, 0.0], np.float32) for k in range(5)]
-    out = dict(V=int(m.V), map_s=round(t_map, 1))
+    out = dict(V=int(m.V), map_s=round(t_map, 1), cost_observer_layer=observer)
 
     def timed(fn, reps):
         ts = []
@@ -44,8 +45,22 @@ def main():
             assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "t_dij_" + label, **params)
             rm.plugin_make_plan(pose(robot), pose(goals[0]))            # warm: tables, graphs
             out["gpu_dijkstra_ms_" + label], out["dijkstra_poses"] = timed(lambda g: rm.plugin_make_plan(pose(robot), pose(g)), 10)
+            if observer and label == "no_sync":
+                # a cost change between two plans: 2 000 vertices of the default layer, picked up as ONE incremental update
+                ids = rng.choice(m.V, 2000, replace=False).astype(np.uint32)
+                c0 = R.RefMap.gpu_plugin_cost_sync_counts()
+                ts = []
+                for k in range(6):
+                    rm.update_array_layer(ids, rng.uniform(0.0, 0.6, ids.shape[0]).astype(np.float32))
+                    t = time.perf_counter()
+                    r = rm.plugin_make_plan(pose(robot), pose(goals[k % len(goals)]))
+                    ts.append((time.perf_counter() - t) * 1e3)
+                    assert r[0] == 0
+                c1 = R.RefMap.gpu_plugin_cost_sync_counts()
+                out["gpu_dijkstra_ms_no_sync_after_a_2000_vertex_cost_change"] = round(float(np.median(ts)), 3)
+                out["cost_syncs_during_those_plans"] = dict(full_uploads=c1[0] - c0[0], incremental_updates=c1[1] - c0[1], signing_passes=c1[2] - c0[2])
             rm.plugin_release()
-        for label, params in (("default", {}),
+        for label, params in () if observer else (("default", {}),      # (the observer run has changed the costs under the CVP goals)
                               ("device_walk", dict(sync_vector_map=False, publish_potential=False, static_costs=True, device_backtracking=True))):
             assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "t_cvp_" + label, step_width=0.25, **params)
             rm.plugin_make_plan(pose(robot), pose(goals[0]))
