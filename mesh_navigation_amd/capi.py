@@ -332,6 +332,13 @@ class MnavContext:
         if rc != 0:
             raise RuntimeError(f"mnav_update_costs failed ({rc}): {self._err()}")
 
+    def update_edge_weights(self, edge_ids, values):
+        """The caller's own incremental edge weights (MeshMap::updateEdgeWeights ran on the host): scatter into the resident weights."""
+        ids, vals = _u32(edge_ids), _f32(values)
+        rc = self._L.mnav_update_edge_weights(self._h, ids.shape[0], _p(ids), _p(vals))
+        if rc != 0:
+            raise RuntimeError(f"mnav_update_edge_weights failed ({rc}): {self._err()}")
+
     def download_costs(self):
         vc = np.empty(self.V, np.float32)
         w = np.empty(self.E, np.float32)

@@ -378,258 +378,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
   return x;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Wide CVP step (batches): a wave takes 64 work-list entries per round instead of 8.
-// The 8-lane replay above spends most of its instructions on in-group shuffles and serves 8 vertices per wave instruction.
-// Here the evaluation is cut where its data dependence allows (mnav_eval.h: make_cvp_item / eval_cvp_items):
-//   phase A, one lane per incident FACE of the 64 vertices (~384 faces = 6 passes of 64 lanes): fire event and float64
-//            candidate, neither depends on the vertex's own state -> a 48-byte item in LDS;
-//   phase B, one lane per VERTEX: the replay over its own items, serially, without a single shuffle;
-//   pushes,  one lane per face again (wave-aggregated list appends as before).
-// Same functions, same decisions as eval_cvp (held against it in the CPU model on every evaluation); which vertices are
-// evaluated concurrently differs, which the fixed-point iteration does not care about.
-// ---------------------------------------------------------------------------------------------
-#ifndef MNAV_WIDE_VERTS
-#define MNAV_WIDE_VERTS 32
-#endif
-constexpr uint32_t kWideVerts = MNAV_WIDE_VERTS;   // work-list entries per wave and round (64, or 32: half the LDS image and shorter rounds for more resident waves)
-constexpr uint32_t kWideSlots = (kWideVerts * 13u) / 2u;   // items per wave and round: 6.5 faces per vertex (64 vertices: 20 KB of LDS; with the table below seven waves per CU)
-constexpr int kWideOcc = kWideVerts == 64u ? 2 : 3;  // waves per SIMD the register allocator must reach
-constexpr uint32_t kWideSeen = 512;           // direct-mapped table of vertices this wave has pushed in this launch (see push_many)
-constexpr uint32_t kWideMaxFaces = 32;        // faces of one vertex that go through the items; beyond: the serial rule (eval_cvp)
-// items field-major: phase A stores a field of 64 consecutive slots at a time, phase B lanes read only the fields they look at
-// (an array of 48-byte structs costs an 8-way bank conflict per read there: the lanes' items lie 6 x 48 bytes apart)
-struct WideLds {
-  unsigned long long hi[kWideSlots], own[kWideSlots];
-  double u3tmp[kWideSlots], cand[kWideSlots];
-  uint32_t up[kWideSlots], lvl[kWideSlots], meta[kWideSlots];
-  float dir[kWideSlots];
-  uint8_t owner[kWideSlots];
-  uint32_t seen[kWideSeen];
-};
-struct WideItems {
-  const WideLds* L; uint32_t off;
-  __device__ __forceinline__ unsigned long long hi(uint32_t k) const { return L->hi[off + k]; }
-  __device__ __forceinline__ uint32_t up(uint32_t k) const { return L->up[off + k]; }
-  __device__ __forceinline__ uint32_t lvl(uint32_t k) const { return L->lvl[off + k]; }
-  __device__ __forceinline__ unsigned long long own(uint32_t k) const { return L->own[off + k]; }
-  __device__ __forceinline__ double u3tmp(uint32_t k) const { return L->u3tmp[off + k]; }
-  __device__ __forceinline__ double cand(uint32_t k) const { return L->cand[off + k]; }
-  __device__ __forceinline__ float dir(uint32_t k) const { return L->dir[off + k]; }
-  __device__ __forceinline__ uint32_t meta(uint32_t k) const { return L->meta[off + k]; }
-};
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, o));
-  return x;
-}
-
-// dedup'd, wave-aggregated append of up to N vertices per lane (kNone: none) to the next work list: the stamp looks, the
-// exchanges and the ONE counter atomic of the whole batch are each in flight together (push_agg per vertex is a chain of three
-// dependent round trips)
-// Neighbouring vertices share most of their neighbours, and a wave's 64 work-list entries are neighbours: most candidates of a
-// batch are duplicates of each other.  They are filtered in LDS first -- `seen` is a direct-mapped table of the vertices this
-// wave has handed on during this launch (one step of one plan: the global stamp of such a vertex is set already, so dropping a
-// repeat is exactly what the stamp would do; a slot taken over by another vertex only lets a repeat through) -- which leaves
-// a third of the global look / exchange pairs.
-template <int N>
-__device__ __forceinline__ void push_many(StepCtx& S, uint32_t (&u)[N], uint32_t* seen, int lane)
-{
-  uint32_t st[N];
-  bool ok[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (u[k] != kNone) { const uint32_t old = atomicExch(&seen[u[k] & (kWideSeen - 1u)], u[k]); if (old == u[k]) u[k] = kNone; }
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) { st[k] = S.sv; if (u[k] != kNone) { S.P->dirty[u[k]] = S.sv; st[k] = S.P->stamp[u[k]]; } }
-#pragma unroll
-  for (int k = 0; k < N; ++k) { uint32_t o = S.sv; if (st[k] != S.sv) o = atomicExch(&S.P->stamp[u[k]], S.sv); st[k] = o; }
-  uint32_t mine = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) { ok[k] = st[k] != S.sv; mine += ok[k] ? 1u : 0u; }
-  uint32_t incl = mine;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
-  const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
-  if (total == 0u) return;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&S.cnt->n_next, total);
-  uint32_t idx = (uint32_t)__shfl((int)base, 0) + incl - mine;
-#pragma unroll
-  for (int k = 0; k < N; ++k) if (ok[k]) { if (idx < S.P->cap) S.next[idx] = u[k]; ++idx; }
-}
-
-constexpr int kWidePassesPerBatch = kWideVerts == 64u ? 4 : 2;   // face passes whose loads are in flight together
-
-#ifdef MNAV_WIDE_TIMING                   // debugging aid: cycles per phase of wide_round, summed over all waves
-__device__ unsigned long long g_wide_timing[12];   // [0..6] cycles per phase, [8] rounds, [9] active entries, [10] evaluated, [11] serial-rule vertices
-#define WD_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); wt[k] += now_ - w_last; w_last = now_; } while (0)
-#else
-#define WD_STAMP(k) do { } while (0)
-#endif
-
-// mode 0: an ordinary step (spec: process_entry); 1: the repair sweep after goal_dist was armed (process_repair: every reached
-// vertex is looked at, those whose pop time lies above goal_dist are evaluated again under the final cut-off and stored, nothing is
-// pushed); 2: the rebuild after a band shrink (process_entry over every reached vertex, band_new == 1)
-template <int MODE>
-__device__ __forceinline__ void wide_round(StepCtx& S, const Plan& P, const Ctl& c, WideLds& L, bool active, uint32_t v, int lane)
-{
-#ifdef MNAV_WIDE_TIMING
-  unsigned long long wt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, w_last = __builtin_readcyclecounter();
-#endif
-  // ---- per vertex: does it have to be evaluated?  (spec: process_entry)
-  bool evaluate = false, retain = false, push_nb = false, self_again = false;
-  float old_d = inf_f(), old_t = inf_f(), t_new = inf_f(), old_dir = 0.0f;
-  uint32_t old_pred = kNone, old_cut = kNone, beg = 0, nf = 0;
-  PopKey old_key = key_inf();
-  if (active && !is_seed(P, v)) {
-    old_d = P.dist[v]; old_key = P.tkey[v];
-    const uint8_t blk = P.blocked[v];
-    const uint32_t dirty = P.dirty[v];
-    const uint32_t b0 = P.crn_ptr[v], b1 = P.crn_ptr[v + 1];
-    old_pred = P.pred[v]; old_cut = P.cutf[v]; old_dir = P.dirn[v];  // (all of the vertex's state in flight together)
-    old_t = key_time(old_key);
-    if constexpr (MODE == 1) {
-      if (old_d < inf_f()) {
-        if (old_t > c.goal_dist) { evaluate = true; beg = b0; nf = b1 - b0; }
-        else { t_new = old_t; retain = (t_new >= c.thr) && (t_new < inf_f()); }
-      }
-    } else {
-      const bool go = !(old_t < c.thr_fixed) && !blk && (MODE == 0 || old_d < inf_f());
-      const bool parked = go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && dirty != (uint32_t)c.it;
-      if (parked) { retain = true; t_new = old_t; }
-      else if (go) { evaluate = true; beg = b0; nf = b1 - b0; }
-    }
-  }
-  // ---- item slots: prefix sum of the face counts.  A vertex of very high valence, and whatever does not fit, takes the serial rule
-  const uint32_t want = (nf <= kWideMaxFaces) ? nf : 0u;
-  uint32_t incl = want;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
-  const bool slots = want > 0u && incl <= kWideSlots;
-  const uint32_t off = incl - want;
-  const uint32_t T = wave_max_u32(slots ? incl : 0u);
-  __syncthreads();                                                     // the previous round's readers of the LDS image are done
-  if (slots) for (uint32_t k = 0; k < nf; ++k) L.owner[off + k] = (uint8_t)lane;
-  __syncthreads();
-  WD_STAMP(0);
-  // ---- phase A: one lane per face; the records of a batch of passes are loaded before the first face is looked at
-  for (uint32_t q00 = 0; q00 < T; q00 += kWidePassesPerBatch * kWave) {
-    Corner ck[kWidePassesPerBatch];
-    uint32_t vs[kWidePassesPerBatch];
-#pragma unroll
-    for (int p = 0; p < kWidePassesPerBatch; ++p) {
-      const uint32_t q = q00 + p * kWave + (uint32_t)lane;
-      ck[p].v1 = kNone; ck[p].v2 = kNone; ck[p].a = 0.f; ck[p].b = 0.f; ck[p].c = 0.f; ck[p].face = 0u; vs[p] = 0u;
-      if (q00 + p * kWave < T) {                                       // (wave-uniform)
-        const int s = L.owner[q < T ? q : T - 1u];
-        vs[p] = (uint32_t)__shfl((int)v, s);
-        const uint32_t bs = (uint32_t)__shfl((int)beg, s), os = (uint32_t)__shfl((int)off, s);
-        if (q < T) ck[p] = P.crn[bs + (q - os)];
-      }
-    }
-    PopKey t1[kWidePassesPerBatch], t2[kWidePassesPerBatch];
-    float d1[kWidePassesPerBatch], d2[kWidePassesPerBatch];
-#pragma unroll
-    for (int p = 0; p < kWidePassesPerBatch; ++p) {
-      t1[p] = key_inf(); t2[p] = key_inf(); d1[p] = inf_f(); d2[p] = inf_f();
-      if (ck[p].v1 != kNone) { t1[p] = P.tkey[ck[p].v1]; t2[p] = P.tkey[ck[p].v2]; d1[p] = P.dist[ck[p].v1]; d2[p] = P.dist[ck[p].v2]; }
-    }
-#ifdef MNAV_WIDE_TIMING
-    { float z = 0.f; for (int p = 0; p < kWidePassesPerBatch; ++p) z += d1[p] + d2[p]; asm volatile("" :: "v"(z)); }   // wait for the loads
-#endif
-    WD_STAMP(1);
-#pragma unroll
-    for (int p = 0; p < kWidePassesPerBatch; ++p) {
-      const uint32_t q = q00 + p * kWave + (uint32_t)lane;
-      if (q < T) {
-        const CvpItem it = make_cvp_item_pre(P, c, vs[p], ck[p], t1[p], t2[p], d1[p], d2[p]);
-        L.hi[q] = it.hi; L.own[q] = it.own; L.u3tmp[q] = it.u3tmp; L.cand[q] = it.cand;
-        L.up[q] = it.up; L.lvl[q] = it.lvl; L.meta[q] = it.meta; L.dir[q] = it.dir;
-      }
-    }
-    WD_STAMP(2);
-  }
-  __syncthreads();
-  // ---- phase B: one lane per vertex
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
-  if (slots) {
-    uint32_t win; int sel;
-    WideItems mine; mine.L = &L; mine.off = off;
-    e = eval_cvp_items_any(P, v, nf, mine, win, sel);
-    if (win != kNone) { const Corner k = P.crn[beg + win]; e.pred = (sel == 1) ? k.v1 : k.v2; e.cut = corner_face(k); }
-  } else if (evaluate) {
-    e = eval_cvp(P, c, v);                                             // no faces / too many / no room left in this round
-  }
-  WD_STAMP(3);
-  if (evaluate) {
-    ++S.levals;
-    const bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != old_pred) || (e.key != old_key) ||
-                         (e.cut != old_cut) || (f2u(e.dir) != f2u(old_dir));
-    if (changed) { P.dist[v] = e.d; P.pred[v] = e.pred; P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; }
-    t_new = e.t;
-    if constexpr (MODE == 1) {
-      if (f2u(e.d) != f2u(old_d) || e.key != old_key) S.lchanged = true;       // sweep again (spec: process_repair)
-      retain = (t_new >= c.thr) && (t_new < inf_f());
-    } else {
-      const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
-      push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
-      retain = !now_in && e.t < inf_f();
-      self_again = (e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key;   // spec: process_entry
-    }
-  }
-  if (push_nb || self_again) {
-    S.lchanged = true;
-    if (push_nb && ((old_t < c.thr) != (t_new < c.thr))) S.lcut = fminf(S.lcut, fminf(old_t, t_new));   // crossed the bound (spec: note_cut)
-  }
-  // ---- pushes: one lane per face of the vertices that moved, the vertex itself when its cascade key moved
-  {
-    constexpr int kPasses = (int)((kWideSlots + kWave - 1) / kWave);
-    uint32_t u[2 * kPasses + 1];
-#pragma unroll
-    for (int p = 0; p < kPasses; ++p) {
-      u[2 * p] = kNone; u[2 * p + 1] = kNone;
-      if ((uint32_t)(p * kWave) < T) {                                  // (wave-uniform)
-        const uint32_t q = p * kWave + (uint32_t)lane;
-        const int s = L.owner[q < T ? q : T - 1u];
-        const bool w = __shfl((int)push_nb, s) != 0 && q < T;
-        const uint32_t bs = (uint32_t)__shfl((int)beg, s), os = (uint32_t)__shfl((int)off, s);
-        if (w) { const Corner k = P.crn[bs + (q - os)]; if (k.v1 != kNone) { u[2 * p] = k.v1; u[2 * p + 1] = k.v2; } }
-      }
-    }
-    u[2 * kPasses] = self_again ? v : kNone;
-    WD_STAMP(4);
-    push_many(S, u, L.seen, lane);
-  }
-  WD_STAMP(5);
-  unsigned long long sm = __ballot(push_nb && !slots);                 // vertices that took the serial rule: the wave walks their faces
-  while (sm) {
-    const int src = __ffsll((long long)sm) - 1;
-    sm &= sm - 1ull;
-    const uint32_t vb = (uint32_t)__shfl((int)beg, src), vn = (uint32_t)__shfl((int)nf, src);
-    for (uint32_t i0 = 0; i0 < vn; i0 += kWave) {
-      const uint32_t i = i0 + (uint32_t)lane;
-      uint32_t a = kNone, b = kNone;
-      if (i < vn) { const Corner k = P.crn[vb + i]; if (k.v1 != kNone) { a = k.v1; b = k.v2; } }
-      push_agg<true>(S, a != kNone, a);
-      push_agg<true>(S, b != kNone, b);
-    }
-  }
-  park_agg(S, retain, v);
-  if (retain) S.lmin = fminf(S.lmin, t_new);
-  WD_STAMP(6);
-#ifdef MNAV_WIDE_TIMING
-  {
-    const unsigned long long ne = __popcll(__ballot(evaluate)), na = __popcll(__ballot(active)), ns = __popcll(__ballot(!slots && evaluate));
-    if (lane == 0) { atomicAdd(&g_wide_timing[8], 1ull); atomicAdd(&g_wide_timing[9], na); atomicAdd(&g_wide_timing[10], ne); atomicAdd(&g_wide_timing[11], ns); }
-  }
-  if (lane == 0) for (int k = 0; k < 8; ++k) if (wt[k]) atomicAdd(&g_wide_timing[k], wt[k]);
-#endif
-}
-
 // grid = (waves per plan, plans).  slot j (0..5) selects the ping-pong control block (j&1) and
 // the counter block (j%3).
 #ifndef MNAV_STEP_OCC                     // waves per SIMD the register allocator must reach: 3 (<= 168 VGPRs).  The CVP replay sits
@@ -725,134 +473,7 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
 template <uint32_t PLANNER>
 __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) { step_body<PLANNER, false>(plans, j, blockIdx.y); }
 
-// ---- CVP batches: one launch of persistent waves per step, the work of ALL plans dealt out in chunks of 64 entries ------------
-// With a grid of (waves per plan, plans) most workgroups of a step find nothing to do -- a plan's work list is a few hundred to a
-// few ten thousand entries, the grid must cover the largest -- and for a kernel with a 22 KB LDS image every one of them holds
-// an LDS slot while it starts and exits: on the benched C3 configuration that kept the wide kernel at the 8-lane kernel's
-// throughput.  k_cvp_ctl evaluates every plan's controller once (what each workgroup of k_step does for itself), writes the
-// control blocks and the prefix sums of the plans' chunk counts; k_step_wide then runs exactly as many waves as stay resident,
-// each taking an equal, contiguous share of the step's chunks, whatever plans they belong to.
-struct WideSched { uint32_t total, n_repair, pad[2]; };
-constexpr uint32_t kWideGroupsMax = 8;        // groups of plans a CVP batch is stepped in, each on its own stream (branch of the captured graph)
-constexpr uint32_t kRepairRows = 16;          // grid rows of k_step_repair: plans in a repair step are rare, a row takes several if there are more
-
-// the plans that k_cvp_ctl found in a repair / rebuild / cut step (rep_list = prefix + n + 1 ...): the 8-lane sweeps over all vertices
-__global__ MNAV_STEP_BOUNDS void k_step_repair(const Plan* __restrict__ plans, int j, const uint32_t* __restrict__ rep_list, const WideSched* __restrict__ sched)
-{
-  const uint32_t nr = sched->n_repair;
-  for (uint32_t r = blockIdx.y; r < nr; r += kRepairRows) {
-    step_body<kPlannerCvp, true>(plans, j, rep_list[r]);
-    __syncthreads();                                                   // (s_ctl of the next plan)
-  }
-}
-
-__global__ __launch_bounds__(256) void k_cvp_ctl(const Plan* __restrict__ plans, uint32_t n, int j, uint32_t* __restrict__ prefix, WideSched* __restrict__ sched)
-{
-  __shared__ uint32_t s_base, s_rep;
-  __shared__ uint32_t s_wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) { s_base = 0u; s_rep = 0u; }
-  __syncthreads();
-  for (uint32_t p0 = 0; p0 < n; p0 += 256) {
-    const uint32_t p = p0 + tid;
-    uint32_t chunks = 0;
-    if (p < n) {
-      const Plan& P = plans[p];
-      const Ctl prev = P.ctl[(j + 1) & 1];
-      const Cnt cprev = P.cnt[(j + 2) % 3];
-      const Ctl cur = controller(P, prev, cprev);
-      P.ctl[j & 1] = cur;
-      Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
-      P.cnt[(j + 1) % 3] = z;
-      if (!cur.done) {
-        if (P.seed_mask == nullptr && cur.repair == 0) chunks = (cur.n + cur.wread + kWideVerts - 1) / kWideVerts;
-        else if (P.seed_mask == nullptr && cur.repair <= 2) chunks = (P.V + kWideVerts - 1) / kWideVerts;   // repair sweep / rebuild: over all vertices
-        else prefix[n + 1u + atomicAdd(&s_rep, 1u)] = p;              // band cut (no evaluation): k_step_repair; its list follows the prefix sums
-      }
-    }
-    uint32_t incl = chunks;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += x; }
-    if (lane == 63) s_wsum[wid] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) { if (w < wid) woff += s_wsum[w]; tot += s_wsum[w]; }
-    if (p < n) prefix[p] = s_base + woff + incl - chunks;
-    __syncthreads();
-    if (tid == 0) s_base += tot;
-    __syncthreads();
-  }
-  if (tid == 0) { prefix[n] = s_base; sched->total = s_base; sched->n_repair = s_rep; }
-}
-
-// the plan that chunk c belongs to: the largest p with prefix[p] <= c (all lanes search together, 64 entries per look)
-__device__ __forceinline__ uint32_t wide_find_plan(const uint32_t* __restrict__ prefix, uint32_t n, uint32_t c, int lane)
-{
-  uint32_t lo = 0, len = n + 1u;                                       // the answer lies in [lo, lo + len)
-  while (len > 1u) {
-    const uint32_t step = (len + kWave - 1u) / kWave;
-    const uint32_t idx = lo + (uint32_t)lane * step;
-    const bool le = idx < lo + len && prefix[idx] <= c;
-    const uint32_t k = (uint32_t)__popcll(__ballot(le));                // samples are ascending: the first k of them are <= c (k >= 1)
-    const uint32_t nlo = lo + (k - 1u) * step;
-    len = min(step, lo + len - nlo);
-    lo = nlo;
-  }
-  return lo;
-}
-
-// bounded by its LDS image (seven waves per CU), not by registers
-__global__ __launch_bounds__(kWave, kWideOcc) void k_step_wide(const Plan* __restrict__ plans, uint32_t n, int j, const uint32_t* __restrict__ prefix,
-                                                        const WideSched* __restrict__ sched)
-{
-  __shared__ WideLds s_wide;
-  const int lane = threadIdx.x;
-  const uint32_t total = sched->total;
-  uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
-  const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1u)) / gridDim.x);
-  if (c0 >= c1) return;
-  uint32_t p = wide_find_plan(prefix, n, c0, lane);
-  while (c0 < c1) {
-    const uint32_t pb = prefix[p], pe = prefix[p + 1];
-    if (pe <= c0) { ++p; continue; }                                   // (a plan without chunks in this step)
-    const Plan& P = plans[p];
-    const Ctl cur = P.ctl[j & 1];
-    Cnt* cnt = &P.cnt[j % 3];
-    StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
-    __syncthreads();
-    for (uint32_t k = (uint32_t)lane; k < kWideSeen; k += kWave) s_wide.seen[k] = kNone;   // vertex ids of another plan (wide_round starts with a barrier)
-    const uint32_t* list = P.list[cur.it & 1];
-    const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
-    const uint32_t ntot = cur.n + cur.wread;
-    const uint32_t ce = min(c1, pe);
-    if (cur.repair == 0) {
-      for (uint32_t c = c0; c < ce; ++c) {
-        const uint32_t i = (c - pb) * kWideVerts + (uint32_t)lane;
-        const bool active = (uint32_t)lane < kWideVerts && i < ntot;
-        const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
-        wide_round<0>(S, P, cur, s_wide, active, v, lane);
-      }
-    } else {
-      for (uint32_t c = c0; c < ce; ++c) {                             // a sweep over the vertices themselves
-        const uint32_t v = (c - pb) * kWideVerts + (uint32_t)lane;
-        const bool act = (uint32_t)lane < kWideVerts && v < P.V;
-        if (cur.repair == 1) wide_round<1>(S, P, cur, s_wide, act, act ? v : 0u, lane);
-        else wide_round<2>(S, P, cur, s_wide, act, act ? v : 0u, lane);
-      }
-    }
-    const float wmin = wave_min(S.lmin);
-    const float wcut = wave_min(S.lcut);
-    const uint32_t wev = wave_sum(S.levals);
-    const bool wch = __any(S.lchanged);
-    if (lane == 0) {
-      if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
-      if (wcut < inf_f()) atomicMin(&cnt->minchg, f2u(wcut));
-      if (wev) atomicAdd(&cnt->evals, wev);
-      if (wch) atomicOr(&cnt->changed, 1u);
-    }
-    c0 = ce; ++p;
-  }
-}
+#include "mnav_cvp_wide.h"   // CVP batches: wide_round, k_cvp_ctl, k_step_wide, k_step_repair
 
 // CVP verification sweep, run once after the last step (the CVP counterpart of k_dij_finalize's fixed-point
 // check): every vertex is evaluated once more on the CONVERGED state.  (1) Its stored (potential, pop key,
@@ -1457,123 +1078,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_weights(uint32_t n, const uint3
   (void)col;
 }
 
-// ---------------------------------------------------------------------------------------------
-// ONE plan on a mesh that is range-partitioned over several processes / GPUs (BASELINE config 4,
-// SURVEY.md 8e).  The tiles are in Morton order; process r owns a contiguous range of them and, with
-// them, their vertices.  Every process runs the ordinary tile rounds (k_tile_round) on its own tiles
-// only; between blocks of rounds the distances of the INTERFACE vertices (vertices with a neighbour
-// owned by somebody else, plus the robot vertex) are exchanged with one min-allreduce over a dense
-// buffer (RCCL over xGMI; torch.distributed in the Python driver), and a vertex whose value dropped
-// wakes the local tiles that have it in their halo.  Label-correcting: the fixed point, and with it
-// every bit of the potential, is the one of the unpartitioned run.
-// ---------------------------------------------------------------------------------------------
-struct ShardDev {
-  uint32_t n_iface, rank, target;
-  uint32_t partition;            // 1: partitioned mesh -- iface_vert holds LOCAL ids (kNone: vertex not held here), every held copy is
-                                 // packed (a valid upper bound) and every held copy takes a smaller reduced value
-  const uint32_t* iface_vert;    // n_iface vertex ids, the same list on every process
-  const uint8_t* iface_owner;    // n_iface owning process
-  const uint32_t* wake_ptr;      // n_iface+1 -> wake_tile: local tiles that hold the vertex in their halo
-  const uint32_t* wake_tile;
-};
-
-// pack: own interface values, +inf for the others (the min-allreduce then delivers every owner's value)
-__global__ __launch_bounds__(kBlock) void k_shard_pack(ShardDev S, const TilePlan* __restrict__ plans, float* __restrict__ buf,
-                                                       uint32_t* __restrict__ changed, uint32_t* __restrict__ minpend)
-{
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *changed = 0u; *minpend = kInfBits; }   // the words the apply step accumulates into ("nothing pending")
-  const float* dist = plans[0].dist;                                  // (the robot vertex comes from the plan record too: the captured
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;               //  exchange graphs hold nothing that changes from plan to plan)
-  if (i < S.n_iface) {
-    const uint32_t v = S.iface_vert[i];
-    buf[i] = (v != kNone && (S.partition || S.iface_owner[i] == S.rank)) ? dist[v] : inf_f();
-  }
-  if (i == S.n_iface) buf[i] = dist[plans[0].target];   // last slot: the robot vertex (bound / goal_dist need it everywhere); stale copies are larger
-}
-
-// apply: ghost values that dropped are stored and wake the local tiles around them for the next round;
-// the round controller is re-armed (its `done` is sticky) and told about the new smallest wake-up value
-__global__ __launch_bounds__(kBlock) void k_shard_apply(ShardDev S, const TilePlan* __restrict__ plans, const float* __restrict__ buf,
-                                                        uint32_t* __restrict__ changed)
-{
-  const TilePlan& P = plans[0];
-  const TCtl a = P.ctl[0], b = P.ctl[1];
-  const int32_t j = (a.it > b.it) ? a.it : b.it;                     // last round executed (-1: none yet)
-  uint32_t* pn = P.pend[(j + 1) & 1];                                // the buffer round j+1 reads
-  TCnt* cnt = &P.cnt[((j % 3) + 3) % 3];                             // ... and the counters it reads as "previous"
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i == 0) { P.ctl[0].done = 0; P.ctl[1].done = 0; }
-  if (i == S.n_iface) { if (buf[i] < P.dist[P.target]) P.dist[P.target] = buf[i]; return; }
-  if (i >= S.n_iface) return;
-  const uint32_t v = S.iface_vert[i];
-  if (v == kNone || (!S.partition && S.iface_owner[i] == S.rank)) return;
-  const float nv = buf[i];
-  if (!(nv < P.dist[v])) return;
-  P.dist[v] = nv;
-  const uint32_t bits = f2u(nv);
-  // Partitioned mesh: v sits INSIDE a local tile (first entry of its wake list).  A tile only re-queues its own vertices
-  // from the threshold of its last solve upwards (k_tile_round: sources in [tlast, thr)), so a value that arrives from
-  // outside below that threshold pulls it down.  Signed min on the float bits: the negative marks (-inf: never solved) stay.
-  if (S.partition) atomicMin((int*)&P.tlast[S.wake_tile[S.wake_ptr[i]]], (int)bits);
-  for (uint32_t k = S.wake_ptr[i]; k < S.wake_ptr[i + 1]; ++k) atomicMin(&pn[S.wake_tile[k]], bits);
-  if (S.wake_ptr[i + 1] > S.wake_ptr[i]) { atomicMin(&cnt->minpend, bits); atomicOr(changed, 1u); }
-}
-
-// smallest wake-up value among the owned tiles (what this process still has to do), as float bits
-__global__ __launch_bounds__(kBlock) void k_shard_minpend(const TilePlan* __restrict__ plans, uint32_t* __restrict__ out)
-{
-  const TilePlan& P = plans[0];
-  const TCtl a = P.ctl[0], b = P.ctl[1];
-  const int32_t j = (a.it > b.it) ? a.it : b.it;
-  const uint32_t* pn = P.pend[(j + 1) & 1];
-  const uint32_t hi = P.t_hi ? P.t_hi : P.ntiles;
-  uint32_t m = kInfBits;
-  for (uint32_t t = P.t_lo + blockIdx.x * kBlock + threadIdx.x; t < hi; t += gridDim.x * kBlock) m = min(m, pn[t]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m != kInfBits) atomicMin(out, m);
-}
-
-// the termination words of one exchange, written on the device: {smallest pending wake-up, dist[target], -status}
-__global__ void k_shard_ctl(const uint32_t* __restrict__ minpend, const TilePlan* __restrict__ plans, const uint32_t* __restrict__ cancel,
-                            float* __restrict__ ctl)
-{
-  if (threadIdx.x || blockIdx.x) return;
-  const float* dist = plans[0].dist; const uint32_t target = plans[0].target;
-  const uint32_t mp = *minpend;
-  ctl[0] = (mp >= kInfBits) ? inf_f() : u2f(mp);
-  ctl[1] = dist[target];
-  ctl[2] = (cancel && __atomic_load_n(cancel, __ATOMIC_RELAXED)) ? -1.0f : 0.0f;
-}
-
-// One segment of the vertex path (dijkstra :358-373) inside this process's part: predecessors are followed from `start` while
-// the vertex is owned here; out = {count, vertex the walk stopped at, status (1: a vertex without predecessor), ids...}
-__global__ void k_shard_walk(const uint32_t* __restrict__ pred, const uint8_t* __restrict__ owned, uint32_t start, uint32_t seed, uint32_t cap,
-                             uint32_t* __restrict__ out)
-{
-  if (threadIdx.x || blockIdx.x) return;
-  uint32_t v = start, n = 0, status = 0;
-  while (v != seed && (!owned || owned[v]) && n < cap) {
-    const uint32_t p = pred[v];
-    if (p == v) { status = 1; break; }
-    out[3 + n++] = p;
-    v = p;
-  }
-  out[0] = n; out[1] = v; out[2] = status;
-}
-
-// final gather buffers: owned entries, neutral elements elsewhere (min-allreduce over dist, pred)
-__global__ __launch_bounds__(kBlock) void k_shard_owned(uint32_t V, const uint32_t* __restrict__ vert_tile, uint32_t t_lo, uint32_t t_hi,
-                                                        const float* __restrict__ dist, const uint32_t* __restrict__ pred,
-                                                        float* __restrict__ dist_out, uint32_t* __restrict__ pred_out)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  const uint32_t t = vert_tile[v];
-  const bool mine = t >= t_lo && t < t_hi;
-  dist_out[v] = mine ? dist[v] : inf_f();
-  pred_out[v] = mine ? pred[v] : 0xFFFFFFFFu;
-}
+#include "mnav_shard.h"   // kernels of the sharded single plan (k_shard_*)
 
 struct PlanResult {
   uint32_t code;
@@ -4279,380 +3784,7 @@ uint32_t mnav_plan_cvp_batch(mnav_ctx* ctx, uint32_t n, const float* seed_pos, c
                   vecmap_out);
 }
 
-// ---------------------------------------------------------------------------------------------
-// sharded single plan: C ABI (include/mnav.h "one plan over several GPUs")
-// ---------------------------------------------------------------------------------------------
-int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world)
-{
-  if (!ctx || !ctx->have_mesh || world == 0 || rank >= world) { if (ctx) ctx->err = "mnav_shard_setup: bad arguments or no mesh"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
-  const HostTiles& M = ctx->tiles_meta;
-  if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
-  if (M.ntiles < world) { ctx->err = "fewer tiles than processes"; return -1; }
-  auto& S = ctx->shard;
-  S.rank = rank; S.world = world; S.partition = false;
-  auto lo = [&](uint32_t r) { return (uint32_t)(((uint64_t)M.ntiles * r) / world); };
-  S.t_lo = lo(rank); S.t_hi = lo(rank + 1);
-  std::vector<uint32_t> bound(world + 1);
-  for (uint32_t r = 0; r <= world; ++r) bound[r] = lo(r);
-  auto owner_of_tile = [&](uint32_t t) { return (uint32_t)(std::upper_bound(bound.begin(), bound.end(), t) - bound.begin() - 1); };
-  // interface = halo vertices owned by another process than the tile that sees them (covers both sides of every cut)
-  std::vector<uint8_t> is_iface(ctx->V, 0);
-  for (uint32_t t = 0; t < M.ntiles; ++t) {
-    const uint32_t ot = owner_of_tile(t);
-    for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
-      const uint32_t h = M.halo_verts[k];
-      if (owner_of_tile(M.vert_tile[h]) != ot) is_iface[h] = 1;
-    }
-  }
-  S.iface_vert.clear();
-  for (uint32_t v = 0; v < ctx->V; ++v) if (is_iface[v]) S.iface_vert.push_back(v);
-  S.n_iface = (uint32_t)S.iface_vert.size();
-  std::vector<uint32_t> idx_of(ctx->V, kNone);
-  std::vector<uint8_t> owner(S.n_iface ? S.n_iface : 1, 0);
-  for (uint32_t i = 0; i < S.n_iface; ++i) { idx_of[S.iface_vert[i]] = i; owner[i] = (uint8_t)owner_of_tile(M.vert_tile[S.iface_vert[i]]); }
-  if (world > 255) { ctx->err = "at most 255 processes"; return -1; }
-  // local tiles to wake per ghost vertex
-  std::vector<uint32_t> wptr(S.n_iface + 1, 0), wtile;
-  for (int pass = 0; pass < 2; ++pass) {
-    std::vector<uint32_t> fill(S.n_iface + 1, 0);
-    for (uint32_t t = S.t_lo; t < S.t_hi; ++t)
-      for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
-        const uint32_t i = idx_of[M.halo_verts[k]];
-        if (i == kNone || owner[i] == rank) continue;
-        if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = t;
-      }
-    if (pass == 0) { for (uint32_t i = 0; i < S.n_iface; ++i) wptr[i + 1] += wptr[i]; wtile.assign(wptr[S.n_iface] ? wptr[S.n_iface] : 1, 0); }
-  }
-  if (dev_upload(ctx, &S.d_iface_vert, S.iface_vert.data(), S.iface_vert.size())) return -1;
-  if (dev_upload(ctx, &S.d_iface_owner, owner.data(), S.n_iface)) return -1;
-  if (dev_upload(ctx, &S.d_wake_ptr, wptr.data(), wptr.size())) return -1;
-  if (dev_upload(ctx, &S.d_wake_tile, wtile.data(), wtile.size())) return -1;
-  if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
-  if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (auto& kv : S.graphs) (void)hipGraphExecDestroy(kv.second);   // the captured exchanges hold the old lists
-  S.graphs.clear();
-  S.ready = true; S.active = false;
-  return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
-}
-
-// The mesh of this context is ONE PART of a partitioned mesh (owned vertices + their 1-ring halo, local ids in ascending
-// global id so that every (value, id) tie breaks as on the whole mesh): all local tiles run, every held copy of an
-// interface vertex is packed (any value reached along real edges is an upper bound of the true distance) and takes the
-// reduced minimum, and the finalize pass does not ask a halo copy for a local predecessor.
-int mnav_shard_setup_partition(mnav_ctx* ctx, uint32_t n_exchange, const uint32_t* exchange_vertex, const uint8_t* owned)
-{
-  if (!ctx || !ctx->have_mesh || (n_exchange && !exchange_vertex) || !owned) { if (ctx) ctx->err = "mnav_shard_setup_partition: bad arguments or no mesh"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
-  const HostTiles& M = ctx->tiles_meta;
-  if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
-  auto& S = ctx->shard;
-  S.rank = 0; S.world = 1; S.partition = true; S.t_lo = 0; S.t_hi = M.ntiles;
-  S.iface_vert.assign(exchange_vertex, exchange_vertex + n_exchange);
-  S.n_iface = n_exchange;
-  std::vector<uint32_t> idx_of(ctx->V, kNone);
-  for (uint32_t i = 0; i < n_exchange; ++i) {
-    const uint32_t v = exchange_vertex[i];
-    if (v == kNone) continue;
-    if (v >= ctx->V || idx_of[v] != kNone) { ctx->err = "mnav_shard_setup_partition: exchange vertex out of range or listed twice"; return -1; }
-    idx_of[v] = i;
-  }
-  // tiles to wake when an exchanged value drops: the vertex's own tile and the tiles that hold it in their halo
-  std::vector<uint32_t> wptr((size_t)n_exchange + 1, 0), wtile;
-  for (int pass = 0; pass < 2; ++pass) {
-    std::vector<uint32_t> fill((size_t)n_exchange + 1, 0);
-    for (uint32_t i = 0; i < n_exchange; ++i) {
-      const uint32_t v = exchange_vertex[i];
-      if (v == kNone) continue;
-      if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = M.vert_tile[v];
-    }
-    for (uint32_t t = 0; t < M.ntiles; ++t)
-      for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
-        const uint32_t i = idx_of[M.halo_verts[k]];
-        if (i == kNone) continue;
-        if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = t;
-      }
-    if (pass == 0) { for (uint32_t i = 0; i < n_exchange; ++i) wptr[i + 1] += wptr[i]; wtile.assign(wptr[n_exchange] ? wptr[n_exchange] : 1, 0); }
-  }
-  std::vector<uint8_t> zero(n_exchange ? n_exchange : 1, 0);
-  if (dev_upload(ctx, &S.d_iface_vert, S.iface_vert.data(), S.iface_vert.size())) return -1;
-  if (dev_upload(ctx, &S.d_iface_owner, zero.data(), n_exchange)) return -1;
-  if (dev_upload(ctx, &S.d_wake_ptr, wptr.data(), wptr.size())) return -1;
-  if (dev_upload(ctx, &S.d_wake_tile, wtile.data(), wtile.size())) return -1;
-  if (dev_upload(ctx, &S.d_owned, owned, (size_t)ctx->V)) return -1;
-  if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
-  if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (auto& kv : S.graphs) (void)hipGraphExecDestroy(kv.second);   // the captured exchanges hold the old lists
-  S.graphs.clear();
-  S.ready = true; S.active = false;
-  return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
-}
-
-uint64_t mnav_device_bytes(const mnav_ctx* ctx)
-{
-  if (!ctx) return 0;
-  uint64_t n = 0;
-  for (const auto& kv : ctx->alloc_bytes) n += kv.second;             // mesh tables, tiles, costs, shard lists (dev_upload)
-  const uint64_t V = ctx->V ? ctx->V : 1;
-  for (const Slot& s : ctx->slots) {                                  // per-plan state (ensure_slots, ensure_tile_state)
-    n += 8 * V;
-    if (s.band_ready) n += 28 * V;
-    if (s.vecmap) n += 12 * V;
-    if (s.cvp_ready) n += (sizeof(PopKey) + 8) * V;
-    if (s.tpend0) n += 12ull * (ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1);
-  }
-  if (ctx->d_nbr) n += 8ull * 2 * ctx->E;
-  if (ctx->d_crn) n += 24ull * 3 * ctx->F;
-  if (ctx->d_blocked) n += V;
-  n += 4ull * ctx->paths_words;
-  return n;
-}
-
-int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_t* ntiles, uint32_t* n_iface)
-{
-  if (!ctx || !ctx->shard.ready) return -1;
-  if (t_lo) *t_lo = ctx->shard.t_lo;
-  if (t_hi) *t_hi = ctx->shard.t_hi;
-  if (ntiles) *ntiles = ctx->tiles_meta.ntiles;
-  if (n_iface) *n_iface = ctx->shard.n_iface + 1;
-  return 0;
-}
-
-static ShardDev shard_dev(const mnav_ctx* ctx)
-{
-  ShardDev D;
-  D.n_iface = ctx->shard.n_iface; D.rank = ctx->shard.rank; D.target = ctx->shard.target; D.partition = ctx->shard.partition ? 1u : 0u; D.iface_vert = ctx->shard.d_iface_vert; D.iface_owner = ctx->shard.d_iface_owner;
-  D.wake_ptr = ctx->shard.d_wake_ptr; D.wake_tile = ctx->shard.d_wake_tile;
-  return D;
-}
-
-int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit)
-{
-  if (check_ready(ctx)) return -1;
-  if (!ctx->shard.ready) { ctx->err = "mnav_shard_setup has not been called"; return -1; }
-  if (seed_vertex >= ctx->V || target_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
-  if (!(goal_dist_offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
-  ctx->err.clear();
-  ctx->cancel.store(0);
-  if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
-  ctx->want_vec = false;
-  ctx->tb.count_pending = false; ctx->tb_args_valid = false;         // slot 0 and d_res are taken over by the sharded plan
-  ctx->last_planner = kPlannerDijkstra; ctx->last_engine = 0; ctx->last_n = 0; ctx->caller_slot.clear();
-  if (materialize(ctx, false, cost_limit)) return -1;
-  if (ensure_slots(ctx, 1, false, false, false)) return -1;
-  if (ensure_paths(ctx, 1)) return -1;
-  if (ensure_tile_state(ctx, 1)) return -1;
-  if (tile_weights(ctx)) return -1;
-  auto& S = ctx->shard;
-  const HostTiles& M = ctx->tiles_meta;
-  Slot& s = ctx->slots[0];
-  Plan P; memset(&P, 0, sizeof(P));
-  P.planner = kPlannerDijkstra; P.V = ctx->V;
-  P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-  P.dist = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-  P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-  P.offset = goal_dist_offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
-  for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
-  P.seed[0] = seed_vertex; P.target[0] = target_vertex; P.seed_face = kNone;
-  TilePlan T; memset(&T, 0, sizeof(T));
-  T.V = ctx->V; T.ntiles = M.ntiles;
-  T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-  T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-  T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-  T.seed = seed_vertex; T.target = target_vertex; T.offset = goal_dist_offset; T.max_rounds = 0x7FFFFFF0u;
-  T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
-  T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
-  T.t_lo = S.t_lo; T.t_hi = S.t_hi;
-  T.owned = S.partition ? S.d_owned : nullptr;
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, &P, sizeof(Plan), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, &T, sizeof(TilePlan), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-  if (gt < 1) gt = 1;
-  hipLaunchKernelGGL(k_tile_init, dim3(gt, 1), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  S.j = 0; S.seed = seed_vertex; S.target = target_vertex; S.offset = goal_dist_offset; S.active = true;
-  return 0;
-}
-
-int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev)
-{
-  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  auto& S = ctx->shard;
-  const uint32_t own = S.t_hi - S.t_lo;
-  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
-  if (G > own) G = own ? own : 1;
-  for (uint32_t r = 0; r < rounds; ++r, ++S.j)
-    hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)(S.j % 6));
-  if (iface_buf_dev)
-    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, ctx->shard.d_changed, ctx->shard.d_minpend);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;
-  return 0;
-}
-
-int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out)
-{
-  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  auto& S = ctx->shard;
-  HIPCHK(hipMemsetAsync(S.d_changed, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)S.d_minpend, (int)kInfBits, 1, ctx->stream));   // +inf: "nothing pending"
-  const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
-  const uint32_t own = S.t_hi - S.t_lo;
-  const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
-  HIPCHK(hipGetLastError());
-  uint32_t mp = 0; float td = INFINITY;
-  HIPCHK(hipMemcpyAsync(&mp, S.d_minpend, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&td, ctx->slots[0].dist + S.target, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (local_min_out) *local_min_out = (mp >= 0x7f800000u) ? INFINITY : u2f(mp);
-  if (target_dist_out) *target_dist_out = td;
-  return 0;
-}
-
-// The same two steps without a host round trip, for an exchange loop that stays on the device (mesh_navigation_amd/sharded.py):
-// the library's stream is linked to `caller_stream` (the stream the caller's collectives are ordered on, e.g. torch's
-// current stream) by events -- our kernels start after what the caller enqueued so far, the caller's next operation after
-// ours.  mnav_shard_apply_async leaves {smallest pending wake-up, dist[target], -cancelled} in ctl_dev[0..2]: the caller
-// reduces those three floats over the ranks and looks at them once every few exchanges (an exchange after convergence
-// changes nothing).
-static int shard_link(mnav_ctx* ctx, hipStream_t caller, bool in)
-{
-  hipEvent_t& e = ctx->ev_link[in ? 0 : 1];
-  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->err = "event creation failed"; return -1; }
-  if (in) { HIPCHK(hipEventRecord(e, caller)); HIPCHK(hipStreamWaitEvent(ctx->stream, e, 0)); }
-  else { HIPCHK(hipEventRecord(e, ctx->stream)); HIPCHK(hipStreamWaitEvent(caller, e, 0)); }
-  return 0;
-}
-
-// One exchange is two fixed sequences of small launches (R rounds + pack; apply + min + control words): each is captured into a
-// hipGraph once per (R, round parity, buffers) and replayed -- the launches of a 10M-vertex plan are ~80 exchanges x 12.
-// KERNELS ONLY: with hipMemsetAsync / hipMemsetD32Async nodes at the head of the second graph (ROCm 7.2) a plan that started
-// right after another one read a wake-up word of the previous plan now and then (a stale "3" instead of +inf; gone with either
-// graph alone, with a device synchronisation at the start of the plan, or -- the fix -- with the two words cleared by the
-// pack kernel of the first sequence): memset nodes do not seem to be ordered like the kernels around them.
-static int shard_replay(mnav_ctx* ctx, const std::array<uint64_t, 3>& key, const std::function<int()>& enqueue)
-{
-  if (!ctx->use_graph) return enqueue();
-  auto& S = ctx->shard;
-  auto it = S.graphs.find(key);
-  if (it == S.graphs.end()) {
-    hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue();
-    const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
-    hipGraphExec_t ge = nullptr;
-    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(g);
-    it = S.graphs.emplace(key, ge).first;
-  }
-  HIPCHK(hipGraphLaunch(it->second, ctx->stream));
-  return 0;
-}
-
-int mnav_shard_rounds_async(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev, void* caller_stream)
-{
-  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  auto& S = ctx->shard;
-  if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
-  const uint32_t own = S.t_hi - S.t_lo;
-  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
-  if (G > own) G = own ? own : 1;
-  const uint32_t j0 = S.j % 6u;
-  const int rc = shard_replay(ctx, { ((uint64_t)rounds << 8) | j0, (uint64_t)(uintptr_t)iface_buf_dev, 1ull }, [&]() {
-    for (uint32_t r = 0; r < rounds; ++r)
-      hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)((j0 + r) % 6u));
-    if (iface_buf_dev)
-      hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, ctx->shard.d_changed, ctx->shard.d_minpend);
-    HIPCHK(hipGetLastError());
-    return 0;
-  });
-  if (rc) return rc;
-  S.j += rounds;
-  return shard_link(ctx, (hipStream_t)caller_stream, false);
-}
-
-int mnav_shard_apply_async(mnav_ctx* ctx, const float* iface_buf_dev, float* ctl_dev, void* caller_stream)
-{
-  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
-  if (!iface_buf_dev || !ctl_dev) { ctx->err = "null buffer"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  auto& S = ctx->shard;
-  if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
-  const int rc = shard_replay(ctx, { (uint64_t)(uintptr_t)iface_buf_dev, (uint64_t)(uintptr_t)ctl_dev, 2ull }, [&]() {
-    const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;          // (k_shard_pack cleared the two accumulator words: kernels only in the graph)
-    hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
-    const uint32_t own = S.t_hi - S.t_lo;
-    const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
-    hipLaunchKernelGGL(k_shard_ctl, dim3(1), dim3(64), 0, ctx->stream, S.d_minpend, ctx->d_tplans, ctx->d_cancel, ctl_dev);
-    HIPCHK(hipGetLastError());
-    return 0;
-  });
-  if (rc) return rc;
-  return shard_link(ctx, (hipStream_t)caller_stream, false);
-}
-
-int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev)
-{
-  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  auto& S = ctx->shard;
-  const uint32_t own = S.t_hi - S.t_lo;
-  if (own) {
-    uint32_t chunks = std::min<uint32_t>(4096u, own);
-    const uint32_t per = (own + chunks - 1) / chunks;
-    chunks = (own + per - 1) / per;
-    hipLaunchKernelGGL((k_dij_finalize<1, false>), dim3(1, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
-                       ctx->d_mismatch, ctx->d_res, per, 1u, FinBlocked{});
-  }
-  const uint32_t gv = (ctx->V + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_shard_owned, dim3(gv ? gv : 1), dim3(kBlock), 0, ctx->stream, ctx->V, ctx->d_vert_tile, S.t_lo, S.t_hi,
-                     ctx->slots[0].dist, ctx->slots[0].pred, dist_buf_dev, pred_buf_dev);
-  HIPCHK(hipGetLastError());
-  uint32_t mism = 0;
-  HIPCHK(hipMemcpyAsync(&mism, ctx->d_mismatch, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  S.active = false;
-  if (mism) { ctx->err = "sharded SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)"; return -2; }
-  return 0;
-}
-
-int mnav_shard_walk(mnav_ctx* ctx, uint32_t start_vertex, uint32_t seed_vertex, uint32_t cap, uint32_t* out_host)
-{
-  if (!ctx || !ctx->shard.ready || !out_host || ctx->slots.empty()) { if (ctx) ctx->err = "mnav_shard_walk: no sharded plan"; return -1; }
-  if (start_vertex >= ctx->V || seed_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
-  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
-  auto& S = ctx->shard;
-  if (S.walk_cap < cap + 3u) {
-    (void)hipFree(S.d_walk); S.d_walk = nullptr;
-    HIPCHK(hipMalloc((void**)&S.d_walk, 4 * (size_t)(cap + 3u)));
-    S.walk_cap = cap + 3u;
-  }
-  hipLaunchKernelGGL(k_shard_walk, dim3(1), dim3(64), 0, ctx->stream, ctx->slots[0].pred, S.partition ? S.d_owned : nullptr, start_vertex, seed_vertex, cap, S.d_walk);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out_host, S.d_walk, 12, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  const uint32_t n = out_host[0];
-  if (n) HIPCHK(hipMemcpy(out_host + 3, S.d_walk + 3, 4 * (size_t)n, hipMemcpyDeviceToHost));
-  return 0;
-}
+#include "mnav_shard_capi.h"   // mnav_shard_* (one plan over several GPUs)
 
 void mnav_cancel(mnav_ctx* ctx)
 {

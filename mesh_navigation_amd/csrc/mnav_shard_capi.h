@@ -1,0 +1,380 @@
+// mnav_shard_capi.h -- the C ABI of the sharded single plan (include/mnav.h "one plan over several GPUs"): mnav_shard_setup /
+// _setup_partition / _info / _begin / _rounds[_async] / _apply[_async] / _finalize / _walk, mnav_device_bytes.  Included by mnav.hip
+// inside its extern "C" block, after mnav_ctx and the host helpers are defined.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// sharded single plan: C ABI (include/mnav.h "one plan over several GPUs")
+// ---------------------------------------------------------------------------------------------
+int mnav_shard_setup(mnav_ctx* ctx, uint32_t rank, uint32_t world)
+{
+  if (!ctx || !ctx->have_mesh || world == 0 || rank >= world) { if (ctx) ctx->err = "mnav_shard_setup: bad arguments or no mesh"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  const HostTiles& M = ctx->tiles_meta;
+  if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
+  if (M.ntiles < world) { ctx->err = "fewer tiles than processes"; return -1; }
+  auto& S = ctx->shard;
+  S.rank = rank; S.world = world; S.partition = false;
+  auto lo = [&](uint32_t r) { return (uint32_t)(((uint64_t)M.ntiles * r) / world); };
+  S.t_lo = lo(rank); S.t_hi = lo(rank + 1);
+  std::vector<uint32_t> bound(world + 1);
+  for (uint32_t r = 0; r <= world; ++r) bound[r] = lo(r);
+  auto owner_of_tile = [&](uint32_t t) { return (uint32_t)(std::upper_bound(bound.begin(), bound.end(), t) - bound.begin() - 1); };
+  // interface = halo vertices owned by another process than the tile that sees them (covers both sides of every cut)
+  std::vector<uint8_t> is_iface(ctx->V, 0);
+  for (uint32_t t = 0; t < M.ntiles; ++t) {
+    const uint32_t ot = owner_of_tile(t);
+    for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
+      const uint32_t h = M.halo_verts[k];
+      if (owner_of_tile(M.vert_tile[h]) != ot) is_iface[h] = 1;
+    }
+  }
+  S.iface_vert.clear();
+  for (uint32_t v = 0; v < ctx->V; ++v) if (is_iface[v]) S.iface_vert.push_back(v);
+  S.n_iface = (uint32_t)S.iface_vert.size();
+  std::vector<uint32_t> idx_of(ctx->V, kNone);
+  std::vector<uint8_t> owner(S.n_iface ? S.n_iface : 1, 0);
+  for (uint32_t i = 0; i < S.n_iface; ++i) { idx_of[S.iface_vert[i]] = i; owner[i] = (uint8_t)owner_of_tile(M.vert_tile[S.iface_vert[i]]); }
+  if (world > 255) { ctx->err = "at most 255 processes"; return -1; }
+  // local tiles to wake per ghost vertex
+  std::vector<uint32_t> wptr(S.n_iface + 1, 0), wtile;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<uint32_t> fill(S.n_iface + 1, 0);
+    for (uint32_t t = S.t_lo; t < S.t_hi; ++t)
+      for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
+        const uint32_t i = idx_of[M.halo_verts[k]];
+        if (i == kNone || owner[i] == rank) continue;
+        if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = t;
+      }
+    if (pass == 0) { for (uint32_t i = 0; i < S.n_iface; ++i) wptr[i + 1] += wptr[i]; wtile.assign(wptr[S.n_iface] ? wptr[S.n_iface] : 1, 0); }
+  }
+  if (dev_upload(ctx, &S.d_iface_vert, S.iface_vert.data(), S.iface_vert.size())) return -1;
+  if (dev_upload(ctx, &S.d_iface_owner, owner.data(), S.n_iface)) return -1;
+  if (dev_upload(ctx, &S.d_wake_ptr, wptr.data(), wptr.size())) return -1;
+  if (dev_upload(ctx, &S.d_wake_tile, wtile.data(), wtile.size())) return -1;
+  if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
+  if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : S.graphs) (void)hipGraphExecDestroy(kv.second);   // the captured exchanges hold the old lists
+  S.graphs.clear();
+  S.ready = true; S.active = false;
+  return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
+}
+
+// The mesh of this context is ONE PART of a partitioned mesh (owned vertices + their 1-ring halo, local ids in ascending
+// global id so that every (value, id) tie breaks as on the whole mesh): all local tiles run, every held copy of an
+// interface vertex is packed (any value reached along real edges is an upper bound of the true distance) and takes the
+// reduced minimum, and the finalize pass does not ask a halo copy for a local predecessor.
+int mnav_shard_setup_partition(mnav_ctx* ctx, uint32_t n_exchange, const uint32_t* exchange_vertex, const uint8_t* owned)
+{
+  if (!ctx || !ctx->have_mesh || (n_exchange && !exchange_vertex) || !owned) { if (ctx) ctx->err = "mnav_shard_setup_partition: bad arguments or no mesh"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  const HostTiles& M = ctx->tiles_meta;
+  if (M.verts.size() != ctx->V || M.vert_tile.size() != ctx->V) { ctx->err = "tile maps missing"; return -1; }
+  auto& S = ctx->shard;
+  S.rank = 0; S.world = 1; S.partition = true; S.t_lo = 0; S.t_hi = M.ntiles;
+  S.iface_vert.assign(exchange_vertex, exchange_vertex + n_exchange);
+  S.n_iface = n_exchange;
+  std::vector<uint32_t> idx_of(ctx->V, kNone);
+  for (uint32_t i = 0; i < n_exchange; ++i) {
+    const uint32_t v = exchange_vertex[i];
+    if (v == kNone) continue;
+    if (v >= ctx->V || idx_of[v] != kNone) { ctx->err = "mnav_shard_setup_partition: exchange vertex out of range or listed twice"; return -1; }
+    idx_of[v] = i;
+  }
+  // tiles to wake when an exchanged value drops: the vertex's own tile and the tiles that hold it in their halo
+  std::vector<uint32_t> wptr((size_t)n_exchange + 1, 0), wtile;
+  for (int pass = 0; pass < 2; ++pass) {
+    std::vector<uint32_t> fill((size_t)n_exchange + 1, 0);
+    for (uint32_t i = 0; i < n_exchange; ++i) {
+      const uint32_t v = exchange_vertex[i];
+      if (v == kNone) continue;
+      if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = M.vert_tile[v];
+    }
+    for (uint32_t t = 0; t < M.ntiles; ++t)
+      for (uint32_t k = M.hptr[t]; k < M.hptr[t + 1]; ++k) {
+        const uint32_t i = idx_of[M.halo_verts[k]];
+        if (i == kNone) continue;
+        if (pass == 0) wptr[i + 1]++; else wtile[wptr[i] + fill[i]++] = t;
+      }
+    if (pass == 0) { for (uint32_t i = 0; i < n_exchange; ++i) wptr[i + 1] += wptr[i]; wtile.assign(wptr[n_exchange] ? wptr[n_exchange] : 1, 0); }
+  }
+  std::vector<uint8_t> zero(n_exchange ? n_exchange : 1, 0);
+  if (dev_upload(ctx, &S.d_iface_vert, S.iface_vert.data(), S.iface_vert.size())) return -1;
+  if (dev_upload(ctx, &S.d_iface_owner, zero.data(), n_exchange)) return -1;
+  if (dev_upload(ctx, &S.d_wake_ptr, wptr.data(), wptr.size())) return -1;
+  if (dev_upload(ctx, &S.d_wake_tile, wtile.data(), wtile.size())) return -1;
+  if (dev_upload(ctx, &S.d_owned, owned, (size_t)ctx->V)) return -1;
+  if (!S.d_changed) HIPCHK(hipMalloc((void**)&S.d_changed, 64));
+  if (!S.d_minpend) HIPCHK(hipMalloc((void**)&S.d_minpend, 64));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (auto& kv : S.graphs) (void)hipGraphExecDestroy(kv.second);   // the captured exchanges hold the old lists
+  S.graphs.clear();
+  S.ready = true; S.active = false;
+  return (int)S.n_iface + 1;                                          // floats in the exchange buffer (interface + robot vertex)
+}
+
+uint64_t mnav_device_bytes(const mnav_ctx* ctx)
+{
+  if (!ctx) return 0;
+  uint64_t n = 0;
+  for (const auto& kv : ctx->alloc_bytes) n += kv.second;             // mesh tables, tiles, costs, shard lists (dev_upload)
+  const uint64_t V = ctx->V ? ctx->V : 1;
+  for (const Slot& s : ctx->slots) {                                  // per-plan state (ensure_slots, ensure_tile_state)
+    n += 8 * V;
+    if (s.band_ready) n += 28 * V;
+    if (s.vecmap) n += 12 * V;
+    if (s.cvp_ready) n += (sizeof(PopKey) + 8) * V;
+    if (s.tpend0) n += 12ull * (ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1);
+  }
+  if (ctx->d_nbr) n += 8ull * 2 * ctx->E;
+  if (ctx->d_crn) n += 24ull * 3 * ctx->F;
+  if (ctx->d_blocked) n += V;
+  n += 4ull * ctx->paths_words;
+  return n;
+}
+
+int mnav_shard_info(const mnav_ctx* ctx, uint32_t* t_lo, uint32_t* t_hi, uint32_t* ntiles, uint32_t* n_iface)
+{
+  if (!ctx || !ctx->shard.ready) return -1;
+  if (t_lo) *t_lo = ctx->shard.t_lo;
+  if (t_hi) *t_hi = ctx->shard.t_hi;
+  if (ntiles) *ntiles = ctx->tiles_meta.ntiles;
+  if (n_iface) *n_iface = ctx->shard.n_iface + 1;
+  return 0;
+}
+
+static ShardDev shard_dev(const mnav_ctx* ctx)
+{
+  ShardDev D;
+  D.n_iface = ctx->shard.n_iface; D.rank = ctx->shard.rank; D.target = ctx->shard.target; D.partition = ctx->shard.partition ? 1u : 0u; D.iface_vert = ctx->shard.d_iface_vert; D.iface_owner = ctx->shard.d_iface_owner;
+  D.wake_ptr = ctx->shard.d_wake_ptr; D.wake_tile = ctx->shard.d_wake_tile;
+  return D;
+}
+
+int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit)
+{
+  if (check_ready(ctx)) return -1;
+  if (!ctx->shard.ready) { ctx->err = "mnav_shard_setup has not been called"; return -1; }
+  if (seed_vertex >= ctx->V || target_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (!(goal_dist_offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
+  ctx->err.clear();
+  ctx->cancel.store(0);
+  if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
+  ctx->want_vec = false;
+  ctx->tb.count_pending = false; ctx->tb_args_valid = false;         // slot 0 and d_res are taken over by the sharded plan
+  ctx->last_planner = kPlannerDijkstra; ctx->last_engine = 0; ctx->last_n = 0; ctx->caller_slot.clear();
+  if (materialize(ctx, false, cost_limit)) return -1;
+  if (ensure_slots(ctx, 1, false, false, false)) return -1;
+  if (ensure_paths(ctx, 1)) return -1;
+  if (ensure_tile_state(ctx, 1)) return -1;
+  if (tile_weights(ctx)) return -1;
+  auto& S = ctx->shard;
+  const HostTiles& M = ctx->tiles_meta;
+  Slot& s = ctx->slots[0];
+  Plan P; memset(&P, 0, sizeof(P));
+  P.planner = kPlannerDijkstra; P.V = ctx->V;
+  P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+  P.dist = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
+  P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+  P.offset = goal_dist_offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
+  for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
+  P.seed[0] = seed_vertex; P.target[0] = target_vertex; P.seed_face = kNone;
+  TilePlan T; memset(&T, 0, sizeof(T));
+  T.V = ctx->V; T.ntiles = M.ntiles;
+  T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+  T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
+  T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
+  T.seed = seed_vertex; T.target = target_vertex; T.offset = goal_dist_offset; T.max_rounds = 0x7FFFFFF0u;
+  T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
+  T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
+  T.t_lo = S.t_lo; T.t_hi = S.t_hi;
+  T.owned = S.partition ? S.d_owned : nullptr;
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, &P, sizeof(Plan), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, &T, sizeof(TilePlan), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
+  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, 1), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
+  if (gt < 1) gt = 1;
+  hipLaunchKernelGGL(k_tile_init, dim3(gt, 1), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.j = 0; S.seed = seed_vertex; S.target = target_vertex; S.offset = goal_dist_offset; S.active = true;
+  return 0;
+}
+
+int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  const uint32_t own = S.t_hi - S.t_lo;
+  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
+  if (G > own) G = own ? own : 1;
+  for (uint32_t r = 0; r < rounds; ++r, ++S.j)
+    hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)(S.j % 6));
+  if (iface_buf_dev)
+    hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, ctx->shard.d_changed, ctx->shard.d_minpend);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;
+  return 0;
+}
+
+int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  HIPCHK(hipMemsetAsync(S.d_changed, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)S.d_minpend, (int)kInfBits, 1, ctx->stream));   // +inf: "nothing pending"
+  const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
+  const uint32_t own = S.t_hi - S.t_lo;
+  const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
+  HIPCHK(hipGetLastError());
+  uint32_t mp = 0; float td = INFINITY;
+  HIPCHK(hipMemcpyAsync(&mp, S.d_minpend, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&td, ctx->slots[0].dist + S.target, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (local_min_out) *local_min_out = (mp >= 0x7f800000u) ? INFINITY : u2f(mp);
+  if (target_dist_out) *target_dist_out = td;
+  return 0;
+}
+
+// The same two steps without a host round trip, for an exchange loop that stays on the device (mesh_navigation_amd/sharded.py):
+// the library's stream is linked to `caller_stream` (the stream the caller's collectives are ordered on, e.g. torch's
+// current stream) by events -- our kernels start after what the caller enqueued so far, the caller's next operation after
+// ours.  mnav_shard_apply_async leaves {smallest pending wake-up, dist[target], -cancelled} in ctl_dev[0..2]: the caller
+// reduces those three floats over the ranks and looks at them once every few exchanges (an exchange after convergence
+// changes nothing).
+static int shard_link(mnav_ctx* ctx, hipStream_t caller, bool in)
+{
+  hipEvent_t& e = ctx->ev_link[in ? 0 : 1];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ctx->err = "event creation failed"; return -1; }
+  if (in) { HIPCHK(hipEventRecord(e, caller)); HIPCHK(hipStreamWaitEvent(ctx->stream, e, 0)); }
+  else { HIPCHK(hipEventRecord(e, ctx->stream)); HIPCHK(hipStreamWaitEvent(caller, e, 0)); }
+  return 0;
+}
+
+// One exchange is two fixed sequences of small launches (R rounds + pack; apply + min + control words): each is captured into a
+// hipGraph once per (R, round parity, buffers) and replayed -- the launches of a 10M-vertex plan are ~80 exchanges x 12.
+// KERNELS ONLY: with hipMemsetAsync / hipMemsetD32Async nodes at the head of the second graph (ROCm 7.2) a plan that started
+// right after another one read a wake-up word of the previous plan now and then (a stale "3" instead of +inf; gone with either
+// graph alone, with a device synchronisation at the start of the plan, or -- the fix -- with the two words cleared by the
+// pack kernel of the first sequence): memset nodes do not seem to be ordered like the kernels around them.
+static int shard_replay(mnav_ctx* ctx, const std::array<uint64_t, 3>& key, const std::function<int()>& enqueue)
+{
+  if (!ctx->use_graph) return enqueue();
+  auto& S = ctx->shard;
+  auto it = S.graphs.find(key);
+  if (it == S.graphs.end()) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue();
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    it = S.graphs.emplace(key, ge).first;
+  }
+  HIPCHK(hipGraphLaunch(it->second, ctx->stream));
+  return 0;
+}
+
+int mnav_shard_rounds_async(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev, void* caller_stream)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
+  const uint32_t own = S.t_hi - S.t_lo;
+  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)(own ? own : 1))) + 8;
+  if (G > own) G = own ? own : 1;
+  const uint32_t j0 = S.j % 6u;
+  const int rc = shard_replay(ctx, { ((uint64_t)rounds << 8) | j0, (uint64_t)(uintptr_t)iface_buf_dev, 1ull }, [&]() {
+    for (uint32_t r = 0; r < rounds; ++r)
+      hipLaunchKernelGGL(k_tile_round, dim3(G, 1), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, (int)((j0 + r) % 6u));
+    if (iface_buf_dev)
+      hipLaunchKernelGGL(k_shard_pack, dim3((S.n_iface + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, ctx->shard.d_changed, ctx->shard.d_minpend);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  S.j += rounds;
+  return shard_link(ctx, (hipStream_t)caller_stream, false);
+}
+
+int mnav_shard_apply_async(mnav_ctx* ctx, const float* iface_buf_dev, float* ctl_dev, void* caller_stream)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (!iface_buf_dev || !ctl_dev) { ctx->err = "null buffer"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  if (shard_link(ctx, (hipStream_t)caller_stream, true)) return -1;
+  const int rc = shard_replay(ctx, { (uint64_t)(uintptr_t)iface_buf_dev, (uint64_t)(uintptr_t)ctl_dev, 2ull }, [&]() {
+    const uint32_t nb = (S.n_iface + 1 + kBlock - 1) / kBlock;          // (k_shard_pack cleared the two accumulator words: kernels only in the graph)
+    hipLaunchKernelGGL(k_shard_apply, dim3(nb), dim3(kBlock), 0, ctx->stream, shard_dev(ctx), ctx->d_tplans, iface_buf_dev, S.d_changed);
+    const uint32_t own = S.t_hi - S.t_lo;
+    const uint32_t gm = std::min<uint32_t>(256, (std::max(own, 1u) + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_shard_minpend, dim3(gm), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, S.d_minpend);
+    hipLaunchKernelGGL(k_shard_ctl, dim3(1), dim3(64), 0, ctx->stream, S.d_minpend, ctx->d_tplans, ctx->d_cancel, ctl_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+  });
+  if (rc) return rc;
+  return shard_link(ctx, (hipStream_t)caller_stream, false);
+}
+
+int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev)
+{
+  if (!ctx || !ctx->shard.active) { if (ctx) ctx->err = "no sharded plan in progress"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  const uint32_t own = S.t_hi - S.t_lo;
+  if (own) {
+    uint32_t chunks = std::min<uint32_t>(4096u, own);
+    const uint32_t per = (own + chunks - 1) / chunks;
+    chunks = (own + per - 1) / per;
+    hipLaunchKernelGGL((k_dij_finalize<1, false>), dim3(1, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
+                       ctx->d_mismatch, ctx->d_res, per, 1u, FinBlocked{});
+  }
+  const uint32_t gv = (ctx->V + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(k_shard_owned, dim3(gv ? gv : 1), dim3(kBlock), 0, ctx->stream, ctx->V, ctx->d_vert_tile, S.t_lo, S.t_hi,
+                     ctx->slots[0].dist, ctx->slots[0].pred, dist_buf_dev, pred_buf_dev);
+  HIPCHK(hipGetLastError());
+  uint32_t mism = 0;
+  HIPCHK(hipMemcpyAsync(&mism, ctx->d_mismatch, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.active = false;
+  if (mism) { ctx->err = "sharded SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)"; return -2; }
+  return 0;
+}
+
+int mnav_shard_walk(mnav_ctx* ctx, uint32_t start_vertex, uint32_t seed_vertex, uint32_t cap, uint32_t* out_host)
+{
+  if (!ctx || !ctx->shard.ready || !out_host || ctx->slots.empty()) { if (ctx) ctx->err = "mnav_shard_walk: no sharded plan"; return -1; }
+  if (start_vertex >= ctx->V || seed_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (hipSetDevice(ctx->device) != hipSuccess) return -1;
+  auto& S = ctx->shard;
+  if (S.walk_cap < cap + 3u) {
+    (void)hipFree(S.d_walk); S.d_walk = nullptr;
+    HIPCHK(hipMalloc((void**)&S.d_walk, 4 * (size_t)(cap + 3u)));
+    S.walk_cap = cap + 3u;
+  }
+  hipLaunchKernelGGL(k_shard_walk, dim3(1), dim3(64), 0, ctx->stream, ctx->slots[0].pred, S.partition ? S.d_owned : nullptr, start_vertex, seed_vertex, cap, S.d_walk);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_host, S.d_walk, 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint32_t n = out_host[0];
+  if (n) HIPCHK(hipMemcpy(out_host + 3, S.d_walk + 3, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+

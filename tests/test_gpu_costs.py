@@ -80,3 +80,37 @@ def test_combination_stays_on_the_device(gpu_ctx_factory):
     assert np.array_equal(vc.view(np.uint32), costs.view(np.uint32)) and np.array_equal(ew.view(np.uint32), want.weights.view(np.uint32))
     vc2, ew2 = ctx.download_costs()
     assert np.array_equal(vc2.view(np.uint32), vc.view(np.uint32)) and np.array_equal(ew2.view(np.uint32), ew.view(np.uint32))
+
+
+def test_update_costs_with_the_callers_edge_weights(gpu_ctx_factory):
+    """mnav_update_costs + mnav_update_edge_weights on UPLOADED weights: the caller's own updateEdgeWeights (mesh_map.cpp:563-618) ran on
+    the host (here: the oracle's), the changed vertices and the weights of their edges go to the device -- the plans that follow equal
+    the plans on a full upload of the new arrays (what the plugin does behind mesh_gpu_planners/CostObserverLayer)."""
+    mesh = meshgen.terrain(160, 0.1, 23)
+    rng = np.random.default_rng(8)
+    c0 = rng.uniform(0.0, 0.5, mesh.V).astype(np.float32)
+    case0 = Case(mesh, c0, 1.0)
+    ctx = gpu_ctx_factory()
+    case0.upload(ctx)
+    s, t = mesh.vertex_at(0.1, 0.15), mesh.vertex_at(0.9, 0.85)
+    assert np.array_equal(ctx.plan_dijkstra(s, t).path, case0.om.dijkstra(case0.weights, case0.costs, s, t).path)
+    ids = rng.choice(mesh.V, 700, replace=False).astype(np.uint32)
+    c1 = c0.copy()
+    c1[ids] = rng.uniform(0.0, 0.95, ids.shape[0]).astype(np.float32)
+    case1 = Case(mesh, c1, 1.0)                                        # the host's recomputed weights
+    changed_edges = np.nonzero(np.isin(mesh.edges[:, 0], ids) | np.isin(mesh.edges[:, 1], ids))[0].astype(np.uint32)
+    assert (case1.weights.view(np.uint32) != case0.weights.view(np.uint32)).sum() > 0
+    assert not (case1.weights.view(np.uint32) != case0.weights.view(np.uint32))[np.setdiff1d(np.arange(mesh.E), changed_edges)].any()
+    ctx.update_costs(ids, c1[ids])
+    ctx.update_edge_weights(changed_edges, case1.weights[changed_edges])
+    vc, w = ctx.download_costs()
+    assert np.array_equal(vc.view(np.uint32), c1.view(np.uint32)) and np.array_equal(w.view(np.uint32), case1.weights.view(np.uint32))
+    for offset in (0.3, float("inf")):
+        ref = case1.om.dijkstra(case1.weights, case1.costs, s, t, goal_dist_offset=offset)
+        out = ctx.plan_dijkstra(s, t, goal_dist_offset=offset)
+        assert out.code == ref.code and np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.path, ref.path)
+    tg = rng.choice(mesh.V, 64, replace=False).astype(np.uint32)      # a batch: the tile-batch engine's weights follow too
+    b = ctx.plan_dijkstra_batch(np.full(64, s, np.uint32), tg, want_fields=False)
+    for k in (0, 31, 63):
+        refk = case1.om.dijkstra(case1.weights, case1.costs, s, int(tg[k]))
+        assert b["codes"][k] == refk.code and np.array_equal(b["paths"][k], refk.path)
