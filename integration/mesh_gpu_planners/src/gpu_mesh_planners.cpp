@@ -105,14 +105,17 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
     std::vector<float> vals(ids.size());
     std::vector<uint32_t> eids;
     std::vector<lvr2::EdgeHandle> edges;
-    for (size_t i = 0; i < ids.size(); ++i) {
+    bool broken = false;
+    for (size_t i = 0; i < ids.size() && !broken; ++i) {
       const lvr2::VertexHandle vH(ids[i]);
       const auto c = std::as_const(vc).get(vH);
       vals[i] = c ? *c : 0.f;
       edges.clear();
-      mesh->getEdgesOfVertex(vH, edges);
+      try { mesh->getEdgesOfVertex(vH, edges); }
+      catch (...) { broken = true; }                                   // a broken vertex (lvr2 panics, cf. dijkstra :312-321): take the full copy instead
       for (const auto eH : edges) eids.push_back((uint32_t)eH.idx());
     }
+    if (broken) return syncCosts(map, err, true);
     std::sort(eids.begin(), eids.end());
     eids.erase(std::unique(eids.begin(), eids.end()), eids.end());
     std::vector<float> evals(eids.size());
