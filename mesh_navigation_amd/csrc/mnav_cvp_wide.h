@@ -18,7 +18,7 @@
 #define MNAV_WIDE_VERTS 32
 #endif
 constexpr uint32_t kWideVerts = MNAV_WIDE_VERTS;   // work-list entries per wave and round (64, or 32: half the LDS image and shorter rounds for more resident waves)
-constexpr uint32_t kWideSlots = (kWideVerts * 13u) / 2u;   // items per wave and round: 6.5 faces per vertex (64 vertices: 20 KB of LDS; with the table below seven waves per CU)
+constexpr uint32_t kWideSlots = (kWideVerts * 13u) / 2u;   // items per wave and round: 6.5 faces per vertex (32 vertices: 10 KB of LDS + the table below = 12 KB; 64 vertices: 22 KB)
 constexpr int kWideOcc = kWideVerts == 64u ? 2 : 3;  // waves per SIMD the register allocator must reach
 constexpr uint32_t kWideSeen = 512;           // direct-mapped table of vertices this wave has pushed in this launch (see push_many)
 constexpr uint32_t kWideMaxFaces = 32;        // faces of one vertex that go through the items; beyond: the serial rule (eval_cvp)
@@ -331,7 +331,7 @@ __device__ __forceinline__ uint32_t wide_find_plan(const uint32_t* __restrict__ 
   return lo;
 }
 
-// bounded by its LDS image (seven waves per CU), not by registers
+// 32 entries per round: 12 KB of LDS and <= 168 VGPRs, 12 resident waves per CU (64 entries: 22 KB, 213 VGPRs, 7 waves)
 __global__ __launch_bounds__(kWave, kWideOcc) void k_step_wide(const Plan* __restrict__ plans, uint32_t n, int j, const uint32_t* __restrict__ prefix,
                                                         const WideSched* __restrict__ sched)
 {
