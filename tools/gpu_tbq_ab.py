@@ -1,5 +1,7 @@
-"""A/B of the tile-batch solve kernels: one tile per wave (MNAV_TB_GRAN=64) against the quarter-wave solve (16), on the C2 (1M)
-and C4 (10M) batch workloads.  Paths of the two runs must be identical."""
+"""Timing probe of the tile-batch engine on the C2 (1M) and C4 (10M) batch workloads: engine-run time, roofline fraction, phase
+cycles with a -DMNAV_TB_TIMING build (MNAV_LIB), band widths (BANDS).  Round 4 used it as the A/B of the one-tile-per-wave solve
+against the quarter-wave solve (the GRANS axis: the old kernel is gone, the values are only labels now); the paths of all runs of a
+workload must be identical."""
 import json
 import os
 import sys
