@@ -224,6 +224,25 @@ class PartModelEngine:
     def local_result(self):
         return self._dist, self._pred
 
+    def walker(self):
+        """the contract of mnav_shard_walk (include/mnav.h): [hops, stop vertex, status, local ids...] of one path segment inside this part"""
+        owned = self.part.owned
+
+        def walk(start, seed, cap):
+            out = np.zeros(cap + 3, np.uint32)
+            v, n, status = int(start), 0, 0
+            while v != seed and owned[v] and n < cap:
+                p = int(self._pred[v])
+                if p == v:
+                    status = 1
+                    break
+                out[3 + n] = p
+                n += 1
+                v = p
+            out[0], out[1], out[2] = n, v, status
+            return out
+        return walk
+
     @staticmethod
     def reduce_int64(host, allreduce_min):
         allreduce_min(host)

@@ -132,3 +132,32 @@ def test_partitioned_virtual_ranks_and_unreachable_target(world):
     engines = [_engine(case2, r, world) for r in range(world)]
     res2 = sharded.plan_virtual_ranks(engines, seed, target, rounds_per_exchange=3)
     assert res2.code == ref2.code == sharded.NO_PATH_FOUND
+
+
+@pytest.mark.parametrize("world", [3, 5])
+def test_path_segments_walked_by_the_parts_themselves(world):
+    """gather=False: nothing mesh-sized is assembled -- every part walks its own path segments (the contract of mnav_shard_walk,
+    here the CPU model's walker) and publishes them; short segments (cap 7) force many hand-overs, also inside one part."""
+    case = _case()
+    m = case.mesh
+    seed, target = m.vertex_at(0.1, 0.15), m.vertex_at(0.9, 0.85)
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target)
+    engines = [_engine(case, r, world) for r in range(world)]
+    res = sharded.plan_virtual_ranks(engines, seed, target, rounds_per_exchange=3, gather=False)
+    assert res.code == ref.code == 0 and res.dist is None and res.pred is None
+    assert np.array_equal(res.path, ref.path)
+    walkers = [e.walker() for e in engines]
+    code, path = sharded._walk_segments(
+        lambda cur, first: np.minimum.reduce([sharded._segment_of(e.part, w, cur, seed, first, 7) for e, w in zip(engines, walkers)]),
+        seed, target, m.V)
+    assert code == 0 and np.array_equal(path, ref.path)
+    # an unreachable robot vertex: the owner of the target reports it in the first segment
+    costs = case.costs.copy()
+    n = int(np.sqrt(m.V))
+    ids = np.arange(m.V).reshape(n, n)
+    costs[ids[:, n // 2]] = 5.0
+    costs[ids[:, n // 2 + 1]] = 5.0
+    case2 = Case(m, costs, 0.5)
+    engines = [_engine(case2, r, world) for r in range(world)]
+    res2 = sharded.plan_virtual_ranks(engines, m.vertex_at(0.2, 0.2), m.vertex_at(0.8, 0.7), rounds_per_exchange=3, gather=False)
+    assert res2.code == sharded.NO_PATH_FOUND and res2.path.size == 0
