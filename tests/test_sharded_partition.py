@@ -161,3 +161,38 @@ def test_path_segments_walked_by_the_parts_themselves(world):
     engines = [_engine(case2, r, world) for r in range(world)]
     res2 = sharded.plan_virtual_ranks(engines, m.vertex_at(0.2, 0.2), m.vertex_at(0.8, 0.7), rounds_per_exchange=3, gather=False)
     assert res2.code == sharded.NO_PATH_FOUND and res2.path.size == 0
+
+
+def _worker_paths_only(rank, world, port, seed, target, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = _engine(_case(), rank, world, asynchronous=True)
+    res = sharded.run_sharded_plan(eng, sharded.torch_allreduce_min(dist), seed, target, 0.3, rounds_per_exchange=4, check_every=3, gather=False)
+    q.put((rank, res.code, res.dist is None, res.path.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_partitioned_plan_paths_only_over_gloo():
+    """the production call of bench.py --config C4 --gpus N: gather=False, the path walked across the processes through real
+    int64 min-allreduces -- every rank ends up with the reference's path, nothing mesh-sized is exchanged"""
+    case = _case()
+    m = case.mesh
+    seed, target = m.vertex_at(0.1, 0.15), m.vertex_at(0.9, 0.85)
+    ref = case.om.dijkstra(case.weights, case.costs, seed, target)
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_paths_only, args=(r, world, port, seed, target, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g[0] for g in got) == list(range(world))
+    for _, code, no_fields, path in got:
+        assert code == ref.code == 0 and no_fields and path == ref.path.tolist()
