@@ -118,9 +118,9 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
  * (predecessors_), vecmap_out V*3 (vector_map_, zero rows where the reference has no entry),
  * path_out/path_len: the vertex path in dijkstra()'s list order (seed first ... pred[target]),
  * at most path_cap entries are written, *path_len is the full length.
- * goal_dist_offset must be >= 0 (reference default 0.3): a negative value is refused with MNAV_INTERNAL_ERROR -- the
- * reference would then stop expanding vertices it popped before the robot vertex, which the pruning engines cannot
- * reproduce. */
+ * goal_dist_offset: any double like the reference's parameter (default 0.3).  A negative value stops the expansion at the
+ * robot vertex (only vertices popped before it are sources, :293-300) and is reproduced exactly; NaN is refused.  The CVP
+ * and sharded entry points below still refuse negative offsets with MNAV_INTERNAL_ERROR. */
 uint32_t mnav_plan_dijkstra(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex,
                             double goal_dist_offset, double cost_limit, float* dist_out,
                             uint32_t* pred_out, uint32_t* path_out, uint32_t path_cap,

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
     cur.sweeps = prev.sweeps + cprev.sweeps;
     const float m = u2f(cprev.minpend);
     const float dt = P.dist[P.target];
-    const float bound = (float)((double)dt + P.offset);            // >= the final goal_dist (dijkstra :296)
+    const float bound = (float)((double)dt + fmax(P.offset, 0.0)); // >= the final goal_dist (dijkstra :296); a negative offset is applied in the finalize pass (goal_cut)
     cur.done = (prev.done || !(m < inf_f()) || m > bound || (uint32_t)cur.it >= P.max_rounds) ? 1u : 0u;
     if (!cur.done && !(m < prev.thr)) {                             // band exhausted: advance
       cur.thr_prev = prev.thr;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
     if ((tid & 63) == 0) s_best[tid >> 6] = best;
     if (tid == 0) {
       const float dt = ldg_f32(g_dist + P.target);
-      s_bound = (float)((double)dt + P.offset);                    // >= the final goal_dist (dijkstra :296)
+      s_bound = (float)((double)dt + fmax(P.offset, 0.0));         // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
       // mnav_cancel (dijkstra :287 `&& !cancel_planning_`): a word in device memory that mnav_cancel sets with a
       // 4-byte copy on its own stream; one agent-scope load every 16 tile activations (~0.3 ms)
       if ((acts & 15u) == 0u) s_stop = P.cancel ? __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -1141,11 +1141,11 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
   unsigned long long* const lkey = reinterpret_cast<unsigned long long*>(lgid + pad_to(T.max_nv + T.max_nh, 4));
   const uint32_t np = (n_plans - p0 < (uint32_t)PG) ? n_plans - p0 : (uint32_t)PG;   // plans of this group
   // per plan of the group: seed, goal_dist, armed, settled count
-  __shared__ uint32_t s_seed[PG], s_armed[PG], s_settled[PG];
-  __shared__ float s_goal[PG];
+  __shared__ uint32_t s_seed[PG], s_armed[PG], s_settled[PG], s_tie[PG];
+  __shared__ float s_goal[PG], s_cut[PG];
   if (tid < PG) {
     const int q = tid;
-    s_settled[q] = 0u; s_seed[q] = kNone; s_goal[q] = inf_f(); s_armed[q] = 0u;
+    s_settled[q] = 0u; s_seed[q] = kNone; s_goal[q] = inf_f(); s_cut[q] = inf_f(); s_tie[q] = kNone; s_armed[q] = 0u;
     if ((uint32_t)q < np) {
       const Plan& P = plans[p0 + q];
       s_seed[q] = P.seed[0];
@@ -1154,7 +1154,8 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       if (BLOCKED) { const uint2 a = B.vaddr[tg]; dt = B.D[(size_t)a.x * B.NP + (size_t)(p0 + q) * (a.y >> 8) + (a.y & 255u)]; }
       else dt = P.dist[tg];
       s_armed[q] = dt < inf_f() ? 1u : 0u;
-      s_goal[q] = s_armed[q] ? (float)((double)dt + P.offset) : inf_f();   // dijkstra :296
+      const GoalCut gc = goal_cut(dt, P.offset, tg);                 // dijkstra :296
+      s_goal[q] = gc.goal; s_cut[q] = gc.cut; s_tie[q] = gc.tie;
     }
   }
   uint32_t bad = 0;
@@ -1196,7 +1197,8 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       const Plan& P = plans[p];
       MNAV_GLOBAL float* g_dist = as_global(P.dist);
       MNAV_GLOBAL uint32_t* g_pred = as_global(P.pred);
-      const float goal_dist = s_goal[q];
+      GoalCut gcut; gcut.goal = s_goal[q]; gcut.cut = s_cut[q]; gcut.tie = s_tie[q];
+      const float goal_dist = gcut.cut;                              // values above it are re-derived from the expanded sources
       const uint32_t seed_q = s_seed[q];
       MNAV_GLOBAL float* g_vm = (BLOCKED && B.vecmaps) ? as_global(B.vecmaps[p]) : nullptr;
       auto value_of = [&](uint32_t gid) -> uint32_t {
@@ -1244,7 +1246,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
         // pass 1 (tiles on the cut-off boundary only): smallest sum offered to the vertices above goal_dist
         for (uint32_t x = tid; x < nl; x += kTileBlock) {
           const float dx = u2f(L.ldu[x]);
-          if (!(dx < inf_f()) || dx > goal_dist) continue;           // not expanded (dijkstra :293-300)
+          if (!expanded_source(gcut, dx, lgid[x])) continue;         // not expanded (dijkstra :293-300)
           for (uint32_t e = L.lrow[x], ee = L.lrow[x + 1]; e < ee; ++e) {
             const uint32_t y = L.lcol[e];
             if (y < nv && u2f(L.ldu[y]) > goal_dist) atomicMin(&lsum[y], f2u(dx + L.lw[e]));   // dijkstra :331
@@ -1258,7 +1260,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
         const uint32_t dxb = L.ldu[x];
         const uint32_t eb = L.lrow[x], ee = L.lrow[x + 1];
         const float dx = u2f(dxb);
-        if (!(dx < inf_f()) || dx > goal_dist) continue;
+        if (!expanded_source(gcut, dx, lgid[x])) continue;
         const unsigned long long key = ((unsigned long long)dxb << 32) | lgid[x];
         uint32_t y[8]; float w[8];
 #pragma unroll
@@ -1469,7 +1471,8 @@ __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ pl
   const TCtl last = (a.it > b.it) ? a : b;
   const uint32_t seed = P.seed[0], target = P.target[0];
   const float dt = P.dist[target];
-  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + P.offset) : inf_f();
+  const GoalCut gcut = goal_cut(dt, P.offset, target);
+  const float goal_dist = gcut.goal;
   uint32_t code = kSuccess, n = 0, bad = 0;
   if (last.pad[0] || !last.done) code = kInternalError;               // activation cap hit / not finished
   else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
@@ -1485,7 +1488,7 @@ __global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ pl
       for (uint32_t i = beg + lane; i < end; i += kWave) {
         const Nbr nb = P.nbr[i];
         const float du = P.dist[nb.u];
-        if (du > goal_dist) continue;                                 // never expanded (dijkstra :299)
+        if (!expanded_source(gcut, du, nb.u)) continue;               // never expanded (dijkstra :299)
         const float sm = du + nb.w;                                   // :331
         if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
       }
@@ -1528,7 +1531,7 @@ __global__ __launch_bounds__(kBlock) void k_count_goal(const Plan* __restrict__ 
 {
   const Plan& P = plans[blockIdx.y];
   const float dt = P.dist[P.target[0]];
-  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + P.offset) : inf_f();
+  const float goal_dist = goal_cut(dt, P.offset, P.target[0]).cut;
   uint32_t c = 0;
   const uint32_t stride = gridDim.x * kBlock;
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) { const float d = P.dist[v]; c += (d < inf_f() && d <= goal_dist) ? 1u : 0u; }
@@ -3428,10 +3431,11 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
 {
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
-  // goal_dist = dist[target] + offset cuts the wave off BEHIND the robot (dijkstra :296).  With a negative offset the
-  // reference stops expanding vertices it popped before the target; the engines prune with the running bound and would
-  // return a tentative target value as final -- refused rather than answered wrongly (the parameter's default is 0.3).
-  if (!(offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return MNAV_INTERNAL_ERROR; }
+  // goal_dist = dist[target] + offset cuts the wave off BEHIND the robot (dijkstra :296).  A negative offset (the reference
+  // takes any double) stops the expansion AT the robot vertex: the engines run with the bound of offset 0 -- everything at or
+  // below dist[target] is final then -- and the passes that derive tentative values, predecessors and paths apply the
+  // reference's expanded set through goal_cut() (mnav_eval.h).
+  if (offset != offset) { ctx->err = "goal_dist_offset is NaN"; return MNAV_INTERNAL_ERROR; }
   ctx->cancel.store(0);                                               // dijkstra :238
   if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   want_vecmap = want_vecmap || ctx->resident_vecmap;
@@ -3476,6 +3480,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       engine = fills ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
     }
     if (engine == 5 && m0 > 65535u) engine = 2;
+    if (engine == 1 && offset < 0.0) engine = 0;                      // the band steps arm goal_dist inside the loop: tile rounds for a negative offset
   }
   if (engine == 5 && in.size() > 1) {
     // plans whose waves start close to each other are neighbours in the batch: their slices of a tile are adjacent in memory

@@ -540,6 +540,25 @@ MNAV_HD bool key_descends_from_pre(const Plan& P, PopKey a, uint32_t v)   // a =
 }
 MNAV_HD bool key_descends_from(const Plan& P, uint32_t t, uint32_t v) { return key_descends_from_pre(P, P.tkey[t], v); }   // (no shortcut through hi / lvl: both may be stale)
 
+// --- which sources the Dijkstra wave expands, as a test on FINAL values ------------------------
+// The reference pops vertices in (value, id) order, arms goal_dist = float(dist[target] + offset) when the robot vertex pops
+// (dijkstra :293-297) and from then on skips every popped vertex above it (:299).  Everything popped BEFORE the robot vertex
+// was expanded whatever the offset.  So with goal_dist >= dist[target] the expanded set is {d <= goal_dist}; with a negative
+// offset that rounds below dist[target] it is {popped before the robot vertex} = {d < dt or (d == dt and id < target)}, the
+// robot vertex itself not among them.  One predicate for both: d < cut || (d == cut && id < tie).
+struct GoalCut { float goal, cut; uint32_t tie; };
+MNAV_HD GoalCut goal_cut(float dt, double offset, uint32_t target)
+{
+  GoalCut g; g.goal = inf_f(); g.cut = inf_f(); g.tie = kNone;
+  if (dt < inf_f()) {
+    g.goal = (float)((double)dt + offset);                             // dijkstra :296
+    g.cut = g.goal;
+    if (g.goal < dt) { g.cut = dt; g.tie = target; }
+  }
+  return g;
+}
+MNAV_HD bool expanded_source(const GoalCut& g, float d, uint32_t id) { return d < inf_f() && (d < g.cut || (d == g.cut && id < g.tie)); }
+
 // --- arming of goal_dist once the robot vertex / robot face is settled -----------------------
 // Dijkstra: goal_dist = dist[target] + offset when the target pops (dijkstra :293-297).
 // CVP: when a robot-face vertex pops that passes the cut-offs while all three are fixed

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
   A.marr[par ^ 1][p] = kTbInfBits;
   const float m = u2f(mb);
   const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
-  const float bound = (float)((double)dt + A.offset);               // >= the final goal_dist (dijkstra :296)
+  const float bound = (float)((double)dt + fmax(A.offset, 0.0));    // >= the final goal_dist (dijkstra :296); a negative offset is applied after the rounds (goal_cut)
   const bool done = !(m < inf_f()) || m > bound;
   float thr = m + A.band;
   if (!(thr > m)) thr = next_up(m);
@@ -577,7 +577,8 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
   PlanResult& R = res[p];
   const uint32_t seed = A.seed[p], target = A.target[p];
   const float dt = A.D[tb::slot_addr(A.vaddr[target], A.NP, p)];
-  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+  const GoalCut gcut = goal_cut(dt, A.offset, target);
+  const float goal_dist = gcut.goal;
   uint32_t code = kSuccess, n = 0, bad = 0;
   if (A.ctl->err || A.ctl->n_cand[0]) code = kInternalError;          // sweep cap hit / pairs still pending (the host stops after an odd iteration: counter 0 is its count)
   else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(kWave) void k_tb_path(tb::Args A, const uint32_t* _
       for (uint32_t i = beg + lane; i < end; i += kWave) {
         const Nbr nb = nbr[i];
         const float du = A.D[tb::slot_addr(A.vaddr[nb.u], A.NP, p)];
-        if (du > goal_dist) continue;                                 // never expanded (dijkstra :299)
+        if (!expanded_source(gcut, du, nb.u)) continue;               // never expanded (dijkstra :299)
         const float sm = du + nb.w;                                   // :331
         if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
       }
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(kWave) void k_tb_vector3(tb::Args A, const uint32_t
   const int lane = threadIdx.x;
   const uint32_t v = blockIdx.x == 0 ? vs.x : blockIdx.x == 1 ? vs.y : vs.z;
   const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
-  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+  const GoalCut gcut = goal_cut(dt, A.offset, A.target[p]);
   float best_s = inf_f(), best_du = inf_f();
   uint32_t best_u = v;
   if (v != A.seed[p]) {
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kWave) void k_tb_vector3(tb::Args A, const uint32_t
     for (uint32_t i = beg + lane; i < end; i += kWave) {
       const Nbr nb = nbr[i];
       const float du = A.D[tb::slot_addr(A.vaddr[nb.u], A.NP, p)];
-      if (du > goal_dist) continue;                                   // never expanded (dijkstra :299)
+      if (!expanded_source(gcut, du, nb.u)) continue;                 // never expanded (dijkstra :299)
       const float sm = du + nb.w;                                     // :331
       if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
     }
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_count(tb::Args A, uint32_t T, Pla
   const TbTile W = A.tiles[t];
   for (uint32_t p = blockIdx.y * (kBlock / 64) + wid; p < A.NP; p += gridDim.y * (kBlock / 64)) {
     const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
-    const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+    const float goal_dist = goal_cut(dt, A.offset, A.target[p]).cut;
     const float* sl = A.D + ((size_t)W.soff * A.NP + (size_t)p * W.sl);
     uint32_t c = 0;
     for (uint32_t i = lane; i < W.nv; i += 64) { const float d = sl[i]; c += (d < inf_f() && d <= goal_dist) ? 1u : 0u; }
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_count(tb::Args A, uint32_t T, Pla
 __global__ __launch_bounds__(kBlock) void k_tb_popped(tb::Args A, uint32_t p, uint32_t V, float* __restrict__ out)
 {
   const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
-  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + A.offset) : inf_f();
+  const float goal_dist = goal_cut(dt, A.offset, A.target[p]).cut;    // (a negative offset: final wherever d <= dist[target])
   const uint32_t stride = gridDim.x * kBlock;
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) {
     const float d = A.D[tb::slot_addr(A.vaddr[v], A.NP, p)];
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_popped(tb::Args A, uint32_t p, ui
 __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dist, uint32_t target, double offset, uint32_t V, float* __restrict__ out)
 {
   const float dt = dist[target];
-  const float goal_dist = (dt < inf_f()) ? (float)((double)dt + offset) : inf_f();
+  const float goal_dist = goal_cut(dt, offset, target).cut;
   const uint32_t stride = gridDim.x * kBlock;
   for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < V; v += stride) { const float d = dist[v]; out[v] = (d <= goal_dist) ? d : inf_f(); }
 }

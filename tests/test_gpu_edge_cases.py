@@ -217,12 +217,33 @@ def test_paths_longer_than_the_default_rows_are_walked_again_into_exact_rows(gpu
     ctx.set_dijkstra_engine("auto")
 
 
-def test_negative_goal_dist_offset_is_refused(gpu_ctx_factory):
-    case = terrain_case(64, 3)
-    ctx = gpu_ctx_factory()
-    case.upload(ctx)
-    with pytest.raises(RuntimeError, match="goal_dist_offset"):
-        ctx.plan_dijkstra(3, 900, goal_dist_offset=-0.1)
-    with pytest.raises(RuntimeError, match="goal_dist_offset"):
-        ctx.plan_dijkstra_batch(np.array([3, 4], np.uint32), np.array([900, 901], np.uint32), goal_dist_offset=float("nan"))
-    assert ctx.plan_dijkstra(3, 900, goal_dist_offset=0.0).code == 0
+def test_negative_goal_dist_offset_matches_the_reference(gpu_ctx_factory):
+    """goal_dist_offset is any double in the reference (dijkstra_mesh_planner.cpp:151, :296).  Below zero the wave stops
+    expanding AT the robot vertex: sources are the vertices popped before it in (value, id) order.  Potential, predecessors
+    and path bit-exact on every engine, on a jittered terrain and on a flat grid (many vertices tie with the robot vertex's
+    value: the id half of the rule); an offset that rounds away (dist - 1e-9 == dist in float32) behaves like 0."""
+    for case, pairs in ((terrain_case(64, 3), ((3, 900), (2000, 77), (4095, 1))),
+                        (Case(meshgen.flat_grid(40, 1.0)), ((820, 831), (820, 207), (820, 3)))):
+        ctx = gpu_ctx_factory()
+        case.upload(ctx)
+        seeds = np.array([p[0] for p in pairs], np.uint32)
+        targets = np.array([p[1] for p in pairs], np.uint32)
+        for off in (-0.2, -1e-9, -50.0, float("-inf")):
+            refs = [case.om.dijkstra(case.weights, case.costs, int(s), int(t), goal_dist_offset=off) for s, t in pairs]
+            for engine in ENGINES:
+                ctx.set_dijkstra_engine(engine)
+                for (s, t), ref in zip(pairs, refs):
+                    assert_dijkstra_equal(ctx.plan_dijkstra(s, t, goal_dist_offset=off), ref)
+                b = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=off, want_fields=True)
+                for k, ref in enumerate(refs):
+                    assert b["codes"][k] == ref.code == 0
+                    assert np.array_equal(b["dist"][k].view(np.uint32), ref.dist.view(np.uint32)), (engine, off, k)
+                    assert np.array_equal(b["pred"][k], ref.pred), (engine, off, k)
+                    assert np.array_equal(b["paths"][k], ref.path), (engine, off, k)
+                b = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=off)          # paths only: no finalize pass
+                for k, ref in enumerate(refs):
+                    assert np.array_equal(b["paths"][k], ref.path), (engine, off, k)
+        ctx.set_dijkstra_engine("auto")
+        with pytest.raises(RuntimeError, match="goal_dist_offset"):
+            ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=float("nan"))
+        assert ctx.plan_dijkstra(int(seeds[0]), int(targets[0]), goal_dist_offset=0.0).code == 0
