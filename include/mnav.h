@@ -282,9 +282,11 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
 /* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round,
  * lowest latency for a single plan), 1 = the distance-band gather steps that the CVP planner uses,
  * 2 = persistent per-plan workgroups walking the tiles best-first (medium batches),
- * 3 = automatic (default: 5 for paths-only batches of >= 256 plans, 2 for batches of >= 128 plans, else 0),
+ * 3 = automatic (default: 5 for batches of >= 48 plans that also hold >= tiles/1000 plans, else 0; 2 only on request),
  * 5 = tile-batch: one wave per (tile, up to 64 plans), one plan per lane, the tile's graph as scalar data
- * (highest throughput for large batches; paths-only calls).  All give identical results. */
+ * (highest throughput for large batches; paths-only calls),
+ * 6 = the LDS tiles without rounds: resident workgroups claim, solve and wake tiles asynchronously, one launch per call
+ * (single plans and small batches; opt-in, never chosen by 3).  All give identical results. */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
 /* Outputs that stay on the device.  mnav_set_resident_outputs(ctx, 1): every plan also computes its vector map
  * (computeVectorMap, dijkstra :189-209 / cvp :204-239) and leaves it in HBM even when no host buffer is passed.

@@ -1047,6 +1047,8 @@ __global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_per
   }
 }
 
+#include "mnav_async.h"   // k_plan_async: the tiles without rounds (engine 6, opt-in)
+
 __global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile, float tlast0)
 {
   const TilePlan& P = plans[blockIdx.y];
@@ -2002,7 +2004,7 @@ struct mnav_ctx {
   float* d_seed_pos = nullptr; uint32_t seed_pos_cap = 1;
   std::map<uint64_t, hipGraphExec_t> graphs;
   // tiled SSSP engine
-  int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 2 persistent per-plan, 3 auto
+  int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 2 persistent per-plan, 3 auto, 5 tile-batch, 6 asynchronous tiles (opt-in)
   int last_engine = 0;
   uint32_t persistent_min_batch = 128;
   bool lazy_paths = false;      // this call only wants vertex paths: k_path_lazy instead of k_dij_finalize + k_finish
@@ -2700,6 +2702,96 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   return 0;
 }
 
+// Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1 or 1 (cancelled).
+int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
+{
+  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
+  if (ensure_paths(ctx, n)) return -1;
+  if (ensure_tile_state(ctx, n)) return -1;
+  if (tile_weights(ctx)) return -1;
+  const HostTiles& M = ctx->tiles_meta;
+  std::vector<Plan> hp(n);
+  std::vector<TilePlan> tp(n);
+  std::vector<float*> vecs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    Slot& s = ctx->slots[i];
+    Plan& P = hp[i];
+    memset(&P, 0, sizeof(P));
+    P.planner = kPlannerDijkstra; P.V = ctx->V;
+    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
+    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
+    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
+    P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
+    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
+    P.seed_face = kNone;
+    vecs[i] = s.vecmap;
+    TilePlan& T = tp[i];
+    memset(&T, 0, sizeof(T));
+    T.V = ctx->V; T.ntiles = M.ntiles;
+    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
+    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
+    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
+    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
+    T.max_rounds = 0x7FFFFFF0u;
+    T.cancel = ctx->d_cancel;
+    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
+    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
+  }
+  AsyncCtl* const actl = reinterpret_cast<AsyncCtl*>(ctx->d_cancel + 4);   // words 4..7 of the 64-byte control line (word 0: mnav_cancel)
+  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(actl, 0, sizeof(AsyncCtl), ctx->stream));     // every polled word is zeroed on the stream before every launch
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
+  if (gi < 1) gi = 1;
+  if (gi > 4096) gi = 4096;
+  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
+  {
+    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
+    if (gt < 1) gt = 1;
+    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
+    hipLaunchKernelGGL(k_async_init, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_tplans, n);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
+  // Workgroups: what is resident at once, and no more per plan than its wavefront has tiles for (idle workgroups poll).
+  int ncu = 256;
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  uint32_t per_cu = 2, per_plan = 48;
+  if (const char* e = getenv("MNAV_ASYNC_WG_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
+  if (const char* e = getenv("MNAV_ASYNC_WG_PER_PLAN")) per_plan = (uint32_t)std::max(1, atoi(e));
+  uint32_t G = std::min<uint64_t>((uint64_t)ncu * per_cu, (uint64_t)n * per_plan);
+  if (G > M.ntiles * n) G = M.ntiles * n;
+  if (G < 1) G = 1;
+  double guard_s = std::min(ctx->max_wall_s, 10.0);                   // in-kernel give-up (100 MHz wall clock)
+  if (const char* e = getenv("MNAV_ASYNC_MAX_S")) guard_s = atof(e);
+  const unsigned long long limit_ticks = (unsigned long long)(guard_s * 1.0e8);
+  ctx->ms_chunks = 0.0;
+  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
+  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_async<2>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
+  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_async<4>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
+  else hipLaunchKernelGGL(k_plan_async<8>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
+  AsyncCtl h{};
+  HIPCHK(hipMemcpyAsync(&h, actl, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
+  ctx->stats.launches = 1;
+  if (getenv("MNAV_VERBOSE"))
+    fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, claim fails %u, idle passes %u\n", n, G, ctx->ms_chunks, h.abort, h.claim_fails, h.idle_passes);
+  if (h.abort == 3u || ctx->cancel.load(std::memory_order_relaxed)) return 1;   // :350-354
+  if (h.abort) { ctx->err = "asynchronous tile engine gave up (in-kernel wall-clock guard)"; return -1; }
+  if (h.done_plans != n) { ctx->err = "asynchronous tile engine left plans unfinished"; return -1; }
+  if (!ctx->lazy_paths) launch_finalize(ctx, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
+  return 0;
+}
+
 #include "mnav_tb_host.h"
 
 float ev_ms(hipEvent_t a, hipEvent_t b)
@@ -2775,7 +2867,7 @@ mnav_ctx* mnav_create(int device)
     if (!strcmp(e, "band") || !strcmp(e, "1")) ctx->dij_engine = 1;
     else if (!strcmp(e, "tiled") || !strcmp(e, "0")) ctx->dij_engine = 0;
     else if (!strcmp(e, "persistent") || !strcmp(e, "2")) ctx->dij_engine = 2;
-    else if (!strcmp(e, "wave") || !strcmp(e, "4")) ctx->dij_engine = 4;
+    else if (!strcmp(e, "async") || !strcmp(e, "6")) ctx->dij_engine = 6;
     else ctx->dij_engine = 3;
   }
   if (const char* e = getenv("MNAV_PERSISTENT_MIN_BATCH")) ctx->persistent_min_batch = (uint32_t)atoi(e);
@@ -2920,6 +3012,9 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
     }
     if (getenv("MNAV_VERBOSE"))
       fprintf(stderr, "[mnav] tiles: size %u, %u tiles, max owned %u, halo %u, edges %u -> LDS %zu B (solve), %zu B (finalize)\n",
@@ -3521,6 +3616,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     const bool want_path = true;
     const int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
                  : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
+                 : (engine == 6) ? run_dijkstra_async(ctx, m, in, offset)
                  : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
                                  : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
     MTRACE("engine returned");
@@ -3840,7 +3936,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta)
 
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 {
-  if (!ctx || engine < 0 || engine > 5 || engine == 4) return -1;   // 4 was the one-wave-per-plan experiment (removed)
+  if (!ctx || engine < 0 || engine > 6 || engine == 4) return -1;   // 4 was the one-wave-per-plan experiment (removed)
   ctx->dij_engine = engine;
   return 0;
 }

@@ -1,0 +1,310 @@
+// async_model.cpp -- CPU model of the PROTOCOL of the asynchronous tile engine (mesh_navigation_amd/csrc/mnav_async.h).
+//
+// TEST INFRASTRUCTURE ONLY (lives under oracle/): never linked into, loaded by, or reachable from the product library.
+//
+// The engine has no rounds: workgroups claim tiles, solve them and wake their neighbours concurrently, and a plan is
+// finished when a counter of pending-or-in-solve tiles reaches zero.  What can go wrong there is the protocol -- a lost
+// wake-up, a premature "finished", two solvers on one tile, a wake-up consumed by a solve whose band does not hold it --
+// not the tile solve (k_tile_round's, tested on the device).  This model restates k_plan_async operation by operation
+// (same words, same order of the shared-memory operations, same decisions) on the tile tables the product builds
+// (mnav_build.h::build_tiles) and runs W virtual workgroups as threads of which exactly ONE runs at a time: before every
+// shared-memory operation a workgroup hands the baton to a pseudo-randomly chosen one (seeded: reproducible), so a test
+// sweeps thousands of different interleavings at the granularity of single atomics.  Checked while it runs: at every
+// plan_finish no tile of the plan is pending, locked or in solve, and it happens once per plan; never two solvers on a
+// tile.  Checked by the test: the distances against the sequential oracle.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../mesh_navigation_amd/csrc/mnav_build.h"
+
+using namespace mnav;
+
+namespace {
+constexpr uint32_t kInf = 0x7f800000u;
+constexpr uint32_t kWakeSlots = 32;       // kAsyncWake
+
+struct PlanState {
+  std::vector<uint32_t> dist, pend, lock, tlast;   // float bits
+  uint32_t work = 1, acts = 0, sweeps = 0, done = 0, finishes = 0;
+  uint32_t seed = 0, target = 0;
+  std::vector<uint8_t> in_solve;                   // model only: a workgroup is between claim and unlock
+};
+
+struct Model {
+  HostTiles T;
+  std::vector<float> tw;
+  std::vector<PlanState> plans;
+  double offset = 0.0; float band = 1.f;
+  // scheduler: one runner at a time
+  std::mutex m; std::condition_variable cv;
+  int turn = 0; std::vector<uint8_t> alive; std::mt19937 rng;
+  uint64_t yields = 0, claim_fails = 0, drops = 0, violations = 0, solves_now = 0, max_solves = 0, putbacks = 0, raised = 0;
+  uint32_t done_plans = 0, abort = 0;
+  uint64_t budget = 0;                             // yield budget: the model's wall-clock guard
+  // deliberately broken variants, to show that the checks see protocol errors (tests/test_async_model.py): 1 = a waker counts the
+  // tile AFTER its atomicMin, 2 = no lock (two solvers on a tile)
+  uint32_t mutate = 0;
+
+  // Uniformly random hand-offs almost never stall ONE workgroup for the length of another one's whole solve -- the windows
+  // protocol errors hide in (a waker between its atomicMin and its count, a claimer between its scan and its claim).  So
+  // every now and then the running workgroup is put to sleep for up to a few thousand scheduling points.
+  std::vector<uint64_t> sleep_until;
+  int next_runner()
+  {
+    std::vector<int> c;
+    for (size_t i = 0; i < alive.size(); ++i) if (alive[i] && sleep_until[i] <= yields) c.push_back((int)i);
+    if (c.empty()) for (size_t i = 0; i < alive.size(); ++i) if (alive[i]) c.push_back((int)i);
+    return c.empty() ? -1 : c[rng() % c.size()];
+  }
+  void pass(int me)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    ++yields;
+    if (yields > budget) abort = 2;
+    if (rng() % 48u == 0u) sleep_until[me] = yields + 1u + rng() % 6000u;
+    turn = next_runner();
+    cv.notify_all();
+    cv.wait(lk, [&] { return turn == me; });
+  }
+  void leave(int me)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    alive[me] = 0;
+    const int nx = next_runner();
+    if (nx >= 0) { turn = nx; cv.notify_all(); }
+  }
+  void enter(int me)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return turn == me; });
+  }
+};
+
+struct Wg {
+  Model& M; int me; std::mt19937 rng;
+  Wg(Model& m_, int me_, uint32_t seed) : M(m_), me(me_), rng(seed) {}
+  // every shared-memory operation is preceded by a scheduling point
+  uint32_t ld(const uint32_t& w) { M.pass(me); return w; }
+  void st(uint32_t& w, uint32_t v) { M.pass(me); w = v; }
+  uint32_t add(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = o + v; return o; }
+  uint32_t sub(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = o - v; return o; }
+  uint32_t amin(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; if (v < o) w = v; return o; }
+  uint32_t xchg(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = v; return o; }
+  bool cas(uint32_t& w, uint32_t e, uint32_t v) { M.pass(me); if (w != e) return false; w = v; return true; }
+
+  void plan_finish(PlanState& P)
+  {
+    // model-only checks, on a consistent snapshot (nobody else runs): nothing of the plan is pending, locked or in solve
+    for (size_t t = 0; t < P.pend.size(); ++t)
+      if (P.pend[t] != kInf || P.lock[t] != kInf || P.in_solve[t]) ++M.violations;
+    if (P.work != 0) ++M.violations;
+    ++P.finishes;
+    st(P.done, 1u);
+    add(M.done_plans, 1u);
+  }
+  void work_dec(PlanState& P, bool& fin) { if (sub(P.work, 1u) == 1u) fin = true; }
+  void wake(PlanState& P, bool& fin, uint32_t t2, uint32_t v)
+  {
+    if (M.mutate == 1u) { if (amin(P.pend[t2], v) == kInf) add(P.work, 1u); return; }
+    add(P.work, 1u);
+    if (amin(P.pend[t2], v) != kInf) work_dec(P, fin);
+  }
+
+  void run(uint32_t n, uint32_t home0)
+  {
+    M.enter(me);
+    const HostTiles& T = M.T;
+    uint32_t home = home0 % n, iter = 0;
+    for (;;) {
+      // ---- leave?
+      std::vector<uint32_t> live;
+      for (uint32_t k = 0; k < std::min(n, 64u); ++k) { const uint32_t pi = (home + k) % n; if (!ld(M.plans[pi].done)) live.push_back(pi); }
+      if (ld(M.abort)) break;
+      if (ld(M.done_plans) >= n) break;
+      bool did = false;
+      for (size_t li = 0; li < live.size() && !did; ++li) {
+        PlanState& P = M.plans[live[li]];
+        ++iter;
+        bool fin = false;
+        // ---- scan 1 (element by element: the real scan is not a snapshot either)
+        uint32_t mn = kInf;
+        for (uint32_t t = 0; t < T.ntiles; ++t) mn = std::min(mn, ld(P.pend[t]));
+        const float dt = u2f(ld(P.dist[P.target]));
+        const float bound = (float)((double)dt + std::max(M.offset, 0.0));
+        if (mn == kInf) continue;
+        const float m = u2f(mn);
+        float thr = m + M.band;
+        if (!(thr > m)) thr = next_up(m);
+        // ---- scan 2
+        unsigned long long key = ~0ull;
+        const uint32_t salt = (uint32_t)(me + 1) * 0x9E3779B9u + iter * 0x85EBCA6Bu;
+        for (uint32_t t = 0; t < T.ntiles; ++t) {
+          const uint32_t pv = ld(P.pend[t]);
+          if (pv == kInf) continue;
+          const float p = u2f(pv);
+          if (p > bound) {
+            const uint32_t v = xchg(P.pend[t], kInf);
+            if (v == kInf) continue;
+            if (u2f(v) > bound) {
+              if (!(u2f(ld(P.tlast[t])) > -inf_f())) st(P.tlast[t], f2u(-3.0e38f));
+              ++M.drops;
+              work_dec(P, fin);
+            } else { ++M.putbacks; if (amin(P.pend[t], v) != kInf) work_dec(P, fin); }
+            continue;
+          }
+          if (p < thr) {
+            const unsigned long long h = ((unsigned long long)((t ^ salt) * 0x9E3779B1u) << 32) | t;
+            key = std::min(key, h);
+          }
+        }
+        if (fin) { plan_finish(P); fin = false; }
+        uint32_t pick = kNone;
+        if (key != ~0ull) {
+          const uint32_t t = (uint32_t)key;
+          if (M.mutate == 2u || cas(P.lock[t], kInf, 0u)) {
+            const uint32_t v = xchg(P.pend[t], kInf);
+            bool ok = v != kInf;
+            if (ok && u2f(v) > bound) {
+              if (!(u2f(ld(P.tlast[t])) > -inf_f())) st(P.tlast[t], f2u(-3.0e38f));
+              st(P.lock[t], kInf);
+              ++M.drops;
+              work_dec(P, fin);
+              ok = false;
+            } else if (!ok) st(P.lock[t], kInf);
+            if (ok) {
+              const float pv = u2f(v);
+              if (!(pv < thr)) { thr = pv + M.band; if (!(thr > pv)) thr = next_up(pv); ++M.raised; }
+              pick = t;
+              if (P.in_solve[t]) ++M.violations;                     // two solvers on one tile
+              P.in_solve[t] = 1;
+              if (++M.solves_now > M.max_solves) M.max_solves = M.solves_now;
+            }
+          }
+          if (pick == kNone) ++M.claim_fails;
+          if (fin) { plan_finish(P); fin = false; }
+        }
+        if (pick == kNone) continue;
+        did = true;
+        const uint32_t t = pick;
+        // ---- solve (k_tile_round's: queue of sources below thr and the bound, min on the float bits)
+        const uint32_t v0 = T.vptr[t], nv = T.vptr[t + 1] - v0;
+        const uint32_t h0 = T.hptr[t], nh = T.hptr[t + 1] - h0;
+        const uint32_t e0 = T.eptr[t], r0 = T.rptr[t];
+        const float tl = u2f(ld(P.tlast[t]));
+        std::vector<uint32_t> ldu(nv + nh), orig(nv), lh0(nh);
+        std::vector<uint32_t> q, qn;
+        std::vector<uint8_t> queued(nv, 0);
+        for (uint32_t i = 0; i < nv; ++i) {
+          orig[i] = ld(P.dist[T.verts[v0 + i]]); ldu[i] = orig[i];
+          const float d = u2f(orig[i]);
+          if (d < thr && d <= bound && !(d < tl)) q.push_back(i);
+        }
+        for (uint32_t i = 0; i < nh; ++i) {
+          const uint32_t b = ld(P.dist[T.halo_verts[h0 + i]]); ldu[nv + i] = b; lh0[i] = b;
+          const float d = u2f(b);
+          if (d < thr && d <= bound) q.push_back(nv + i);
+        }
+        uint32_t sweep = 0;
+        while (!q.empty()) {
+          qn.clear(); std::fill(queued.begin(), queued.end(), 0);
+          for (uint32_t x : q) {
+            const float di = u2f(ldu[x]);
+            if (!(di < thr) || !(di <= bound)) continue;
+            for (uint32_t e = T.rowptr[r0 + x]; e < T.rowptr[r0 + x + 1]; ++e) {
+              const uint32_t c = T.col[e0 + e];
+              const uint32_t nd = f2u(di + M.tw[e0 + e]);
+              if (nd < ldu[c]) { ldu[c] = nd; if (c < nv && !queued[c]) { queued[c] = 1; qn.push_back(c); } }
+            }
+          }
+          q.swap(qn); ++sweep;
+        }
+        // ---- publish: distances, then (after the drain) the wake-ups
+        uint32_t own_left = kInf;
+        for (uint32_t i = 0; i < nv; ++i) {
+          const uint32_t db = ldu[i];
+          if (db != orig[i]) st(P.dist[T.verts[v0 + i]], db);
+          const float d = u2f(db);
+          if (!(d < thr) && d <= bound) own_left = std::min(own_left, db);
+        }
+        uint32_t wt[kWakeSlots], wv[kWakeSlots]; bool over = false;
+        for (uint32_t s = 0; s < kWakeSlots; ++s) { wt[s] = kNone; wv[s] = kInf; }
+        auto collect = [&](uint32_t t2, uint32_t v) {
+          uint32_t slot = (t2 * 0x9E3779B1u) >> 27;
+          for (uint32_t probe = 0; probe < kWakeSlots; ++probe, slot = (slot + 1u) & (kWakeSlots - 1u))
+            if (wt[slot] == kNone || wt[slot] == t2) { wt[slot] = t2; wv[slot] = std::min(wv[slot], v); return; }
+          over = true;
+        };
+        for (uint32_t i = 0; i < nh; ++i) if (ldu[nv + i] < lh0[i]) collect(T.halo_tile[h0 + i], ldu[nv + i]);
+        if (own_left != kInf) collect(t, own_left);
+        for (uint32_t s = 0; s < kWakeSlots; ++s) if (wt[s] != kNone) wake(P, fin, wt[s], wv[s]);
+        if (over) {
+          for (uint32_t i = 0; i < nh; ++i) if (ldu[nv + i] < lh0[i]) wake(P, fin, T.halo_tile[h0 + i], ldu[nv + i]);
+          if (own_left != kInf) wake(P, fin, t, own_left);
+        }
+        if (fin) ++M.violations;                                     // a wake-up can never take the count to zero
+        st(P.tlast[t], f2u(thr));
+        add(P.acts, 1u); add(P.sweeps, sweep);
+        P.in_solve[t] = 0; --M.solves_now;
+        st(P.lock[t], kInf);
+        work_dec(P, fin);
+        if (fin) { plan_finish(P); fin = false; }
+      }
+      if (!did && n > 64u) home = (home + 64u) % n;
+    }
+    M.leave(me);
+  }
+};
+}  // namespace
+
+extern "C" {
+// stats_out: [0] activations, [1] sweeps, [2] claim fails, [3] tiles dropped beyond the bound, [4] plan finishes, [5] scheduling
+// points, [6] most concurrent solves, [7] invariant violations, [8] abort code, [9] put-backs, [10] bands raised at claim, [11] tiles
+uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx, const float* edge_weights,
+                 const float* vertex_costs, const uint8_t* invalid, const float* xyz, uint32_t tile_size, uint32_t n, const uint32_t* seeds,
+                 const uint32_t* targets, double offset, double cost_limit, float band, uint32_t n_wg, uint32_t sched_seed, uint64_t budget,
+                 uint32_t mutate, float* dist_out, uint64_t* stats_out)
+{
+  Model M;
+  HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
+  std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
+  materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
+  M.T = build_tiles(topo, xyz, tile_size);
+  M.tw.resize(M.T.col.size());
+  for (size_t i = 0; i < M.tw.size(); ++i) M.tw[i] = (M.T.src[i] == kNone) ? inf_f() : nbr[M.T.src[i]].w;   // k_tile_weights
+  M.offset = offset; M.band = band; M.rng.seed(sched_seed); M.budget = budget; M.mutate = mutate;
+  M.plans.resize(n);
+  for (uint32_t p = 0; p < n; ++p) {
+    PlanState& P = M.plans[p];
+    P.dist.assign(V, kInf); P.pend.assign(M.T.ntiles, kInf); P.lock.assign(M.T.ntiles, kInf); P.tlast.assign(M.T.ntiles, f2u(-inf_f()));
+    P.in_solve.assign(M.T.ntiles, 0);
+    P.seed = seeds[p]; P.target = targets[p];
+    P.dist[P.seed] = 0u; P.pend[M.T.vert_tile[P.seed]] = 0u; P.work = 1u;                  // k_init, k_tile_init, k_async_init
+  }
+  M.alive.assign(n_wg, 1); M.sleep_until.assign(n_wg, 0); M.turn = 0;
+  std::vector<std::thread> th;
+  std::vector<Wg*> wgs;
+  for (uint32_t w = 0; w < n_wg; ++w) wgs.push_back(new Wg(M, (int)w, sched_seed * 7919u + w));
+  for (uint32_t w = 0; w < n_wg; ++w) th.emplace_back([&, w] { wgs[w]->run(n, w); });
+  for (auto& t : th) t.join();
+  for (auto* w : wgs) delete w;
+  uint64_t acts = 0, sweeps = 0, fins = 0;
+  for (uint32_t p = 0; p < n; ++p) {
+    const PlanState& P = M.plans[p];
+    acts += P.acts; sweeps += P.sweeps; fins += P.finishes;
+    if (P.finishes != 1u && !M.abort) ++M.violations;
+    for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(P.dist[v]);
+  }
+  stats_out[0] = acts; stats_out[1] = sweeps; stats_out[2] = M.claim_fails; stats_out[3] = M.drops; stats_out[4] = fins; stats_out[5] = M.yields;
+  stats_out[6] = M.max_solves; stats_out[7] = M.violations; stats_out[8] = M.abort; stats_out[9] = M.putbacks; stats_out[10] = M.raised;
+  stats_out[11] = M.T.ntiles;
+  return M.abort ? 1u : 0u;
+}
+}

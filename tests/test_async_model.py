@@ -1,0 +1,105 @@
+"""CPU: the PROTOCOL of the asynchronous tile engine (mesh_navigation_amd/csrc/mnav_async.h: claim / lock / wake-up / the count of
+pending-or-in-solve tiles that ends a plan) on oracle/async_model.cpp -- the kernel's shared-memory operations restated one by one,
+run by several virtual workgroups that are interleaved pseudo-randomly (seeded, reproducible) at every single operation, with long
+random stalls -- against the sequential oracle (dijkstra_mesh_planner.cpp:287-348).
+
+What the engine promises (like every engine: the finalize pass and the lazy path walk rely on it): when a plan is declared finished,
+every vertex the reference pops -- dist <= dist[target] + max(offset, 0) -- holds the reference's float32 potential bit for bit.
+The model also checks, while it runs, that a plan is finished exactly once and only when none of its tiles is pending, locked or in
+solve, and that a tile never has two solvers."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from mesh_navigation_amd import meshgen
+from oracle import oracle as O
+from tests.common import Case, terrain_case
+
+
+def run(case: Case, seeds, targets, offset=0.3, cost_limit=1.0, **kw):
+    m = case.mesh
+    r = O.async_tile_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, offset=offset, cost_limit=cost_limit,
+                           invalid=case.invalid, **kw)
+    info = {k: v for k, v in r.items() if k != "dist"}
+    assert r["code"] == 0 and r["abort"] == 0, info
+    assert r["violations"] == 0, info
+    assert r["finishes"] == len(seeds), info
+    for k, (s, t) in enumerate(zip(seeds, targets)):
+        full = case.om.dijkstra(case.weights, case.costs, int(s), int(t), goal_dist_offset=np.inf, cost_limit=cost_limit, invalid=case.invalid).dist
+        dt = full[t]
+        bound = np.float32(np.float64(dt) + max(offset, 0.0)) if np.isfinite(dt) else np.float32(np.inf)
+        popped = full <= bound
+        got = r["dist"][k]
+        assert np.array_equal(got[popped].view(np.uint32), full[popped].view(np.uint32)), (k, info)
+        assert (got >= full).all()                                   # every value is the length of a real path
+    return r
+
+
+@pytest.mark.parametrize("workgroups", [1, 3, 8])
+def test_terrain_offsets_bands_and_workgroup_counts(workgroups):
+    case = terrain_case(40, 5)
+    m = case.mesh
+    rng = np.random.default_rng(workgroups)
+    for k, (offset, band, tile) in enumerate(((0.3, None, 64), (0.0, 0.05, 32), (np.inf, 5.0, 64), (-0.5, None, 32))):
+        n = 1 + k % 3
+        seeds, targets = rng.choice(m.V, n, replace=False), rng.choice(m.V, n, replace=False)
+        r = run(case, seeds, targets, offset=offset, band=band, tile=tile, workgroups=workgroups, sched_seed=10 * workgroups + k)
+        assert r["max_concurrent_solves"] <= workgroups
+    # a batch larger than the workgroups: they move on to the plans that are left
+    seeds, targets = rng.choice(m.V, 6, replace=False), rng.choice(m.V, 6, replace=False)
+    run(case, seeds, targets, tile=64, workgroups=workgroups, sched_seed=99)
+
+
+def test_cost_limit_invalid_and_unreachable_targets():
+    mesh = meshgen.terrain(36, 0.1, 11)
+    rng = np.random.default_rng(5)
+    costs = rng.uniform(0.0, 1.4, mesh.V).astype(np.float32)
+    inv = (rng.uniform(size=mesh.V) < 0.05).astype(np.uint8)
+    case = Case(mesh, costs, edge_cost_factor=1.0, invalid=inv)
+    ok = np.flatnonzero((inv == 0) & (costs <= 0.8))
+    run(case, rng.choice(ok, 3, replace=False), rng.choice(ok, 3, replace=False), cost_limit=0.8, tile=32, workgroups=4, sched_seed=3)
+    # a wall of over-limit vertices: the target is never reached, the plan still ends (its component is swept, then nothing is pending)
+    N = 36
+    costs2 = np.zeros(mesh.V, np.float32)
+    costs2[np.arange(N) * N + N // 2] = 5.0
+    case2 = Case(mesh, costs2, edge_cost_factor=0.0)
+    s, t = mesh.vertex_at(0.2, 0.5), mesh.vertex_at(0.8, 0.5)
+    r = run(case2, [s], [t], tile=32, workgroups=5, sched_seed=4)
+    assert not np.isfinite(r["dist"][0][t])
+    # holes, several components, a face-less target
+    p = meshgen.punched(40, 0.1, 4, drop=0.15)
+    casep = Case(p)
+    deg = np.bincount(p.edges.ravel(), minlength=p.V)
+    okp = np.flatnonzero(deg > 0)
+    run(casep, rng.choice(okp, 3, replace=False), rng.choice(okp, 3, replace=False), tile=32, workgroups=4, sched_seed=5)
+
+
+def test_many_interleavings_on_a_mesh_of_seven_tiles():
+    """Few tiles: the count of pending-or-in-solve tiles is 1 or 2 most of the time, which is where a premature `finished` or a
+    lost wake-up would show; 40 schedules, the band far narrower than a tile (every tile is solved many times)."""
+    case = terrain_case(14, 5)
+    m = case.mesh
+    rng = np.random.default_rng(0)
+    raised = 0
+    for seed in range(40):
+        s, t = (int(x) for x in rng.choice(m.V, 2, replace=False))
+        r = run(case, [s], [t], offset=[np.inf, 0.0, 0.3, -1.0][seed % 4], tile=32, band=0.05, workgroups=2 + seed % 5, sched_seed=seed + 1)
+        raised += r["bands_raised"]
+    assert raised > 0              # the rare claim of a tile that was re-woken beyond the scanned band happened (and was handled)
+
+
+def test_the_model_sees_protocol_errors():
+    """Deliberately broken variants of the protocol are caught by the model's checks: that is what makes a green run mean something."""
+    case = terrain_case(14, 5)
+    m = case.mesh
+    kw = dict(offset=np.inf, tile=32, band=0.05, workgroups=4, budget=3_000_000)
+    # no lock: two workgroups solve one tile at the same time
+    r = O.async_tile_model(m.xyz, m.faces, m.edges, case.weights, case.costs, [97], [5], sched_seed=2, mutate=2, **kw)
+    assert r["violations"] > 0
+    # a waker that counts the tile AFTER waking it: the woken tile can be solved and given back in between -- "finished" while the
+    # waker is still solving (this schedule stalls the waker exactly there; the intact protocol passes the same schedule)
+    r = O.async_tile_model(m.xyz, m.faces, m.edges, case.weights, case.costs, [97], [5], sched_seed=15, mutate=1, **kw)
+    assert r["violations"] > 0
+    r = O.async_tile_model(m.xyz, m.faces, m.edges, case.weights, case.costs, [97], [5], sched_seed=15, mutate=0, **kw)
+    assert r["violations"] == 0 and r["finishes"] == 1
