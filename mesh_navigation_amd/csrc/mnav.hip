@@ -53,1856 +53,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte cop
 constexpr int kBlock = 256;   // streaming kernels (init, vector map, input preparation)
 constexpr int kChunk = 96;  // step launches per graph replay; multiple of 6 (slot parities)
 
-// ---------------------------------------------------------------------------------------------
-// Step kernel.  One wave (64 lanes) per workgroup, 8 lanes cooperate on one work-list entry:
-// the lanes of a group fetch the CSR row / the corner records of the vertex in parallel, the
-// gather rule of mnav_eval.h is then evaluated with in-group shuffles, and list pushes are
-// aggregated per wave (one atomicAdd per wave and push round).  The serial rules in mnav_eval.h
-// (eval_dijkstra / eval_cvp / process_entry) are the specification; this is the same arithmetic
-// spread over lanes, and tests compare both against the oracle.
-// ---------------------------------------------------------------------------------------------
-constexpr int kWave = 64;
-constexpr int kGroup = 8;                 // lanes per work-list entry
-constexpr int kGroupsPerWave = kWave / kGroup;
+#include "mnav_band.h"
 
-struct StepCtx {
-  const Plan* P;
-  Cnt* cnt;
-  uint32_t* next;
-  uint32_t sv;          // dedup stamp of this step
-  float lmin;
-  uint32_t levals;
-  bool lchanged;
-  uint32_t* wcur;       // waiting list of the current epoch (Plan.wlist), entries before this step, epoch id
-  uint32_t wbase, epoch;
-  float lcut;           // min pop time over in-band vertices that moved (Cnt.minchg)
-};
-
-// dedup'd, wave-aggregated append of v to the next work list (all lanes of the wave that reach
-// this point take part; `want` selects the lanes that actually push)
-template <bool DIRTY>
-__device__ __forceinline__ void push_agg(StepCtx& S, bool want, uint32_t v)
-{
-  bool ok = false;
-  if (want) {
-    if (DIRTY) S.P->dirty[v] = S.sv;                       // "a neighbour moved": re-evaluate next step
-    if (S.P->stamp[v] != S.sv) ok = atomicExch(&S.P->stamp[v], S.sv) != S.sv;
-  }
-  const unsigned long long m = __ballot(ok);
-  if (m == 0ull) return;
-  const int leader = __ffsll((long long)m) - 1;
-  const int lane = threadIdx.x & (kWave - 1);
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(&S.cnt->n_next, (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (ok) {
-    const uint32_t idx = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (idx < S.P->cap) S.next[idx] = v;
-  }
-}
-
-// dedup'd (per epoch), wave-aggregated append of v to the waiting list (spec: Ops::park, mnav_eval.h)
-__device__ __forceinline__ void park_agg(StepCtx& S, bool want, uint32_t v)
-{
-  bool ok = false;
-  if (want && S.P->wstamp[v] != S.epoch) ok = atomicExch(&S.P->wstamp[v], S.epoch) != S.epoch;
-  const unsigned long long m = __ballot(ok);
-  if (m == 0ull) return;
-  const int leader = __ffsll((long long)m) - 1;
-  const int lane = threadIdx.x & (kWave - 1);
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(&S.cnt->n_wait, (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (ok) {
-    const uint32_t idx = S.wbase + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (idx < S.P->cap) S.wcur[idx] = v;
-  }
-}
-
-template <class T>
-__device__ __forceinline__ T gshfl(T x, int src) { return __shfl(x, src, kGroup); }
-
-// --- Dijkstra gather over 8 lanes (spec: mnav_eval.h::eval_dijkstra) ---------------------------
-__device__ __forceinline__ Eval group_eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v, int sub)
-{
-  float best_s = inf_f(), best_du = inf_f();
-  uint32_t best_u = v;
-  const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
-  for (uint32_t i = beg + sub; i < end; i += kGroup) {
-    const Nbr nb = P.nbr[i];
-    const float du = P.dist[nb.u];
-    if (!(du < c.thr) || du > c.goal_dist) continue;
-    const float s = du + nb.w;                                    // dijkstra :331
-    if (s < best_s || (s == best_s && s < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) {
-      best_s = s; best_du = du; best_u = nb.u;
-    }
-  }
-#pragma unroll
-  for (int o = 1; o < kGroup; o <<= 1) {
-    const float os = __shfl_xor(best_s, o, kGroup), odu = __shfl_xor(best_du, o, kGroup);
-    const uint32_t ou = __shfl_xor(best_u, o, kGroup);
-    if (os < best_s || (os == best_s && os < inf_f() && (odu < best_du || (odu == best_du && ou < best_u)))) {
-      best_s = os; best_du = odu; best_u = ou;
-    }
-  }
-  Eval e; e.d = best_s; e.t = best_s; e.key = key_inf(); e.pred = (best_s < inf_f()) ? best_u : v; e.dir = 0.0f; e.cut = kNone;
-  return e;
-}
-
-// --- CVP replay over 8 lanes (spec: mnav_eval.h::eval_cvp) ------------------------------------
-// corners per lane in the 8-lane replay: 2 = vertices of up to 16 faces in parallel, the rest through the serial rule.
-// 1 saves 18 VGPRs (152 instead of 170 unconstrained) but not enough for a fourth wave per SIMD without spilling, and
-// measured the same (207 vs 203 plans/s in batches of 128)
-#ifndef MNAV_CVP_ROUNDS
-#define MNAV_CVP_ROUNDS 2
-#endif
-constexpr int kCvpRounds = MNAV_CVP_ROUNDS;
-struct CornerItem { KeyRef fk; uint32_t trig; bool valid; bool first; CvpCand k; uint32_t v1, v2, face; };
-
-__device__ __forceinline__ KeyRef gshfl_key(const KeyRef& r, int src)
-{
-  KeyRef o;
-  o.k.hi = gshfl(r.k.hi, src); o.k.up = gshfl(r.k.up, src); o.k.lvl = gshfl(r.k.lvl, src); o.own = gshfl(r.own, src);
-  return o;
-}
-
-// Lanes hold one corner each (fire event + float64 candidate, computed in parallel); the replay walks
-// the triggers in pop order with in-group shuffles.  Pop keys of different main-front pops compare by
-// the integer `hi` alone; only keys inside one cascade need key_less()'s walk over the cascade tree
-// (PopKey, mnav_eval.h), which every lane of the group then performs on the same operands.
-__device__ __forceinline__ Eval group_eval_cvp(const Plan& P, const Ctl& c, uint32_t v, int sub)
-{
-  const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
-  if (end - beg > kCvpRounds * kGroup) return eval_cvp(P, c, v);   // rare high-valence vertex: serial rule
-  const bool infl = P.seed_mask != nullptr;
-  const bool mute = infl && P.seed_mask[v] == kInflMute;
-  CornerItem it[kCvpRounds];
-#pragma unroll
-  for (int r = 0; r < kCvpRounds; ++r) {
-    const uint32_t i = beg + sub + r * kGroup;
-    it[r].fk = key_ref_of(key_inf(), inf_f(), 0); it[r].trig = kNone; it[r].valid = false;
-    it[r].v1 = kNone; it[r].v2 = kNone; it[r].face = kNone; it[r].first = false;
-    it[r].k.u3tmp = 0.0; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = 0; it[r].k.kind = 0;
-    if (i < end) {
-      const Corner k = P.crn[i];
-      const Fire f = corner_fire(P, c, k);
-      if (f.trig != kNone && !key_descends_from(P, f.trig, v)) {       // (spec: eval_cvp)
-        it[r].valid = true; it[r].fk = f.key; it[r].trig = f.trig;
-        if (infl) {                                                    // inflation wave: float32 rule (spec: eval_cvp)
-          const InflCand u = infl_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c, P.infl_max);
-          it[r].k.u3tmp = (double)u.u3tmp; it[r].k.cand = 0.0; it[r].k.dir = 0.0f; it[r].k.sel = u.requeue ? 1 : 0; it[r].k.kind = u.ok ? 3 : 0;
-        } else
-        it[r].k = cvp_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c);
-        it[r].v1 = k.v1; it[r].v2 = k.v2; it[r].face = corner_face(k); it[r].first = corner_first_for(k, f.trig);
-      }
-    }
-  }
-  const int gbase = (threadIdx.x & (kWave - 1)) & ~(kGroup - 1);
-  Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
-  constexpr unsigned long long kNoKey = ~0ull;
-  KeyRef last = key_ref_of(key_inf(), inf_f(), 0);
-  bool first = true, queued = false;
-  const uint32_t max_pass = 2u * (end - beg) + 2u;                  // (spec: eval_cvp)
-  for (uint32_t pass_no = 0;; ++pass_no) {
-    if (pass_no == max_pass) { raise_flag(P, kFlagWalkLimit); break; }
-    // next trigger pop strictly after the last one: smallest `hi` first, the tree decides among equals
-    bool el[kCvpRounds];
-    unsigned long long mh = kNoKey;
-#pragma unroll
-    for (int r = 0; r < kCvpRounds; ++r) {
-      el[r] = it[r].valid && (first || key_less(P, last, it[r].fk));
-      if (el[r] && it[r].fk.k.hi < mh) mh = it[r].fk.k.hi;
-    }
-#pragma unroll
-    for (int o = 1; o < kGroup; o <<= 1) { const unsigned long long om = __shfl_xor(mh, o, kGroup); mh = om < mh ? om : mh; }
-    if (mh == kNoKey) break;
-    KeyRef m = last; uint32_t m_trig = kNone;
-#pragma unroll
-    for (int r = 0; r < kCvpRounds; ++r) {
-      unsigned gm = (unsigned)((__ballot(el[r] && it[r].fk.k.hi == mh) >> gbase) & 0xFFull);
-      while (gm) {
-        const int src = __ffs((int)gm) - 1;
-        gm &= gm - 1;
-        const uint32_t ct = gshfl(it[r].trig, src);
-        if (ct == m_trig) continue;
-        const KeyRef cand = gshfl_key(it[r].fk, src);
-        if (m_trig == kNone || key_less(P, cand, m)) { m = cand; m_trig = ct; }
-      }
-    }
-    if (queued && !key_less(P, m, key_ref_of(e.key, e.keyd, v))) break;   // v pops before this trigger
-    bool any = false;
-    float ins_d = 0.0f;
-#pragma unroll
-    for (int pr = 0; pr < 2 * kCvpRounds; ++pr) {                  // trigger's circulator order: flagged face first
-      const int r = pr % kCvpRounds;
-      const bool want_first = pr < kCvpRounds;
-      unsigned gm = (unsigned)((__ballot(it[r].valid && it[r].trig == m_trig && it[r].first == want_first) >> gbase) & 0xFFull);
-      while (gm) {
-        const int src = __ffs((int)gm) - 1;
-        gm &= gm - 1;
-        CvpCand k;
-        k.u3tmp = gshfl(it[r].k.u3tmp, src); k.cand = gshfl(it[r].k.cand, src); k.dir = gshfl(it[r].k.dir, src);
-        k.sel = gshfl(it[r].k.sel, src); k.kind = gshfl(it[r].k.kind, src);
-        int sel = 0; float dir = 0.0f;
-        if (k.kind == 3) {                                           // inflation :252,:298-311
-          const float u3tmp = (float)k.u3tmp;
-          if (e.d != 0.0f && u3tmp < e.d) {
-            e.d = u3tmp; e.pred = gshfl(it[r].v1, src); e.cut = gshfl(it[r].v2, src);   // supports of the last lowering update (vector field)
-            if (k.sel) { any = true; ins_d = e.d; }
-          }
-        } else if (k.kind != 0 && cvp_apply(k, e.d, sel, dir)) {
-          const uint32_t v1 = gshfl(it[r].v1, src), v2 = gshfl(it[r].v2, src);
-          e.pred = (sel == 1) ? v1 : v2; e.dir = dir; e.cut = gshfl(it[r].face, src);
-          any = true; ins_d = e.d;
-        }
-      }
-    }
-    if (any && !mute) { e.key = key_for(P, ins_d, v, m); e.keyd = ins_d; queued = true; }   // ordinary pop, or a place inside this trigger's cascade
-    last = m; first = false;
-  }
-  if (!queued) { if (!infl) e.pred = v; e.key = key_inf(); e.keyd = inf_f(); }
-  e.t = key_time(e.key);
-  return e;
-}
-
-template <uint32_t PLANNER>
-__device__ __forceinline__ Eval group_eval(const Plan& P, const Ctl& c, uint32_t v, int sub)
-{
-  if constexpr (PLANNER == kPlannerCvp) return group_eval_cvp(P, c, v, sub);
-  else return group_eval_dijkstra(P, c, v, sub);
-}
-
-// push the neighbourhood of v (spec: process_entry)
-template <uint32_t PLANNER>
-__device__ __forceinline__ void group_push_neighbours(StepCtx& S, const Plan& P, uint32_t v, int sub, bool want)
-{
-  if constexpr (PLANNER == kPlannerCvp) {
-    const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
-    const uint32_t rounds = want ? (end - beg + kGroup - 1) / kGroup : 0;
-    // every lane of the wave must reach push_agg the same number of times -> wave-max of rounds
-    uint32_t wr = rounds;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wr = max(wr, (uint32_t)__shfl_xor((int)wr, o));
-    for (uint32_t r = 0; r < wr; ++r) {
-      const uint32_t i = beg + sub + r * kGroup;
-      uint32_t a = kNone, b = kNone;
-      if (want && i < end) { const Corner k = P.crn[i]; if (k.v1 != kNone) { a = k.v1; b = k.v2; } }
-      push_agg<true>(S, a != kNone, a);
-      push_agg<true>(S, b != kNone, b);
-    }
-  } else {
-    const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
-    const uint32_t rounds = want ? (end - beg + kGroup - 1) / kGroup : 0;
-    uint32_t wr = rounds;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wr = max(wr, (uint32_t)__shfl_xor((int)wr, o));
-    for (uint32_t r = 0; r < wr; ++r) {
-      const uint32_t i = beg + sub + r * kGroup;
-      const bool w = want && i < end;
-      const uint32_t u = w ? P.nbr[i].u : kNone;
-      push_agg<true>(S, w, u);
-    }
-  }
-}
-
-// one work-list entry per 8-lane group; `active` = this group has an entry (inactive groups only
-// take part in the wave-wide pushes).  Spec: mnav_eval.h::process_entry / process_repair.
-template <uint32_t PLANNER, bool REPAIR>
-__device__ __forceinline__ void group_process(StepCtx& S, const Plan& P, const Ctl& c, bool active, uint32_t v, int sub)
-{
-  constexpr bool cvp = (PLANNER == kPlannerCvp);
-  bool push_nb = false, retain = false, self_again = false;
-  float t_new = inf_f(), t_old_for_cut = inf_f();
-  if (active && !is_seed(P, v)) {
-    const float old_d = P.dist[v];
-    PopKey old_key = key_inf();
-    if constexpr (cvp) old_key = P.tkey[v];
-    const float old_t = cvp ? key_time(old_key) : old_d;
-    t_old_for_cut = old_t;
-    bool go;
-    if (REPAIR) go = (old_d < inf_f());
-    else go = !(old_t < c.thr_fixed) && !(cvp && P.blocked[v]);
-    // parked out of band and no neighbour moved since the last evaluation: keep waiting, as is
-    const bool parked = !REPAIR && go && !c.band_new && !(old_t < c.thr) && old_t < inf_f() && P.dirty[v] != (uint32_t)c.it;
-    if (parked) { retain = true; t_new = old_t; }
-    else if (go) {
-      if (!REPAIR || old_t > c.goal_dist) {                          // spec: process_repair (pop time, not value)
-        if (sub == 0) ++S.levals;
-        const Eval e = group_eval<PLANNER>(P, c, v, sub);
-        bool changed = (f2u(e.d) != f2u(old_d)) || (f2u(e.t) != f2u(old_t)) || (e.pred != P.pred[v]);
-        if (cvp) changed = changed || (e.key != old_key) || (e.cut != P.cutf[v]) || (f2u(e.dir) != f2u(P.dirn[v])) ||
-                           (P.keyd && f2u(e.keyd) != f2u(P.keyd[v]));
-#ifdef MNAV_DEBUG_FLIP                    // debugging aid: who keeps changing in a band that does not settle
-        if (changed && sub == 0 && !REPAIR && c.band_steps >= 40 && c.band_steps < 44)
-          printf("flip it %d v %u d %.9g->%.9g t %.9g->%.9g key hi %llx->%llx up %d->%d lvl %u->%u keyd %.9g->%.9g\n", c.it, v, old_d, e.d, old_t, e.t,
-                 old_key.hi, e.key.hi, (int)old_key.up, (int)e.key.up, old_key.lvl, e.key.lvl, P.keyd ? P.keyd[v] : 0.f, e.keyd);
-#endif
-        if ((changed || REPAIR) && sub == 0) {
-          P.dist[v] = e.d; P.pred[v] = e.pred;
-          if constexpr (cvp) { P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut; if (P.keyd) P.keyd[v] = e.keyd; }
-        }
-        t_new = e.t;
-        if (REPAIR && cvp && sub == 0 && (f2u(e.d) != f2u(old_d) || e.key != old_key)) S.lchanged = true;   // sweep again
-        if (!REPAIR) {
-          const bool was_in = old_t < c.thr, now_in = e.t < c.thr;
-          push_nb = (changed && (was_in || now_in)) || (now_in && c.band_new);
-          retain = !now_in && e.t < inf_f();
-          if constexpr (cvp) self_again = (e.key.lvl > 0u || old_key.lvl > 0u) && e.key != old_key;   // spec: process_entry
-        }
-      } else {
-        t_new = old_t;
-      }
-      if (REPAIR) retain = (t_new >= c.thr) && (t_new < inf_f());
-    }
-  }
-  if ((push_nb || self_again) && sub == 0) {
-    S.lchanged = true;
-    if (push_nb && ((t_old_for_cut < c.thr) != (t_new < c.thr))) S.lcut = fminf(S.lcut, fminf(t_old_for_cut, t_new));   // crossed the bound (spec: note_cut)
-  }
-  group_push_neighbours<PLANNER>(S, P, v, sub, push_nb);
-  push_agg<true>(S, self_again && sub == 0, v);
-  park_agg(S, retain && sub == 0, v);
-  if (retain && sub == 0) S.lmin = fminf(S.lmin, t_new);
-}
-
-__device__ __forceinline__ float wave_min(float x)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = fminf(x, __shfl_xor(x, o));
-  return x;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  return x;
-}
-
-// grid = (waves per plan, plans).  slot j (0..5) selects the ping-pong control block (j&1) and
-// the counter block (j%3).
-#ifndef MNAV_STEP_OCC                     // waves per SIMD the register allocator must reach: 3 (<= 168 VGPRs).  The CVP replay sits
-#define MNAV_STEP_OCC 3                   // right at that edge (159-170 VGPRs); at 2 waves a batch is 20 % slower, forcing 4 or 5
-#endif                                    // spills and is slower still (measured: 179 / 150 / 120 plans/s at 3 / 4 / 5)
-#define MNAV_STEP_BOUNDS __launch_bounds__(kWave, MNAV_STEP_OCC)
-// PRECTL: the step's control block was computed by k_cvp_ctl (batches on the wide kernel); this kernel then only serves the plans
-// that are in a repair / rebuild / cut step, which sweep over all vertices with the 8-lane code below.
-template <uint32_t PLANNER, bool PRECTL>
-__device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j, uint32_t plan_index)
-{
-  const Plan& P = plans[plan_index];
-  const int lane = threadIdx.x;
-  __shared__ Ctl s_ctl;
-  if (lane == 0) {
-    if constexpr (PRECTL) s_ctl = P.ctl[j & 1];
-    else {
-      const Ctl prev = P.ctl[(j + 1) & 1];
-      const Cnt cprev = P.cnt[(j + 2) % 3];
-      const Ctl cur = controller(P, prev, cprev);
-      s_ctl = cur;
-      if (blockIdx.x == 0) {
-        P.ctl[j & 1] = cur;
-        Cnt z; z.n_next = 0; z.changed = 0; z.minkey = 0x7f800000u; z.evals = 0; z.n_wait = 0; z.minchg = 0x7f800000u; z.pad[0] = z.pad[1] = 0;
-        P.cnt[(j + 1) % 3] = z;
-      }
-    }
-  }
-  __syncthreads();
-  const Ctl cur = s_ctl;
-  if (cur.done) return;
-  if constexpr (PRECTL) { if (cur.repair <= 2 && P.seed_mask == nullptr) return; }   // k_step_wide's
-  Cnt* cnt = &P.cnt[j % 3];
-  StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
-  const int sub = lane & (kGroup - 1), grp = lane >> 3;
-  const uint32_t ngroups = gridDim.x * kGroupsPerWave;
-  const uint32_t g0 = blockIdx.x * kGroupsPerWave + grp;
-  if (cur.repair == 3) {                                             // spec: process_cut -- no evaluation
-    const uint32_t nthreads = gridDim.x * kWave, tid = blockIdx.x * kWave + lane;
-    const uint32_t* list = P.list[cur.it & 1];
-    for (uint32_t base = 0; base < cur.n; base += nthreads) {         // the work list is carried over
-      const uint32_t i = base + tid;
-      push_agg<true>(S, i < cur.n, i < cur.n ? list[i] : 0u);
-    }
-    for (uint32_t base = 0; base < P.V; base += nthreads) {           // keyed vertices at or above the cut wait for the restarted band
-      const uint32_t v = base + tid;
-      bool want = false; float t = inf_f();
-      if (v < P.V && !is_seed(P, v)) {
-        t = (PLANNER == kPlannerCvp) ? key_time(P.tkey[v]) : P.dist[v];
-        want = t >= cur.thr && t < inf_f();
-      }
-      park_agg(S, want, v);
-      if (want) S.lmin = fminf(S.lmin, t);
-    }
-  } else if (cur.repair == 1) {                                      // spec: process_repair
-    const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
-    for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t v = g0 + r * ngroups;
-      group_process<PLANNER, true>(S, P, cur, v < P.V, v < P.V ? v : 0u, sub);
-    }
-  } else if (cur.repair == 2) {                                      // spec: process_rebuild (band shrink, band_new == 1)
-    const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
-    for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t v = g0 + r * ngroups;
-      const bool active = v < P.V && P.dist[v < P.V ? v : 0u] < inf_f();
-      group_process<PLANNER, false>(S, P, cur, active, active ? v : 0u, sub);
-    }
-  } else {
-    // the work list; in the first step of a band also the waiting list the previous band left behind
-    const uint32_t* list = P.list[cur.it & 1];
-    const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
-    const uint32_t ntot = cur.n + cur.wread;
-    const uint32_t rounds = (ntot + ngroups - 1) / ngroups;
-    for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t i = g0 + r * ngroups;
-      const bool active = i < ntot;
-      const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
-      group_process<PLANNER, false>(S, P, cur, active, v, sub);
-    }
-  }
-  const float wmin = wave_min(S.lmin);
-  const float wcut = wave_min(S.lcut);
-  const uint32_t wev = wave_sum(S.levals);
-  const bool wch = __any(S.lchanged);
-  if (lane == 0) {
-    if (wmin < inf_f()) atomicMin(&cnt->minkey, f2u(wmin));
-    if (wcut < inf_f()) atomicMin(&cnt->minchg, f2u(wcut));
-    if (wev) atomicAdd(&cnt->evals, wev);
-    if (wch) atomicOr(&cnt->changed, 1u);
-  }
-}
-
-template <uint32_t PLANNER>
-__global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) { step_body<PLANNER, false>(plans, j, blockIdx.y); }
-
-#include "mnav_cvp_wide.h"   // CVP batches: wide_round, k_cvp_ctl, k_step_wide, k_step_repair
-
-// CVP verification sweep, run once after the last step (the CVP counterpart of k_dij_finalize's fixed-point
-// check): every vertex is evaluated once more on the CONVERGED state.  (1) Its stored (potential, pop key,
-// predecessor, direction, cutting face) must be reproduced exactly -- a vertex that was evaluated against a
-// stale or torn key of a far cascade ancestor and never re-queued shows up here; (2) a walk over the cascade
-// tree that hits its bound on the converged tree would silently change the pop order -- during the iteration
-// such hits are transient and ignored (k_flags_reset clears them), here they count.  Either way the plan
-// returns INTERNAL_ERROR instead of a potential that may not be the reference's.
-__global__ void k_flags_reset(const Plan* __restrict__ plans)
-{
-  if (threadIdx.x == 0) { Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; plans[blockIdx.x].cnt[3] = z; }
-}
-
-__global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans, int fix, uint32_t* __restrict__ any_bad)
-{
-  const Plan& P = plans[blockIdx.y];
-  const int lane = threadIdx.x;
-  const Ctl a = P.ctl[0], b = P.ctl[1];
-  const Ctl cur = (a.it > b.it) ? a : b;
-  if (!cur.done || cur.overflow) return;                               // reported as an error anyway
-  const int sub = lane & (kGroup - 1), grp = lane >> 3;
-  const uint32_t ngroups = gridDim.x * kGroupsPerWave;
-  const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
-  uint32_t bad = 0;
-  for (uint32_t r = 0; r < rounds; ++r) {
-    const uint32_t v = blockIdx.x * kGroupsPerWave + grp + r * ngroups;
-    const bool act = v < P.V && !is_seed(P, v < P.V ? v : 0u) && !P.blocked[v < P.V ? v : 0u];
-    if (!act) continue;                                               // whole 8-lane groups skip together
-    const Eval e = group_eval_cvp(P, cur, v, sub);
-    if (sub == 0 && !verify_entry(P, cur, v, e, fix != 0)) ++bad;     // spec: mnav_eval.h (with fix: stores the re-evaluated state)
-  }
-  bad = wave_sum(bad);
-  if (lane == 0 && bad) { atomicAdd(&P.cnt[3].changed, bad); atomicOr(any_bad, 1u); }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tiled label-correcting SSSP (Dijkstra planner).  The final float32 distances of the reference
-// loop (dijkstra :287-348) are the unique fixed point of d[v] = min_u fl(d[u] + w(u,v)) over
-// expanding sources u, so any relaxation schedule reproduces them bit for bit.  Schedule used
-// here: the mesh is cut into Morton tiles of <= tile_size vertices (mnav_build.h).  One
-// workgroup stages a tile's push graph, its distances and its halo in LDS and relaxes to the
-// local fixed point with LDS-only sweeps over an active queue (ds_min on the float bits, 8 lanes
-// per active vertex), restricted to sources below the current band threshold `thr`; it then
-// writes the owned distances back and leaves a wake-up value (the smallest source value still
-// to be propagated) for itself and for the tiles owning halo vertices it undercut.  One launch
-// = one round over all tiles whose wake-up value lies below thr; thr advances by `band` when
-// nothing below it is left.  Sources above the running bound dist[target] + offset are never
-// relaxed (goal_dist cut-off, dijkstra :293-300); the exact cut-off semantics and the
-// predecessors are then produced by one gather pass (k_dij_finalize).
-// ---------------------------------------------------------------------------------------------
-struct TCtl { int32_t it; uint32_t done; float thr; float thr_prev; uint32_t acts; uint32_t sweeps; uint32_t pad[2]; };
-struct TCnt { uint32_t minpend; uint32_t acts; uint32_t sweeps; uint32_t pad; };
-
-struct TilePlan {
-  uint32_t V, ntiles;
-  const uint32_t *vptr, *verts, *hptr, *halo_verts, *halo_tile, *eptr, *rptr;
-  const uint16_t* rowptr;
-  const uint16_t* col;     // per local edge: local target            } split arrays: 6 B per edge in LDS;
-  const float* tw;         // per local edge: push weight (+inf on padding) } tiles padded to 8 entries
-  float* dist;
-  uint32_t* pend[2];       // per-tile wake-up value (float bits), ping-pong by round parity
-  float* tlast;            // per-tile threshold of its last solve
-  TCtl* ctl;               // [2]
-  TCnt* cnt;               // [3]
-  uint32_t seed, target;
-  double offset;
-  float band;
-  uint32_t max_rounds;
-  uint32_t max_nv, max_nh, max_ne;
-  const uint32_t* cancel;  // device word set by mnav_cancel (polled by the persistent kernels), may be null
-  uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
-  const uint8_t* owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
-                           // neighbourhood is incomplete here (its value arrives through the exchange); null: every vertex is owned
-};
-
-constexpr int kTileBlock = 256;
-#ifndef MNAV_PERSIST_WG_PER_CU
-#define MNAV_PERSIST_WG_PER_CU 6        // register budget of k_plan_persistent: 6 workgroups (24 waves) per CU -> <= 80 VGPRs
-#endif
-// Tiles solved per best-first scan of k_plan_persistent (<= kTileBlock / 64) and how far behind the best one a further
-// candidate may lie, in bands.  Measured on C2 (5120 plans, ms per launch): 1 -> 408.5; 2 within one band -> 398.4;
-// 4 within one band -> 453.7 (the order matters more than the scans cost); 4 within 0.1 / 0.25 / 0.5 bands -> 405.6 /
-// 408.5 / 413.0; 2 within 0.5 -> 402.6.
-#ifndef MNAV_SCAN_SLACK
-#define MNAV_SCAN_SLACK 1.0f
-#endif
-#ifndef MNAV_SCAN_CANDS
-#define MNAV_SCAN_CANDS 2
-#endif
-constexpr int kTileVpt = 8;              // owned vertices per thread: tile_size <= 2048
-constexpr int kTileTodo = 64;            // tiles one workgroup takes per round
-constexpr uint32_t kInfBits = 0x7f800000u;
-
-__host__ __device__ inline uint32_t pad_to(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
-
-// LDS image of one tile (dynamic shared memory), shared by k_tile_round and k_plan_persistent
-struct TileLds {
-  float* lw;        // push weights                      4 B x ne
-  uint16_t* lcol;   // push targets (local ids)          2 B x ne
-  uint32_t* ldu;    // distances as float bits           owned, then halo
-  uint32_t* lh0;    // halo distances as loaded
-  uint32_t* mask;   // 3 rotating "already queued" bitmasks over the owned vertices
-  uint16_t* lrow;   // local row pointers
-  uint16_t *q0, *q1;
-  uint32_t mw;      // words per bitmask
-};
-__host__ __device__ inline uint32_t tile_mask_words(uint32_t max_nv) { return (max_nv + 31) / 32; }
-__host__ __device__ inline size_t tile_lds_bytes(uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
-{
-  const uint32_t nl = max_nv + max_nh;
-  return 6 * (size_t)pad_to(max_ne, 8) + 4 * (size_t)pad_to(nl, 4) + 4 * (size_t)pad_to(max_nh, 4) +
-         4 * (size_t)pad_to(3 * tile_mask_words(max_nv), 4) + 2 * (size_t)pad_to(nl + 1, 8) + 2 * 2 * (size_t)pad_to(nl, 8);
-}
-__device__ __forceinline__ TileLds tile_lds_layout(char* smem, uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
-{
-  const uint32_t nl = max_nv + max_nh;
-  TileLds L;
-  L.lw = reinterpret_cast<float*>(smem);
-  L.lcol = reinterpret_cast<uint16_t*>(L.lw + pad_to(max_ne, 8));
-  L.ldu = reinterpret_cast<uint32_t*>(L.lcol + pad_to(max_ne, 8));
-  L.lh0 = L.ldu + pad_to(nl, 4);
-  L.mask = L.lh0 + pad_to(max_nh, 4);
-  L.mw = tile_mask_words(max_nv);
-  L.lrow = reinterpret_cast<uint16_t*>(L.mask + pad_to(3 * L.mw, 4));
-  L.q0 = L.lrow + pad_to(nl + 1, 8);
-  L.q1 = L.q0 + pad_to(nl, 8);
-  return L;
-}
-
-#ifdef MNAV_TILE_TIMING
-__device__ unsigned long long g_tile_timing[4096 * 8];
-__device__ unsigned int g_tile_timing_n;
-#define TT_STAMP(k) do { if (tid == 0) tt[k] = clock64(); } while (0)
-#else
-#define TT_STAMP(k) do { } while (0)
-#endif
-
-// Stage a tile's push graph (weights, targets, row pointers) into LDS: every 16-byte global load of
-// a thread is issued before the first LDS store, so one memory round trip covers the whole copy
-// for tiles of up to 4 x 256 x 4 edges (larger tiles loop).  The arrays have a 64-byte tail slack.
-__device__ __forceinline__ void stage_tile_graph(const TilePlan& P, const TileLds& L, uint32_t e0, uint32_t ne, uint32_t r0,
-                                                 uint32_t nl, int tid)
-{
-  MNAV_GLOBAL const u32x4* sw = (MNAV_GLOBAL const u32x4*)(P.tw + e0);          // e0, ne multiples of 8 entries
-  MNAV_GLOBAL const u32x4* sc = (MNAV_GLOBAL const u32x4*)(P.col + e0);
-  MNAV_GLOBAL const u32x4* sr = (MNAV_GLOBAL const u32x4*)(P.rowptr + r0);      // r0 multiple of 8 entries
-  u32x4* dw = reinterpret_cast<u32x4*>(L.lw);
-  u32x4* dc = reinterpret_cast<u32x4*>(L.lcol);
-  u32x4* dr = reinterpret_cast<u32x4*>(L.lrow);
-  const uint32_t nw16 = ne / 4, nc16 = ne / 8, nr16 = (nl + 1 + 7) / 8;
-  u32x4 aw[4], ac[2], ar;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { const uint32_t i = tid + u * kTileBlock; aw[u] = sw[i < nw16 ? i : 0]; }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) { const uint32_t i = tid + u * kTileBlock; ac[u] = sc[i < nc16 ? i : 0]; }
-  ar = sr[(uint32_t)tid < nr16 ? tid : 0];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) { const uint32_t i = tid + u * kTileBlock; if (i < nw16) dw[i] = aw[u]; }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) { const uint32_t i = tid + u * kTileBlock; if (i < nc16) dc[i] = ac[u]; }
-  if ((uint32_t)tid < nr16) dr[tid] = ar;
-  for (uint32_t i = tid + 4 * kTileBlock; i < nw16; i += kTileBlock) dw[i] = sw[i];
-  for (uint32_t i = tid + 2 * kTileBlock; i < nc16; i += kTileBlock) dc[i] = sc[i];
-  for (uint32_t i = tid + kTileBlock; i < nr16; i += kTileBlock) dr[i] = sr[i];
-  for (uint32_t i = tid; i < 3 * L.mw; i += kTileBlock) L.mask[i] = 0u;
-}
-
-// Sweeps over the active queue of the staged tile until it runs dry: 8 lanes per active vertex push
-// along its row with ds_min on the float bits (the float add is dijkstra :331); improved owned
-// targets enter the next queue once (ds_or on a rotating bitmask).  s_nq[3] rotates like the masks:
-// [sweep % 3] is consumed, [(sweep+1) % 3] filled, [(sweep+2) % 3] cleared.  Returns the sweep count.
-__device__ __forceinline__ uint32_t tile_sweeps(const TileLds& L, uint32_t nv, float thr, float bound, uint32_t* s_nq, int tid)
-{
-  const int sub = tid & (kGroup - 1);
-  uint32_t sweep = 0;
-  for (;;) {
-    const uint32_t nq = s_nq[sweep % 3];
-    if (nq == 0) break;
-    if (tid == 0) s_nq[(sweep + 2) % 3] = 0;
-    if ((uint32_t)tid < L.mw) L.mask[((sweep + 2) % 3) * L.mw + tid] = 0u;
-    for (uint32_t i = tid + kTileBlock; i < L.mw; i += kTileBlock) L.mask[((sweep + 2) % 3) * L.mw + i] = 0u;
-    const uint16_t* qa = (sweep & 1) ? L.q1 : L.q0;
-    uint16_t* qb = (sweep & 1) ? L.q0 : L.q1;
-    uint32_t* nqb = &s_nq[(sweep + 1) % 3];
-    uint32_t* mk = L.mask + ((sweep + 1) % 3) * L.mw;
-    for (uint32_t idx = (uint32_t)tid >> 3; idx < nq; idx += kTileBlock / kGroup) {
-      const uint32_t x = qa[idx];
-      const uint32_t dib = L.ldu[x];
-      const uint32_t eb = L.lrow[x], ee = L.lrow[x + 1];          // issued together with ldu[x]
-      const float di = u2f(dib);
-      if (!(di < thr) || !(di <= bound)) continue;
-      for (uint32_t e = eb + sub; e < ee; e += kGroup) {
-        const uint32_t c = L.lcol[e];
-        const uint32_t ndb = f2u(di + L.lw[e]);
-        const uint32_t old = atomicMin(&L.ldu[c], ndb);
-        if (ndb < old && c < nv) {
-          const uint32_t bit = 1u << (c & 31);
-          if (!(atomicOr(&mk[c >> 5], bit) & bit)) qb[atomicAdd(nqb, 1u)] = (uint16_t)c;
-        }
-      }
-    }
-    ++sweep;
-    __syncthreads();
-  }
-  return sweep;
-}
-
-__global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __restrict__ plans, int j)
-{
-#ifdef MNAV_TILE_TIMING
-  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
-  const TilePlan& P = plans[blockIdx.y];
-  const int tid = threadIdx.x;
-  TT_STAMP(0);
-  __shared__ TCtl s_ctl;
-  __shared__ float s_bound;
-  __shared__ uint32_t s_todo[kTileTodo];
-  __shared__ uint32_t s_ntodo;
-  __shared__ uint32_t s_hdr[kTileTodo][8];
-  __shared__ uint32_t s_nq[3];
-  __shared__ uint32_t s_left;
-  if (tid == 0) {
-    const TCtl prev = P.ctl[(j + 1) & 1];
-    const TCnt cprev = P.cnt[(j + 2) % 3];
-    TCtl cur = prev;
-    cur.it = prev.it + 1;
-    cur.acts = prev.acts + cprev.acts;
-    cur.sweeps = prev.sweeps + cprev.sweeps;
-    const float m = u2f(cprev.minpend);
-    const float dt = P.dist[P.target];
-    const float bound = (float)((double)dt + fmax(P.offset, 0.0)); // >= the final goal_dist (dijkstra :296); a negative offset is applied in the finalize pass (goal_cut)
-    cur.done = (prev.done || !(m < inf_f()) || m > bound || (uint32_t)cur.it >= P.max_rounds) ? 1u : 0u;
-    if (!cur.done && !(m < prev.thr)) {                             // band exhausted: advance
-      cur.thr_prev = prev.thr;
-      float thr = m + P.band;
-      if (!(thr > m)) thr = next_up(m);
-      cur.thr = thr;
-    }
-    s_ctl = cur; s_bound = bound; s_ntodo = 0;
-    if (blockIdx.x == 0) {
-      P.ctl[j & 1] = cur;
-      TCnt z; z.minpend = kInfBits; z.acts = 0; z.sweeps = 0; z.pad = 0;
-      P.cnt[(j + 1) % 3] = z;
-    }
-  }
-  __syncthreads();
-  const TCtl cur = s_ctl;
-  if (cur.done) return;
-  TT_STAMP(1);
-  const float bound = s_bound, thr = cur.thr;
-  TCnt* cnt = &P.cnt[j % 3];
-  MNAV_GLOBAL uint32_t* pc = as_global(P.pend[cur.it & 1]);
-  MNAV_GLOBAL uint32_t* pn = as_global(P.pend[(cur.it + 1) & 1]);
-  MNAV_GLOBAL const uint32_t* g_vptr = as_global(P.vptr);
-  MNAV_GLOBAL const uint32_t* g_hptr = as_global(P.hptr);
-  MNAV_GLOBAL const uint32_t* g_eptr = as_global(P.eptr);
-  MNAV_GLOBAL const uint32_t* g_rptr = as_global(P.rptr);
-  MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
-  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
-  MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
-  MNAV_GLOBAL float* g_dist = as_global(P.dist);
-  MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
-
-  // every tile is looked at by exactly one thread of one workgroup per round
-  uint32_t carry_min = kInfBits;
-  const uint32_t t_end_owned = P.t_hi ? P.t_hi : P.ntiles;
-  for (uint32_t t = P.t_lo + blockIdx.x + (uint32_t)tid * gridDim.x; t < t_end_owned; t += gridDim.x * kTileBlock) {
-    const uint32_t pb = pc[t];
-    if (pb == kInfBits) continue;
-    pc[t] = kInfBits;
-    const float p = u2f(pb);
-    if (!(p <= bound)) {                                            // can never propagate any more; the finalize pass
-      if (!(g_tlast[t] > -inf_f())) g_tlast[t] = -3.0e38f;          // still has to visit the tile (finite mark, filters nothing)
-      continue;
-    }
-    bool take = false;
-    if (p < thr) {
-      const uint32_t k = atomicAdd(&s_ntodo, 1u);
-      if (k < (uint32_t)kTileTodo) {
-        s_todo[k] = t; take = true;                                 // ... and fetches the tile header
-        s_hdr[k][0] = g_vptr[t]; s_hdr[k][1] = g_vptr[t + 1]; s_hdr[k][2] = g_hptr[t]; s_hdr[k][3] = g_hptr[t + 1];
-        s_hdr[k][4] = g_eptr[t]; s_hdr[k][5] = g_eptr[t + 1]; s_hdr[k][6] = g_rptr[t]; s_hdr[k][7] = f2u(g_tlast[t]);
-      }
-    }
-    if (!take) { atomicMin((uint32_t*)&pn[t], pb); carry_min = min(carry_min, pb); }   // carry the wake-up over
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) carry_min = min(carry_min, (uint32_t)__shfl_xor((int)carry_min, o));
-  if ((tid & 63) == 0 && carry_min != kInfBits) atomicMin(&cnt->minpend, carry_min);
-  __syncthreads();
-  const uint32_t ntodo = min(s_ntodo, (uint32_t)kTileTodo);
-  if (ntodo == 0) return;
-  TT_STAMP(2);
-  TT_STAMP(3);
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileLds L = tile_lds_layout(smem, P.max_nv, P.max_nh, P.max_ne);
-  uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
-
-  for (uint32_t ti = 0; ti < ntodo; ++ti) {
-    const uint32_t t = s_todo[ti];
-    const uint32_t v0 = s_hdr[ti][0], nv = s_hdr[ti][1] - v0;
-    const uint32_t h0 = s_hdr[ti][2], nh = s_hdr[ti][3] - h0;
-    const uint32_t e0 = s_hdr[ti][4], ne = s_hdr[ti][5] - e0;
-    const uint32_t r0 = s_hdr[ti][6];
-    const uint32_t nl = nv + nh;
-    const float tl = u2f(s_hdr[ti][7]);
-    if (tid == 0) { s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0; s_left = kInfBits; }
-    __syncthreads();
-    // stage: all index / bulk loads in flight at once (16-byte vectors), then the distance gathers
-    uint32_t gi[kTileVpt];
-#pragma unroll
-    for (int k = 0; k < kTileVpt; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
-    uint32_t hi[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
-    stage_tile_graph(P, L, e0, ne, r0, nl, tid);
-    uint32_t orig[kTileVpt];
-#pragma unroll
-    for (int k = 0; k < kTileVpt; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      orig[k] = 0u;
-      if (i < nv) {
-        const float d = g_dist[gi[k]];
-        orig[k] = f2u(d); ldu[i] = orig[k];
-        if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;   // owned sources in [tlast, thr)
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      if (i < nh) { const float d = g_dist[hi[k]]; ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i); }
-    }
-    for (uint32_t i = tid + 2 * kTileBlock; i < nh; i += kTileBlock) {
-      const float d = g_dist[g_halo_verts[h0 + i]];
-      ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
-    }
-    __syncthreads();
-    TT_STAMP(4);
-    const uint32_t sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
-    TT_STAMP(5);
-    // wake the owners of the halo vertices we undercut (value = the candidate we found for them)
-    uint32_t left = kInfBits, own_left = kInfBits;
-    for (uint32_t i = tid; i < nh; i += kTileBlock) {
-      const uint32_t b = ldu[nv + i];
-      if (b < lh0[i]) { atomicMin((uint32_t*)&pn[g_halo_tile[h0 + i]], b); left = min(left, b); }
-    }
-    // write back what moved; remember the smallest owned value that still has to propagate
-#pragma unroll
-    for (int k = 0; k < kTileVpt; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      if (i < nv) {
-        const uint32_t db = ldu[i];
-        if (db != orig[k]) g_dist[gi[k]] = u2f(db);
-        const float d = u2f(db);
-        if (!(d < thr) && d <= bound) { if (db < left) left = db; own_left = min(own_left, db); }
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      left = min(left, (uint32_t)__shfl_xor((int)left, o));
-      own_left = min(own_left, (uint32_t)__shfl_xor((int)own_left, o));
-    }
-    if ((tid & 63) == 0) {
-      if (left != kInfBits) atomicMin(&s_left, left);
-      if (own_left != kInfBits) atomicMin((uint32_t*)&pn[t], own_left);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      g_tlast[t] = thr;
-      const uint32_t l = s_left;                                   // own left-overs and halo wake-ups
-      if (l != kInfBits) atomicMin(&cnt->minpend, l);
-      atomicAdd(&cnt->acts, 1u); atomicAdd(&cnt->sweeps, sweep);
-    }
-    __syncthreads();
-#ifdef MNAV_TILE_TIMING
-    if (tid == 0 && ti == 0) {
-      tt[6] = clock64(); tt[7] = ((unsigned long long)cur.it << 32) | sweep;
-      const unsigned int k = atomicAdd(&g_tile_timing_n, 1u);
-      if (k < 4096) for (int q = 0; q < 8; ++q) g_tile_timing[k * 8 + q] = tt[q];
-    }
-#endif
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Persistent per-plan variant (batches): ONE workgroup owns a plan from seed to convergence and
-// walks its tiles best-first -- always the tile with the smallest wake-up value, with the band
-// [m, m + band) -- without any launch or grid-wide round in between.  Independent plans never
-// talk to each other, so there is no inter-workgroup protocol at all; hundreds of plans run
-// concurrently (2 workgroups per CU).  Same tile solve as k_tile_round (LDS queue sweeps, ds_min
-// on float bits); state that the workgroup re-reads after writing it (dist, wake-ups, tlast) is
-// read with L1-bypassing (non-temporal) loads, i.e. served by the L2 and never by a stale L1 line.
-// ---------------------------------------------------------------------------------------------
-// Non-temporal loads bypass the per-CU L1 (served by the L2) like agent-scope atomic loads do, but
-// unlike those they are ordinary loads: many stay in flight, one wait at the first use.  Stores are
-// write-through to the L2 anyway; everything this workgroup re-reads is read through these.
-__device__ __forceinline__ uint32_t ldg_u32(MNAV_GLOBAL const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ float ldg_f32(MNAV_GLOBAL const float* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void stg_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { *p = v; }
-__device__ __forceinline__ void stg_f32(MNAV_GLOBAL float* p, float v) { *p = v; }
-
-template <int VPT>   // owned vertices per thread: tile_size <= VPT * 256
-__global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_persistent(const TilePlan* __restrict__ plans)
-{
-  const TilePlan& P = plans[blockIdx.x];
-  const int tid = threadIdx.x;
-  __shared__ unsigned long long s_best[kTileBlock / 64];
-  __shared__ uint32_t s_hdr[8];
-  __shared__ uint32_t s_nq[3];
-  __shared__ float s_bound;
-  __shared__ uint32_t s_stop;
-  if (tid == 0) s_stop = 0u;
-  MNAV_GLOBAL uint32_t* pend = as_global(P.pend[0]);
-  MNAV_GLOBAL const uint32_t* g_vptr = as_global(P.vptr);
-  MNAV_GLOBAL const uint32_t* g_hptr = as_global(P.hptr);
-  MNAV_GLOBAL const uint32_t* g_eptr = as_global(P.eptr);
-  MNAV_GLOBAL const uint32_t* g_rptr = as_global(P.rptr);
-  MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
-  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
-  MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
-  MNAV_GLOBAL float* g_dist = as_global(P.dist);
-  MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileLds L = tile_lds_layout(smem, P.max_nv, P.max_nh, P.max_ne);
-  uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
-
-  uint32_t acts = 0, sweeps_total = 0;
-  uint32_t status = 0;   // 0 converged, 2 activation cap hit
-#ifdef MNAV_TILE_TIMING
-  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#define PT_STAMP(k) do { if (tid == 0 && blockIdx.x == 0) tt[k] = clock64(); } while (0)
-#else
-#define PT_STAMP(k) do { } while (0)
-#endif
-  for (;;) {
-    PT_STAMP(0);
-    // best-first: the tile with the smallest wake-up value
-    unsigned long long best = ~0ull;
-    for (uint32_t t0 = tid; t0 < P.ntiles; t0 += 8 * kTileBlock) {        // 8 loads in flight per thread
-      uint32_t pv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const uint32_t t = t0 + u * kTileBlock; pv[u] = (t < P.ntiles) ? ldg_u32(pend + t) : kInfBits; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned long long k = ((unsigned long long)pv[u] << 32) | (t0 + u * kTileBlock);
-        best = k < best ? k : best;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); best = ob < best ? ob : best; }
-    if ((tid & 63) == 0) s_best[tid >> 6] = best;
-    if (tid == 0) {
-      const float dt = ldg_f32(g_dist + P.target);
-      s_bound = (float)((double)dt + fmax(P.offset, 0.0));         // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
-      // mnav_cancel (dijkstra :287 `&& !cancel_planning_`): a word in device memory that mnav_cancel sets with a
-      // 4-byte copy on its own stream; one agent-scope load every 16 tile activations (~0.3 ms)
-      if ((acts & 15u) == 0u) s_stop = P.cancel ? __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    }
-    __syncthreads();
-    if (s_stop) { status = 3; break; }
-    // the four waves scanned disjoint quarters of the tiles: their four minima, in ascending order, are the candidates
-    // of this scan.  Every candidate below the band threshold is solved without another scan (MNAV_SCAN_CANDS of them at
-    // most; label-correcting: the order of the solves does not change the fixed point, only the work).
-    unsigned long long cand[kTileBlock / 64];
-#pragma unroll
-    for (int w = 0; w < kTileBlock / 64; ++w) cand[w] = s_best[w];
-#pragma unroll
-    for (int a = 0; a < kTileBlock / 64; ++a)
-#pragma unroll
-      for (int b = a + 1; b < kTileBlock / 64; ++b)
-        if (cand[b] < cand[a]) { const unsigned long long x = cand[a]; cand[a] = cand[b]; cand[b] = x; }
-    best = cand[0];
-    const float bound = s_bound;
-    const float m = u2f((uint32_t)(best >> 32));
-    if (!(m < inf_f()) || m > bound) break;                        // nothing left that may propagate
-    if (acts >= P.max_rounds) { status = 2; break; }
-    float thr = m + P.band;
-    if (!(thr > m)) thr = next_up(m);
-    PT_STAMP(1);
-#pragma unroll 1
-    for (int ci = 0; ci < MNAV_SCAN_CANDS; ++ci) {
-    const float mc = u2f((uint32_t)(cand[ci] >> 32));
-    if (ci > 0 && (!(mc < m + MNAV_SCAN_SLACK * P.band) || mc > bound)) break;   // only tiles about as urgent as the best one (uniform over the workgroup)
-    const uint32_t t = (uint32_t)cand[ci];
-    if (tid == 0) {
-      stg_u32(pend + t, kInfBits);
-      s_hdr[0] = g_vptr[t]; s_hdr[1] = g_vptr[t + 1]; s_hdr[2] = g_hptr[t]; s_hdr[3] = g_hptr[t + 1];
-      s_hdr[4] = g_eptr[t]; s_hdr[5] = g_eptr[t + 1]; s_hdr[6] = g_rptr[t]; s_hdr[7] = f2u(ldg_f32(g_tlast + t));
-      s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
-    }
-    __syncthreads();
-    const uint32_t v0 = s_hdr[0], nv = s_hdr[1] - v0;
-    const uint32_t h0 = s_hdr[2], nh = s_hdr[3] - h0;
-    const uint32_t e0 = s_hdr[4], ne = s_hdr[5] - e0;
-    const uint32_t r0 = s_hdr[6];
-    const uint32_t nl = nv + nh;
-    const float tl = u2f(s_hdr[7]);
-    PT_STAMP(2);
-    // stage (see k_tile_round)
-    uint32_t gi[VPT];
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
-    uint32_t hi[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
-    stage_tile_graph(P, L, e0, ne, r0, nl, tid);
-    uint32_t orig[VPT];
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      orig[k] = 0u;
-      if (i < nv) {
-        const float d = ldg_f32(g_dist + gi[k]);
-        orig[k] = f2u(d); ldu[i] = orig[k];
-        if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      if (i < nh) { const float d = ldg_f32(g_dist + hi[k]); ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i); }
-    }
-    for (uint32_t i = tid + 2 * kTileBlock; i < nh; i += kTileBlock) {
-      const float d = ldg_f32(g_dist + g_halo_verts[h0 + i]);
-      ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
-    }
-    __syncthreads();
-    PT_STAMP(3);
-    const uint32_t sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
-    PT_STAMP(4);
-    // wake-ups for the owners of undercut halo vertices, write-back, own left-over
-    uint32_t own_left = kInfBits;
-    for (uint32_t i = tid; i < nh; i += kTileBlock) {
-      const uint32_t b = ldu[nv + i];
-      if (b < lh0[i]) atomicMin((uint32_t*)&pend[g_halo_tile[h0 + i]], b);
-    }
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      if (i < nv) {
-        const uint32_t db = ldu[i];
-        if (db != orig[k]) stg_f32(g_dist + gi[k], u2f(db));
-        const float d = u2f(db);
-        if (!(d < thr) && d <= bound) own_left = min(own_left, db);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) own_left = min(own_left, (uint32_t)__shfl_xor((int)own_left, o));
-    if ((tid & 63) == 0 && own_left != kInfBits) atomicMin((uint32_t*)&pend[t], own_left);
-    if (tid == 0) stg_f32(g_tlast + t, thr);
-    ++acts; sweeps_total += sweep;
-    // every store / atomic of this activation must have reached the L2 before the next scan
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    }                                                              // candidates of this scan
-#ifdef MNAV_TILE_TIMING
-    if (tid == 0 && blockIdx.x == 0) {
-      tt[5] = clock64(); tt[6] = sweep; tt[7] = nl;
-      const unsigned int k = atomicAdd(&g_tile_timing_n, 1u);
-      if (k < 4096) for (int q = 0; q < 8; ++q) g_tile_timing[k * 8 + q] = tt[q];
-    }
-#endif
-  }
-  if (tid == 0) {
-    TCtl c; memset(&c, 0, sizeof(c));
-    c.it = (int32_t)acts; c.done = 1; c.acts = acts; c.sweeps = sweeps_total; c.pad[0] = status;
-    P.ctl[0] = c; P.ctl[1] = c;
-  }
-}
-
-#include "mnav_async.h"   // k_plan_async: the tiles without rounds (engine 6, opt-in)
-
-__global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile, float tlast0)
-{
-  const TilePlan& P = plans[blockIdx.y];
-  const uint32_t stride = gridDim.x * kBlock;
-  const uint32_t st = vert_tile[P.seed];
-  for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) {
-    if (P.pend[1] != P.pend[0]) P.pend[1][t] = kInfBits;            // (the per-plan engines use a single buffer)
-    P.pend[0][t] = (t == st) ? 0u : kInfBits;                       // the seed's tile wakes at 0
-    P.tlast[t] = tlast0;                                            // -inf: never solved (the finalize pass skips the tile unless it was woken)
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    P.dist[P.seed] = 0.0f;                                          // dijkstra :276
-    TCtl c0; memset(&c0, 0, sizeof(c0));
-    c0.it = -1; c0.done = 0; c0.thr = -inf_f(); c0.thr_prev = -inf_f();
-    P.ctl[0] = c0; P.ctl[1] = c0;
-    TCnt ci; ci.minpend = 0u; ci.acts = 0; ci.sweeps = 0; ci.pad = 0;
-    P.cnt[2] = ci;
-    TCnt z; z.minpend = kInfBits; z.acts = 0; z.sweeps = 0; z.pad = 0;
-    P.cnt[0] = z; P.cnt[1] = z;
-  }
-}
-
-// per-tile weights from the (cost-limit folded) gather CSR
-__global__ __launch_bounds__(kBlock) void k_tile_weights(uint32_t n, const uint32_t* __restrict__ src, const uint16_t* __restrict__ col,
-                                                         const Nbr* __restrict__ nbr, float* __restrict__ tw)
-{
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) tw[i] = (src[i] == kNone) ? inf_f() : nbr[src[i]].w;       // padding never relaxes anything
-  (void)col;
-}
+#include "mnav_tiles.h"
 
 #include "mnav_shard.h"   // kernels of the sharded single plan (k_shard_*)
 
-struct PlanResult {
-  uint32_t code;
-  uint32_t path_len;
-  uint32_t steps, bands, armed, overflow;
-  float goal_dist;
-  uint32_t shrinks;
-  unsigned long long settled;
-  unsigned long long evals;
-};
+#include "mnav_finalize.h"
 
-// Exact cut-off semantics + predecessors in one gather pass over all vertices (8 lanes per
-// vertex).  After the tile rounds every vertex with dist <= goal_dist holds its final value.
-// A vertex above goal_dist keeps, in the reference, the tentative value it got from expanded
-// (dist <= goal_dist) neighbours only, or +inf -- exactly eval_dijkstra with thr = +inf.
-// pred = first-popped neighbour attaining the minimum (DESIGN.md tie rule).
-constexpr int kFinVpt = 3;               // local vertices (owned + halo) per thread held in registers
-__host__ __device__ inline size_t finalize_lds_bytes(uint32_t max_nv, uint32_t max_nh, uint32_t max_ne)
-{
-  return tile_lds_bytes(max_nv, max_nh, max_ne) + 4 * (size_t)pad_to(max_nv, 4) + 4 * (size_t)pad_to(max_nv + max_nh, 4) + 8 * (size_t)max_nv;
-}
+#include "mnav_plan_kernels.h"
 
-__device__ __forceinline__ void store3(float* p, float x, float y, float z) { p[0] = x; p[1] = y; p[2] = z; }
-
-// Source of the distances when the tile-batch engine ran (mnav_tb.h): its blocked per-(tile, plan) slices, addressed through
-// vaddr[v] = {slice offset of v's tile, slice length << 8 | local index}; the engine's control words for the plan records.
-struct FinBlocked { const float* D; const uint2* vaddr; uint32_t NP; const uint32_t* iters; const uint32_t* err; const uint32_t* n_cand;
-                    const float* xyz; float* const* vecmaps; };   // vecmaps != null: computeVectorMap (dijkstra :189-209) in the same pass
-
-// PG plans per workgroup share ONE staged tile graph (the staging -- 21 KB per tile out of L2 -- was most of this pass in
-// large batches); BLOCKED: the distances are gathered from the tile-batch engine's slices, every value is written.
-template <int PG, bool BLOCKED>
-__global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans,
-                                                             uint32_t* __restrict__ mismatch, PlanResult* __restrict__ res,
-                                                             uint32_t tiles_per_block, uint32_t n_plans, FinBlocked B)
-{
-  // grid: x = group of PG plans, y = chunk of tiles.  Only tiles that were activated or woken are looked at: any
-  // vertex that owes a value to an expanded source sits in such a tile (its source pushed to it
-  // through a halo copy, which wakes the owner); everything else keeps dist = inf / pred = itself.
-  // Per tile the push graph is staged in LDS like in the solve and read backwards: every edge
-  // x -> y with an expanded source offers (d[x] + w, d[x], x) to its owned target y; pass 1 takes the
-  // smallest sum (ds_min on the float bits), pass 2 the smallest (d[x], x) among the edges that attain
-  // it (64-bit ds_min) -- the reference's predecessor under the (value, id) pop order.
-  const uint32_t p0 = blockIdx.x * PG;
-  const TilePlan& T = tplans[BLOCKED ? 0u : p0];                     // the mesh tables are the same in every record
-  const int tid = threadIdx.x;
-  MNAV_GLOBAL const uint32_t* g_vptr = as_global(T.vptr);
-  MNAV_GLOBAL const uint32_t* g_hptr = as_global(T.hptr);
-  MNAV_GLOBAL const uint32_t* g_eptr = as_global(T.eptr);
-  MNAV_GLOBAL const uint32_t* g_rptr = as_global(T.rptr);
-  MNAV_GLOBAL const uint32_t* g_verts = as_global(T.verts);
-  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(T.halo_verts);
-  MNAV_GLOBAL const u32x2* g_va = (MNAV_GLOBAL const u32x2*)as_global((const uint32_t*)B.vaddr);
-  MNAV_GLOBAL const float* g_D = as_global(B.D);
-  MNAV_GLOBAL const float* g_xyz = as_global(B.xyz);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileLds L = tile_lds_layout(smem, T.max_nv, T.max_nh, T.max_ne);
-  uint32_t* const lsum = reinterpret_cast<uint32_t*>(smem + tile_lds_bytes(T.max_nv, T.max_nh, T.max_ne));
-  uint32_t* const lgid = lsum + pad_to(T.max_nv, 4);
-  unsigned long long* const lkey = reinterpret_cast<unsigned long long*>(lgid + pad_to(T.max_nv + T.max_nh, 4));
-  const uint32_t np = (n_plans - p0 < (uint32_t)PG) ? n_plans - p0 : (uint32_t)PG;   // plans of this group
-  // per plan of the group: seed, goal_dist, armed, settled count
-  __shared__ uint32_t s_seed[PG], s_armed[PG], s_settled[PG], s_tie[PG];
-  __shared__ float s_goal[PG], s_cut[PG];
-  if (tid < PG) {
-    const int q = tid;
-    s_settled[q] = 0u; s_seed[q] = kNone; s_goal[q] = inf_f(); s_cut[q] = inf_f(); s_tie[q] = kNone; s_armed[q] = 0u;
-    if ((uint32_t)q < np) {
-      const Plan& P = plans[p0 + q];
-      s_seed[q] = P.seed[0];
-      const uint32_t tg = P.target[0];
-      float dt;
-      if (BLOCKED) { const uint2 a = B.vaddr[tg]; dt = B.D[(size_t)a.x * B.NP + (size_t)(p0 + q) * (a.y >> 8) + (a.y & 255u)]; }
-      else dt = P.dist[tg];
-      s_armed[q] = dt < inf_f() ? 1u : 0u;
-      const GoalCut gc = goal_cut(dt, P.offset, tg);                 // dijkstra :296
-      s_goal[q] = gc.goal; s_cut[q] = gc.cut; s_tie[q] = gc.tie;
-    }
-  }
-  uint32_t bad = 0;
-  __syncthreads();
-  const uint32_t t_beg = T.t_lo + blockIdx.y * tiles_per_block;
-  const uint32_t t_end = min(t_beg + tiles_per_block, T.t_hi ? T.t_hi : T.ntiles);
-  for (uint32_t t = t_beg; t < t_end; ++t) {
-    if (!BLOCKED) {                                                   // (PG == 1 there) uniform over the workgroup
-      MNAV_GLOBAL const float* g_tlast = as_global((const float*)T.tlast);
-      MNAV_GLOBAL const uint32_t* g_p0 = as_global((const uint32_t*)T.pend[0]);
-      MNAV_GLOBAL const uint32_t* g_p1 = as_global((const uint32_t*)T.pend[1]);
-      if (!(g_tlast[t] > -inf_f()) && g_p0[t] == kInfBits && g_p1[t] == kInfBits) continue;
-    }
-    const uint32_t v0 = g_vptr[t], nv = g_vptr[t + 1] - v0;
-    const uint32_t h0 = g_hptr[t], nh = g_hptr[t + 1] - h0;
-    const uint32_t e0 = g_eptr[t], ne = g_eptr[t + 1] - e0;
-    const uint32_t r0 = g_rptr[t], nl = nv + nh;
-    __syncthreads();                                               // the previous tile's LDS image is dead
-    uint32_t g[kFinVpt];
-    u32x2 va[kFinVpt];
-#pragma unroll
-    for (int k = 0; k < kFinVpt; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      g[k] = (i < nv) ? g_verts[v0 + i] : (i < nl ? g_halo_verts[h0 + i - nv] : 0u);
-      if (BLOCKED) va[k] = g_va[g[k]];
-      if (i < nl) lgid[i] = g[k];
-    }
-    for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock) lgid[i] = (i < nv) ? g_verts[v0 + i] : g_halo_verts[h0 + i - nv];
-    stage_tile_graph(T, L, e0, ne, r0, nl, tid);                   // (ends with a barrier: lgid is visible too)
-    uint32_t dbn[kFinVpt];                                           // values of the first plan of the group
-#pragma unroll
-    for (int k = 0; k < kFinVpt; ++k) {
-      if (BLOCKED) dbn[k] = f2u(g_D[(size_t)va[k].x * B.NP + (size_t)p0 * (va[k].y >> 8) + (va[k].y & 255u)]);
-      else dbn[k] = f2u(as_global(plans[p0].dist)[g[k]]);
-    }
-#pragma unroll 1
-    for (uint32_t q = 0; q < np; ++q) {
-      const uint32_t p = p0 + q;
-      const Plan& P = plans[p];
-      MNAV_GLOBAL float* g_dist = as_global(P.dist);
-      MNAV_GLOBAL uint32_t* g_pred = as_global(P.pred);
-      GoalCut gcut; gcut.goal = s_goal[q]; gcut.cut = s_cut[q]; gcut.tie = s_tie[q];
-      const float goal_dist = gcut.cut;                              // values above it are re-derived from the expanded sources
-      const uint32_t seed_q = s_seed[q];
-      MNAV_GLOBAL float* g_vm = (BLOCKED && B.vecmaps) ? as_global(B.vecmaps[p]) : nullptr;
-      auto value_of = [&](uint32_t gid) -> uint32_t {
-        if (BLOCKED) { const u32x2 a = g_va[gid]; return f2u(g_D[(size_t)a.x * B.NP + (size_t)p * (a.y >> 8) + (a.y & 255u)]); }
-        return f2u(g_dist[gid]);
-      };
-      if (q) __syncthreads();                                        // the previous plan's ldu / lsum / lkey are dead
-      uint32_t db[kFinVpt];
-#pragma unroll
-      for (int k = 0; k < kFinVpt; ++k) db[k] = dbn[k];
-      if (BLOCKED && q + 1 < np) {                                   // the next plan's values are in flight during this plan's passes
-#pragma unroll
-        for (int k = 0; k < kFinVpt; ++k) dbn[k] = f2u(g_D[(size_t)va[k].x * B.NP + (size_t)(p + 1) * (va[k].y >> 8) + (va[k].y & 255u)]);
-      }
-      {
-        // no reached vertex among the tile's own and halo vertices: nothing to derive here (dist = inf, pred = itself)
-        int reached = 0;
-#pragma unroll
-        for (int k = 0; k < kFinVpt; ++k) reached |= ((uint32_t)(tid + k * kTileBlock) < nl && db[k] != kInfBits) ? 1 : 0;
-        for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock) reached |= (value_of(lgid[i]) != kInfBits) ? 1 : 0;
-        if (!__syncthreads_or(reached)) {                             // uniform over the workgroup
-          if (BLOCKED) for (uint32_t i = tid; i < nv; i += kTileBlock) {
-            const uint32_t gg = lgid[i]; g_dist[gg] = inf_f(); g_pred[gg] = gg;
-            if (g_vm) store3((float*)g_vm + 3 * (size_t)gg, 0.f, 0.f, 0.f);
-          }
-          continue;
-        }
-      }
-      int cut = 0;                                                   // owned vertices above goal_dist: their value is re-derived
-#pragma unroll
-      for (int k = 0; k < kFinVpt; ++k) {
-        const uint32_t i = tid + k * kTileBlock;
-        if (i < nl) {
-          L.ldu[i] = db[k];
-          if (i < nv) { const bool c = u2f(db[k]) > goal_dist; cut |= c; lsum[i] = c ? kInfBits : db[k]; lkey[i] = ~0ull; }
-        }
-      }
-      for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock) {
-        const uint32_t b = value_of(lgid[i]);
-        L.ldu[i] = b;
-        if (i < nv) { const bool c = u2f(b) > goal_dist; cut |= c; lsum[i] = c ? kInfBits : b; lkey[i] = ~0ull; }
-      }
-      cut = __syncthreads_or(cut);
-      if (cut) {
-        // pass 1 (tiles on the cut-off boundary only): smallest sum offered to the vertices above goal_dist
-        for (uint32_t x = tid; x < nl; x += kTileBlock) {
-          const float dx = u2f(L.ldu[x]);
-          if (!expanded_source(gcut, dx, lgid[x])) continue;         // not expanded (dijkstra :293-300)
-          for (uint32_t e = L.lrow[x], ee = L.lrow[x + 1]; e < ee; ++e) {
-            const uint32_t y = L.lcol[e];
-            if (y < nv && u2f(L.ldu[y]) > goal_dist) atomicMin(&lsum[y], f2u(dx + L.lw[e]));   // dijkstra :331
-          }
-        }
-        __syncthreads();
-      }
-      // pass 2: every edge checks the fixed point (no expanded source may offer less than the target
-      // holds) and the edges that attain the value compete with (d[x], x) for the predecessor
-      for (uint32_t x = tid; x < nl; x += kTileBlock) {
-        const uint32_t dxb = L.ldu[x];
-        const uint32_t eb = L.lrow[x], ee = L.lrow[x + 1];
-        const float dx = u2f(dxb);
-        if (!expanded_source(gcut, dx, lgid[x])) continue;
-        const unsigned long long key = ((unsigned long long)dxb << 32) | lgid[x];
-        uint32_t y[8]; float w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { y[u] = L.lcol[eb + u]; w[u] = L.lw[eb + u]; }   // reads past the row stay inside the LDS image
-        uint32_t sy[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const bool ok = eb + u < ee && y[u] < nv; y[u] = ok ? y[u] : 0xFFFFFFFFu; sy[u] = ok ? lsum[y[u]] : 0u; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (y[u] == 0xFFFFFFFFu) continue;
-          const uint32_t sb = f2u(dx + w[u]);
-          if (sb < sy[u]) ++bad;                                      // fixed point violated: internal error
-          else if (sb == sy[u] && sb != kInfBits) atomicMin(&lkey[y[u]], key);
-        }
-        for (uint32_t e = eb + 8; e < ee; ++e) {                     // valence > 8: rare
-          const uint32_t yy = L.lcol[e];
-          if (yy >= nv) continue;
-          const uint32_t sb = f2u(dx + L.lw[e]), syy = lsum[yy];
-          if (sb < syy) ++bad;
-          else if (sb == syy && sb != kInfBits) atomicMin(&lkey[yy], key);
-        }
-      }
-      __syncthreads();
-      uint32_t cnt = 0;
-      for (uint32_t i = tid; i < nv; i += kTileBlock) {
-        const uint32_t gg = lgid[i];
-        if (gg == seed_q) {
-          ++cnt;
-          if (BLOCKED) { g_dist[gg] = u2f(L.ldu[i]); g_pred[gg] = gg; if (g_vm) store3((float*)g_vm + 3 * (size_t)gg, 0.f, 0.f, 0.f); }
-          continue;
-        }
-        const uint32_t sb = lsum[i], ob = L.ldu[i];
-        const unsigned long long key = lkey[i];
-        if (sb != kInfBits && key == ~0ull && (!T.owned || T.owned[gg])) ++bad;   // a finite value no expanded neighbour supports (a halo copy's support may live on another process)
-        const uint32_t pv = (sb != kInfBits) ? (uint32_t)key : gg;
-        g_pred[gg] = pv;
-        if (BLOCKED || sb != ob) g_dist[gg] = u2f(sb);                // (else only above goal_dist: tentative value, dijkstra :337-343)
-        if (sb != kInfBits) ++cnt;
-        if (BLOCKED && g_vm) {                                        // k_vecmap_dijkstra's arithmetic
-          float x = 0.f, y = 0.f, z = 0.f;
-          if (pv != gg) {                                             // :197
-            x = g_xyz[3 * (size_t)pv] - g_xyz[3 * (size_t)gg];        // :204
-            y = g_xyz[3 * (size_t)pv + 1] - g_xyz[3 * (size_t)gg + 1];
-            z = g_xyz[3 * (size_t)pv + 2] - g_xyz[3 * (size_t)gg + 2];
-            const float len = sqrtf(x * x + y * y + z * z);           // normalized(), :206
-            x = x / len; y = y / len; z = z / len;
-          }
-          store3((float*)g_vm + 3 * (size_t)gg, x, y, z);
-        }
-      }
-      cnt = wave_sum(cnt);
-      if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_settled[q], cnt);
-    }
-  }
-  bad = wave_sum(bad);
-  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatch, bad);
-  __syncthreads();
-  if ((uint32_t)tid < np) {
-    const int q = tid;
-    if (s_settled[q]) atomicAdd(&res[p0 + q].settled, (unsigned long long)s_settled[q]);
-    if (blockIdx.y == 0) {
-      const Plan& P = plans[p0 + q];
-      Ctl r; memset(&r, 0, sizeof(r));
-      r.armed = s_armed[q]; r.goal_dist = s_goal[q]; r.thr = inf_f(); r.thr_fixed = inf_f();
-      if (BLOCKED) { r.it = (int32_t)*B.iters; r.done = 1u; r.overflow = (*B.err || *B.n_cand) ? 1u : 0u; }
-      else {
-        const TilePlan& Tq = tplans[p0 + q];
-        const TCtl a = Tq.ctl[0], b = Tq.ctl[1];
-        const TCtl last = (a.it > b.it) ? a : b;
-        r.it = last.it; r.done = last.done; r.bands = last.sweeps; r.evals = last.acts; r.overflow = last.pad[0];
-      }
-      P.ctl[0] = r; P.ctl[1] = r;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// plan state initialisation (dijkstra :266-270, cvp :710-714) and seeding (:272-277, :719-728)
-// ---------------------------------------------------------------------------------------------
-template <uint32_t PLANNER>
-__global__ __launch_bounds__(kBlock) void k_init(const Plan* __restrict__ plans)
-{
-  const Plan& P = plans[blockIdx.y];
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
-    P.dist[v] = inf_f();
-    P.pred[v] = v;
-    if (P.stamp) { P.stamp[v] = 0u; P.dirty[v] = 0u; P.wstamp[v] = 0u; }   // work-list state of the band steps only
-    if (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
-  }
-}
-
-template <uint32_t PLANNER>
-__global__ void k_seed(const Plan* __restrict__ plans)
-{
-  const Plan& P = plans[blockIdx.x];
-  if (threadIdx.x != 0) return;
-  constexpr int ns = (PLANNER == kPlannerCvp) ? 3 : 1;
-  float m0 = inf_f();
-  for (int k = 0; k < ns; ++k) {
-    const uint32_t s = P.seed[k];
-    P.dist[s] = P.seed_d[k];
-    if (PLANNER == kPlannerCvp) { P.tkey[s] = make_key(P.seed_d[k], s); P.cutf[s] = P.seed_face; }
-    m0 = fminf(m0, P.seed_d[k]);
-  }
-  uint32_t n = 0;
-  uint32_t* l0 = P.list[0];
-  for (int k = 0; k < ns; ++k) {
-    const uint32_t s = P.seed[k];
-    if (PLANNER == kPlannerCvp) {
-      for (uint32_t i = P.crn_ptr[s]; i < P.crn_ptr[s + 1]; ++i) {
-        const Corner c = P.crn[i];
-        if (c.v1 == kNone) continue;
-        if (P.stamp[c.v1] != 0xFFFFFFFFu) { P.stamp[c.v1] = 0xFFFFFFFFu; if (n < P.cap) l0[n] = c.v1; ++n; }
-        if (P.stamp[c.v2] != 0xFFFFFFFFu) { P.stamp[c.v2] = 0xFFFFFFFFu; if (n < P.cap) l0[n] = c.v2; ++n; }
-      }
-    } else {
-      for (uint32_t i = P.row_ptr[s]; i < P.row_ptr[s + 1]; ++i) {
-        const uint32_t u = P.nbr[i].u;
-        if (P.stamp[u] != 0xFFFFFFFFu) { P.stamp[u] = 0xFFFFFFFFu; if (n < P.cap) l0[n] = u; ++n; }
-      }
-    }
-  }
-  Ctl c0; memset(&c0, 0, sizeof(c0));
-  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
-  c0.thr = m0 + P.delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
-  for (int k = 0; k < ns; ++k) if (!(P.seed_d[k] < c0.thr)) c0.thr = next_up(P.seed_d[k]);   // the first band holds every seed
-  c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
-  P.ctl[1] = c0;
-  P.ctl[0] = c0;
-  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.n_next = n; ci.changed = 1; ci.minkey = 0x7f800000u; ci.minchg = 0x7f800000u;
-  P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"
-  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; z.minchg = 0x7f800000u;
-  P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;                         // cnt[3]: sticky flags (mnav_eval.h kFlag*)
-}
-
-// ---------------------------------------------------------------------------------------------
-// result assembly: code + vertex path (dijkstra :358-373) / reachability (cvp :902-918), stats
-// ---------------------------------------------------------------------------------------------
-
-constexpr uint32_t kPathOverflow = 0xFFFFFFF0u;   // internal: the path row was too short; path_len then holds the FULL length and
-                                                  // the host walks the overflowed plans again into exact-size rows
-// Where the vertex path of plan k goes: rows of `stride` ids, or -- second pass, for the plans whose path did not fit --
-// rows of exactly the needed size in a packed buffer (off / cap per plan, cap 0 = plan not part of this pass).
-struct PathRows {
-  uint32_t* base; uint32_t stride;
-  const unsigned long long* off; const uint32_t* cap;
-  __device__ __forceinline__ uint32_t* row(uint32_t k) const { return base + (off ? (size_t)off[k] : (size_t)k * stride); }
-  __device__ __forceinline__ uint32_t capacity(uint32_t k) const { return cap ? cap[k] : stride; }
-  __device__ __forceinline__ bool skip(uint32_t k) const { return cap && cap[k] == 0u; }
-};
-
-template <uint32_t PLANNER>
-__global__ void k_finish(const Plan* __restrict__ plans, PlanResult* __restrict__ res, PathRows rows)
-{
-  const Plan& P = plans[blockIdx.x];
-  if (threadIdx.x != 0 || rows.skip(blockIdx.x)) return;
-  PlanResult& R = res[blockIdx.x];
-  const Ctl a = P.ctl[0], b = P.ctl[1];
-  const Ctl last = (a.it > b.it) ? a : b;
-  R.steps = (uint32_t)(last.it < 0 ? 0 : last.it);
-  R.bands = last.bands; R.armed = last.armed; R.overflow = last.overflow; R.goal_dist = last.goal_dist; R.shrinks = last.shrinks | (last.cuts << 16);
-  R.evals = last.evals;
-  R.path_len = 0;
-  uint32_t code = kSuccess;
-  if (PLANNER == kPlannerCvp) {                                     // k_cvp_verify
-    if (P.cnt[3].n_next & kFlagWalkLimit) R.overflow |= 8u;         // cascade-tree walk bound hit on the converged tree
-    if (P.cnt[3].changed) R.overflow |= 16u;                        // a vertex is not a fixed point of the gather rule
-  }
-  if (R.overflow || !last.done) code = kInternalError;
-  else if (PLANNER == kPlannerDijkstra) {
-    const uint32_t seed = P.seed[0], target = P.target[0];
-    if (P.pred[target] == target) code = kNoPathFound;             // dijkstra :358
-    else {
-      uint32_t* path = rows.row(blockIdx.x);                       // written target-side first
-      const uint32_t cap = rows.capacity(blockIdx.x);
-      uint32_t n = 0, v = target;
-      while (v != seed && n <= P.V) { v = P.pred[v]; if (n < cap) path[n] = v; ++n; }   // :369-373; the full length is counted
-      if (v != seed) code = kInternalError;                         // a predecessor cycle
-      else if (n > cap) code = kPathOverflow;                       // row too short: the host walks this plan again into an exact row
-      R.path_len = n;
-    }
-  } else {
-    bool any = false;
-    for (int k = 0; k < 3; ++k) any = any || (P.pred[P.target[k]] != P.target[k]);   // cvp :904-911
-    if (!any && !(P.target[0] == P.seed[0] && P.target[1] == P.seed[1] && P.target[2] == P.seed[2]))
-      code = kNoPathFound;                                                           // :912-918
-  }
-  R.code = code;
-}
-
-// Paths without the finalize pass.  When a caller only wants the vertex path (no potential, predecessors or vector map:
-// the batch bench, mbf_mesh_nav's getPath), k_dij_finalize -- which re-stages every touched tile to derive ALL
-// predecessors and the tentative values beyond goal_dist -- is 10 % of a batch for nothing: after the tile rounds
-// every vertex with dist <= goal_dist is final (its shortest paths only use such sources), the path only visits such
-// vertices, and a path vertex's predecessor is the argmin (dist[u] + w, dist[u], u) over its neighbours of eval_dijkstra,
-// computed here on the fly along the walk (one wave per plan, one neighbour per lane).  Every hop also checks that the
-// minimum IS the vertex's distance (the fixed-point property k_dij_finalize verifies everywhere; here along the path).
-__global__ __launch_bounds__(kWave) void k_path_lazy(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans, PlanResult* __restrict__ res,
-                                                     PathRows rows, uint32_t* __restrict__ mismatch)
-{
-  if (rows.skip(blockIdx.x)) return;
-  const Plan& P = plans[blockIdx.x];
-  const TilePlan& T = tplans[blockIdx.x];
-  const int lane = threadIdx.x;
-  PlanResult& R = res[blockIdx.x];
-  const TCtl a = T.ctl[0], b = T.ctl[1];
-  const TCtl last = (a.it > b.it) ? a : b;
-  const uint32_t seed = P.seed[0], target = P.target[0];
-  const float dt = P.dist[target];
-  const GoalCut gcut = goal_cut(dt, P.offset, target);
-  const float goal_dist = gcut.goal;
-  uint32_t code = kSuccess, n = 0, bad = 0;
-  if (last.pad[0] || !last.done) code = kInternalError;               // activation cap hit / not finished
-  else if (!(dt < inf_f())) code = kNoPathFound;                      // the target was never reached (dijkstra :358)
-  else {
-    uint32_t* path = rows.row(blockIdx.x);                            // written target-side first
-    const uint32_t cap = rows.capacity(blockIdx.x);
-    uint32_t v = target;
-    while (v != seed && n <= P.V) {
-      const float dv = P.dist[v];
-      float best_s = inf_f(), best_du = inf_f();
-      uint32_t best_u = v;
-      const uint32_t beg = P.row_ptr[v], end = P.row_ptr[v + 1];
-      for (uint32_t i = beg + lane; i < end; i += kWave) {
-        const Nbr nb = P.nbr[i];
-        const float du = P.dist[nb.u];
-        if (!expanded_source(gcut, du, nb.u)) continue;               // never expanded (dijkstra :299)
-        const float sm = du + nb.w;                                   // :331
-        if (sm < best_s || (sm == best_s && sm < inf_f() && (du < best_du || (du == best_du && nb.u < best_u)))) { best_s = sm; best_du = du; best_u = nb.u; }
-      }
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const float os = __shfl_xor(best_s, o), odu = __shfl_xor(best_du, o);
-        const uint32_t ou = __shfl_xor(best_u, o);
-        if (os < best_s || (os == best_s && os < inf_f() && (odu < best_du || (odu == best_du && ou < best_u)))) { best_s = os; best_du = odu; best_u = ou; }
-      }
-      if (f2u(best_s) != f2u(dv) || best_u == v) { bad = 1; break; }  // not a fixed point here: reported, never returned
-      v = best_u;
-      if (lane == 0 && n < cap) path[n] = v;
-      ++n;
-    }
-    if (bad || v != seed) code = kInternalError;
-    else if (n > cap) code = kPathOverflow;
-  }
-  if (lane == 0) {
-    R.code = code; R.path_len = (code == kSuccess || code == kPathOverflow) ? n : 0;
-    R.steps = (uint32_t)(last.it < 0 ? 0 : last.it); R.bands = last.sweeps; R.armed = (dt < inf_f()) ? 1u : 0u; R.overflow = last.pad[0];
-    R.goal_dist = goal_dist; R.evals = last.acts; R.shrinks = 0;
-    if (bad) atomicAdd(mismatch, 1u);
-  }
-}
-
-// vertex paths of a batch, packed back to back and turned into the reference's list order (seed ... pred[target]) on the
-// device: ONE dense copy to a pinned buffer instead of a strided 2-D copy of n rows
-__global__ __launch_bounds__(kBlock) void k_pack_paths(PathRows rows, PathRows over, const uint32_t* __restrict__ offs,
-                                                       const uint32_t* __restrict__ lens, uint32_t* __restrict__ out)
-{
-  const uint32_t k = blockIdx.x, len = lens[k];
-  const uint32_t* src = (over.cap && over.cap[k]) ? over.row(k) : rows.row(k);   // second-pass rows where the first ones were too short
-  uint32_t* dst = out + offs[k];
-  for (uint32_t q = threadIdx.x; q < len; q += kBlock) dst[q] = src[len - 1 - q];
-}
-
-// settled vertices of a lazily finished plan: the popped ones, dist <= goal_dist (conservative against k_dij_finalize's
-// count, which includes the tentative ring beyond goal_dist)
-__global__ __launch_bounds__(kBlock) void k_count_goal(const Plan* __restrict__ plans, PlanResult* __restrict__ res)
-{
-  const Plan& P = plans[blockIdx.y];
-  const float dt = P.dist[P.target[0]];
-  const float goal_dist = goal_cut(dt, P.offset, P.target[0]).cut;
-  uint32_t c = 0;
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) { const float d = P.dist[v]; c += (d < inf_f() && d <= goal_dist) ? 1u : 0u; }
-  c = wave_sum(c);
-  __shared__ uint32_t s_c[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int k = 0; k < kBlock / 64; ++k) tot += s_c[k];
-    if (tot) atomicAdd(&res[blockIdx.y].settled, (unsigned long long)tot);
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_count(const Plan* __restrict__ plans, PlanResult* __restrict__ res)
-{
-  const Plan& P = plans[blockIdx.y];
-  uint32_t c = 0;
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) c += (P.dist[v] < inf_f()) ? 1u : 0u;
-  c = wave_sum(c);
-  __shared__ uint32_t s_c[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int k = 0; k < kBlock / 64; ++k) tot += s_c[k];
-    if (tot) atomicAdd(&res[blockIdx.y].settled, (unsigned long long)tot);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// vector maps: dijkstra :189-209, cvp :204-239
-// ---------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(kBlock) void k_vecmap_dijkstra(const Plan* __restrict__ plans, const float* __restrict__ xyz,
-                                                            float* const* __restrict__ vecmaps)
-{
-  const Plan& P = plans[blockIdx.y];
-  float* vm = vecmaps[blockIdx.y];
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
-    const uint32_t p = P.pred[v];
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (p != v) {                                               // :197
-      x = xyz[3 * (size_t)p] - xyz[3 * (size_t)v];              // :204
-      y = xyz[3 * (size_t)p + 1] - xyz[3 * (size_t)v + 1];
-      z = xyz[3 * (size_t)p + 2] - xyz[3 * (size_t)v + 2];
-      const float len = sqrtf(x * x + y * y + z * z);           // normalized(), :206
-      x = x / len; y = y / len; z = z / len;
-    }
-    store3(vm + 3 * (size_t)v, x, y, z);
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_vecmap_cvp(const Plan* __restrict__ plans, const float* __restrict__ xyz,
-                                                       const float* __restrict__ nrm, float* const* __restrict__ vecmaps,
-                                                       const float* __restrict__ seed_pos)
-{
-  const Plan& P = plans[blockIdx.y];
-  float* vm = vecmaps[blockIdx.y];
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
-    const uint32_t p = P.pred[v];
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (is_seed(P, v)) {                                        // cvp :722-724 (un-normalised diff)
-      const float* sp = seed_pos + 3 * (size_t)blockIdx.y;
-      x = sp[0] - xyz[3 * (size_t)v]; y = sp[1] - xyz[3 * (size_t)v + 1]; z = sp[2] - xyz[3 * (size_t)v + 2];
-    } else if (p != v && P.cutf[v] != kNone) {                  // :218, :222-225
-      const float dx = xyz[3 * (size_t)p] - xyz[3 * (size_t)v];
-      const float dy = xyz[3 * (size_t)p + 1] - xyz[3 * (size_t)v + 1];
-      const float dz = xyz[3 * (size_t)p + 2] - xyz[3 * (size_t)v + 2];
-      const float nx = nrm[3 * (size_t)v], ny = nrm[3 * (size_t)v + 1], nz = nrm[3 * (size_t)v + 2];
-      // rotated(normal, direction) :234 -- Rodrigues (CONVENTION, lvr2 un-vendored; see oracle)
-      const float ang = P.dirn[v];
-      const float c = cosf_ref(ang), s = sinf_ref(ang);   // the host libm's bits (mnav_eval.h): the field is the reference's bit for bit
-      const float cx = ny * dz - nz * dy, cy = nz * dx - nx * dz, cz = nx * dy - ny * dx;
-      const float ndv = nx * dx + ny * dy + nz * dz;
-      const float k = ndv * (1.0f - c);
-      x = dx * c + cx * s + nx * k; y = dy * c + cy * s + ny * k; z = dz * c + cz * s + nz * k;
-      const float len = sqrtf(x * x + y * y + z * z);           // :236
-      x = x / len; y = y / len; z = z / len;
-    }
-    store3(vm + 3 * (size_t)v, x, y, z);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// input preparation
-// ---------------------------------------------------------------------------------------------
-// MeshMap::computeEdgeWeights, mesh_map.cpp:517-561 (exact promotion order, no contraction)
-// Combination layers on the device (mesh_layers/src/combination_layer.cpp:44-85 Max, :185-248 weighted
-// sum): the inputs are dense V-sized layers (missing entries already replaced by the layer default,
-// :62-65 / :201-205), combined in the order given, starting from defaultValue() = 0.
-__global__ __launch_bounds__(kBlock) void k_combine(uint32_t V, int mode, uint32_t n_layers, const float* __restrict__ layers,
-                                                    const float* __restrict__ weights, float* __restrict__ out)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  float cost = 0.0f;                                               // defaultValue(), combination_layer.h:52,94
-  for (uint32_t l = 0; l < n_layers; ++l) {
-    const float tmp = layers[(size_t)l * V + v];
-    if (mode == 0) cost = (cost < tmp) ? tmp : cost;               // std::max(cost, tmp) :66
-    else cost += weights[l] * tmp;                                 // :206 (float multiply, float add)
-  }
-  out[v] = cost;
-}
-
-__global__ __launch_bounds__(kBlock) void k_edge_weights(uint32_t E, const uint32_t* __restrict__ edge_vtx,
-                                                         const float* __restrict__ edge_dist, const float* __restrict__ cost,
-                                                         double factor, float* __restrict__ w)
-{
-  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
-  if (e >= E) return;
-  const float c1 = cost[edge_vtx[2 * (size_t)e]], c2 = cost[edge_vtx[2 * (size_t)e + 1]];   // :528-529
-  if (isinf(c1) || isinf(c2)) { w[e] = inf_f(); return; }                                    // :538-542
-  const float vd = edge_dist[e];                                                             // :548
-  const float edge_cost = (float)((double)(vd * (c1 + c2)) / 2.0);                           // :550
-  w[e] = (float)((double)vd + factor * (double)edge_cost);                                   // :552
-}
-
-// Incremental cost change (MeshMap::layerChanged mesh_map.cpp:454-493 + updateEdgeWeights :563-618): the changed
-// vertices get their new cost, then only the edges around them are re-weighted -- same expressions as :550-552.
-__global__ __launch_bounds__(kBlock) void k_scatter_costs(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ values,
-                                                          float* __restrict__ cost)
-{
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) cost[ids[i]] = values[i];
-}
-__global__ __launch_bounds__(kBlock) void k_update_edge_weights(uint32_t n, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ row_ptr,
-                                                                const uint32_t* __restrict__ nbr_u, const uint32_t* __restrict__ nbr_e,
-                                                                const float* __restrict__ edge_dist, const float* __restrict__ cost,
-                                                                double factor, float* __restrict__ w)
-{
-  // 8 lanes per changed vertex, one incident edge each (an edge between two changed vertices is written twice with
-  // the same value)
-  const uint32_t i = (blockIdx.x * kBlock + threadIdx.x) >> 3;
-  const int sub = threadIdx.x & 7;
-  if (i >= n) return;
-  const uint32_t v = ids[i];
-  const float c1 = cost[v];
-  for (uint32_t k = row_ptr[v] + sub; k < row_ptr[v + 1]; k += 8) {
-    const uint32_t e = nbr_e[k];
-    const float c2 = cost[nbr_u[k]];
-    if (isinf(c1) || isinf(c2)) { w[e] = inf_f(); continue; }       // :596-600
-    const float vd = edge_dist[e];                                   // :606
-    const float edge_cost = (float)((double)(vd * (c1 + c2)) / 2.0); // :608 (float sum: commutative, the endpoint order is free)
-    w[e] = (float)((double)vd + factor * (double)edge_cost);        // :610
-  }
-}
-
-// gather CSR for Dijkstra: {u, w(u,v)}; w=+inf when v is invalid (:328) or u is over the cost
-// limit (:302, u would be popped but never expanded)
-__global__ __launch_bounds__(kBlock) void k_build_nbr(uint32_t V, const uint32_t* __restrict__ row_ptr,
-                                                      const uint32_t* __restrict__ nbr_u, const uint32_t* __restrict__ nbr_e,
-                                                      const float* __restrict__ w, const float* __restrict__ cost,
-                                                      const uint8_t* __restrict__ invalid, double cost_limit, Nbr* __restrict__ out)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  const bool vinv = invalid[v] != 0;
-  for (uint32_t i = row_ptr[v]; i < row_ptr[v + 1]; ++i) {
-    const uint32_t u = nbr_u[i];
-    float ww = w[nbr_e[i]];
-    if (vinv || (double)cost[u] > cost_limit) ww = inf_f();
-    Nbr n; n.u = u; n.w = ww;
-    out[i] = n;
-  }
-}
-
-struct CornerIdx { uint32_t v1, v2, ea, eb, ec, face; };
-
-__global__ __launch_bounds__(kBlock) void k_build_crn(uint32_t V, const uint32_t* __restrict__ crn_ptr,
-                                                      const CornerIdx* __restrict__ idx, const float* __restrict__ w,
-                                                      const float* __restrict__ cost, const uint8_t* __restrict__ invalid,
-                                                      double cost_limit, Corner* __restrict__ out, uint8_t* __restrict__ blocked)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  const bool vinv = invalid[v] != 0;
-  blocked[v] = ((double)cost[v] >= cost_limit || vinv) ? 1 : 0;      // cvp :802,825,848 / :785
-  for (uint32_t i = crn_ptr[v]; i < crn_ptr[v + 1]; ++i) {
-    const CornerIdx k = idx[i];
-    Corner c;
-    c.v1 = (vinv || invalid[k.v1] || invalid[k.v2]) ? kNone : k.v1;   // cvp :785
-    c.v2 = k.v2; c.a = w[k.ea]; c.b = w[k.eb]; c.c = w[k.ec]; c.face = k.face;
-    out[i] = c;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Layers on the device (mesh_layers): Steepness (steepness_layer.cpp:157-166, :82-93), Inflation
-// (inflation_layer.cpp:341-491 as a multi-source wave on the band engine; spec: mnav_eval.h eval_cvp / Plan.seed_mask)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_edge_dist(uint32_t E, const uint32_t* __restrict__ edge_vtx, const float* __restrict__ xyz,
-                                                      float* __restrict__ out)
-{
-  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
-  if (e >= E) return;
-  const float* a = xyz + 3 * (size_t)edge_vtx[2 * (size_t)e];
-  const float* b = xyz + 3 * (size_t)edge_vtx[2 * (size_t)e + 1];
-  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-  out[e] = sqrtf(dx * dx + dy * dy + dz * dz);                     // lvr2 BaseVector::distanceFrom in float (mesh_map.cpp:347)
-}
-
-__global__ __launch_bounds__(kBlock) void k_steepness(uint32_t V, const float* __restrict__ nrm, double threshold,
-                                                      float* __restrict__ cost, uint8_t* __restrict__ lethal)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  const float st = acosf_ref(nrm[3 * (size_t)v + 2]);              // :165 (float overload of acos; the host libm's bits, mnav_eval.h)
-  cost[v] = st;
-  lethal[v] = ((double)st > threshold) ? 1 : 0;                    // :88
-}
-
-// corners with the edge DISTANCES as side lengths (waveCostInflation reads map->edgeDistances() :383); no face is
-// skipped here: what may fire is decided by Plan.seed_mask
-__global__ __launch_bounds__(kBlock) void k_build_crn_infl(uint32_t V, const uint32_t* __restrict__ crn_ptr,
-                                                           const CornerIdx* __restrict__ idx, const float* __restrict__ w,
-                                                           Corner* __restrict__ out)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  for (uint32_t i = crn_ptr[v]; i < crn_ptr[v + 1]; ++i) {
-    const CornerIdx k = idx[i];
-    Corner c;
-    c.v1 = k.v1; c.v2 = k.v2; c.a = w[k.ea]; c.b = w[k.eb]; c.c = w[k.ec]; c.face = corner_face_for_inflation(k.face);
-    out[i] = c;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_infl_mask(uint32_t V, const uint8_t* __restrict__ lethal, const uint8_t* __restrict__ invalid,
-                                                      uint8_t* __restrict__ mask)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  const bool l = lethal[v] != 0, inv = invalid && invalid[v] != 0;
-  mask[v] = l ? (inv ? kInflSeedMute : kInflSeed) : (inv ? kInflMute : kInflFree);
-}
-
-// control blocks of the wave (the single-thread part of k_seed), then the seeds in parallel: every lethal vertex is
-// fixed at distance 0 (:397-402) and the free vertices around it form the first work list
-__global__ void k_infl_ctl(const Plan* __restrict__ plans)
-{
-  const Plan& P = plans[0];
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Ctl c0; memset(&c0, 0, sizeof(c0));
-  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
-  c0.thr = P.delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
-  c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
-  P.ctl[1] = c0;
-  P.ctl[0] = c0;
-  Cnt ci; memset(&ci, 0, sizeof(ci)); ci.changed = 1; ci.minkey = 0x7f800000u; ci.minchg = 0x7f800000u;
-  P.cnt[2] = ci;                       // read by step 0 as "(0-1) mod 3"; k_infl_seed counts the list into it
-  Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; z.minchg = 0x7f800000u;
-  P.cnt[0] = z; P.cnt[1] = z; P.cnt[3] = z;
-}
-
-__global__ __launch_bounds__(kBlock) void k_infl_seed(const Plan* __restrict__ plans)
-{
-  const Plan& P = plans[0];
-  const uint32_t stride = gridDim.x * kBlock;
-  uint32_t* l0 = P.list[0];
-  for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < P.V; v += stride) {
-    if (!is_seed(P, v)) continue;
-    P.dist[v] = 0.0f; P.tkey[v] = make_key(0.0f, v); P.keyd[v] = 0.0f;
-    for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) {
-      const Corner c = P.crn[i];
-      const uint32_t nb[2] = { c.v1, c.v2 };
-      for (int q = 0; q < 2; ++q) {
-        const uint32_t u = nb[q];
-        if (u == kNone || is_seed(P, u)) continue;
-        if (P.stamp[u] != 0xFFFFFFFFu && atomicExch(&P.stamp[u], 0xFFFFFFFFu) != 0xFFFFFFFFu) {
-          const uint32_t at = atomicAdd(&P.cnt[2].n_next, 1u);
-          if (at < P.cap) l0[at] = u;
-        }
-      }
-    }
-  }
-}
-
-// The inflation layer's repulsive vector field from the converged wave (spec: mnav_eval.h infl_accumulate / infl_assign).
-// state: 0 = open (a free vertex with a distance whose vector may still be assigned), 1 = final with a vector, 2 = final
-// without one.  k_infl_assign is launched until nothing is open; it reads the states of the PREVIOUS launch and writes the
-// next ones to a second array, so a vector is only ever read after the launch that wrote it has ended.
-__global__ __launch_bounds__(kBlock) void k_infl_accum(const Plan* __restrict__ plans, const uint32_t* __restrict__ crn_walk,
-                                                       const float* __restrict__ xyz, float* __restrict__ vec, uint8_t* __restrict__ state,
-                                                       uint8_t* __restrict__ acc, uint32_t* __restrict__ ctl)
-{
-  const Plan& P = plans[0];
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= P.V) return;
-  float o[3] = { 0.f, 0.f, 0.f };
-  const int r = infl_accumulate(P, crn_walk, xyz, v, o);
-  if (r < 0) { atomicOr(&ctl[2], 1u); return; }
-  vec[3 * (size_t)v] = o[0]; vec[3 * (size_t)v + 1] = o[1]; vec[3 * (size_t)v + 2] = o[2];
-  acc[v] = r == 1 ? 1 : 0;
-  const bool open = !is_seed(P, v) && P.dist[v] < inf_f();
-  state[v] = open ? 0 : (r == 1 ? 1 : 2);
-}
-
-__global__ __launch_bounds__(kBlock) void k_infl_assign(const Plan* __restrict__ plans, float* __restrict__ vec, const uint8_t* __restrict__ state,
-                                                        uint8_t* __restrict__ state_next, const uint8_t* __restrict__ acc, uint32_t* __restrict__ ctl)
-{
-  const Plan& P = plans[0];
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= P.V) return;
-  const uint8_t st = state[v];
-  if (st != 0) { state_next[v] = st; return; }
-  float o[3];
-  const int r = infl_assign(P, vec, state, v, o);
-  if (r == 2) { state_next[v] = 0; atomicAdd(&ctl[0], 1u); return; }   // a support is still open: next launch
-  if (r == 1) { vec[3 * (size_t)v] = o[0]; vec[3 * (size_t)v + 1] = o[1]; vec[3 * (size_t)v + 2] = o[2]; }
-  state_next[v] = (r == 1 || acc[v]) ? 1 : 2;
-  atomicAdd(&ctl[1], 1u);
-}
-
-// riskiness from the distances: fading() :315-339; vertices the wave never reached keep the default 0
-// (inflation_layer.h:74-77).  The exponential runs in float64 and is rounded to float32 (:326).
-__global__ __launch_bounds__(kBlock) void k_infl_cost(uint32_t V, const float* __restrict__ dist, double inflation_radius,
-                                                      double inscribed_radius, double inscribed_value, double lethal_value,
-                                                      double cost_scaling_factor, float* __restrict__ cost)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  const float d = dist[v];
-  float c;
-  if (!(d < inf_f())) c = 0.0f;
-  else if ((double)d > inflation_radius) c = 0.0f;                                        // :317-320
-  else if ((double)d > inscribed_radius) {                                                // :323
-    const float factor = (float)exp(-1.0 * cost_scaling_factor * ((double)d - inscribed_radius));   // :326
-    c = (float)(inscribed_value * (double)factor);                                        // :327
-  }
-  else if (d > 0) c = (float)inscribed_value;                                             // :332-335
-  else c = (float)lethal_value;                                                           // :338
-  cost[v] = c;
-}
-
-__global__ __launch_bounds__(kBlock) void k_combine_resident(uint32_t V, int mode, uint32_t n_layers, const float* const* __restrict__ layers,
-                                                             const float* __restrict__ weights, float* __restrict__ out)
-{
-  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-  if (v >= V) return;
-  float cost = 0.0f;                                               // defaultValue(), combination_layer.h:52,94
-  for (uint32_t l = 0; l < n_layers; ++l) {
-    const float tmp = layers[l][v];
-    if (mode == 0) cost = (cost < tmp) ? tmp : cost;               // std::max(cost, tmp) :66
-    else cost += weights[l] * tmp;                                 // :206
-  }
-  out[v] = cost;
-}
-
-// CombinationLayer::onInputChanged (combination_layer.cpp:87-147 max, :250-302 weighted sum): only the changed vertices
-__global__ __launch_bounds__(kBlock) void k_combine_resident_ids(uint32_t n, const uint32_t* __restrict__ ids, int mode, uint32_t n_layers,
-                                                                 const float* const* __restrict__ layers, const float* __restrict__ weights,
-                                                                 float* __restrict__ out, float* __restrict__ values)
-{
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t v = ids[i];
-  float cost = 0.0f;
-  for (uint32_t l = 0; l < n_layers; ++l) {
-    const float tmp = layers[l][v];
-    if (mode == 0) cost = (tmp < cost) ? cost : tmp;               // std::max(tmp, cost) :117
-    else cost += weights[l] * tmp;                                 // :281
-  }
-  out[v] = cost;
-  values[i] = cost;
-}
+#include "mnav_map_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -2069,7 +230,7 @@ namespace {
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
     if (e_ != hipSuccess) {                                                                        \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_) + " (mnav.hip:" + std::to_string(__LINE__) + ")"; \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE_NAME__ ":" + std::to_string(__LINE__) + ")"; \
       return -1;                                                                                   \
     }                                                                                              \
   } while (0)
@@ -2331,466 +492,7 @@ int verify_sweeps(mnav_ctx* ctx, uint32_t n)
   return 0;
 }
 
-struct PlanIn {
-  uint32_t seed[3], target[3];
-  float seed_d[3];
-  uint32_t seed_face;
-  uint32_t seed_expands[3], target_expands[3];
-};
-
-// Runs n plans of one planner to completion on the device.  Returns 0, -1 (error) or 1 (cancelled).
-template <uint32_t PLANNER>
-int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, bool want_path)
-{
-  constexpr bool cvp = PLANNER == kPlannerCvp;
-  if (ensure_slots(ctx, n, cvp, true, cvp || ctx->want_vec)) return -1;
-  if (want_path && ensure_paths(ctx, n)) return -1;
-  // default band width: 3 mean edge weights for the Dijkstra gather steps, 12 for CVP (measured on C3:
-  // fewer, fuller bands -- 20 % less time for one plan and for batches; results do not depend on it)
-  const float delta = ctx->delta_user > 0.f ? ctx->delta_user : (cvp ? 4.0f * ctx->delta_auto : ctx->delta_auto);
-  std::vector<Plan> hp(n);
-  std::vector<float*> vecs(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    Plan& P = hp[i];
-    memset(&P, 0, sizeof(P));
-    P.planner = PLANNER; P.V = ctx->V;
-    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = cvp ? s.tkey : nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = delta; P.offset = offset; P.max_steps = ctx->max_steps; P.walk_max = ctx->walk_max; P.descend_max = ctx->descend_max;
-    for (int k = 0; k < 3; ++k) {
-      P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = in[i].seed_d[k];
-      P.seed_expands[k] = in[i].seed_expands[k]; P.target_expands[k] = in[i].target_expands[k];
-    }
-    P.seed_face = in[i].seed_face;
-    vecs[i] = s.vecmap;
-  }
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
-
-  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<PLANNER>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  hipLaunchKernelGGL(k_seed<PLANNER>, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-
-  // CVP batches: the wide step kernel (64 work-list entries per wave and round); single plans keep the 8-lane replay, whose
-  // many small waves finish a short work list sooner
-  bool wide = cvp && n >= ctx->cvp_wide_min_batch;
-  if (const char* e = getenv("MNAV_CVP_WIDE")) wide = cvp && atoi(e) != 0;
-  uint32_t G = blocks_per_plan(ctx);
-  if (wide) {
-    int ncu = 256;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    G = (kWideVerts == 64u ? 7u : 12u) * (uint32_t)ncu;               // waves of the whole batch, not per plan: what stays resident
-    if (const char* e = getenv("MNAV_WIDE_WAVES")) G = (uint32_t)std::max(1, atoi(e));
-    ctx->wide_groups = std::min(4u, std::max(1u, n / 40u));            // measured on the benched C3 configuration, plans/s with 1 / 2 / 3 / 4 / 8 groups:
-                                                                      // 128 plans 277 / 315 / 320 / 320 / 221, 512 plans 330 / 425 / 463 / 468 / 422
-    if (const char* e = getenv("MNAV_CVP_GROUPS")) ctx->wide_groups = (uint32_t)std::min(std::max(1, atoi(e)), (int)kWideGroupsMax);
-    if (ctx->wide_groups > n) ctx->wide_groups = 1;
-    if (ctx->wide_cap < n + 1u) {
-      (void)hipFree(ctx->d_wide_prefix); ctx->d_wide_prefix = nullptr;
-      HIPCHK(hipMalloc((void**)&ctx->d_wide_prefix, 4 * (size_t)(2u * n + 2u * kWideGroupsMax + 8u)));   // per group: prefix sums [ng + 1], then the list of plans in a band cut [ng]
-      ctx->wide_cap = n + 1u;
-      drop_graphs(ctx);                                               // (captured with the old pointer)
-    }
-    if (!ctx->d_wide_sched) HIPCHK(hipMalloc((void**)&ctx->d_wide_sched, kWideGroupsMax * sizeof(WideSched)));
-    if (!ctx->stream_g[1]) {
-      for (uint32_t g = 1; g < kWideGroupsMax; ++g) HIPCHK(hipStreamCreateWithFlags(&ctx->stream_g[g], hipStreamNonBlocking));
-      for (auto& e : ctx->ev_fork) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-  }
-  uint32_t launches = 0;
-  int rc = 0;
-  const auto t_start = std::chrono::steady_clock::now();
-  ctx->ms_chunks = 0.0;
-  for (;;) {
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
-      ctx->err = "wavefront steps exceeded the wall-clock guard"; return -1;
-    }
-    HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-    if (run_chunk<PLANNER>(ctx, n, G, wide)) return -1;
-    HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-    launches += kChunk;
-    HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl) * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->ms_chunks += ev_ms(ctx->evc[0], ctx->evc[1]);
-    bool all_done = true;
-    for (uint32_t i = 0; i < n; ++i) {
-      const Ctl& a = ctx->h_ctl[2 * i];
-      const Ctl& b = ctx->h_ctl[2 * i + 1];
-      const Ctl& last = a.it > b.it ? a : b;
-      if (!last.done) all_done = false;
-    }
-    if (all_done) break;
-    if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
-  }
-  ctx->stats.launches = launches;
-  if (cvp && rc == 0 && ctx->cvp_verify && verify_sweeps(ctx, n)) return -1;
-  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-  return rc;
-}
-
-int ensure_tile_state(mnav_ctx* ctx, uint32_t n)
-{
-  const size_t nt = ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1;
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    if (!s.tile_ready) {
-      HIPCHK(hipMalloc((void**)&s.tpend0, 4 * nt)); HIPCHK(hipMalloc((void**)&s.tpend1, 4 * nt));
-      HIPCHK(hipMalloc((void**)&s.tlast, 4 * nt));
-      HIPCHK(hipMalloc((void**)&s.tcnt, 3 * sizeof(TCnt)));
-      s.tile_ready = true;
-    }
-  }
-  if (ctx->tctl_pool_cap < n) {
-    if (ctx->d_tctl_pool) (void)hipFree(ctx->d_tctl_pool);
-    ctx->d_tctl_pool = nullptr;
-    HIPCHK(hipMalloc((void**)&ctx->d_tctl_pool, 2 * sizeof(TCtl) * n));
-    ctx->tctl_pool_cap = n;
-  }
-  for (uint32_t i = 0; i < n; ++i) ctx->slots[i].tctl = ctx->d_tctl_pool + 2 * i;
-  if (ctx->tplans_cap < n) {
-    if (ctx->d_tplans) (void)hipFree(ctx->d_tplans);
-    if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
-    ctx->d_tplans = nullptr; ctx->h_tctl = nullptr;
-    drop_graphs(ctx);
-    HIPCHK(hipMalloc((void**)&ctx->d_tplans, sizeof(TilePlan) * n));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_tctl, sizeof(TCtl) * 2 * n, hipHostMallocDefault));
-    ctx->tplans_cap = n;
-  }
-  if (!ctx->d_mismatch) HIPCHK(hipMalloc((void**)&ctx->d_mismatch, 4));
-  return 0;
-}
-
-// one workgroup per (plan, chunk of tiles); small batches get more, smaller chunks to fill the chip
-void launch_finalize(mnav_ctx* ctx, uint32_t n, uint32_t ntiles_in = 0, size_t fin_lds_in = 0)
-{
-  const uint32_t nt_ = ntiles_in ? ntiles_in : ctx->tiles_meta.ntiles;
-  const size_t fin_lds = fin_lds_in ? fin_lds_in : ctx->fin_lds;
-  const uint32_t ntiles = nt_ ? nt_ : 1u;
-  uint32_t chunks = (4096u + n - 1) / n;                 // >= 4096 workgroups in flight
-  if (chunks > ntiles) chunks = ntiles;
-  if (chunks < 1) chunks = 1;
-  const uint32_t per = (ntiles + chunks - 1) / chunks;
-  chunks = (ntiles + per - 1) / per;
-  hipLaunchKernelGGL((k_dij_finalize<1, false>), dim3(n, chunks), dim3(kTileBlock), fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
-                     ctx->d_mismatch, ctx->d_res, per, n, FinBlocked{});
-}
-
-// the tile-batch engine's batches: groups of kFinGroup plans per staged tile, distances straight from the engine's slices
-constexpr int kFinGroup = 8;
-void launch_finalize_blocked(mnav_ctx* ctx, uint32_t n, const FinBlocked& B)
-{
-  const uint32_t ntiles = ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1u;
-  const uint32_t groups = (n + kFinGroup - 1) / kFinGroup;
-  uint32_t chunks = (8192u + groups - 1) / groups;
-  if (chunks > ntiles) chunks = ntiles;
-  if (chunks < 1) chunks = 1;
-  const uint32_t per = (ntiles + chunks - 1) / chunks;
-  chunks = (ntiles + per - 1) / per;
-  hipLaunchKernelGGL((k_dij_finalize<kFinGroup, true>), dim3(groups, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
-                     ctx->d_mismatch, ctx->d_res, per, n, B);
-}
-
-int tile_weights(mnav_ctx* ctx)
-{
-  if (ctx->tw_valid) return 0;
-  const uint32_t n = ctx->t_nnz;
-  const uint32_t gb = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(k_tile_weights, dim3(gb ? gb : 1), dim3(kBlock), 0, ctx->stream, n, ctx->d_t_src, ctx->d_t_col, ctx->d_nbr, ctx->d_t_tw);
-  HIPCHK(hipGetLastError());
-  ctx->tw_valid = true;
-  return 0;
-}
-
-constexpr int kTileChunk = 24;   // rounds per graph replay (multiple of 6)
-
-int launch_tile_rounds(mnav_ctx* ctx, uint32_t n, uint32_t G, int count)
-{
-  for (int j = 0; j < count; ++j)
-    hipLaunchKernelGGL(k_tile_round, dim3(G, n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, j % 6);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-int run_tile_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G)
-{
-  if (!ctx->use_graph) return launch_tile_rounds(ctx, n, G, kTileChunk);
-  const uint64_t key = (7ull << 60) | ((uint64_t)n << 32) | G;
-  auto it = ctx->graphs.find(key);
-  if (it == ctx->graphs.end()) {
-    hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = launch_tile_rounds(ctx, n, G, kTileChunk);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-    if (rc != 0 || e != hipSuccess) { ctx->err = "graph capture failed"; return -1; }
-    hipGraphExec_t ge = nullptr;
-    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(g);
-    it = ctx->graphs.emplace(key, ge).first;
-  }
-  HIPCHK(hipGraphLaunch(it->second, ctx->stream));
-  return 0;
-}
-
-// Dijkstra through the tiled engine.  Returns 0, -1 (error) or 1 (cancelled).
-int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
-{
-  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_paths(ctx, n)) return -1;
-  if (ensure_tile_state(ctx, n)) return -1;
-  if (tile_weights(ctx)) return -1;
-  const HostTiles& M = ctx->tiles_meta;
-  std::vector<Plan> hp(n);
-  std::vector<TilePlan> tp(n);
-  std::vector<float*> vecs(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    Plan& P = hp[i];
-    memset(&P, 0, sizeof(P));
-    P.planner = kPlannerDijkstra; P.V = ctx->V;
-    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = 0.f; P.offset = offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
-    for (int k = 0; k < 3; ++k) {
-      P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1;
-    }
-    P.seed_face = kNone;
-    vecs[i] = s.vecmap;
-    TilePlan& T = tp[i];
-    memset(&T, 0, sizeof(T));
-    T.V = ctx->V; T.ntiles = M.ntiles;
-    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset; T.max_rounds = ctx->max_steps;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto * ctx->rounds_band_mult;
-    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
-  }
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-
-  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  {
-    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-    if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-
-  // active tiles form a ring along the wavefront: O(sqrt(ntiles)); every workgroup scans a
-  // strided share of the tile table, so any grid size is correct
-  uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)M.ntiles)) + 8;
-  if (const char* e = getenv("MNAV_TILE_BLOCKS")) G = (uint32_t)atoi(e);
-  if (G > M.ntiles) G = M.ntiles;
-  if (G < 1) G = 1;
-  uint32_t launches = 0;
-  int rc = 0;
-  const auto t_start = std::chrono::steady_clock::now();
-  ctx->ms_chunks = 0.0;
-  for (;;) {
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
-      ctx->err = "tile rounds exceeded the wall-clock guard"; return -1;
-    }
-    HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-    if (run_tile_chunk(ctx, n, G)) return -1;
-    HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-    launches += kTileChunk;
-    HIPCHK(hipMemcpyAsync(ctx->h_tctl, ctx->d_tctl_pool, 2 * sizeof(TCtl) * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->ms_chunks += ev_ms(ctx->evc[0], ctx->evc[1]);
-    bool all_done = true;
-    for (uint32_t i = 0; i < n; ++i) {
-      const TCtl& a = ctx->h_tctl[2 * i];
-      const TCtl& b = ctx->h_tctl[2 * i + 1];
-      const TCtl& last = a.it > b.it ? a : b;
-      if (!last.done) all_done = false;
-    }
-    if (all_done) break;
-    if (ctx->cancel.load(std::memory_order_relaxed)) { rc = 1; break; }
-  }
-  ctx->stats.launches = launches;
-  if (rc == 0 && !ctx->lazy_paths) {
-    launch_finalize(ctx, n);
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-  return rc;
-}
-
-// Dijkstra batches through the persistent per-plan kernel.  Returns 0, -1 (error) or 1 (cancelled).
-int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
-{
-  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_paths(ctx, n)) return -1;
-  if (ensure_tile_state(ctx, n)) return -1;
-  if (tile_weights(ctx)) return -1;
-  const HostTiles& M = ctx->tiles_meta;
-  std::vector<Plan> hp(n);
-  std::vector<TilePlan> tp(n);
-  std::vector<float*> vecs(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    Plan& P = hp[i];
-    memset(&P, 0, sizeof(P));
-    P.planner = kPlannerDijkstra; P.V = ctx->V;
-    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
-    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
-    P.seed_face = kNone;
-    vecs[i] = s.vecmap;
-    TilePlan& T = tp[i];
-    memset(&T, 0, sizeof(T));
-    T.V = ctx->V; T.ntiles = M.ntiles;
-    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
-    T.max_rounds = 64u * (M.ntiles ? M.ntiles : 1u) + 1024u;          // activation cap per plan
-    T.cancel = ctx->d_cancel;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
-    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
-  }
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  {
-    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-    if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-  ctx->ms_chunks = 0.0;
-  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_persistent<2>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
-  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_persistent<4>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
-  else hipLaunchKernelGGL(k_plan_persistent<8>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  if (!ctx->lazy_paths) launch_finalize(ctx, n);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
-  ctx->stats.launches = 1;
-  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;        // the kernel left its loops early (status 3): :350-354
-  return 0;
-}
-
-// Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1 or 1 (cancelled).
-int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
-{
-  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_paths(ctx, n)) return -1;
-  if (ensure_tile_state(ctx, n)) return -1;
-  if (tile_weights(ctx)) return -1;
-  const HostTiles& M = ctx->tiles_meta;
-  std::vector<Plan> hp(n);
-  std::vector<TilePlan> tp(n);
-  std::vector<float*> vecs(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    Plan& P = hp[i];
-    memset(&P, 0, sizeof(P));
-    P.planner = kPlannerDijkstra; P.V = ctx->V;
-    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
-    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
-    P.seed_face = kNone;
-    vecs[i] = s.vecmap;
-    TilePlan& T = tp[i];
-    memset(&T, 0, sizeof(T));
-    T.V = ctx->V; T.ntiles = M.ntiles;
-    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
-    T.max_rounds = 0x7FFFFFF0u;
-    T.cancel = ctx->d_cancel;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
-    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
-  }
-  AsyncCtl* const actl = reinterpret_cast<AsyncCtl*>(ctx->d_cancel + 4);   // words 4..7 of the 64-byte control line (word 0: mnav_cancel)
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(actl, 0, sizeof(AsyncCtl), ctx->stream));     // every polled word is zeroed on the stream before every launch
-  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  {
-    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-    if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
-    hipLaunchKernelGGL(k_async_init, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_tplans, n);
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-  // Workgroups: what is resident at once, and no more per plan than its wavefront has tiles for (idle workgroups poll).
-  int ncu = 256;
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  uint32_t per_cu = 2, per_plan = 48;
-  if (const char* e = getenv("MNAV_ASYNC_WG_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
-  if (const char* e = getenv("MNAV_ASYNC_WG_PER_PLAN")) per_plan = (uint32_t)std::max(1, atoi(e));
-  uint32_t G = std::min<uint64_t>((uint64_t)ncu * per_cu, (uint64_t)n * per_plan);
-  if (G > M.ntiles * n) G = M.ntiles * n;
-  if (G < 1) G = 1;
-  double guard_s = std::min(ctx->max_wall_s, 10.0);                   // in-kernel give-up (100 MHz wall clock)
-  if (const char* e = getenv("MNAV_ASYNC_MAX_S")) guard_s = atof(e);
-  const unsigned long long limit_ticks = (unsigned long long)(guard_s * 1.0e8);
-  ctx->ms_chunks = 0.0;
-  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_async<2>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
-  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_async<4>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
-  else hipLaunchKernelGGL(k_plan_async<8>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  AsyncCtl h{};
-  HIPCHK(hipMemcpyAsync(&h, actl, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
-  ctx->stats.launches = 1;
-  if (getenv("MNAV_VERBOSE"))
-    fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, claim fails %u, idle passes %u\n", n, G, ctx->ms_chunks, h.abort, h.claim_fails, h.idle_passes);
-  if (h.abort == 3u || ctx->cancel.load(std::memory_order_relaxed)) return 1;   // :350-354
-  if (h.abort) { ctx->err = "asynchronous tile engine gave up (in-kernel wall-clock guard)"; return -1; }
-  if (h.done_plans != n) { ctx->err = "asynchronous tile engine left plans unfinished"; return -1; }
-  if (!ctx->lazy_paths) launch_finalize(ctx, n);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-  return 0;
-}
+#include "mnav_engines_host.h"
 
 #include "mnav_tb_host.h"
 

@@ -416,7 +416,7 @@ inline void materialize_host(const HostTopology& t, const float* edge_weights, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS tiles for the label-correcting SSSP engine (mnav.hip: k_tile_round).  Vertices are sorted
+// LDS tiles for the label-correcting SSSP engine (mnav_tiles.h: k_tile_round).  Vertices are sorted
 // along a Morton curve of their quantised positions and cut into chunks of <= tile_size
 // vertices.  A tile's local graph is PUSH oriented: local vertex x (owned vertices first, then
 // the halo = neighbours owned by other tiles) lists the local vertices y it can relax, with the

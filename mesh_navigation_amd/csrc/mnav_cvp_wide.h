@@ -5,7 +5,7 @@
 
 // ---------------------------------------------------------------------------------------------
 // Wide CVP step (batches): a wave takes 32 (first version: 64) work-list entries per round instead of 8.
-// The 8-lane replay (mnav.hip: group_eval_cvp) spends most of its instructions on in-group shuffles and serves 8 vertices per wave instruction.
+// The 8-lane replay (mnav_band.h: group_eval_cvp) spends most of its instructions on in-group shuffles and serves 8 vertices per wave instruction.
 // Here the evaluation is cut where its data dependence allows (mnav_eval.h: make_cvp_item / eval_cvp_items):
 //   phase A, one lane per incident FACE of the round's vertices (~192 faces = 3-4 passes of 64 lanes): fire event and float64
 //            candidate, neither depends on the vertex's own state -> a 48-byte item in LDS;
