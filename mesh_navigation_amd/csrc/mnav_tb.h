@@ -329,7 +329,63 @@ __device__ __forceinline__ unsigned long long tbq_sweep(MNAV_GLOBAL const uint32
   return any;
 }
 
+// The pipelined sweep (opt-in, MNAV_TB_PIPE=1 when the streams are built; NOT YET RUN ON HARDWARE).  In tbq_sweep the LDS reads of
+// block j + 1 are issued after block j's write (the compiler cannot know that they touch other rows), so every block pays a full
+// LDS round trip on top of its arithmetic.  Here the reads of block j + 1 are issued BEFORE block j is retired: the stream builder
+// guarantees that two adjacent blocks of a chunk never write the same row, and marks (d15, slot 1) the one source of block j + 1
+// that is the row block j writes -- that value is taken from block j's registers.  Every value a block sees is the value the
+// Gauss-Seidel sweep of tbq_sweep sees: same sweeps, same bits (oracle/tb_model.cpp emulates exactly this read order).  The pipeline
+// is drained at the end of every chunk (the descriptors of the next chunk are not there yet).
+__device__ __forceinline__ bool tb_retire_fwd(const TbBlk& B, uint32_t& written)
+{
+  const uint32_t acc0 = B.raw & 0x7fffffffu;
+  const uint32_t t0 = f2u(fabsf(u2f(B.v[0])) + u2f(B.w0.x)), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(B.w0.y));
+  const uint32_t t2 = f2u(fabsf(u2f(B.v[2])) + u2f(B.w0.z)), t3 = f2u(fabsf(u2f(B.v[3])) + u2f(B.w0.w));
+  const uint32_t t4 = f2u(fabsf(u2f(B.v[4])) + u2f(B.w1.x)), t5 = f2u(fabsf(u2f(B.v[5])) + u2f(B.w1.y));
+  const uint32_t t6 = f2u(fabsf(u2f(B.v[6])) + u2f(B.w1.z));
+  uint32_t acc = min(min(acc0, t0), t1);
+  acc = min(min(acc, t2), t3); acc = min(min(acc, t4), t5); acc = min(acc, t6);
+  const bool ch = acc < acc0;
+  written = ch ? (acc | kTbDirty) : B.raw;
+  tb::ldsw(B.ya, written);
+  return ch;
+}
+
 template <int T>
+__device__ __forceinline__ unsigned long long tbq_sweep_pipe(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t max_nch,
+                                                             uint32_t stage_q, uint32_t l16, uint32_t lane4)
+{
+  unsigned long long any = 0ull;
+  tb::QStream S; S.begin(stream, chunk_off, nch, stage_q, l16);
+  for (uint32_t c = 0; c < max_nch; ++c) {
+    u32x4 d[kTbBlocksPerChunk][4];
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(stage_q + 64 * j + 16 * q);
+    S.advance();
+    TbBlk B[kTbBlocksPerChunk];
+    auto issue = [&](int j) {
+      B[j].w0 = d[j][2]; B[j].w1 = d[j][3];
+      B[j].ya = d[j][0].x + lane4;
+      B[j].raw = tb::ldsr(B[j].ya);
+      B[j].v[0] = tb::ldsr(d[j][0].y + lane4); B[j].v[1] = tb::ldsr(d[j][0].z + lane4); B[j].v[2] = tb::ldsr(d[j][0].w + lane4);
+      B[j].v[3] = tb::ldsr(d[j][1].x + lane4); B[j].v[4] = tb::ldsr(d[j][1].y + lane4); B[j].v[5] = tb::ldsr(d[j][1].z + lane4);
+      B[j].v[6] = tb::ldsr(d[j][1].w + lane4);
+    };
+    issue(0);
+    uint32_t written = 0u;
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+      if (j + 1 < (int)kTbBlocksPerChunk) issue(j + 1);              // in flight while block j is retired
+      if (j > 0 && (B[j].w1.w & 1u)) B[j].v[0] = written;            // the marked source: the row block j - 1 has just written
+      any |= __ballot(tb_retire_fwd(B[j], written));
+    }
+  }
+  return any;
+}
+
+template <int T, bool PIPE>
 __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
 {
 #ifdef MNAV_TB_TIMING
@@ -443,7 +499,8 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
       uint32_t sweep = 0;
       for (;;) {
         const uint32_t off = W.sweep_off + ((sweep + first_order) & 3u) * W.sweep_chunks;
-        const unsigned long long any = tbq_sweep<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4);
+        const unsigned long long any = PIPE ? tbq_sweep_pipe<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4)
+                                            : tbq_sweep<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4);
         ++sweep;
         if (any == 0ull) break;
         if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
@@ -703,7 +760,7 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
 
 // host-side state of the engine (device arrays of the mesh-dependent streams, and of the running batch)
 struct TbState {
-  bool built = false, w_valid = false;
+  bool built = false, w_valid = false, pipe = false;   // pipe: streams with forward marks + the pipelined sweep (MNAV_TB_PIPE, opt-in)
   uint32_t T = 120, ntiles = 0, max_nh = 0;   // 120 rows x 256 B + staging = 31 232 B of LDS: five waves per CU (128 rows: four)
   uint64_t S = 0;                       // words per plan
   size_t nrec = 0, nexp = 0;

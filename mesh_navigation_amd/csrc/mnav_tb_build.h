@@ -139,7 +139,12 @@ inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k
 }
 }  // namespace detail
 
-inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
+// forward_marks (the pipelined sweep, k_tb_solve_q<T, true>: opt-in): a block whose sources include the row the PREVIOUS block of its
+// chunk writes gets that source moved to slot 1 and d15 = 1.  The pipelined sweep issues the LDS reads of block j + 1 before block
+// j's result is written and takes a marked source from block j's registers instead: the same Gauss-Seidel values, one LDS round
+// trip less on the critical path of every block.  (Two adjacent blocks of a chunk never write the same row: see below.)  The
+// ordinary sweep ignores slot order and d15.
+inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool forward_marks = false)
 {
   if (T == 0 || T > 255 || (T & 3)) throw std::invalid_argument("tile-batch engine: T must be a multiple of 4 below 256");
   HostTb H;
@@ -282,6 +287,21 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
       }
       H.stream.resize((size_t)W.sweep_off * kTbChunk); H.wsrc.resize((size_t)W.sweep_off * kTbChunk);
       H.stream.insert(H.stream.end(), st2.begin(), st2.end()); H.wsrc.insert(H.wsrc.end(), ws2.begin(), ws2.end());
+    }
+    if (forward_marks) {
+      for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c)
+        for (uint32_t j = 1; j < kTbBlocksPerChunk; ++j) {
+          uint32_t* K = &H.stream[c * kTbChunk + kTbBlock * j];
+          uint32_t* Ws = &H.wsrc[c * kTbChunk + kTbBlock * j];
+          const uint32_t prev = K[-(int)kTbBlock];                     // row the previous block of the chunk writes
+          if (K[0] == prev) throw std::logic_error("tile-batch streams: adjacent blocks of a chunk write the same row");
+          for (int q = 1; q <= 7; ++q)
+            if (K[q] == prev && Ws[7 + q] != kNone) {                  // a real edge from that row (unused slots hold the block's own row)
+              std::swap(K[q], K[1]); std::swap(K[7 + q], K[8]); std::swap(Ws[7 + q], Ws[8]);
+              K[15] = 1u;
+              break;
+            }
+        }
     }
     // which of the four sweep orders runs WITH a wave that enters through ghost gv: the one whose direction has the largest
     // component along (tile centroid - ghost position).  The solve starts its sweeps with the order most lanes ask for.

@@ -22,8 +22,10 @@ inline uint32_t fabs_bits_add(uint32_t v, uint32_t w) { return f2u(std::fabs(u2f
 
 extern "C" {
 
-// jacobi: 1 = every activation of an iteration sees the slices as they were when the iteration started (what concurrent
-// waves may see at worst), 0 = in place, in item order.
+// jacobi: bit 0: 1 = every activation of an iteration sees the slices as they were when the iteration started (what concurrent
+// waves may see at worst), 0 = in place, in item order.  bit 1: the PIPELINED sweep (tbq_sweep_pipe) on streams with forward
+// marks: the reads of block j + 1 of a chunk are issued before block j's write, the marked source comes from block j's registers;
+// stats_out[10] counts reads that would then see a value older than the Gauss-Seidel sweep's (the marks must make that zero).
 // stats_out: [0] iterations, [1] (tile, plan) activations, [2] sweeps summed over activations, [3] wake-ups, [4] max sweeps of
 // one item, [5] tiles, [6] slots per plan, [7] items (waves of <= 64 plans), [8] sweep blocks visited, [9] sweep blocks evaluated;
 // [2] counts sweeps per ITEM (the lanes of an item sweep in lockstep until no lane changes)
@@ -34,7 +36,9 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
-  HostTb H = build_tb(topo, xyz, T);
+  const bool pipe = (jacobi & 2) != 0, no_marks = (jacobi & 4) != 0;   // bit 2: the pipelined order on streams WITHOUT marks (what the marks are for)
+  jacobi &= 1;
+  HostTb H = build_tb(topo, xyz, T, pipe && !no_marks);
   for (size_t i = 0; i < H.stream.size(); ++i) if (H.wsrc[i] != kNone) H.stream[i] = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
   const uint32_t NP = n, nt = H.ntiles;
   auto slot = [&](uint32_t t, uint32_t p, uint32_t i) { return (size_t)H.tiles[t].soff * NP + (size_t)p * H.tiles[t].sl + i; };
@@ -51,7 +55,8 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     for (uint32_t k = 0; k < W.exp_n; ++k) { const TbExp& e = H.exps[W.exp_off + k]; if (e.u == loc * 256u) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off] = 0u; }
     pend[(size_t)t * NP + p] = 0u; marr[0][p] = 0u; cand[0].push_back({ t, p });
   }
-  uint64_t iters = 0, acts = 0, sweeps_tot = 0, wakes = 0, max_sweeps = 0, items = 0, blocks_total = 0, blocks_eval = 0;
+  uint64_t iters = 0, acts = 0, sweeps_tot = 0, wakes = 0, max_sweeps = 0, items = 0, blocks_total = 0, blocks_eval = 0, stale_reads = 0;
+  std::vector<uint32_t> prev_old(64, 0u);                          // pipelined sweep: what the previous block's row held before its write
   std::vector<std::vector<uint16_t>> bucket(nt);
   std::vector<std::vector<uint32_t>> ldsv(64, std::vector<uint32_t>(256));   // per lane: row -> value
   for (int par = 0;; par ^= 1) {
@@ -119,11 +124,24 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
               const uint32_t* K = C + kTbBlock * j;
               ++blocks_eval;
               const uint32_t y = K[0] / 256u;
+              const bool piped = pipe && j > 0;                      // the reads of this block were issued before block j - 1 wrote
+              const uint32_t py = piped ? K[-(int)kTbBlock] / 256u : kNone;
+              if (piped && y == py) return 62;                       // adjacent blocks of a chunk must not write the same row
+              if (pipe && (K[15] & 1u) && (j == 0 || K[1] / 256u != py)) return 63;   // a mark that does not name the previous block's row
               for (uint32_t l = 0; l < cnt_l; ++l) {
                 uint32_t* lds = ldsv[l].data();
                 const uint32_t acc0 = lds[y] & 0x7fffffffu;
                 uint32_t acc = acc0;
-                for (uint32_t k = 0; k < 7; ++k) acc = std::min(acc, fabs_bits_add(lds[K[1 + k] / 256u], K[8 + k]));
+                for (uint32_t k = 0; k < 7; ++k) {
+                  const uint32_t row = K[1 + k] / 256u;
+                  uint32_t v = lds[row];
+                  if (piped && row == py && !(k == 0 && (K[15] & 1u))) {   // not forwarded: the value from before block j - 1's write
+                    if (prev_old[l] != v && K[8 + k] != kTbInfBits) ++stale_reads;
+                    v = prev_old[l];
+                  }
+                  acc = std::min(acc, fabs_bits_add(v, K[8 + k]));
+                }
+                prev_old[l] = lds[y];
                 if (acc < acc0) { lds[y] = acc | kTbDirty; chg_cur |= 1u << (y * 32u / T); }
               }
             }
@@ -176,7 +194,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   }
   for (uint32_t p = 0; p < NP; ++p)
     for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(D[slot(H.vert_tile[v], p, H.vert_local[v])]);
-  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; stats_out[7] = items; stats_out[8] = blocks_total; stats_out[9] = blocks_eval; }
+  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; stats_out[7] = items; stats_out[8] = blocks_total; stats_out[9] = blocks_eval; stats_out[10] = stale_reads; }
   return 0;
 }
 

@@ -83,3 +83,31 @@ def test_punched_and_fan_meshes():
     for tile in (64, 128):                                          # the hub's rows need continuation blocks (7 sources per block)
         r = check(casef, [1, f.V - 1], [f.V - 2, 0], tile=tile)
         assert r["max_sweeps"] <= 40
+
+
+def test_pipelined_sweep_order_with_forward_marks_is_the_gauss_seidel_sweep():
+    """The opt-in pipelined sweep (mnav_tb.h tbq_sweep_pipe: the LDS reads of block j + 1 of a chunk are issued before block j's
+    write) on streams with forward marks (mnav_tb_build.h) sees exactly the values the plain sweep sees: same sweep counts, same
+    bits, no read older than the Gauss-Seidel order's.  Without the marks the same read order goes stale."""
+    case = terrain_case(128, 1)
+    m = case.mesh
+    rng = np.random.default_rng(3)
+    seeds = rng.choice(m.V, 6, replace=False)
+    targets = np.full(6, m.vertex_at(0.9, 0.9))
+    kw = dict(tile=120, jacobi=1)
+    plain = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, **kw)
+    piped = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, **kw)
+    assert plain["code"] == 0 and piped["code"] == 0
+    assert piped["stale_reads"] == 0
+    assert piped["sweeps"] == plain["sweeps"] and piped["iterations"] == plain["iterations"] and piped["wakes"] == plain["wakes"]
+    assert np.array_equal(piped["dist"].view(np.uint32), plain["dist"].view(np.uint32))
+    unmarked = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, forward_marks=False, **kw)
+    assert unmarked["code"] == 0 and unmarked["stale_reads"] > 0 and unmarked["sweeps"] > plain["sweeps"]
+    # a valence-40 hub (continuation blocks of one row) and the other checks of this file, through the pipelined order
+    f = meshgen.fan_field(spokes=40, rings=6, seed=1)
+    casef = Case(f)
+    for tile in (64, 128):
+        a = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile)
+        b = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile, pipelined=True)
+        assert b["code"] == 0 and b["stale_reads"] == 0 and b["sweeps"] == a["sweeps"]
+        assert np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
