@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
   uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
 
   const unsigned long long t_begin = wall_clock64();
-  uint32_t home = blockIdx.x % n, idle = 0, iter = 0;
+  uint32_t home = blockIdx.x % n, idle = 0, iter = 0, passes = 0;
   uint32_t my_fails = 0, my_idle = 0;
   for (;;) {
     // ---- leave?  (thread 0 decides, the workgroup follows) and which plans of the window [home, home + 64) still run
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
         else if (aq::ld(&actl->done_plans) >= n) f = 1u;
         else if (plans[0].cancel && aq::ld(plans[0].cancel)) { aq::st(&actl->abort, 3u); f = 1u; }          // mnav_cancel, dijkstra :287
         else if (wall_clock64() - t_begin > limit_ticks) { aq::st(&actl->abort, 2u); f = 1u; }
+        else if (++passes > 20000000u) { aq::st(&actl->abort, 4u); f = 1u; }                       // second guard, should the clock not tick
         s_flag = f; s_live = mask;
       }
     }
