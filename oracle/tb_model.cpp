@@ -1,8 +1,8 @@
 // tb_model.cpp -- CPU model of the tile-batch SSSP engine (mesh_navigation_amd/csrc/mnav_tb.h).
 //
 // TEST INFRASTRUCTURE ONLY (lives under oracle/): it interprets the very same record streams the HIP kernel reads
-// (mnav_tb_build.h), lane by lane, and runs the same level-synchronous schedule (k_tb_plan / k_tb_filter / k_tb_items /
-// k_tb_solve) serially on the host, so that tests without a GPU can check the stream builder and the schedule against
+// (mnav_tb_build.h), lane by lane, and runs the same level-synchronous schedule (k_tb_plan / k_tb_scan / k_tb_items /
+// k_tb_solve_q) serially on the host, so that tests without a GPU can check the stream builder and the schedule against
 // the sequential oracle (mnav_oracle.c).  Never linked into, loaded by, or reachable from the product library.
 #include <algorithm>
 #include <cmath>
@@ -73,7 +73,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
       float th = m + band; if (!(th > m)) th = next_up(m);
       thr[p] = done ? 0.0f : th; bnd[p] = bound;
     }
-    // k_tb_filter
+    // k_tb_scan
     cand[par ^ 1].clear();
     for (auto& e : cand[par]) {
       const size_t pi = (size_t)e.first * NP + e.second;
@@ -84,7 +84,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     }
     if (jacobi) Dsnap = D;
     const std::vector<uint32_t>& Din = jacobi ? Dsnap : D;
-    // k_tb_items + k_tb_solve: items of <= 64 plans of one tile, one plan per lane, the lanes in lockstep
+    // k_tb_items + k_tb_solve_q: items (here of <= 64 plans; the kernel cuts them into quarters of 16, same values) of one tile, one plan per lane, the lanes in lockstep
     for (uint32_t t = 0; t < nt; ++t) {
       const TbTile& W = H.tiles[t];
       for (size_t start = 0; start < bucket[t].size(); start += 64) {

@@ -1,5 +1,5 @@
 """CPU: the tile-batch SSSP engine's streams and schedule (mesh_navigation_amd/csrc/mnav_tb_build.h, interpreted by
-oracle/tb_model.cpp exactly as k_tb_solve reads them) against the sequential oracle (dijkstra_mesh_planner.cpp:287-348).
+oracle/tb_model.cpp exactly as k_tb_solve_q reads them) against the sequential oracle (dijkstra_mesh_planner.cpp:287-348).
 
 What the engine promises (and the lazy path walk / the finalize pass rely on): every vertex the reference POPS --
 dist <= goal_dist = dist[target] + goal_dist_offset -- holds the reference's float32 potential bit for bit."""
