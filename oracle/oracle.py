@@ -465,6 +465,20 @@ def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
                 abort=int(stats[8]), putbacks=int(stats[9]), bands_raised=int(stats[10]), tiles=int(stats[11]))
 
 
+def product_expanded_sources(dist, target: int, offset: float):
+    """mnav_eval.h goal_cut / expanded_source (the device's finalize pass, path walks and lazy vector entries) on a FINAL potential:
+    (mask of expanded sources, reported goal_dist, cut value)."""
+    d = _f32(dist)
+    ids = np.arange(d.shape[0], dtype=np.uint32)
+    out = np.zeros(d.shape[0], np.uint8)
+    gct = np.zeros(3, np.float32)
+    L = model_lib()
+    L.sm_expanded_sources.restype = None
+    L.sm_expanded_sources.argtypes = [C.c_float, C.c_double, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sm_expanded_sources(float(d[target]), float(offset), int(target), d.shape[0], _p(d), _p(ids), _p(out), _p(gct))
+    return out.astype(bool), float(gct[0]), float(gct[1])
+
+
 def product_acosf(x) -> float:
     """mnav_eval.h acosf_ref: the device's restatement of the host libm's acosf (SteepnessLayer)."""
     return float(model_lib().sm_acosf_ref(float(x)))

@@ -357,6 +357,15 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
 // vertex, or NaN when it is not finite; *requeue = the :311 condition
 // mnav_eval.h acosf_ref (the device's SteepnessLayer arithmetic) for the host-side check against libm
 float sm_acosf_ref(float x) { return acosf_ref(x); }
+// mnav_eval.h goal_cut / expanded_source: which sources the Dijkstra wave expands, as the finalize pass, the lazy path walks and
+// the lazy vector entries of the device decide it (incl. negative goal_dist_offset); out[i] = 1 when vertex ids[i] with FINAL
+// value d[i] is an expanded source of a plan whose robot vertex `target` has the final value dt
+void sm_expanded_sources(float dt, double offset, uint32_t target, uint32_t n, const float* d, const uint32_t* ids, uint8_t* out, float* goal_cut_tie)
+{
+  const GoalCut g = goal_cut(dt, offset, target);
+  for (uint32_t i = 0; i < n; ++i) out[i] = expanded_source(g, d[i], ids[i]) ? 1 : 0;
+  if (goal_cut_tie) { goal_cut_tie[0] = g.goal; goal_cut_tie[1] = g.cut; goal_cut_tie[2] = (g.tie == kNone) ? -1.0f : (float)g.tie; }
+}
 float sm_cosf_ref(float x) { return cosf_ref(x); }
 float sm_sinf_ref(float x) { return sinf_ref(x); }
 
