@@ -385,7 +385,62 @@ __device__ __forceinline__ unsigned long long tbq_sweep_pipe(MNAV_GLOBAL const u
   return any;
 }
 
-template <int T, bool PIPE>
+// Level 2 of the same idea (MNAV_TB_PIPE=2, streams with cross-chunk forward marks): the pipeline is NOT drained at the chunk ends.
+// The descriptors of chunk c + 1 sit in a second register set while chunk c is retired (the kernel's occupancy is bound by its LDS
+// image, not by registers), block 0 of chunk c + 1 is issued while block 3 of chunk c retires, and its marked source comes from that
+// block's registers -- unless this quarter is past the end of its own stream and re-runs its last chunk (then block 0 follows the
+// SAME chunk's block 3: no forwarding; the builder makes those two write different rows, and a relaxation re-applied to values that
+// are at most one write old changes nothing).
+template <int T>
+__device__ __forceinline__ unsigned long long tbq_sweep_pipe2(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t max_nch,
+                                                              uint32_t stage_q, uint32_t l16, uint32_t lane4)
+{
+  unsigned long long any = 0ull;
+  tb::QStream S; S.begin(stream, chunk_off, nch, stage_q, l16);
+  u32x4 da[kTbBlocksPerChunk][4], db[kTbBlocksPerChunk][4];
+  auto read_desc = [&](u32x4 (&d)[kTbBlocksPerChunk][4]) {
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(stage_q + 64 * j + 16 * q);
+  };
+  auto issue = [&](TbBlk& B, const u32x4 (&d)[kTbBlocksPerChunk][4], int j) {
+    B.w0 = d[j][2]; B.w1 = d[j][3];
+    B.ya = d[j][0].x + lane4;
+    B.raw = tb::ldsr(B.ya);
+    B.v[0] = tb::ldsr(d[j][0].y + lane4); B.v[1] = tb::ldsr(d[j][0].z + lane4); B.v[2] = tb::ldsr(d[j][0].w + lane4);
+    B.v[3] = tb::ldsr(d[j][1].x + lane4); B.v[4] = tb::ldsr(d[j][1].y + lane4); B.v[5] = tb::ldsr(d[j][1].z + lane4);
+    B.v[6] = tb::ldsr(d[j][1].w + lane4);
+  };
+  uint32_t written = 0u;
+  TbBlk carry;                                                       // block 0 of the chunk that is processed next, already issued
+  // one chunk: `d` its descriptors, `dn` those of the next chunk (valid when has_next); c = its index in the longest stream
+  auto chunk = [&](const u32x4 (&d)[kTbBlocksPerChunk][4], const u32x4 (&dn)[kTbBlocksPerChunk][4], bool has_next, uint32_t c) {
+    TbBlk B[kTbBlocksPerChunk];
+    B[0] = carry;
+    const bool fwd0 = c > 0u && c < nch;                            // block 0 follows the PREVIOUS chunk's block 3 (not a re-run of this quarter's last chunk)
+#pragma unroll
+    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
+      if (j + 1 < (int)kTbBlocksPerChunk) issue(B[j + 1], d, j + 1);
+      else if (has_next) issue(carry, dn, 0);
+      if ((B[j].w1.w & 1u) && (j > 0 || fwd0)) B[j].v[0] = written;
+      any |= __ballot(tb_retire_fwd(B[j], written));
+    }
+  };
+  read_desc(da); S.advance();                                       // staging now holds chunk 1
+  if (max_nch > 1u) { read_desc(db); S.advance(); }                  // ... chunk 2
+  issue(carry, da, 0);
+  for (uint32_t c = 0; c < max_nch; c += 2u) {
+    chunk(da, db, c + 1u < max_nch, c);
+    if (c + 1u >= max_nch) break;
+    if (c + 2u < max_nch) { read_desc(da); S.advance(); }            // chunk c + 2 (its block 0 is issued at the end of chunk c + 1)
+    chunk(db, da, c + 2u < max_nch, c + 1u);
+    if (c + 3u < max_nch) { read_desc(db); S.advance(); }
+  }
+  return any;
+}
+
+template <int T, int PIPE>
 __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
 {
 #ifdef MNAV_TB_TIMING
@@ -499,8 +554,9 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
       uint32_t sweep = 0;
       for (;;) {
         const uint32_t off = W.sweep_off + ((sweep + first_order) & 3u) * W.sweep_chunks;
-        const unsigned long long any = PIPE ? tbq_sweep_pipe<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4)
-                                            : tbq_sweep<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4);
+        const unsigned long long any = PIPE == 2 ? tbq_sweep_pipe2<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4)
+                                     : PIPE == 1 ? tbq_sweep_pipe<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4)
+                                                 : tbq_sweep<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4);
         ++sweep;
         if (any == 0ull) break;
         if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
@@ -760,7 +816,8 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
 
 // host-side state of the engine (device arrays of the mesh-dependent streams, and of the running batch)
 struct TbState {
-  bool built = false, w_valid = false, pipe = false;   // pipe: streams with forward marks + the pipelined sweep (MNAV_TB_PIPE, opt-in)
+  bool built = false, w_valid = false;
+  int pipe = 0;                         // streams with forward marks + the pipelined sweep (MNAV_TB_PIPE = 1: drained per chunk, 2: across chunks; opt-in)
   uint32_t T = 120, ntiles = 0, max_nh = 0;   // 120 rows x 256 B + staging = 31 232 B of LDS: five waves per CU (128 rows: four)
   uint64_t S = 0;                       // words per plan
   size_t nrec = 0, nexp = 0;

@@ -143,8 +143,11 @@ inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k
 // chunk writes gets that source moved to slot 1 and d15 = 1.  The pipelined sweep issues the LDS reads of block j + 1 before block
 // j's result is written and takes a marked source from block j's registers instead: the same Gauss-Seidel values, one LDS round
 // trip less on the critical path of every block.  (Two adjacent blocks of a chunk never write the same row: see below.)  The
-// ordinary sweep ignores slot order and d15.
-inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool forward_marks = false)
+// ordinary sweep ignores slot order and d15.  Level 2 extends both guarantees across the chunk boundaries of a sweep order (block 0 of
+// a chunk against block 3 of the chunk before it) for a pipeline that is not drained at the chunk ends, and makes the first and the
+// last block of every order's LAST chunk write different rows (a quarter of a wave whose stream is shorter than its neighbours'
+// re-runs its last chunk: its block 0 then follows its own block 3).
+inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, int forward_marks = 0)
 {
   if (T == 0 || T > 255 || (T & 3)) throw std::invalid_argument("tile-batch engine: T must be a multiple of 4 below 256");
   HostTb H;
@@ -198,9 +201,9 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool
   // Every sweep block rewrites its target row (with the bits it read when nothing improved); two ADJACENT blocks of a chunk
   // never have the same target, so that a kernel may have the reads of block j+1 in flight before block j's result is
   // written (tried and dropped: +24 % sweeps).  `last_target` = target row of the previous block of the open chunk.
-  uint32_t last_target = kNone;
+  uint32_t last_target = kNone, chunk_first = kNone;                 // chunk_first: the row block 0 of the open chunk writes
   auto open_block = [&]() -> size_t {                                // returns the dword index of the new block
-    if (in_chunk == kTbBlocksPerChunk) { in_chunk = 0; last_target = kNone; }
+    if (in_chunk == kTbBlocksPerChunk) { in_chunk = 0; chunk_first = kNone; if (forward_marks < 2) last_target = kNone; }
     const size_t at = H.stream.size();
     H.stream.resize(at + kTbBlock, 0u); H.wsrc.resize(at + kTbBlock, kNone);
     ++in_chunk;
@@ -211,14 +214,18 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool
     for (int q = 8; q <= 14; ++q) H.stream[at + q] = kTbInfBits;
   };
   auto noop_sweep_block = [&]() {                                    // all weights +inf, on a row the previous block did not target
-    const uint32_t row = (last_target == 0u) ? 1u : 0u;
-    init_sweep_block(open_block(), row);
+    uint32_t row = (last_target == 0u) ? 1u : 0u;
+    // (level 2: a do-nothing block that closes a chunk must not write the row the chunk's first block writes either)
+    if (forward_marks >= 2 && in_chunk == kTbBlocksPerChunk - 1u) for (row = 0u; row == last_target || row == chunk_first; ++row) { }
+    const size_t at = open_block();
+    init_sweep_block(at, row);
+    if (in_chunk == 1u) chunk_first = row;
     last_target = row;
   };
   auto close_chunk = [&](bool sweep) {                               // pad the open chunk
     if (in_chunk == 0) return;
     while (in_chunk < kTbBlocksPerChunk) { if (sweep) noop_sweep_block(); else open_block(); }
-    in_chunk = 0; last_target = kNone;
+    in_chunk = 0; last_target = kNone; chunk_first = kNone;
   };
   std::vector<uint16_t> order;
   std::vector<uint32_t> ts;
@@ -253,8 +260,9 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool
           const uint32_t u = t.nbr_u[k];
           if (H.vert_tile[u] != tl) continue;
           if (n == 0) {
-            if (in_chunk != kTbBlocksPerChunk && in_chunk != 0 && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
+            if ((forward_marks >= 2 || (in_chunk != kTbBlocksPerChunk && in_chunk != 0)) && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
             at = open_block();
+            if (in_chunk == 1u) chunk_first = y;
             last_target = y;
             init_sweep_block(at, y);
           }
@@ -277,11 +285,14 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool
         st2.insert(st2.end(), H.stream.begin() + src, H.stream.begin() + src + len);
         ws2.insert(ws2.end(), H.wsrc.begin() + src, H.wsrc.begin() + src + len);
         src += len;
+        // (level 2: the first do-nothing block must not write the row the block before it writes)
+        uint32_t flip = 0u;
+        if (forward_marks >= 2 && order_chunks[o] > 0 && order_chunks[o] < W.sweep_chunks && st2[st2.size() - kTbBlock] == 0u) flip = 1u;
         for (uint32_t c = order_chunks[o]; c < W.sweep_chunks; ++c)
           for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
             const size_t at = st2.size();
             st2.resize(at + kTbBlock, 0u); ws2.resize(at + kTbBlock, kNone);
-            for (int q = 0; q <= 7; ++q) st2[at + q] = (j & 1u) * kRow;
+            for (int q = 0; q <= 7; ++q) st2[at + q] = ((j & 1u) ^ flip) * kRow;
             for (int q = 8; q <= 14; ++q) st2[at + q] = kTbInfBits;
           }
       }
@@ -289,8 +300,12 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool
       H.stream.insert(H.stream.end(), st2.begin(), st2.end()); H.wsrc.insert(H.wsrc.end(), ws2.begin(), ws2.end());
     }
     if (forward_marks) {
-      for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c)
-        for (uint32_t j = 1; j < kTbBlocksPerChunk; ++j) {
+      for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c) {
+        const bool first_of_order = ((c - W.sweep_off) % std::max(W.sweep_chunks, 1u)) == 0;
+        if (forward_marks >= 2 && ((c - W.sweep_off) % std::max(W.sweep_chunks, 1u)) == W.sweep_chunks - 1u &&
+            H.stream[c * kTbChunk] == H.stream[c * kTbChunk + 3 * kTbBlock])
+          throw std::logic_error("tile-batch streams: the last chunk of a sweep order starts and ends on the same row");
+        for (uint32_t j = (forward_marks >= 2 && !first_of_order) ? 0u : 1u; j < kTbBlocksPerChunk; ++j) {
           uint32_t* K = &H.stream[c * kTbChunk + kTbBlock * j];
           uint32_t* Ws = &H.wsrc[c * kTbChunk + kTbBlock * j];
           const uint32_t prev = K[-(int)kTbBlock];                     // row the previous block of the chunk writes
@@ -302,6 +317,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, bool
               break;
             }
         }
+      }
     }
     // which of the four sweep orders runs WITH a wave that enters through ghost gv: the one whose direction has the largest
     // component along (tile centroid - ghost position).  The solve starts its sweeps with the order most lanes ask for.

@@ -40,7 +40,7 @@ int tb_build(mnav_ctx* ctx)
   t.V = ctx->V; t.E = ctx->E; t.F = ctx->F;
   t.row_ptr = ctx->h_row_ptr; t.nbr_u = ctx->h_nbr_u;
   HostTb H;
-  S.pipe = getenv("MNAV_TB_PIPE") != nullptr && atoi(getenv("MNAV_TB_PIPE")) != 0;   // opt-in experiment (mnav_tb.h: tbq_sweep_pipe)
+  S.pipe = getenv("MNAV_TB_PIPE") ? std::min(std::max(atoi(getenv("MNAV_TB_PIPE")), 0), 2) : 0;   // opt-in experiments (mnav_tb.h: tbq_sweep_pipe / _pipe2)
   try { H = build_tb(t, ctx->h_xyz.data(), S.T, S.pipe); }
   catch (const std::exception& ex) { ctx->err = ex.what(); return -1; }
   std::vector<uint2> vaddr(ctx->V);
@@ -121,16 +121,22 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_scan, dim3(gp, (A.ntiles + kTbScanTiles - 1) / kTbScanTiles), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
-    if (ctx->tb.pipe) {                                              // the pipelined sweep on streams with forward marks (opt-in)
-      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, true>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, true>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, true>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else hipLaunchKernelGGL((k_tb_solve_q<128, true>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    } else
-    if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, false>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, false>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, false>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    else hipLaunchKernelGGL((k_tb_solve_q<128, false>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    if (ctx->tb.pipe == 2) {                                         // the pipelined sweeps on streams with forward marks (opt-in)
+      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else hipLaunchKernelGGL((k_tb_solve_q<128, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    } else if (ctx->tb.pipe == 1) {
+      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else hipLaunchKernelGGL((k_tb_solve_q<128, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    } else {
+      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+      else hipLaunchKernelGGL((k_tb_solve_q<128, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;

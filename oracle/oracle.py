@@ -419,7 +419,7 @@ def model_lib():
 
 
 def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targets, offset=0.3, cost_limit=1.0, tile=128,
-                     band=None, jacobi=1, invalid=None, pipelined=False, forward_marks=True):
+                     band=None, jacobi=1, invalid=None, pipelined=False, forward_marks=True, across_chunks=False, rerun_last_chunk=0):
     """The tile-batch SSSP engine (mnav_tb.h) on the CPU model (oracle/tb_model.cpp): potentials of a batch of plans."""
     faces, edges = _u32(faces), _u32(edges)
     w, vc, pos = _f32(edge_weights), _f32(vertex_costs), _f32(xyz)
@@ -433,7 +433,8 @@ def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
     dist = np.empty((n, V), np.float32)
     stats = np.zeros(12, np.uint64)
     code = model_lib().tbm_run(V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(pos), int(tile), n, _p(sd), _p(tg),
-                               float(offset), float(cost_limit), float(band), int(jacobi) | (2 if pipelined else 0) | (0 if forward_marks else 4), _p(dist), _p(stats))
+                               float(offset), float(cost_limit), float(band), int(jacobi) | (2 if pipelined else 0) | (0 if forward_marks else 4) | (8 if across_chunks else 0) | ((int(rerun_last_chunk) & 15) << 4),
+                               _p(dist), _p(stats))
     return dict(code=code, dist=dist, iterations=int(stats[0]), activations=int(stats[1]), sweeps=int(stats[2]), wakes=int(stats[3]),
                 max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]), items=int(stats[7]),
                 blocks_total=int(stats[8]), blocks_evaluated=int(stats[9]), stale_reads=int(stats[10]))

@@ -37,8 +37,12 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
   const bool pipe = (jacobi & 2) != 0, no_marks = (jacobi & 4) != 0;   // bit 2: the pipelined order on streams WITHOUT marks (what the marks are for)
+  const bool cross = pipe && (jacobi & 8) != 0;                       // bit 3: the pipeline is not drained at the chunk ends (tbq_sweep_pipe2)
+  const uint32_t rerun = (uint32_t)((jacobi >> 4) & 15);              // bits 4-7: every sweep re-runs its last chunk that many times (a quarter whose stream is shorter than its wave's)
   jacobi &= 1;
-  HostTb H = build_tb(topo, xyz, T, pipe && !no_marks);
+  HostTb H;
+  try { H = build_tb(topo, xyz, T, (pipe && !no_marks) ? (cross ? 2 : 1) : 0); }
+  catch (const std::exception& ex) { fprintf(stderr, "tbm_run: %s\n", ex.what()); return 64; }
   for (size_t i = 0; i < H.stream.size(); ++i) if (H.wsrc[i] != kNone) H.stream[i] = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
   const uint32_t NP = n, nt = H.ntiles;
   auto slot = [&](uint32_t t, uint32_t p, uint32_t i) { return (size_t)H.tiles[t].soff * NP + (size_t)p * H.tiles[t].sl + i; };
@@ -117,17 +121,22 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
         for (;;) {
           const uint32_t* B = &H.stream[((size_t)W.sweep_off + (size_t)(sweep & 3u) * W.sweep_chunks) * kTbChunk];
           uint32_t chg_cur = 0;
-          for (uint32_t c = 0; c < W.sweep_chunks; ++c) {
+          for (uint32_t cc = 0; cc < W.sweep_chunks + (W.sweep_chunks ? rerun : 0u); ++cc) {
+            const uint32_t c = std::min(cc, W.sweep_chunks - 1u);
+            const bool again = cc >= W.sweep_chunks;                     // a re-run of the last chunk
             const uint32_t* C = B + (size_t)c * kTbChunk;
             blocks_total += kTbBlocksPerChunk;
             for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
               const uint32_t* K = C + kTbBlock * j;
               ++blocks_eval;
               const uint32_t y = K[0] / 256u;
-              const bool piped = pipe && j > 0;                      // the reads of this block were issued before block j - 1 wrote
-              const uint32_t py = piped ? K[-(int)kTbBlock] / 256u : kNone;
+              // the reads of this block were issued before the previous block wrote: block j - 1 of the chunk, or (not drained at
+              // the chunk ends) block 3 of the chunk before -- in a re-run that is this chunk's own block 3, and nothing is forwarded
+              const bool piped = pipe && (j > 0 || (cross && cc > 0));
+              const bool fwd_ok = j > 0 || !again;
+              const uint32_t py = !piped ? kNone : (j == 0 && again) ? C[kTbBlock * 3] / 256u : K[-(int)kTbBlock] / 256u;
               if (piped && y == py) return 62;                       // adjacent blocks of a chunk must not write the same row
-              if (pipe && (K[15] & 1u) && (j == 0 || K[1] / 256u != py)) return 63;   // a mark that does not name the previous block's row
+              if (pipe && (K[15] & 1u) && fwd_ok && (!piped || K[1] / 256u != py)) return 63;   // a mark that does not name the previous block's row
               for (uint32_t l = 0; l < cnt_l; ++l) {
                 uint32_t* lds = ldsv[l].data();
                 const uint32_t acc0 = lds[y] & 0x7fffffffu;
@@ -135,8 +144,8 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
                 for (uint32_t k = 0; k < 7; ++k) {
                   const uint32_t row = K[1 + k] / 256u;
                   uint32_t v = lds[row];
-                  if (piped && row == py && !(k == 0 && (K[15] & 1u))) {   // not forwarded: the value from before block j - 1's write
-                    if (prev_old[l] != v && K[8 + k] != kTbInfBits) ++stale_reads;
+                  if (piped && row == py && !(k == 0 && (K[15] & 1u) && fwd_ok)) {   // not forwarded: the value from before the previous block's write
+                    if (prev_old[l] != v && K[8 + k] != kTbInfBits && !again) ++stale_reads;
                     v = prev_old[l];
                   }
                   acc = std::min(acc, fabs_bits_add(v, K[8 + k]));

@@ -101,6 +101,15 @@ def test_pipelined_sweep_order_with_forward_marks_is_the_gauss_seidel_sweep():
     assert piped["stale_reads"] == 0
     assert piped["sweeps"] == plain["sweeps"] and piped["iterations"] == plain["iterations"] and piped["wakes"] == plain["wakes"]
     assert np.array_equal(piped["dist"].view(np.uint32), plain["dist"].view(np.uint32))
+    # level 2 (tbq_sweep_pipe2): not drained at the chunk ends; and the same with every sweep re-running its last chunk twice -- what a
+    # quarter of a wave does whose stream is shorter than its neighbours' (block 0 then follows its own chunk's block 3, unforwarded)
+    across = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, across_chunks=True, **kw)
+    assert across["code"] == 0 and across["stale_reads"] == 0 and across["sweeps"] == plain["sweeps"]
+    assert np.array_equal(across["dist"].view(np.uint32), plain["dist"].view(np.uint32))
+    rerun = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, across_chunks=True,
+                               rerun_last_chunk=2, **kw)
+    assert rerun["code"] == 0 and rerun["sweeps"] <= plain["sweeps"]
+    assert np.array_equal(rerun["dist"].view(np.uint32), plain["dist"].view(np.uint32))
     unmarked = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, forward_marks=False, **kw)
     assert unmarked["code"] == 0 and unmarked["stale_reads"] > 0 and unmarked["sweeps"] > plain["sweeps"]
     # a valence-40 hub (continuation blocks of one row) and the other checks of this file, through the pipelined order
@@ -111,3 +120,7 @@ def test_pipelined_sweep_order_with_forward_marks_is_the_gauss_seidel_sweep():
         b = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile, pipelined=True)
         assert b["code"] == 0 and b["stale_reads"] == 0 and b["sweeps"] == a["sweeps"]
         assert np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
+        c = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile, pipelined=True,
+                               across_chunks=True, rerun_last_chunk=3)
+        assert c["code"] == 0 and c["stale_reads"] == 0 and c["sweeps"] <= a["sweeps"]
+        assert np.array_equal(a["dist"].view(np.uint32), c["dist"].view(np.uint32))

@@ -1,5 +1,5 @@
-"""A/B of the pipelined sweep of the tile-batch engine (MNAV_TB_PIPE=1: streams with forward marks + k_tb_solve_q<T, true>, mnav_tb.h)
-against the plain sweep, in one process: two contexts on the same mesh, the same batch through both, paths compared, engine-run time
+"""A/B of the pipelined sweeps of the tile-batch engine (MNAV_TB_PIPE=1 / 2: streams with forward marks + k_tb_solve_q<T, 1 / 2>, mnav_tb.h)
+against the plain sweep, in one process: three contexts on the same mesh, the same batch through both, paths compared, engine-run time
 and roofline fraction printed.  The pipelined variant was written after round 4's GPU minutes were spent: this is its first run.
 
     timeout 600 python tools/gpu_tb_pipe_ab.py [grid=1000] [batch=7168] [reps=3]
@@ -25,7 +25,7 @@ def main():
     goals = np.random.default_rng(5).choice(mesh.V, size=B, replace=False).astype(np.uint32)
     targets = np.full(B, robot, np.uint32)
     out, sigs = {}, {}
-    for label, env in (("plain", "0"), ("pipelined", "1")):
+    for label, env in (("plain", "0"), ("pipelined", "1"), ("pipelined_across_chunks", "2")):
         os.environ["MNAV_TB_PIPE"] = env                                 # read when the context builds its streams (first batch)
         ctx = capi.MnavContext(0)
         ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
@@ -46,8 +46,9 @@ def main():
         sigs[label] = (int(lens.sum()), [int(np.asarray(p, np.uint64).sum()) for p in b["paths"][:512]])
         out[label] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in best.items()}
         del ctx
-    out["paths_identical"] = sigs["plain"] == sigs["pipelined"]
+    out["paths_identical"] = sigs["plain"] == sigs["pipelined"] == sigs["pipelined_across_chunks"]
     out["speedup_engine"] = round(out["plain"]["engine_ms"] / out["pipelined"]["engine_ms"], 3)
+    out["speedup_engine_across_chunks"] = round(out["plain"]["engine_ms"] / out["pipelined_across_chunks"]["engine_ms"], 3)
     print(json.dumps(dict(grid=N, batch=B, **out)))
 
 
