@@ -279,15 +279,24 @@ int mnav_get_timing(const mnav_ctx* ctx, mnav_stats* out);
  * (3 x mean finite edge weight for the Dijkstra band steps, 12 x for CVP, recomputed on every cost
  * upload).  Results do not depend on it. */
 int mnav_set_band_width(mnav_ctx* ctx, float delta);
-/* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round,
- * lowest latency for a single plan), 1 = the distance-band gather steps that the CVP planner uses,
- * 2 = persistent per-plan workgroups walking the tiles best-first (medium batches),
- * 3 = automatic (default: 5 for batches of >= 48 plans that also hold >= tiles/1000 plans, else 0; 2 only on request),
- * 5 = tile-batch: one wave per (tile, up to 64 plans), one plan per lane, the tile's graph as scalar data
- * (highest throughput for large batches; paths-only calls),
- * 6 = the LDS tiles without rounds: resident workgroups claim, solve and wake tiles asynchronously, one launch per call
- * (single plans and small batches; opt-in, never chosen by 3).  All give identical results. */
+/* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round),
+ * 1 = the distance-band gather steps that the CVP planner uses,
+ * 2 = persistent per-plan workgroups walking the tiles best-first (on request only),
+ * 3 = automatic (default): 5 for batches of >= 48 plans that also hold >= tiles/1000 plans, 6 for smaller calls (up to
+ *     option async_max_batch = 47 plans; a call whose ticket ring overflows is re-run on 0), else 0,
+ * 5 = tile-batch: one plan per lane, 16 plans per quarter of a wave, the tile's graph as record streams
+ *     (highest throughput for large batches),
+ * 6 = the LDS tiles without rounds: resident workgroups serve a ticket queue of woken tiles, solve and wake tiles
+ *     asynchronously, one launch per call (single plans -- what MeshPlanner::makePlan runs -- and small batches).
+ * All give identical results (the label-correcting fixed point does not depend on the schedule). */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
+/* Tuning / debug options by name (the list with one line each: mesh_navigation_amd/csrc/mnav_options.h; e.g. "cvp_wide",
+ * "cvp_groups", "no_graph", "lazy_paths", "max_wall_s", "async_wg_per_plan").  mnav_create reads the process environment ONCE
+ * (MNAV_<NAME>); afterwards this call is the only way to change an option -- no plan path ever looks at the environment.
+ * value = NaN restores the built-in default.  Options read at upload time ("tile_size", "tb_tile") act on the next
+ * mnav_upload_mesh.  Returns 0, or -1 for an unknown name; mnav_get_option returns NaN for unset / unknown. */
+int mnav_set_option(mnav_ctx* ctx, const char* name, double value);
+double mnav_get_option(const mnav_ctx* ctx, const char* name);
 /* Outputs that stay on the device.  mnav_set_resident_outputs(ctx, 1): every plan also computes its vector map
  * (computeVectorMap, dijkstra :189-209 / cvp :204-239) and leaves it in HBM even when no host buffer is passed.
  * mnav_download_output copies one V-sized output of plan `slot` to the host on demand (what as below; 12 B/vertex for

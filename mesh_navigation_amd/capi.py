@@ -27,6 +27,7 @@ SYMBOLS = [
     "mnav_shard_finalize", "mnav_update_costs", "mnav_update_edge_weights", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
+    "mnav_set_option", "mnav_get_option",
 ]
 
 
@@ -108,6 +109,10 @@ def load(path: str | None = None):
     L.mnav_set_band_width.argtypes = [vp, C.c_float]
     L.mnav_set_dijkstra_engine.restype = C.c_int
     L.mnav_set_dijkstra_engine.argtypes = [vp, C.c_int]
+    L.mnav_set_option.restype = C.c_int
+    L.mnav_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    L.mnav_get_option.restype = C.c_double
+    L.mnav_get_option.argtypes = [vp, C.c_char_p]
     L.mnav_device_output.restype = vp
     L.mnav_device_output.argtypes = [vp, u32, C.c_int]
     L.mnav_set_resident_outputs.restype = C.c_int
@@ -286,9 +291,19 @@ class MnavContext:
 
     def set_dijkstra_engine(self, engine: str):
         """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan), 'tile_batch' (large batches: one plan per lane)
-        or 'async' (the tiles without rounds, mnav_async.h: opt-in, never chosen by 'auto')."""
+        or 'async' (the tiles without rounds, mnav_async.h: what 'auto' takes for single plans and small batches)."""
         if self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "tile_batch": 5, "async": 6}[engine]) != 0:
             raise ValueError(f"engine {engine!r} refused")
+
+    def set_option(self, name: str, value=None):
+        """Tuning / debug option by name (csrc/mnav_options.h); None restores the built-in default.  The library reads the
+        environment once, in mnav_create: after that this is the only way to change an option."""
+        if self._L.mnav_set_option(self._h, name.encode(), float("nan") if value is None else float(value)) != 0:
+            raise ValueError(f"mnav_set_option: {self._err()}")
+
+    def get_option(self, name: str):
+        v = self._L.mnav_get_option(self._h, name.encode())
+        return None if v != v else v
 
     def set_resident_outputs(self, on: bool = True):
         self._L.mnav_set_resident_outputs(self._h, 1 if on else 0)

@@ -36,6 +36,7 @@
 #include "../../include/mnav.h"
 #include "mnav_build.h"
 #include "mnav_eval.h"
+#include "mnav_options.h"
 
 using namespace mnav;
 
@@ -212,6 +213,9 @@ struct mnav_ctx {
   uint32_t wide_groups = 1; hipStream_t stream_g[kWideGroupsMax] = {}; hipEvent_t ev_fork[kWideGroupsMax] = {};   // CVP batches in groups on their own streams ([0] unused / fork event)
   uint32_t cvp_wide_min_batch = 32;                                  // CVP batches of at least this many plans run k_step_wide
   float delta_user = 0.f, delta_auto = 0.f;
+  Options opt;                                                       // mnav_options.h: read from the environment once, by mnav_create
+  uint32_t max_steps_auto = 1u << 20;
+  uint32_t* d_ring = nullptr; uint32_t ring_cap = 0, ring_used = 0; struct AsyncCtl* h_actl = nullptr;   // asynchronous tile engine: ticket ring, pinned copy of its control words
   uint32_t last_planner = 0, last_n = 0;
   std::vector<uint32_t> last_target; double last_offset = 0.0;   // Dijkstra: robot vertex per device slot, goal_dist_offset of the last call
   mnav_stats stats{};
@@ -225,7 +229,7 @@ struct mnav_ctx {
 
 namespace {
 
-#define MTRACE(msg) do { if (getenv("MNAV_TRACE")) { fprintf(stderr, "[mnav] %9.3f ms %s:%d %s\n", 1e-3 * (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(), __func__, __LINE__, msg); fflush(stderr); } } while (0)
+#define MTRACE(msg) do { if (opt_on(ctx->opt.trace)) { fprintf(stderr, "[mnav] %9.3f ms %s:%d %s\n", 1e-3 * (double)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(), __func__, __LINE__, msg); fflush(stderr); } } while (0)
 #define HIPCHK(call)                                                                               \
   do {                                                                                             \
     hipError_t e_ = (call);                                                                        \
@@ -287,6 +291,23 @@ void drop_graphs(mnav_ctx* ctx)
   ctx->graphs.clear();
   for (auto& kv : ctx->shard.graphs) (void)hipGraphExecDestroy(kv.second);
   ctx->shard.graphs.clear();
+}
+
+// the options that are mirrored in context fields (everything else is read from ctx->opt where it is used)
+void apply_options(mnav_ctx* ctx)
+{
+  const Options& o = ctx->opt;
+  ctx->use_graph = !opt_on(o.no_graph);
+  if (opt_set(o.dijkstra_engine)) { const int e = (int)o.dijkstra_engine; ctx->dij_engine = (e == 0 || e == 1 || e == 2 || e == 5 || e == 6) ? e : 3; }
+  ctx->persistent_min_batch = opt_u32(o.persistent_min_batch, 128u);
+  ctx->max_steps = opt_u32(o.max_steps, ctx->max_steps_auto);
+  ctx->max_wall_s = opt_set(o.max_wall_s) ? o.max_wall_s : 120.0;
+  ctx->cvp_verify = !opt_set(o.cvp_verify) || o.cvp_verify != 0.0;
+  ctx->walk_max = opt_set(o.key_walk_max) ? (int)o.key_walk_max : kKeyWalkMax;
+  ctx->descend_max = opt_set(o.descend_walk_max) ? (int)o.descend_walk_max : kDescendWalkMax;
+  ctx->allow_lazy_paths = !opt_set(o.lazy_paths) || o.lazy_paths != 0.0;
+  ctx->tile_band_user = opt_set(o.tile_band) ? (float)o.tile_band : 0.f;
+  ctx->rounds_band_mult = opt_set(o.rounds_band_mult) ? (float)o.rounds_band_mult : 4.0f;
 }
 
 int ensure_plan_tables(mnav_ctx* ctx, uint32_t n);
@@ -380,7 +401,7 @@ uint32_t blocks_per_plan(const mnav_ctx* ctx)
   // 128 (225 vs 178 plans/s: fewer idle waves to dispatch per step); 256 waves cost 5 % / 10 %.
   const double want = 4.0 * std::sqrt((double)ctx->V) / kGroupsPerWave;
   uint32_t g = (uint32_t)std::ceil(want);
-  if (const char* e = getenv("MNAV_BLOCKS_PER_PLAN")) g = (uint32_t)atoi(e);
+  if (opt_set(ctx->opt.blocks_per_plan)) g = opt_u32(ctx->opt.blocks_per_plan, g);
   if (g < 4) g = 4;
   if (g > 4096) g = 4096;
   return g;
@@ -427,7 +448,7 @@ int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count, bool wide)
 template <uint32_t PLANNER>
 int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G, bool wide)
 {
-  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, getenv("MNAV_DEBUG_CHUNK") ? atoi(getenv("MNAV_DEBUG_CHUNK")) : kChunk, wide);   // debug: finer control-block trace
+  if (!ctx->use_graph) return launch_steps<PLANNER>(ctx, n, G, opt_set(ctx->opt.debug_chunk) ? (int)ctx->opt.debug_chunk : kChunk, wide);   // debug: finer control-block trace
   const uint64_t key = ((uint64_t)PLANNER << 60) | ((uint64_t)(wide ? ctx->wide_groups : 0u) << 57) | ((uint64_t)n << 32) | G;
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
@@ -488,7 +509,7 @@ int verify_sweeps(mnav_ctx* ctx, uint32_t n)
     if (!any) break;
     ++ctx->verify_sweeps_used;
   }
-  if (getenv("MNAV_TRACE")) fprintf(stderr, "[mnav] verification: %u fixing sweep(s)\n", ctx->verify_sweeps_used);
+  if (opt_on(ctx->opt.trace)) fprintf(stderr, "[mnav] verification: %u fixing sweep(s)\n", ctx->verify_sweeps_used);
   return 0;
 }
 
@@ -564,15 +585,9 @@ mnav_ctx* mnav_create(int device)
       hipHostMalloc((void**)&ctx->h_one, 64, hipHostMallocDefault) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->cancel_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   *ctx->h_one = 1u;
-  if (const char* e = getenv("MNAV_NO_GRAPH")) ctx->use_graph = !(atoi(e) != 0);
-  if (const char* e = getenv("MNAV_DIJKSTRA_ENGINE")) {
-    if (!strcmp(e, "band") || !strcmp(e, "1")) ctx->dij_engine = 1;
-    else if (!strcmp(e, "tiled") || !strcmp(e, "0")) ctx->dij_engine = 0;
-    else if (!strcmp(e, "persistent") || !strcmp(e, "2")) ctx->dij_engine = 2;
-    else if (!strcmp(e, "async") || !strcmp(e, "6")) ctx->dij_engine = 6;
-    else ctx->dij_engine = 3;
-  }
-  if (const char* e = getenv("MNAV_PERSISTENT_MIN_BATCH")) ctx->persistent_min_batch = (uint32_t)atoi(e);
+  if (hipHostMalloc((void**)&ctx->h_actl, sizeof(AsyncCtl), hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
+  ctx->opt.from_environment();                                        // the ONLY look at the environment (mnav_options.h)
+  apply_options(ctx);
   return ctx;
 }
 
@@ -601,7 +616,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend); (void)hipFree(ctx->shard.d_walk);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
-  (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any);
+  (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any); (void)hipFree(ctx->d_ring); if (ctx->h_actl) (void)hipHostFree(ctx->h_actl);
   (void)hipFree(ctx->d_over); (void)hipFree(ctx->d_over_off); (void)hipFree(ctx->d_over_cap);
   (void)hipFree(ctx->d_pack); (void)hipFree(ctx->d_pack_meta); if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);
@@ -666,11 +681,8 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     // a planar wavefront needs a few steps per hop of the mesh diameter ~ sqrt(V); generous cap
     const double cap = 400.0 * std::sqrt((double)V) + 20000.0;
     ctx->max_steps = cap > 2.0e9 ? 2000000000u : (uint32_t)cap;
-    if (const char* e = getenv("MNAV_MAX_STEPS")) ctx->max_steps = (uint32_t)atoll(e);
-    if (const char* e = getenv("MNAV_MAX_WALL_S")) ctx->max_wall_s = atof(e);
-    if (const char* e = getenv("MNAV_CVP_VERIFY")) ctx->cvp_verify = atoi(e) != 0;
-    if (const char* e = getenv("MNAV_KEY_WALK_MAX")) ctx->walk_max = atoi(e);
-    if (const char* e = getenv("MNAV_DESCEND_WALK_MAX")) ctx->descend_max = atoi(e);
+    ctx->max_steps_auto = ctx->max_steps;
+    apply_options(ctx);
   }
   ctx->h_xyz.assign(xyz, xyz + 3 * (size_t)V);
   ctx->h_faces.assign(face_vtx, face_vtx + 3 * (size_t)F);
@@ -691,8 +703,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
   if (dev_upload(ctx, &ctx->d_nrm, vertex_normals, vertex_normals ? 3 * (size_t)V : 0)) return -1;
   // LDS tiles of the SSSP engine
   {
-    if (const char* e = getenv("MNAV_TILE_SIZE")) ctx->tile_size = (uint32_t)atoi(e);
-    if (const char* e = getenv("MNAV_LAZY_PATHS")) ctx->allow_lazy_paths = atoi(e) != 0;
+    ctx->tile_size = opt_u32(ctx->opt.tile_size, 512u);
     if (ctx->tile_size < 64) ctx->tile_size = 64;
     if (ctx->tile_size > (uint32_t)(kTileBlock * kTileVpt)) ctx->tile_size = kTileBlock * kTileVpt;
     HostTiles T;
@@ -718,7 +729,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
     }
-    if (getenv("MNAV_VERBOSE"))
+    if (opt_on(ctx->opt.verbose))
       fprintf(stderr, "[mnav] tiles: size %u, %u tiles, max owned %u, halo %u, edges %u -> LDS %zu B (solve), %zu B (finalize)\n",
               ctx->tile_size, T.ntiles, T.max_nv, T.max_nh, T.max_ne, ctx->tile_lds, ctx->fin_lds);
     (void)hipFree(ctx->d_t_tw); ctx->d_t_tw = nullptr; ctx->tw_valid = false;
@@ -755,8 +766,6 @@ static void auto_delta(mnav_ctx* ctx, const float* w, uint32_t E)
   if (!(ctx->delta_auto > 0.f)) ctx->delta_auto = 1.0f;
   // tile band ~ the potential difference across one tile (sqrt(tile_size) mean edges)
   ctx->tile_band_auto = (ctx->delta_auto / 3.0f) * std::sqrt((float)ctx->tile_size);
-  if (const char* e = getenv("MNAV_TILE_BAND")) ctx->tile_band_user = (float)atof(e);
-  if (const char* e = getenv("MNAV_ROUNDS_BAND_MULT")) ctx->rounds_band_mult = (float)atof(e);
 }
 
 int mnav_upload_costs(mnav_ctx* ctx, const float* vertex_costs, const float* edge_weights, const uint8_t* invalid)
@@ -1046,7 +1055,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
-    if (getenv("MNAV_TRACE"))
+    if (opt_on(ctx->opt.trace))
       fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u)\n", last.it,
               last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used);
     if (last.done) break;
@@ -1274,9 +1283,12 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       // 10M: 64 plans 196 / 41 / 189, 256: 252 / 163 / 409, 1024: 254 / 594 / 924).
       const double tiles = std::max(1.0, (double)V / (0.9 * ctx->tb.T));
       const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && (double)m0 >= tiles / 1000.0;
-      engine = fills ? 5 : (m0 >= ctx->persistent_min_batch) ? 2 : 0;
+      // Below that: the asynchronous tile engine (mnav_async.h: one launch, a ticket queue of woken tiles; what a real makePlan
+      // call -- ONE plan -- runs on), up to async_max_batch plans; the tile rounds for what lies in between.
+      engine = fills ? 5 : (m0 <= opt_u32(ctx->opt.async_max_batch, 47u)) ? 6 : 0;
     }
-    if (engine == 5 && m0 > 65535u) engine = 2;
+    if (engine == 5 && m0 > 65535u) engine = 2;                       // (plan ids are 16 bits in the tile-batch buckets)
+    if (engine == 6 && m0 > 255u) engine = 0;                         // (8 bits in a ticket)
     if (engine == 1 && offset < 0.0) engine = 0;                      // the band steps arm goal_dist inside the loop: tile rounds for a negative offset
   }
   if (engine == 5 && in.size() > 1) {
@@ -1316,11 +1328,12 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   if (m) {
     if (materialize(ctx, false, cost_limit)) return MNAV_INTERNAL_ERROR;
     const bool want_path = true;
-    const int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
-                 : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
-                 : (engine == 6) ? run_dijkstra_async(ctx, m, in, offset)
-                 : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
-                                 : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
+    int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
+           : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
+           : (engine == 6) ? run_dijkstra_async(ctx, m, in, offset)
+           : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
+                           : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
+    if (engine == 6 && rc == 2) { engine = 0; rc = run_dijkstra_tiled(ctx, m, in, offset); }   // ticket ring exhausted: the rounds start over
     MTRACE("engine returned");
     if (rc != 0) (void)hipStreamSynchronize(ctx->stream);             // nothing of a failed / cancelled call stays in flight
     if (rc < 0) return MNAV_INTERNAL_ERROR;
@@ -1640,7 +1653,26 @@ int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 {
   if (!ctx || engine < 0 || engine > 6 || engine == 4) return -1;   // 4 was the one-wave-per-plan experiment (removed)
   ctx->dij_engine = engine;
+  ctx->opt.dijkstra_engine = (double)engine;
   return 0;
+}
+
+int mnav_set_option(mnav_ctx* ctx, const char* name, double value)
+{
+  if (!ctx || !name) return -1;
+  double* f = ctx->opt.find(name);
+  if (!f) { ctx->err = std::string("unknown option: ") + name; return -1; }
+  *f = value;                                                         // NaN: back to the built-in default
+  apply_options(ctx);
+  drop_graphs(ctx);                                                   // (captured launch sequences may hold what the option decides)
+  return 0;
+}
+
+double mnav_get_option(const mnav_ctx* ctx, const char* name)
+{
+  if (!ctx || !name) return NAN;
+  const double* f = const_cast<mnav_ctx*>(ctx)->opt.find(name);
+  return f ? *f : NAN;
 }
 
 const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what)

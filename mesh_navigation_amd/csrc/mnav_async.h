@@ -1,32 +1,55 @@
-// mnav_async.h -- Dijkstra on the LDS tiles WITHOUT rounds: an asynchronous label-correcting engine for single plans
-// and small batches (engine 6, "async"; opt-in).  Included by mnav.hip after the tile kernels.
+// mnav_async.h -- Dijkstra on the LDS tiles WITHOUT rounds and WITHOUT scans: an asynchronous label-correcting engine for
+// single plans and small batches (engine 6, "async").  Included by mnav.hip after the tile kernels.
 //
-// k_tile_round pays one dependent launch per round (260-670 rounds of 22-100 us for one plan on the 1M mesh, whatever
-// the batch), k_plan_persistent gives a plan ONE workgroup.  Here a set of resident workgroups shares the plans of a call:
-// a workgroup scans a plan's wake-up values, claims one tile of the current band [m, m + band) -- any of them, the
-// label-correcting fixed point does not depend on the order (dijkstra :287-348 reformulated) -- solves it
-// in LDS exactly like k_tile_round (same staging, same sweeps), publishes the lowered distances and wakes the neighbour
-// tiles it undercut.  No round, no barrier between workgroups, no host round trip: the critical path is the chain of
-// tile solves along the shortest path.
+// k_tile_round pays one dependent launch per round (260-670 rounds of 22-100 us for ONE plan, whatever the batch); a real
+// makePlan call is one plan (mbf_mesh_nav/src/mesh_planner_execution.cpp:55-66).  Here a set of resident workgroups serves a
+// TICKET QUEUE of woken tiles: a workgroup takes the next ticket (plan, tile), solves that tile in LDS exactly like
+// k_tile_round (same staging, same sweeps; dijkstra :287-348 reformulated as the label-correcting fixed point, DESIGN.md
+// 3.1), publishes the lowered distances, wakes the neighbour tiles it undercut -- the first waker of a tile files its
+// ticket -- and takes the next ticket.  No round, no barrier between workgroups, no host round trip, no scan over the
+// tiles: the critical path is the chain of tile solves along the shortest path.  The fixed point does not depend on the
+// order, so the results are the bits of every other engine.
 //
-// Protocol (every word another workgroup may read or write is accessed with relaxed AGENT-scope atomics = sc1 loads /
-// stores / RMWs, which bypass the per-CU L1 and the per-XCD L2: MI355X_MICROARCH.md, visibility):
-//   pend[t]   wake-up value of tile t (float bits, inf = none).  Wakers atomicMin it; the solver takes it with an exchange.
-//   lock[t]   (the second pend buffer of the slot) inf = free, 0 = a workgroup is solving t.  One solver per tile: two
-//             concurrent solves would race on tlast[t] (the "owned sources below it have been propagated" mark).
-//   work      per plan: number of tiles that are pending or being solved, never below the true count: a waker adds 1
-//             BEFORE its atomicMin and takes it back when the tile was pending already; the solver's 1 is the pending 1
-//             it took over and is given back after its own wake-ups.  work == 0 <=> the plan is at its fixed point.
-//   order     a solver's distance stores are drained (s_waitcnt vmcnt(0) in every storing wave, then a barrier) before
-//             the first wake-up is posted; a later solver reads distances only after its claim returned.
+// Round 4's first version of this engine found its work by scanning all wake-up values twice per attempt (48 workgroups
+// per plan, 4 500 failed claims per plan: 6.1 ms for a 1M-vertex plan against 7.4 ms for the rounds, first hardware run of
+// round 5); the queue replaces the scans, the claims and the band.
+//
+// Protocol.  Every word another workgroup may touch is accessed with relaxed AGENT-scope atomics (sc1: past the per-CU L1
+// and the per-XCD L2, MI355X_MICROARCH.md "visibility"), through GLOBAL pointers (vmcnt only).
+//   pend[t]    wake-up value of tile t (float bits, inf = none): wakers atomicMin it, the solver takes it with an exchange.
+//   state[t]   (the slot's second pend buffer) 1 = the tile has a ticket in the queue or is being solved, 0 = neither.
+//              WHOEVER TURNS IT FROM 0 TO 1 FILES THE TICKET: at most one ticket per tile, hence one solver per tile (two
+//              would race on tlast[t] and on the owned distances).
+//              waker:   old = atomicMin(pend[t], v);  if (old == inf && atomicOr(state[t], 1) == 0) push(t)
+//              solver:  ... solve, publish ...;  atomicAnd(state[t], 0);  if (pend[t] != inf && atomicOr(state[t], 1) == 0) push(t)
+//              Both sides do "write mine, THEN look at yours", each RMW awaited before the next operation is issued
+//              (Dekker): a wake-up that arrives while the tile is in solve is seen by the solver's look or files its own ticket.
+//   ring[i]    ticket i = plan << 24 | tile, 0xffffffff = not filed yet.  push: i = tail++, ring[i] = ticket;
+//              pop: i = head++, then the workgroup polls ring[i] (one word, with s_sleep).  A ticket index belongs to exactly
+//              one popper, a slot is written exactly once per call: no reuse, no ABA.  The ring holds every ticket a call can
+//              file in practice (host: 16 per tile and plan); a call that runs out of slots sets abort = 5 and the host
+//              re-runs it on the tile rounds.
+//   work[p]    per plan: tickets filed and not yet retired, counted BEFORE the ticket becomes visible and given back after
+//              the solver's own wake-ups: work == 0 <=> the plan is at its fixed point.  The workgroup that takes it to 0
+//              publishes the plan record (plan_finish) and counts the plan in done_plans; done_plans == n ends the kernel.
+//   order      a solver's distance stores are drained (s_waitcnt vmcnt(0) in every storing wave, then a barrier) before its
+//              first wake-up; a later solver reads distances only after its ticket arrived.
 // Tiles whose wake-up value lies beyond the running bound dist[target] + offset can never propagate (dijkstra :293-300):
-// whoever sees one takes it out of the count.
-// Every wait is bounded: workgroups never wait FOR each other (an idle one re-scans, sleeps, and gives up after
-// `limit_ticks` of the 100 MHz wall clock with abort = 2); a grid larger than what is resident only starts later.
+// their ticket is retired without a solve.  No workgroup waits FOR another one -- a popper whose ticket is never filed leaves
+// with done_plans == n --, every poll loop is bounded by the 100 MHz wall clock (abort = 2) and looks at mnav_cancel's word
+// (abort = 3), so residency is not a correctness condition: a grid larger than what fits only starts later.
+//
+// Band.  The rounds relax a tile only up to a band threshold and come back for the rest (2.8 activations per touched tile in
+// batches: work-efficient).  A single plan has 256 idle CUs: here a solve runs the tile to its LOCAL FIXED POINT for everything
+// below the bound (thr = +inf) -- fewer dependent activations on the critical path, more re-solves off it.  TilePlan.band > 0
+// and finite restores the banded solve (thr = wake-up value + band, the tile wakes itself for the rest).
 #pragma once
 
 constexpr uint32_t kAsyncWake = 32;        // distinct neighbour tiles one solve can wake through the LDS table (more: slow path)
-struct AsyncCtl { uint32_t abort; uint32_t done_plans; uint32_t claim_fails; uint32_t idle_passes; };
+constexpr uint32_t kTicketNone = 0xFFFFFFFFu;
+constexpr uint32_t kTicketExit = 0xFFFFFFFEu;
+// words 4.. of the context's control line (word 0: mnav_cancel)
+struct AsyncCtl { uint32_t abort; uint32_t done_plans; uint32_t head; uint32_t tail; uint32_t polls; uint32_t dropped; uint32_t ring_cap; uint32_t pad; };
 
 namespace aq {
 typedef MNAV_GLOBAL uint32_t* gptr;    // every shared word is accessed through a GLOBAL pointer (global_* instructions, vmcnt only), never flat
@@ -36,17 +59,14 @@ __device__ __forceinline__ uint32_t add(uint32_t* p, uint32_t v) { return __hip_
 __device__ __forceinline__ uint32_t sub(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_sub((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t amin(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t xchg(uint32_t* p, uint32_t v) { return __hip_atomic_exchange((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool cas(uint32_t* p, uint32_t expect, uint32_t v)
-{
-  return __hip_atomic_compare_exchange_strong((gptr)p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ uint32_t aor(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_or((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t aand(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_and((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // the per-plan words live in the slot's three TCnt records (unused by this engine otherwise)
 __device__ __forceinline__ uint32_t* work_of(const TilePlan& P) { return &P.cnt[0].minpend; }
 __device__ __forceinline__ uint32_t* acts_of(const TilePlan& P) { return &P.cnt[0].acts; }
 __device__ __forceinline__ uint32_t* sweeps_of(const TilePlan& P) { return &P.cnt[0].sweeps; }
-__device__ __forceinline__ uint32_t* done_of(const TilePlan& P) { return &P.cnt[0].pad; }
 
 // the plan reached its fixed point: publish the control record the finalize pass / the path walk read (after the kernel)
 __device__ __forceinline__ void plan_finish(const TilePlan& P, AsyncCtl* actl)
@@ -55,178 +75,124 @@ __device__ __forceinline__ void plan_finish(const TilePlan& P, AsyncCtl* actl)
   c.acts = ld(acts_of(P)); c.sweeps = ld(sweeps_of(P));
   c.it = (int32_t)c.acts; c.done = 1u; c.thr = inf_f(); c.thr_prev = inf_f();
   P.ctl[0] = c; P.ctl[1] = c;
-  st(done_of(P), 1u);
+  drain();
   add(&actl->done_plans, 1u);
 }
-// one pending-or-in-solve tile less; `fin`: this thread took the count to zero and owes the plan its plan_finish (the callers
-// settle that at a few places of the loop instead of inlining the record stores at every decrement)
-__device__ __forceinline__ void work_dec(const TilePlan& P, bool& fin)
+// file the ticket of tile t of plan p (the caller has just turned state[t] from 0 to 1)
+__device__ __forceinline__ void push(const TilePlan& P, uint32_t p, uint32_t t, uint32_t* ring, AsyncCtl* actl)
 {
-  if (sub(work_of(P), 1u) == 1u) fin = true;
+  add(work_of(P), 1u);                                                // counted before it can be seen
+  drain();
+  const uint32_t i = add(&actl->tail, 1u);
+  if (i < actl->ring_cap) st(ring + i, (p << 24) | t);
+  else st(&actl->abort, 5u);                                          // out of slots: the host re-runs the call on the tile rounds
 }
 // wake tile t2 with value v (float bits)
-__device__ __forceinline__ void wake(const TilePlan& P, bool& fin, uint32_t t2, uint32_t v)
+__device__ __forceinline__ void wake(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, uint32_t* ring, AsyncCtl* actl)
 {
-  add(work_of(P), 1u);
-  if (amin(P.pend[0] + t2, v) != kInfBits) work_dec(P, fin);        // (never the last one: the caller's own count is still held)
+  if (amin(P.pend[0] + t2, v) != kInfBits) return;                    // pending already: whoever made it so files (or filed) the ticket
+  if (aor(P.pend[1] + t2, 1u) == 0u) push(P, p, t2, ring, actl);      // (the atomicMin has returned: its value is visible before the OR is issued)
 }
 }  // namespace aq
 
-__global__ void k_async_init(const TilePlan* __restrict__ plans, uint32_t n)
+// work = 1, the seed's tile queued (ticket p), every other tile idle; the control words; grid (tiles / 256, n)
+__global__ __launch_bounds__(kBlock) void k_async_init(const TilePlan* __restrict__ plans, uint32_t* __restrict__ ring, const uint32_t* __restrict__ vert_tile,
+                                                       AsyncCtl* __restrict__ actl, uint32_t n, uint32_t ring_cap)
 {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const TilePlan& P = plans[p];
-  TCnt z; z.minpend = 1u; z.acts = 0u; z.sweeps = 0u; z.pad = 0u;   // work = 1: the seed's tile is pending (k_tile_init)
-  P.cnt[0] = z;
-  z.minpend = 0u; P.cnt[1] = z; P.cnt[2] = z;
+  const TilePlan& P = plans[blockIdx.y];
+  const uint32_t st = vert_tile[P.seed];
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) P.pend[1][t] = (t == st) ? 1u : 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    TCnt z; z.minpend = 1u; z.acts = 0u; z.sweeps = 0u; z.pad = 0u;
+    P.cnt[0] = z;
+    z.minpend = 0u; P.cnt[1] = z; P.cnt[2] = z;
+    ring[blockIdx.y] = (blockIdx.y << 24) | st;
+    if (blockIdx.y == 0) {
+      AsyncCtl c; c.abort = 0u; c.done_plans = 0u; c.head = 0u; c.tail = n; c.polls = 0u; c.dropped = 0u; c.ring_cap = ring_cap; c.pad = 0u;
+      *actl = c;
+    }
+  }
 }
 
 template <int VPT>   // owned vertices per thread: tile_size <= VPT * 256
 __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __restrict__ plans, uint32_t n, AsyncCtl* __restrict__ actl,
-                                                           unsigned long long limit_ticks)
+                                                           uint32_t* __restrict__ ring, unsigned long long limit_ticks)
 {
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  __shared__ unsigned long long s_red[kTileBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63;
   __shared__ uint32_t s_hdr[8];
   __shared__ uint32_t s_nq[3];
-  __shared__ uint32_t s_pick, s_flag, s_bound_bits, s_thr_bits, s_wover;
-  __shared__ unsigned long long s_live;
+  __shared__ uint32_t s_ticket, s_bound_bits, s_thr_bits, s_wover, s_solve;
   __shared__ uint32_t s_wtile[kAsyncWake], s_wval[kAsyncWake];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TileLds L = tile_lds_layout(smem, plans[0].max_nv, plans[0].max_nh, plans[0].max_ne);   // one mesh: the same for every plan
   uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
-
   const unsigned long long t_begin = wall_clock64();
-  uint32_t home = blockIdx.x % n, idle = 0, iter = 0, passes = 0;
-  uint32_t my_fails = 0, my_idle = 0;
+  uint32_t my_polls = 0, my_dropped = 0;
   for (;;) {
-    // ---- leave?  (thread 0 decides, the workgroup follows) and which plans of the window [home, home + 64) still run
-    if (wid == 0) {
-      uint32_t live = 0;
-      if ((uint32_t)lane < min(n, 64u)) { const uint32_t pi = (home + lane) % n; live = aq::ld(aq::done_of(plans[pi])) ? 0u : 1u; }
-      const unsigned long long mask = __ballot(live != 0u);
-      if (lane == 0) {
-        uint32_t f = 0;
-        if (aq::ld(&actl->abort)) f = 1u;
-        else if (aq::ld(&actl->done_plans) >= n) f = 1u;
-        else if (plans[0].cancel && aq::ld(plans[0].cancel)) { aq::st(&actl->abort, 3u); f = 1u; }          // mnav_cancel, dijkstra :287
-        else if (wall_clock64() - t_begin > limit_ticks) { aq::st(&actl->abort, 2u); f = 1u; }
-        else if (++passes > 20000000u) { aq::st(&actl->abort, 4u); f = 1u; }                       // second guard, should the clock not tick
-        s_flag = f; s_live = mask;
-      }
+    // ---- the next ticket (thread 0 takes and awaits it, the workgroup sits in the barrier)
+    if (tid == 0) {
+      uint32_t e = kTicketExit;
+      const uint32_t i = aq::add(&actl->head, 1u);
+      if (i < actl->ring_cap) {
+        for (uint32_t spins = 0;; ++spins) {
+          e = aq::ld(ring + i);
+          if (e != kTicketNone) break;
+          if ((spins & 7u) == 7u) {                                   // leave?  (every 8th look: the flags live in one line)
+            e = kTicketExit;
+            if (aq::ld(&actl->abort) || aq::ld(&actl->done_plans) >= n) break;
+            if (plans[0].cancel && aq::ld(plans[0].cancel)) { aq::st(&actl->abort, 3u); break; }   // mnav_cancel, dijkstra :287
+            if (wall_clock64() - t_begin > limit_ticks) { aq::st(&actl->abort, 2u); break; }
+            if (spins > 400000000u) { aq::st(&actl->abort, 4u); break; }                            // second guard, should the clock not tick
+            e = kTicketNone;
+          }
+          ++my_polls;
+          if (spins < 64u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
+        }
+      } else aq::st(&actl->abort, 5u);
+      s_ticket = e;
     }
     __syncthreads();
-    if (s_flag) break;
-    unsigned long long live = s_live;
-    bool did = false;
-    while (live && !did) {
-      const uint32_t k = (uint32_t)__ffsll((long long)live) - 1u;
-      live &= live - 1ull;
-      const TilePlan& P = plans[(home + k) % n];
-      uint32_t* const pend = P.pend[0];
-      uint32_t* const lock = P.pend[1];
-      uint32_t* const dbits = reinterpret_cast<uint32_t*>(P.dist);
-      ++iter;
-      bool fin = false;                                              // this thread owes P its plan_finish
-      // ---- scan 1: the smallest wake-up value of the plan
-      uint32_t mn = kInfBits;
-      for (uint32_t t0 = tid; t0 < P.ntiles; t0 += 8 * kTileBlock) {
-        uint32_t pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t t = t0 + u * kTileBlock; pv[u] = (t < P.ntiles) ? aq::ld(pend + t) : kInfBits; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mn = min(mn, pv[u]);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-      __syncthreads();                                               // (s_red / s_pick of the previous attempt are dead)
-      if (lane == 0) s_red[wid] = mn;
-      if (tid == 0) {
-        const float dt = u2f(aq::ld(dbits + P.target));
-        s_bound_bits = f2u((float)((double)dt + fmax(P.offset, 0.0)));   // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
-        s_pick = kNone; s_wover = 0u;
-      }
-      if (tid < (int)kAsyncWake) { s_wtile[tid] = kNone; s_wval[tid] = kInfBits; }
-      __syncthreads();
-      mn = min(min((uint32_t)s_red[0], (uint32_t)s_red[1]), min((uint32_t)s_red[2], (uint32_t)s_red[3]));
-      if (mn == kInfBits) continue;                                  // nothing pending here (tiles in solve may still wake some)
-      const float bound = u2f(s_bound_bits);
-      const float m = u2f(mn);
-      float thr = m + P.band;
-      if (!(thr > m)) thr = next_up(m);
-      // ---- scan 2: a tile of the band, a different one for every workgroup; tiles beyond the bound leave the count
-      unsigned long long key = ~0ull;
-      const uint32_t salt = (blockIdx.x + 1u) * 0x9E3779B9u + iter * 0x85EBCA6Bu;
-      for (uint32_t t0 = tid; t0 < P.ntiles; t0 += 8 * kTileBlock) {
-        uint32_t pv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t t = t0 + u * kTileBlock; pv[u] = (t < P.ntiles) ? aq::ld(pend + t) : kInfBits; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (pv[u] == kInfBits) continue;
-          const uint32_t t = t0 + u * kTileBlock;
-          const float p = u2f(pv[u]);
-          if (p > bound) {                                           // can never propagate any more (k_tile_round does the same)
-            const uint32_t v = aq::xchg(pend + t, kInfBits);
-            if (v == kInfBits) continue;                             // somebody else took it
-            if (u2f(v) > bound) {
-              uint32_t* const tl = reinterpret_cast<uint32_t*>(P.tlast) + t;
-              if (!(u2f(aq::ld(tl)) > -inf_f())) aq::st(tl, f2u(-3.0e38f));   // the finalize pass still has to visit the tile
-              aq::work_dec(P, fin);
-            } else if (aq::amin(pend + t, v) != kInfBits) aq::work_dec(P, fin);   // lowered in between: put it back (merged with a newer wake-up)
-            continue;
-          }
-          if (p < thr) {
-            const unsigned long long h = ((unsigned long long)((t ^ salt) * 0x9E3779B1u) << 32) | t;
-            key = h < key ? h : key;
-          }
+    const uint32_t ticket = s_ticket;
+    if (ticket == kTicketExit) break;
+    const uint32_t p = ticket >> 24, t = ticket & 0xFFFFFFu;
+    const TilePlan& P = plans[p];
+    uint32_t* const pend = P.pend[0];
+    uint32_t* const state = P.pend[1];
+    uint32_t* const dbits = reinterpret_cast<uint32_t*>(P.dist);
+    if (tid == 0) {
+      const uint32_t v = aq::xchg(pend + t, kInfBits);
+      const float dt = u2f(aq::ld(dbits + P.target));
+      const float bound = (float)((double)dt + fmax(P.offset, 0.0));  // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
+      s_bound_bits = f2u(bound);
+      uint32_t solve = 0u;
+      if (v != kInfBits) {
+        if (u2f(v) > bound) {                                         // can never propagate any more (k_tile_round does the same)
+          uint32_t* const tl = reinterpret_cast<uint32_t*>(P.tlast) + t;
+          if (!(u2f(aq::ld(tl)) > -inf_f())) aq::st(tl, f2u(-3.0e38f));   // the finalize pass still has to visit the tile
+          ++my_dropped;
+        } else {
+          solve = 1u;
+          const float pv = u2f(v);
+          float thr = inf_f();
+          if (P.band > 0.f && P.band < inf_f()) { thr = pv + P.band; if (!(thr > pv)) thr = next_up(pv); }
+          s_thr_bits = f2u(thr);
+          s_hdr[0] = P.vptr[t]; s_hdr[1] = P.vptr[t + 1]; s_hdr[2] = P.hptr[t]; s_hdr[3] = P.hptr[t + 1];
+          s_hdr[4] = P.eptr[t]; s_hdr[5] = P.eptr[t + 1]; s_hdr[6] = P.rptr[t];
+          s_hdr[7] = aq::ld(reinterpret_cast<uint32_t*>(P.tlast) + t);
+          s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
         }
       }
-      if (fin) { aq::plan_finish(P, actl); fin = false; }           // (the last pending tile lay beyond the bound)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(key, o); key = ok < key ? ok : key; }
-      __syncthreads();
-      if (lane == 0) s_red[wid] = key;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned long long best = s_red[0];
-        for (int w = 1; w < kTileBlock / 64; ++w) best = s_red[w] < best ? s_red[w] : best;
-        if (best != ~0ull) {
-          const uint32_t t = (uint32_t)best;
-          // ---- claim: the lock first (one solver per tile), then the wake-up value
-          if (aq::cas(lock + t, kInfBits, 0u)) {
-            const uint32_t v = aq::xchg(pend + t, kInfBits);
-            bool ok = v != kInfBits;
-            if (ok && u2f(v) > bound) {                              // (re-woken with a value beyond the bound since the scan)
-              uint32_t* const tl = reinterpret_cast<uint32_t*>(P.tlast) + t;
-              if (!(u2f(aq::ld(tl)) > -inf_f())) aq::st(tl, f2u(-3.0e38f));
-              aq::drain();
-              aq::st(lock + t, kInfBits);
-              aq::work_dec(P, fin);
-              ok = false;
-            } else if (!ok) aq::st(lock + t, kInfBits);
-            if (ok) {
-              const float pv = u2f(v);
-              if (!(pv < thr)) { thr = pv + P.band; if (!(thr > pv)) thr = next_up(pv); }   // a wake-up is only consumed by a solve whose band holds it
-              s_thr_bits = f2u(thr);
-              s_hdr[0] = P.vptr[t]; s_hdr[1] = P.vptr[t + 1]; s_hdr[2] = P.hptr[t]; s_hdr[3] = P.hptr[t + 1];
-              s_hdr[4] = P.eptr[t]; s_hdr[5] = P.eptr[t + 1]; s_hdr[6] = P.rptr[t];
-              s_hdr[7] = aq::ld(reinterpret_cast<uint32_t*>(P.tlast) + t);
-              s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
-              s_pick = t;
-            }
-          }
-          if (s_pick == kNone) ++my_fails;
-        }
-        if (fin) { aq::plan_finish(P, actl); fin = false; }
-      }
-      __syncthreads();
-      const uint32_t t = s_pick;
-      if (t == kNone) continue;
-      did = true;
-      thr = u2f(s_thr_bits);
+      s_solve = solve; s_wover = 0u;
+    }
+    if (tid < (int)kAsyncWake) { s_wtile[tid] = kNone; s_wval[tid] = kInfBits; }
+    __syncthreads();
+    uint32_t sweep = 0;
+    float thr = inf_f();
+    if (s_solve) {
       // ---- solve tile t (k_tile_round's solve; distances through agent-scope loads / stores)
+      thr = u2f(s_thr_bits);
+      const float bound = u2f(s_bound_bits);
       const uint32_t v0 = s_hdr[0], nv = s_hdr[1] - v0;
       const uint32_t h0 = s_hdr[2], nh = s_hdr[3] - h0;
       const uint32_t e0 = s_hdr[4], ne = s_hdr[5] - e0;
@@ -270,7 +236,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
         if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
       }
       __syncthreads();
-      const uint32_t sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
+      sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
       // ---- publish: the lowered owned distances first ...
       uint32_t own_left = kInfBits;
 #pragma unroll
@@ -280,7 +246,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
           const uint32_t db = ldu[i];
           if (db != orig[k2]) aq::st(dbits + gi[k2], db);
           const float d = u2f(db);
-          if (!(d < thr) && d <= bound) own_left = min(own_left, db);   // owned values that still have to propagate: the tile's own wake-up
+          if (!(d < thr) && d <= bound) own_left = min(own_left, db);   // owned values that still have to propagate: the tile's own wake-up (banded solve only)
         }
       }
       // ... the wake-ups collected per neighbour tile in LDS (a tile has a handful of neighbours, a hundred halo vertices)
@@ -294,37 +260,36 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       };
       for (uint32_t i = tid; i < nh; i += kTileBlock) {
         const uint32_t b = ldu[nv + i];
-        if (b < lh0[i]) collect(g_halo_tile[h0 + i], b);            // we undercut a neighbour's vertex: it has to re-derive it
+        if (b < lh0[i]) collect(g_halo_tile[h0 + i], b);              // we undercut a neighbour's vertex: it has to re-derive it
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) own_left = min(own_left, (uint32_t)__shfl_xor((int)own_left, o));
       if (lane == 0 && own_left != kInfBits) collect(t, own_left);
-      aq::drain();                                                   // every storing wave: its distance stores have left the CU ...
-      __syncthreads();                                               // ... before the first wake-up can be seen
-      if (tid < (int)kAsyncWake && s_wtile[tid] != kNone) aq::wake(P, fin, s_wtile[tid], s_wval[tid]);
-      if (s_wover) {                                                 // more neighbour tiles than table slots: one wake-up per halo vertex
+      aq::drain();                                                     // every storing wave: its distance stores have left the CU ...
+      __syncthreads();                                                 // ... before the first wake-up can be seen
+      if (tid < (int)kAsyncWake && s_wtile[tid] != kNone) aq::wake(P, p, s_wtile[tid], s_wval[tid], ring, actl);
+      if (s_wover) {                                                   // more neighbour tiles than table slots: one wake-up per halo vertex
         for (uint32_t i = tid; i < nh; i += kTileBlock) {
           const uint32_t b = ldu[nv + i];
-          if (b < lh0[i]) aq::wake(P, fin, g_halo_tile[h0 + i], b);
+          if (b < lh0[i]) aq::wake(P, p, g_halo_tile[h0 + i], b, ring, actl);
         }
-        if (lane == 0 && own_left != kInfBits) aq::wake(P, fin, t, own_left);   // (own_left: this wave's minimum)
+        if (lane == 0 && own_left != kInfBits) aq::wake(P, p, t, own_left, ring, actl);   // (own_left: this wave's minimum)
       }
-      __syncthreads();                                               // every wake-up has returned (its old value was looked at)
-      if (tid == 0) {
+      aq::drain();
+      __syncthreads();                                                 // every wake-up has returned
+    }
+    // ---- retire the ticket: the tile is ours until state[t] is cleared; a wake-up that came in meanwhile gets its ticket here
+    if (tid == 0) {
+      if (s_solve) {
         aq::st(reinterpret_cast<uint32_t*>(P.tlast) + t, f2u(thr));
         aq::add(aq::acts_of(P), 1u); aq::add(aq::sweeps_of(P), sweep);
-        aq::drain();
-        aq::st(lock + t, kInfBits);                                  // the next solver of t reads tlast after its claim returned
-        aq::work_dec(P, fin);                                        // the count this solve held
+        aq::drain();                                                   // the next solver of t reads tlast after its ticket arrived
       }
-      if (fin) { aq::plan_finish(P, actl); fin = false; }            // (wake-ups never take the count to zero: only thread 0 can get here)
+      (void)aq::aand(state + t, 0u);
+      aq::drain();                                                     // cleared BEFORE the look (Dekker, see the header)
+      if (aq::ld(pend + t) != kInfBits && aq::aor(state + t, 1u) == 0u) aq::push(P, p, t, ring, actl);
+      if (aq::sub(aq::work_of(P), 1u) == 1u) aq::plan_finish(P, actl);   // the count this ticket held
     }
-    if (did) { idle = 0; continue; }
-    // nothing to do in this window: look at the next one, back off a little (255 pollers cost the chip a third of its bandwidth)
-    ++idle; ++my_idle;
-    if (n > 64u) home = (home + 64u) % n;
-    __builtin_amdgcn_s_sleep(32);
-    if (idle > 4u) __builtin_amdgcn_s_sleep(127);
   }
-  if (tid == 0 && (my_fails | my_idle)) { atomicAdd(&actl->claim_fails, my_fails); atomicAdd(&actl->idle_passes, my_idle); }
+  if (tid == 0 && (my_polls | my_dropped)) { atomicAdd(&actl->polls, my_polls); atomicAdd(&actl->dropped, my_dropped); }
 }

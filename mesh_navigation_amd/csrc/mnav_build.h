@@ -499,6 +499,11 @@ inline HostTiles build_tiles(const HostTopology& t, const float* xyz, uint32_t t
   }
   T.ntiles = uint32_t(T.vptr.size() - 1);
   if (V == 0) { T.ntiles = 0; T.vptr.assign(1, 0); }
+  // Inside a tile the vertices are listed in ascending id (the halo likewise, below): whatever walks a tile with consecutive
+  // lanes -- staging, write-back, the finalize pass's V-sized outputs -- then touches runs of consecutive addresses of the
+  // caller's vertex-order arrays (a scan row of the patch) instead of the Z-curve's pairs.  The local numbering is free: every
+  // engine computes the order-independent fixed point.
+  for (uint32_t tl = 0; tl < T.ntiles; ++tl) std::sort(T.verts.begin() + T.vptr[tl], T.verts.begin() + T.vptr[tl + 1]);
 
   // position of source x inside row y of the gather CSR
   auto pos_in_row = [&](uint32_t y, uint32_t x) -> uint32_t {
@@ -516,9 +521,11 @@ inline HostTiles build_tiles(const HostTopology& t, const float* xyz, uint32_t t
       const uint32_t v = T.verts[i];
       for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
         const uint32_t u = t.nbr_u[k];
-        if (local[u] == kNone) { local[u] = nv + uint32_t(halo.size()); halo.push_back(u); }
+        if (local[u] == kNone) { local[u] = nv; halo.push_back(u); }   // (marked; numbered below)
       }
     }
+    std::sort(halo.begin(), halo.end());
+    for (uint32_t h = 0; h < uint32_t(halo.size()); ++h) local[halo[h]] = nv + h;
     const uint32_t nh = uint32_t(halo.size());
     if (nv + nh > 0xFFFFu) throw std::invalid_argument("tile too large for 16-bit local indices");
     uint32_t ne = 0;

@@ -55,16 +55,16 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   // CVP batches: the wide step kernel (64 work-list entries per wave and round); single plans keep the 8-lane replay, whose
   // many small waves finish a short work list sooner
   bool wide = cvp && n >= ctx->cvp_wide_min_batch;
-  if (const char* e = getenv("MNAV_CVP_WIDE")) wide = cvp && atoi(e) != 0;
+  if (opt_set(ctx->opt.cvp_wide)) wide = cvp && ctx->opt.cvp_wide != 0.0;
   uint32_t G = blocks_per_plan(ctx);
   if (wide) {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
     G = (kWideVerts == 64u ? 7u : 12u) * (uint32_t)ncu;               // waves of the whole batch, not per plan: what stays resident
-    if (const char* e = getenv("MNAV_WIDE_WAVES")) G = (uint32_t)std::max(1, atoi(e));
+    if (opt_set(ctx->opt.wide_waves)) G = std::max(1u, opt_u32(ctx->opt.wide_waves, G));
     ctx->wide_groups = std::min(4u, std::max(1u, n / 40u));            // measured on the benched C3 configuration, plans/s with 1 / 2 / 3 / 4 / 8 groups:
                                                                       // 128 plans 277 / 315 / 320 / 320 / 221, 512 plans 330 / 425 / 463 / 468 / 422
-    if (const char* e = getenv("MNAV_CVP_GROUPS")) ctx->wide_groups = (uint32_t)std::min(std::max(1, atoi(e)), (int)kWideGroupsMax);
+    if (opt_set(ctx->opt.cvp_groups)) ctx->wide_groups = std::min(std::max(1u, opt_u32(ctx->opt.cvp_groups, 1u)), (uint32_t)kWideGroupsMax);
     if (ctx->wide_groups > n) ctx->wide_groups = 1;
     if (ctx->wide_cap < n + 1u) {
       (void)hipFree(ctx->d_wide_prefix); ctx->d_wide_prefix = nullptr;
@@ -269,7 +269,7 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   // active tiles form a ring along the wavefront: O(sqrt(ntiles)); every workgroup scans a
   // strided share of the tile table, so any grid size is correct
   uint32_t G = (uint32_t)std::ceil(8.0 * std::sqrt((double)M.ntiles)) + 8;
-  if (const char* e = getenv("MNAV_TILE_BLOCKS")) G = (uint32_t)atoi(e);
+  if (opt_set(ctx->opt.tile_blocks)) G = opt_u32(ctx->opt.tile_blocks, G);
   if (G > M.ntiles) G = M.ntiles;
   if (G < 1) G = 1;
   uint32_t launches = 0;
@@ -375,7 +375,8 @@ int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>
   return 0;
 }
 
-// Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1 or 1 (cancelled).
+// Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1, 1 (cancelled) or
+// 2 (the ticket ring ran out: nothing of the call is usable, run it on another engine).
 int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
   if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
@@ -407,16 +408,26 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
     T.max_rounds = 0x7FFFFFF0u;
     T.cancel = ctx->d_cancel;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
+    T.band = opt_set(ctx->opt.async_band_mult) && ctx->opt.async_band_mult > 0.0 ? (float)(ctx->opt.async_band_mult * ctx->tile_band_auto) : 0.f;   // 0: every solve runs to the tile's local fixed point
     T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
-  AsyncCtl* const actl = reinterpret_cast<AsyncCtl*>(ctx->d_cancel + 4);   // words 4..7 of the 64-byte control line (word 0: mnav_cancel)
+  AsyncCtl* const actl = reinterpret_cast<AsyncCtl*>(ctx->d_cancel + 4);   // words 4..11 of the 64-byte control line (word 0: mnav_cancel)
+  // the ticket ring: every slot is written at most once per call, so it only has to hold what a call can file (a tile is
+  // re-filed when a neighbour undercuts it after its solve: a handful of times) -- 16 per tile and plan; a call that runs out
+  // gives up (abort 5) and is re-run on the tile rounds by the caller
+  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>((uint64_t)n * M.ntiles * 16u, 1u << 16), 1u << 27);
+  if (ctx->ring_cap < want) {
+    (void)hipFree(ctx->d_ring); ctx->d_ring = nullptr; ctx->ring_cap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_ring, 4 * (size_t)want));
+    ctx->ring_cap = (uint32_t)want; ctx->ring_used = ctx->ring_cap;
+  }
   HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(actl, 0, sizeof(AsyncCtl), ctx->stream));     // every polled word is zeroed on the stream before every launch
+  HIPCHK(hipMemsetAsync(ctx->d_ring, 0xFF, 4 * (size_t)std::min<uint64_t>(ctx->ring_cap, (uint64_t)ctx->ring_used + 4096u), ctx->stream));   // the slots the previous call touched
+  ctx->ring_used = ctx->ring_cap;                                     // (until this call's tail has been read back)
   HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
   uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
   if (gi < 1) gi = 1;
@@ -426,37 +437,37 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
     if (gt < 1) gt = 1;
     hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
-    hipLaunchKernelGGL(k_async_init, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_tplans, n);
+    hipLaunchKernelGGL(k_async_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_ring, ctx->d_vert_tile, actl, n, ctx->ring_cap);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-  // Workgroups: what is resident at once, and no more per plan than its wavefront has tiles for (idle workgroups poll).
+  // Workgroups: what is resident at once (4 per CU: 36 KB of LDS each), and no more per plan than its wave front has tiles for
+  // (a workgroup without a ticket polls one word)
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-  uint32_t per_cu = 2, per_plan = 48;
-  if (const char* e = getenv("MNAV_ASYNC_WG_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
-  if (const char* e = getenv("MNAV_ASYNC_WG_PER_PLAN")) per_plan = (uint32_t)std::max(1, atoi(e));
-  uint32_t G = std::min<uint64_t>((uint64_t)ncu * per_cu, (uint64_t)n * per_plan);
+  const uint32_t per_cu = std::max(1u, opt_u32(ctx->opt.async_wg_per_cu, 4u)), per_plan = std::max(1u, opt_u32(ctx->opt.async_wg_per_plan, 128u));
+  uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ncu * per_cu, (uint64_t)n * per_plan);
   if (G > M.ntiles * n) G = M.ntiles * n;
   if (G < 1) G = 1;
-  double guard_s = std::min(ctx->max_wall_s, 10.0);                   // in-kernel give-up (100 MHz wall clock)
-  if (const char* e = getenv("MNAV_ASYNC_MAX_S")) guard_s = atof(e);
+  const double guard_s = opt_set(ctx->opt.async_max_s) && ctx->opt.async_max_s > 0.0 ? ctx->opt.async_max_s : std::min(ctx->max_wall_s, 10.0);   // in-kernel give-up (100 MHz wall clock)
   const unsigned long long limit_ticks = (unsigned long long)(guard_s * 1.0e8);
   ctx->ms_chunks = 0.0;
   HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_async<2>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
-  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_async<4>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
-  else hipLaunchKernelGGL(k_plan_async<8>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, limit_ticks);
+  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_async<2>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, ctx->d_ring, limit_ticks);
+  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_async<4>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, ctx->d_ring, limit_ticks);
+  else hipLaunchKernelGGL(k_plan_async<8>, dim3(G), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans, n, actl, ctx->d_ring, limit_ticks);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  AsyncCtl h{};
+  AsyncCtl& h = *ctx->h_actl;                                         // (pinned)
   HIPCHK(hipMemcpyAsync(&h, actl, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->ring_used = std::min(h.tail, ctx->ring_cap);
   ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
   ctx->stats.launches = 1;
-  if (getenv("MNAV_VERBOSE"))
-    fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, claim fails %u, idle passes %u\n", n, G, ctx->ms_chunks, h.abort, h.claim_fails, h.idle_passes);
+  if (opt_on(ctx->opt.verbose))
+    fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, tickets %u, polls %u, retired beyond the bound %u\n", n, G, ctx->ms_chunks, h.abort, h.tail, h.polls, h.dropped);
   if (h.abort == 3u || ctx->cancel.load(std::memory_order_relaxed)) return 1;   // :350-354
+  if (h.abort == 5u) return 2;                                         // out of ticket slots: the caller re-runs the call on the tile rounds
   if (h.abort) { ctx->err = "asynchronous tile engine gave up (in-kernel wall-clock guard)"; return -1; }
   if (h.done_plans != n) { ctx->err = "asynchronous tile engine left plans unfinished"; return -1; }
   if (!ctx->lazy_paths) launch_finalize(ctx, n);

@@ -228,20 +228,7 @@ __global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
 
 // One block of a Gauss-Seidel sweep: the target row is relaxed from up to 7 source rows (dijkstra :331).  No branch: the row is
 // rewritten unconditionally (old bits when nothing improved).
-struct TbBlk { uint32_t ya, raw, v[7]; u32x4 w0, w1; };
-__device__ __forceinline__ bool tb_retire(const TbBlk& B)
-{
-  const uint32_t acc0 = B.raw & 0x7fffffffu;
-  const uint32_t t0 = f2u(fabsf(u2f(B.v[0])) + u2f(B.w0.x)), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(B.w0.y));
-  const uint32_t t2 = f2u(fabsf(u2f(B.v[2])) + u2f(B.w0.z)), t3 = f2u(fabsf(u2f(B.v[3])) + u2f(B.w0.w));
-  const uint32_t t4 = f2u(fabsf(u2f(B.v[4])) + u2f(B.w1.x)), t5 = f2u(fabsf(u2f(B.v[5])) + u2f(B.w1.y));
-  const uint32_t t6 = f2u(fabsf(u2f(B.v[6])) + u2f(B.w1.z));
-  uint32_t acc = min(min(acc0, t0), t1);
-  acc = min(min(acc, t2), t3); acc = min(min(acc, t4), t5); acc = min(acc, t6);
-  const bool ch = acc < acc0;
-  tb::ldsw(B.ya, ch ? (acc | kTbDirty) : B.raw);
-  return ch;
-}
+struct TbBlk { uint32_t ya, raw, v[7]; };
 
 #ifdef MNAV_TB_TIMING                      // debugging aid: cycles per phase of k_tb_solve_q, summed over all waves
 __device__ unsigned long long g_tb_timing[8];
@@ -301,146 +288,86 @@ struct QStream {
 };
 }  // namespace tb
 
-template <int T>
-__device__ __forceinline__ unsigned long long tbq_sweep(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t max_nch,
-                                                        uint32_t stage_q, uint32_t l16, uint32_t lane4)
+// One Gauss-Seidel sweep of a quarter's tile.  The sweep chunks are stored transposed (mnav_tb_build.h, tb_sweep_index): lane l
+// of a quarter loads the 16 bytes l of the quarter's chunk -- register k of the load holds dword l of block k in lane l -- and
+// every descriptor dword is consumed as a DPP operand of the instruction that needs it (row_newbcast:q = lane q of each 16-lane
+// row, i.e. of each quarter, broadcast to the row): v_add_u32_dpp for the eight LDS addresses, v_add_f32_dpp with |.| on the
+// other operand for the seven relaxations.  No LDS staging, no descriptor reads: the LDS carries the eight data reads and the
+// one write of a block and nothing else (before: four broadcast ds_read_b128 per block on top, two thirds of the kernel's LDS
+// cycles -- profiles/r05_c2_sq.md).  The two chunks after the current one are in registers or in flight.
+namespace tb {
+template <int Q> __device__ __forceinline__ uint32_t bc(uint32_t d)   // dword Q of the block whose descriptor register is d
 {
-  unsigned long long any = 0ull;
-  tb::QStream S; S.begin(stream, chunk_off, nch, stage_q, l16);
-  for (uint32_t c = 0; c < max_nch; ++c) {
-    u32x4 d[kTbBlocksPerChunk][4];
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(stage_q + 64 * j + 16 * q);
-    S.advance();
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-      TbBlk B;
-      B.w0 = d[j][2]; B.w1 = d[j][3];
-      B.ya = d[j][0].x + lane4;
-      B.raw = tb::ldsr(B.ya);
-      B.v[0] = tb::ldsr(d[j][0].y + lane4); B.v[1] = tb::ldsr(d[j][0].z + lane4); B.v[2] = tb::ldsr(d[j][0].w + lane4);
-      B.v[3] = tb::ldsr(d[j][1].x + lane4); B.v[4] = tb::ldsr(d[j][1].y + lane4); B.v[5] = tb::ldsr(d[j][1].z + lane4);
-      B.v[6] = tb::ldsr(d[j][1].w + lane4);
-      any |= __ballot(tb_retire(B));
-    }
-  }
-  return any;
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x150 + Q, 0xf, 0xf, true);   // row_newbcast:Q, folded into the consumer
 }
+}  // namespace tb
 
-// The pipelined sweep (opt-in, MNAV_TB_PIPE=1 when the streams are built; NOT YET RUN ON HARDWARE).  In tbq_sweep the LDS reads of
-// block j + 1 are issued after block j's write (the compiler cannot know that they touch other rows), so every block pays a full
-// LDS round trip on top of its arithmetic.  Here the reads of block j + 1 are issued BEFORE block j is retired: the stream builder
-// guarantees that two adjacent blocks of a chunk never write the same row, and marks (d15, slot 1) the one source of block j + 1
-// that is the row block j writes -- that value is taken from block j's registers.  Every value a block sees is the value the
-// Gauss-Seidel sweep of tbq_sweep sees: same sweeps, same bits (oracle/tb_model.cpp emulates exactly this read order).  The pipeline
-// is drained at the end of every chunk (the descriptors of the next chunk are not there yet).
-__device__ __forceinline__ bool tb_retire_fwd(const TbBlk& B, uint32_t& written)
+__device__ __forceinline__ bool tb_block(uint32_t D, uint32_t lane4)
 {
+  TbBlk B;
+  B.ya = tb::bc<0>(D) + lane4;
+  B.raw = tb::ldsr(B.ya);
+  B.v[0] = tb::ldsr(tb::bc<1>(D) + lane4); B.v[1] = tb::ldsr(tb::bc<2>(D) + lane4); B.v[2] = tb::ldsr(tb::bc<3>(D) + lane4);
+  B.v[3] = tb::ldsr(tb::bc<4>(D) + lane4); B.v[4] = tb::ldsr(tb::bc<5>(D) + lane4); B.v[5] = tb::ldsr(tb::bc<6>(D) + lane4);
+  B.v[6] = tb::ldsr(tb::bc<7>(D) + lane4);
   const uint32_t acc0 = B.raw & 0x7fffffffu;
-  const uint32_t t0 = f2u(fabsf(u2f(B.v[0])) + u2f(B.w0.x)), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(B.w0.y));
-  const uint32_t t2 = f2u(fabsf(u2f(B.v[2])) + u2f(B.w0.z)), t3 = f2u(fabsf(u2f(B.v[3])) + u2f(B.w0.w));
-  const uint32_t t4 = f2u(fabsf(u2f(B.v[4])) + u2f(B.w1.x)), t5 = f2u(fabsf(u2f(B.v[5])) + u2f(B.w1.y));
-  const uint32_t t6 = f2u(fabsf(u2f(B.v[6])) + u2f(B.w1.z));
+  const uint32_t t0 = f2u(fabsf(u2f(B.v[0])) + u2f(tb::bc<8>(D))), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(tb::bc<9>(D)));
+  const uint32_t t2 = f2u(fabsf(u2f(B.v[2])) + u2f(tb::bc<10>(D))), t3 = f2u(fabsf(u2f(B.v[3])) + u2f(tb::bc<11>(D)));
+  const uint32_t t4 = f2u(fabsf(u2f(B.v[4])) + u2f(tb::bc<12>(D))), t5 = f2u(fabsf(u2f(B.v[5])) + u2f(tb::bc<13>(D)));
+  const uint32_t t6 = f2u(fabsf(u2f(B.v[6])) + u2f(tb::bc<14>(D)));
   uint32_t acc = min(min(acc0, t0), t1);
   acc = min(min(acc, t2), t3); acc = min(min(acc, t4), t5); acc = min(acc, t6);
   const bool ch = acc < acc0;
-  written = ch ? (acc | kTbDirty) : B.raw;
-  tb::ldsw(B.ya, written);
+  tb::ldsw(B.ya, ch ? (acc | kTbDirty) : B.raw);
   return ch;
 }
 
+// All sweeps of an activation as ONE stream of chunks: three chunk registers in rotation, the load cursor three chunks ahead of the
+// compute cursor and running on into the next sweep's order while the current sweep finishes (speculatively: when the sweep turns
+// out to have changed nothing, the three loads in flight are dropped) -- no stall at a sweep boundary.  Each load is followed by
+// an empty memory-clobbering asm statement: without it the compiler sinks the load to its use three chunks later (a full memory
+// latency per three chunks, seen in the ISA); with it the load is issued where it is written and waited for where it is used.
+// A quarter past the end of its own stream re-runs its last chunk.  Returns the number of sweeps (the last one changed nothing in
+// any lane), or 0 with `overrun` set when the cap was hit.
 template <int T>
-__device__ __forceinline__ unsigned long long tbq_sweep_pipe(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t max_nch,
-                                                             uint32_t stage_q, uint32_t l16, uint32_t lane4)
+__device__ __forceinline__ uint32_t tbq_sweeps(MNAV_GLOBAL const uint32_t* stream, uint32_t sweep_off, uint32_t nch, uint32_t max_nch, uint32_t first_order,
+                                               uint32_t l16, uint32_t lane4, bool& overrun)
 {
-  unsigned long long any = 0ull;
-  tb::QStream S; S.begin(stream, chunk_off, nch, stage_q, l16);
-  for (uint32_t c = 0; c < max_nch; ++c) {
-    u32x4 d[kTbBlocksPerChunk][4];
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(stage_q + 64 * j + 16 * q);
-    S.advance();
-    TbBlk B[kTbBlocksPerChunk];
-    auto issue = [&](int j) {
-      B[j].w0 = d[j][2]; B[j].w1 = d[j][3];
-      B[j].ya = d[j][0].x + lane4;
-      B[j].raw = tb::ldsr(B[j].ya);
-      B[j].v[0] = tb::ldsr(d[j][0].y + lane4); B[j].v[1] = tb::ldsr(d[j][0].z + lane4); B[j].v[2] = tb::ldsr(d[j][0].w + lane4);
-      B[j].v[3] = tb::ldsr(d[j][1].x + lane4); B[j].v[4] = tb::ldsr(d[j][1].y + lane4); B[j].v[5] = tb::ldsr(d[j][1].z + lane4);
-      B[j].v[6] = tb::ldsr(d[j][1].w + lane4);
-    };
-    issue(0);
-    uint32_t written = 0u;
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-      if (j + 1 < (int)kTbBlocksPerChunk) issue(j + 1);              // in flight while block j is retired
-      if (j > 0 && (B[j].w1.w & 1u)) B[j].v[0] = written;            // the marked source: the row block j - 1 has just written
-      any |= __ballot(tb_retire_fwd(B[j], written));
-    }
-  }
-  return any;
-}
-
-// Level 2 of the same idea (MNAV_TB_PIPE=2, streams with cross-chunk forward marks): the pipeline is NOT drained at the chunk ends.
-// The descriptors of chunk c + 1 sit in a second register set while chunk c is retired (the kernel's occupancy is bound by its LDS
-// image, not by registers), block 0 of chunk c + 1 is issued while block 3 of chunk c retires, and its marked source comes from that
-// block's registers -- unless this quarter is past the end of its own stream and re-runs its last chunk (then block 0 follows the
-// SAME chunk's block 3: no forwarding; the builder makes those two write different rows, and a relaxation re-applied to values that
-// are at most one write old changes nothing).
-template <int T>
-__device__ __forceinline__ unsigned long long tbq_sweep_pipe2(MNAV_GLOBAL const uint32_t* stream, uint32_t chunk_off, uint32_t nch, uint32_t max_nch,
-                                                              uint32_t stage_q, uint32_t l16, uint32_t lane4)
-{
-  unsigned long long any = 0ull;
-  tb::QStream S; S.begin(stream, chunk_off, nch, stage_q, l16);
-  u32x4 da[kTbBlocksPerChunk][4], db[kTbBlocksPerChunk][4];
-  auto read_desc = [&](u32x4 (&d)[kTbBlocksPerChunk][4]) {
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) d[j][q] = tb::ldsr4(stage_q + 64 * j + 16 * q);
+  MNAV_GLOBAL const u32x4* const st0 = (MNAV_GLOBAL const u32x4*)(stream + (size_t)sweep_off * kTbChunk) + l16;   // this lane's 16 bytes of chunk 0 of order 0
+  const uint32_t last = nch ? nch - 1u : 0u;
+  uint32_t s_ld = 0, c_ld = 0;                                       // load cursor: sweep, chunk (wave-uniform)
+  auto load = [&](u32x4& R) {
+    MNAV_GLOBAL const u32x4* const p = st0 + ((size_t)((s_ld + first_order) & 3u) * nch + min(c_ld, last)) * 16u;
+    R = *p;
+    asm volatile("" ::: "memory");                                    // pins the load here: written plainly, the compiler sinks it to its use three chunks later
+    if (++c_ld >= max_nch) { c_ld = 0; ++s_ld; }
   };
-  auto issue = [&](TbBlk& B, const u32x4 (&d)[kTbBlocksPerChunk][4], int j) {
-    B.w0 = d[j][2]; B.w1 = d[j][3];
-    B.ya = d[j][0].x + lane4;
-    B.raw = tb::ldsr(B.ya);
-    B.v[0] = tb::ldsr(d[j][0].y + lane4); B.v[1] = tb::ldsr(d[j][0].z + lane4); B.v[2] = tb::ldsr(d[j][0].w + lane4);
-    B.v[3] = tb::ldsr(d[j][1].x + lane4); B.v[4] = tb::ldsr(d[j][1].y + lane4); B.v[5] = tb::ldsr(d[j][1].z + lane4);
-    B.v[6] = tb::ldsr(d[j][1].w + lane4);
-  };
-  uint32_t written = 0u;
-  TbBlk carry;                                                       // block 0 of the chunk that is processed next, already issued
-  // one chunk: `d` its descriptors, `dn` those of the next chunk (valid when has_next); c = its index in the longest stream
-  auto chunk = [&](const u32x4 (&d)[kTbBlocksPerChunk][4], const u32x4 (&dn)[kTbBlocksPerChunk][4], bool has_next, uint32_t c) {
-    TbBlk B[kTbBlocksPerChunk];
-    B[0] = carry;
-    const bool fwd0 = c > 0u && c < nch;                            // block 0 follows the PREVIOUS chunk's block 3 (not a re-run of this quarter's last chunk)
-#pragma unroll
-    for (int j = 0; j < (int)kTbBlocksPerChunk; ++j) {
-      if (j + 1 < (int)kTbBlocksPerChunk) issue(B[j + 1], d, j + 1);
-      else if (has_next) issue(carry, dn, 0);
-      if ((B[j].w1.w & 1u) && (j > 0 || fwd0)) B[j].v[0] = written;
-      any |= __ballot(tb_retire_fwd(B[j], written));
+  unsigned long long any = 0ull;
+  uint32_t sweep = 0, c = 0;
+  overrun = false;
+  bool done = false;
+  auto step = [&](u32x4& R) {
+    any |= __ballot(tb_block(R.x, lane4)); any |= __ballot(tb_block(R.y, lane4));
+    any |= __ballot(tb_block(R.z, lane4)); any |= __ballot(tb_block(R.w, lane4));
+    load(R);
+    if (++c >= max_nch) {
+      c = 0; ++sweep;
+      if (any == 0ull) done = true;
+      else if (sweep >= 16u * T) { overrun = true; done = true; }
+      any = 0ull;
     }
   };
-  read_desc(da); S.advance();                                       // staging now holds chunk 1
-  if (max_nch > 1u) { read_desc(db); S.advance(); }                  // ... chunk 2
-  issue(carry, da, 0);
-  for (uint32_t c = 0; c < max_nch; c += 2u) {
-    chunk(da, db, c + 1u < max_nch, c);
-    if (c + 1u >= max_nch) break;
-    if (c + 2u < max_nch) { read_desc(da); S.advance(); }            // chunk c + 2 (its block 0 is issued at the end of chunk c + 1)
-    chunk(db, da, c + 2u < max_nch, c + 1u);
-    if (c + 3u < max_nch) { read_desc(db); S.advance(); }
+  u32x4 A, B, C;
+  load(A); load(B); load(C);
+  for (;;) {
+    step(A); if (done) break;
+    step(B); if (done) break;
+    step(C); if (done) break;
   }
-  return any;
+  return sweep;
 }
 
-template <int T, int PIPE>
+template <int T>
 __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
 {
 #ifdef MNAV_TB_TIMING
@@ -551,16 +478,9 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
       }
       TB_STAMP(2);
       // ---- Gauss-Seidel sweeps to the tile-local fixed point of every quarter (a converged quarter changes nothing any more)
-      uint32_t sweep = 0;
-      for (;;) {
-        const uint32_t off = W.sweep_off + ((sweep + first_order) & 3u) * W.sweep_chunks;
-        const unsigned long long any = PIPE == 2 ? tbq_sweep_pipe2<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4)
-                                     : PIPE == 1 ? tbq_sweep_pipe<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4)
-                                                 : tbq_sweep<T>(stream, off, W.sweep_chunks, max_sweep, stage_q, l16, lane4);
-        ++sweep;
-        if (any == 0ull) break;
-        if (sweep >= 16u * T) { if (lane == 0) A.ctl->err = 1u; break; }
-      }
+      bool overrun;
+      const uint32_t sweep = max_sweep ? tbq_sweeps<T>(stream, W.sweep_off, W.sweep_chunks, max_sweep, first_order, l16, lane4, overrun) : 1u;
+      if (max_sweep && overrun && lane == 0) A.ctl->err = 1u;
       my_sweeps += sweep;
       TB_STAMP(3);
       // ---- write back the 16-byte chunks that hold a lowered value
@@ -817,7 +737,6 @@ __global__ __launch_bounds__(kBlock) void k_popped(const float* __restrict__ dis
 // host-side state of the engine (device arrays of the mesh-dependent streams, and of the running batch)
 struct TbState {
   bool built = false, w_valid = false;
-  int pipe = 0;                         // streams with forward marks + the pipelined sweep (MNAV_TB_PIPE = 1: drained per chunk, 2: across chunks; opt-in)
   uint32_t T = 120, ntiles = 0, max_nh = 0;   // 120 rows x 256 B + staging = 31 232 B of LDS: five waves per CU (128 rows: four)
   uint64_t S = 0;                       // words per plan
   size_t nrec = 0, nexp = 0;

@@ -139,15 +139,15 @@ inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k
 }
 }  // namespace detail
 
-// forward_marks (the pipelined sweep, k_tb_solve_q<T, true>: opt-in): a block whose sources include the row the PREVIOUS block of its
-// chunk writes gets that source moved to slot 1 and d15 = 1.  The pipelined sweep issues the LDS reads of block j + 1 before block
-// j's result is written and takes a marked source from block j's registers instead: the same Gauss-Seidel values, one LDS round
-// trip less on the critical path of every block.  (Two adjacent blocks of a chunk never write the same row: see below.)  The
-// ordinary sweep ignores slot order and d15.  Level 2 extends both guarantees across the chunk boundaries of a sweep order (block 0 of
-// a chunk against block 3 of the chunk before it) for a pipeline that is not drained at the chunk ends, and makes the first and the
-// last block of every order's LAST chunk write different rows (a quarter of a wave whose stream is shorter than its neighbours'
-// re-runs its last chunk: its block 0 then follows its own block 3).
-inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, int forward_marks = 0)
+// SWEEP chunks are stored TRANSPOSED: dword q of block j of a chunk sits at chunk dword 4 * q + j.  Lane l of a 16-lane
+// quarter loads the 16 bytes l of its quarter's chunk -- one VGPR per block, holding dword l of that block in lane l -- and
+// the sweep consumes a descriptor dword as a DPP operand (row_newbcast:q broadcasts lane q of every 16-lane row to the row):
+// the block descriptors never pass through the LDS (they were two thirds of the kernel's LDS traffic: four broadcast
+// ds_read_b128 per block against eight ds_read_b32 of data).  The ghost and export streams keep the plain layout (block j =
+// dwords 16 j .. 16 j + 15; they are parked in the LDS staging area).
+inline uint32_t tb_sweep_index(uint32_t j, uint32_t q) { return 4u * q + j; }
+
+inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
 {
   if (T == 0 || T > 255 || (T & 3)) throw std::invalid_argument("tile-batch engine: T must be a multiple of 4 below 256");
   HostTb H;
@@ -201,9 +201,9 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, int 
   // Every sweep block rewrites its target row (with the bits it read when nothing improved); two ADJACENT blocks of a chunk
   // never have the same target, so that a kernel may have the reads of block j+1 in flight before block j's result is
   // written (tried and dropped: +24 % sweeps).  `last_target` = target row of the previous block of the open chunk.
-  uint32_t last_target = kNone, chunk_first = kNone;                 // chunk_first: the row block 0 of the open chunk writes
+  uint32_t last_target = kNone;
   auto open_block = [&]() -> size_t {                                // returns the dword index of the new block
-    if (in_chunk == kTbBlocksPerChunk) { in_chunk = 0; chunk_first = kNone; if (forward_marks < 2) last_target = kNone; }
+    if (in_chunk == kTbBlocksPerChunk) { in_chunk = 0; last_target = kNone; }
     const size_t at = H.stream.size();
     H.stream.resize(at + kTbBlock, 0u); H.wsrc.resize(at + kTbBlock, kNone);
     ++in_chunk;
@@ -214,18 +214,15 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, int 
     for (int q = 8; q <= 14; ++q) H.stream[at + q] = kTbInfBits;
   };
   auto noop_sweep_block = [&]() {                                    // all weights +inf, on a row the previous block did not target
-    uint32_t row = (last_target == 0u) ? 1u : 0u;
-    // (level 2: a do-nothing block that closes a chunk must not write the row the chunk's first block writes either)
-    if (forward_marks >= 2 && in_chunk == kTbBlocksPerChunk - 1u) for (row = 0u; row == last_target || row == chunk_first; ++row) { }
+    const uint32_t row = (last_target == 0u) ? 1u : 0u;
     const size_t at = open_block();
     init_sweep_block(at, row);
-    if (in_chunk == 1u) chunk_first = row;
     last_target = row;
   };
   auto close_chunk = [&](bool sweep) {                               // pad the open chunk
     if (in_chunk == 0) return;
     while (in_chunk < kTbBlocksPerChunk) { if (sweep) noop_sweep_block(); else open_block(); }
-    in_chunk = 0; last_target = kNone; chunk_first = kNone;
+    in_chunk = 0; last_target = kNone;
   };
   std::vector<uint16_t> order;
   std::vector<uint32_t> ts;
@@ -260,9 +257,8 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, int 
           const uint32_t u = t.nbr_u[k];
           if (H.vert_tile[u] != tl) continue;
           if (n == 0) {
-            if ((forward_marks >= 2 || (in_chunk != kTbBlocksPerChunk && in_chunk != 0)) && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
+            if (in_chunk != kTbBlocksPerChunk && in_chunk != 0 && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
             at = open_block();
-            if (in_chunk == 1u) chunk_first = y;
             last_target = y;
             init_sweep_block(at, y);
           }
@@ -285,39 +281,27 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T, int 
         st2.insert(st2.end(), H.stream.begin() + src, H.stream.begin() + src + len);
         ws2.insert(ws2.end(), H.wsrc.begin() + src, H.wsrc.begin() + src + len);
         src += len;
-        // (level 2: the first do-nothing block must not write the row the block before it writes)
-        uint32_t flip = 0u;
-        if (forward_marks >= 2 && order_chunks[o] > 0 && order_chunks[o] < W.sweep_chunks && st2[st2.size() - kTbBlock] == 0u) flip = 1u;
         for (uint32_t c = order_chunks[o]; c < W.sweep_chunks; ++c)
           for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
             const size_t at = st2.size();
             st2.resize(at + kTbBlock, 0u); ws2.resize(at + kTbBlock, kNone);
-            for (int q = 0; q <= 7; ++q) st2[at + q] = ((j & 1u) ^ flip) * kRow;
+            for (int q = 0; q <= 7; ++q) st2[at + q] = (j & 1u) * kRow;
             for (int q = 8; q <= 14; ++q) st2[at + q] = kTbInfBits;
           }
       }
       H.stream.resize((size_t)W.sweep_off * kTbChunk); H.wsrc.resize((size_t)W.sweep_off * kTbChunk);
       H.stream.insert(H.stream.end(), st2.begin(), st2.end()); H.wsrc.insert(H.wsrc.end(), ws2.begin(), ws2.end());
     }
-    if (forward_marks) {
-      for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c) {
-        const bool first_of_order = ((c - W.sweep_off) % std::max(W.sweep_chunks, 1u)) == 0;
-        if (forward_marks >= 2 && ((c - W.sweep_off) % std::max(W.sweep_chunks, 1u)) == W.sweep_chunks - 1u &&
-            H.stream[c * kTbChunk] == H.stream[c * kTbChunk + 3 * kTbBlock])
-          throw std::logic_error("tile-batch streams: the last chunk of a sweep order starts and ends on the same row");
-        for (uint32_t j = (forward_marks >= 2 && !first_of_order) ? 0u : 1u; j < kTbBlocksPerChunk; ++j) {
-          uint32_t* K = &H.stream[c * kTbChunk + kTbBlock * j];
-          uint32_t* Ws = &H.wsrc[c * kTbChunk + kTbBlock * j];
-          const uint32_t prev = K[-(int)kTbBlock];                     // row the previous block of the chunk writes
-          if (K[0] == prev) throw std::logic_error("tile-batch streams: adjacent blocks of a chunk write the same row");
-          for (int q = 1; q <= 7; ++q)
-            if (K[q] == prev && Ws[7 + q] != kNone) {                  // a real edge from that row (unused slots hold the block's own row)
-              std::swap(K[q], K[1]); std::swap(K[7 + q], K[8]); std::swap(Ws[7 + q], Ws[8]);
-              K[15] = 1u;
-              break;
-            }
+    // transpose the tile's sweep chunks (tb_sweep_index): built block by block above, read lane by lane by the kernel
+    for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c) {
+      uint32_t tmp[kTbChunk], tmpw[kTbChunk];
+      std::copy(H.stream.begin() + c * kTbChunk, H.stream.begin() + (c + 1) * kTbChunk, tmp);
+      std::copy(H.wsrc.begin() + c * kTbChunk, H.wsrc.begin() + (c + 1) * kTbChunk, tmpw);
+      for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j)
+        for (uint32_t q = 0; q < kTbBlock; ++q) {
+          H.stream[c * kTbChunk + tb_sweep_index(j, q)] = tmp[kTbBlock * j + q];
+          H.wsrc[c * kTbChunk + tb_sweep_index(j, q)] = tmpw[kTbBlock * j + q];
         }
-      }
     }
     // which of the four sweep orders runs WITH a wave that enters through ghost gv: the one whose direction has the largest
     // component along (tile centroid - ghost position).  The solve starts its sweeps with the order most lanes ask for.

@@ -34,14 +34,13 @@ int tb_build(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
   if (S.built) return 0;
-  if (const char* e = getenv("MNAV_TB_TILE")) S.T = (uint32_t)atoi(e);
+  if (opt_set(ctx->opt.tb_tile)) S.T = opt_u32(ctx->opt.tb_tile, S.T);
   if (S.T != 64 && S.T != 96 && S.T != 120 && S.T != 128) S.T = 120;
   HostTopology t;
   t.V = ctx->V; t.E = ctx->E; t.F = ctx->F;
   t.row_ptr = ctx->h_row_ptr; t.nbr_u = ctx->h_nbr_u;
   HostTb H;
-  S.pipe = getenv("MNAV_TB_PIPE") ? std::min(std::max(atoi(getenv("MNAV_TB_PIPE")), 0), 2) : 0;   // opt-in experiments (mnav_tb.h: tbq_sweep_pipe / _pipe2)
-  try { H = build_tb(t, ctx->h_xyz.data(), S.T, S.pipe); }
+  try { H = build_tb(t, ctx->h_xyz.data(), S.T); }
   catch (const std::exception& ex) { ctx->err = ex.what(); return -1; }
   std::vector<uint2> vaddr(ctx->V);
   for (uint32_t v = 0; v < ctx->V; ++v) {
@@ -60,7 +59,7 @@ int tb_build(mnav_ctx* ctx)
   S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.stream.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
   S.vert_tile = std::move(H.vert_tile);
   S.built = true; S.w_valid = false;
-  if (getenv("MNAV_VERBOSE"))
+  if (opt_on(ctx->opt.verbose))
     fprintf(stderr, "[mnav] tile-batch engine: T %u, %u tiles, %.2f slots per vertex, max ghosts %u, %.1f MB of streams\n", S.T, S.ntiles,
             ctx->V ? (double)S.S / ctx->V : 0.0, S.max_nh, (4.0 * S.nrec + 16.0 * S.nexp) / 1e6);
   return 0;
@@ -83,7 +82,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   tb_free_batch(ctx);
   const size_t nt = S.ntiles ? S.ntiles : 1, pairs = nt * (size_t)np;
   HIPCHK(hipMalloc((void**)&S.D, 4 * (size_t)S.S * np + 64));
-  if (8 * (size_t)S.S * np <= ((size_t)96 << 30) && !getenv("MNAV_TB_NO_PREFILL")) {
+  if (8 * (size_t)S.S * np <= ((size_t)96 << 30) && !opt_on(ctx->opt.tb_no_prefill)) {
     if (hipMalloc((void**)&S.D2, 4 * (size_t)S.S * np + 64) != hipSuccess) { S.D2 = nullptr; (void)hipGetLastError(); }
     if (S.D2 && !S.fill_stream) { HIPCHK(hipStreamCreateWithFlags(&S.fill_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&S.fill_done, hipEventDisableTiming)); }
   }
@@ -121,22 +120,10 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_scan, dim3(gp, (A.ntiles + kTbScanTiles - 1) / kTbScanTiles), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
-    if (ctx->tb.pipe == 2) {                                         // the pipelined sweeps on streams with forward marks (opt-in)
-      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else hipLaunchKernelGGL((k_tb_solve_q<128, 2>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    } else if (ctx->tb.pipe == 1) {
-      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else hipLaunchKernelGGL((k_tb_solve_q<128, 1>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    } else {
-      if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-      else hipLaunchKernelGGL((k_tb_solve_q<128, 0>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
-    }
+    if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    else hipLaunchKernelGGL((k_tb_solve_q<128>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -210,7 +197,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   A.offset = offset;
   {
     float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * S.band_mult;   // potential across one tile
-    if (const char* e = getenv("MNAV_TB_BAND_MULT")) band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * (float)atof(e);
+    if (opt_set(ctx->opt.tb_band_mult)) band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * (float)ctx->opt.tb_band_mult;
     if (ctx->tile_band_user > 0.f) band = ctx->tile_band_user;
     A.band = band;
   }
@@ -248,7 +235,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
   uint32_t per_cu = (uint32_t)((160u * 1024u) / (S.T * 256u + kTbQStride * 4u));   // LDS: T x 256 bytes + staging per wave, 160 KB per CU
-  if (const char* e = getenv("MNAV_TB_WAVES_PER_CU")) S.waves_per_cu = atoi(e);
+  if (opt_set(ctx->opt.tb_waves_per_cu)) S.waves_per_cu = (int)ctx->opt.tb_waves_per_cu;
   if (S.waves_per_cu > 0) per_cu = (uint32_t)S.waves_per_cu;
   const uint32_t waves = per_cu * (uint32_t)ncu;
   const int chunk = S.iters_per_replay & ~1;
@@ -297,7 +284,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   S.last = *S.h_ctl;
   ctx->stats.launches = 1;                                           // one engine run per batch (iterations: stats.steps)
   ctx->tb_args = A; ctx->tb_args_valid = (rc == 0);
-  if (getenv("MNAV_TRACE"))
+  if (opt_on(ctx->opt.trace))
     fprintf(stderr, "[mnav] tile-batch: %u iterations, %llu activations (%.1f per item), %llu items, %.2f sweeps per item, %llu wakes\n", S.h_ctl->iters,
             S.h_ctl->acts, S.h_ctl->items ? (double)S.h_ctl->acts / S.h_ctl->items : 0.0, S.h_ctl->items,
             S.h_ctl->items ? (double)S.h_ctl->sweeps / S.h_ctl->items : 0.0, S.h_ctl->wakes);

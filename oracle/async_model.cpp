@@ -2,16 +2,17 @@
 //
 // TEST INFRASTRUCTURE ONLY (lives under oracle/): never linked into, loaded by, or reachable from the product library.
 //
-// The engine has no rounds: workgroups claim tiles, solve them and wake their neighbours concurrently, and a plan is
-// finished when a counter of pending-or-in-solve tiles reaches zero.  What can go wrong there is the protocol -- a lost
-// wake-up, a premature "finished", two solvers on one tile, a wake-up consumed by a solve whose band does not hold it --
-// not the tile solve (k_tile_round's, tested on the device).  This model restates k_plan_async operation by operation
-// (same words, same order of the shared-memory operations, same decisions) on the tile tables the product builds
-// (mnav_build.h::build_tiles) and runs W virtual workgroups as threads of which exactly ONE runs at a time: before every
-// shared-memory operation a workgroup hands the baton to a pseudo-randomly chosen one (seeded: reproducible), so a test
-// sweeps thousands of different interleavings at the granularity of single atomics.  Checked while it runs: at every
-// plan_finish no tile of the plan is pending, locked or in solve, and it happens once per plan; never two solvers on a
-// tile.  Checked by the test: the distances against the sequential oracle.
+// The engine has no rounds and no scans: workgroups serve a TICKET QUEUE of woken tiles, solve them and wake their neighbours
+// concurrently; the first waker of an idle tile files its ticket, and a plan is finished when its count of filed-and-not-retired
+// tickets reaches zero.  What can go wrong there is the protocol -- a lost wake-up (a tile woken while it is in solve that nobody
+// files again), a premature "finished", two solvers on one tile, a ticket filed twice -- not the tile solve (k_tile_round's, tested
+// on the device).  This model restates k_plan_async operation by operation (same words, same order of the shared-memory
+// operations, same decisions) on the tile tables the product builds (mnav_build.h::build_tiles) and runs W virtual workgroups as
+// threads of which exactly ONE runs at a time: before every shared-memory operation a workgroup hands the baton to a
+// pseudo-randomly chosen one (seeded: reproducible), so a test sweeps thousands of different interleavings at the granularity of
+// single atomics.  Checked while it runs: at every plan_finish no tile of the plan is pending, queued or in solve, and it happens
+// once per plan; never two solvers on a tile; never two live tickets of one tile.  Checked by the test: the distances against the
+// sequential oracle.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -32,7 +33,8 @@ constexpr uint32_t kInf = 0x7f800000u;
 constexpr uint32_t kWakeSlots = 32;       // kAsyncWake
 
 struct PlanState {
-  std::vector<uint32_t> dist, pend, lock, tlast;   // float bits
+  std::vector<uint32_t> dist, pend, lock, tlast;   // float bits; lock = the state word (1: a ticket is filed or the tile is in solve)
+  std::vector<uint8_t> ticketed;                   // model only: a ticket of the tile is in the ring and not yet retired
   uint32_t work = 1, acts = 0, sweeps = 0, done = 0, finishes = 0;
   uint32_t seed = 0, target = 0;
   std::vector<uint8_t> in_solve;                   // model only: a workgroup is between claim and unlock
@@ -48,9 +50,10 @@ struct Model {
   int turn = 0; std::vector<uint8_t> alive; std::mt19937 rng;
   uint64_t yields = 0, claim_fails = 0, drops = 0, violations = 0, solves_now = 0, max_solves = 0, putbacks = 0, raised = 0;
   uint32_t done_plans = 0, abort = 0;
+  std::vector<uint32_t> ring; uint32_t head = 0, tail = 0;           // the ticket ring (kTicketNone = not filed yet)
   uint64_t budget = 0;                             // yield budget: the model's wall-clock guard
-  // deliberately broken variants, to show that the checks see protocol errors (tests/test_async_model.py): 1 = a waker counts the
-  // tile AFTER its atomicMin, 2 = no lock (two solvers on a tile)
+  // deliberately broken variants, to show that the checks see protocol errors (tests/test_async_model.py): 2 = the solver does not look at the wake-up value again after clearing the state word (a wake-up that
+  // arrived during the solve is lost), 3 = wakers file a ticket whatever the state word says (two solvers on a tile)
   uint32_t mutate = 0;
 
   // Uniformly random hand-offs almost never stall ONE workgroup for the length of another one's whole solve -- the windows
@@ -100,100 +103,73 @@ struct Wg {
   uint32_t xchg(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = v; return o; }
   bool cas(uint32_t& w, uint32_t e, uint32_t v) { M.pass(me); if (w != e) return false; w = v; return true; }
 
+  uint32_t aor(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = o | v; return o; }
+  uint32_t aand(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = o & v; return o; }
+
   void plan_finish(PlanState& P)
   {
-    // model-only checks, on a consistent snapshot (nobody else runs): nothing of the plan is pending, locked or in solve
+    // model-only checks, on a consistent snapshot (nobody else runs): nothing of the plan is pending, queued or in solve
     for (size_t t = 0; t < P.pend.size(); ++t)
-      if (P.pend[t] != kInf || P.lock[t] != kInf || P.in_solve[t]) ++M.violations;
+      if (P.pend[t] != kInf || P.lock[t] != 0u || P.in_solve[t] || P.ticketed[t]) ++M.violations;
     if (P.work != 0) ++M.violations;
     ++P.finishes;
-    st(P.done, 1u);
     add(M.done_plans, 1u);
   }
-  void work_dec(PlanState& P, bool& fin) { if (sub(P.work, 1u) == 1u) fin = true; }
-  void wake(PlanState& P, bool& fin, uint32_t t2, uint32_t v)
+  void push(PlanState& P, uint32_t p, uint32_t t)
   {
-    if (M.mutate == 1u) { if (amin(P.pend[t2], v) == kInf) add(P.work, 1u); return; }
-    add(P.work, 1u);
-    if (amin(P.pend[t2], v) != kInf) work_dec(P, fin);
+    if (P.ticketed[t]) ++M.violations;                               // a second live ticket of the tile
+    P.ticketed[t] = 1;
+    add(P.work, 1u);                                                 // counted before it can be seen
+    const uint32_t i = add(M.tail, 1u);
+    if (i < M.ring.size()) st(M.ring[i], (p << 24) | t); else st(M.abort, 5u);
+  }
+  void wake(PlanState& P, uint32_t p, uint32_t t2, uint32_t v)
+  {
+    if (amin(P.pend[t2], v) != kInf) return;                         // pending already: whoever made it so files (or filed) the ticket
+    if (M.mutate == 3u) { aor(P.lock[t2], 1u); push(P, p, t2); return; }
+    if (aor(P.lock[t2], 1u) == 0u) push(P, p, t2);
   }
 
-  void run(uint32_t n, uint32_t home0)
+  void run(uint32_t n, uint32_t)
   {
     M.enter(me);
     const HostTiles& T = M.T;
-    uint32_t home = home0 % n, iter = 0;
     for (;;) {
-      // ---- leave?
-      std::vector<uint32_t> live;
-      for (uint32_t k = 0; k < std::min(n, 64u); ++k) { const uint32_t pi = (home + k) % n; if (!ld(M.plans[pi].done)) live.push_back(pi); }
-      if (ld(M.abort)) break;
-      if (ld(M.done_plans) >= n) break;
-      bool did = false;
-      for (size_t li = 0; li < live.size() && !did; ++li) {
-        PlanState& P = M.plans[live[li]];
-        ++iter;
-        bool fin = false;
-        // ---- scan 1 (element by element: the real scan is not a snapshot either)
-        uint32_t mn = kInf;
-        for (uint32_t t = 0; t < T.ntiles; ++t) mn = std::min(mn, ld(P.pend[t]));
-        const float dt = u2f(ld(P.dist[P.target]));
-        const float bound = (float)((double)dt + std::max(M.offset, 0.0));
-        if (mn == kInf) continue;
-        const float m = u2f(mn);
-        float thr = m + M.band;
-        if (!(thr > m)) thr = next_up(m);
-        // ---- scan 2
-        unsigned long long key = ~0ull;
-        const uint32_t salt = (uint32_t)(me + 1) * 0x9E3779B9u + iter * 0x85EBCA6Bu;
-        for (uint32_t t = 0; t < T.ntiles; ++t) {
-          const uint32_t pv = ld(P.pend[t]);
-          if (pv == kInf) continue;
-          const float p = u2f(pv);
-          if (p > bound) {
-            const uint32_t v = xchg(P.pend[t], kInf);
-            if (v == kInf) continue;
-            if (u2f(v) > bound) {
-              if (!(u2f(ld(P.tlast[t])) > -inf_f())) st(P.tlast[t], f2u(-3.0e38f));
-              ++M.drops;
-              work_dec(P, fin);
-            } else { ++M.putbacks; if (amin(P.pend[t], v) != kInf) work_dec(P, fin); }
-            continue;
-          }
-          if (p < thr) {
-            const unsigned long long h = ((unsigned long long)((t ^ salt) * 0x9E3779B1u) << 32) | t;
-            key = std::min(key, h);
-          }
+      // ---- the next ticket
+      const uint32_t i = add(M.head, 1u);
+      uint32_t e = kNone - 1u;                                       // kTicketExit
+      if (i < M.ring.size()) {
+        for (uint32_t spins = 0;; ++spins) {
+          e = ld(M.ring[i]);
+          if (e != kNone) break;
+          e = kNone - 1u;
+          if (ld(M.abort) || ld(M.done_plans) >= n) break;
+          e = kNone;
         }
-        if (fin) { plan_finish(P); fin = false; }
-        uint32_t pick = kNone;
-        if (key != ~0ull) {
-          const uint32_t t = (uint32_t)key;
-          if (M.mutate == 2u || cas(P.lock[t], kInf, 0u)) {
-            const uint32_t v = xchg(P.pend[t], kInf);
-            bool ok = v != kInf;
-            if (ok && u2f(v) > bound) {
-              if (!(u2f(ld(P.tlast[t])) > -inf_f())) st(P.tlast[t], f2u(-3.0e38f));
-              st(P.lock[t], kInf);
-              ++M.drops;
-              work_dec(P, fin);
-              ok = false;
-            } else if (!ok) st(P.lock[t], kInf);
-            if (ok) {
-              const float pv = u2f(v);
-              if (!(pv < thr)) { thr = pv + M.band; if (!(thr > pv)) thr = next_up(pv); ++M.raised; }
-              pick = t;
-              if (P.in_solve[t]) ++M.violations;                     // two solvers on one tile
-              P.in_solve[t] = 1;
-              if (++M.solves_now > M.max_solves) M.max_solves = M.solves_now;
-            }
-          }
-          if (pick == kNone) ++M.claim_fails;
-          if (fin) { plan_finish(P); fin = false; }
+      } else st(M.abort, 5u);
+      if (e == kNone - 1u) break;
+      const uint32_t p = e >> 24, t = e & 0xFFFFFFu;
+      PlanState& P = M.plans[p];
+      const uint32_t v = xchg(P.pend[t], kInf);
+      const float dt = u2f(ld(P.dist[P.target]));
+      const float bound = (float)((double)dt + std::max(M.offset, 0.0));
+      bool solve = false;
+      float thr = inf_f();
+      if (v != kInf) {
+        if (u2f(v) > bound) {
+          if (!(u2f(ld(P.tlast[t])) > -inf_f())) st(P.tlast[t], f2u(-3.0e38f));
+          ++M.drops;
+        } else {
+          solve = true;
+          const float pv = u2f(v);
+          if (M.band > 0.f && M.band < inf_f()) { thr = pv + M.band; if (!(thr > pv)) thr = next_up(pv); }
         }
-        if (pick == kNone) continue;
-        did = true;
-        const uint32_t t = pick;
+      }
+      uint32_t sweep = 0;
+      if (solve) {
+        if (P.in_solve[t]) ++M.violations;                           // two solvers on one tile
+        P.in_solve[t] = 1;
+        if (++M.solves_now > M.max_solves) M.max_solves = M.solves_now;
         // ---- solve (k_tile_round's: queue of sources below thr and the bound, min on the float bits)
         const uint32_t v0 = T.vptr[t], nv = T.vptr[t + 1] - v0;
         const uint32_t h0 = T.hptr[t], nh = T.hptr[t + 1] - h0;
@@ -202,25 +178,24 @@ struct Wg {
         std::vector<uint32_t> ldu(nv + nh), orig(nv), lh0(nh);
         std::vector<uint32_t> q, qn;
         std::vector<uint8_t> queued(nv, 0);
-        for (uint32_t i = 0; i < nv; ++i) {
-          orig[i] = ld(P.dist[T.verts[v0 + i]]); ldu[i] = orig[i];
-          const float d = u2f(orig[i]);
-          if (d < thr && d <= bound && !(d < tl)) q.push_back(i);
+        for (uint32_t k = 0; k < nv; ++k) {
+          orig[k] = ld(P.dist[T.verts[v0 + k]]); ldu[k] = orig[k];
+          const float d = u2f(orig[k]);
+          if (d < thr && d <= bound && !(d < tl)) q.push_back(k);
         }
-        for (uint32_t i = 0; i < nh; ++i) {
-          const uint32_t b = ld(P.dist[T.halo_verts[h0 + i]]); ldu[nv + i] = b; lh0[i] = b;
+        for (uint32_t k = 0; k < nh; ++k) {
+          const uint32_t b = ld(P.dist[T.halo_verts[h0 + k]]); ldu[nv + k] = b; lh0[k] = b;
           const float d = u2f(b);
-          if (d < thr && d <= bound) q.push_back(nv + i);
+          if (d < thr && d <= bound) q.push_back(nv + k);
         }
-        uint32_t sweep = 0;
         while (!q.empty()) {
           qn.clear(); std::fill(queued.begin(), queued.end(), 0);
           for (uint32_t x : q) {
             const float di = u2f(ldu[x]);
             if (!(di < thr) || !(di <= bound)) continue;
-            for (uint32_t e = T.rowptr[r0 + x]; e < T.rowptr[r0 + x + 1]; ++e) {
-              const uint32_t c = T.col[e0 + e];
-              const uint32_t nd = f2u(di + M.tw[e0 + e]);
+            for (uint32_t ed = T.rowptr[r0 + x]; ed < T.rowptr[r0 + x + 1]; ++ed) {
+              const uint32_t c = T.col[e0 + ed];
+              const uint32_t nd = f2u(di + M.tw[e0 + ed]);
               if (nd < ldu[c]) { ldu[c] = nd; if (c < nv && !queued[c]) { queued[c] = 1; qn.push_back(c); } }
             }
           }
@@ -228,36 +203,36 @@ struct Wg {
         }
         // ---- publish: distances, then (after the drain) the wake-ups
         uint32_t own_left = kInf;
-        for (uint32_t i = 0; i < nv; ++i) {
-          const uint32_t db = ldu[i];
-          if (db != orig[i]) st(P.dist[T.verts[v0 + i]], db);
+        for (uint32_t k = 0; k < nv; ++k) {
+          const uint32_t db = ldu[k];
+          if (db != orig[k]) st(P.dist[T.verts[v0 + k]], db);
           const float d = u2f(db);
           if (!(d < thr) && d <= bound) own_left = std::min(own_left, db);
         }
         uint32_t wt[kWakeSlots], wv[kWakeSlots]; bool over = false;
-        for (uint32_t s = 0; s < kWakeSlots; ++s) { wt[s] = kNone; wv[s] = kInf; }
-        auto collect = [&](uint32_t t2, uint32_t v) {
+        for (uint32_t sl = 0; sl < kWakeSlots; ++sl) { wt[sl] = kNone; wv[sl] = kInf; }
+        auto collect = [&](uint32_t t2, uint32_t val) {
           uint32_t slot = (t2 * 0x9E3779B1u) >> 27;
           for (uint32_t probe = 0; probe < kWakeSlots; ++probe, slot = (slot + 1u) & (kWakeSlots - 1u))
-            if (wt[slot] == kNone || wt[slot] == t2) { wt[slot] = t2; wv[slot] = std::min(wv[slot], v); return; }
+            if (wt[slot] == kNone || wt[slot] == t2) { wt[slot] = t2; wv[slot] = std::min(wv[slot], val); return; }
           over = true;
         };
-        for (uint32_t i = 0; i < nh; ++i) if (ldu[nv + i] < lh0[i]) collect(T.halo_tile[h0 + i], ldu[nv + i]);
+        for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) collect(T.halo_tile[h0 + k], ldu[nv + k]);
         if (own_left != kInf) collect(t, own_left);
-        for (uint32_t s = 0; s < kWakeSlots; ++s) if (wt[s] != kNone) wake(P, fin, wt[s], wv[s]);
+        for (uint32_t sl = 0; sl < kWakeSlots; ++sl) if (wt[sl] != kNone) wake(P, p, wt[sl], wv[sl]);
         if (over) {
-          for (uint32_t i = 0; i < nh; ++i) if (ldu[nv + i] < lh0[i]) wake(P, fin, T.halo_tile[h0 + i], ldu[nv + i]);
-          if (own_left != kInf) wake(P, fin, t, own_left);
+          for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) wake(P, p, T.halo_tile[h0 + k], ldu[nv + k]);
+          if (own_left != kInf) wake(P, p, t, own_left);
         }
-        if (fin) ++M.violations;                                     // a wake-up can never take the count to zero
         st(P.tlast[t], f2u(thr));
         add(P.acts, 1u); add(P.sweeps, sweep);
         P.in_solve[t] = 0; --M.solves_now;
-        st(P.lock[t], kInf);
-        work_dec(P, fin);
-        if (fin) { plan_finish(P); fin = false; }
       }
-      if (!did && n > 64u) home = (home + 64u) % n;
+      // ---- retire the ticket
+      P.ticketed[t] = 0;
+      aand(P.lock[t], 0u);
+      if (M.mutate != 2u && ld(P.pend[t]) != kInf && aor(P.lock[t], 1u) == 0u) push(P, p, t);
+      if (sub(P.work, 1u) == 1u) plan_finish(P);
     }
     M.leave(me);
   }
@@ -265,12 +240,12 @@ struct Wg {
 }  // namespace
 
 extern "C" {
-// stats_out: [0] activations, [1] sweeps, [2] claim fails, [3] tiles dropped beyond the bound, [4] plan finishes, [5] scheduling
-// points, [6] most concurrent solves, [7] invariant violations, [8] abort code, [9] put-backs, [10] bands raised at claim, [11] tiles
+// stats_out: [0] activations, [1] sweeps, [2] -, [3] tickets retired beyond the bound, [4] plan finishes, [5] scheduling
+// points, [6] most concurrent solves, [7] invariant violations, [8] abort code, [9] tickets filed, [10] -, [11] tiles
 uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx, const float* edge_weights,
                  const float* vertex_costs, const uint8_t* invalid, const float* xyz, uint32_t tile_size, uint32_t n, const uint32_t* seeds,
                  const uint32_t* targets, double offset, double cost_limit, float band, uint32_t n_wg, uint32_t sched_seed, uint64_t budget,
-                 uint32_t mutate, float* dist_out, uint64_t* stats_out)
+                 uint32_t mutate, uint32_t ring_cap, float* dist_out, uint64_t* stats_out)
 {
   Model M;
   HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
@@ -283,11 +258,15 @@ uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   M.plans.resize(n);
   for (uint32_t p = 0; p < n; ++p) {
     PlanState& P = M.plans[p];
-    P.dist.assign(V, kInf); P.pend.assign(M.T.ntiles, kInf); P.lock.assign(M.T.ntiles, kInf); P.tlast.assign(M.T.ntiles, f2u(-inf_f()));
-    P.in_solve.assign(M.T.ntiles, 0);
+    P.dist.assign(V, kInf); P.pend.assign(M.T.ntiles, kInf); P.lock.assign(M.T.ntiles, 0u); P.tlast.assign(M.T.ntiles, f2u(-inf_f()));
+    P.in_solve.assign(M.T.ntiles, 0); P.ticketed.assign(M.T.ntiles, 0);
     P.seed = seeds[p]; P.target = targets[p];
-    P.dist[P.seed] = 0u; P.pend[M.T.vert_tile[P.seed]] = 0u; P.work = 1u;                  // k_init, k_tile_init, k_async_init
+    const uint32_t st = M.T.vert_tile[P.seed];
+    P.dist[P.seed] = 0u; P.pend[st] = 0u; P.lock[st] = 1u; P.ticketed[st] = 1; P.work = 1u;   // k_init, k_tile_init, k_async_init
   }
+  M.ring.assign((size_t)std::max<uint32_t>(ring_cap, n), kNone);
+  for (uint32_t p = 0; p < n; ++p) M.ring[p] = (p << 24) | M.T.vert_tile[M.plans[p].seed];
+  M.head = 0; M.tail = n;
   M.alive.assign(n_wg, 1); M.sleep_until.assign(n_wg, 0); M.turn = 0;
   std::vector<std::thread> th;
   std::vector<Wg*> wgs;
@@ -303,7 +282,7 @@ uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(P.dist[v]);
   }
   stats_out[0] = acts; stats_out[1] = sweeps; stats_out[2] = M.claim_fails; stats_out[3] = M.drops; stats_out[4] = fins; stats_out[5] = M.yields;
-  stats_out[6] = M.max_solves; stats_out[7] = M.violations; stats_out[8] = M.abort; stats_out[9] = M.putbacks; stats_out[10] = M.raised;
+  stats_out[6] = M.max_solves; stats_out[7] = M.violations; stats_out[8] = M.abort; stats_out[9] = M.tail; stats_out[10] = 0;
   stats_out[11] = M.T.ntiles;
   return M.abort ? 1u : 0u;
 }

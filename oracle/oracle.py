@@ -419,7 +419,7 @@ def model_lib():
 
 
 def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targets, offset=0.3, cost_limit=1.0, tile=128,
-                     band=None, jacobi=1, invalid=None, pipelined=False, forward_marks=True, across_chunks=False, rerun_last_chunk=0):
+                     band=None, jacobi=1, invalid=None, rerun_last_chunk=0):
     """The tile-batch SSSP engine (mnav_tb.h) on the CPU model (oracle/tb_model.cpp): potentials of a batch of plans."""
     faces, edges = _u32(faces), _u32(edges)
     w, vc, pos = _f32(edge_weights), _f32(vertex_costs), _f32(xyz)
@@ -433,37 +433,41 @@ def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
     dist = np.empty((n, V), np.float32)
     stats = np.zeros(12, np.uint64)
     code = model_lib().tbm_run(V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(pos), int(tile), n, _p(sd), _p(tg),
-                               float(offset), float(cost_limit), float(band), int(jacobi) | (2 if pipelined else 0) | (0 if forward_marks else 4) | (8 if across_chunks else 0) | ((int(rerun_last_chunk) & 15) << 4),
+                               float(offset), float(cost_limit), float(band), int(jacobi) | ((int(rerun_last_chunk) & 15) << 4),
                                _p(dist), _p(stats))
     return dict(code=code, dist=dist, iterations=int(stats[0]), activations=int(stats[1]), sweeps=int(stats[2]), wakes=int(stats[3]),
                 max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]), items=int(stats[7]),
                 blocks_total=int(stats[8]), blocks_evaluated=int(stats[9]), stale_reads=int(stats[10]))
 
 
-def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targets, offset=0.3, cost_limit=1.0, tile=64, band=None,
-                     workgroups=4, sched_seed=1, budget=50_000_000, invalid=None, mutate=0):
-    """The PROTOCOL of the asynchronous tile engine (mnav_async.h) on the CPU model (oracle/async_model.cpp): `workgroups` virtual
-    workgroups, interleaved pseudo-randomly (seed) at every shared-memory operation, on the product's own tile tables."""
+def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targets, offset=0.3, cost_limit=1.0, tile=64, band=0.0,
+                     workgroups=4, sched_seed=1, budget=50_000_000, invalid=None, mutate=0, ring_cap=None):
+    """The PROTOCOL of the asynchronous tile engine (mnav_async.h: ticket queue of woken tiles) on the CPU model
+    (oracle/async_model.cpp): `workgroups` virtual workgroups, interleaved pseudo-randomly (seed) at every shared-memory operation,
+    on the product's own tile tables.  band = 0: every solve runs to the tile's local fixed point (the product's default);
+    band > 0: banded solves, in potential units; band = 'tile': one tile width."""
     faces, edges = _u32(faces), _u32(edges)
     w, vc, pos = _f32(edge_weights), _f32(vertex_costs), _f32(xyz)
     V, F, E = vc.shape[0], faces.shape[0], edges.shape[0]
     inv = None if invalid is None else _u8(invalid)
     sd, tg = _u32(seeds), _u32(targets)
     n = sd.shape[0]
-    if band is None:
+    if band == "tile":
         fin = w[np.isfinite(w)]
         band = float(fin.mean() * np.sqrt(tile)) if fin.size else 1.0
     dist = np.empty((n, V), np.float32)
     stats = np.zeros(12, np.uint64)
+    if ring_cap is None:
+        ring_cap = 64 * n * (V // max(int(tile) // 2, 1) + 8)
     L = model_lib()
     L.asm_run.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
-                                                                C.c_float, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+                                                                C.c_float, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     L.asm_run.restype = C.c_uint32
     code = L.asm_run(V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(pos), int(tile), n, _p(sd), _p(tg), float(offset),
-                     float(cost_limit), float(band), int(workgroups), int(sched_seed), int(budget), int(mutate), _p(dist), _p(stats))
-    return dict(code=code, dist=dist, activations=int(stats[0]), sweeps=int(stats[1]), claim_fails=int(stats[2]), drops=int(stats[3]),
+                     float(cost_limit), float(band), int(workgroups), int(sched_seed), int(budget), int(mutate), int(ring_cap), _p(dist), _p(stats))
+    return dict(code=code, dist=dist, activations=int(stats[0]), sweeps=int(stats[1]), drops=int(stats[3]),
                 finishes=int(stats[4]), scheduling_points=int(stats[5]), max_concurrent_solves=int(stats[6]), violations=int(stats[7]),
-                abort=int(stats[8]), putbacks=int(stats[9]), bands_raised=int(stats[10]), tiles=int(stats[11]))
+                abort=int(stats[8]), tickets=int(stats[9]), tiles=int(stats[11]))
 
 
 def product_expanded_sources(dist, target: int, offset: float):

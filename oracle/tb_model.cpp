@@ -23,9 +23,8 @@ inline uint32_t fabs_bits_add(uint32_t v, uint32_t w) { return f2u(std::fabs(u2f
 extern "C" {
 
 // jacobi: bit 0: 1 = every activation of an iteration sees the slices as they were when the iteration started (what concurrent
-// waves may see at worst), 0 = in place, in item order.  bit 1: the PIPELINED sweep (tbq_sweep_pipe) on streams with forward
-// marks: the reads of block j + 1 of a chunk are issued before block j's write, the marked source comes from block j's registers;
-// stats_out[10] counts reads that would then see a value older than the Gauss-Seidel sweep's (the marks must make that zero).
+// waves may see at worst), 0 = in place, in item order.  bits 4-7: every sweep re-runs its
+// last chunk that many times (what a quarter whose stream is shorter than its wave's does).
 // stats_out: [0] iterations, [1] (tile, plan) activations, [2] sweeps summed over activations, [3] wake-ups, [4] max sweeps of
 // one item, [5] tiles, [6] slots per plan, [7] items (waves of <= 64 plans), [8] sweep blocks visited, [9] sweep blocks evaluated;
 // [2] counts sweeps per ITEM (the lanes of an item sweep in lockstep until no lane changes)
@@ -36,12 +35,10 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   HostTopology topo = build_topology(V, F, E, face_vtx, edge_vtx);
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
-  const bool pipe = (jacobi & 2) != 0, no_marks = (jacobi & 4) != 0;   // bit 2: the pipelined order on streams WITHOUT marks (what the marks are for)
-  const bool cross = pipe && (jacobi & 8) != 0;                       // bit 3: the pipeline is not drained at the chunk ends (tbq_sweep_pipe2)
   const uint32_t rerun = (uint32_t)((jacobi >> 4) & 15);              // bits 4-7: every sweep re-runs its last chunk that many times (a quarter whose stream is shorter than its wave's)
   jacobi &= 1;
   HostTb H;
-  try { H = build_tb(topo, xyz, T, (pipe && !no_marks) ? (cross ? 2 : 1) : 0); }
+  try { H = build_tb(topo, xyz, T); }
   catch (const std::exception& ex) { fprintf(stderr, "tbm_run: %s\n", ex.what()); return 64; }
   for (size_t i = 0; i < H.stream.size(); ++i) if (H.wsrc[i] != kNone) H.stream[i] = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
   const uint32_t NP = n, nt = H.ntiles;
@@ -60,7 +57,6 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     pend[(size_t)t * NP + p] = 0u; marr[0][p] = 0u; cand[0].push_back({ t, p });
   }
   uint64_t iters = 0, acts = 0, sweeps_tot = 0, wakes = 0, max_sweeps = 0, items = 0, blocks_total = 0, blocks_eval = 0, stale_reads = 0;
-  std::vector<uint32_t> prev_old(64, 0u);                          // pipelined sweep: what the previous block's row held before its write
   std::vector<std::vector<uint16_t>> bucket(nt);
   std::vector<std::vector<uint32_t>> ldsv(64, std::vector<uint32_t>(256));   // per lane: row -> value
   for (int par = 0;; par ^= 1) {
@@ -123,34 +119,17 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
           uint32_t chg_cur = 0;
           for (uint32_t cc = 0; cc < W.sweep_chunks + (W.sweep_chunks ? rerun : 0u); ++cc) {
             const uint32_t c = std::min(cc, W.sweep_chunks - 1u);
-            const bool again = cc >= W.sweep_chunks;                     // a re-run of the last chunk
             const uint32_t* C = B + (size_t)c * kTbChunk;
             blocks_total += kTbBlocksPerChunk;
             for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
-              const uint32_t* K = C + kTbBlock * j;
+              auto K = [&](uint32_t q) { return C[tb_sweep_index(j, q)]; };   // sweep chunks are stored transposed (mnav_tb_build.h)
               ++blocks_eval;
-              const uint32_t y = K[0] / 256u;
-              // the reads of this block were issued before the previous block wrote: block j - 1 of the chunk, or (not drained at
-              // the chunk ends) block 3 of the chunk before -- in a re-run that is this chunk's own block 3, and nothing is forwarded
-              const bool piped = pipe && (j > 0 || (cross && cc > 0));
-              const bool fwd_ok = j > 0 || !again;
-              const uint32_t py = !piped ? kNone : (j == 0 && again) ? C[kTbBlock * 3] / 256u : K[-(int)kTbBlock] / 256u;
-              if (piped && y == py) return 62;                       // adjacent blocks of a chunk must not write the same row
-              if (pipe && (K[15] & 1u) && fwd_ok && (!piped || K[1] / 256u != py)) return 63;   // a mark that does not name the previous block's row
+              const uint32_t y = K(0) / 256u;
               for (uint32_t l = 0; l < cnt_l; ++l) {
                 uint32_t* lds = ldsv[l].data();
                 const uint32_t acc0 = lds[y] & 0x7fffffffu;
                 uint32_t acc = acc0;
-                for (uint32_t k = 0; k < 7; ++k) {
-                  const uint32_t row = K[1 + k] / 256u;
-                  uint32_t v = lds[row];
-                  if (piped && row == py && !(k == 0 && (K[15] & 1u) && fwd_ok)) {   // not forwarded: the value from before the previous block's write
-                    if (prev_old[l] != v && K[8 + k] != kTbInfBits && !again) ++stale_reads;
-                    v = prev_old[l];
-                  }
-                  acc = std::min(acc, fabs_bits_add(v, K[8 + k]));
-                }
-                prev_old[l] = lds[y];
+                for (uint32_t k = 0; k < 7; ++k) acc = std::min(acc, fabs_bits_add(lds[K(1 + k) / 256u], K(8 + k)));
                 if (acc < acc0) { lds[y] = acc | kTbDirty; chg_cur |= 1u << (y * 32u / T); }
               }
             }

@@ -156,3 +156,95 @@ def test_vector_at_matches_direction_at_position(c3):
                 assert np.abs(got - want).max() <= 4e-7
     finally:
         ctx.set_resident_outputs(False)
+
+
+# ---- the BATCHES bench.py times on this configuration (configs.C3: 128 plans = 3 plan groups on their own streams, 512 plans =
+# ---- 4 groups; k_cvp_ctl + k_step_wide + k_step_repair per step).  The loop they stand for: cvp_mesh_planner.cpp:747-886.
+
+def _bench_draw(c3):
+    """bench.py leg_c3's draw: goals among the vertices of the largest traversable component with cost < 0.5, rng(5):
+    160 goals (the batch of 128 = goals[16:144]), then 512 more; the common robot face"""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as cg
+    mesh, vn, ctx, vc, w, om, first_face = c3
+    N = 1000
+    fr = vc < 1.0
+    e = mesh.edges
+    ok = fr[e[:, 0]] & fr[e[:, 1]]
+    g = sp.coo_matrix((np.ones(int(ok.sum()), np.int8), (e[ok, 0], e[ok, 1])), shape=(mesh.V, mesh.V)).tocsr()
+    _, lab = cg.connected_components(g, directed=False)
+    big = int(np.argmax(np.bincount(lab[fr])))
+    free = np.nonzero((lab == big) & fr)[0]
+    robot = int(free[np.argmin(np.abs(mesh.xyz[free, 0] - 0.9 * N * 0.1) + np.abs(mesh.xyz[free, 1] - 0.9 * N * 0.1))])
+    free = free[vc[free] < 0.5]
+    rng = np.random.default_rng(5)
+    goals = rng.choice(free, size=160, replace=False)
+    goals512 = rng.choice(free, size=512, replace=False)
+    return goals, goals512, int(first_face[robot])
+
+
+def _batch_args(c3, verts, tf):
+    mesh, first_face = c3[0], c3[6]
+    seeds = [wave_seed(mesh, first_face, int(v)) for v in verts]
+    return np.stack([s[0] for s in seeds]), np.array([s[1] for s in seeds], np.uint32), np.full(len(seeds), tf, np.uint32)
+
+
+def _slot_fields(ctx, slot):
+    return {k: ctx.download_output(k, slot) for k in ("dist", "pred", "direction", "cutface", "vecmap")}
+
+
+def _assert_slot_is_the_oracle(c3, ctx, sps, sfs, tf, slot, code):
+    mesh, vn, _, vc, w, om, _ = c3
+    ref = om.cvp(w, vc, vn, sps[slot], int(sfs[slot]), tf)
+    assert code == ref.code, slot
+    o = _slot_fields(ctx, slot)
+    assert np.array_equal(o["dist"].view(np.uint32), ref.dist.view(np.uint32)), slot
+    assert np.array_equal(o["pred"], ref.pred), slot
+    upd = ref.pred != np.arange(mesh.V)
+    assert np.array_equal(o["cutface"][upd], ref.cutface[upd]), slot
+    assert np.array_equal(o["direction"][upd].view(np.uint32), ref.direction[upd].view(np.uint32)), slot
+    hv = ref.has_vec.astype(bool)
+    assert np.array_equal(o["vecmap"][hv].view(np.uint32), ref.vecmap[hv].view(np.uint32)), slot
+    assert not o["vecmap"][~hv].any(), slot
+
+
+@pytest.mark.parametrize("nb,slots", [(128, (0, 21, 43, 64, 86, 127)), (512, (0, 101, 129, 254, 257, 383, 385, 511))])
+def test_cvp_batches_of_the_benched_c3_bit_exact(c3, nb, slots):
+    """the two batches of configs.C3 (wide step kernel, multi-group stepping as branches of one captured graph): at least two
+    plans of EVERY plan group -- potential, predecessors, cutting faces, directions and vector map against the sequential oracle"""
+    ctx = c3[2]
+    goals, goals512, tf = _bench_draw(c3)
+    sps, sfs, tfs = _batch_args(c3, goals[16:16 + nb] if nb <= 128 else goals512[:nb], tf)
+    ctx.set_resident_outputs(True)
+    try:
+        r = ctx.plan_cvp_batch(sps, sfs, tfs)
+        assert r["rc"] == 0 and (r["codes"] == 0).all()                 # (bench.py checks exactly this)
+        assert r["stats"]["steps"] > 500
+        for s in slots:
+            _assert_slot_is_the_oracle(c3, ctx, sps, sfs, tf, s, int(r["codes"][s]))
+    finally:
+        ctx.set_resident_outputs(False)
+
+
+def test_cvp_batch_one_group_equals_the_grouped_default(c3):
+    """option cvp_groups = 1 (every plan stepped on one stream) against the default three groups: the same bits in every field of
+    a sample of slots across the batch"""
+    ctx = c3[2]
+    goals, _, tf = _bench_draw(c3)
+    sps, sfs, tfs = _batch_args(c3, goals[16:144], tf)
+    slots = range(0, 128, 9)
+    ctx.set_resident_outputs(True)
+    try:
+        ctx.set_option("cvp_groups", None)
+        a = ctx.plan_cvp_batch(sps, sfs, tfs)
+        fa = {s: _slot_fields(ctx, s) for s in slots}
+        ctx.set_option("cvp_groups", 1)
+        b = ctx.plan_cvp_batch(sps, sfs, tfs)
+        ctx.set_option("cvp_groups", None)
+        assert np.array_equal(a["codes"], b["codes"])
+        for s in slots:
+            fb = _slot_fields(ctx, s)
+            for k, v in fa[s].items():
+                assert np.array_equal(v.view(np.uint32), fb[k].view(np.uint32)), (s, k)
+    finally:
+        ctx.set_resident_outputs(False)

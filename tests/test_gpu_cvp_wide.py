@@ -1,6 +1,6 @@
 """The wide CVP step kernel (k_step_wide: 64 work-list entries per wave and round; phase A one lane per incident face,
 phase B one lane per vertex over the prepared items; mnav_eval.h make_cvp_item / eval_cvp_items) against the oracle
-(cvp_mesh_planner.cpp:369-556, 651-918) and against the 8-lane replay: batches pick it from 32 plans on, MNAV_CVP_WIDE forces
+(cvp_mesh_planner.cpp:369-556, 651-918) and against the 8-lane replay: batches pick it from 32 plans on, the option cvp_wide forces
 either.  Potential and predecessors bit for bit."""
 import numpy as np
 import pytest
@@ -24,18 +24,18 @@ def _batch(case, n, seed):
     return sps, sfs, np.full(n, tf, np.uint32)
 
 
-def test_wide_batch_on_layered_costs_matches_oracle_and_the_8_lane_replay(gpu_ctx_factory, monkeypatch):
+def test_wide_batch_on_layered_costs_matches_oracle_and_the_8_lane_replay(gpu_ctx_factory):
     base = terrain_case(224, 1)
     costs, _ = layered_costs(base, "avg")                             # Steepness + Inflation: cost-inflated triangles, cascades
     case = Case(base.mesh, costs, 1.0)
     ctx = gpu_ctx_factory()
     case.upload(ctx)
     sps, sfs, tfs = _batch(case, 32, 11)
-    monkeypatch.delenv("MNAV_CVP_WIDE", raising=False)
+    ctx.set_option("cvp_wide", None)
     wide = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)         # 32 plans: the wide kernel
-    monkeypatch.setenv("MNAV_CVP_WIDE", "0")
+    ctx.set_option("cvp_wide", 0)
     narrow = ctx.plan_cvp_batch(sps, sfs, tfs, want_fields=True)
-    monkeypatch.delenv("MNAV_CVP_WIDE")
+    ctx.set_option("cvp_wide", None)
     assert np.array_equal(wide["codes"], narrow["codes"])
     assert np.array_equal(wide["dist"].view(np.uint32), narrow["dist"].view(np.uint32)) and np.array_equal(wide["pred"], narrow["pred"])
     assert wide["stats"]["steps"] > 50
@@ -45,13 +45,13 @@ def test_wide_batch_on_layered_costs_matches_oracle_and_the_8_lane_replay(gpu_ct
         assert np.array_equal(wide["dist"][k].view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(wide["pred"][k], ref.pred)
 
 
-def test_wide_kernel_on_irregular_valence_and_adversarial_costs(gpu_ctx_factory, monkeypatch):
+def test_wide_kernel_on_irregular_valence_and_adversarial_costs(gpu_ctx_factory):
     """a valence-40 hub (more faces than a vertex gets item slots for: the serial rule inside the wide kernel) and random
     per-vertex costs that break the triangle inequality on most faces (non-causal updates, cascades)"""
-    monkeypatch.setenv("MNAV_CVP_WIDE", "1")
     mesh = meshgen.fan_field(40, 6, 1)
     case = Case(mesh)
     ctx = gpu_ctx_factory()
+    ctx.set_option("cvp_wide", 1)
     case.upload(ctx)
     for sv, tv in ((1 + 5 * 40 + 3, 1 + 5 * 40 + 23), (0, 1 + 5 * 40 + 23)):
         sf = int(np.where((mesh.faces == sv).any(axis=1))[0][0]); tf = int(np.where((mesh.faces == tv).any(axis=1))[0][0])
@@ -64,6 +64,7 @@ def test_wide_kernel_on_irregular_valence_and_adversarial_costs(gpu_ctx_factory,
     rng = np.random.default_rng(2)
     case2 = Case(m2, rng.uniform(0.0, 0.9, m2.V).astype(np.float32), 3.0)
     ctx2 = gpu_ctx_factory()
+    ctx2.set_option("cvp_wide", 1)
     case2.upload(ctx2)
     sps, sfs, tfs = _batch(Case(m2, np.zeros(m2.V, np.float32)), 6, 3)
     for k in range(6):

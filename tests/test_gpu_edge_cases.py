@@ -154,8 +154,8 @@ def test_empty_batch_and_batch_mixing_all_codes(gpu_ctx_factory):
     ctx.set_dijkstra_engine("auto")
 
 
-def test_walk_bound_hit_returns_internal_error_instead_of_a_reordered_plan(gpu_ctx_factory, monkeypatch):
-    """Cascade-tree walks cut to 3 links (MNAV_KEY_WALK_MAX, read at mesh upload) on a punched terrain whose
+def test_walk_bound_hit_returns_internal_error_instead_of_a_reordered_plan(gpu_ctx_factory):
+    """Cascade-tree walks cut to 3 links (options key_walk_max / descend_walk_max) on a punched terrain whose
     cascades nest hundreds of levels deep: the comparison falls back to another pop order.  k_cvp_verify has to
     notice (walk-limit flag on the converged tree, or a vertex that is no fixed point) and the plan must come back
     as INTERNAL_ERROR (60); with the default bounds the same plan is clean and bit-equal to the oracle."""
@@ -173,10 +173,10 @@ def test_walk_bound_hit_returns_internal_error_instead_of_a_reordered_plan(gpu_c
     out = ctx.plan_cvp(sp, sf, tf)
     assert out.code == ref.code == 0
     assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
-    monkeypatch.setenv("MNAV_KEY_WALK_MAX", "3")
-    monkeypatch.setenv("MNAV_DESCEND_WALK_MAX", "1")
     cut = gpu_ctx_factory()
-    case.upload(cut)                                  # the bounds are read here
+    cut.set_option("key_walk_max", 3)
+    cut.set_option("descend_walk_max", 1)
+    case.upload(cut)
     with pytest.raises(RuntimeError, match="internal error"):
         cut.plan_cvp(sp, sf, tf)
 

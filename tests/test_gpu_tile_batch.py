@@ -34,10 +34,10 @@ def check_against_oracle(case, ctx, b, seeds, targets, sample, offset=0.3, cost_
 
 
 @pytest.mark.parametrize("tile", ["64", "128"])
-def test_c1_batch_paths_and_popped_potential(gpu_ctx_factory, tile, monkeypatch):
-    monkeypatch.setenv("MNAV_TB_TILE", tile)
+def test_c1_batch_paths_and_popped_potential(gpu_ctx_factory, tile):
     case = terrain_case(224, 1)
     ctx = gpu_ctx_factory()
+    ctx.set_option("tb_tile", int(tile))           # read when the engine builds its streams (first batch)
     case.upload(ctx)
     ctx.set_dijkstra_engine("tile_batch")
     m = case.mesh

@@ -85,10 +85,11 @@ def test_punched_and_fan_meshes():
         assert r["max_sweeps"] <= 40
 
 
-def test_pipelined_sweep_order_with_forward_marks_is_the_gauss_seidel_sweep():
-    """The opt-in pipelined sweep (mnav_tb.h tbq_sweep_pipe: the LDS reads of block j + 1 of a chunk are issued before block j's
-    write) on streams with forward marks (mnav_tb_build.h) sees exactly the values the plain sweep sees: same sweep counts, same
-    bits, no read older than the Gauss-Seidel order's.  Without the marks the same read order goes stale."""
+def test_a_quarter_that_reruns_its_last_chunk_changes_nothing():
+    """k_tb_solve_q runs the four quarters of a wave to the LONGEST of their sweep streams: a quarter past the end of its own stream
+    re-runs its last chunk.  A relaxation applied again changes nothing: same bits, never more sweeps.  (The sweep chunks are
+    stored transposed for the DPP reads of the kernel -- mnav_tb_build.h tb_sweep_index --; the model reads them through the same
+    index function, so every test of this file also checks that layout.)"""
     case = terrain_case(128, 1)
     m = case.mesh
     rng = np.random.default_rng(3)
@@ -96,31 +97,14 @@ def test_pipelined_sweep_order_with_forward_marks_is_the_gauss_seidel_sweep():
     targets = np.full(6, m.vertex_at(0.9, 0.9))
     kw = dict(tile=120, jacobi=1)
     plain = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, **kw)
-    piped = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, **kw)
-    assert plain["code"] == 0 and piped["code"] == 0
-    assert piped["stale_reads"] == 0
-    assert piped["sweeps"] == plain["sweeps"] and piped["iterations"] == plain["iterations"] and piped["wakes"] == plain["wakes"]
-    assert np.array_equal(piped["dist"].view(np.uint32), plain["dist"].view(np.uint32))
-    # level 2 (tbq_sweep_pipe2): not drained at the chunk ends; and the same with every sweep re-running its last chunk twice -- what a
-    # quarter of a wave does whose stream is shorter than its neighbours' (block 0 then follows its own chunk's block 3, unforwarded)
-    across = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, across_chunks=True, **kw)
-    assert across["code"] == 0 and across["stale_reads"] == 0 and across["sweeps"] == plain["sweeps"]
-    assert np.array_equal(across["dist"].view(np.uint32), plain["dist"].view(np.uint32))
-    rerun = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, across_chunks=True,
-                               rerun_last_chunk=2, **kw)
-    assert rerun["code"] == 0 and rerun["sweeps"] <= plain["sweeps"]
+    rerun = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, rerun_last_chunk=2, **kw)
+    assert plain["code"] == 0 and rerun["code"] == 0 and rerun["sweeps"] <= plain["sweeps"]
     assert np.array_equal(rerun["dist"].view(np.uint32), plain["dist"].view(np.uint32))
-    unmarked = O.tile_batch_model(m.xyz, m.faces, m.edges, case.weights, case.costs, seeds, targets, pipelined=True, forward_marks=False, **kw)
-    assert unmarked["code"] == 0 and unmarked["stale_reads"] > 0 and unmarked["sweeps"] > plain["sweeps"]
-    # a valence-40 hub (continuation blocks of one row) and the other checks of this file, through the pipelined order
-    f = meshgen.fan_field(spokes=40, rings=6, seed=1)
+    f = meshgen.fan_field(spokes=40, rings=6, seed=1)               # a valence-40 hub: continuation blocks of one row
     casef = Case(f)
     for tile in (64, 128):
         a = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile)
-        b = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile, pipelined=True)
-        assert b["code"] == 0 and b["stale_reads"] == 0 and b["sweeps"] == a["sweeps"]
-        assert np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
-        c = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile, pipelined=True,
-                               across_chunks=True, rerun_last_chunk=3)
-        assert c["code"] == 0 and c["stale_reads"] == 0 and c["sweeps"] <= a["sweeps"]
+        c = O.tile_batch_model(f.xyz, f.faces, f.edges, casef.weights, casef.costs, [1, f.V - 1], [f.V - 2, 0], tile=tile, rerun_last_chunk=3)
+        assert c["code"] == 0 and c["sweeps"] <= a["sweeps"]
         assert np.array_equal(a["dist"].view(np.uint32), c["dist"].view(np.uint32))
+
