@@ -215,7 +215,7 @@ struct mnav_ctx {
   float delta_user = 0.f, delta_auto = 0.f;
   Options opt;                                                       // mnav_options.h: read from the environment once, by mnav_create
   uint32_t max_steps_auto = 1u << 20;
-  uint32_t* d_ring = nullptr; uint32_t ring_cap = 0, ring_used = 0; struct AsyncCtl* h_actl = nullptr;   // asynchronous tile engine: ticket ring, pinned copy of its control words
+  uint32_t* d_ring = nullptr; uint32_t ring_cap = 0, ring_used = 0; struct AsyncCtl* h_actl = nullptr; uint32_t* d_parked = nullptr; size_t parked_words = 0;   // asynchronous tile engine: ticket ring, pinned copy of its control words
   uint32_t last_planner = 0, last_n = 0;
   std::vector<uint32_t> last_target; double last_offset = 0.0;   // Dijkstra: robot vertex per device slot, goal_dist_offset of the last call
   mnav_stats stats{};
@@ -616,7 +616,7 @@ void mnav_destroy(mnav_ctx* ctx)
   (void)hipFree(ctx->shard.d_owned); (void)hipFree(ctx->shard.d_changed); (void)hipFree(ctx->shard.d_minpend); (void)hipFree(ctx->shard.d_walk);
   if (ctx->cancel_stream) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipStreamDestroy(ctx->cancel_stream); }
   if (ctx->h_one) (void)hipHostFree(ctx->h_one);
-  (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any); (void)hipFree(ctx->d_ring); if (ctx->h_actl) (void)hipHostFree(ctx->h_actl);
+  (void)hipFree(ctx->d_cancel); (void)hipFree(ctx->d_verify_any); (void)hipFree(ctx->d_ring); (void)hipFree(ctx->d_parked); if (ctx->h_actl) (void)hipHostFree(ctx->h_actl);
   (void)hipFree(ctx->d_over); (void)hipFree(ctx->d_over_off); (void)hipFree(ctx->d_over_cap);
   (void)hipFree(ctx->d_pack); (void)hipFree(ctx->d_pack_meta); if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
   if (ctx->h_tctl) (void)hipHostFree(ctx->h_tctl);

@@ -14,35 +14,45 @@
 // per plan, 4 500 failed claims per plan: 6.1 ms for a 1M-vertex plan against 7.4 ms for the rounds, first hardware run of
 // round 5); the queue replaces the scans, the claims and the band.
 //
+// Bands.  A queue alone is not enough: served first-in-first-out with every solve run to its tile's local fixed point the wave
+// races ahead on values that are corrected later, and every correction is propagated again -- the first hardware run of the
+// queue took 128 workgroups 9.7 ms for ONE 1M-vertex plan (26 ms with 32 workgroups: it is the amount of work, not the critical
+// path), 124 ms for 47 plans against 49 ms on the rounds.  So the plans advance in BANDS like the rounds do (delta-stepping):
+// a plan has a threshold thr; a tile woken with a value below thr gets a ticket at once (ACTIVE), one woken at or beyond thr is
+// PARKED on the plan's list; a solve relaxes sources below thr only (the tile parks itself for the rest).  Inside a band
+// everything is asynchronous -- a tile woken by a neighbour's solve is solved as soon as a workgroup is free, not a round later
+// --; when a plan's last active ticket is retired, the workgroup that retired it advances the band: thr = smallest parked
+// wake-up value + band, the parked tiles below it get their tickets.  Only that one workgroup touches the plan then (nobody
+// else holds a ticket of it); other plans are not involved.
+//
 // Protocol.  Every word another workgroup may touch is accessed with relaxed AGENT-scope atomics (sc1: past the per-CU L1
 // and the per-XCD L2, MI355X_MICROARCH.md "visibility"), through GLOBAL pointers (vmcnt only).
 //   pend[t]    wake-up value of tile t (float bits, inf = none): wakers atomicMin it, the solver takes it with an exchange.
-//   state[t]   (the slot's second pend buffer) 1 = the tile has a ticket in the queue or is being solved, 0 = neither.
-//              WHOEVER TURNS IT FROM 0 TO 1 FILES THE TICKET: at most one ticket per tile, hence one solver per tile (two
-//              would race on tlast[t] and on the owned distances).
-//              waker:   old = atomicMin(pend[t], v);  if (old == inf && atomicOr(state[t], 1) == 0) push(t)
-//              solver:  ... solve, publish ...;  atomicAnd(state[t], 0);  if (pend[t] != inf && atomicOr(state[t], 1) == 0) push(t)
-//              Both sides do "write mine, THEN look at yours", each RMW awaited before the next operation is issued
-//              (Dekker): a wake-up that arrives while the tile is in solve is seen by the solver's look or files its own ticket.
+//   state[t]   (the slot's second pend buffer) 0 = idle, 1 / 2 = parked on the list of band parity 0 / 1, 3 = ACTIVE: a ticket
+//              is in the queue or the tile is being solved.  WHOEVER RAISES IT TO 3 FILES THE TICKET (at most one ticket per
+//              tile, hence one solver per tile: two would race on tlast[t] and on the owned distances); whoever raises it from
+//              below the current parked value appends the tile to the current parked list.
+//              waker:   atomicMin(pend[t], v);  v < thr ?  atomicMax(state[t], 3) < 3 -> push(t)
+//                                                       :  atomicMax(state[t], parked) < parked -> park(t)
+//              solver:  ... solve, publish ...;  state[t] = 0;  v = pend[t];  v != inf -> as a waker, without the atomicMin
+//              Both sides do "write mine, THEN look at yours", every operation awaited before the next one is issued (Dekker):
+//              a wake-up that arrives while the tile is in solve is seen by the solver's look or files / parks for itself.
 //   ring[i]    ticket i = plan << 24 | tile, 0xffffffff = not filed yet.  push: i = tail++, ring[i] = ticket;
 //              pop: i = head++, then the workgroup polls ring[i] (one word, with s_sleep).  A ticket index belongs to exactly
 //              one popper, a slot is written exactly once per call: no reuse, no ABA.  The ring holds every ticket a call can
-//              file in practice (host: 16 per tile and plan); a call that runs out of slots sets abort = 5 and the host
-//              re-runs it on the tile rounds.
+//              file in practice (host: 16 per tile and plan); a call that runs out of slots -- or of room on a parked list --
+//              sets abort = 5 and the host re-runs it on the tile rounds.
 //   work[p]    per plan: tickets filed and not yet retired, counted BEFORE the ticket becomes visible and given back after
-//              the solver's own wake-ups: work == 0 <=> the plan is at its fixed point.  The workgroup that takes it to 0
+//              the solver's own wake-ups.  The workgroup that takes it to 0 advances the band (holding a count of its own
+//              while it files the next band's tickets); no parked tile left <=> the plan is at its fixed point: that workgroup
 //              publishes the plan record (plan_finish) and counts the plan in done_plans; done_plans == n ends the kernel.
 //   order      a solver's distance stores are drained (s_waitcnt vmcnt(0) in every storing wave, then a barrier) before its
 //              first wake-up; a later solver reads distances only after its ticket arrived.
 // Tiles whose wake-up value lies beyond the running bound dist[target] + offset can never propagate (dijkstra :293-300):
-// their ticket is retired without a solve.  No workgroup waits FOR another one -- a popper whose ticket is never filed leaves
-// with done_plans == n --, every poll loop is bounded by the 100 MHz wall clock (abort = 2) and looks at mnav_cancel's word
-// (abort = 3), so residency is not a correctness condition: a grid larger than what fits only starts later.
-//
-// Band.  The rounds relax a tile only up to a band threshold and come back for the rest (2.8 activations per touched tile in
-// batches: work-efficient).  A single plan has 256 idle CUs: here a solve runs the tile to its LOCAL FIXED POINT for everything
-// below the bound (thr = +inf) -- fewer dependent activations on the critical path, more re-solves off it.  TilePlan.band > 0
-// and finite restores the banded solve (thr = wake-up value + band, the tile wakes itself for the rest).
+// their ticket is retired without a solve (the band advance hands such parked tiles a ticket for exactly that).  No workgroup
+// waits FOR another one -- a popper whose ticket is never filed leaves with done_plans == n --, every ticket and every poll
+// looks at the 100 MHz wall clock (abort = 2) and at mnav_cancel's word (abort = 3), so residency is not a correctness
+// condition: a grid larger than what fits only starts later.
 #pragma once
 
 constexpr uint32_t kAsyncWake = 32;        // distinct neighbour tiles one solve can wake through the LDS table (more: slow path)
@@ -59,54 +69,81 @@ __device__ __forceinline__ uint32_t add(uint32_t* p, uint32_t v) { return __hip_
 __device__ __forceinline__ uint32_t sub(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_sub((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t amin(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_min((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t xchg(uint32_t* p, uint32_t v) { return __hip_atomic_exchange((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t aor(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_or((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t aand(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_and((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool cas(uint32_t* p, uint32_t expect, uint32_t v)
+{
+  return __hip_atomic_compare_exchange_strong((gptr)p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t amax(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_max((gptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// the per-plan words live in the slot's three TCnt records (unused by this engine otherwise)
-__device__ __forceinline__ uint32_t* work_of(const TilePlan& P) { return &P.cnt[0].minpend; }
-__device__ __forceinline__ uint32_t* acts_of(const TilePlan& P) { return &P.cnt[0].acts; }
-__device__ __forceinline__ uint32_t* sweeps_of(const TilePlan& P) { return &P.cnt[0].sweeps; }
+// the per-plan words live in the slot's three TCnt records (48 bytes, unused by this engine otherwise)
+struct PlanWords { uint32_t work, acts, sweeps, epochs, thr, par, nparked[2], pad[4]; };
+static_assert(sizeof(PlanWords) == 3 * sizeof(TCnt), "PlanWords overlays TilePlan.cnt[3]");
+__device__ __forceinline__ PlanWords* words_of(const TilePlan& P) { return reinterpret_cast<PlanWords*>(P.cnt); }
+constexpr uint32_t kActive = 3u;
+constexpr uint32_t kParkedLists = 4u;    // capacity of a parked list in tiles-of-the-mesh (a tile can be parked, promoted, solved and parked again within a band)
 
 // the plan reached its fixed point: publish the control record the finalize pass / the path walk read (after the kernel)
 __device__ __forceinline__ void plan_finish(const TilePlan& P, AsyncCtl* actl)
 {
+  PlanWords* const W = words_of(P);
   TCtl c; memset(&c, 0, sizeof(c));
-  c.acts = ld(acts_of(P)); c.sweeps = ld(sweeps_of(P));
+  c.acts = ld(&W->acts); c.sweeps = ld(&W->sweeps);
   c.it = (int32_t)c.acts; c.done = 1u; c.thr = inf_f(); c.thr_prev = inf_f();
   P.ctl[0] = c; P.ctl[1] = c;
   drain();
   add(&actl->done_plans, 1u);
 }
-// file the ticket of tile t of plan p (the caller has just turned state[t] from 0 to 1)
+// file the ticket of tile t of plan p (the caller has just raised state[t] to ACTIVE)
 __device__ __forceinline__ void push(const TilePlan& P, uint32_t p, uint32_t t, uint32_t* ring, AsyncCtl* actl)
 {
-  add(work_of(P), 1u);                                                // counted before it can be seen
+  add(&words_of(P)->work, 1u);                                        // counted before it can be seen
   drain();
   const uint32_t i = add(&actl->tail, 1u);
   if (i < actl->ring_cap) st(ring + i, (p << 24) | t);
   else st(&actl->abort, 5u);                                          // out of slots: the host re-runs the call on the tile rounds
 }
-// wake tile t2 with value v (float bits)
-__device__ __forceinline__ void wake(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, uint32_t* ring, AsyncCtl* actl)
+// put tile t on the parked list of band parity `par` (the caller has just raised state[t] to that list's parked value)
+__device__ __forceinline__ void park(const TilePlan& P, uint32_t t, uint32_t par, AsyncCtl* actl)
 {
-  if (amin(P.pend[0] + t2, v) != kInfBits) return;                    // pending already: whoever made it so files (or filed) the ticket
-  if (aor(P.pend[1] + t2, 1u) == 0u) push(P, p, t2, ring, actl);      // (the atomicMin has returned: its value is visible before the OR is issued)
+  const uint32_t cap = kParkedLists * P.ntiles;
+  const uint32_t i = add(&words_of(P)->nparked[par], 1u);
+  if (i < cap) st(P.parked + (size_t)par * cap + i, t);
+  else st(&actl->abort, 5u);
+}
+// tile t2 has the pending value v (already merged into pend[t2]): ticket or parked list, unless somebody else saw to it
+__device__ __forceinline__ void route(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* ring, AsyncCtl* actl)
+{
+  if (u2f(v) < thr) { if (amax(P.pend[1] + t2, kActive) < kActive) push(P, p, t2, ring, actl); }
+  else {
+    // (a tile still in the OTHER parity's parked state is on the list the band advance is working through: with pk above that value
+    //  this call takes it over -- the advance then finds the state changed and skips it --, with pk below it the advance moves it)
+    const uint32_t pk = 1u + par;
+    if (amax(P.pend[1] + t2, pk) < pk) park(P, t2, par, actl);
+  }
+}
+// wake tile t2 with value v (float bits)
+__device__ __forceinline__ void wake(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* ring, AsyncCtl* actl)
+{
+  (void)amin(P.pend[0] + t2, v);
+  drain();                                                            // merged BEFORE the state word is touched (Dekker, see the header)
+  route(P, p, t2, v, thr, par, ring, actl);
 }
 }  // namespace aq
 
-// work = 1, the seed's tile queued (ticket p), every other tile idle; the control words; grid (tiles / 256, n)
+// work = 1, the seed's tile ACTIVE (ticket p), every other tile idle, first band [0, band); the control words; grid (tiles / 256, n)
 __global__ __launch_bounds__(kBlock) void k_async_init(const TilePlan* __restrict__ plans, uint32_t* __restrict__ ring, const uint32_t* __restrict__ vert_tile,
                                                        AsyncCtl* __restrict__ actl, uint32_t n, uint32_t ring_cap)
 {
   const TilePlan& P = plans[blockIdx.y];
   const uint32_t st = vert_tile[P.seed];
   const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) P.pend[1][t] = (t == st) ? 1u : 0u;
+  for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) P.pend[1][t] = (t == st) ? aq::kActive : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    TCnt z; z.minpend = 1u; z.acts = 0u; z.sweeps = 0u; z.pad = 0u;
-    P.cnt[0] = z;
-    z.minpend = 0u; P.cnt[1] = z; P.cnt[2] = z;
+    aq::PlanWords W; memset(&W, 0, sizeof(W));
+    W.work = 1u;
+    W.thr = f2u((P.band > 0.f && P.band < inf_f()) ? P.band : inf_f());
+    *aq::words_of(P) = W;
     ring[blockIdx.y] = (blockIdx.y << 24) | st;
     if (blockIdx.y == 0) {
       AsyncCtl c; c.abort = 0u; c.done_plans = 0u; c.head = 0u; c.tail = n; c.polls = 0u; c.dropped = 0u; c.ring_cap = ring_cap; c.pad = 0u;
@@ -119,11 +156,12 @@ template <int VPT>   // owned vertices per thread: tile_size <= VPT * 256
 __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __restrict__ plans, uint32_t n, AsyncCtl* __restrict__ actl,
                                                            uint32_t* __restrict__ ring, unsigned long long limit_ticks)
 {
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   __shared__ uint32_t s_hdr[8];
   __shared__ uint32_t s_nq[3];
-  __shared__ uint32_t s_ticket, s_bound_bits, s_thr_bits, s_wover, s_solve;
+  __shared__ uint32_t s_ticket, s_bound_bits, s_thr_bits, s_par, s_wover, s_solve, s_advance;
   __shared__ uint32_t s_wtile[kAsyncWake], s_wval[kAsyncWake];
+  __shared__ uint32_t s_min[kTileBlock / 64], s_bey[kTileBlock / 64];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TileLds L = tile_lds_layout(smem, plans[0].max_nv, plans[0].max_nh, plans[0].max_ne);   // one mesh: the same for every plan
   uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
@@ -133,8 +171,15 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
     // ---- the next ticket (thread 0 takes and awaits it, the workgroup sits in the barrier)
     if (tid == 0) {
       uint32_t e = kTicketExit;
+      // (three independent operations in flight together: a workgroup that always finds its ticket filed never enters the poll
+      //  loop below, and must still see an abort or mnav_cancel)
+      const uint32_t ab = aq::ld(&actl->abort);
+      const uint32_t cn = plans[0].cancel ? aq::ld(plans[0].cancel) : 0u;
       const uint32_t i = aq::add(&actl->head, 1u);
-      if (i < actl->ring_cap) {
+      if (ab) { }
+      else if (cn) aq::st(&actl->abort, 3u);                          // mnav_cancel, dijkstra :287
+      else if (wall_clock64() - t_begin > limit_ticks) aq::st(&actl->abort, 2u);
+      else if (i < actl->ring_cap) {
         for (uint32_t spins = 0;; ++spins) {
           e = aq::ld(ring + i);
           if (e != kTicketNone) break;
@@ -157,6 +202,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
     if (ticket == kTicketExit) break;
     const uint32_t p = ticket >> 24, t = ticket & 0xFFFFFFu;
     const TilePlan& P = plans[p];
+    aq::PlanWords* const W = aq::words_of(P);
     uint32_t* const pend = P.pend[0];
     uint32_t* const state = P.pend[1];
     uint32_t* const dbits = reinterpret_cast<uint32_t*>(P.dist);
@@ -165,6 +211,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       const float dt = u2f(aq::ld(dbits + P.target));
       const float bound = (float)((double)dt + fmax(P.offset, 0.0));  // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
       s_bound_bits = f2u(bound);
+      s_thr_bits = aq::ld(&W->thr); s_par = aq::ld(&W->par);           // (constant while anybody holds a ticket of the plan)
       uint32_t solve = 0u;
       if (v != kInfBits) {
         if (u2f(v) > bound) {                                         // can never propagate any more (k_tile_round does the same)
@@ -173,25 +220,21 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
           ++my_dropped;
         } else {
           solve = 1u;
-          const float pv = u2f(v);
-          float thr = inf_f();
-          if (P.band > 0.f && P.band < inf_f()) { thr = pv + P.band; if (!(thr > pv)) thr = next_up(pv); }
-          s_thr_bits = f2u(thr);
           s_hdr[0] = P.vptr[t]; s_hdr[1] = P.vptr[t + 1]; s_hdr[2] = P.hptr[t]; s_hdr[3] = P.hptr[t + 1];
           s_hdr[4] = P.eptr[t]; s_hdr[5] = P.eptr[t + 1]; s_hdr[6] = P.rptr[t];
           s_hdr[7] = aq::ld(reinterpret_cast<uint32_t*>(P.tlast) + t);
           s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
         }
       }
-      s_solve = solve; s_wover = 0u;
+      s_solve = solve; s_wover = 0u; s_advance = 0u;
     }
     if (tid < (int)kAsyncWake) { s_wtile[tid] = kNone; s_wval[tid] = kInfBits; }
     __syncthreads();
     uint32_t sweep = 0;
-    float thr = inf_f();
+    const float thr = u2f(s_thr_bits);
+    const uint32_t par = s_par;
     if (s_solve) {
       // ---- solve tile t (k_tile_round's solve; distances through agent-scope loads / stores)
-      thr = u2f(s_thr_bits);
       const float bound = u2f(s_bound_bits);
       const uint32_t v0 = s_hdr[0], nv = s_hdr[1] - v0;
       const uint32_t h0 = s_hdr[2], nh = s_hdr[3] - h0;
@@ -246,7 +289,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
           const uint32_t db = ldu[i];
           if (db != orig[k2]) aq::st(dbits + gi[k2], db);
           const float d = u2f(db);
-          if (!(d < thr) && d <= bound) own_left = min(own_left, db);   // owned values that still have to propagate: the tile's own wake-up (banded solve only)
+          if (!(d < thr) && d <= bound) own_left = min(own_left, db);   // owned values that still have to propagate: the tile parks itself for them
         }
       }
       // ... the wake-ups collected per neighbour tile in LDS (a tile has a handful of neighbours, a hundred halo vertices)
@@ -267,28 +310,84 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       if (lane == 0 && own_left != kInfBits) collect(t, own_left);
       aq::drain();                                                     // every storing wave: its distance stores have left the CU ...
       __syncthreads();                                                 // ... before the first wake-up can be seen
-      if (tid < (int)kAsyncWake && s_wtile[tid] != kNone) aq::wake(P, p, s_wtile[tid], s_wval[tid], ring, actl);
+      if (tid < (int)kAsyncWake && s_wtile[tid] != kNone) aq::wake(P, p, s_wtile[tid], s_wval[tid], thr, par, ring, actl);
       if (s_wover) {                                                   // more neighbour tiles than table slots: one wake-up per halo vertex
         for (uint32_t i = tid; i < nh; i += kTileBlock) {
           const uint32_t b = ldu[nv + i];
-          if (b < lh0[i]) aq::wake(P, p, g_halo_tile[h0 + i], b, ring, actl);
+          if (b < lh0[i]) aq::wake(P, p, g_halo_tile[h0 + i], b, thr, par, ring, actl);
         }
-        if (lane == 0 && own_left != kInfBits) aq::wake(P, p, t, own_left, ring, actl);   // (own_left: this wave's minimum)
+        if (lane == 0 && own_left != kInfBits) aq::wake(P, p, t, own_left, thr, par, ring, actl);   // (own_left: this wave's minimum)
       }
       aq::drain();
       __syncthreads();                                                 // every wake-up has returned
     }
-    // ---- retire the ticket: the tile is ours until state[t] is cleared; a wake-up that came in meanwhile gets its ticket here
+    // ---- retire the ticket: the tile is ours until state[t] is cleared; a wake-up that came in meanwhile is routed here
     if (tid == 0) {
       if (s_solve) {
         aq::st(reinterpret_cast<uint32_t*>(P.tlast) + t, f2u(thr));
-        aq::add(aq::acts_of(P), 1u); aq::add(aq::sweeps_of(P), sweep);
+        aq::add(&W->acts, 1u); aq::add(&W->sweeps, sweep);
         aq::drain();                                                   // the next solver of t reads tlast after its ticket arrived
       }
-      (void)aq::aand(state + t, 0u);
+      (void)aq::xchg(state + t, 0u);
       aq::drain();                                                     // cleared BEFORE the look (Dekker, see the header)
-      if (aq::ld(pend + t) != kInfBits && aq::aor(state + t, 1u) == 0u) aq::push(P, p, t, ring, actl);
-      if (aq::sub(aq::work_of(P), 1u) == 1u) aq::plan_finish(P, actl);   // the count this ticket held
+      const uint32_t v2 = aq::ld(pend + t);
+      if (v2 != kInfBits) aq::route(P, p, t, v2, thr, par, ring, actl);
+      aq::drain();
+      if (aq::sub(&W->work, 1u) == 1u) s_advance = 1u;                 // the count this ticket held was the plan's last: nobody else touches the plan now
+    }
+    __syncthreads();
+    // ---- advance the band (the whole workgroup; exclusive until its first ticket is filed: no ticket of the plan is out)
+    uint32_t par_c = par;
+    while (s_advance) {
+      const uint32_t cap = aq::kParkedLists * P.ntiles;
+      const uint32_t pk_old = 1u + par_c, par2 = par_c ^ 1u, pk_new = 1u + par2;
+      uint32_t* const list = P.parked + (size_t)par_c * cap;
+      const uint32_t cnt = min(aq::ld(&W->nparked[par_c]), cap);
+      const float bound = (float)((double)u2f(aq::ld(dbits + P.target)) + fmax(P.offset, 0.0));
+      // pass 1: the smallest parked wake-up value that can still propagate
+      uint32_t mn = kInfBits, beyond = 0u;
+      for (uint32_t i = tid; i < cnt; i += kTileBlock) {
+        const uint32_t t2 = aq::ld(list + i);
+        if (aq::ld(state + t2) != pk_old) continue;                    // promoted since it was listed (a tile parked again has a second entry)
+        const uint32_t v = aq::ld(pend + t2);
+        if (u2f(v) > bound) beyond = 1u; else mn = min(mn, v);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o)); beyond |= (uint32_t)__shfl_xor((int)beyond, o); }
+      if (lane == 0) { s_min[wid] = mn; s_bey[wid] = beyond; }
+      __syncthreads();
+      mn = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+      beyond = s_bey[0] | s_bey[1] | s_bey[2] | s_bey[3];
+      __syncthreads();
+      if (mn == kInfBits && !beyond) {                                 // nothing parked: the plan is at its fixed point
+        if (tid == 0) { aq::plan_finish(P, actl); s_advance = 0u; }
+        __syncthreads();
+        break;
+      }
+      // the next band [m, m + band); parked tiles beyond the bound get a ticket too (it is retired without a solve, tlast marked)
+      float thr2 = inf_f();
+      if (mn != kInfBits && P.band > 0.f && P.band < inf_f()) { const float m = u2f(mn); thr2 = m + P.band; if (!(thr2 > m)) thr2 = next_up(m); }
+      if (tid == 0) {
+        aq::st(&W->work, 1u);                                          // this workgroup's own hold while it files the band's tickets
+        aq::st(&W->thr, f2u(thr2)); aq::st(&W->par, par2); aq::st(&W->nparked[par2], 0u);
+        aq::add(&W->epochs, 1u);
+        aq::drain();
+      }
+      __syncthreads();
+      // pass 2: tickets for the parked tiles of the new band, the others move to the new list.  The first ticket filed ends the
+      // exclusivity: wakers of the new band route tiles concurrently (also tiles still in the old parked state: see route()).
+      for (uint32_t i = tid; i < cnt; i += kTileBlock) {
+        const uint32_t t2 = aq::ld(list + i);
+        if (aq::ld(state + t2) != pk_old) continue;                    // (also: the second entry of a tile this pass has handled already)
+        const uint32_t v = aq::ld(pend + t2);
+        if (u2f(v) < thr2 || u2f(v) > bound) { if (aq::amax(state + t2, aq::kActive) < aq::kActive) aq::push(P, p, t2, ring, actl); }
+        else if (aq::cas(state + t2, pk_old, pk_new)) aq::park(P, t2, par2, actl);   // (failed: a waker has routed it meanwhile)
+      }
+      aq::drain();
+      __syncthreads();
+      if (tid == 0) s_advance = (aq::sub(&W->work, 1u) == 1u) ? 1u : 0u;   // the band's tickets are retired already (or none was filed): once more
+      __syncthreads();
+      par_c = par2;
     }
   }
   if (tid == 0 && (my_polls | my_dropped)) { atomicAdd(&actl->polls, my_polls); atomicAdd(&actl->dropped, my_dropped); }

@@ -408,18 +408,29 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
     T.max_rounds = 0x7FFFFFF0u;
     T.cancel = ctx->d_cancel;
-    T.band = opt_set(ctx->opt.async_band_mult) && ctx->opt.async_band_mult > 0.0 ? (float)(ctx->opt.async_band_mult * ctx->tile_band_auto) : 0.f;   // 0: every solve runs to the tile's local fixed point
+    T.band = (float)((opt_set(ctx->opt.async_band_mult) ? ctx->opt.async_band_mult : 4.0) * ctx->tile_band_auto);   // band of the plan (<= 0: one band, every solve runs to its tile's fixed point)
     T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
   AsyncCtl* const actl = reinterpret_cast<AsyncCtl*>(ctx->d_cancel + 4);   // words 4..11 of the 64-byte control line (word 0: mnav_cancel)
   // the ticket ring: every slot is written at most once per call, so it only has to hold what a call can file (a tile is
   // re-filed when a neighbour undercuts it after its solve: a handful of times) -- 16 per tile and plan; a call that runs out
   // gives up (abort 5) and is re-run on the tile rounds by the caller
-  const uint64_t want = std::min<uint64_t>(std::max<uint64_t>((uint64_t)n * M.ntiles * 16u, 1u << 16), 1u << 27);
-  if (ctx->ring_cap < want) {
+  const bool ring_forced = opt_set(ctx->opt.async_ring_cap);
+  const uint64_t want = ring_forced ? std::max<uint64_t>(n + 1u, opt_u32(ctx->opt.async_ring_cap, 0u))
+                                    : std::min<uint64_t>(std::max<uint64_t>((uint64_t)n * M.ntiles * 16u, 1u << 16), 1u << 27);
+  if (ctx->ring_cap < want || (ring_forced && ctx->ring_cap != want)) {
     (void)hipFree(ctx->d_ring); ctx->d_ring = nullptr; ctx->ring_cap = 0;
     HIPCHK(hipMalloc((void**)&ctx->d_ring, 4 * (size_t)want));
     ctx->ring_cap = (uint32_t)want; ctx->ring_used = ctx->ring_cap;
+  }
+  {
+    const size_t per_plan = 2u * (size_t)aq::kParkedLists * M.ntiles;   // the two parked lists of a plan
+    if (ctx->parked_words < per_plan * n) {
+      (void)hipFree(ctx->d_parked); ctx->d_parked = nullptr; ctx->parked_words = 0;
+      HIPCHK(hipMalloc((void**)&ctx->d_parked, 4 * per_plan * n));
+      ctx->parked_words = per_plan * n;
+    }
+    for (uint32_t i = 0; i < n; ++i) tp[i].parked = ctx->d_parked + per_plan * i;
   }
   HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));

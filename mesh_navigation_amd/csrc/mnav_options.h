@@ -25,8 +25,9 @@
   X(tb_tile)             /* tile-batch engine: rows per tile, read when its streams are built */                                          \
   X(tb_no_prefill) X(tb_band_mult) X(tb_waves_per_cu)                                                                                    \
   X(async_wg_per_cu) X(async_wg_per_plan) X(async_max_s)                                                                                 \
-  X(async_band_mult)     /* > 0: banded solves in the asynchronous engine (multiples of a tile width); default: local fixed point */     \
-  X(async_max_batch)     /* auto: batches of up to this many plans take the asynchronous engine */
+  X(async_band_mult)     /* band of the asynchronous engine in tile widths of potential (default 4; <= 0: no bands) */                         \
+  X(async_max_batch)     /* auto: batches of up to this many plans take the asynchronous engine */                                      \
+  X(async_ring_cap)      /* ticket slots of the asynchronous engine (default 16 per tile and plan; tests force the overflow path) */
 
 struct Options {
 #define X(name) double name = NAN;

@@ -302,24 +302,53 @@ template <int Q> __device__ __forceinline__ uint32_t bc(uint32_t d)   // dword Q
 }
 }  // namespace tb
 
-__device__ __forceinline__ bool tb_block(uint32_t D, uint32_t lane4)
+// One block of the sweep in two halves.  tb_issue: the LDS reads (FIRST: block 0 of a chunk reads all seven sources; a follower
+// reads six -- its slot 1 is the row the block before it writes, mnav_tb_build.h).  tb_retire: the relaxation (dijkstra :331) and
+// the unconditional rewrite of the target row (old bits when nothing improved; the sign bit marks "lowered in this activation");
+// `fwd` = what the block before wrote, a follower's slot-1 source.  Returns the bits written.
+template <bool FIRST>
+__device__ __forceinline__ void tb_issue(TbBlk& B, uint32_t D, uint32_t lane4)
 {
-  TbBlk B;
   B.ya = tb::bc<0>(D) + lane4;
   B.raw = tb::ldsr(B.ya);
-  B.v[0] = tb::ldsr(tb::bc<1>(D) + lane4); B.v[1] = tb::ldsr(tb::bc<2>(D) + lane4); B.v[2] = tb::ldsr(tb::bc<3>(D) + lane4);
+  if (FIRST) B.v[0] = tb::ldsr(tb::bc<1>(D) + lane4);
+  B.v[1] = tb::ldsr(tb::bc<2>(D) + lane4); B.v[2] = tb::ldsr(tb::bc<3>(D) + lane4);
   B.v[3] = tb::ldsr(tb::bc<4>(D) + lane4); B.v[4] = tb::ldsr(tb::bc<5>(D) + lane4); B.v[5] = tb::ldsr(tb::bc<6>(D) + lane4);
   B.v[6] = tb::ldsr(tb::bc<7>(D) + lane4);
+}
+template <bool FIRST>
+__device__ __forceinline__ uint32_t tb_retire(const TbBlk& B, uint32_t D, uint32_t fwd, bool& ch)
+{
   const uint32_t acc0 = B.raw & 0x7fffffffu;
-  const uint32_t t0 = f2u(fabsf(u2f(B.v[0])) + u2f(tb::bc<8>(D))), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(tb::bc<9>(D)));
+  const uint32_t s0 = FIRST ? B.v[0] : fwd;
+  const uint32_t t0 = f2u(fabsf(u2f(s0)) + u2f(tb::bc<8>(D))), t1 = f2u(fabsf(u2f(B.v[1])) + u2f(tb::bc<9>(D)));
   const uint32_t t2 = f2u(fabsf(u2f(B.v[2])) + u2f(tb::bc<10>(D))), t3 = f2u(fabsf(u2f(B.v[3])) + u2f(tb::bc<11>(D)));
   const uint32_t t4 = f2u(fabsf(u2f(B.v[4])) + u2f(tb::bc<12>(D))), t5 = f2u(fabsf(u2f(B.v[5])) + u2f(tb::bc<13>(D)));
   const uint32_t t6 = f2u(fabsf(u2f(B.v[6])) + u2f(tb::bc<14>(D)));
   uint32_t acc = min(min(acc0, t0), t1);
   acc = min(min(acc, t2), t3); acc = min(min(acc, t4), t5); acc = min(acc, t6);
-  const bool ch = acc < acc0;
-  tb::ldsw(B.ya, ch ? (acc | kTbDirty) : B.raw);
-  return ch;
+  ch = acc < acc0;
+  const uint32_t w = ch ? (acc | kTbDirty) : B.raw;
+  tb::ldsw(B.ya, w);
+  return w;
+}
+// A chunk = four blocks, software-pipelined: the reads of block j + 1 are issued before block j is computed and written.  That
+// is the plain Gauss-Seidel sweep bit for bit: block j + 1 never has block j's target, its only source that IS block j's target
+// sits in slot 1 and is taken from block j's result register, and everything older was written before the reads were issued (the
+// LDS executes in order).  Drained at the end of the chunk (block 0 of the next chunk reads everything from the LDS).
+__device__ __forceinline__ bool tb_chunk(const u32x4& ch4, uint32_t lane4)
+{
+  TbBlk b0, b1, b2, b3;
+  bool c0, c1, c2, c3;
+  tb_issue<true>(b0, ch4.x, lane4);
+  tb_issue<false>(b1, ch4.y, lane4);
+  const uint32_t w0 = tb_retire<true>(b0, ch4.x, 0u, c0);
+  tb_issue<false>(b2, ch4.z, lane4);
+  const uint32_t w1 = tb_retire<false>(b1, ch4.y, w0, c1);
+  tb_issue<false>(b3, ch4.w, lane4);
+  const uint32_t w2 = tb_retire<false>(b2, ch4.z, w1, c2);
+  (void)tb_retire<false>(b3, ch4.w, w2, c3);
+  return c0 | c1 | c2 | c3;
 }
 
 // All sweeps of an activation as ONE stream of chunks: three chunk registers in rotation, the load cursor three chunks ahead of the
@@ -329,6 +358,14 @@ __device__ __forceinline__ bool tb_block(uint32_t D, uint32_t lane4)
 // latency per three chunks, seen in the ISA); with it the load is issued where it is written and waited for where it is used.
 // A quarter past the end of its own stream re-runs its last chunk.  Returns the number of sweeps (the last one changed nothing in
 // any lane), or 0 with `overrun` set when the cap was hit.
+#ifndef MNAV_TB_DEPTH
+#define MNAV_TB_DEPTH 8
+#endif
+constexpr int kTbDepth = MNAV_TB_DEPTH;   // stream chunks in registers or in flight per wave
+#ifndef MNAV_TB_ROT
+#define MNAV_TB_ROT 2
+#endif
+constexpr int kTbRot = MNAV_TB_ROT;
 template <int T>
 __device__ __forceinline__ uint32_t tbq_sweeps(MNAV_GLOBAL const uint32_t* stream, uint32_t sweep_off, uint32_t nch, uint32_t max_nch, uint32_t first_order,
                                                uint32_t l16, uint32_t lane4, bool& overrun)
@@ -347,8 +384,7 @@ __device__ __forceinline__ uint32_t tbq_sweeps(MNAV_GLOBAL const uint32_t* strea
   overrun = false;
   bool done = false;
   auto step = [&](u32x4& R) {
-    any |= __ballot(tb_block(R.x, lane4)); any |= __ballot(tb_block(R.y, lane4));
-    any |= __ballot(tb_block(R.z, lane4)); any |= __ballot(tb_block(R.w, lane4));
+    any |= __ballot(tb_chunk(R, lane4));
     load(R);
     if (++c >= max_nch) {
       c = 0; ++sweep;
@@ -357,12 +393,19 @@ __device__ __forceinline__ uint32_t tbq_sweeps(MNAV_GLOBAL const uint32_t* strea
       any = 0ull;
     }
   };
-  u32x4 A, B, C;
-  load(A); load(B); load(C);
+  // kTbDepth chunk registers in rotation (the loop body is one full rotation: a load lands in the register it is consumed from)
+  u32x4 R[kTbDepth];
+#pragma unroll
+  for (int k = 0; k < kTbDepth; ++k) load(R[k]);
   for (;;) {
-    step(A); if (done) break;
-    step(B); if (done) break;
-    step(C); if (done) break;
+    // (the compiler waits for EVERY load in flight at the head of a loop, whatever the head needs -- seen in the ISA: vmcnt(0)
+    //  there, vmcnt(kTbDepth - 1) at the other steps --, so the body holds several rotations: one drain per kTbRot * kTbDepth chunks)
+#pragma unroll
+    for (int k = 0; k < kTbRot * kTbDepth; ++k) {
+      step(R[k % kTbDepth]);
+      if (done) break;
+    }
+    if (done) break;
   }
   return sweep;
 }

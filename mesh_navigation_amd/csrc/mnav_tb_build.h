@@ -53,7 +53,11 @@ static_assert(sizeof(TbTile) == 64, "TbTile is read as one 64-byte scalar load")
 // A chunk holds 4 BLOCKS of 16 dwords.  A "row" is a local vertex; offsets are the row's LDS byte offset (row * 256:
 // 64 lanes x 4 B).
 //   sweep block:  d0 = target offset, d1..d7 = source offsets, d8..d14 = weight bits of the sources (unused slots:
-//                 source = target, weight = +inf), d15 = 0
+//                 source = target, weight = +inf), d15 = 0.  A block that FOLLOWS another one inside its chunk (blocks 1..3)
+//                 never has that block's target, and its slot 1 (d1, d8) is reserved for the edge from that block's target row
+//                 (weight +inf when there is no such edge); no other slot names that row.  Read in order the stream is a plain
+//                 Gauss-Seidel sweep; the kernel uses the rule to have the LDS reads of block j + 1 in flight while block j is
+//                 computed: the one value block j + 1 needs from block j comes from a register (k_tb_solve_q).
 //   pre block:    d0 = flags | j | n << 8 (n = edges, 0 = empty block), d1..d5 = target offsets, d6..d10 = weight bits:
 //                 the ghost -> owned edges of ghost 4 * group + j;  in block 0 of a chunk d12 = the chunk's ghost group
 //                 (which 16-byte quad of the slice's ghost part), d13 = the NEXT chunk's group (prefetch)
@@ -209,14 +213,18 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     ++in_chunk;
     return at;
   };
-  auto init_sweep_block = [&](size_t at, uint32_t row) {             // every slot "target, +inf" until filled
+  // the row the block opened NEXT follows inside its chunk (kNone: it will be block 0 of a chunk)
+  auto chunk_prev = [&]() -> uint32_t { return (in_chunk == 0 || in_chunk == kTbBlocksPerChunk) ? kNone : last_target; };
+  auto init_sweep_block = [&](size_t at, uint32_t row, uint32_t prev) {   // every slot "target, +inf" until filled; slot 1 of a follower: "prev, +inf"
     for (int q = 0; q <= 7; ++q) H.stream[at + q] = row * kRow;
+    if (prev != kNone) H.stream[at + 1] = prev * kRow;
     for (int q = 8; q <= 14; ++q) H.stream[at + q] = kTbInfBits;
   };
   auto noop_sweep_block = [&]() {                                    // all weights +inf, on a row the previous block did not target
     const uint32_t row = (last_target == 0u) ? 1u : 0u;
+    const uint32_t prev = chunk_prev();
     const size_t at = open_block();
-    init_sweep_block(at, row);
+    init_sweep_block(at, row, prev);
     last_target = row;
   };
   auto close_chunk = [&](bool sweep) {                               // pad the open chunk
@@ -225,6 +233,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     in_chunk = 0; last_target = kNone;
   };
   std::vector<uint16_t> order;
+  std::vector<std::pair<uint32_t, uint32_t>> srcs;
   std::vector<uint32_t> ts;
   for (uint32_t tl = 0; tl < H.ntiles; ++tl) {
     TbTile& W = H.tiles[tl];
@@ -252,19 +261,25 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
       const size_t first = H.stream.size() / kTbChunk;
       for (uint32_t i = 0; i < W.nv; ++i) {
         const uint32_t y = order[i], v = H.verts[W.v0 + y];
-        uint32_t n = 0; size_t at = 0;
-        for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
-          const uint32_t u = t.nbr_u[k];
-          if (H.vert_tile[u] != tl) continue;
-          if (n == 0) {
-            if (in_chunk != kTbBlocksPerChunk && in_chunk != 0 && last_target == y) noop_sweep_block();   // continuation of a high-valence vertex
-            at = open_block();
-            last_target = y;
-            init_sweep_block(at, y);
+        srcs.clear();                                                // the row's sources inside the tile: {local row, entry of the gather CSR}
+        for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k)
+          if (H.vert_tile[t.nbr_u[k]] == tl) srcs.push_back({ H.vert_local[t.nbr_u[k]], k });
+        while (!srcs.empty()) {
+          if (chunk_prev() == y) noop_sweep_block();                 // continuation of a high-valence vertex: never the same target twice in a row
+          const uint32_t prev = chunk_prev();
+          const size_t at = open_block();
+          init_sweep_block(at, y, prev);
+          last_target = y;
+          uint32_t slot = 1;
+          if (prev != kNone) {                                       // a follower: slot 1 belongs to the edge from the row the block before it writes
+            for (size_t e = 0; e < srcs.size(); ++e)
+              if (srcs[e].first == prev) { H.wsrc[at + 8] = srcs[e].second; srcs.erase(srcs.begin() + e); break; }
+            slot = 2;
           }
-          H.stream[at + 1 + n] = H.vert_local[u] * kRow;
-          H.wsrc[at + 8 + n] = k;
-          if (++n == 7) n = 0;
+          while (slot <= 7 && !srcs.empty()) {
+            H.stream[at + slot] = srcs.front().first * kRow; H.wsrc[at + 7 + slot] = srcs.front().second;
+            srcs.erase(srcs.begin()); ++slot;
+          }
         }
       }
       close_chunk(true);
@@ -286,12 +301,23 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
             const size_t at = st2.size();
             st2.resize(at + kTbBlock, 0u); ws2.resize(at + kTbBlock, kNone);
             for (int q = 0; q <= 7; ++q) st2[at + q] = (j & 1u) * kRow;
+            if (j) st2[at + 1] = ((j - 1u) & 1u) * kRow;             // (a follower's slot 1 names the row the block before it writes)
             for (int q = 8; q <= 14; ++q) st2[at + q] = kTbInfBits;
           }
       }
       H.stream.resize((size_t)W.sweep_off * kTbChunk); H.wsrc.resize((size_t)W.sweep_off * kTbChunk);
       H.stream.insert(H.stream.end(), st2.begin(), st2.end()); H.wsrc.insert(H.wsrc.end(), ws2.begin(), ws2.end());
     }
+    // what the software-pipelined sweep of the kernel relies on (see the stream description above), checked on every chunk
+    for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c)
+      for (uint32_t j = 1; j < kTbBlocksPerChunk; ++j) {
+        const uint32_t* K = &H.stream[c * kTbChunk + kTbBlock * j];
+        const uint32_t* Ws = &H.wsrc[c * kTbChunk + kTbBlock * j];
+        const uint32_t prev = K[-(int)kTbBlock];
+        bool ok = K[0] != prev && K[1] == prev;
+        for (int q = 2; q <= 7; ++q) ok = ok && !(K[q] == prev && Ws[7 + q] != kNone);
+        if (!ok) throw std::logic_error("tile-batch streams: a follower block breaks the forwarding rules");
+      }
     // transpose the tile's sweep chunks (tb_sweep_index): built block by block above, read lane by lane by the kernel
     for (size_t c = (size_t)W.sweep_off; c < (size_t)W.sweep_off + 4u * W.sweep_chunks; ++c) {
       uint32_t tmp[kTbChunk], tmpw[kTbChunk];

@@ -40,6 +40,7 @@ struct TilePlan {
   uint32_t max_nv, max_nh, max_ne;
   const uint32_t* cancel;  // device word set by mnav_cancel (polled by the persistent kernels), may be null
   uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
+  uint32_t* parked;        // asynchronous engine (mnav_async.h): the two parked lists of the plan, 2 x kParkedLists x ntiles tile ids
   const uint8_t* owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
                            // neighbourhood is incomplete here (its value arrives through the exchange); null: every vertex is owned
 };

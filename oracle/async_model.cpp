@@ -35,6 +35,8 @@ constexpr uint32_t kWakeSlots = 32;       // kAsyncWake
 struct PlanState {
   std::vector<uint32_t> dist, pend, lock, tlast;   // float bits; lock = the state word (1: a ticket is filed or the tile is in solve)
   std::vector<uint8_t> ticketed;                   // model only: a ticket of the tile is in the ring and not yet retired
+  uint32_t thr = 0, par = 0, nparked[2] = { 0, 0 }, epochs = 0;   // the plan's band: threshold (float bits), parity of the current parked list
+  std::vector<uint32_t> parked[2];
   uint32_t work = 1, acts = 0, sweeps = 0, done = 0, finishes = 0;
   uint32_t seed = 0, target = 0;
   std::vector<uint8_t> in_solve;                   // model only: a workgroup is between claim and unlock
@@ -103,12 +105,11 @@ struct Wg {
   uint32_t xchg(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = v; return o; }
   bool cas(uint32_t& w, uint32_t e, uint32_t v) { M.pass(me); if (w != e) return false; w = v; return true; }
 
-  uint32_t aor(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = o | v; return o; }
-  uint32_t aand(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; w = o & v; return o; }
+  uint32_t amax(uint32_t& w, uint32_t v) { M.pass(me); const uint32_t o = w; if (v > o) w = v; return o; }
 
   void plan_finish(PlanState& P)
   {
-    // model-only checks, on a consistent snapshot (nobody else runs): nothing of the plan is pending, queued or in solve
+    // model-only checks, on a consistent snapshot (nobody else runs): nothing of the plan is pending, parked, queued or in solve
     for (size_t t = 0; t < P.pend.size(); ++t)
       if (P.pend[t] != kInf || P.lock[t] != 0u || P.in_solve[t] || P.ticketed[t]) ++M.violations;
     if (P.work != 0) ++M.violations;
@@ -123,11 +124,22 @@ struct Wg {
     const uint32_t i = add(M.tail, 1u);
     if (i < M.ring.size()) st(M.ring[i], (p << 24) | t); else st(M.abort, 5u);
   }
-  void wake(PlanState& P, uint32_t p, uint32_t t2, uint32_t v)
+  void park(PlanState& P, uint32_t t, uint32_t par)
   {
-    if (amin(P.pend[t2], v) != kInf) return;                         // pending already: whoever made it so files (or filed) the ticket
-    if (M.mutate == 3u) { aor(P.lock[t2], 1u); push(P, p, t2); return; }
-    if (aor(P.lock[t2], 1u) == 0u) push(P, p, t2);
+    const uint32_t i = add(P.nparked[par], 1u);
+    if (i < P.parked[par].size()) st(P.parked[par][i], t); else st(M.abort, 5u);
+  }
+  void route(PlanState& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par)
+  {
+    if (u2f(v) < thr) {
+      if (M.mutate == 3u) { amax(P.lock[t2], 3u); push(P, p, t2); return; }
+      if (amax(P.lock[t2], 3u) < 3u) push(P, p, t2);
+    } else { const uint32_t pk = 1u + par; if (amax(P.lock[t2], pk) < pk) park(P, t2, par); }
+  }
+  void wake(PlanState& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par)
+  {
+    amin(P.pend[t2], v);
+    route(P, p, t2, v, thr, par);
   }
 
   void run(uint32_t n, uint32_t)
@@ -139,7 +151,7 @@ struct Wg {
       const uint32_t i = add(M.head, 1u);
       uint32_t e = kNone - 1u;                                       // kTicketExit
       if (i < M.ring.size()) {
-        for (uint32_t spins = 0;; ++spins) {
+        for (;;) {
           e = ld(M.ring[i]);
           if (e != kNone) break;
           e = kNone - 1u;
@@ -153,17 +165,14 @@ struct Wg {
       const uint32_t v = xchg(P.pend[t], kInf);
       const float dt = u2f(ld(P.dist[P.target]));
       const float bound = (float)((double)dt + std::max(M.offset, 0.0));
+      const float thr = u2f(ld(P.thr));
+      const uint32_t par = ld(P.par);
       bool solve = false;
-      float thr = inf_f();
       if (v != kInf) {
         if (u2f(v) > bound) {
           if (!(u2f(ld(P.tlast[t])) > -inf_f())) st(P.tlast[t], f2u(-3.0e38f));
           ++M.drops;
-        } else {
-          solve = true;
-          const float pv = u2f(v);
-          if (M.band > 0.f && M.band < inf_f()) { thr = pv + M.band; if (!(thr > pv)) thr = next_up(pv); }
-        }
+        } else solve = true;
       }
       uint32_t sweep = 0;
       if (solve) {
@@ -219,10 +228,10 @@ struct Wg {
         };
         for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) collect(T.halo_tile[h0 + k], ldu[nv + k]);
         if (own_left != kInf) collect(t, own_left);
-        for (uint32_t sl = 0; sl < kWakeSlots; ++sl) if (wt[sl] != kNone) wake(P, p, wt[sl], wv[sl]);
+        for (uint32_t sl = 0; sl < kWakeSlots; ++sl) if (wt[sl] != kNone) wake(P, p, wt[sl], wv[sl], thr, par);
         if (over) {
-          for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) wake(P, p, T.halo_tile[h0 + k], ldu[nv + k]);
-          if (own_left != kInf) wake(P, p, t, own_left);
+          for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) wake(P, p, T.halo_tile[h0 + k], ldu[nv + k], thr, par);
+          if (own_left != kInf) wake(P, p, t, own_left, thr, par);
         }
         st(P.tlast[t], f2u(thr));
         add(P.acts, 1u); add(P.sweeps, sweep);
@@ -230,9 +239,39 @@ struct Wg {
       }
       // ---- retire the ticket
       P.ticketed[t] = 0;
-      aand(P.lock[t], 0u);
-      if (M.mutate != 2u && ld(P.pend[t]) != kInf && aor(P.lock[t], 1u) == 0u) push(P, p, t);
-      if (sub(P.work, 1u) == 1u) plan_finish(P);
+      xchg(P.lock[t], 0u);
+      if (M.mutate != 2u) { const uint32_t v2 = ld(P.pend[t]); if (v2 != kInf) route(P, p, t, v2, thr, par); }
+      bool advance = sub(P.work, 1u) == 1u;
+      // ---- advance the band (exclusive until its first ticket is filed)
+      uint32_t par_c = par;
+      while (advance) {
+        if (M.solves_now && P.work == 0) { for (size_t k = 0; k < P.in_solve.size(); ++k) if (P.in_solve[k]) ++M.violations; }   // somebody still solves a tile of the plan
+        const uint32_t pk_old = 1u + par_c, par2 = par_c ^ 1u, pk_new = 1u + par2;
+        const uint32_t cnt = std::min<uint32_t>(ld(P.nparked[par_c]), (uint32_t)P.parked[par_c].size());
+        const float bound2 = (float)((double)u2f(ld(P.dist[P.target])) + std::max(M.offset, 0.0));
+        uint32_t mn = kInf; bool beyond = false;
+        for (uint32_t k = 0; k < cnt; ++k) {
+          const uint32_t t2 = ld(P.parked[par_c][k]);
+          if (ld(P.lock[t2]) != pk_old) continue;
+          const uint32_t pv = ld(P.pend[t2]);
+          if (u2f(pv) > bound2) beyond = true; else mn = std::min(mn, pv);
+        }
+        if (mn == kInf && !beyond) { plan_finish(P); break; }
+        float thr2 = inf_f();
+        if (mn != kInf && M.band > 0.f && M.band < inf_f()) { const float m = u2f(mn); thr2 = m + M.band; if (!(thr2 > m)) thr2 = next_up(m); }
+        st(P.work, 1u);
+        st(P.thr, f2u(thr2)); st(P.par, par2); st(P.nparked[par2], 0u);
+        add(P.epochs, 1u);
+        for (uint32_t k = 0; k < cnt; ++k) {
+          const uint32_t t2 = ld(P.parked[par_c][k]);
+          if (ld(P.lock[t2]) != pk_old) continue;
+          const uint32_t pv = ld(P.pend[t2]);
+          if (u2f(pv) < thr2 || u2f(pv) > bound2) { if (amax(P.lock[t2], 3u) < 3u) push(P, p, t2); }
+          else if (cas(P.lock[t2], pk_old, pk_new)) park(P, t2, par2);
+        }
+        advance = sub(P.work, 1u) == 1u;
+        par_c = par2;
+      }
     }
     M.leave(me);
   }
@@ -240,7 +279,7 @@ struct Wg {
 }  // namespace
 
 extern "C" {
-// stats_out: [0] activations, [1] sweeps, [2] -, [3] tickets retired beyond the bound, [4] plan finishes, [5] scheduling
+// stats_out: [0] activations, [1] sweeps, [2] band advances, [3] tickets retired beyond the bound, [4] plan finishes, [5] scheduling
 // points, [6] most concurrent solves, [7] invariant violations, [8] abort code, [9] tickets filed, [10] -, [11] tiles
 uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, const uint32_t* edge_vtx, const float* edge_weights,
                  const float* vertex_costs, const uint8_t* invalid, const float* xyz, uint32_t tile_size, uint32_t n, const uint32_t* seeds,
@@ -262,7 +301,9 @@ uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     P.in_solve.assign(M.T.ntiles, 0); P.ticketed.assign(M.T.ntiles, 0);
     P.seed = seeds[p]; P.target = targets[p];
     const uint32_t st = M.T.vert_tile[P.seed];
-    P.dist[P.seed] = 0u; P.pend[st] = 0u; P.lock[st] = 1u; P.ticketed[st] = 1; P.work = 1u;   // k_init, k_tile_init, k_async_init
+    P.dist[P.seed] = 0u; P.pend[st] = 0u; P.lock[st] = 3u; P.ticketed[st] = 1; P.work = 1u;   // k_init, k_tile_init, k_async_init
+    P.thr = f2u((band > 0.f && band < inf_f()) ? band : inf_f()); P.par = 0;
+    P.parked[0].assign(4 * (size_t)M.T.ntiles, 0u); P.parked[1].assign(4 * (size_t)M.T.ntiles, 0u);
   }
   M.ring.assign((size_t)std::max<uint32_t>(ring_cap, n), kNone);
   for (uint32_t p = 0; p < n; ++p) M.ring[p] = (p << 24) | M.T.vert_tile[M.plans[p].seed];
@@ -281,7 +322,8 @@ uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     if (P.finishes != 1u && !M.abort) ++M.violations;
     for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(P.dist[v]);
   }
-  stats_out[0] = acts; stats_out[1] = sweeps; stats_out[2] = M.claim_fails; stats_out[3] = M.drops; stats_out[4] = fins; stats_out[5] = M.yields;
+  uint64_t epochs = 0; for (uint32_t p = 0; p < n; ++p) epochs += M.plans[p].epochs;
+  stats_out[0] = acts; stats_out[1] = sweeps; stats_out[2] = epochs; stats_out[3] = M.drops; stats_out[4] = fins; stats_out[5] = M.yields;
   stats_out[6] = M.max_solves; stats_out[7] = M.violations; stats_out[8] = M.abort; stats_out[9] = M.tail; stats_out[10] = 0;
   stats_out[11] = M.T.ntiles;
   return M.abort ? 1u : 0u;

@@ -444,8 +444,8 @@ def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
                      workgroups=4, sched_seed=1, budget=50_000_000, invalid=None, mutate=0, ring_cap=None):
     """The PROTOCOL of the asynchronous tile engine (mnav_async.h: ticket queue of woken tiles) on the CPU model
     (oracle/async_model.cpp): `workgroups` virtual workgroups, interleaved pseudo-randomly (seed) at every shared-memory operation,
-    on the product's own tile tables.  band = 0: every solve runs to the tile's local fixed point (the product's default);
-    band > 0: banded solves, in potential units; band = 'tile': one tile width."""
+    on the product's own tile tables.  band = 0: no bands (every solve runs to the tile's local fixed point);
+    band > 0: the plans advance in bands of that width, in potential units; band = 'tile': one tile width."""
     faces, edges = _u32(faces), _u32(edges)
     w, vc, pos = _f32(edge_weights), _f32(vertex_costs), _f32(xyz)
     V, F, E = vc.shape[0], faces.shape[0], edges.shape[0]
@@ -465,7 +465,7 @@ def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
     L.asm_run.restype = C.c_uint32
     code = L.asm_run(V, F, E, _p(faces), _p(edges), _p(w), _p(vc), _p(inv), _p(pos), int(tile), n, _p(sd), _p(tg), float(offset),
                      float(cost_limit), float(band), int(workgroups), int(sched_seed), int(budget), int(mutate), int(ring_cap), _p(dist), _p(stats))
-    return dict(code=code, dist=dist, activations=int(stats[0]), sweeps=int(stats[1]), drops=int(stats[3]),
+    return dict(code=code, dist=dist, activations=int(stats[0]), sweeps=int(stats[1]), epochs=int(stats[2]), drops=int(stats[3]),
                 finishes=int(stats[4]), scheduling_points=int(stats[5]), max_concurrent_solves=int(stats[6]), violations=int(stats[7]),
                 abort=int(stats[8]), tickets=int(stats[9]), tiles=int(stats[11]))
 

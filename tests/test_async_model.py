@@ -93,6 +93,7 @@ def test_many_interleavings_on_a_mesh_of_seven_tiles():
                 sched_seed=seed + 1)
         tickets += r["tickets"]
         assert r["tickets"] >= r["activations"] + r["drops"]
+        assert (r["epochs"] > 0) == bool(seed % 2)                    # band advances only with a band
     assert tickets > 40 * 7
 
 
@@ -109,7 +110,7 @@ def test_the_model_sees_protocol_errors():
     them; the intact protocol passes all of those schedules): that is what makes a green run mean something."""
     case = terrain_case(14, 5)
     m = case.mesh
-    kw = dict(offset=np.inf, tile=32, band=0.05, workgroups=4, budget=3_000_000)
+    kw = dict(offset=np.inf, tile=32, band=0.5, workgroups=4, budget=3_000_000)   # (a band a few tiles wide: several tiles in flight at once)
     seeds = range(1, 25)
     def bad(mutate):
         return [O.async_tile_model(m.xyz, m.faces, m.edges, case.weights, case.costs, [97], [5], sched_seed=s, mutate=mutate, **kw) for s in seeds]
