@@ -252,6 +252,11 @@ int mnav_shard_walk(mnav_ctx* ctx, uint32_t start_vertex, uint32_t seed_vertex, 
 uint64_t mnav_device_bytes(const mnav_ctx* ctx);
 
 int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit);
+/* Partitioned data, negative goal_dist_offset only: with such an offset the reference expands exactly the vertices popped BEFORE
+ * the robot vertex (dijkstra_mesh_planner.cpp:293-300), and among vertices of the robot vertex's potential the vertex id decides.
+ * A part that does not hold the robot vertex passes the robot's RANK among its own (ascending) ids -- the number of local vertices
+ * with a smaller global id -- before mnav_shard_begin; parts that hold it need not call this. */
+int mnav_shard_set_goal_tie(mnav_ctx* ctx, uint32_t tie_id);
 int mnav_shard_rounds(mnav_ctx* ctx, uint32_t rounds, float* iface_buf_dev);
 int mnav_shard_apply(mnav_ctx* ctx, const float* iface_buf_dev, float* local_min_out, float* target_dist_out);
 int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_dev);
@@ -283,7 +288,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
  * 1 = the distance-band gather steps that the CVP planner uses,
  * 2 = persistent per-plan workgroups walking the tiles best-first (on request only),
  * 3 = automatic (default): 5 for batches of >= 48 plans that also hold >= tiles/1000 plans, 6 for smaller calls (up to
- *     option async_max_batch = 47 plans; a call whose ticket ring overflows is re-run on 0), else 0,
+ *     option async_max_batch = 8 plans; a call whose ticket ring overflows is re-run on 0), else 0,
  * 5 = tile-batch: one plan per lane, 16 plans per quarter of a wave, the tile's graph as record streams
  *     (highest throughput for large batches),
  * 6 = the LDS tiles without rounds: resident workgroups serve a ticket queue of woken tiles, solve and wake tiles

@@ -56,6 +56,7 @@ private:
   mnav_ctx* ctx_ = nullptr;
   uint32_t V_ = 0, F_ = 0, E_ = 0;
   uint64_t cost_hash_ = 0;
+  uint32_t probe_v_ = 0, probe_e_ = 0;   // rotating windows of the backstop check behind the change signal (syncCosts)
   bool have_costs_ = false;
   std::vector<float> costs_, weights_;
   std::vector<uint8_t> invalid_;

@@ -98,9 +98,38 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
   if (have_costs_ && !force && log_ && log_->attached()) {
     // The change signal (cost_observer_layer.h): MeshMap::layerChanged (mesh_map.cpp:454-493) has updated vertex_costs and, through
     // updateEdgeWeights(changed) (:563-618), the weights of the changed vertices' edges; exactly those go to the device.
-    // (`invalid` only changes when a planner trips over a broken vertex, dijkstra :312-321: picked up by `reload_costs`.)
+    // What the signal does NOT cover -- `mesh_map.edge_cost_factor` reconfigured (mesh_map.cpp:1379-1397 recomputes every edge
+    // weight with no layer notification), `invalid` flipped by a planner that tripped over a broken vertex (dijkstra :306-321) --
+    // is caught by a BACKSTOP: every plan compares a rotating window of kProbe vertices (cost, invalid) and kProbe edges
+    // (weight) of the map with the mirror of what the device holds; any difference takes the full copy.  A change of every
+    // edge weight is seen by the very next plan, a sparse unsignalled change within ceil(V / kProbe) plans (or at once with
+    // `reload_costs`).
+    constexpr uint32_t kProbe = 4096;
+    auto probe_differs = [&]() -> bool {
+      bool diff = false;
+      const uint32_t nv = std::min(kProbe, V_), ne = std::min(kProbe, E_);
+      for (uint32_t i = 0; i < nv && !diff; ++i) {
+        const uint32_t v = (probe_v_ + i) % V_;
+        const lvr2::VertexHandle vH(v);
+        const auto c = std::as_const(vc).get(vH);
+        const float f = c ? *c : 0.f;
+        diff = std::memcmp(&f, &costs_[v], 4) != 0 || (map.invalid[vH] ? 1 : 0) != invalid_[v];
+      }
+      for (uint32_t i = 0; i < ne && !diff; ++i) {
+        const uint32_t e = (probe_e_ + i) % E_;
+        const auto w = std::as_const(ew).get(lvr2::EdgeHandle((size_t)e));
+        const float f = w ? *w : std::numeric_limits<float>::infinity();
+        diff = std::memcmp(&f, &weights_[e], 4) != 0;
+      }
+      if (V_) probe_v_ = (probe_v_ + nv) % V_;
+      if (E_) probe_e_ = (probe_e_ + ne) % E_;
+      return diff;
+    };
     const std::vector<uint32_t> ids = log_->take(log_id_);
-    if (ids.empty()) return true;
+    if (ids.empty()) {
+      if (costs_.size() == V_ && weights_.size() == E_ && probe_differs()) return syncCosts(map, err, true);
+      return true;
+    }
     const auto mesh = map.mesh();
     std::vector<float> vals(ids.size());
     std::vector<uint32_t> eids;
@@ -126,6 +155,11 @@ bool DeviceMap::syncCosts(mesh_map::MeshMap& map, std::string& err, bool force)
     if (mnav_update_costs(ctx_, (uint32_t)ids.size(), ids.data(), vals.data()) != 0 ||
         mnav_update_edge_weights(ctx_, (uint32_t)eids.size(), eids.data(), evals.data()) != 0) { err = mnav_last_error(ctx_); return false; }
     ++g_incremental_updates;
+    if (costs_.size() == V_ && weights_.size() == E_) {               // the mirror follows (the backstop compares against it)
+      for (size_t i = 0; i < ids.size(); ++i) costs_[ids[i]] = vals[i];
+      for (size_t i = 0; i < eids.size(); ++i) weights_[eids[i]] = evals[i];
+      if (probe_differs()) return syncCosts(map, err, true);
+    }
     return true;
   }
   ++g_signing_passes;

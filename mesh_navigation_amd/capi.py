@@ -27,7 +27,7 @@ SYMBOLS = [
     "mnav_shard_finalize", "mnav_update_costs", "mnav_update_edge_weights", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
-    "mnav_set_option", "mnav_get_option",
+    "mnav_set_option", "mnav_get_option", "mnav_shard_set_goal_tie",
 ]
 
 
@@ -109,6 +109,8 @@ def load(path: str | None = None):
     L.mnav_set_band_width.argtypes = [vp, C.c_float]
     L.mnav_set_dijkstra_engine.restype = C.c_int
     L.mnav_set_dijkstra_engine.argtypes = [vp, C.c_int]
+    L.mnav_shard_set_goal_tie.restype = C.c_int
+    L.mnav_shard_set_goal_tie.argtypes = [vp, u32]
     L.mnav_set_option.restype = C.c_int
     L.mnav_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     L.mnav_get_option.restype = C.c_double
@@ -452,6 +454,9 @@ class MnavContext:
         if self._L.mnav_shard_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0:
             raise RuntimeError("mnav_shard_setup has not been called")
         return dict(t_lo=a.value, t_hi=b.value, ntiles=c.value, n_exchange=d.value)
+
+    def shard_set_goal_tie(self, tie_id: int):
+        self._L.mnav_shard_set_goal_tie(self._h, int(tie_id))
 
     def shard_begin(self, seed: int, target: int, goal_dist_offset: float = 0.3, cost_limit: float = 1.0):
         if self._L.mnav_shard_begin(self._h, int(seed), int(target), float(goal_dist_offset), float(cost_limit)) != 0:

@@ -71,6 +71,7 @@ constexpr int kChunk = 96;  // step launches per graph replay; multiple of 6 (sl
 // ---------------------------------------------------------------------------------------------
 }  // namespace
 #include "mnav_tb.h"
+#include "mnav_tb_finalize.h"
 #include "mnav_walk.h"
 
 // One back-tracking job: the plan's resident vector map and the two ends of the walk.
@@ -184,9 +185,9 @@ struct mnav_ctx {
   float* d_t_tw = nullptr; bool tw_valid = false; uint32_t t_nnz = 0;
   // sharded single plan (mnav_shard_*)
   struct Shard {
-    bool ready = false, active = false;
+    bool ready = false, active = false, finalized = false;   // finalized: slot 0 holds the predecessors of the last sharded plan (mnav_shard_walk)
     uint32_t rank = 0, world = 1, t_lo = 0, t_hi = 0, n_iface = 0, rounds_per_exchange = 8, j = 0;
-    uint32_t seed = 0, target = 0; double offset = 0.3;
+    uint32_t seed = 0, target = 0; double offset = 0.3; uint32_t goal_tie1 = 0;
     uint32_t *d_iface_vert = nullptr, *d_wake_ptr = nullptr, *d_wake_tile = nullptr, *d_changed = nullptr, *d_minpend = nullptr;
     uint8_t* d_iface_owner = nullptr;
     std::vector<uint32_t> iface_vert;
@@ -1021,6 +1022,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   if (ensure_slots(ctx, 1, true, true, false)) return -1;
   Slot& s = ctx->slots[0];
   ctx->caller_slot.assign(1, kNone);                                // the wave works in plan slot 0: the last plan's resident outputs are gone
+  ctx->shard.finalized = false;
   Plan P;
   memset(&P, 0, sizeof(P));
   P.planner = kPlannerCvp; P.V = V;
@@ -1284,8 +1286,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       const double tiles = std::max(1.0, (double)V / (0.9 * ctx->tb.T));
       const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && (double)m0 >= tiles / 1000.0;
       // Below that: the asynchronous tile engine (mnav_async.h: one launch, a ticket queue of woken tiles; what a real makePlan
-      // call -- ONE plan -- runs on), up to async_max_batch plans; the tile rounds for what lies in between.
-      engine = fills ? 5 : (m0 <= opt_u32(ctx->opt.async_max_batch, 47u)) ? 6 : 0;
+      // call -- ONE plan -- runs on), up to async_max_batch plans (8: measured round 5, ms per call on the 1M / 10M mesh, rounds vs
+      // asynchronous -- 1 plan 10.1 / 7.3 vs 6.5 / 6.5, 8 plans 26.6 / 83 vs 16.2 / 85, 47 plans 49 / 243 vs 52 / 424); the tile rounds
+      // for what lies in between.
+      engine = fills ? 5 : (m0 <= opt_u32(ctx->opt.async_max_batch, 8u)) ? 6 : 0;
     }
     if (engine == 5 && m0 > 65535u) engine = 2;                       // (plan ids are 16 bits in the tile-batch buckets)
     if (engine == 6 && m0 > 255u) engine = 0;                         // (8 bits in a ticket)
@@ -1318,6 +1322,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     in.swap(in2); map.swap(map2);
   }
   ctx->caller_slot.assign(n, kNone);
+  ctx->shard.finalized = false;
   for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   const uint32_t m = (uint32_t)in.size();
@@ -1521,6 +1526,7 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
   }
   const uint32_t m = (uint32_t)in.size();
   ctx->caller_slot.assign(n, kNone);
+  ctx->shard.finalized = false;
   for (size_t i = 0; i < map.size(); ++i) ctx->caller_slot[map[i]] = (uint32_t)i;
   (void)hipEventRecord(ctx->ev[0], ctx->stream);
   ctx->tb.count_pending = false; ctx->tb_args_valid = false;         // (a lazy settled-vertex count of an earlier Dijkstra batch is void now)

@@ -95,10 +95,13 @@ __device__ __forceinline__ void plan_finish(const TilePlan& P, AsyncCtl* actl)
   add(&actl->done_plans, 1u);
 }
 // file the ticket of tile t of plan p (the caller has just raised state[t] to ACTIVE)
-__device__ __forceinline__ void push(const TilePlan& P, uint32_t p, uint32_t t, uint32_t* ring, AsyncCtl* actl)
+// `filed`: the caller holds a RESERVATION in work[p] (it added more than it can file before its first wake-up and gives back what it
+// did not use: two dependent memory round trips less on the path from a solve to the next one) and counts its tickets here;
+// null: the ticket is counted on the spot, before it can be seen.
+__device__ __forceinline__ void push(const TilePlan& P, uint32_t p, uint32_t t, uint32_t* ring, AsyncCtl* actl, uint32_t* filed)
 {
-  add(&words_of(P)->work, 1u);                                        // counted before it can be seen
-  drain();
+  if (filed) atomicAdd(filed, 1u);                                    // (LDS)
+  else { add(&words_of(P)->work, 1u); drain(); }
   const uint32_t i = add(&actl->tail, 1u);
   if (i < actl->ring_cap) st(ring + i, (p << 24) | t);
   else st(&actl->abort, 5u);                                          // out of slots: the host re-runs the call on the tile rounds
@@ -112,9 +115,9 @@ __device__ __forceinline__ void park(const TilePlan& P, uint32_t t, uint32_t par
   else st(&actl->abort, 5u);
 }
 // tile t2 has the pending value v (already merged into pend[t2]): ticket or parked list, unless somebody else saw to it
-__device__ __forceinline__ void route(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* ring, AsyncCtl* actl)
+__device__ __forceinline__ void route(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* ring, AsyncCtl* actl, uint32_t* filed)
 {
-  if (u2f(v) < thr) { if (amax(P.pend[1] + t2, kActive) < kActive) push(P, p, t2, ring, actl); }
+  if (u2f(v) < thr) { if (amax(P.pend[1] + t2, kActive) < kActive) push(P, p, t2, ring, actl, filed); }
   else {
     // (a tile still in the OTHER parity's parked state is on the list the band advance is working through: with pk above that value
     //  this call takes it over -- the advance then finds the state changed and skips it --, with pk below it the advance moves it)
@@ -123,11 +126,11 @@ __device__ __forceinline__ void route(const TilePlan& P, uint32_t p, uint32_t t2
   }
 }
 // wake tile t2 with value v (float bits)
-__device__ __forceinline__ void wake(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* ring, AsyncCtl* actl)
+__device__ __forceinline__ void wake(const TilePlan& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* ring, AsyncCtl* actl, uint32_t* filed)
 {
   (void)amin(P.pend[0] + t2, v);
   drain();                                                            // merged BEFORE the state word is touched (Dekker, see the header)
-  route(P, p, t2, v, thr, par, ring, actl);
+  route(P, p, t2, v, thr, par, ring, actl, filed);
 }
 }  // namespace aq
 
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   __shared__ uint32_t s_hdr[8];
   __shared__ uint32_t s_nq[3];
-  __shared__ uint32_t s_ticket, s_bound_bits, s_thr_bits, s_par, s_wover, s_solve, s_advance;
+  __shared__ uint32_t s_ticket, s_bound_bits, s_thr_bits, s_par, s_wover, s_solve, s_advance, s_filed;
   __shared__ uint32_t s_wtile[kAsyncWake], s_wval[kAsyncWake];
   __shared__ uint32_t s_min[kTileBlock / 64], s_bey[kTileBlock / 64];
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,7 +229,8 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
           s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
         }
       }
-      s_solve = solve; s_wover = 0u; s_advance = 0u;
+      s_solve = solve; s_wover = 0u; s_advance = 0u; s_filed = 0u;
+      if (solve) (void)aq::add(&W->work, kAsyncWake + 1u);             // reservation for the tickets this solve may file (given back at the retire); nobody waits for it
     }
     if (tid < (int)kAsyncWake) { s_wtile[tid] = kNone; s_wval[tid] = kInfBits; }
     __syncthreads();
@@ -310,13 +314,13 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       if (lane == 0 && own_left != kInfBits) collect(t, own_left);
       aq::drain();                                                     // every storing wave: its distance stores have left the CU ...
       __syncthreads();                                                 // ... before the first wake-up can be seen
-      if (tid < (int)kAsyncWake && s_wtile[tid] != kNone) aq::wake(P, p, s_wtile[tid], s_wval[tid], thr, par, ring, actl);
+      if (tid < (int)kAsyncWake && s_wtile[tid] != kNone) aq::wake(P, p, s_wtile[tid], s_wval[tid], thr, par, ring, actl, &s_filed);
       if (s_wover) {                                                   // more neighbour tiles than table slots: one wake-up per halo vertex
         for (uint32_t i = tid; i < nh; i += kTileBlock) {
           const uint32_t b = ldu[nv + i];
-          if (b < lh0[i]) aq::wake(P, p, g_halo_tile[h0 + i], b, thr, par, ring, actl);
+          if (b < lh0[i]) aq::wake(P, p, g_halo_tile[h0 + i], b, thr, par, ring, actl, nullptr);   // (beyond the reservation: counted one by one)
         }
-        if (lane == 0 && own_left != kInfBits) aq::wake(P, p, t, own_left, thr, par, ring, actl);   // (own_left: this wave's minimum)
+        if (lane == 0 && own_left != kInfBits) aq::wake(P, p, t, own_left, thr, par, ring, actl, nullptr);   // (own_left: this wave's minimum)
       }
       aq::drain();
       __syncthreads();                                                 // every wake-up has returned
@@ -331,9 +335,12 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       (void)aq::xchg(state + t, 0u);
       aq::drain();                                                     // cleared BEFORE the look (Dekker, see the header)
       const uint32_t v2 = aq::ld(pend + t);
-      if (v2 != kInfBits) aq::route(P, p, t, v2, thr, par, ring, actl);
+      if (v2 != kInfBits) aq::route(P, p, t, v2, thr, par, ring, actl, s_solve ? &s_filed : nullptr);
       aq::drain();
-      if (aq::sub(&W->work, 1u) == 1u) s_advance = 1u;                 // the count this ticket held was the plan's last: nobody else touches the plan now
+      // give back this ticket's count and what is left of the reservation; taking the count to zero: the plan's last ticket, nobody
+      // else touches the plan now
+      const uint32_t back = 1u + (s_solve ? kAsyncWake + 1u - s_filed : 0u);
+      if (aq::sub(&W->work, back) == back) s_advance = 1u;
     }
     __syncthreads();
     // ---- advance the band (the whole workgroup; exclusive until its first ticket is filed: no ticket of the plan is out)
@@ -368,7 +375,8 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       float thr2 = inf_f();
       if (mn != kInfBits && P.band > 0.f && P.band < inf_f()) { const float m = u2f(mn); thr2 = m + P.band; if (!(thr2 > m)) thr2 = next_up(m); }
       if (tid == 0) {
-        aq::st(&W->work, 1u);                                          // this workgroup's own hold while it files the band's tickets
+        s_filed = 0u;
+        aq::st(&W->work, 1u + cnt);                                    // this workgroup's own hold + a reservation for every ticket the pass may file
         aq::st(&W->thr, f2u(thr2)); aq::st(&W->par, par2); aq::st(&W->nparked[par2], 0u);
         aq::add(&W->epochs, 1u);
         aq::drain();
@@ -380,12 +388,12 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
         const uint32_t t2 = aq::ld(list + i);
         if (aq::ld(state + t2) != pk_old) continue;                    // (also: the second entry of a tile this pass has handled already)
         const uint32_t v = aq::ld(pend + t2);
-        if (u2f(v) < thr2 || u2f(v) > bound) { if (aq::amax(state + t2, aq::kActive) < aq::kActive) aq::push(P, p, t2, ring, actl); }
+        if (u2f(v) < thr2 || u2f(v) > bound) { if (aq::amax(state + t2, aq::kActive) < aq::kActive) aq::push(P, p, t2, ring, actl, &s_filed); }
         else if (aq::cas(state + t2, pk_old, pk_new)) aq::park(P, t2, par2, actl);   // (failed: a waker has routed it meanwhile)
       }
       aq::drain();
       __syncthreads();
-      if (tid == 0) s_advance = (aq::sub(&W->work, 1u) == 1u) ? 1u : 0u;   // the band's tickets are retired already (or none was filed): once more
+      if (tid == 0) { const uint32_t back = 1u + cnt - s_filed; s_advance = (aq::sub(&W->work, back) == back) ? 1u : 0u; }   // the band's tickets are retired already (or none was filed): once more
       __syncthreads();
       par_c = par2;
     }

@@ -413,6 +413,8 @@ struct Plan {
   // parameters
   float delta;             // band width
   double offset;           // goal_dist_offset
+  uint32_t goal_tie1;      // 1 + the id that stands for the robot vertex in (value, id) ties of goal_cut (a part of a partitioned mesh that
+                           // does not hold the robot vertex: its rank among the part's ids); 0: the robot vertex itself
   uint32_t seed[3];        // wave seed vertices (Dijkstra: seed[0], others kNone)
   uint32_t seed_expands[3];// seed passes the cost/invalid cut-offs (cvp :757,760)
   float seed_d[3];         // initial potential of the seeds (Dijkstra 0; CVP Euclidean, cvp :721-723)

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       if (BLOCKED) { const uint2 a = B.vaddr[tg]; dt = B.D[(size_t)a.x * B.NP + (size_t)(p0 + q) * (a.y >> 8) + (a.y & 255u)]; }
       else dt = P.dist[tg];
       s_armed[q] = dt < inf_f() ? 1u : 0u;
-      const GoalCut gc = goal_cut(dt, P.offset, tg);                 // dijkstra :296
+      const GoalCut gc = goal_cut(dt, P.offset, P.goal_tie1 ? P.goal_tie1 - 1u : tg);   // dijkstra :296
       s_goal[q] = gc.goal; s_cut[q] = gc.cut; s_tie[q] = gc.tie;
     }
   }

@@ -154,10 +154,13 @@ static ShardDev shard_dev(const mnav_ctx* ctx)
 
 int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit)
 {
+  if (ctx) ctx->shard.finalized = false;
   if (check_ready(ctx)) return -1;
   if (!ctx->shard.ready) { ctx->err = "mnav_shard_setup has not been called"; return -1; }
   if (seed_vertex >= ctx->V || target_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
-  if (!(goal_dist_offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return -1; }
+  // any double, like the reference (dijkstra :296): the rounds run with the bound of offset 0 for a negative one, the finalize pass
+  // applies the reference's expanded set through goal_cut (mnav_eval.h), like the single-GPU engines
+  if (goal_dist_offset != goal_dist_offset) { ctx->err = "goal_dist_offset is NaN"; return -1; }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return -1; }
   ctx->err.clear();
   ctx->cancel.store(0);
@@ -178,7 +181,7 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
   P.dist = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
   P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-  P.offset = goal_dist_offset; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
+  P.offset = goal_dist_offset; P.goal_tie1 = ctx->shard.goal_tie1; ctx->shard.goal_tie1 = 0u; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
   for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
   P.seed[0] = seed_vertex; P.target[0] = target_vertex; P.seed_face = kNone;
   TilePlan T; memset(&T, 0, sizeof(T));
@@ -355,17 +358,29 @@ int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_d
   HIPCHK(hipStreamSynchronize(ctx->stream));
   S.active = false;
   if (mism) { ctx->err = "sharded SSSP did not reach its fixed point (" + std::to_string(mism) + " vertices)"; return -2; }
+  S.finalized = true;                                                // slot 0 holds this sharded plan's predecessors until the next plan of any kind
+  return 0;
+}
+
+int mnav_shard_set_goal_tie(mnav_ctx* ctx, uint32_t tie_id)
+{
+  if (!ctx) return -1;
+  ctx->shard.goal_tie1 = tie_id + 1u;                                 // taken (and cleared) by the next mnav_shard_begin
   return 0;
 }
 
 int mnav_shard_walk(mnav_ctx* ctx, uint32_t start_vertex, uint32_t seed_vertex, uint32_t cap, uint32_t* out_host)
 {
   if (!ctx || !ctx->shard.ready || !out_host || ctx->slots.empty()) { if (ctx) ctx->err = "mnav_shard_walk: no sharded plan"; return -1; }
+  // only the predecessors of a FINALIZED sharded plan may be walked: any other plan, a new mnav_shard_begin or a failed finalize
+  // leaves slot 0 with something else (or nothing)
+  if (!ctx->shard.finalized) { ctx->err = "mnav_shard_walk: the last call was not a successful mnav_shard_finalize"; return -1; }
   if (start_vertex >= ctx->V || seed_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
+  if (cap > ctx->V + 1u) cap = ctx->V + 1u;                           // (a path has at most V vertices; also keeps cap + 3 from wrapping)
   if (hipSetDevice(ctx->device) != hipSuccess) return -1;
   auto& S = ctx->shard;
   if (S.walk_cap < cap + 3u) {
-    (void)hipFree(S.d_walk); S.d_walk = nullptr;
+    (void)hipFree(S.d_walk); S.d_walk = nullptr; S.walk_cap = 0;
     HIPCHK(hipMalloc((void**)&S.d_walk, 4 * (size_t)(cap + 3u)));
     S.walk_cap = cap + 3u;
   }

@@ -40,7 +40,8 @@ struct TbTile {
   uint32_t post_off, post_chunks;   // owned -> ghost edges
   uint32_t exp_off, exp_n;          // TbExp records
   uint32_t v0;            // position of the first owned vertex in `verts`
-  uint32_t pad[3];
+  uint32_t goff;          // position of the tile's first ghost in `ghost_gid` (ghosts in slice order)
+  uint32_t ovf_off, ovf_n;          // TbFinOvf records: sources beyond the kTbFinSlots a vertex has in the finalize tables
 };
 static_assert(sizeof(TbTile) == 64, "TbTile is read as one 64-byte scalar load");
 
@@ -72,7 +73,18 @@ constexpr uint32_t kTbOrderShift = 12;      // pre blocks, 2 bits: the sweep ord
 constexpr uint32_t kTbInfBits = 0x7f800000u;
 constexpr uint32_t kTbDirty = 0x80000000u;  // sign bit of an LDS value: lowered during this activation
 
+// Finalize tables (k_tb_finalize: potential with the reference's cut-off semantics, predecessors and vector map straight from a
+// tile's slice): per tile and owned vertex y the SOURCES of y -- the pull form of the tile's graph --, kTbFinSlots per vertex,
+// slot-major: entry (tile, k, y) at (tile * kTbFinSlots + k) * T + y.  fin_src: the source's index in the tile's SLICE (owned:
+// its local index, ghost: T + its ghost slot; kTbFinNone: no source), fin_wsrc: the entry of the gather CSR its weight
+// w(source -> y) comes from.  The few vertices of higher valence continue in TbFinOvf records.
+constexpr uint32_t kTbFinSlots = 8;
+constexpr uint16_t kTbFinNone = 0xFFFFu;
+struct TbFinOvf { uint32_t y, src, wsrc, pad; };
+
 struct HostTb {
+  std::vector<uint16_t> fin_src; std::vector<uint32_t> fin_wsrc; std::vector<TbFinOvf> fin_ovf;
+  std::vector<uint32_t> ghost_gid;    // vertex ids of the tiles' ghosts, tile after tile in slice order (TbTile.goff)
   uint32_t T = 0, ntiles = 0, V = 0;
   uint64_t S = 0;                     // words per plan (sum of the slice lengths)
   uint32_t max_nh = 0, max_sl = 0;
@@ -199,6 +211,27 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     const auto it = std::lower_bound(g.begin(), g.end(), v, [&](uint32_t a, uint32_t b) { return gkey(a) < gkey(b); });
     return (uint32_t)(it - g.begin());
   };
+  // finalize tables
+  H.fin_src.assign((size_t)H.ntiles * kTbFinSlots * T, kTbFinNone);
+  H.fin_wsrc.assign((size_t)H.ntiles * kTbFinSlots * T, kNone);
+  for (uint32_t tl = 0; tl < H.ntiles; ++tl) {
+    TbTile& W = H.tiles[tl];
+    W.goff = (uint32_t)H.ghost_gid.size();
+    H.ghost_gid.insert(H.ghost_gid.end(), ghosts[tl].begin(), ghosts[tl].end());
+    W.ovf_off = (uint32_t)H.fin_ovf.size();
+    for (uint32_t y = 0; y < W.nv; ++y) {
+      const uint32_t v = H.verts[W.v0 + y];
+      uint32_t n = 0;
+      for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k, ++n) {
+        const uint32_t u = t.nbr_u[k];
+        const uint32_t si = (H.vert_tile[u] == tl) ? H.vert_local[u] : T + ghost_slot(tl, u);
+        if (si >= kTbFinNone) throw std::invalid_argument("tile-batch engine: a slice is too long for the finalize tables");
+        if (n < kTbFinSlots) { const size_t at = ((size_t)tl * kTbFinSlots + n) * T + y; H.fin_src[at] = (uint16_t)si; H.fin_wsrc[at] = k; }
+        else H.fin_ovf.push_back(TbFinOvf{ y, si, k, 0u });
+      }
+    }
+    W.ovf_n = (uint32_t)H.fin_ovf.size() - W.ovf_off;
+  }
   const uint32_t kRow = 256;   // bytes per LDS row
   // chunk writer: blocks are appended to the open chunk, a closed chunk is padded with empty blocks
   uint32_t in_chunk = 0;

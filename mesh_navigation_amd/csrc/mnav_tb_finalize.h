@@ -1,0 +1,223 @@
+// mnav_tb_finalize.h -- the V-sized outputs of a tile-batch batch: potential with the reference's exact cut-off semantics
+// (dijkstra :293-300: tentative values beyond goal_dist come from expanded sources only), predecessors (:331-343 under the
+// (value, id) pop order) and the vector map (computeVectorMap :189-209), straight from the engine's blocked distances.
+// Included by mnav.hip after mnav_tb.h; not a stand-alone header.
+//
+// Round 3/4 ran k_dij_finalize<8, true> for this: the 512-vertex LDS tiles of the per-plan engines, distances gathered through
+// vaddr[], the tile's PUSH graph read backwards with ds_min / 64-bit ds_min and six workgroup barriers per (tile, plan) -- 91 ms
+// of the 323 ms headline step, LDS 41 % busy with half of it bank conflicts (profiles/r05_c2_before_sq.md).  This pass works on
+// the tile-batch engine's own tiles instead: one WAVE per (tile, range of plans); a (tile, plan) slice is one contiguous run of
+// <= 200 floats that already holds the ghosts -- one coalesced load, no gather --; a lane owns two of the tile's vertices and
+// keeps their <= 8 SOURCES (slice index, weight, vertex id: the pull form of the tile's graph, mnav_tb_build.h) in registers
+// for all its plans, so a vertex is 8 LDS reads, 8 float adds and a (sum, value, id) argmin in registers: no atomics, no
+// barrier (a wave is its own workgroup).  Adjacent tiles of the same plans are handled by neighbouring workgroups of the SAME
+// XCD (blockIdx -> (xcd, tile, plan range)), so that the short runs of a tile's rows meet in one L2 before they are written.
+#pragma once
+
+namespace {
+
+struct FinTb {
+  const uint16_t* src; const float* w; const TbFinOvf* ovf; const float* ovf_w;   // finalize tables (mnav_tb_build.h), weights materialised per cost limit
+  const uint32_t* verts; const uint32_t* ghost_gid;
+  const float* xyz; float* const* vecmaps;        // vecmaps != null: the vector map in the same pass
+  const Plan* plans; PlanResult* res; uint32_t* mismatch; GoalCut* gcs;
+  uint32_t plans_per_wave, tiles_per_xcd, max_sl;
+};
+
+// per plan: the plan record the path walk reads (k_finish) -- what k_dij_finalize's first tile chunk used to write
+__global__ __launch_bounds__(kBlock) void k_tb_fin_plans(tb::Args A, const Plan* __restrict__ plans, GoalCut* __restrict__ gcs)
+{
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= A.NP) return;
+  const Plan& P = plans[p];
+  const float dt = A.D[tb::slot_addr(A.vaddr[A.target[p]], A.NP, p)];
+  const GoalCut gc = goal_cut(dt, A.offset, A.target[p]);              // dijkstra :296
+  Ctl r; memset(&r, 0, sizeof(r));
+  r.armed = dt < inf_f() ? 1u : 0u; r.goal_dist = gc.goal; r.thr = inf_f(); r.thr_fixed = inf_f();
+  r.it = (int32_t)A.ctl->iters; r.done = 1u; r.overflow = (A.ctl->err || A.ctl->n_cand[0]) ? 1u : 0u;
+  P.ctl[0] = r; P.ctl[1] = r;
+  gcs[p] = gc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_tb_fin_weights(size_t n, const uint32_t* __restrict__ wsrc, const Nbr* __restrict__ nbr, float* __restrict__ w)
+{
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) w[i] = (wsrc[i] == kNone) ? inf_f() : nbr[wsrc[i]].w;
+}
+
+// kFinWaves waves per workgroup: one tile each -- consecutive tiles of the bisection order, a compact patch -- walking the SAME
+// plans in step (a barrier per plan).  A tile's rows are runs of ~11 vertices = a third of a 128-byte line of a vertex-order
+// output array; written by one wave alone the lines leave the L2 partially filled long before the neighbouring tile gets to
+// the same plan (first version of this kernel: no faster than the pass it replaced).  In step, the patch's lines are completed
+// within a microsecond.
+#ifndef MNAV_FIN_WAVES
+#define MNAV_FIN_WAVES 8
+#endif
+#ifndef MNAV_FIN_OCC
+#define MNAV_FIN_OCC 4
+#endif
+constexpr int kFinWaves = MNAV_FIN_WAVES;
+template <int T>
+__global__ __launch_bounds__(64 * kFinWaves, MNAV_FIN_OCC) void k_tb_finalize(tb::Args A, FinTb F)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t fin_lds_all[];   // per wave: [max_sl] distances of the plan | [max_sl] vertex ids | [3 * max_sl] positions
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* const fin_lds = fin_lds_all + (size_t)wave * 5u * F.max_sl;
+  // blockIdx -> (xcd, tile group of that xcd, plan range): workgroups are dealt to the XCDs round-robin
+  const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+  const uint32_t grp = xcd * F.tiles_per_xcd + j % F.tiles_per_xcd, pg = j / F.tiles_per_xcd;   // (tiles_per_xcd: GROUPS of kFinWaves tiles per xcd)
+  const uint32_t t_raw = grp * kFinWaves + wave;
+  const bool live = t_raw < A.ntiles;
+  const uint32_t t = live ? t_raw : A.ntiles - 1u;                    // (a wave without a tile shadows the last one and stores nothing)
+  const uint32_t p_beg = pg * F.plans_per_wave, p_end = min(p_beg + F.plans_per_wave, A.NP);
+  if (grp * kFinWaves >= A.ntiles || p_beg >= p_end) return;          // (uniform over the workgroup)
+  const TbTile W = A.tiles[t];
+  uint32_t* const ld = fin_lds;
+  uint32_t* const lgid = fin_lds + F.max_sl;
+  float* const lxyz = reinterpret_cast<float*>(fin_lds + 2 * F.max_sl);
+  const uint32_t NP = A.NP;
+  // ---- once per wave: ids (and positions) of the slice's vertices, this lane's two vertices and their sources
+  for (uint32_t i = lane; i < W.sl; i += 64) {
+    uint32_t g = kNone;
+    if (i < W.nv) g = F.verts[W.v0 + i];
+    else if (i >= (uint32_t)T && i - T < W.nh) g = F.ghost_gid[W.goff + (i - T)];
+    lgid[i] = g;
+    if (F.vecmaps && g != kNone) { lxyz[3 * i] = F.xyz[3 * (size_t)g]; lxyz[3 * i + 1] = F.xyz[3 * (size_t)g + 1]; lxyz[3 * i + 2] = F.xyz[3 * (size_t)g + 2]; }
+  }
+  uint32_t ys[2] = { (uint32_t)lane, (uint32_t)lane + 64u };
+  bool own[2]; uint32_t gid[2];
+  uint32_t src[2][kTbFinSlots]; float wt[2][kTbFinSlots];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    own[v] = live && ys[v] < W.nv;
+#pragma unroll
+    for (int k = 0; k < (int)kTbFinSlots; ++k) {
+      const size_t at = ((size_t)t * kTbFinSlots + k) * T + (own[v] ? ys[v] : 0u);
+      src[v][k] = own[v] ? (uint32_t)F.src[at] : (uint32_t)kTbFinNone;
+      wt[v][k] = own[v] ? F.w[at] : inf_f();
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    gid[v] = own[v] ? lgid[ys[v]] : kNone;
+#pragma unroll
+    for (int k = 0; k < (int)kTbFinSlots; ++k)
+      if (src[v][k] == kTbFinNone) src[v][k] = ys[v] < (uint32_t)T ? ys[v] : 0u;   // (an unused slot reads the vertex's own row; its weight is +inf: the sum is +inf)
+  }
+  float px[2] = { 0.f, 0.f }, py[2] = { 0.f, 0.f }, pz[2] = { 0.f, 0.f };
+  if (F.vecmaps) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) if (own[v]) { px[v] = lxyz[3 * ys[v]]; py[v] = lxyz[3 * ys[v] + 1]; pz[v] = lxyz[3 * ys[v] + 2]; }
+  }
+  // ---- the plans of this wave: the next plan's slice is in flight while a plan is worked on
+  MNAV_GLOBAL const float* const gD = as_global(A.D) + (size_t)W.soff * NP;
+  const uint32_t i0 = lane, i1 = lane + 64u, i2 = lane + 128u, i3 = lane + 192u;
+  auto load_slice = [&](uint32_t p, uint32_t (&r)[4]) {
+    MNAV_GLOBAL const uint32_t* s = (MNAV_GLOBAL const uint32_t*)(gD + (size_t)p * W.sl);
+    r[0] = i0 < W.sl ? s[i0] : kTbInfBits; r[1] = i1 < W.sl ? s[i1] : kTbInfBits;
+    r[2] = i2 < W.sl ? s[i2] : kTbInfBits; r[3] = i3 < W.sl ? s[i3] : kTbInfBits;
+  };
+  uint32_t cur[4], nxt[4];
+  load_slice(p_beg, cur);
+  uint32_t bad = 0;
+  for (uint32_t p = p_beg; p < p_end; ++p) {
+    __syncthreads();                                                  // the tiles of the patch write plan p together
+    if (p + 1 < p_end) load_slice(p + 1, nxt);
+    const Plan& P = F.plans[p];
+    MNAV_GLOBAL float* const g_dist = as_global(P.dist);
+    MNAV_GLOBAL uint32_t* const g_pred = as_global(P.pred);
+    MNAV_GLOBAL float* const g_vm = F.vecmaps ? as_global(F.vecmaps[p]) : nullptr;
+    const uint32_t seed = A.seed[p];
+    const bool reached = __ballot(cur[0] != kTbInfBits || cur[1] != kTbInfBits || cur[2] != kTbInfBits || cur[3] != kTbInfBits) != 0ull;
+    uint32_t cnt = 0;
+    if (!reached) {                                                    // the plan's wave never came near this tile: dist = inf, pred = itself
+#pragma unroll
+      for (int v = 0; v < 2; ++v) if (own[v]) {
+        g_dist[gid[v]] = inf_f(); g_pred[gid[v]] = gid[v];
+        if (g_vm) { g_vm[3 * (size_t)gid[v]] = 0.f; g_vm[3 * (size_t)gid[v] + 1] = 0.f; g_vm[3 * (size_t)gid[v] + 2] = 0.f; }
+      }
+    } else {
+      const GoalCut gcut = F.gcs[p];                                    // dijkstra :296 (k_tb_fin_plans)
+      __builtin_amdgcn_wave_barrier();                                 // (the previous plan's reads of ld[] are done: one wave, program order)
+      if (i0 < W.sl) ld[i0] = cur[0];
+      if (i1 < W.sl) ld[i1] = cur[1];
+      if (i2 < W.sl) ld[i2] = cur[2];
+      if (i3 < W.sl) ld[i3] = cur[3];
+      for (uint32_t i = lane + 256u; i < W.sl; i += 64) ld[i] = ((MNAV_GLOBAL const uint32_t*)(gD + (size_t)p * W.sl))[i];   // (slices beyond 256 slots: rare meshes)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        if (!own[v]) continue;
+        const uint32_t dyb = ld[ys[v]];
+        const float dy = u2f(dyb);
+        uint32_t sum[kTbFinSlots], dsb[kTbFinSlots];
+#pragma unroll
+        for (int k = 0; k < (int)kTbFinSlots; ++k) {
+          dsb[k] = ld[src[v][k]];
+          const float ds = u2f(dsb[k]);
+          // expanded_source (dijkstra :293-300); the vertex id only matters AT the cut value: read then
+          bool ex = ds < inf_f() && ds < gcut.cut;
+          if (ds == gcut.cut && ds < inf_f()) ex = lgid[src[v][k]] < gcut.tie;
+          sum[k] = ex ? f2u(ds + wt[v][k]) : kTbInfBits;               // :331
+        }
+        const bool is_seed = gid[v] == seed;
+        const bool cut = dy > gcut.cut;                                // beyond goal_dist: the value is re-derived from the expanded sources
+        uint32_t val = cut ? kTbInfBits : dyb;
+        if (cut) {
+#pragma unroll
+          for (int k = 0; k < (int)kTbFinSlots; ++k) val = min(val, sum[k]);
+        }
+        // every expanded source checks the fixed point; those that attain the value compete with (d[x], x) for the predecessor
+        unsigned long long key = ~0ull;
+        uint32_t best_s = ys[v];
+#pragma unroll
+        for (int k = 0; k < (int)kTbFinSlots; ++k) {
+          if (sum[k] < val && !is_seed) ++bad;
+          if (sum[k] == val && val != kTbInfBits) {
+            const unsigned long long kk = ((unsigned long long)dsb[k] << 32) | lgid[src[v][k]];   // (one or two slots attain the value)
+            if (kk < key) { key = kk; best_s = src[v][k]; }
+          }
+        }
+        for (uint32_t e = 0; e < W.ovf_n; ++e) {                       // valence above kTbFinSlots: rare
+          const TbFinOvf o = F.ovf[W.ovf_off + e];
+          if (o.y != ys[v]) continue;
+          const uint32_t db = ld[o.src], g2 = lgid[o.src];
+          if (!expanded_source(gcut, u2f(db), g2)) continue;
+          const uint32_t sm = f2u(u2f(db) + F.ovf_w[W.ovf_off + e]);
+          if (cut && sm < val) { val = sm; key = ~0ull; }              // (a smaller sum from the overflow list restarts the argmin)
+          else if (sm < val && !is_seed) ++bad;
+          if (sm == val && val != kTbInfBits) {
+            const unsigned long long kk = ((unsigned long long)db << 32) | g2;
+            if (kk < key) { key = kk; best_s = o.src; }
+          }
+        }
+        uint32_t pv = gid[v];
+        float outd = u2f(val);
+        if (is_seed) { outd = dy; ++cnt; }
+        else {
+          if (val != kTbInfBits && key == ~0ull) ++bad;                // a finite value no expanded neighbour supports
+          if (val != kTbInfBits) { pv = (uint32_t)key; ++cnt; }
+        }
+        g_dist[gid[v]] = outd; g_pred[gid[v]] = pv;
+        if (g_vm) {                                                    // k_vecmap_dijkstra's arithmetic
+          float x = 0.f, y = 0.f, z = 0.f;
+          if (pv != gid[v]) {                                          // :197
+            x = lxyz[3 * best_s] - px[v]; y = lxyz[3 * best_s + 1] - py[v]; z = lxyz[3 * best_s + 2] - pz[v];   // :204
+            const float len = sqrtf(x * x + y * y + z * z);            // normalized(), :206
+            x = x / len; y = y / len; z = z / len;
+          }
+          g_vm[3 * (size_t)gid[v]] = x; g_vm[3 * (size_t)gid[v] + 1] = y; g_vm[3 * (size_t)gid[v] + 2] = z;
+        }
+      }
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0 && cnt && live) atomicAdd(&F.res[p].settled, (unsigned long long)cnt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+  }
+  bad = wave_sum(bad);
+  if (lane == 0 && bad) atomicAdd(F.mismatch, bad);
+}
+
+}  // namespace

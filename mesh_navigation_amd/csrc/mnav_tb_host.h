@@ -7,7 +7,7 @@ void tb_free_batch(mnav_ctx* ctx)
   TbState& S = ctx->tb;
   (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
   (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
-  (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target);
+  (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target); (void)hipFree(S.d_gcs); S.d_gcs = nullptr;
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
   for (int k = 0; k < 2; ++k) { if (S.graph[k]) (void)hipGraphExecDestroy(S.graph[k]); S.graph[k] = nullptr; }
   if (S.fill_stream) (void)hipStreamSynchronize(S.fill_stream);
@@ -22,9 +22,12 @@ void tb_free(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
   tb_free_batch(ctx);
-  for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile, (void*)S.d_verts })
+  for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile, (void*)S.d_verts,
+                   (void*)S.d_fin_src, (void*)S.d_fin_wsrc, (void*)S.d_fin_ovf, (void*)S.d_fin_ovf_wsrc, (void*)S.d_ghost_gid })
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
   S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr; S.d_verts = nullptr;
+  S.d_fin_src = nullptr; S.d_fin_wsrc = nullptr; S.d_fin_ovf = nullptr; S.d_fin_ovf_wsrc = nullptr; S.d_ghost_gid = nullptr;
+  (void)hipFree(S.d_fin_w); S.d_fin_w = nullptr; (void)hipFree(S.d_fin_ovf_w); S.d_fin_ovf_w = nullptr; S.fin_w_valid = false;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
   S.count_pending = false; ctx->tb_args_valid = false;
 }
@@ -55,6 +58,20 @@ int tb_build(mnav_ctx* ctx)
   if (dev_upload(ctx, &S.d_vaddr, vaddr.data(), vaddr.size())) return -1;
   if (dev_upload(ctx, &S.d_vert_tile, H.vert_tile.data(), H.vert_tile.size())) return -1;
   if (dev_upload(ctx, &S.d_verts, H.verts.data(), H.verts.size())) return -1;
+  // finalize tables (mnav_tb_finalize.h)
+  if (dev_upload(ctx, &S.d_fin_src, H.fin_src.data(), H.fin_src.size())) return -1;
+  if (dev_upload(ctx, &S.d_fin_wsrc, H.fin_wsrc.data(), H.fin_wsrc.size())) return -1;
+  if (dev_upload(ctx, &S.d_fin_ovf, H.fin_ovf.data(), H.fin_ovf.size())) return -1;
+  {
+    std::vector<uint32_t> ow(H.fin_ovf.size());
+    for (size_t i = 0; i < ow.size(); ++i) ow[i] = H.fin_ovf[i].wsrc;
+    if (dev_upload(ctx, &S.d_fin_ovf_wsrc, ow.data(), ow.size())) return -1;
+  }
+  if (dev_upload(ctx, &S.d_ghost_gid, H.ghost_gid.data(), H.ghost_gid.size())) return -1;
+  (void)hipFree(S.d_fin_w); S.d_fin_w = nullptr; (void)hipFree(S.d_fin_ovf_w); S.d_fin_ovf_w = nullptr;
+  S.fin_n = H.fin_src.size(); S.fin_novf = H.fin_ovf.size(); S.fin_w_valid = false; S.max_sl = H.max_sl;
+  HIPCHK(hipMalloc((void**)&S.d_fin_w, 4 * std::max<size_t>(S.fin_n, 1)));
+  HIPCHK(hipMalloc((void**)&S.d_fin_ovf_w, 4 * std::max<size_t>(S.fin_novf, 1)));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.stream.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
   S.vert_tile = std::move(H.vert_tile);
@@ -71,7 +88,19 @@ int tb_weights(mnav_ctx* ctx)
   if (S.w_valid) return 0;
   hipLaunchKernelGGL(k_tb_weights, dim3(4096), dim3(kBlock), 0, ctx->stream, S.nrec, S.d_wsrc, ctx->d_nbr, S.d_stream);
   HIPCHK(hipGetLastError());
-  S.w_valid = true;
+  S.w_valid = true; S.fin_w_valid = false;
+  return 0;
+}
+
+// weights of the finalize tables: like the streams' they follow the cost-limit folded gather CSR (w_valid is reset with it)
+int tb_fin_weights(mnav_ctx* ctx)
+{
+  TbState& S = ctx->tb;
+  if (S.fin_w_valid) return 0;
+  hipLaunchKernelGGL(k_tb_fin_weights, dim3(4096), dim3(kBlock), 0, ctx->stream, S.fin_n, S.d_fin_wsrc, ctx->d_nbr, S.d_fin_w);
+  if (S.fin_novf) hipLaunchKernelGGL(k_tb_fin_weights, dim3(64), dim3(kBlock), 0, ctx->stream, S.fin_novf, S.d_fin_ovf_wsrc, ctx->d_nbr, S.d_fin_ovf_w);
+  HIPCHK(hipGetLastError());
+  S.fin_w_valid = true;
   return 0;
 }
 
@@ -98,6 +127,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   }
   HIPCHK(hipMalloc((void**)&S.thr, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.bnd, 4 * (size_t)np));
   HIPCHK(hipMalloc((void**)&S.seed, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.target, 4 * (size_t)np));
+  HIPCHK(hipMalloc((void**)&S.d_gcs, sizeof(GoalCut) * (size_t)np));
   S.cap_np = np;
   return 0;
 }
@@ -132,10 +162,9 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
 // per-plan arrays in vertex order + the finalize pass, for calls that want V-sized outputs
 int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset, const tb::Args& A)
 {
+  TbState& S = ctx->tb;
   if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_tile_state(ctx, 1)) return -1;                          // one TilePlan record: the LDS tiles' mesh tables
-  if (tile_weights(ctx)) return -1;
-  const HostTiles& M = ctx->tiles_meta;
+  if (tb_fin_weights(ctx)) return -1;
   std::vector<Plan> hp(n);
   std::vector<float*> vecs(n);
   for (uint32_t i = 0; i < n; ++i) {
@@ -150,24 +179,25 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
     P.seed_face = kNone;
     vecs[i] = s.vecmap;
   }
-  TilePlan T;
-  memset(&T, 0, sizeof(T));
-  T.V = ctx->V; T.ntiles = M.ntiles;
-  T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-  T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-  T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, &T, sizeof(TilePlan), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));                          // hp / T / vecs go out of scope
-  // potential (with the reference's tentative values beyond goal_dist) and predecessors of every plan, in vertex order,
-  // straight from the blocked distances: k_dij_finalize gathers them per LDS tile, eight plans per staged tile graph
-  FinBlocked B{};
-  B.D = A.D; B.vaddr = A.vaddr; B.NP = A.NP; B.xyz = ctx->d_xyz; B.vecmaps = ctx->want_vec ? ctx->d_vecptrs : nullptr;
-  B.iters = (const uint32_t*)((const char*)A.ctl + offsetof(tb::Ctl, iters));
-  B.err = (const uint32_t*)((const char*)A.ctl + offsetof(tb::Ctl, err));
-  B.n_cand = (const uint32_t*)((const char*)A.ctl + offsetof(tb::Ctl, n_cand));
-  launch_finalize_blocked(ctx, n, B);
+  HIPCHK(hipStreamSynchronize(ctx->stream));                          // hp / vecs go out of scope
+  // potential (with the reference's tentative values beyond goal_dist), predecessors and vector map of every plan, in vertex
+  // order, straight from the blocked distances: one wave per (tile, 64 plans), eight tiles per workgroup, mnav_tb_finalize.h
+  FinTb F{};
+  F.src = S.d_fin_src; F.w = S.d_fin_w; F.ovf = S.d_fin_ovf; F.ovf_w = S.d_fin_ovf_w; F.verts = S.d_verts; F.ghost_gid = S.d_ghost_gid;
+  F.xyz = ctx->d_xyz; F.vecmaps = ctx->want_vec ? ctx->d_vecptrs : nullptr;
+  F.plans = ctx->d_plans; F.res = ctx->d_res; F.mismatch = ctx->d_mismatch; F.gcs = S.d_gcs;
+  const uint32_t groups = (S.ntiles + kFinWaves - 1u) / kFinWaves;    // a workgroup = kFinWaves consecutive tiles of the bisection order
+  F.plans_per_wave = 64u; F.tiles_per_xcd = (groups + 7u) / 8u; F.max_sl = S.max_sl;
+  hipLaunchKernelGGL(k_tb_fin_plans, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A, ctx->d_plans, S.d_gcs);
+  const uint32_t npg = (n + F.plans_per_wave - 1u) / F.plans_per_wave;
+  const size_t lds = 4 * 5 * (size_t)S.max_sl * kFinWaves;
+  const dim3 grid(8u * F.tiles_per_xcd * npg);
+  if (S.T == 64) hipLaunchKernelGGL((k_tb_finalize<64>), grid, dim3(64 * kFinWaves), lds, ctx->stream, A, F);
+  else if (S.T == 96) hipLaunchKernelGGL((k_tb_finalize<96>), grid, dim3(64 * kFinWaves), lds, ctx->stream, A, F);
+  else if (S.T == 120) hipLaunchKernelGGL((k_tb_finalize<120>), grid, dim3(64 * kFinWaves), lds, ctx->stream, A, F);
+  else hipLaunchKernelGGL((k_tb_finalize<128>), grid, dim3(64 * kFinWaves), lds, ctx->stream, A, F);
   HIPCHK(hipGetLastError());
   return 0;
 }

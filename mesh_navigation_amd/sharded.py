@@ -113,8 +113,8 @@ def run_sharded_plan(engine, allreduce_min: Callable, seed: int, target: int, go
             gmin, gtarget, st = float(ctl[0]), float(ctl[1]), int(round(-float(ctl[2])))
         if st:
             return failed(st)
-        if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
-            break                                                     # nothing left that may still propagate
+        if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + max(goal_dist_offset, 0.0)):
+            break                                                     # nothing left that may still propagate (a negative offset: the bound of offset 0, the finalize pass applies the rest)
         if exchanges >= max_exchanges:
             raise RuntimeError("sharded plan did not terminate")      # (the count is the same on every rank)
 
@@ -436,6 +436,8 @@ class PartitionedShardEngine(GpuShardEngine):
         self.status = 0
         ls, lt = self.part.local_of(seed), self.part.local_of(target)
         n0 = self.part.gid.shape[0]
+        if lt < 0 and offset < 0:                                     # (value, id) ties at the robot vertex's potential: its rank among this part's ids
+            self.ctx.shard_set_goal_tie(int(np.searchsorted(self.part.gid, target)))
         self.ctx.shard_begin(ls if ls >= 0 else n0, lt if lt >= 0 else n0 + 1, offset, self.cost_limit)
 
     def finalize(self):
@@ -522,7 +524,7 @@ def plan_virtual_ranks(engines: Sequence, seed: int, target: int, goal_dist_offs
             gmin, gtarget, st = float(ctls[0][0]), float(ctls[0][1]), int(round(-float(ctls[0][2])))
         if st:
             return ShardedResult(CANCELED if st == 1 else INTERNAL_ERROR, None, None, np.zeros(0, np.uint32), exchanges, rounds)
-        if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + goal_dist_offset):
+        if not np.isfinite(gmin) or gmin > np.float32(np.float64(np.float32(gtarget)) + max(goal_dist_offset, 0.0)):
             break
         if exchanges >= max_exchanges:
             raise RuntimeError("sharded plan did not terminate")

@@ -116,11 +116,12 @@ struct Wg {
     ++P.finishes;
     add(M.done_plans, 1u);
   }
-  void push(PlanState& P, uint32_t p, uint32_t t)
+  void push(PlanState& P, uint32_t p, uint32_t t, uint32_t* filed = nullptr)
   {
     if (P.ticketed[t]) ++M.violations;                               // a second live ticket of the tile
     P.ticketed[t] = 1;
-    add(P.work, 1u);                                                 // counted before it can be seen
+    if (filed) ++*filed;                                             // covered by the caller's reservation
+    else add(P.work, 1u);                                            // counted before it can be seen
     const uint32_t i = add(M.tail, 1u);
     if (i < M.ring.size()) st(M.ring[i], (p << 24) | t); else st(M.abort, 5u);
   }
@@ -129,17 +130,17 @@ struct Wg {
     const uint32_t i = add(P.nparked[par], 1u);
     if (i < P.parked[par].size()) st(P.parked[par][i], t); else st(M.abort, 5u);
   }
-  void route(PlanState& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par)
+  void route(PlanState& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* filed = nullptr)
   {
     if (u2f(v) < thr) {
-      if (M.mutate == 3u) { amax(P.lock[t2], 3u); push(P, p, t2); return; }
-      if (amax(P.lock[t2], 3u) < 3u) push(P, p, t2);
+      if (M.mutate == 3u) { amax(P.lock[t2], 3u); push(P, p, t2, filed); return; }
+      if (amax(P.lock[t2], 3u) < 3u) push(P, p, t2, filed);
     } else { const uint32_t pk = 1u + par; if (amax(P.lock[t2], pk) < pk) park(P, t2, par); }
   }
-  void wake(PlanState& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par)
+  void wake(PlanState& P, uint32_t p, uint32_t t2, uint32_t v, float thr, uint32_t par, uint32_t* filed = nullptr)
   {
     amin(P.pend[t2], v);
-    route(P, p, t2, v, thr, par);
+    route(P, p, t2, v, thr, par, filed);
   }
 
   void run(uint32_t n, uint32_t)
@@ -174,8 +175,9 @@ struct Wg {
           ++M.drops;
         } else solve = true;
       }
-      uint32_t sweep = 0;
+      uint32_t sweep = 0, filed = 0;
       if (solve) {
+        add(P.work, kWakeSlots + 1u);                                // reservation for the tickets this solve may file
         if (P.in_solve[t]) ++M.violations;                           // two solvers on one tile
         P.in_solve[t] = 1;
         if (++M.solves_now > M.max_solves) M.max_solves = M.solves_now;
@@ -228,7 +230,7 @@ struct Wg {
         };
         for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) collect(T.halo_tile[h0 + k], ldu[nv + k]);
         if (own_left != kInf) collect(t, own_left);
-        for (uint32_t sl = 0; sl < kWakeSlots; ++sl) if (wt[sl] != kNone) wake(P, p, wt[sl], wv[sl], thr, par);
+        for (uint32_t sl = 0; sl < kWakeSlots; ++sl) if (wt[sl] != kNone) wake(P, p, wt[sl], wv[sl], thr, par, &filed);
         if (over) {
           for (uint32_t k = 0; k < nh; ++k) if (ldu[nv + k] < lh0[k]) wake(P, p, T.halo_tile[h0 + k], ldu[nv + k], thr, par);
           if (own_left != kInf) wake(P, p, t, own_left, thr, par);
@@ -240,8 +242,9 @@ struct Wg {
       // ---- retire the ticket
       P.ticketed[t] = 0;
       xchg(P.lock[t], 0u);
-      if (M.mutate != 2u) { const uint32_t v2 = ld(P.pend[t]); if (v2 != kInf) route(P, p, t, v2, thr, par); }
-      bool advance = sub(P.work, 1u) == 1u;
+      if (M.mutate != 2u) { const uint32_t v2 = ld(P.pend[t]); if (v2 != kInf) route(P, p, t, v2, thr, par, solve ? &filed : nullptr); }
+      const uint32_t back = 1u + (solve ? kWakeSlots + 1u - filed : 0u);
+      bool advance = sub(P.work, back) == back;
       // ---- advance the band (exclusive until its first ticket is filed)
       uint32_t par_c = par;
       while (advance) {
@@ -259,17 +262,18 @@ struct Wg {
         if (mn == kInf && !beyond) { plan_finish(P); break; }
         float thr2 = inf_f();
         if (mn != kInf && M.band > 0.f && M.band < inf_f()) { const float m = u2f(mn); thr2 = m + M.band; if (!(thr2 > m)) thr2 = next_up(m); }
-        st(P.work, 1u);
+        uint32_t filed2 = 0;
+        st(P.work, 1u + cnt);                                        // own hold + a reservation for every ticket the pass may file
         st(P.thr, f2u(thr2)); st(P.par, par2); st(P.nparked[par2], 0u);
         add(P.epochs, 1u);
         for (uint32_t k = 0; k < cnt; ++k) {
           const uint32_t t2 = ld(P.parked[par_c][k]);
           if (ld(P.lock[t2]) != pk_old) continue;
           const uint32_t pv = ld(P.pend[t2]);
-          if (u2f(pv) < thr2 || u2f(pv) > bound2) { if (amax(P.lock[t2], 3u) < 3u) push(P, p, t2); }
+          if (u2f(pv) < thr2 || u2f(pv) > bound2) { if (amax(P.lock[t2], 3u) < 3u) push(P, p, t2, &filed2); }
           else if (cas(P.lock[t2], pk_old, pk_new)) park(P, t2, par2);
         }
-        advance = sub(P.work, 1u) == 1u;
+        { const uint32_t back2 = 1u + cnt - filed2; advance = sub(P.work, back2) == back2; }
         par_c = par2;
       }
     }

@@ -7,6 +7,21 @@ terrain); the GPU engine owns ranges of Morton tiles -- the protocol does not ca
 import numpy as np
 
 
+def goal_cut_expanded(d, target, offset, tie=None):
+    """mnav_eval.h goal_cut / expanded_source on an array of potentials: (mask of expanded sources, cut value).  With a negative offset the
+    reference expands exactly what popped before the robot vertex (dijkstra :293-300): d < dt, or d == dt with a smaller id (`tie`: the id
+    that stands for the robot vertex in that comparison, default the target itself)."""
+    dt = d[target]
+    if not np.isfinite(dt):
+        return np.isfinite(d), np.float32(np.inf)
+    goal = np.float32(np.float64(dt) + offset)
+    if goal < dt:
+        t = target if tie is None else tie
+        ids = np.arange(d.shape[0])
+        return np.isfinite(d) & ((d < dt) | ((d == dt) & (ids < t))), np.float32(dt)
+    return np.isfinite(d) & (d <= goal), goal
+
+
 class ModelShardEngine:
     def __init__(self, mesh, weights, costs, rank, world, cost_limit=1.0, invalid=None):
         self.V = mesh.V
@@ -38,7 +53,7 @@ class ModelShardEngine:
         return self.ctl
 
     def _bound(self):
-        return np.float32(np.float64(self.dist[self.target]) + self.offset)
+        return np.float32(np.float64(self.dist[self.target]) + max(self.offset, 0.0))   # (a negative offset: the bound of offset 0, the finalize applies the rest)
 
     def rounds(self, r):
         d = self.dist
@@ -77,8 +92,7 @@ class ModelShardEngine:
     def finalize(self):
         """cut-off semantics + predecessors for the owned vertices (what k_dij_finalize does per tile)"""
         d = self.dist
-        goal = np.float32(np.float64(d[self.target]) + self.offset) if np.isfinite(d[self.target]) else np.float32(np.inf)
-        expanded = np.isfinite(d) & (d <= goal)
+        expanded, goal = goal_cut_expanded(d, self.target, self.offset)
         ok = self.mine & expanded[self.src]
         cand = (d[self.src] + self.w).astype(np.float32)
         best = np.full(self.V, np.inf, np.float32)
@@ -153,6 +167,7 @@ class PartModelEngine:
         n0 = self.part.gid.shape[0]
         ls, lt = self.part.local_of(seed), self.part.local_of(target)
         self.seed, self.target, self.offset = (ls if ls >= 0 else n0), (lt if lt >= 0 else n0 + 1), offset
+        self.tie = None if lt >= 0 else int(np.searchsorted(self.part.gid, target))   # the robot vertex's rank among this part's ids (mnav_shard_set_goal_tie)
         self.dist = np.full(self.n, np.inf, np.float32)
         self.dist[self.seed] = 0.0
         self.ctl = np.zeros(3, np.float32)
@@ -162,7 +177,7 @@ class PartModelEngine:
         return self.ctl
 
     def _bound(self):
-        return np.float32(np.float64(self.dist[self.target]) + self.offset)
+        return np.float32(np.float64(self.dist[self.target]) + max(self.offset, 0.0))   # (a negative offset: the bound of offset 0, the finalize applies the rest)
 
     def rounds(self, r):
         d = self.dist
@@ -200,8 +215,7 @@ class PartModelEngine:
 
     def finalize(self):
         d = self.dist
-        goal = np.float32(np.float64(d[self.target]) + self.offset) if np.isfinite(d[self.target]) else np.float32(np.inf)
-        expanded = np.isfinite(d) & (d <= goal)
+        expanded, goal = goal_cut_expanded(d, self.target, self.offset, getattr(self, "tie", None))
         ok = expanded[self.src]
         cand = (d[self.src] + self.w).astype(np.float32)
         best = np.full(self.n, np.inf, np.float32)

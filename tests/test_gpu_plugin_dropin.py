@@ -222,3 +222,37 @@ def test_gpu_plugin_with_the_cost_observer_layer_updates_only_what_changed(world
     crc, prc, krc, mrc = rm.cvp_make_plan(pose(robot), pose(goal))
     assert cc == crc and mc == mrc and len(pc) == len(prc) and (len(pc) == 0 or np.array_equal(pc, prc))
     rm.plugin_release()
+
+
+def test_gpu_plugin_backstop_sees_what_the_change_signal_cannot(world):
+    """Behind the observer layer's change signal the plugin keeps a backstop (a rotating window of the map compared with the mirror of
+    the device copy on every plan): `mesh_map.edge_cost_factor` reconfigured -- every edge weight recomputed with no layer notification,
+    mesh_map.cpp:1379-1397 -- is seen by the next plan; `invalid` flipped behind everybody's back (what a planner does when it trips
+    over a broken vertex, dijkstra_mesh_planner.cpp:306-321) within ceil(V / 4096) plans."""
+    m, _, robot, goal = world
+    rng = np.random.default_rng(4)
+    costs = rng.uniform(0.0, 0.6, m.V).astype(np.float32)
+    rm = R.RefMap(m.xyz, m.faces, layers="array+observer", vertex_costs=costs, edge_cost_factor=1.0)
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_backstop")
+    c0, p0, k0, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    cr0, pr0, kr0 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
+    full0, inc0, sign0 = R.RefMap.gpu_plugin_cost_sync_counts()
+    w_before = rm.edge_weights().copy()
+    assert rm.set_param("mesh_map.edge_cost_factor", 6.0)               # the map recomputes all its edge weights; no layer says a word
+    assert not np.array_equal(rm.edge_weights(), w_before)
+    cr1, pr1, kr1 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    c1, p1, k1, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c1 == cr1 == 0 and np.array_equal(p1, pr1) and k1 == kr1
+    full1, inc1, sign1 = R.RefMap.gpu_plugin_cost_sync_counts()
+    assert full1 - full0 == 1                                           # the backstop took ONE full copy
+    # a wall of invalid vertices across the straight line, set directly in the map
+    N = m.N
+    wall = (np.arange(N // 6, 5 * N // 6) * N + N // 2).astype(np.int64)
+    inv = rm.get_invalid(); inv[wall] = 1
+    rm.set_invalid(inv)
+    cr2, pr2, kr2 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    for _ in range(m.V // 4096 + 2):
+        c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c2 == cr2 and np.array_equal(p2, pr2) and k2 == kr2 and not np.array_equal(pr2, pr1)
+    rm.plugin_release()

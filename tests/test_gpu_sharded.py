@@ -21,7 +21,7 @@ def engines(case, world, gpu_ctx_factory, cost_limit=1.0):
 
 
 @pytest.mark.parametrize("device_loop", [True, False])             # exchange loop resident on the device (stream events, termination
-@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0)])   # words read every 8 exchanges) / host-checked
+@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0), (3, -0.5)])   # words read every 8 exchanges) / host-checked
 def test_sharded_plan_c1_bit_exact(gpu_ctx_factory, world, offset, device_loop):
     case = terrain_case(224, 1)
     m = case.mesh
@@ -85,7 +85,7 @@ def part_engines(case, world, gpu_ctx_factory, cost_limit=1.0):
 
 
 @pytest.mark.parametrize("device_loop", [True, False])
-@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0)])
+@pytest.mark.parametrize("world,offset", [(2, 0.3), (4, float("inf")), (3, 0.0), (3, -0.5)])
 def test_partitioned_plan_c1_bit_exact(gpu_ctx_factory, world, offset, device_loop):
     case = terrain_case(224, 1)
     m = case.mesh
@@ -155,3 +155,21 @@ def test_partitioned_plan_1m_four_ranks_and_device_footprint(gpu_ctx_factory):
     for e in eng:
         assert e.ctx.V <= 1.2 * m.V / world
         assert e.ctx.device_bytes() < 1.2 * whole_bytes / world, (e.ctx.device_bytes(), whole_bytes)
+
+
+def test_partitioned_plan_negative_offset_on_a_flat_grid_full_of_ties(gpu_ctx_factory):
+    """A negative goal_dist_offset stops the expansion AT the robot vertex (dijkstra_mesh_planner.cpp:293-300): among the vertices of
+    exactly the robot's potential the vertex id decides who was expanded.  On a flat regular grid there are many of them; a part that
+    does not hold the robot vertex compares with the robot's rank among its own ids (mnav_shard_set_goal_tie)."""
+    from mesh_navigation_amd import meshgen
+    from tests.common import Case
+    m = meshgen.flat_grid(96, 0.1)
+    case = Case(m)
+    seed, target = m.vertex_at(0.15, 0.2), m.vertex_at(0.8, 0.75)
+    for offset in (-0.05, -1.0):
+        ref = case.om.dijkstra(case.weights, case.costs, seed, target, goal_dist_offset=offset)
+        eng = part_engines(case, 3, gpu_ctx_factory)
+        res = sharded.plan_virtual_ranks(eng, seed, target, offset, rounds_per_exchange=4, max_exchanges=5000)
+        assert res.code == ref.code == 0
+        assert np.array_equal(res.dist.view(np.uint32), ref.dist.view(np.uint32))
+        assert np.array_equal(res.pred, ref.pred) and np.array_equal(res.path, ref.path)

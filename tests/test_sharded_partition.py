@@ -87,7 +87,7 @@ def _worker(rank, world, port, seed, target, offset, rpe, q, check_every):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,offset,rpe,check_every", [(2, 0.3, 4, 0), (3, float("inf"), 2, 0), (2, 0.0, 16, 0), (3, 0.3, 2, 4)])
+@pytest.mark.parametrize("world,offset,rpe,check_every", [(2, 0.3, 4, 0), (3, float("inf"), 2, 0), (2, 0.0, 16, 0), (3, 0.3, 2, 4), (3, -0.4, 4, 0)])
 def test_partitioned_plan_matches_oracle_gloo(world, offset, rpe, check_every):
     case = _case()
     m = case.mesh
