@@ -49,12 +49,14 @@ __global__ __launch_bounds__(kBlock) void k_tb_fin_weights(size_t n, const uint3
 // plans in step (a barrier per plan).  A tile's rows are runs of ~11 vertices = a third of a 128-byte line of a vertex-order
 // output array; written by one wave alone the lines leave the L2 partially filled long before the neighbouring tile gets to
 // the same plan (first version of this kernel: no faster than the pass it replaced).  In step, the patch's lines are completed
-// within a microsecond.
+// within a microsecond.  Measured (ms of the pass per 7168-plan batch on the 1M mesh, waves per workgroup / waves per SIMD the
+// register budget allows): 1 / 3 -> 96, 4 / 3 -> 90, 8 / 3 -> 125, 8 / 4 (31 spilled dwords) -> 149, 16 / 4 -> 151: in step costs more
+// than the merged lines save beyond four tiles -- the pass is bound by its instruction count, not by the writes.
 #ifndef MNAV_FIN_WAVES
-#define MNAV_FIN_WAVES 8
+#define MNAV_FIN_WAVES 4
 #endif
 #ifndef MNAV_FIN_OCC
-#define MNAV_FIN_OCC 4
+#define MNAV_FIN_OCC 3
 #endif
 constexpr int kFinWaves = MNAV_FIN_WAVES;
 template <int T>
@@ -148,50 +150,74 @@ __global__ __launch_bounds__(64 * kFinWaves, MNAV_FIN_OCC) void k_tb_finalize(tb
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
-        if (!own[v]) continue;
+        // ---- the common case without a branch: no source AT the cut value, one source attains the vertex's value
         const uint32_t dyb = ld[ys[v]];
         const float dy = u2f(dyb);
         uint32_t sum[kTbFinSlots], dsb[kTbFinSlots];
+        bool at_cut = false;
 #pragma unroll
         for (int k = 0; k < (int)kTbFinSlots; ++k) {
           dsb[k] = ld[src[v][k]];
           const float ds = u2f(dsb[k]);
-          // expanded_source (dijkstra :293-300); the vertex id only matters AT the cut value: read then
-          bool ex = ds < inf_f() && ds < gcut.cut;
-          if (ds == gcut.cut && ds < inf_f()) ex = lgid[src[v][k]] < gcut.tie;
-          sum[k] = ex ? f2u(ds + wt[v][k]) : kTbInfBits;               // :331
+          at_cut |= ds == gcut.cut;
+          sum[k] = (ds < gcut.cut) ? f2u(ds + wt[v][k]) : kTbInfBits;   // expanded source (dijkstra :293-300), :331; an unused slot's weight is +inf
         }
+        const uint32_t m = min(min(min(sum[0], sum[1]), min(sum[2], sum[3])), min(min(sum[4], sum[5]), min(sum[6], sum[7])));
         const bool is_seed = gid[v] == seed;
         const bool cut = dy > gcut.cut;                                // beyond goal_dist: the value is re-derived from the expanded sources
-        uint32_t val = cut ? kTbInfBits : dyb;
-        if (cut) {
+        uint32_t val = cut ? m : dyb;
+        // the sources that attain the value compete with (d[x], x) for the predecessor: smallest d first
+        uint32_t c[kTbFinSlots];
 #pragma unroll
-          for (int k = 0; k < (int)kTbFinSlots; ++k) val = min(val, sum[k]);
-        }
-        // every expanded source checks the fixed point; those that attain the value compete with (d[x], x) for the predecessor
-        unsigned long long key = ~0ull;
-        uint32_t best_s = ys[v];
+        for (int k = 0; k < (int)kTbFinSlots; ++k) c[k] = (sum[k] == val) ? dsb[k] : kTbInfBits;
+        const uint32_t bd = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
+        uint32_t best_s = ys[v], nbest = 0;
 #pragma unroll
-        for (int k = 0; k < (int)kTbFinSlots; ++k) {
-          if (sum[k] < val && !is_seed) ++bad;
-          if (sum[k] == val && val != kTbInfBits) {
-            const unsigned long long kk = ((unsigned long long)dsb[k] << 32) | lgid[src[v][k]];   // (one or two slots attain the value)
-            if (kk < key) { key = kk; best_s = src[v][k]; }
+        for (int k = (int)kTbFinSlots - 1; k >= 0; --k) { const bool hit = c[k] == bd; best_s = hit ? src[v][k] : best_s; nbest += hit ? 1u : 0u; }
+        const bool finite = val != kTbInfBits;
+        unsigned long long key = finite && bd != kTbInfBits ? (((unsigned long long)bd << 32) | lgid[best_s]) : ~0ull;
+        uint32_t nbad = (m < val && !is_seed) ? 1u : 0u;
+        // ---- the rest, exactly: a source AT the cut value (the vertex id decides whether it was expanded: negative offsets, ties with
+        // goal_dist), several sources of the same potential attaining the value (the smaller id wins), valence above kTbFinSlots
+        if (own[v] && (at_cut || (finite && nbest > 1u) || W.ovf_n)) {
+          nbad = 0u;
+#pragma unroll
+          for (int k = 0; k < (int)kTbFinSlots; ++k) {
+            const float ds = u2f(dsb[k]);
+            bool ex = ds < inf_f() && ds < gcut.cut;
+            if (ds == gcut.cut && ds < inf_f()) ex = lgid[src[v][k]] < gcut.tie;
+            sum[k] = ex ? f2u(ds + wt[v][k]) : kTbInfBits;
+          }
+          val = cut ? kTbInfBits : dyb;
+          if (cut) {
+#pragma unroll
+            for (int k = 0; k < (int)kTbFinSlots; ++k) val = min(val, sum[k]);
+          }
+          key = ~0ull; best_s = ys[v];
+#pragma unroll
+          for (int k = 0; k < (int)kTbFinSlots; ++k) {
+            if (sum[k] < val && !is_seed) ++nbad;
+            if (sum[k] == val && val != kTbInfBits) {
+              const unsigned long long kk = ((unsigned long long)dsb[k] << 32) | lgid[src[v][k]];
+              if (kk < key) { key = kk; best_s = src[v][k]; }
+            }
+          }
+          for (uint32_t e = 0; e < W.ovf_n; ++e) {
+            const TbFinOvf o = F.ovf[W.ovf_off + e];
+            if (o.y != ys[v]) continue;
+            const uint32_t db = ld[o.src], g2 = lgid[o.src];
+            if (!expanded_source(gcut, u2f(db), g2)) continue;
+            const uint32_t sm = f2u(u2f(db) + F.ovf_w[W.ovf_off + e]);
+            if (cut && sm < val) { val = sm; key = ~0ull; }            // (a smaller sum from the overflow list restarts the argmin)
+            else if (sm < val && !is_seed) ++nbad;
+            if (sm == val && val != kTbInfBits) {
+              const unsigned long long kk = ((unsigned long long)db << 32) | g2;
+              if (kk < key) { key = kk; best_s = o.src; }
+            }
           }
         }
-        for (uint32_t e = 0; e < W.ovf_n; ++e) {                       // valence above kTbFinSlots: rare
-          const TbFinOvf o = F.ovf[W.ovf_off + e];
-          if (o.y != ys[v]) continue;
-          const uint32_t db = ld[o.src], g2 = lgid[o.src];
-          if (!expanded_source(gcut, u2f(db), g2)) continue;
-          const uint32_t sm = f2u(u2f(db) + F.ovf_w[W.ovf_off + e]);
-          if (cut && sm < val) { val = sm; key = ~0ull; }              // (a smaller sum from the overflow list restarts the argmin)
-          else if (sm < val && !is_seed) ++bad;
-          if (sm == val && val != kTbInfBits) {
-            const unsigned long long kk = ((unsigned long long)db << 32) | g2;
-            if (kk < key) { key = kk; best_s = o.src; }
-          }
-        }
+        if (!own[v]) continue;
+        bad += nbad;
         uint32_t pv = gid[v];
         float outd = u2f(val);
         if (is_seed) { outd = dy; ++cnt; }

@@ -239,6 +239,7 @@ def test_gpu_plugin_backstop_sees_what_the_change_signal_cannot(world):
     assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
     full0, inc0, sign0 = R.RefMap.gpu_plugin_cost_sync_counts()
     w_before = rm.edge_weights().copy()
+    assert rm.set_param("mesh_map.edge_cost_factor", 1.0)               # (the reference swallows its FIRST parameter callback: `first_config`, mesh_map.cpp:1369-1372)
     assert rm.set_param("mesh_map.edge_cost_factor", 6.0)               # the map recomputes all its edge weights; no layer says a word
     assert not np.array_equal(rm.edge_weights(), w_before)
     cr1, pr1, kr1 = rm.dijkstra_make_plan(pose(robot), pose(goal))
