@@ -718,8 +718,7 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     }
     if (ctx->fin_lds > 160 * 1024) { ctx->err = "mesh valence too high for the LDS tile engine"; return -2; }
     if (ctx->fin_lds > 64 * 1024)
-      HIPCHK(hipFuncSetAttribute((const void*)k_dij_finalize<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->fin_lds));
-      HIPCHK(hipFuncSetAttribute((const void*)k_dij_finalize<kFinGroup, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->fin_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)k_dij_finalize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->fin_lds));
     if (ctx->tile_lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void*)k_tile_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
     if (ctx->tile_lds > 64 * 1024) {

@@ -152,23 +152,8 @@ void launch_finalize(mnav_ctx* ctx, uint32_t n, uint32_t ntiles_in = 0, size_t f
   if (chunks < 1) chunks = 1;
   const uint32_t per = (ntiles + chunks - 1) / chunks;
   chunks = (ntiles + per - 1) / per;
-  hipLaunchKernelGGL((k_dij_finalize<1, false>), dim3(n, chunks), dim3(kTileBlock), fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
-                     ctx->d_mismatch, ctx->d_res, per, n, FinBlocked{});
-}
-
-// the tile-batch engine's batches: groups of kFinGroup plans per staged tile, distances straight from the engine's slices
-constexpr int kFinGroup = 8;
-void launch_finalize_blocked(mnav_ctx* ctx, uint32_t n, const FinBlocked& B)
-{
-  const uint32_t ntiles = ctx->tiles_meta.ntiles ? ctx->tiles_meta.ntiles : 1u;
-  const uint32_t groups = (n + kFinGroup - 1) / kFinGroup;
-  uint32_t chunks = (8192u + groups - 1) / groups;
-  if (chunks > ntiles) chunks = ntiles;
-  if (chunks < 1) chunks = 1;
-  const uint32_t per = (ntiles + chunks - 1) / chunks;
-  chunks = (ntiles + per - 1) / per;
-  hipLaunchKernelGGL((k_dij_finalize<kFinGroup, true>), dim3(groups, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
-                     ctx->d_mismatch, ctx->d_res, per, n, B);
+  hipLaunchKernelGGL(k_dij_finalize, dim3(n, chunks), dim3(kTileBlock), fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
+                     ctx->d_mismatch, ctx->d_res, per, n);
 }
 
 int tile_weights(mnav_ctx* ctx)

@@ -1,6 +1,7 @@
 // mnav_finalize.h -- PlanResult and k_dij_finalize: the reference's exact cut-off semantics (tentative values beyond goal_dist,
-// negative offsets through goal_cut) and the predecessors of every vertex in one gather pass over the LDS tiles; for the
-// tile-batch engine also the vector map.  Included by mnav.hip inside its anonymous namespace; not a stand-alone header.
+// negative offsets through goal_cut) and the predecessors of every vertex in one gather pass over the LDS tiles (the per-plan
+// engines: tile rounds, persistent, asynchronous, sharded; the tile-batch engine has its own pass, mnav_tb_finalize.h).
+// Included by mnav.hip inside its anonymous namespace; not a stand-alone header.
 #pragma once
 
 struct PlanResult {
@@ -26,27 +27,21 @@ __host__ __device__ inline size_t finalize_lds_bytes(uint32_t max_nv, uint32_t m
 
 __device__ __forceinline__ void store3(float* p, float x, float y, float z) { p[0] = x; p[1] = y; p[2] = z; }
 
-// Source of the distances when the tile-batch engine ran (mnav_tb.h): its blocked per-(tile, plan) slices, addressed through
-// vaddr[v] = {slice offset of v's tile, slice length << 8 | local index}; the engine's control words for the plan records.
-struct FinBlocked { const float* D; const uint2* vaddr; uint32_t NP; const uint32_t* iters; const uint32_t* err; const uint32_t* n_cand;
-                    const float* xyz; float* const* vecmaps; };   // vecmaps != null: computeVectorMap (dijkstra :189-209) in the same pass
-
-// PG plans per workgroup share ONE staged tile graph (the staging -- 21 KB per tile out of L2 -- was most of this pass in
-// large batches); BLOCKED: the distances are gathered from the tile-batch engine's slices, every value is written.
-template <int PG, bool BLOCKED>
+// One workgroup per (plan, chunk of tiles).
 __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restrict__ plans, const TilePlan* __restrict__ tplans,
                                                              uint32_t* __restrict__ mismatch, PlanResult* __restrict__ res,
-                                                             uint32_t tiles_per_block, uint32_t n_plans, FinBlocked B)
+                                                             uint32_t tiles_per_block, uint32_t n_plans)
 {
-  // grid: x = group of PG plans, y = chunk of tiles.  Only tiles that were activated or woken are looked at: any
+  // grid: x = plan, y = chunk of tiles.  Only tiles that were activated or woken are looked at: any
   // vertex that owes a value to an expanded source sits in such a tile (its source pushed to it
   // through a halo copy, which wakes the owner); everything else keeps dist = inf / pred = itself.
   // Per tile the push graph is staged in LDS like in the solve and read backwards: every edge
   // x -> y with an expanded source offers (d[x] + w, d[x], x) to its owned target y; pass 1 takes the
   // smallest sum (ds_min on the float bits), pass 2 the smallest (d[x], x) among the edges that attain
   // it (64-bit ds_min) -- the reference's predecessor under the (value, id) pop order.
+  constexpr int PG = 1;                                              // (plans per workgroup; the per-plan arrays below are what is left of a grouped variant)
   const uint32_t p0 = blockIdx.x * PG;
-  const TilePlan& T = tplans[BLOCKED ? 0u : p0];                     // the mesh tables are the same in every record
+  const TilePlan& T = tplans[p0];
   const int tid = threadIdx.x;
   MNAV_GLOBAL const uint32_t* g_vptr = as_global(T.vptr);
   MNAV_GLOBAL const uint32_t* g_hptr = as_global(T.hptr);
@@ -54,9 +49,6 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
   MNAV_GLOBAL const uint32_t* g_rptr = as_global(T.rptr);
   MNAV_GLOBAL const uint32_t* g_verts = as_global(T.verts);
   MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(T.halo_verts);
-  MNAV_GLOBAL const u32x2* g_va = (MNAV_GLOBAL const u32x2*)as_global((const uint32_t*)B.vaddr);
-  MNAV_GLOBAL const float* g_D = as_global(B.D);
-  MNAV_GLOBAL const float* g_xyz = as_global(B.xyz);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TileLds L = tile_lds_layout(smem, T.max_nv, T.max_nh, T.max_ne);
   uint32_t* const lsum = reinterpret_cast<uint32_t*>(smem + tile_lds_bytes(T.max_nv, T.max_nh, T.max_ne));
@@ -74,8 +66,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       s_seed[q] = P.seed[0];
       const uint32_t tg = P.target[0];
       float dt;
-      if (BLOCKED) { const uint2 a = B.vaddr[tg]; dt = B.D[(size_t)a.x * B.NP + (size_t)(p0 + q) * (a.y >> 8) + (a.y & 255u)]; }
-      else dt = P.dist[tg];
+      dt = P.dist[tg];
       s_armed[q] = dt < inf_f() ? 1u : 0u;
       const GoalCut gc = goal_cut(dt, P.offset, P.goal_tie1 ? P.goal_tie1 - 1u : tg);   // dijkstra :296
       s_goal[q] = gc.goal; s_cut[q] = gc.cut; s_tie[q] = gc.tie;
@@ -86,7 +77,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
   const uint32_t t_beg = T.t_lo + blockIdx.y * tiles_per_block;
   const uint32_t t_end = min(t_beg + tiles_per_block, T.t_hi ? T.t_hi : T.ntiles);
   for (uint32_t t = t_beg; t < t_end; ++t) {
-    if (!BLOCKED) {                                                   // (PG == 1 there) uniform over the workgroup
+    {                                                                 // uniform over the workgroup
       MNAV_GLOBAL const float* g_tlast = as_global((const float*)T.tlast);
       MNAV_GLOBAL const uint32_t* g_p0 = as_global((const uint32_t*)T.pend[0]);
       MNAV_GLOBAL const uint32_t* g_p1 = as_global((const uint32_t*)T.pend[1]);
@@ -98,12 +89,10 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
     const uint32_t r0 = g_rptr[t], nl = nv + nh;
     __syncthreads();                                               // the previous tile's LDS image is dead
     uint32_t g[kFinVpt];
-    u32x2 va[kFinVpt];
 #pragma unroll
     for (int k = 0; k < kFinVpt; ++k) {
       const uint32_t i = tid + k * kTileBlock;
       g[k] = (i < nv) ? g_verts[v0 + i] : (i < nl ? g_halo_verts[h0 + i - nv] : 0u);
-      if (BLOCKED) va[k] = g_va[g[k]];
       if (i < nl) lgid[i] = g[k];
     }
     for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock) lgid[i] = (i < nv) ? g_verts[v0 + i] : g_halo_verts[h0 + i - nv];
@@ -111,8 +100,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
     uint32_t dbn[kFinVpt];                                           // values of the first plan of the group
 #pragma unroll
     for (int k = 0; k < kFinVpt; ++k) {
-      if (BLOCKED) dbn[k] = f2u(g_D[(size_t)va[k].x * B.NP + (size_t)p0 * (va[k].y >> 8) + (va[k].y & 255u)]);
-      else dbn[k] = f2u(as_global(plans[p0].dist)[g[k]]);
+      dbn[k] = f2u(as_global(plans[p0].dist)[g[k]]);
     }
 #pragma unroll 1
     for (uint32_t q = 0; q < np; ++q) {
@@ -123,19 +111,13 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       GoalCut gcut; gcut.goal = s_goal[q]; gcut.cut = s_cut[q]; gcut.tie = s_tie[q];
       const float goal_dist = gcut.cut;                              // values above it are re-derived from the expanded sources
       const uint32_t seed_q = s_seed[q];
-      MNAV_GLOBAL float* g_vm = (BLOCKED && B.vecmaps) ? as_global(B.vecmaps[p]) : nullptr;
       auto value_of = [&](uint32_t gid) -> uint32_t {
-        if (BLOCKED) { const u32x2 a = g_va[gid]; return f2u(g_D[(size_t)a.x * B.NP + (size_t)p * (a.y >> 8) + (a.y & 255u)]); }
         return f2u(g_dist[gid]);
       };
       if (q) __syncthreads();                                        // the previous plan's ldu / lsum / lkey are dead
       uint32_t db[kFinVpt];
 #pragma unroll
       for (int k = 0; k < kFinVpt; ++k) db[k] = dbn[k];
-      if (BLOCKED && q + 1 < np) {                                   // the next plan's values are in flight during this plan's passes
-#pragma unroll
-        for (int k = 0; k < kFinVpt; ++k) dbn[k] = f2u(g_D[(size_t)va[k].x * B.NP + (size_t)(p + 1) * (va[k].y >> 8) + (va[k].y & 255u)]);
-      }
       {
         // no reached vertex among the tile's own and halo vertices: nothing to derive here (dist = inf, pred = itself)
         int reached = 0;
@@ -143,10 +125,6 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
         for (int k = 0; k < kFinVpt; ++k) reached |= ((uint32_t)(tid + k * kTileBlock) < nl && db[k] != kInfBits) ? 1 : 0;
         for (uint32_t i = tid + kFinVpt * kTileBlock; i < nl; i += kTileBlock) reached |= (value_of(lgid[i]) != kInfBits) ? 1 : 0;
         if (!__syncthreads_or(reached)) {                             // uniform over the workgroup
-          if (BLOCKED) for (uint32_t i = tid; i < nv; i += kTileBlock) {
-            const uint32_t gg = lgid[i]; g_dist[gg] = inf_f(); g_pred[gg] = gg;
-            if (g_vm) store3((float*)g_vm + 3 * (size_t)gg, 0.f, 0.f, 0.f);
-          }
           continue;
         }
       }
@@ -212,7 +190,6 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
         const uint32_t gg = lgid[i];
         if (gg == seed_q) {
           ++cnt;
-          if (BLOCKED) { g_dist[gg] = u2f(L.ldu[i]); g_pred[gg] = gg; if (g_vm) store3((float*)g_vm + 3 * (size_t)gg, 0.f, 0.f, 0.f); }
           continue;
         }
         const uint32_t sb = lsum[i], ob = L.ldu[i];
@@ -220,19 +197,8 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
         if (sb != kInfBits && key == ~0ull && (!T.owned || T.owned[gg])) ++bad;   // a finite value no expanded neighbour supports (a halo copy's support may live on another process)
         const uint32_t pv = (sb != kInfBits) ? (uint32_t)key : gg;
         g_pred[gg] = pv;
-        if (BLOCKED || sb != ob) g_dist[gg] = u2f(sb);                // (else only above goal_dist: tentative value, dijkstra :337-343)
+        if (sb != ob) g_dist[gg] = u2f(sb);                // (else only above goal_dist: tentative value, dijkstra :337-343)
         if (sb != kInfBits) ++cnt;
-        if (BLOCKED && g_vm) {                                        // k_vecmap_dijkstra's arithmetic
-          float x = 0.f, y = 0.f, z = 0.f;
-          if (pv != gg) {                                             // :197
-            x = g_xyz[3 * (size_t)pv] - g_xyz[3 * (size_t)gg];        // :204
-            y = g_xyz[3 * (size_t)pv + 1] - g_xyz[3 * (size_t)gg + 1];
-            z = g_xyz[3 * (size_t)pv + 2] - g_xyz[3 * (size_t)gg + 2];
-            const float len = sqrtf(x * x + y * y + z * z);           // normalized(), :206
-            x = x / len; y = y / len; z = z / len;
-          }
-          store3((float*)g_vm + 3 * (size_t)gg, x, y, z);
-        }
       }
       cnt = wave_sum(cnt);
       if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_settled[q], cnt);
@@ -248,8 +214,7 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       const Plan& P = plans[p0 + q];
       Ctl r; memset(&r, 0, sizeof(r));
       r.armed = s_armed[q]; r.goal_dist = s_goal[q]; r.thr = inf_f(); r.thr_fixed = inf_f();
-      if (BLOCKED) { r.it = (int32_t)*B.iters; r.done = 1u; r.overflow = (*B.err || *B.n_cand) ? 1u : 0u; }
-      else {
+      {
         const TilePlan& Tq = tplans[p0 + q];
         const TCtl a = Tq.ctl[0], b = Tq.ctl[1];
         const TCtl last = (a.it > b.it) ? a : b;

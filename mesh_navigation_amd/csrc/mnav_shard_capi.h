@@ -346,8 +346,8 @@ int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_d
     uint32_t chunks = std::min<uint32_t>(4096u, own);
     const uint32_t per = (own + chunks - 1) / chunks;
     chunks = (own + per - 1) / per;
-    hipLaunchKernelGGL((k_dij_finalize<1, false>), dim3(1, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
-                       ctx->d_mismatch, ctx->d_res, per, 1u, FinBlocked{});
+    hipLaunchKernelGGL(k_dij_finalize, dim3(1, chunks), dim3(kTileBlock), ctx->fin_lds, ctx->stream, ctx->d_plans, ctx->d_tplans,
+                       ctx->d_mismatch, ctx->d_res, per, 1u);
   }
   const uint32_t gv = (ctx->V + kBlock - 1) / kBlock;
   hipLaunchKernelGGL(k_shard_owned, dim3(gv ? gv : 1), dim3(kBlock), 0, ctx->stream, ctx->V, ctx->d_vert_tile, S.t_lo, S.t_hi,

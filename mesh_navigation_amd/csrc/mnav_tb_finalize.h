@@ -16,6 +16,8 @@
 
 namespace {
 
+typedef float f32x3_u __attribute__((ext_vector_type(3), aligned(4)));   // one 12-byte store per vector-map entry (global_store_dwordx3)
+
 struct FinTb {
   const uint16_t* src; const float* w; const TbFinOvf* ovf; const float* ovf_w;   // finalize tables (mnav_tb_build.h), weights materialised per cost limit
   const uint32_t* verts; const uint32_t* ghost_gid;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(64 * kFinWaves, MNAV_FIN_OCC) void k_tb_finalize(tb
 #pragma unroll
       for (int v = 0; v < 2; ++v) if (own[v]) {
         g_dist[gid[v]] = inf_f(); g_pred[gid[v]] = gid[v];
-        if (g_vm) { g_vm[3 * (size_t)gid[v]] = 0.f; g_vm[3 * (size_t)gid[v] + 1] = 0.f; g_vm[3 * (size_t)gid[v] + 2] = 0.f; }
+        if (g_vm) { const f32x3_u z3 = { 0.f, 0.f, 0.f }; *(MNAV_GLOBAL f32x3_u*)(g_vm + 3 * (size_t)gid[v]) = z3; }
       }
     } else {
       const GoalCut gcut = F.gcs[p];                                    // dijkstra :296 (k_tb_fin_plans)
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(64 * kFinWaves, MNAV_FIN_OCC) void k_tb_finalize(tb
             const float len = sqrtf(x * x + y * y + z * z);            // normalized(), :206
             x = x / len; y = y / len; z = z / len;
           }
-          g_vm[3 * (size_t)gid[v]] = x; g_vm[3 * (size_t)gid[v] + 1] = y; g_vm[3 * (size_t)gid[v] + 2] = z;
+          const f32x3_u o3 = { x, y, z };
+          *(MNAV_GLOBAL f32x3_u*)(g_vm + 3 * (size_t)gid[v]) = o3;
         }
       }
     }

@@ -305,7 +305,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
   if (rc == 0 && !ctx->lazy_paths) {
     // V-sized outputs wanted (potential, predecessors, vector map): the finalize pass of the tile engines derives the
-    // reference's exact cut-off semantics and predecessors straight from the blocked distances (k_dij_finalize<8, true>)
+    // reference's exact cut-off semantics and predecessors straight from the blocked distances (k_tb_finalize)
     if (tb_fields(ctx, n, in, offset, A)) return -1;
   }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));

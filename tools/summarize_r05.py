@@ -129,7 +129,7 @@ if what in ("c4", "c2"):
     print("engine ms per batch: rocprof", round(eng_ms, 1), "events", round(ev_ms, 1), "| traffic/algorithmic", round(traffic["ratio_traffic_to_algorithmic"], 3), "-", round(traffic["ratio_high"], 3))
 else:
     sq = merge_sq()
-    ks = [k for k in sq if k.startswith(("k_tb_solve_q", "k_dij_finalize", "k_tb_scan"))]
+    ks = [k for k in sq if k.startswith(("k_tb_solve_q", "k_dij_finalize", "k_tb_finalize", "k_tb_scan"))]
     with open(os.path.join(P, f"r05_{tag}_sq.md"), "w") as f:
         f.write(f"# profiles/r05_{tag}_sq.md — shader-core counters of the headline bench command\n\n")
         f.write("MI355X (gfx950). `tools/prof_r05.sh c2sq`: three passes of `rocprofv3 --pmc <group> -- python bench.py --steps 1 --warmup 1 --no-cpu --no-latency --no-configs` "
