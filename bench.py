@@ -200,7 +200,7 @@ def main() -> None:
         # incident edge, summed over the batch) divided by the average launch duration, measured live with HIP events that
         # the library records on ITS OWN stream around the engine's launches.  Batches of >= 256 plans run on the tile-batch
         # engine: ONE engine run per batch = a few hundred iterations of k_tb_plan / k_tb_scan / k_tb_items / k_tb_solve
-        # replayed from a hipGraph (k_tb_solve is > 90 % of it, profiles/r03_bench_kernel_stats.md); the events bracket the
+        # replayed from a hipGraph (k_tb_solve_q is > 85 % of it, profiles/r05_bench_kernel_stats.md); the events bracket the
         # whole run, so `achieved` prices the scheduling kernels too.  HBM traffic per run from the PMC passes committed
         # under profiles/ (tools/prof_pmc.sh: FETCH_SIZE / WRITE_SIZE summed over the engine's kernels of one batch) -- only
         # quoted when it was measured on this very workload.
@@ -210,10 +210,10 @@ def main() -> None:
         traffic = None
         traffic_profiled = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_pmc_traffic.json")))
             if pm.get("kernel") == "k_tb_solve_q" and B == pm.get("batch") and N == pm.get("grid"):
                 traffic_profiled = {"bytes_per_launch": pm["traffic_bytes_per_launch"], "bytes_per_launch_high": pm.get("traffic_bytes_per_launch_high"),
-                                    "source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"}
+                                    "source": "profiles/r05_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"}
         except (OSError, ValueError, KeyError):
             pass
         per_launch_bytes = algo / max(launches, 1)
@@ -538,7 +538,7 @@ def leg_c4(local_rank, args):
                "ms_per_makeplan_single": float(np.median(lat)), "ms_per_makeplan_single_p95": float(np.percentile(lat, 95)),
                "batch": B, "plans_per_s_batch": B / tb, "ms_per_batch": tb * 1e3,
                "roofline": roofline_of(sb, "k_tb_solve_q (tile-batch engine run)" if sb["launches"] <= 1 else "k_tile_round"),
-               "roofline_single_plan": roofline_of(st, "k_tile_round")}
+               "roofline_single_plan": roofline_of(st, "k_plan_async (asynchronous tile engine: one launch per plan)" if st["launches"] == 1 else "k_tile_round")}
         if not args.no_cpu:
             from oracle import oracle as O
             om = O.OracleMesh(mesh.xyz, mesh.faces)

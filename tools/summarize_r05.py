@@ -97,6 +97,7 @@ if what in ("c4", "c2"):
     traffic = {
         "command": f"tools/prof_r05.sh {what}: rocprofv3 --pmc FETCH_SIZE (then, separately, WRITE_SIZE) -- {cmd}",
         "kernel": "k_tb_solve_q", "engine_kernels": list(ENGINE),
+        "batch": (line.get("config") or {}).get("batch_per_gpu", line.get("batch")), "grid": 1000 if what == "c2" else 3163,
         "fetch_bytes_per_engine_run_raw": f_b, "write_bytes_per_engine_run_raw": w_b,
         "note": "FETCH_SIZE / WRITE_SIZE (KB) summed over every launch of the engine's four kernels, per batch.  gfx950: FETCH_SIZE reports 1/2 of the "
                 "bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md, HBM section); the engine's slice loads are 16-byte per-lane loads, its "
@@ -110,12 +111,13 @@ if what in ("c4", "c2"):
     sq = merge_sq() if what == "c4" else {}
     name = f"r05_{tag}_pmc.json" if what == "c4" else f"r05_{tag}_pmc_traffic.json"
     json.dump(traffic, open(os.path.join(P, name), "w"), indent=1)
-    eng_ms = sum(float(r["TotalDurationNs"]) for r in rows if short(r["Name"]).startswith(ENGINE)) / 1e6 / batches
+    trace_batches = (line.get("steps", 1) + line.get("warmup", 1)) if what == "c2" else batches   # the trace pass of c2 runs --steps 3 --warmup 1
+    eng_ms = sum(float(r["TotalDurationNs"]) for r in rows if short(r["Name"]).startswith(ENGINE)) / 1e6 / trace_batches
     with open(os.path.join(P, f"r05_{tag}_kernel_stats.md"), "w") as f:
         f.write(f"# profiles/r05_{tag}_kernel_stats.md — rocprofv3 kernel trace, HBM traffic and shader-core counters\n\n")
         f.write(f"MI355X (gfx950). Commands: `tools/prof_r05.sh {what}` = `cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}`, "
                 "then one `rocprofv3 --pmc <group>` pass per counter group (FETCH_SIZE; WRITE_SIZE; three SQ_* groups), never combined with a trace domain.\n")
-        f.write(f"Raw CSV: `profiles/r05_{tag}_kernel_stats.csv`. Workload: {workload}; {batches} batches (1 warm-up + 1 timed).\n\n")
+        f.write(f"Raw CSV: `profiles/r05_{tag}_kernel_stats.csv`. Workload: {workload}; {trace_batches} batches in the trace pass, {batches} in each counter pass.\n\n")
         f.write("| kernel | calls | total ms | avg µs | min µs | max µs | % |\n|---|---|---|---|---|---|---|\n")
         for r in rows[:14]:
             f.write(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
