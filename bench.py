@@ -342,7 +342,7 @@ def leg_c5(ctx, mesh, edge_w, costs, robot, args):
     st = r["stats"]
     out = {"workload": "C5: 64 concurrent goals, common robot vertex, 1M-vertex C2 mesh, one batch on one GPU",
            "plans_per_s": 64 / med, "ms_per_batch": med * 1e3, "ms_per_batch_p95": float(np.percentile(ts, 95)) * 1e3,
-           "roofline": roofline_of(st, "k_tile_round" if st["launches"] > 1 else "k_tb_solve_q (tile-batch engine run)")}
+           "roofline": roofline_of(st, "k_tile_round" if st["launches"] > 1 else "k_plan_async (asynchronous tile engine: one launch for the 64 plans)")}
     if not args.no_cpu:
         from oracle import oracle as O
         om = O.OracleMesh(mesh.xyz, mesh.faces)

@@ -287,12 +287,12 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
 /* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round),
  * 1 = the distance-band gather steps that the CVP planner uses,
  * 2 = persistent per-plan workgroups walking the tiles best-first (on request only),
- * 3 = automatic (default): 5 for batches of >= 48 plans that also hold >= tiles/1000 plans, 6 for smaller calls (up to
- *     option async_max_batch = 8 plans; a call whose ticket ring overflows is re-run on 0), else 0,
+ * 3 = automatic (default): 6 for calls of up to `async_max_batch` = 96 plans (a call whose ticket ring overflows is re-run on 0),
+ *     5 beyond that (batches that also hold >= tiles/1000 plans), else 0,
  * 5 = tile-batch: one plan per lane, 16 plans per quarter of a wave, the tile's graph as record streams
  *     (highest throughput for large batches),
  * 6 = the LDS tiles without rounds: resident workgroups serve a ticket queue of woken tiles, solve and wake tiles
- *     asynchronously, one launch per call (single plans -- what MeshPlanner::makePlan runs -- and small batches).
+ *     asynchronously, one launch per call (single plans -- what MeshPlanner::makePlan runs -- and batches up to ~100 plans).
  * All give identical results (the label-correcting fixed point does not depend on the schedule). */
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine);
 /* Tuning / debug options by name (the list with one line each: mesh_navigation_amd/csrc/mnav_options.h; e.g. "cvp_wide",

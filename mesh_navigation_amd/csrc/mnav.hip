@@ -216,7 +216,7 @@ struct mnav_ctx {
   float delta_user = 0.f, delta_auto = 0.f;
   Options opt;                                                       // mnav_options.h: read from the environment once, by mnav_create
   uint32_t max_steps_auto = 1u << 20;
-  uint32_t* d_ring = nullptr; uint32_t ring_cap = 0, ring_used = 0; struct AsyncCtl* h_actl = nullptr; uint32_t* d_parked = nullptr; size_t parked_words = 0;   // asynchronous tile engine: ticket ring, pinned copy of its control words
+  uint32_t* d_ring = nullptr; uint32_t ring_cap = 0; size_t ring_words = 0; struct AsyncCtl* h_actl = nullptr; uint32_t* d_parked = nullptr; size_t parked_words = 0;   // asynchronous tile engine: ticket ring, pinned copy of its control words
   uint32_t last_planner = 0, last_n = 0;
   std::vector<uint32_t> last_target; double last_offset = 0.0;   // Dijkstra: robot vertex per device slot, goal_dist_offset of the last call
   mnav_stats stats{};
@@ -1284,14 +1284,14 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       // 10M: 64 plans 196 / 41 / 189, 256: 252 / 163 / 409, 1024: 254 / 594 / 924).
       const double tiles = std::max(1.0, (double)V / (0.9 * ctx->tb.T));
       const bool fills = m0 >= ctx->tb.min_batch && m0 <= 65535u && (double)m0 >= tiles / 1000.0;
-      // Below that: the asynchronous tile engine (mnav_async.h: one launch, a ticket queue of woken tiles; what a real makePlan
-      // call -- ONE plan -- runs on), up to async_max_batch plans (8: measured round 5, ms per call on the 1M / 10M mesh, rounds vs
-      // asynchronous -- 1 plan 10.1 / 7.3 vs 6.5 / 6.5, 8 plans 26.6 / 83 vs 16.2 / 85, 47 plans 49 / 243 vs 52 / 424); the tile rounds
-      // for what lies in between.
-      engine = fills ? 5 : (m0 <= opt_u32(ctx->opt.async_max_batch, 8u)) ? 6 : 0;
+      // Below that: the asynchronous tile engine (mnav_async.h: one launch, per-plan ticket queues of woken tiles; what a real
+      // makePlan call -- ONE plan -- runs on), up to async_max_batch plans.  Measured round 5, ms per call on the 1M mesh, rounds /
+      // tile-batch / asynchronous: 1 plan 10.1 / 20 / 6.8, 8 plans 28 / 29 / 9.7, 47 plans 55 / 38 / 22.9, 64 plans 65 / 46 / 27.5
+      // (10M mesh: 8 plans 83 / - / 45, 47 plans 243 / - / 182, 64 plans 330 / 340 / 224); it grows linearly with the batch
+      // where the tile-batch engine's iterations are shared by all plans: the engines cross at about a hundred plans.
+      engine = (m0 <= opt_u32(ctx->opt.async_max_batch, 96u)) ? 6 : fills ? 5 : 0;
     }
     if (engine == 5 && m0 > 65535u) engine = 2;                       // (plan ids are 16 bits in the tile-batch buckets)
-    if (engine == 6 && m0 > 255u) engine = 0;                         // (8 bits in a ticket)
     if (engine == 1 && offset < 0.0) engine = 0;                      // the band steps arm goal_dist inside the loop: tile rounds for a negative offset
   }
   if (engine == 5 && in.size() > 1) {

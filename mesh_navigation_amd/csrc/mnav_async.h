@@ -37,11 +37,13 @@
 //              solver:  ... solve, publish ...;  state[t] = 0;  v = pend[t];  v != inf -> as a waker, without the atomicMin
 //              Both sides do "write mine, THEN look at yours", every operation awaited before the next one is issued (Dekker):
 //              a wake-up that arrives while the tile is in solve is seen by the solver's look or files / parks for itself.
-//   ring[i]    ticket i = plan << 24 | tile, 0xffffffff = not filed yet.  push: i = tail++, ring[i] = ticket;
-//              pop: i = head++, then the workgroup polls ring[i] (one word, with s_sleep).  A ticket index belongs to exactly
-//              one popper, a slot is written exactly once per call: no reuse, no ABA.  The ring holds every ticket a call can
-//              file in practice (host: 16 per tile and plan); a call that runs out of slots -- or of room on a parked list --
-//              sets abort = 5 and the host re-runs it on the tile rounds.
+//   ring[p][i] ticket i of plan p = a tile id, 0xffffffff = not filed yet.  push: i = tail[p]++, ring[p][i] = tile;
+//              pop: i = head[p]++, then the workgroup polls ring[p][i] (one word, with s_sleep).  A ticket index belongs to exactly
+//              one popper, a slot is written exactly once per call: no reuse, no ABA.  A ring holds every ticket a plan can file
+//              in practice (host: 16 per tile); a plan that runs out of slots -- or of room on a parked list -- sets abort = 5
+//              and the host re-runs the call on the tile rounds.  ONE ring PER PLAN, and a workgroup serves one plan (block id
+//              mod plans) until that plan is finished, then the next unfinished one: with one ring for the whole call its head
+//              and tail words took every atomic of every plan -- 47 plans ran 8x slower per plan than one (round 5, first runs).
 //   work[p]    per plan: tickets filed and not yet retired, counted BEFORE the ticket becomes visible and given back after
 //              the solver's own wake-ups.  The workgroup that takes it to 0 advances the band (holding a count of its own
 //              while it files the next band's tickets); no parked tile left <=> the plan is at its fixed point: that workgroup
@@ -59,7 +61,7 @@ constexpr uint32_t kAsyncWake = 32;        // distinct neighbour tiles one solve
 constexpr uint32_t kTicketNone = 0xFFFFFFFFu;
 constexpr uint32_t kTicketExit = 0xFFFFFFFEu;
 // words 4.. of the context's control line (word 0: mnav_cancel)
-struct AsyncCtl { uint32_t abort; uint32_t done_plans; uint32_t head; uint32_t tail; uint32_t polls; uint32_t dropped; uint32_t ring_cap; uint32_t pad; };
+struct AsyncCtl { uint32_t abort; uint32_t done_plans; uint32_t tickets; uint32_t switches; uint32_t polls; uint32_t dropped; uint32_t ring_cap; uint32_t pad; };   // ring_cap: slots per plan
 
 namespace aq {
 typedef MNAV_GLOBAL uint32_t* gptr;    // every shared word is accessed through a GLOBAL pointer (global_* instructions, vmcnt only), never flat
@@ -77,7 +79,7 @@ __device__ __forceinline__ uint32_t amax(uint32_t* p, uint32_t v) { return __hip
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // the per-plan words live in the slot's three TCnt records (48 bytes, unused by this engine otherwise)
-struct PlanWords { uint32_t work, acts, sweeps, epochs, thr, par, nparked[2], pad[4]; };
+struct PlanWords { uint32_t work, acts, sweeps, epochs, thr, par, nparked[2], head, tail, done, pad; };
 static_assert(sizeof(PlanWords) == 3 * sizeof(TCnt), "PlanWords overlays TilePlan.cnt[3]");
 __device__ __forceinline__ PlanWords* words_of(const TilePlan& P) { return reinterpret_cast<PlanWords*>(P.cnt); }
 constexpr uint32_t kActive = 3u;
@@ -92,6 +94,8 @@ __device__ __forceinline__ void plan_finish(const TilePlan& P, AsyncCtl* actl)
   c.it = (int32_t)c.acts; c.done = 1u; c.thr = inf_f(); c.thr_prev = inf_f();
   P.ctl[0] = c; P.ctl[1] = c;
   drain();
+  st(&W->done, 1u);                                                   // (its workgroups move on to another plan)
+  add(&actl->tickets, ld(&W->tail));
   add(&actl->done_plans, 1u);
 }
 // file the ticket of tile t of plan p (the caller has just raised state[t] to ACTIVE)
@@ -102,8 +106,8 @@ __device__ __forceinline__ void push(const TilePlan& P, uint32_t p, uint32_t t, 
 {
   if (filed) atomicAdd(filed, 1u);                                    // (LDS)
   else { add(&words_of(P)->work, 1u); drain(); }
-  const uint32_t i = add(&actl->tail, 1u);
-  if (i < actl->ring_cap) st(ring + i, (p << 24) | t);
+  const uint32_t i = add(&words_of(P)->tail, 1u);
+  if (i < actl->ring_cap) st(ring + (size_t)p * actl->ring_cap + i, t);
   else st(&actl->abort, 5u);                                          // out of slots: the host re-runs the call on the tile rounds
 }
 // put tile t on the parked list of band parity `par` (the caller has just raised state[t] to that list's parked value)
@@ -144,12 +148,12 @@ __global__ __launch_bounds__(kBlock) void k_async_init(const TilePlan* __restric
   for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P.ntiles; t += stride) P.pend[1][t] = (t == st) ? aq::kActive : 0u;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     aq::PlanWords W; memset(&W, 0, sizeof(W));
-    W.work = 1u;
+    W.work = 1u; W.tail = 1u;
     W.thr = f2u((P.band > 0.f && P.band < inf_f()) ? P.band : inf_f());
     *aq::words_of(P) = W;
-    ring[blockIdx.y] = (blockIdx.y << 24) | st;
+    ring[(size_t)blockIdx.y * ring_cap] = st;
     if (blockIdx.y == 0) {
-      AsyncCtl c; c.abort = 0u; c.done_plans = 0u; c.head = 0u; c.tail = n; c.polls = 0u; c.dropped = 0u; c.ring_cap = ring_cap; c.pad = 0u;
+      AsyncCtl c; c.abort = 0u; c.done_plans = 0u; c.tickets = 0u; c.switches = 0u; c.polls = 0u; c.dropped = 0u; c.ring_cap = ring_cap; c.pad = 0u;
       *actl = c;
     }
   }
@@ -162,48 +166,61 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   __shared__ uint32_t s_hdr[8];
   __shared__ uint32_t s_nq[3];
-  __shared__ uint32_t s_ticket, s_bound_bits, s_thr_bits, s_par, s_wover, s_solve, s_advance, s_filed;
+  __shared__ uint32_t s_ticket, s_plan, s_bound_bits, s_thr_bits, s_par, s_wover, s_solve, s_advance, s_filed;
   __shared__ uint32_t s_wtile[kAsyncWake], s_wval[kAsyncWake];
   __shared__ uint32_t s_min[kTileBlock / 64], s_bey[kTileBlock / 64];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TileLds L = tile_lds_layout(smem, plans[0].max_nv, plans[0].max_nh, plans[0].max_ne);   // one mesh: the same for every plan
   uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
   const unsigned long long t_begin = wall_clock64();
-  uint32_t my_polls = 0, my_dropped = 0;
+  uint32_t my_polls = 0, my_dropped = 0, my_switches = 0;
+  uint32_t p_cur = blockIdx.x % n;                                    // the plan this workgroup serves (thread 0's copy decides)
   for (;;) {
-    // ---- the next ticket (thread 0 takes and awaits it, the workgroup sits in the barrier)
+    // ---- the next ticket of the plan this workgroup serves (thread 0 takes and awaits it, the workgroup sits in the barrier);
+    // when that plan is finished: the next unfinished one
     if (tid == 0) {
       uint32_t e = kTicketExit;
-      // (three independent operations in flight together: a workgroup that always finds its ticket filed never enters the poll
-      //  loop below, and must still see an abort or mnav_cancel)
-      const uint32_t ab = aq::ld(&actl->abort);
-      const uint32_t cn = plans[0].cancel ? aq::ld(plans[0].cancel) : 0u;
-      const uint32_t i = aq::add(&actl->head, 1u);
-      if (ab) { }
-      else if (cn) aq::st(&actl->abort, 3u);                          // mnav_cancel, dijkstra :287
-      else if (wall_clock64() - t_begin > limit_ticks) aq::st(&actl->abort, 2u);
-      else if (i < actl->ring_cap) {
-        for (uint32_t spins = 0;; ++spins) {
-          e = aq::ld(ring + i);
-          if (e != kTicketNone) break;
-          if ((spins & 7u) == 7u) {                                   // leave?  (every 8th look: the flags live in one line)
-            e = kTicketExit;
-            if (aq::ld(&actl->abort) || aq::ld(&actl->done_plans) >= n) break;
-            if (plans[0].cancel && aq::ld(plans[0].cancel)) { aq::st(&actl->abort, 3u); break; }   // mnav_cancel, dijkstra :287
-            if (wall_clock64() - t_begin > limit_ticks) { aq::st(&actl->abort, 2u); break; }
-            if (spins > 400000000u) { aq::st(&actl->abort, 4u); break; }                            // second guard, should the clock not tick
-            e = kTicketNone;
+      for (bool again = true; again;) {
+        again = false;
+        aq::PlanWords* const Wc = aq::words_of(plans[p_cur]);
+        uint32_t* const ring_p = ring + (size_t)p_cur * actl->ring_cap;
+        // (three independent operations in flight together: a workgroup that always finds its ticket filed never enters the poll
+        //  loop below, and must still see an abort or mnav_cancel)
+        const uint32_t ab = aq::ld(&actl->abort);
+        const uint32_t cn = plans[0].cancel ? aq::ld(plans[0].cancel) : 0u;
+        const uint32_t i = aq::add(&Wc->head, 1u);
+        if (ab) { }
+        else if (cn) aq::st(&actl->abort, 3u);                        // mnav_cancel, dijkstra :287
+        else if (wall_clock64() - t_begin > limit_ticks) aq::st(&actl->abort, 2u);
+        else if (i < actl->ring_cap) {
+          for (uint32_t spins = 0;; ++spins) {
+            e = aq::ld(ring_p + i);
+            if (e != kTicketNone) break;
+            if ((spins & 7u) == 7u) {                                 // leave?  (every 8th look)
+              e = kTicketExit;
+              if (aq::ld(&actl->abort) || aq::ld(&actl->done_plans) >= n) break;
+              if (plans[0].cancel && aq::ld(plans[0].cancel)) { aq::st(&actl->abort, 3u); break; }   // mnav_cancel, dijkstra :287
+              if (wall_clock64() - t_begin > limit_ticks) { aq::st(&actl->abort, 2u); break; }
+              if (spins > 400000000u) { aq::st(&actl->abort, 4u); break; }                            // second guard, should the clock not tick
+              if (aq::ld(&Wc->done)) {                                // this plan is finished: serve the next unfinished one
+                uint32_t q = p_cur;
+                for (uint32_t k = 1; k < n; ++k) { const uint32_t c2 = (p_cur + k) % n; if (!aq::ld(&aq::words_of(plans[c2])->done)) { q = c2; break; } }
+                if (q != p_cur) { p_cur = q; ++my_switches; again = true; }
+                break;                                                // (no unfinished plan left: done_plans reaches n in a moment; e = exit)
+              }
+              e = kTicketNone;
+            }
+            ++my_polls;
+            if (spins < 64u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
           }
-          ++my_polls;
-          if (spins < 64u) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);
-        }
-      } else aq::st(&actl->abort, 5u);
-      s_ticket = e;
+        } else aq::st(&actl->abort, 5u);
+      }
+      s_ticket = e; s_plan = p_cur;
     }
     __syncthreads();
     const uint32_t ticket = s_ticket;
     if (ticket == kTicketExit) break;
-    const uint32_t p = ticket >> 24, t = ticket & 0xFFFFFFu;
+    const uint32_t p = s_plan, t = ticket;
     const TilePlan& P = plans[p];
     aq::PlanWords* const W = aq::words_of(P);
     uint32_t* const pend = P.pend[0];
@@ -398,5 +415,5 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       par_c = par2;
     }
   }
-  if (tid == 0 && (my_polls | my_dropped)) { atomicAdd(&actl->polls, my_polls); atomicAdd(&actl->dropped, my_dropped); }
+  if (tid == 0 && (my_polls | my_dropped | my_switches)) { atomicAdd(&actl->polls, my_polls); atomicAdd(&actl->dropped, my_dropped); atomicAdd(&actl->switches, my_switches); }
 }

@@ -400,14 +400,17 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   // the ticket ring: every slot is written at most once per call, so it only has to hold what a call can file (a tile is
   // re-filed when a neighbour undercuts it after its solve: a handful of times) -- 16 per tile and plan; a call that runs out
   // gives up (abort 5) and is re-run on the tile rounds by the caller
+  // the ticket rings, one per plan: every slot is written at most once per call, so a ring only has to hold what a plan can file
+  // (a tile is re-filed when a neighbour undercuts it after its solve: a handful of times) -- 16 per tile; a call that runs out
+  // gives up (abort 5) and is re-run on the tile rounds by the caller
   const bool ring_forced = opt_set(ctx->opt.async_ring_cap);
-  const uint64_t want = ring_forced ? std::max<uint64_t>(n + 1u, opt_u32(ctx->opt.async_ring_cap, 0u))
-                                    : std::min<uint64_t>(std::max<uint64_t>((uint64_t)n * M.ntiles * 16u, 1u << 16), 1u << 27);
-  if (ctx->ring_cap < want || (ring_forced && ctx->ring_cap != want)) {
-    (void)hipFree(ctx->d_ring); ctx->d_ring = nullptr; ctx->ring_cap = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_ring, 4 * (size_t)want));
-    ctx->ring_cap = (uint32_t)want; ctx->ring_used = ctx->ring_cap;
+  const uint32_t cap1 = ring_forced ? std::max(2u, opt_u32(ctx->opt.async_ring_cap, 0u)) : std::max(1024u, std::min(M.ntiles * 16u, 1u << 24));
+  if (ctx->ring_words < (size_t)cap1 * n) {
+    (void)hipFree(ctx->d_ring); ctx->d_ring = nullptr; ctx->ring_words = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_ring, 4 * (size_t)cap1 * n));
+    ctx->ring_words = (size_t)cap1 * n;
   }
+  ctx->ring_cap = cap1;
   {
     const size_t per_plan = 2u * (size_t)aq::kParkedLists * M.ntiles;   // the two parked lists of a plan
     if (ctx->parked_words < per_plan * n) {
@@ -422,8 +425,7 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_ring, 0xFF, 4 * (size_t)std::min<uint64_t>(ctx->ring_cap, (uint64_t)ctx->ring_used + 4096u), ctx->stream));   // the slots the previous call touched
-  ctx->ring_used = ctx->ring_cap;                                     // (until this call's tail has been read back)
+  HIPCHK(hipMemsetAsync(ctx->d_ring, 0xFF, 4 * (size_t)ctx->ring_cap * n, ctx->stream));
   HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
   uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
   if (gi < 1) gi = 1;
@@ -457,11 +459,10 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   AsyncCtl& h = *ctx->h_actl;                                         // (pinned)
   HIPCHK(hipMemcpyAsync(&h, actl, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->ring_used = std::min(h.tail, ctx->ring_cap);
   ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
   ctx->stats.launches = 1;
   if (opt_on(ctx->opt.verbose))
-    fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, tickets %u, polls %u, retired beyond the bound %u\n", n, G, ctx->ms_chunks, h.abort, h.tail, h.polls, h.dropped);
+    fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, tickets %u, polls %u, retired beyond the bound %u, plan switches %u\n", n, G, ctx->ms_chunks, h.abort, h.tickets, h.polls, h.dropped, h.switches);
   if (h.abort == 3u || ctx->cancel.load(std::memory_order_relaxed)) return 1;   // :350-354
   if (h.abort == 5u) return 2;                                         // out of ticket slots: the caller re-runs the call on the tile rounds
   if (h.abort) { ctx->err = "asynchronous tile engine gave up (in-kernel wall-clock guard)"; return -1; }

@@ -36,6 +36,7 @@ struct PlanState {
   std::vector<uint32_t> dist, pend, lock, tlast;   // float bits; lock = the state word (1: a ticket is filed or the tile is in solve)
   std::vector<uint8_t> ticketed;                   // model only: a ticket of the tile is in the ring and not yet retired
   uint32_t thr = 0, par = 0, nparked[2] = { 0, 0 }, epochs = 0;   // the plan's band: threshold (float bits), parity of the current parked list
+  std::vector<uint32_t> ring; uint32_t head = 0, tail = 0, done_flag = 0;   // the plan's ticket ring (kNone = not filed yet)
   std::vector<uint32_t> parked[2];
   uint32_t work = 1, acts = 0, sweeps = 0, done = 0, finishes = 0;
   uint32_t seed = 0, target = 0;
@@ -52,7 +53,6 @@ struct Model {
   int turn = 0; std::vector<uint8_t> alive; std::mt19937 rng;
   uint64_t yields = 0, claim_fails = 0, drops = 0, violations = 0, solves_now = 0, max_solves = 0, putbacks = 0, raised = 0;
   uint32_t done_plans = 0, abort = 0;
-  std::vector<uint32_t> ring; uint32_t head = 0, tail = 0;           // the ticket ring (kTicketNone = not filed yet)
   uint64_t budget = 0;                             // yield budget: the model's wall-clock guard
   // deliberately broken variants, to show that the checks see protocol errors (tests/test_async_model.py): 2 = the solver does not look at the wake-up value again after clearing the state word (a wake-up that
   // arrived during the solve is lost), 3 = wakers file a ticket whatever the state word says (two solvers on a tile)
@@ -114,6 +114,7 @@ struct Wg {
       if (P.pend[t] != kInf || P.lock[t] != 0u || P.in_solve[t] || P.ticketed[t]) ++M.violations;
     if (P.work != 0) ++M.violations;
     ++P.finishes;
+    st(P.done_flag, 1u);
     add(M.done_plans, 1u);
   }
   void push(PlanState& P, uint32_t p, uint32_t t, uint32_t* filed = nullptr)
@@ -122,8 +123,9 @@ struct Wg {
     P.ticketed[t] = 1;
     if (filed) ++*filed;                                             // covered by the caller's reservation
     else add(P.work, 1u);                                            // counted before it can be seen
-    const uint32_t i = add(M.tail, 1u);
-    if (i < M.ring.size()) st(M.ring[i], (p << 24) | t); else st(M.abort, 5u);
+    (void)p;
+    const uint32_t i = add(P.tail, 1u);
+    if (i < P.ring.size()) st(P.ring[i], t); else st(M.abort, 5u);
   }
   void park(PlanState& P, uint32_t t, uint32_t par)
   {
@@ -143,25 +145,36 @@ struct Wg {
     route(P, p, t2, v, thr, par, filed);
   }
 
-  void run(uint32_t n, uint32_t)
+  void run(uint32_t n, uint32_t home)
   {
     M.enter(me);
     const HostTiles& T = M.T;
+    uint32_t p_cur = home % n;                                       // the plan this workgroup serves
     for (;;) {
-      // ---- the next ticket
-      const uint32_t i = add(M.head, 1u);
+      // ---- the next ticket of the plan this workgroup serves; when that plan is finished: the next unfinished one
       uint32_t e = kNone - 1u;                                       // kTicketExit
-      if (i < M.ring.size()) {
-        for (;;) {
-          e = ld(M.ring[i]);
-          if (e != kNone) break;
-          e = kNone - 1u;
-          if (ld(M.abort) || ld(M.done_plans) >= n) break;
-          e = kNone;
-        }
-      } else st(M.abort, 5u);
+      for (bool again = true; again;) {
+        again = false;
+        PlanState& Pc = M.plans[p_cur];
+        const uint32_t i = add(Pc.head, 1u);
+        if (i < Pc.ring.size()) {
+          for (;;) {
+            e = ld(Pc.ring[i]);
+            if (e != kNone) break;
+            e = kNone - 1u;
+            if (ld(M.abort) || ld(M.done_plans) >= n) break;
+            if (ld(Pc.done_flag)) {
+              uint32_t q = p_cur;
+              for (uint32_t k = 1; k < n; ++k) { const uint32_t c2 = (p_cur + k) % n; if (!ld(M.plans[c2].done_flag)) { q = c2; break; } }
+              if (q != p_cur) { p_cur = q; again = true; }
+              break;
+            }
+            e = kNone;
+          }
+        } else st(M.abort, 5u);
+      }
       if (e == kNone - 1u) break;
-      const uint32_t p = e >> 24, t = e & 0xFFFFFFu;
+      const uint32_t p = p_cur, t = e;
       PlanState& P = M.plans[p];
       const uint32_t v = xchg(P.pend[t], kInf);
       const float dt = u2f(ld(P.dist[P.target]));
@@ -309,14 +322,16 @@ uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
     P.thr = f2u((band > 0.f && band < inf_f()) ? band : inf_f()); P.par = 0;
     P.parked[0].assign(4 * (size_t)M.T.ntiles, 0u); P.parked[1].assign(4 * (size_t)M.T.ntiles, 0u);
   }
-  M.ring.assign((size_t)std::max<uint32_t>(ring_cap, n), kNone);
-  for (uint32_t p = 0; p < n; ++p) M.ring[p] = (p << 24) | M.T.vert_tile[M.plans[p].seed];
-  M.head = 0; M.tail = n;
+  for (uint32_t p = 0; p < n; ++p) {
+    PlanState& P = M.plans[p];
+    P.ring.assign((size_t)std::max<uint32_t>(ring_cap, 2u), kNone);
+    P.ring[0] = M.T.vert_tile[P.seed]; P.head = 0; P.tail = 1;
+  }
   M.alive.assign(n_wg, 1); M.sleep_until.assign(n_wg, 0); M.turn = 0;
   std::vector<std::thread> th;
   std::vector<Wg*> wgs;
   for (uint32_t w = 0; w < n_wg; ++w) wgs.push_back(new Wg(M, (int)w, sched_seed * 7919u + w));
-  for (uint32_t w = 0; w < n_wg; ++w) th.emplace_back([&, w] { wgs[w]->run(n, w); });
+  for (uint32_t w = 0; w < n_wg; ++w) th.emplace_back([&, w] { wgs[w]->run(n, w); });   // (workgroup w starts on plan w mod n)
   for (auto& t : th) t.join();
   for (auto* w : wgs) delete w;
   uint64_t acts = 0, sweeps = 0, fins = 0;
@@ -328,7 +343,8 @@ uint32_t asm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   }
   uint64_t epochs = 0; for (uint32_t p = 0; p < n; ++p) epochs += M.plans[p].epochs;
   stats_out[0] = acts; stats_out[1] = sweeps; stats_out[2] = epochs; stats_out[3] = M.drops; stats_out[4] = fins; stats_out[5] = M.yields;
-  stats_out[6] = M.max_solves; stats_out[7] = M.violations; stats_out[8] = M.abort; stats_out[9] = M.tail; stats_out[10] = 0;
+  stats_out[6] = M.max_solves; stats_out[7] = M.violations; uint64_t tickets = 0; for (uint32_t p = 0; p < n; ++p) tickets += M.plans[p].tail;
+  stats_out[8] = M.abort; stats_out[9] = tickets; stats_out[10] = 0;
   stats_out[11] = M.T.ntiles;
   return M.abort ? 1u : 0u;
 }

@@ -458,7 +458,7 @@ def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
     dist = np.empty((n, V), np.float32)
     stats = np.zeros(12, np.uint64)
     if ring_cap is None:
-        ring_cap = 64 * n * (V // max(int(tile) // 2, 1) + 8)
+        ring_cap = 64 * (V // max(int(tile) // 2, 1) + 8)            # slots per plan
     L = model_lib()
     L.asm_run.argtypes = [C.c_uint32] * 3 + [C.c_void_p] * 6 + [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                                                 C.c_float, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]

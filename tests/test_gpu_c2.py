@@ -16,7 +16,7 @@ def c2(gpu_ctx_factory):
     return case, ctx
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band", "persistent", "tile_batch"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "persistent", "tile_batch", "async"])
 def test_dijkstra_c2_bit_exact(c2, engine):
     case, ctx = c2
     ctx.set_dijkstra_engine(engine)
@@ -109,7 +109,7 @@ def test_punched_terrain_1m_deep_cascades(gpu_ctx_factory):
     while deg[s] == 0: s += 1
     while deg[t] == 0: t += 1
     ref = case.om.dijkstra(case.weights, case.costs, s, t)
-    for engine in ("tiled", "persistent", "tile_batch"):
+    for engine in ("tiled", "persistent", "tile_batch", "async"):
         ctx.set_dijkstra_engine(engine)
         out = ctx.plan_dijkstra(s, t)
         assert out.code == ref.code == 0
