@@ -49,6 +49,7 @@ struct Ctl {
   unsigned long long sweeps; // wave sweeps
   unsigned long long items;  // work items (waves of <= 64 plans)
   unsigned long long wakes;
+  uint32_t n_pairs, pad_;    // (tile, block of 64 plans) pairs whose pending flag is set this iteration (k_tb_pairs -> k_tb_scan)
 };
 
 struct Args {
@@ -61,6 +62,7 @@ struct Args {
   const uint2* vaddr; const uint32_t* vert_tile;                      // per vertex: {soff, sl << 8 | local}, tile
   double offset; float band;
   uint8_t* pflag; uint32_t nblk;                                     // per (tile, block of 64 plans): 1 = some pend[tile][plan] of the block may be set
+  uint32_t* pairs; uint32_t n_flag16;                                // the flagged pairs of the iteration (tile * nblk + block); 16-byte units of the flag matrix
 };
 
 __device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_t p)
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_seed(tb::Args A)
 __global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
 {
   const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p == 0) { A.ctl->n_cand[par ^ 1] = 0u; A.ctl->next_item = 0u; A.ctl->iters += 1u; }
+  if (p == 0) { A.ctl->n_cand[par ^ 1] = 0u; A.ctl->next_item = 0u; A.ctl->n_items = 0u; A.ctl->n_pairs = 0u; A.ctl->iters += 1u; }
   if (p >= A.NP) return;
   const uint32_t mb = A.marr[par][p];
   A.marr[par ^ 1][p] = kTbInfBits;
@@ -132,98 +134,100 @@ __global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
   A.bnd[p] = bound;
 }
 
-// The pending values pend[tile][plan] (+inf: none), all of them, once per iteration: an entry below its plan's band threshold
-// is READY (cleared, the plan goes into the tile's bucket), one beyond the goal bound is dropped (it can never propagate any
-// more: the bound only shrinks), the rest is CARRIED (counted, and its smallest value per plan is next iteration's band
-// start).  Dense on purpose: the matrix is 4 B x tiles x plans (265 MB for 7168 plans on the 1M mesh, ~65 us at HBM speed),
-// which is less than walking lists of pending pairs cost (random 4-byte reads, an atomic per ready pair and per list append:
-// 165 us).  A thread owns one plan and walks a range of tiles (coalesced along the plans): threshold, bound and the running
-// minimum stay in registers; a wave that finds ready plans for a tile takes its bucket slots with ONE atomic, whose answer is
-// picked up an iteration of the loop later.
-#ifndef MNAV_TB_SCAN_TILES
-#define MNAV_TB_SCAN_TILES 16          // measured on C2: 4 -> 217, 8 -> 200, 16 -> 191, 64 -> 193, 128 -> 197, 512 -> 251 ms per 5120-plan engine run
-#endif
-constexpr uint32_t kTbScanTiles = MNAV_TB_SCAN_TILES;   // tiles per workgroup of k_tb_scan
+// The pending values pend[tile][plan] (+inf: none) once per iteration: an entry below its plan's band threshold is READY (cleared,
+// the plan goes into the tile's bucket), one beyond the goal bound is dropped (it can never propagate any more: the bound only
+// shrinks), the rest is CARRIED (counted, and its smallest value per plan is next iteration's band start).  The matrix is sparse --
+// a plan's pending tiles are the ring around its front --: one byte per (tile, block of 64 plans), set by whoever writes a pending
+// value, says whether a 256-byte row of it may hold anything.  Rounds 3-4 walked ALL rows (a thread per plan down a column of 16
+// tiles, skipping rows by their flag): 92 600 tiles x 64 blocks of flags per iteration on the 10M mesh, 21 % of the engine run
+// (profiles/r05_c4_kernel_stats.md).  Now k_tb_pairs compacts the set flags into a list (the 5.9 MB flag matrix read as 16-byte
+// units: microseconds) and k_tb_scan gives one wave to each listed row.
+__global__ __launch_bounds__(kBlock) void k_tb_pairs(tb::Args A)
+{
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  u32x4 f = { 0u, 0u, 0u, 0u };
+  if (i < A.n_flag16) f = ((MNAV_GLOBAL const u32x4*)as_global(A.pflag))[i];
+  const uint32_t w[4] = { f.x, f.y, f.z, f.w };
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) c += ((w[k] >> (8 * b)) & 0xFFu) ? 1u : 0u;
+  uint32_t incl = c;                                                 // inclusive scan over the wave, one atomic per wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+  const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+  uint32_t base = 0;
+  if (lane == 63 && tot) base = atomicAdd(&A.ctl->n_pairs, tot);
+  base = (uint32_t)__shfl((int)base, 63) + incl - c;
+  if (c) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if ((w[k] >> (8 * b)) & 0xFFu) A.pairs[base++] = 16u * i + 4u * k + b;
+  }
+}
+
+constexpr uint32_t kTbScanWaves = 8192;                              // persistent waves of k_tb_scan (a row of the list after the other)
 __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
 {
-  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const bool live = p < A.NP;
-  const uint32_t pc = live ? p : A.NP - 1u;
-  const float thr = A.thr[pc], bnd = A.bnd[pc];
-  const uint32_t t0 = blockIdx.y * kTbScanTiles, t1 = min(t0 + kTbScanTiles, A.ntiles);
-  MNAV_GLOBAL uint32_t* pend = as_global(A.pend) + pc;
-  uint32_t mn = kTbInfBits, carried = 0;
-  // one tile behind: the bucket slots asked for in the previous loop iteration
-  uint32_t base_prev = 0, t_prev = 0; unsigned long long m_prev = 0ull;
-  auto place = [&]() {
-    if (m_prev) {
-      const uint32_t base = tb::rfl(base_prev);
-      if ((m_prev >> lane) & 1ull) A.bucket[(size_t)t_prev * A.NP + base + (uint32_t)__popcll(m_prev & ((1ull << lane) - 1ull))] = (uint16_t)p;
-    }
-  };
-  // the matrix is sparse (a plan's pending tiles are the ring around its front): a byte per (tile, 64 plans), set by whoever
-  // writes a pending value and cleared here when nothing of the block is carried over, lets a wave skip the 256-byte rows that
-  // hold nothing -- most of them (the plans of a block have neighbouring wave sources, hence similar rings)
-  MNAV_GLOBAL uint8_t* const pf = as_global(A.pflag) + (pc >> 6);
-  for (uint32_t t = t0; t < t1; ++t) {
-    bool ready = false;
-    if (tb::rfl((uint32_t)pf[(size_t)t * A.nblk])) {                  // (wave-uniform: a wave is one block of plans)
-      const uint32_t pb = live ? pend[(size_t)t * A.NP] : kTbInfBits;
-      const float pv = u2f(pb);
-      bool keep = false;
-      if (pb != kTbInfBits) {
-        if (pv > bnd) pend[(size_t)t * A.NP] = kTbInfBits;
-        else if (pv < thr) { pend[(size_t)t * A.NP] = kTbInfBits; ready = true; }
-        else { ++carried; mn = min(mn, pb); keep = true; }
+  const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kBlock / 64);
+  const uint32_t n_pairs = A.ctl->n_pairs;
+  uint32_t carried = 0;
+  for (uint32_t k = wave; k < n_pairs; k += nwaves) {
+    const uint32_t pr = A.pairs[k], t = pr / A.nblk, blk = pr - t * A.nblk;
+    if (t >= A.ntiles) continue;                                     // (padding bytes of the flag matrix are never set)
+    const uint32_t p = blk * 64u + (uint32_t)lane;
+    const bool live = p < A.NP;
+    MNAV_GLOBAL uint32_t* const pe = as_global(A.pend) + ((size_t)t * A.NP + (live ? p : 0u));
+    const uint32_t pb = live ? *pe : kTbInfBits;
+    bool ready = false, keep = false;
+    if (pb != kTbInfBits) {
+      const float pv = u2f(pb), thr = A.thr[p], bnd = A.bnd[p];
+      if (pv > bnd) *pe = kTbInfBits;
+      else if (pv < thr) { *pe = kTbInfBits; ready = true; }
+      else {
+        keep = true; ++carried;
+        MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
+        if (pb < *pm) atomicMin((uint32_t*)pm, pb);                    // plain look first (see k_tb_solve_q)
       }
-      if (!__any(keep) && lane == 0 && live) pf[(size_t)t * A.nblk] = 0;   // (lane 0 is live in every wave that holds plans)
     }
+    if (!__any(keep) && lane == 0) A.pflag[pr] = 0;
     const unsigned long long m = __ballot(ready);
-    place();
-    m_prev = m; t_prev = t;
-    if (m && lane == 0) base_prev = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));
-  }
-  place();
-  if (live && mn != kTbInfBits) {
-    MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
-    if (mn < *pm) atomicMin((uint32_t*)pm, mn);                        // plain look first (see k_tb_solve_q)
+    if (m) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));
+      base = tb::rfl(base);
+      if (ready) A.bucket[(size_t)t * A.NP + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
+    }
   }
   carried = wave_sum(carried);
   if (lane == 0 && carried) atomicAdd(&A.ctl->n_cand[par ^ 1], carried);
 }
 
 constexpr uint32_t kTbItemPlans = 16;     // plans per work item = lanes per quarter of a wave (k_tb_solve_q)
-// per tile: cut the bucket into items of <= kTbItemPlans plans (one workgroup, a few dozen tiles per thread)
-__global__ __launch_bounds__(1024) void k_tb_items(tb::Args A)
+// per tile: cut the bucket into items of <= kTbItemPlans plans.  One thread per tile, one atomic per wave for the item slots (the
+// items of a tile stay adjacent; their order among the tiles is whatever the atomics make it -- the fixed point does not care).
+// Rounds 3-4 ran ONE workgroup over all tiles for a deterministic order: 122 us per iteration at 92 600 tiles, 8 % of the C4 run.
+__global__ __launch_bounds__(kBlock) void k_tb_items(tb::Args A)
 {
-  __shared__ uint32_t s_base;
-  __shared__ uint32_t s_wsum[16];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   constexpr uint32_t gran = kTbItemPlans;
-  if (tid == 0) s_base = 0u;
-  __syncthreads();
-  for (uint32_t t0 = 0; t0 < A.ntiles; t0 += 1024) {
-    const uint32_t t = t0 + tid;
-    uint32_t c = 0;
-    if (t < A.ntiles) { c = A.bcnt[t]; if (c) A.bcnt[t] = 0u; }
-    const uint32_t k = (c + gran - 1u) / gran;
-    uint32_t incl = k;                                               // inclusive scan over the wave, then over the 16 waves
+  uint32_t c = 0;
+  if (t < A.ntiles) { c = A.bcnt[t]; if (c) A.bcnt[t] = 0u; }
+  const uint32_t k = (c + gran - 1u) / gran;
+  uint32_t incl = k;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
-    if (lane == 63) s_wsum[wid] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_wsum[w];
-    uint32_t tot = 0;
-    for (int w = 0; w < 16; ++w) tot += s_wsum[w];
-    const uint32_t base = s_base + woff + incl - k;
-    for (uint32_t q = 0; q < k; ++q) A.items[base + q] = make_uint2(t, (q * gran) | (min(gran, c - q * gran) << 16));
-    __syncthreads();
-    if (tid == 0) s_base += tot;
-    __syncthreads();
-  }
-  if (tid == 0) A.ctl->n_items = s_base;
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+  const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
+  uint32_t base = 0;
+  if (lane == 63 && tot) base = atomicAdd(&A.ctl->n_items, tot);
+  base = (uint32_t)__shfl((int)base, 63) + incl - k;
+  for (uint32_t q = 0; q < k; ++q) A.items[base + q] = make_uint2(t, (q * gran) | (min(gran, c - q * gran) << 16));
 }
 
 // One block of a Gauss-Seidel sweep: the target row is relaxed from up to 7 source rows (dijkstra :331).  No branch: the row is
@@ -792,7 +796,7 @@ struct TbState {
   uint32_t* d_ghost_gid = nullptr; GoalCut* d_gcs = nullptr; size_t fin_n = 0, fin_novf = 0; bool fin_w_valid = false; uint32_t max_sl = 0;
   // batch state, sized for cap_np plans
   uint32_t cap_np = 0;
-  float* D = nullptr; uint32_t* pend = nullptr; uint8_t* pflag = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;
+  float* D = nullptr; uint32_t* pend = nullptr; uint8_t* pflag = nullptr; uint32_t* pairs = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;
   tb::Ctl* ctl = nullptr; tb::Ctl* h_ctl = nullptr;
   uint32_t* marr[2] = { nullptr, nullptr };
   float *thr = nullptr, *bnd = nullptr; uint32_t *seed = nullptr, *target = nullptr;

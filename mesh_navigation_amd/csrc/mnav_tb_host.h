@@ -5,7 +5,7 @@
 void tb_free_batch(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
-  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
+  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.pairs); S.pairs = nullptr; (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
   (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
   (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target); (void)hipFree(S.d_gcs); S.d_gcs = nullptr;
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
@@ -117,6 +117,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   }
   HIPCHK(hipMalloc((void**)&S.pend, 4 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.pflag, nt * (((size_t)np + 63) / 64) + 64));
+  HIPCHK(hipMalloc((void**)&S.pairs, 4 * (nt * (((size_t)np + 63) / 64) + 64)));   // worst case: every (tile, block) flagged
   HIPCHK(hipMalloc((void**)&S.bucket, 2 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.bcnt, 4 * nt));
   HIPCHK(hipMalloc((void**)&S.items, 8 * (nt + pairs / kTbItemPlans + 64)));
@@ -148,8 +149,9 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
   for (int j = 0; j < count; ++j) {
     const int par = j & 1;
     hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
-    hipLaunchKernelGGL(k_tb_scan, dim3(gp, (A.ntiles + kTbScanTiles - 1) / kTbScanTiles), dim3(kBlock), 0, ctx->stream, A, par);
-    hipLaunchKernelGGL(k_tb_items, dim3(1), dim3(1024), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_tb_pairs, dim3((A.n_flag16 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_tb_scan, dim3(kTbScanWaves / (kBlock / 64)), dim3(kBlock), 0, ctx->stream, A, par);
+    hipLaunchKernelGGL(k_tb_items, dim3((A.ntiles + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
     if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
@@ -222,6 +224,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   tb::Args A{};
   A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.pflag = S.pflag; A.nblk = (n + 63u) / 64u; A.NP = n; A.ntiles = S.ntiles;
   A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl;
+  A.pairs = S.pairs; A.n_flag16 = (uint32_t)(((size_t)S.ntiles * A.nblk + 15u) / 16u);
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
   A.offset = offset;
@@ -241,7 +244,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   S.d2_clean = false;
   if (!prefilled && tb_fill(ctx, S.D, 4 * (size_t)S.S * n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.pend, 4 * (size_t)S.ntiles * n, kTbInfBits)) return -1;
-  HIPCHK(hipMemsetAsync(S.pflag, 0, (size_t)(S.ntiles ? S.ntiles : 1) * ((n + 63u) / 64u), ctx->stream));
+  HIPCHK(hipMemsetAsync(S.pflag, 0, (size_t)(S.ntiles ? S.ntiles : 1) * ((n + 63u) / 64u) + 64u, ctx->stream));   // (+ the padding k_tb_pairs reads as 16-byte units)
   if (tb_fill(ctx, S.marr[0], 4 * (size_t)n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.marr[1], 4 * (size_t)n, kTbInfBits)) return -1;
   HIPCHK(hipMemsetAsync(S.ctl, 0, sizeof(tb::Ctl), ctx->stream));
