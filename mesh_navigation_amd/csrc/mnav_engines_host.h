@@ -393,7 +393,9 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
     T.max_rounds = 0x7FFFFFF0u;
     T.cancel = ctx->d_cancel;
-    T.band = (float)((opt_set(ctx->opt.async_band_mult) ? ctx->opt.async_band_mult : 4.0) * ctx->tile_band_auto);   // band of the plan (<= 0: one band, every solve runs to its tile's fixed point)
+    // band of the plan in tile widths (<= 0: one band, every solve runs to its tile's fixed point); measured round 5, ms per call at
+    // 1 / 8 / 47 / 64 plans on the 1M mesh: 2 widths 7.1 / 11.1 / 20.8 / 25.4, 3: 6.9 / 10.8 / 21.9 / 26.8, 4: 6.8 / 9.9 / 23.2 / 27.7, 6: 7.2 / 10.3 / 25.7 / 31.8, 8: 7.1 / 10.6 / 28.2 / 34.8
+    T.band = (float)((opt_set(ctx->opt.async_band_mult) ? ctx->opt.async_band_mult : (n >= 32u ? 2.0 : 4.0)) * ctx->tile_band_auto);
     T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
   }
   AsyncCtl* const actl = reinterpret_cast<AsyncCtl*>(ctx->d_cancel + 4);   // words 4..11 of the 64-byte control line (word 0: mnav_cancel)

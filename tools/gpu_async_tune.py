@@ -23,7 +23,7 @@ def main():
     out = dict(grid=N, V=int(mesh.V))
     ref_paths = None
     variants = [("tiled", {}), ("async", {}), ("async_wg512", dict(async_wg_per_plan=512)), ("async_band2", dict(async_band_mult=2.0)),
-                ("async_band8", dict(async_band_mult=8.0)), ("async_band16_wg512", dict(async_band_mult=16.0, async_wg_per_plan=512))]
+                ("async_band8", dict(async_band_mult=8.0)), ("async_band3", dict(async_band_mult=3.0)), ("async_band6", dict(async_band_mult=6.0))]
     if len(sys.argv) > 3:
         variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
     for label, opts in variants:
