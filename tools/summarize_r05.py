@@ -17,7 +17,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "c4"
 tag = sys.argv[2] if len(sys.argv) > 2 else {"c4": "c4", "c2sq": "c2", "c2": "bench"}[what]
 G = os.path.join(ROOT, "gpurun_out", "prof_r05", what)
 P = os.path.join(ROOT, "profiles")
-ENGINE = ("k_tb_plan", "k_tb_scan", "k_tb_items", "k_tb_solve_q")
+ENGINE = ("k_tb_plan", "k_tb_pairs", "k_tb_scan", "k_tb_items", "k_tb_solve_q")
 CLK_GHZ = 2.4          # MI355X peak engine clock (MI355X_MICROARCH.md); the SQ counters below are ratios, the clock only scales the "busy" lines
 N_CU, N_SIMD, N_SE = 256, 1024, 32
 
@@ -99,7 +99,7 @@ if what in ("c4", "c2"):
         "kernel": "k_tb_solve_q", "engine_kernels": list(ENGINE),
         "batch": (line.get("config") or {}).get("batch_per_gpu", line.get("batch")), "grid": 1000 if what == "c2" else 3163,
         "fetch_bytes_per_engine_run_raw": f_b, "write_bytes_per_engine_run_raw": w_b,
-        "note": "FETCH_SIZE / WRITE_SIZE (KB) summed over every launch of the engine's four kernels, per batch.  gfx950: FETCH_SIZE reports 1/2 of the "
+        "note": "FETCH_SIZE / WRITE_SIZE (KB) summed over every launch of the engine's five kernels, per batch.  gfx950: FETCH_SIZE reports 1/2 of the "
                 "bytes of wide (16 B/lane) reads (MI355X_MICROARCH.md, HBM section); the engine's slice loads are 16-byte per-lane loads, its "
                 "stream loads too: traffic = raw fetch + write is a lower bound, traffic_high = 2 x fetch + write an upper bound.",
         "traffic_bytes_per_launch": f_b + w_b, "traffic_bytes_per_launch_high": 2 * f_b + w_b, "algorithmic_bytes_per_launch": algo,
@@ -123,7 +123,7 @@ if what in ("c4", "c2"):
             f.write(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
                     f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |\n")
         f.write("\nLine printed by the profiled run:\n```json\n" + json.dumps(line) + "\n```\n\n")
-        f.write(f"Agreement check: rocprofv3 total of the engine's four kernels per batch = **{eng_ms:.1f} ms**; HIP events on the library's stream around the "
+        f.write(f"Agreement check: rocprofv3 total of the engine's five kernels per batch = **{eng_ms:.1f} ms**; HIP events on the library's stream around the "
                 f"engine run in the same process (`roofline.avg_launch_us`) = **{ev_ms:.1f} ms**.\n\n")
         f.write("## HBM traffic (PMC, separate passes)\n\n```json\n" + json.dumps(traffic, indent=1) + "\n```\n")
         if sq:
