@@ -3,6 +3,8 @@
 // reference each block stands in for.
 #include <mesh_gpu_planners/gpu_mesh_planners.h>
 
+#include <mnav_planner_host.hpp>
+
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -259,13 +261,11 @@ uint32_t GpuDijkstraMeshPlanner::plan(const mesh_map::Vector& wave_seed, const m
   path.clear();
   std::string err;
   if (!dev_->syncCosts(*mesh_map_, err, reload_costs_.exchange(false))) { RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err); return Result::INTERNAL_ERROR; }
-  const uint32_t V = dev_->numVertices();
-  std::vector<uint32_t> ids(V ? V : 1);
-  uint32_t n = 0;
-  const uint32_t code = mnav_plan_dijkstra(dev_->ctx(), seed_opt.unwrap().idx(), target_opt.unwrap().idx(), config_.goal_dist_offset,
-                                           config_.cost_limit, nullptr, nullptr, ids.data(), V, &n, nullptr);
+  std::vector<uint32_t> ids;
+  const uint32_t code = mnav_host::dijkstra_vertex_path(dev_->ctx(), seed_opt.unwrap().idx(), target_opt.unwrap().idx(), config_.goal_dist_offset,
+                                                       config_.cost_limit, dev_->numVertices(), ids);
   if (code != Result::SUCCESS) return code;
-  for (uint32_t i = 0; i < n; ++i) path.push_back(lvr2::VertexHandle(ids[i]));
+  for (const uint32_t id : ids) path.push_back(lvr2::VertexHandle(id));
   // computeVectorMap ends with mesh_map_->setVectorMap(vector_map_) (:208): the controller copies the map's field in
   // setPlan (mesh_controller.cpp:182), so a drop-in has to leave it there after every successful plan.  16 bytes per
   // vertex cross PCIe for it; a deployment whose controller samples the resident field instead (mnav_vector_at) turns
@@ -312,26 +312,18 @@ uint32_t GpuDijkstraMeshPlanner::makePlan(const PoseStamped& start, const PoseSt
   std_msgs::msg::Header header;
   header.stamp = node_->now();
   header.frame_id = mesh_map_->mapFrame();
-  cost = 0;
-  if (!path.empty()) {                                             // one pose per path vertex, looking at the next one (:90-116)
+  {                                                                // one pose per path vertex, looking at the next one (:89-116)
     const auto mesh = mesh_map_->mesh();
     const auto& normals = mesh_map_->vertexNormals();
-    mesh_map::Vector here = robot;
-    mesh_map::Normal up = normals[path.front()];
-    float step = 0.f;
-    PoseStamped pose;
-    pose.header = header;
-    for (const lvr2::VertexHandle vH : path) {
-      const mesh_map::Vector next = mesh->getVertexPosition(vH);
-      pose.pose = mesh_map::calculatePoseFromPosition(here, next, up, step);
-      cost += step;
-      here = next;
-      up = normals[vH];
-      plan_out.push_back(pose);
-    }
-    pose.pose = mesh_map::calculatePoseFromPosition(here, target, up, step);
-    cost += step;
-    plan_out.push_back(pose);
+    PoseStamped stamped;
+    stamped.header = header;
+    mnav_host::vertex_path_poses(path, robot, target, stamped,
+                                 [&](lvr2::VertexHandle vH) -> mesh_map::Vector { return mesh->getVertexPosition(vH); },
+                                 [&](lvr2::VertexHandle vH) -> mesh_map::Normal { return normals[vH]; },
+                                 [](const mesh_map::Vector& from, const mesh_map::Vector& to, const mesh_map::Normal& up, float& len) {
+                                   return mesh_map::calculatePoseFromPosition(from, to, up, len);
+                                 },
+                                 plan_out, cost);
   }
   // :119-131: the path, the potential as a vertex-cost layer, the vector field on request
   nav_msgs::msg::Path path_msg;
@@ -444,15 +436,10 @@ uint32_t GpuCVPMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_m
     // offset from the seed position, :722-724) and for every vertex the wave updated; the device writes zeros elsewhere.
     lvr2::DenseVertexMap<mesh_map::Vector>& field = vector_map_;
     field.clear();
-    const auto mesh = mesh_map_->mesh();
-    for (uint32_t v = 0; v < V; ++v) {
-      const float* q = &vm[3 * (size_t)v];
-      if (q[0] != 0.f || q[1] != 0.f || q[2] != 0.f) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(q[0], q[1], q[2]));
-    }
-    for (const auto vH : mesh->getVerticesOfFace(seed_face)) {
-      const float* q = &vm[3 * (size_t)vH.idx()];
-      field.insert(vH, mesh_map::Vector(q[0], q[1], q[2]));
-    }
+    const auto seed_vertices = mesh_map_->mesh()->getVerticesOfFace(seed_face);
+    const uint32_t seeds[3] = { seed_vertices[0].idx(), seed_vertices[1].idx(), seed_vertices[2].idx() };
+    for (uint32_t v = 0; v < V; ++v)
+      if (mnav_host::cvp_field_is_set(vm.data(), v, seeds)) field.insert(lvr2::VertexHandle(v), mesh_map::Vector(vm[3 * (size_t)v], vm[3 * (size_t)v + 1], vm[3 * (size_t)v + 2]));
     mesh_map_->setVectorMap(field);
   }
   if (code == Result::NO_PATH_FOUND) { message = "Predecessor of the goal is not set! No path found!"; return code; }   // :912-918
@@ -476,24 +463,13 @@ uint32_t GpuCVPMeshPlanner::plan(const mesh_map::Vector& wave_seed, const mesh_m
     if (cancel_planning_) return Result::CANCELED;
     return Result::SUCCESS;
   }
-  lvr2::FaceHandle face = target_face;                                                             // :920-951
-  mesh_map::Vector pos = target;
-  path.push_front(std::make_pair(pos, face));
-  while (pos.distance2(seed) > config_.step_width && !cancel_planning_) {                          // (squared distance against the width, as is)
-    try {
-      if (!mesh_map_->meshAhead(pos, face, config_.step_width)) {
-        message = "Could not find a valid path, while back-tracking from the goal";
-        return Result::NO_PATH_FOUND;
-      }
-      path.push_front(std::make_pair(pos, face));
-    } catch (lvr2::PanicException&) {
-      message = "Could not find a valid path, while back-tracking from the goal: HalfEdgeMesh panicked!";
-      return Result::NO_PATH_FOUND;
-    }
-  }
-  path.push_front(std::make_pair(seed, seed_face));
-  if (cancel_planning_) return Result::CANCELED;
-  return Result::SUCCESS;
+  // :920-966 on the host: the map's own meshAhead over the field just handed to it
+  return mnav_host::backtrack_on_host(seed, seed_face, target, target_face, config_.step_width, [&] { return cancel_planning_.load(); },
+                                      [&](mesh_map::Vector& pos, lvr2::FaceHandle& face, double width) {
+                                        try { return mesh_map_->meshAhead(pos, face, width) ? 1 : 0; }
+                                        catch (lvr2::PanicException&) { return -1; }
+                                      },
+                                      0, path, message);
 }
 
 uint32_t GpuCVPMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped& goal, double /*tolerance*/,
@@ -515,24 +491,16 @@ uint32_t GpuCVPMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped
   std_msgs::msg::Header header;
   header.stamp = node_->now();
   header.frame_id = mesh_map_->mapFrame();
-  cost = 0;
-  if (!cancel_planning_ && !path.empty()) {                        // :101-124
+  {                                                                // :99-124
     const auto& face_normals = mesh_map_->faceNormals();
-    mesh_map::Vector here = path.front().first;
-    lvr2::FaceHandle face = path.front().second;
-    path.pop_front();
-    float step = 0.f;
-    PoseStamped pose;
-    pose.header = header;
-    for (const auto& next : path) {
-      pose.pose = mesh_map::calculatePoseFromPosition(here, next.first, face_normals[face], step);
-      cost += step;
-      here = next.first;
-      face = next.second;
-      plan_out.push_back(pose);
-    }
-    pose.pose = goal_in_map.pose;                                  // the goal pose itself closes the plan
-    plan_out.push_back(pose);
+    PoseStamped stamped;
+    stamped.header = header;
+    mnav_host::face_path_poses(path, cancel_planning_, goal_in_map.pose, stamped,
+                               [&](lvr2::FaceHandle fH) -> mesh_map::Normal { return face_normals[fH]; },
+                               [](const mesh_map::Vector& from, const mesh_map::Vector& to, const mesh_map::Normal& up, float& len) {
+                                 return mesh_map::calculatePoseFromPosition(from, to, up, len);
+                               },
+                               plan_out, cost);
   }
   // :125-137: the path, the potential as a vertex-cost layer, the vector field on request
   nav_msgs::msg::Path path_msg;

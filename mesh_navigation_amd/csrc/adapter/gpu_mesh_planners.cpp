@@ -1,8 +1,9 @@
 // gpu_mesh_planners.cpp -- see gpu_mesh_planners.h.  Reference line numbers in the comments.
-// Said plainly: the two makePlan bodies below are statement-for-statement re-typings of the reference's
-// (dijkstra_mesh_planner.cpp:55-116, cvp_mesh_planner.cpp:62-124) on flat arrays -- O(path) glue whose job is to be
-// the same steps; the wavefront loops they used to contain are one mnav_plan_* call each.  Do not let this file grow.
+// The host half of makePlan (poses along the path, the vector-field back-tracking, the device call) is
+// include/mnav_planner_host.hpp, shared with the ROS 2 plugin package; this file binds it to the ROS-free host map.
 #include "gpu_mesh_planners.h"
+
+#include "mnav_planner_host.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -76,27 +77,14 @@ uint32_t DijkstraMeshPlanner::makePlan(const PoseStamped& start, const PoseStamp
   std_msgs::msg::Header header;
   header.stamp = node_ ? node_->now() : builtin_interfaces::msg::Time();
   header.frame_id = mesh_map_->mapFrame();                                    // :87
-  cost = 0;                                                                   // :89
-  if (!path.empty()) {                                                        // :90
-    mesh_map::Vector& vec = start_vec;                                        // :92
-    mesh_map::Normal normal = mesh_map_->vertexNormal(path.front());          // :94
-    float dir_length;
-    PoseStamped pose;
-    pose.header = header;
-    while (!path.empty()) {                                                   // :100
-      const uint32_t vH = path.front();
-      const mesh_map::Vector next = mesh_map_->vertex(vH);                    // :104
-      pose.pose = mesh_map::calculatePoseFromPosition(vec, next, normal, dir_length);   // :106
-      cost += dir_length;                                                     // :107
-      vec = next;                                                             // :108
-      normal = mesh_map_->vertexNormal(vH);                                   // :109
-      plan.push_back(pose);
-      path.pop_front();
-    }
-    pose.pose = mesh_map::calculatePoseFromPosition(vec, goal_vec, normal, dir_length);   // :113
-    cost += dir_length;                                                       // :114
-    plan.push_back(pose);
-  }
+  PoseStamped stamped;
+  stamped.header = header;
+  mnav_host::vertex_path_poses(path, start_vec, goal_vec, stamped,           // :89-116
+                               [&](uint32_t vH) { return mesh_map_->vertex(vH); }, [&](uint32_t vH) { return mesh_map_->vertexNormal(vH); },
+                               [](const mesh_map::Vector& from, const mesh_map::Vector& to, const mesh_map::Normal& up, float& len) {
+                                 return mesh_map::calculatePoseFromPosition(from, to, up, len);
+                               },
+                               plan, cost);
   // :118-131 publishing (path, "Potential" vertex costs, vector field) is ROS I/O and out of scope here
   return outcome;
 }
@@ -138,17 +126,15 @@ uint32_t DijkstraMeshPlanner::dijkstra(const mesh_map::Vector& original_start, c
   path.clear();
   std::string err;
   if (!dev_ || !dev_->sync(*mesh_map_, err)) return Result::INTERNAL_ERROR;
-  const uint32_t V = mesh_map_->V;
   fields_on_host_ = false;
-  std::vector<uint32_t> p(V ? V : 1);
-  uint32_t n = 0;
   // potential, predecessors and the vector map (computeVectorMap :380) are computed and kept on the device; only
   // the vertex path comes back.  They are fetched when somebody reads them (potential(), the controller's
   // MeshMap::getVectorMap, publishing) -- fetchFields().
-  const uint32_t code = mnav_plan_dijkstra(dev_->ctx(), start_vertex, goal_vertex, config_.goal_dist_offset, config_.cost_limit,
-                                           nullptr, nullptr, p.data(), V, &n, nullptr);
+  std::vector<uint32_t> ids;
+  const uint32_t code = mnav_host::dijkstra_vertex_path(dev_->ctx(), start_vertex, goal_vertex, config_.goal_dist_offset, config_.cost_limit,
+                                                       mesh_map_->V, ids);
   if (code != Result::SUCCESS) return code;
-  for (uint32_t i = 0; i < n; ++i) path.push_back(p[i]);                      // :367-373 list order: seed first
+  path.assign(ids.begin(), ids.end());                                        // :367-373 list order: seed first
   if (config_.publish_vector_field || eager_fields_) fetchFields();          // :126-129
   return Result::SUCCESS;
 }
@@ -185,26 +171,14 @@ uint32_t CVPMeshPlanner::makePlan(const PoseStamped& start, const PoseStamped& g
   std_msgs::msg::Header header;
   header.stamp = node_ ? node_->now() : builtin_interfaces::msg::Time();
   header.frame_id = mesh_map_->mapFrame();
-  cost = 0;                                                                   // :99
-  float dir_length;
-  if (!cancel_planning_ && !path.empty()) {                                   // :101
-    mesh_map::Vector vec = path.front().first;                                // :103
-    uint32_t fH = path.front().second;                                        // :104
-    path.pop_front();
-    for (auto& next : path) {                                                 // :108
-      PoseStamped pose;
-      pose.header = header;
-      pose.pose = mesh_map::calculatePoseFromPosition(vec, next.first, mesh_map_->faceNormal(fH), dir_length);   // :112
-      cost += dir_length;
-      vec = next.first;
-      fH = next.second;
-      plan.push_back(pose);
-    }
-    PoseStamped pose;                                                         // :119-123 goal pose verbatim
-    pose.header = header;
-    pose.pose = goal_in_map.pose;
-    plan.push_back(pose);
-  }
+  PoseStamped stamped;
+  stamped.header = header;
+  mnav_host::face_path_poses(path, cancel_planning_, goal_in_map.pose, stamped,   // :99-124
+                             [&](uint32_t fH) { return mesh_map_->faceNormal(fH); },
+                             [](const mesh_map::Vector& from, const mesh_map::Vector& to, const mesh_map::Normal& up, float& len) {
+                               return mesh_map::calculatePoseFromPosition(from, to, up, len);
+                             },
+                             plan, cost);
   return outcome;
 }
 
@@ -261,36 +235,18 @@ uint32_t CVPMeshPlanner::waveFrontPropagation(const mesh_map::Vector& original_s
   // MeshMap::setVectorMap (:238): seeds hold their raw offset vector (:722-724), updated vertices the rotated direction;
   // everything else is the all-zero entry the device writes for "no value"
   std::vector<uint8_t> set(V, 0);
-  for (uint32_t v = 0; v < V; ++v) {
-    const float* q = &vector_map_[3 * (size_t)v];
-    set[v] = !(q[0] == 0.f && q[1] == 0.f && q[2] == 0.f);
-  }
-  for (int k = 0; k < 3; ++k) set[mesh_map_->faces[3 * (size_t)start_face + k]] = 1;
+  const uint32_t* seeds = &mesh_map_->faces[3 * (size_t)start_face];
+  for (uint32_t v = 0; v < V; ++v) set[v] = mnav_host::cvp_field_is_set(vector_map_.data(), v, seeds);
   mesh_map_->setVectorMap(vector_map_, set);
   if (config_.publish_vector_field || eager_fields_) fetchFields();
   if (code == Result::NO_PATH_FOUND) { message = "Predecessor of the goal is not set! No path found!"; return code; }   // :912-918
-  // vector field back-tracking :920-951 (sequential, ~path_length / step_width iterations, host)
-  uint32_t current_face = goal_face;
-  mesh_map::Vector current_pos = goal;
-  path.push_front(std::make_pair(current_pos, current_face));                 // :924
-  size_t guard = 0;
-  while (current_pos.distance2(start) > config_.step_width && !cancel_planning_) {   // :927 (squared distance vs width, as is)
-    try {
-      if (mesh_map_->meshAhead(current_pos, current_face, (float)config_.step_width)) {   // :933
-        path.push_front(std::make_pair(current_pos, current_face));           // :935
-      } else {
-        message = "Could not find a valid path, while back-tracking from the goal";   // :939
-        return Result::NO_PATH_FOUND;
-      }
-    } catch (const mesh_map::MeshMap::MapPanic&) {                            // :944-949 lvr2::PanicException
-      message = "Could not find a valid path, while back-tracking from the goal: HalfEdgeMesh panicked!";
-      return Result::NO_PATH_FOUND;
-    }
-    if (++guard > 10u * (size_t)V + 1000u) { message = "vector field back-tracking does not terminate"; return Result::NO_PATH_FOUND; }
-  }
-  path.push_front(std::make_pair(start, start_face));                         // :951
-  if (cancel_planning_) return Result::CANCELED;                              // :962-966
-  return Result::SUCCESS;
+  // vector field back-tracking :920-966 (sequential, ~path_length / step_width iterations, host)
+  return mnav_host::backtrack_on_host(start, start_face, goal, goal_face, config_.step_width, [&] { return cancel_planning_.load(); },
+                                      [&](mesh_map::Vector& pos, uint32_t& face, double width) {
+                                        try { return mesh_map_->meshAhead(pos, face, (float)width) ? 1 : 0; }
+                                        catch (const mesh_map::MeshMap::MapPanic&) { return -1; }   // lvr2::PanicException
+                                      },
+                                      10u * (size_t)V + 1000u, path, message);
 }
 
 void CVPMeshPlanner::fetchFields()
