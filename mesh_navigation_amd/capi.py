@@ -292,9 +292,9 @@ class MnavContext:
         self._L.mnav_set_band_width(self._h, float(delta))
 
     def set_dijkstra_engine(self, engine: str):
-        """'auto' (default), 'tiled', 'band', 'persistent' (one workgroup per plan), 'tile_batch' (large batches: one plan per lane)
+        """'auto' (default), 'tiled', 'band', 'tile_batch' (large batches: one plan per lane)
         or 'async' (the tiles without rounds, mnav_async.h: what 'auto' takes for single plans and small batches)."""
-        if self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "persistent": 2, "auto": 3, "tile_batch": 5, "async": 6}[engine]) != 0:
+        if self._L.mnav_set_dijkstra_engine(self._h, {"tiled": 0, "band": 1, "auto": 3, "tile_batch": 5, "async": 6}[engine]) != 0:
             raise ValueError(f"engine {engine!r} refused")
 
     def set_option(self, name: str, value=None):

@@ -167,15 +167,14 @@ struct mnav_ctx {
   float* d_seed_pos = nullptr; uint32_t seed_pos_cap = 1;
   std::map<uint64_t, hipGraphExec_t> graphs;
   // tiled SSSP engine
-  int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 2 persistent per-plan, 3 auto, 5 tile-batch, 6 asynchronous tiles (opt-in)
+  int dij_engine = 3;          // 0 tiled rounds, 1 band steps, 3 auto, 5 tile-batch, 6 asynchronous tiles (2: the per-plan persistent kernel, retired round 5)
   int last_engine = 0;
-  uint32_t persistent_min_batch = 128;
   bool lazy_paths = false;      // this call only wants vertex paths: k_path_lazy instead of k_dij_finalize + k_finish
   bool allow_lazy_paths = true; // MNAV_LAZY_PATHS=0: always finalize (predecessors / tentative values for everybody)
   uint32_t max_steps = 1u << 20;   // per plan; set from the mesh size at upload (a wavefront needs O(diameter) steps)
   double max_wall_s = 120.0;   // host-side guard: a plan that takes longer is abandoned with an error
   uint32_t tile_size = 512;    // 4 workgroups of the tile kernels per CU (36 KB LDS each)
-  float rounds_band_mult = 4.0f;   // the round engine (latency) prefers wider bands than the persistent one
+  float rounds_band_mult = 4.0f;   // the round engine (latency) prefers wide bands
   float tile_band_user = 0.f, tile_band_auto = 1.f;
   uint32_t* d_t_rptr = nullptr;
   HostTiles tiles_meta;        // only the small per-tile vectors are kept (vert_tile, sizes)
@@ -299,8 +298,7 @@ void apply_options(mnav_ctx* ctx)
 {
   const Options& o = ctx->opt;
   ctx->use_graph = !opt_on(o.no_graph);
-  if (opt_set(o.dijkstra_engine)) { const int e = (int)o.dijkstra_engine; ctx->dij_engine = (e == 0 || e == 1 || e == 2 || e == 5 || e == 6) ? e : 3; }
-  ctx->persistent_min_batch = opt_u32(o.persistent_min_batch, 128u);
+  if (opt_set(o.dijkstra_engine)) { const int e = (int)o.dijkstra_engine; ctx->dij_engine = (e == 0 || e == 1 || e == 5 || e == 6) ? e : 3; }
   ctx->max_steps = opt_u32(o.max_steps, ctx->max_steps_auto);
   ctx->max_wall_s = opt_set(o.max_wall_s) ? o.max_wall_s : 120.0;
   ctx->cvp_verify = !opt_set(o.cvp_verify) || o.cvp_verify != 0.0;
@@ -722,9 +720,6 @@ int mnav_upload_mesh(mnav_ctx* ctx, uint32_t V, uint32_t F, uint32_t E, const fl
     if (ctx->tile_lds > 64 * 1024)
       HIPCHK(hipFuncSetAttribute((const void*)k_tile_round, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
     if (ctx->tile_lds > 64 * 1024) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
-      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
-      HIPCHK(hipFuncSetAttribute((const void*)k_plan_persistent<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
       HIPCHK(hipFuncSetAttribute((const void*)k_plan_async<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->tile_lds));
@@ -1269,7 +1264,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   // vertex, i.e. with the squared seed-target distance.  Workgroups are dispatched in plan order, so when a
   // batch holds more plans than the device runs at once the short ones back-fill behind the long ones
   // instead of leaving a tail (results are mapped back through `map`).
-  // engine: 0 = tiled rounds, 1 = band steps, 2 = persistent per-plan, 3 = auto, 5 = tile-batch (plan-vectorised, large batches)
+  // engine: 0 = tiled rounds, 1 = band steps, 3 = auto, 5 = tile-batch (plan-vectorised, large batches), 6 = asynchronous tiles
   int engine = ctx->dij_engine;
   // paths only (nothing V-sized asked for, nothing kept resident): no finalize pass, predecessors along the path only
   ctx->lazy_paths = ctx->allow_lazy_paths && !dist_out && !pred_out && !want_vecmap && !ctx->resident_vecmap;
@@ -1291,7 +1286,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       // where the tile-batch engine's iterations are shared by all plans: the engines cross at about a hundred plans.
       engine = (m0 <= opt_u32(ctx->opt.async_max_batch, 96u)) ? 6 : fills ? 5 : 0;
     }
-    if (engine == 5 && m0 > 65535u) engine = 2;                       // (plan ids are 16 bits in the tile-batch buckets)
+    if (engine == 5 && m0 > 65535u) engine = 0;                       // (plan ids are 16 bits in the tile-batch buckets)
     if (engine == 1 && offset < 0.0) engine = 0;                      // the band steps arm goal_dist inside the loop: tile rounds for a negative offset
   }
   if (engine == 5 && in.size() > 1) {
@@ -1333,7 +1328,6 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     if (materialize(ctx, false, cost_limit)) return MNAV_INTERNAL_ERROR;
     const bool want_path = true;
     int rc = (engine == 0) ? run_dijkstra_tiled(ctx, m, in, offset)
-           : (engine == 2) ? run_dijkstra_persistent(ctx, m, in, offset)
            : (engine == 6) ? run_dijkstra_async(ctx, m, in, offset)
            : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
                            : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
@@ -1656,7 +1650,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta)
 
 int mnav_set_dijkstra_engine(mnav_ctx* ctx, int engine)
 {
-  if (!ctx || engine < 0 || engine > 6 || engine == 4) return -1;   // 4 was the one-wave-per-plan experiment (removed)
+  if (!ctx || engine < 0 || engine > 6 || engine == 2 || engine == 4) return -1;   // 2: one workgroup per plan, 4: one wave per plan (both retired)
   ctx->dij_engine = engine;
   ctx->opt.dijkstra_engine = (double)engine;
   return 0;

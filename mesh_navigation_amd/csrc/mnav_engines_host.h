@@ -1,5 +1,5 @@
 // mnav_engines_host.h -- host drivers of the per-plan engines: the band steps (run_plans: CVP, inflation wave, Dijkstra on request),
-// the tile rounds (run_dijkstra_tiled), the persistent per-plan kernel (run_dijkstra_persistent) and the asynchronous tiles
+// the tile rounds (run_dijkstra_tiled) and the asynchronous tiles
 // (run_dijkstra_async), with the finalize launchers and the per-slot tile state.  Included by mnav.hip inside its anonymous
 // namespace, after mnav_ctx and its helpers; not a stand-alone header.
 #pragma once
@@ -289,75 +289,6 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   return rc;
-}
-
-// Dijkstra batches through the persistent per-plan kernel.  Returns 0, -1 (error) or 1 (cancelled).
-int run_dijkstra_persistent(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
-{
-  if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
-  if (ensure_paths(ctx, n)) return -1;
-  if (ensure_tile_state(ctx, n)) return -1;
-  if (tile_weights(ctx)) return -1;
-  const HostTiles& M = ctx->tiles_meta;
-  std::vector<Plan> hp(n);
-  std::vector<TilePlan> tp(n);
-  std::vector<float*> vecs(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    Slot& s = ctx->slots[i];
-    Plan& P = hp[i];
-    memset(&P, 0, sizeof(P));
-    P.planner = kPlannerDijkstra; P.V = ctx->V;
-    P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
-    P.dist = s.dist; P.tkey = nullptr; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
-    P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-    P.delta = 0.f; P.offset = offset; P.max_steps = ctx->max_steps;
-    for (int k = 0; k < 3; ++k) { P.seed[k] = in[i].seed[k]; P.target[k] = in[i].target[k]; P.seed_d[k] = 0.f; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
-    P.seed_face = kNone;
-    vecs[i] = s.vecmap;
-    TilePlan& T = tp[i];
-    memset(&T, 0, sizeof(T));
-    T.V = ctx->V; T.ntiles = M.ntiles;
-    T.vptr = ctx->d_t_vptr; T.verts = ctx->d_t_verts; T.hptr = ctx->d_t_hptr; T.halo_verts = ctx->d_t_halo_verts;
-    T.halo_tile = ctx->d_t_halo_tile; T.eptr = ctx->d_t_eptr; T.rptr = ctx->d_t_rptr; T.rowptr = ctx->d_t_rowptr; T.col = ctx->d_t_col; T.tw = ctx->d_t_tw;
-    T.dist = s.dist; T.pend[0] = s.tpend0; T.pend[1] = s.tpend1; T.tlast = s.tlast; T.ctl = s.tctl; T.cnt = s.tcnt;
-    T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
-    T.max_rounds = 64u * (M.ntiles ? M.ntiles : 1u) + 1024u;          // activation cap per plan
-    T.cancel = ctx->d_cancel;
-    T.band = ctx->tile_band_user > 0.f ? ctx->tile_band_user : ctx->tile_band_auto;
-    T.max_nv = M.max_nv; T.max_nh = M.max_nh; T.max_ne = M.max_ne;
-  }
-  HIPCHK(hipMemcpyAsync(ctx->d_plans, hp.data(), sizeof(Plan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_tplans, tp.data(), sizeof(TilePlan) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_vecptrs, vecs.data(), sizeof(float*) * n, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_res, 0, sizeof(PlanResult) * n, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
-  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
-  uint32_t gi = (ctx->V + kBlock * 4 - 1) / (kBlock * 4);
-  if (gi < 1) gi = 1;
-  if (gi > 4096) gi = 4096;
-  hipLaunchKernelGGL(k_init<kPlannerDijkstra>, dim3(gi, n), dim3(kBlock), 0, ctx->stream, ctx->d_plans);
-  {
-    uint32_t gt = (M.ntiles + kBlock - 1) / kBlock;
-    if (gt < 1) gt = 1;
-    hipLaunchKernelGGL(k_tile_init, dim3(gt, n), dim3(kBlock), 0, ctx->stream, ctx->d_tplans, ctx->d_vert_tile, -inf_f());
-  }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-  ctx->ms_chunks = 0.0;
-  HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
-  if (ctx->tile_size <= 2 * kTileBlock) hipLaunchKernelGGL(k_plan_persistent<2>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
-  else if (ctx->tile_size <= 4 * kTileBlock) hipLaunchKernelGGL(k_plan_persistent<4>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
-  else hipLaunchKernelGGL(k_plan_persistent<8>, dim3(n), dim3(kTileBlock), ctx->tile_lds, ctx->stream, ctx->d_tplans);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->evc[1], ctx->stream));
-  if (!ctx->lazy_paths) launch_finalize(ctx, n);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->ms_chunks = ev_ms(ctx->evc[0], ctx->evc[1]);
-  ctx->stats.launches = 1;
-  if (ctx->cancel.load(std::memory_order_relaxed)) return 1;        // the kernel left its loops early (status 3): :350-354
-  return 0;
 }
 
 // Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1, 1 (cancelled) or

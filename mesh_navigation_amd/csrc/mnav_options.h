@@ -9,8 +9,7 @@
   X(trace)               /* 1: host-side trace points on stderr */                                                                        \
   X(no_graph)            /* 1: launch the step / round kernels one by one instead of replaying hipGraphs (profilers that cannot see into graphs) */ \
   X(debug_chunk)         /* steps per host look when no_graph is set */                                                                   \
-  X(dijkstra_engine)     /* 0 tile rounds, 1 band steps, 2 one workgroup per plan, 3 auto, 5 tile-batch, 6 asynchronous tiles */          \
-  X(persistent_min_batch)                                                                                                                \
+  X(dijkstra_engine)     /* 0 tile rounds, 1 band steps, 3 auto, 5 tile-batch, 6 asynchronous tiles */                            \
   X(blocks_per_plan)     /* band steps: workgroups per plan */                                                                            \
   X(tile_blocks)         /* tile rounds: workgroups per plan */                                                                           \
   X(cvp_wide)            /* 0 / 1: never / always the wide CVP step kernel (default: batches from 32 plans) */                            \
@@ -61,7 +60,7 @@ struct Options {
       if (!e || !*e) continue;
       double v = atof(e);
       if (!strcmp(t[i].name, "dijkstra_engine")) {
-        v = !strcmp(e, "tiled") ? 0 : !strcmp(e, "band") ? 1 : !strcmp(e, "persistent") ? 2 : !strcmp(e, "tile_batch") ? 5 : !strcmp(e, "async") ? 6
+        v = !strcmp(e, "tiled") ? 0 : !strcmp(e, "band") ? 1 : !strcmp(e, "tile_batch") ? 5 : !strcmp(e, "async") ? 6
           : (e[0] >= '0' && e[0] <= '9') ? atof(e) : 3;
       }
       this->*t[i].field = v;

@@ -1,5 +1,5 @@
 // mnav_tiles.h -- Dijkstra on LDS tiles: the tile plan record, the LDS image and the tile solve (stage_tile_graph, tile_sweeps)
-// and the kernels built on them -- k_tile_round (one launch per round), k_plan_persistent (one workgroup per plan), k_plan_async
+// and the kernels built on them -- k_tile_round (one launch per round), k_plan_async
 // (mnav_async.h, included here) --, k_tile_init, k_tile_weights.  Included by mnav.hip inside its anonymous namespace; not a
 // stand-alone header.
 #pragma once
@@ -38,7 +38,7 @@ struct TilePlan {
   float band;
   uint32_t max_rounds;
   uint32_t max_nv, max_nh, max_ne;
-  const uint32_t* cancel;  // device word set by mnav_cancel (polled by the persistent kernels), may be null
+  const uint32_t* cancel;  // device word set by mnav_cancel (polled by k_plan_async), may be null
   uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
   uint32_t* parked;        // asynchronous engine (mnav_async.h): the two parked lists of the plan, 2 x kParkedLists x ntiles tile ids
   const uint8_t* owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
@@ -46,26 +46,13 @@ struct TilePlan {
 };
 
 constexpr int kTileBlock = 256;
-#ifndef MNAV_PERSIST_WG_PER_CU
-#define MNAV_PERSIST_WG_PER_CU 6        // register budget of k_plan_persistent: 6 workgroups (24 waves) per CU -> <= 80 VGPRs
-#endif
-// Tiles solved per best-first scan of k_plan_persistent (<= kTileBlock / 64) and how far behind the best one a further
-// candidate may lie, in bands.  Measured on C2 (5120 plans, ms per launch): 1 -> 408.5; 2 within one band -> 398.4;
-// 4 within one band -> 453.7 (the order matters more than the scans cost); 4 within 0.1 / 0.25 / 0.5 bands -> 405.6 /
-// 408.5 / 413.0; 2 within 0.5 -> 402.6.
-#ifndef MNAV_SCAN_SLACK
-#define MNAV_SCAN_SLACK 1.0f
-#endif
-#ifndef MNAV_SCAN_CANDS
-#define MNAV_SCAN_CANDS 2
-#endif
 constexpr int kTileVpt = 8;              // owned vertices per thread: tile_size <= 2048
 constexpr int kTileTodo = 64;            // tiles one workgroup takes per round
 constexpr uint32_t kInfBits = 0x7f800000u;
 
 __host__ __device__ inline uint32_t pad_to(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
 
-// LDS image of one tile (dynamic shared memory), shared by k_tile_round and k_plan_persistent
+// LDS image of one tile (dynamic shared memory), shared by k_tile_round and k_plan_async
 struct TileLds {
   float* lw;        // push weights                      4 B x ne
   uint16_t* lcol;   // push targets (local ids)          2 B x ne
@@ -356,194 +343,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_round(const TilePlan* __res
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Persistent per-plan variant (batches): ONE workgroup owns a plan from seed to convergence and
-// walks its tiles best-first -- always the tile with the smallest wake-up value, with the band
-// [m, m + band) -- without any launch or grid-wide round in between.  Independent plans never
-// talk to each other, so there is no inter-workgroup protocol at all; hundreds of plans run
-// concurrently (2 workgroups per CU).  Same tile solve as k_tile_round (LDS queue sweeps, ds_min
-// on float bits); state that the workgroup re-reads after writing it (dist, wake-ups, tlast) is
-// read with L1-bypassing (non-temporal) loads, i.e. served by the L2 and never by a stale L1 line.
-// ---------------------------------------------------------------------------------------------
-// Non-temporal loads bypass the per-CU L1 (served by the L2) like agent-scope atomic loads do, but
-// unlike those they are ordinary loads: many stay in flight, one wait at the first use.  Stores are
-// write-through to the L2 anyway; everything this workgroup re-reads is read through these.
-__device__ __forceinline__ uint32_t ldg_u32(MNAV_GLOBAL const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ float ldg_f32(MNAV_GLOBAL const float* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void stg_u32(MNAV_GLOBAL uint32_t* p, uint32_t v) { *p = v; }
-__device__ __forceinline__ void stg_f32(MNAV_GLOBAL float* p, float v) { *p = v; }
-
-template <int VPT>   // owned vertices per thread: tile_size <= VPT * 256
-__global__ __launch_bounds__(kTileBlock, MNAV_PERSIST_WG_PER_CU) void k_plan_persistent(const TilePlan* __restrict__ plans)
-{
-  const TilePlan& P = plans[blockIdx.x];
-  const int tid = threadIdx.x;
-  __shared__ unsigned long long s_best[kTileBlock / 64];
-  __shared__ uint32_t s_hdr[8];
-  __shared__ uint32_t s_nq[3];
-  __shared__ float s_bound;
-  __shared__ uint32_t s_stop;
-  if (tid == 0) s_stop = 0u;
-  MNAV_GLOBAL uint32_t* pend = as_global(P.pend[0]);
-  MNAV_GLOBAL const uint32_t* g_vptr = as_global(P.vptr);
-  MNAV_GLOBAL const uint32_t* g_hptr = as_global(P.hptr);
-  MNAV_GLOBAL const uint32_t* g_eptr = as_global(P.eptr);
-  MNAV_GLOBAL const uint32_t* g_rptr = as_global(P.rptr);
-  MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
-  MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
-  MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
-  MNAV_GLOBAL float* g_dist = as_global(P.dist);
-  MNAV_GLOBAL float* g_tlast = as_global(P.tlast);
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileLds L = tile_lds_layout(smem, P.max_nv, P.max_nh, P.max_ne);
-  uint32_t* const ldu = L.ldu; uint32_t* const lh0 = L.lh0; uint16_t* const q0 = L.q0;
-
-  uint32_t acts = 0, sweeps_total = 0;
-  uint32_t status = 0;   // 0 converged, 2 activation cap hit
-#ifdef MNAV_TILE_TIMING
-  unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#define PT_STAMP(k) do { if (tid == 0 && blockIdx.x == 0) tt[k] = clock64(); } while (0)
-#else
-#define PT_STAMP(k) do { } while (0)
-#endif
-  for (;;) {
-    PT_STAMP(0);
-    // best-first: the tile with the smallest wake-up value
-    unsigned long long best = ~0ull;
-    for (uint32_t t0 = tid; t0 < P.ntiles; t0 += 8 * kTileBlock) {        // 8 loads in flight per thread
-      uint32_t pv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const uint32_t t = t0 + u * kTileBlock; pv[u] = (t < P.ntiles) ? ldg_u32(pend + t) : kInfBits; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const unsigned long long k = ((unsigned long long)pv[u] << 32) | (t0 + u * kTileBlock);
-        best = k < best ? k : best;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(best, o); best = ob < best ? ob : best; }
-    if ((tid & 63) == 0) s_best[tid >> 6] = best;
-    if (tid == 0) {
-      const float dt = ldg_f32(g_dist + P.target);
-      s_bound = (float)((double)dt + fmax(P.offset, 0.0));         // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
-      // mnav_cancel (dijkstra :287 `&& !cancel_planning_`): a word in device memory that mnav_cancel sets with a
-      // 4-byte copy on its own stream; one agent-scope load every 16 tile activations (~0.3 ms)
-      if ((acts & 15u) == 0u) s_stop = P.cancel ? __hip_atomic_load(P.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    }
-    __syncthreads();
-    if (s_stop) { status = 3; break; }
-    // the four waves scanned disjoint quarters of the tiles: their four minima, in ascending order, are the candidates
-    // of this scan.  Every candidate below the band threshold is solved without another scan (MNAV_SCAN_CANDS of them at
-    // most; label-correcting: the order of the solves does not change the fixed point, only the work).
-    unsigned long long cand[kTileBlock / 64];
-#pragma unroll
-    for (int w = 0; w < kTileBlock / 64; ++w) cand[w] = s_best[w];
-#pragma unroll
-    for (int a = 0; a < kTileBlock / 64; ++a)
-#pragma unroll
-      for (int b = a + 1; b < kTileBlock / 64; ++b)
-        if (cand[b] < cand[a]) { const unsigned long long x = cand[a]; cand[a] = cand[b]; cand[b] = x; }
-    best = cand[0];
-    const float bound = s_bound;
-    const float m = u2f((uint32_t)(best >> 32));
-    if (!(m < inf_f()) || m > bound) break;                        // nothing left that may propagate
-    if (acts >= P.max_rounds) { status = 2; break; }
-    float thr = m + P.band;
-    if (!(thr > m)) thr = next_up(m);
-    PT_STAMP(1);
-#pragma unroll 1
-    for (int ci = 0; ci < MNAV_SCAN_CANDS; ++ci) {
-    const float mc = u2f((uint32_t)(cand[ci] >> 32));
-    if (ci > 0 && (!(mc < m + MNAV_SCAN_SLACK * P.band) || mc > bound)) break;   // only tiles about as urgent as the best one (uniform over the workgroup)
-    const uint32_t t = (uint32_t)cand[ci];
-    if (tid == 0) {
-      stg_u32(pend + t, kInfBits);
-      s_hdr[0] = g_vptr[t]; s_hdr[1] = g_vptr[t + 1]; s_hdr[2] = g_hptr[t]; s_hdr[3] = g_hptr[t + 1];
-      s_hdr[4] = g_eptr[t]; s_hdr[5] = g_eptr[t + 1]; s_hdr[6] = g_rptr[t]; s_hdr[7] = f2u(ldg_f32(g_tlast + t));
-      s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
-    }
-    __syncthreads();
-    const uint32_t v0 = s_hdr[0], nv = s_hdr[1] - v0;
-    const uint32_t h0 = s_hdr[2], nh = s_hdr[3] - h0;
-    const uint32_t e0 = s_hdr[4], ne = s_hdr[5] - e0;
-    const uint32_t r0 = s_hdr[6];
-    const uint32_t nl = nv + nh;
-    const float tl = u2f(s_hdr[7]);
-    PT_STAMP(2);
-    // stage (see k_tile_round)
-    uint32_t gi[VPT];
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) { const uint32_t i = tid + k * kTileBlock; gi[k] = (i < nv) ? g_verts[v0 + i] : 0u; }
-    uint32_t hi[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const uint32_t i = tid + k * kTileBlock; hi[k] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
-    stage_tile_graph(P, L, e0, ne, r0, nl, tid);
-    uint32_t orig[VPT];
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      orig[k] = 0u;
-      if (i < nv) {
-        const float d = ldg_f32(g_dist + gi[k]);
-        orig[k] = f2u(d); ldu[i] = orig[k];
-        if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      if (i < nh) { const float d = ldg_f32(g_dist + hi[k]); ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i); }
-    }
-    for (uint32_t i = tid + 2 * kTileBlock; i < nh; i += kTileBlock) {
-      const float d = ldg_f32(g_dist + g_halo_verts[h0 + i]);
-      ldu[nv + i] = f2u(d); lh0[i] = f2u(d); if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
-    }
-    __syncthreads();
-    PT_STAMP(3);
-    const uint32_t sweep = tile_sweeps(L, nv, thr, bound, s_nq, tid);
-    PT_STAMP(4);
-    // wake-ups for the owners of undercut halo vertices, write-back, own left-over
-    uint32_t own_left = kInfBits;
-    for (uint32_t i = tid; i < nh; i += kTileBlock) {
-      const uint32_t b = ldu[nv + i];
-      if (b < lh0[i]) atomicMin((uint32_t*)&pend[g_halo_tile[h0 + i]], b);
-    }
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-      const uint32_t i = tid + k * kTileBlock;
-      if (i < nv) {
-        const uint32_t db = ldu[i];
-        if (db != orig[k]) stg_f32(g_dist + gi[k], u2f(db));
-        const float d = u2f(db);
-        if (!(d < thr) && d <= bound) own_left = min(own_left, db);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) own_left = min(own_left, (uint32_t)__shfl_xor((int)own_left, o));
-    if ((tid & 63) == 0 && own_left != kInfBits) atomicMin((uint32_t*)&pend[t], own_left);
-    if (tid == 0) stg_f32(g_tlast + t, thr);
-    ++acts; sweeps_total += sweep;
-    // every store / atomic of this activation must have reached the L2 before the next scan
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    }                                                              // candidates of this scan
-#ifdef MNAV_TILE_TIMING
-    if (tid == 0 && blockIdx.x == 0) {
-      tt[5] = clock64(); tt[6] = sweep; tt[7] = nl;
-      const unsigned int k = atomicAdd(&g_tile_timing_n, 1u);
-      if (k < 4096) for (int q = 0; q < 8; ++q) g_tile_timing[k * 8 + q] = tt[q];
-    }
-#endif
-  }
-  if (tid == 0) {
-    TCtl c; memset(&c, 0, sizeof(c));
-    c.it = (int32_t)acts; c.done = 1; c.acts = acts; c.sweeps = sweeps_total; c.pad[0] = status;
-    P.ctl[0] = c; P.ctl[1] = c;
-  }
-}
-
-#include "mnav_async.h"   // k_plan_async: the tiles without rounds (engine 6, opt-in)
+#include "mnav_async.h"   // k_plan_async: the tiles without rounds (engine 6)
 
 __global__ __launch_bounds__(kBlock) void k_tile_init(const TilePlan* __restrict__ plans, const uint32_t* __restrict__ vert_tile, float tlast0)
 {

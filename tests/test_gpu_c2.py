@@ -16,7 +16,7 @@ def c2(gpu_ctx_factory):
     return case, ctx
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band", "persistent", "tile_batch", "async"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "tile_batch", "async"])
 def test_dijkstra_c2_bit_exact(c2, engine):
     case, ctx = c2
     ctx.set_dijkstra_engine(engine)
@@ -109,7 +109,7 @@ def test_punched_terrain_1m_deep_cascades(gpu_ctx_factory):
     while deg[s] == 0: s += 1
     while deg[t] == 0: t += 1
     ref = case.om.dijkstra(case.weights, case.costs, s, t)
-    for engine in ("tiled", "persistent", "tile_batch", "async"):
+    for engine in ("tiled", "tile_batch", "async"):
         ctx.set_dijkstra_engine(engine)
         out = ctx.plan_dijkstra(s, t)
         assert out.code == ref.code == 0
@@ -129,9 +129,9 @@ def test_punched_terrain_1m_deep_cascades(gpu_ctx_factory):
     assert np.array_equal(outc.direction[upd].view(np.uint32), refc.direction[upd].view(np.uint32))
 
 
-def test_cancel_stops_a_running_persistent_batch(c2):
-    """mnav_cancel during a long k_plan_persistent launch (1280 full-field plans on the 1M mesh, ~0.2 s): the
-    kernel polls the pinned flag, leaves its loops and every plan reports CANCELED (51), like the reference's
+def test_cancel_stops_a_running_batch_on_the_tile_rounds(c2):
+    """mnav_cancel during a long run of the tile rounds (640 full-field plans on the 1M mesh, ~0.3 s): the host loop
+    looks at the flag between its graph replays, stops launching and every plan reports CANCELED (51), like the reference's
     `while (!pq.isEmpty() && !cancel_planning_)` + `:350-354`.  A later plan is unaffected (flag reset, :238)."""
     import threading
     import time
@@ -139,10 +139,10 @@ def test_cancel_stops_a_running_persistent_batch(c2):
     case, ctx = c2
     m = case.mesh
     rng = np.random.default_rng(11)
-    n = 1280
+    n = 640
     seeds = rng.choice(m.V, n, replace=False).astype(np.uint32)
     targets = np.full(n, m.vertex_at(0.5, 0.5), np.uint32)
-    ctx.set_dijkstra_engine("persistent")
+    ctx.set_dijkstra_engine("tiled")
     t0 = time.perf_counter()
     full = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=float("inf"), path_cap=4096)   # warm-up + reference time
     t_full = time.perf_counter() - t0

@@ -10,7 +10,7 @@ from tests.common import Case, terrain_case
 from tests.test_gpu_planners import assert_cvp_close, assert_dijkstra_equal
 
 pytestmark = pytest.mark.gpu
-ENGINES = ("tiled", "band", "persistent", "tile_batch", "async")
+ENGINES = ("tiled", "band", "tile_batch", "async")
 
 
 def face_of(mesh, v):
@@ -131,7 +131,7 @@ def test_empty_batch_and_batch_mixing_all_codes(gpu_ctx_factory):
     inside = np.where(lab == big)[0]
     outside = np.where((lab != big) & (deg > 0))[0]
     rng = np.random.default_rng(2)
-    n = 160                                                          # >= 128: the persistent engine in 'auto'
+    n = 160                                                          # > 96: the tile-batch engine in 'auto'
     goals = rng.choice(inside, n).astype(np.uint32)
     targets = np.full(n, int(inside[len(inside) // 2]), np.uint32)
     goals[7] = mesh.V + 3                                             # INVALID_START
@@ -205,7 +205,7 @@ def test_paths_longer_than_the_default_rows_are_walked_again_into_exact_rows(gpu
     targets[::3] = seeds[::3] + 4 * 50                                 # ... and every third plan a short one
     refs = [case.om.dijkstra(case.weights, case.costs, int(s), int(t)) for s, t in zip(seeds, targets)]
     assert max(len(r.path) for r in refs) > 8000 and min(len(r.path) for r in refs) < 200
-    for engine in ("tiled", "persistent", "tile_batch", "async"):
+    for engine in ("tiled", "tile_batch", "async"):
         ctx.set_dijkstra_engine(engine)
         for fields in (False, True):
             b = ctx.plan_dijkstra_batch(seeds, targets, want_fields=fields)

@@ -52,7 +52,7 @@ def test_paths_only_batches_equal_the_oracle_and_the_finalize_path(c2_costs, off
                                 invalid=case.invalid) for k in sample}
     assert {int(r.code) for r in refs.values()} >= {0, 54}
     results = {}
-    for engine in ("tile_batch", "persistent", "tiled", "async"):
+    for engine in ("tile_batch", "tiled", "async"):
         ctx.set_dijkstra_engine(engine)
         lazy = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=offset, cost_limit=0.8, want_fields=False, path_cap=16384)
         assert ctx.device_output(0, 1) == 0                            # a paths-only call leaves no predecessor / potential array behind
@@ -62,7 +62,7 @@ def test_paths_only_batches_equal_the_oracle_and_the_finalize_path(c2_costs, off
             assert np.array_equal(lazy["paths"][k], refs[k].path), (engine, k)
         results[engine] = ([int(c) for c in lazy["codes"]], [p.tolist() for p in lazy["paths"]])
     # every engine returns the same paths for ALL plans ...
-    for engine in ("persistent", "tiled", "async"):
+    for engine in ("tiled", "async"):
         assert results[engine] == results["tile_batch"], engine
     # ... and they equal the paths of the finalize path (V-sized fields asked for) on a subset that fits the host
     ctx.set_dijkstra_engine("tile_batch")

@@ -54,7 +54,7 @@ def c1(gpu_ctx_factory):
     return case, ctx
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band", "persistent", "tile_batch", "async"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "tile_batch", "async"])
 def test_dijkstra_c1_bit_exact_and_golden(c1, engine):
     case, ctx = c1
     ctx.set_dijkstra_engine(engine)
@@ -98,7 +98,7 @@ def test_cvp_c1_and_golden(c1):
     assert np.array_equal(pos_d.view(np.uint32), pos_r.view(np.uint32))
 
 
-@pytest.mark.parametrize("engine", ["tiled", "band", "persistent", "tile_batch", "async"])
+@pytest.mark.parametrize("engine", ["tiled", "band", "tile_batch", "async"])
 @pytest.mark.parametrize("offset", [0.0, 0.01, 0.3, 5.0, float("inf")])
 def test_dijkstra_goal_dist_offsets(c1, engine, offset):
     case, ctx = c1
@@ -133,7 +133,7 @@ def test_cost_limit_invalid_unreachable(gpu_ctx_factory):
     case = Case(mesh, costs, 1.0, invalid)
     ctx = gpu_ctx_factory()
     case.upload(ctx)
-    for engine in ("tiled", "band", "persistent", "tile_batch", "async"):
+    for engine in ("tiled", "band", "tile_batch", "async"):
         ctx.set_dijkstra_engine(engine)
         for lim in (1.0, 0.6):
             ref = case.om.dijkstra(case.weights, case.costs, s, t, cost_limit=lim, invalid=case.invalid)
@@ -240,7 +240,7 @@ def test_golden_order_sensitive_fixtures(gpu_ctx_factory, which):
     ctx = gpu_ctx_factory()
     case.upload(ctx)
     s, t = (int(x) for x in RAGGED[which + "_seed_target"])
-    for engine in ("tiled", "band", "persistent", "tile_batch", "async"):
+    for engine in ("tiled", "band", "tile_batch", "async"):
         ctx.set_dijkstra_engine(engine)
         out = ctx.plan_dijkstra(s, t)
         assert out.code == int(RAGGED[which + "_dij_code"][0]) and np.array_equal(out.path, RAGGED[which + "_dij_path"])
@@ -265,7 +265,7 @@ def test_batch_equals_single_plans(c1):
     goals[3] = goals[0]                                               # duplicate goal
     targets = np.full(12, m.vertex_at(0.9, 0.9), np.uint32)
     goals[5] = targets[5]                                             # seed == target inside a batch
-    for engine in ("tiled", "persistent", "tile_batch", "async"):
+    for engine in ("tiled", "tile_batch", "async"):
         ctx.set_dijkstra_engine(engine)
         b = ctx.plan_dijkstra_batch(goals, targets, want_fields=True)
         check_batch(case, b, goals, targets)

@@ -1,6 +1,6 @@
 """GPU: the tile-batch SSSP engine (mnav_tb.h: one wave per (tile, <= 64 plans), one plan per lane) through the C ABI
 against the CPU oracle -- vertex-index paths identical, popped potential (dist <= goal_dist) bit-exact -- and against
-the persistent per-plan engine on a 1M-vertex batch (dijkstra_mesh_planner.cpp:287-348, :358-373)."""
+the tile rounds on a 1M-vertex batch (dijkstra_mesh_planner.cpp:287-348, :358-373)."""
 import os
 
 import numpy as np
@@ -96,8 +96,8 @@ def test_costs_limit_invalid_unreachable(gpu_ctx_factory):
     ctx.close()
 
 
-def test_c2_batch_equals_oracle_and_persistent_engine(gpu_ctx_factory):
-    """1M vertices, 512 plans: every path equals the persistent engine's, a sample equals the oracle's."""
+def test_c2_batch_equals_oracle_and_tile_rounds(gpu_ctx_factory):
+    """1M vertices, 512 plans: every path equals the tile rounds', a sample equals the oracle's."""
     case = terrain_case(1000, 2)
     ctx = gpu_ctx_factory()
     case.upload(ctx)
@@ -111,7 +111,7 @@ def test_c2_batch_equals_oracle_and_persistent_engine(gpu_ctx_factory):
     assert (b["codes"] == 0).all()
     st = b["stats"]
     check_against_oracle(case, ctx, b, seeds, targets, [0, 101, 255, 511])
-    ctx.set_dijkstra_engine("persistent")
+    ctx.set_dijkstra_engine("tiled")
     p = ctx.plan_dijkstra_batch(seeds, targets, want_fields=False, path_cap=16384)
     assert (p["codes"] == 0).all()
     for k in range(n):
