@@ -50,7 +50,8 @@ def build_adapter(force: bool = False, verbose: bool = False) -> str:
     if not cpps:
         return ""
     build_lib(force=False, verbose=verbose)
-    if force or _stale(ADAPTER_LIB, srcs + [LIB]):
+    shared = [os.path.join(_HERE, "..", "include", f) for f in ("mnav.h", "mnav_planner_host.hpp")]
+    if force or _stale(ADAPTER_LIB, srcs + shared + [LIB]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
                "-I", os.path.join(_HERE, "..", "include"), "-I", adir, "-o", ADAPTER_LIB, *cpps,
                "-L", _HERE, "-lmnav", "-Wl,-rpath,$ORIGIN"]
