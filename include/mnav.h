@@ -120,7 +120,8 @@ int mnav_combine_costs(mnav_ctx* ctx, int mode, uint32_t n_layers, const float* 
  * at most path_cap entries are written, *path_len is the full length.
  * goal_dist_offset: any double like the reference's parameter (default 0.3).  A negative value stops the expansion at the
  * robot vertex (only vertices popped before it are sources, :293-300) and is reproduced exactly; NaN is refused.  The CVP
- * and sharded entry points below still refuse negative offsets with MNAV_INTERNAL_ERROR. */
+ * and sharded entry points below take negative offsets too (CVP: every pop up to and including the arming one expands,
+ * cvp_mesh_planner.cpp:754 before :765-769). */
 uint32_t mnav_plan_dijkstra(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex,
                             double goal_dist_offset, double cost_limit, float* dist_out,
                             uint32_t* pred_out, uint32_t* path_out, uint32_t path_cap,

@@ -1485,7 +1485,8 @@ static uint32_t cvp_impl(mnav_ctx* ctx, uint32_t n, const float* seed_pos, const
 {
   if (check_ready(ctx)) return MNAV_INTERNAL_ERROR;
   ctx->err.clear();
-  if (!(goal_dist_offset >= 0.0)) { ctx->err = "goal_dist_offset must be >= 0"; return MNAV_INTERNAL_ERROR; }   // see dijkstra_impl
+  if (goal_dist_offset != goal_dist_offset) { ctx->err = "goal_dist_offset is NaN"; return MNAV_INTERNAL_ERROR; }   // any double otherwise: a negative one
+                                                                                                                      // stops the wave at the arming pop (passes_goal_cut)
   ctx->cancel.store(0);                                               // cvp :679
   if (ctx->d_cancel) { (void)hipStreamSynchronize(ctx->cancel_stream); (void)hipMemsetAsync(ctx->d_cancel, 0, 4, ctx->stream); }
   if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return MNAV_INTERNAL_ERROR; }

@@ -371,6 +371,8 @@ struct Ctl {
   uint32_t cuts;       // statistics: band cuts (kCutAfter)
   uint32_t epoch;      // id of the current waiting list (1 for the list the first steps append to, then step index of the
                        // epoch step + 2); Plan.wstamp (0 = never parked) dedups with it
+  uint32_t arm_vertex; // CVP: the robot-face vertex whose pop armed goal_dist (kNone until then): pops up to and including its
+                       // own met goal_dist = +inf at :754 and expand whatever their value (passes_goal_cut)
 };
 
 struct Cnt {
@@ -504,6 +506,21 @@ MNAV_HD bool key_less(const Plan& P, const KeyRef& a, const KeyRef& b)
   return key_less_walk(P, a, b);                                   //  two faces fired by one pop are compared all the time)
 }
 
+// cvp :754 `if (distances[cur] > goal_dist) continue;` as a test on the converged state.  goal_dist is +inf until the arming
+// pop (:765-769, which comes AFTER :754 in the same iteration), so every pop up to and including that one expands whatever
+// its value; later pops expand when their value does not exceed goal_dist.  With goal_dist_offset >= 0 the first clause
+// decides nearly always; a negative offset (goal_dist below the arming vertex's own value) is where the pop order does.
+MNAV_HD_COLD bool popped_by_arming(const Plan& P, uint32_t arm_vertex, KeyRef k)   // rare (values above goal_dist only): a real call
+{
+  return !key_less(P, key_ref(P, arm_vertex), k);                    // popped no later than the arming vertex
+}
+MNAV_HD bool passes_goal_cut(const Plan& P, const Ctl& c, float d, const KeyRef& k)
+{
+  if (!(d > c.goal_dist)) return true;
+  if (c.arm_vertex == kNone) return false;
+  return popped_by_arming(P, c.arm_vertex, k);
+}
+
 // key of vertex v whose value d was set by the pop `trig`
 MNAV_HD PopKey key_for(const Plan& P, float d, uint32_t v, KeyRef trig)
 {
@@ -591,7 +608,7 @@ MNAV_HD void try_arm(const Plan& P, Ctl& q)
     if (!(key_time(kg.k) < q.thr_fixed)) continue; // has not popped yet
     if ((!have_all || !key_less(P, kg, k_all)) && (best_i == kNone || key_less(P, kg, best_k))) { best_k = kg; best_d = P.dist[g]; best_i = g; }
   }
-  if (best_i != kNone) { q.goal_dist = (float)((double)best_d + P.offset); q.armed = 1; }
+  if (best_i != kNone) { q.goal_dist = (float)((double)best_d + P.offset); q.armed = 1; q.arm_vertex = best_i; }
 }
 
 // Band controller: pure function of the previous control block and the previous step's counters.
@@ -744,8 +761,8 @@ MNAV_HD Fire corner_fire_pre(const Plan& P, const Ctl& c, const Corner& k, const
     if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
   }
   const bool one_first = key_less(P, k1, k2);                        // v1 pops before v2
-  const bool trig1 = t1 < c.thr && ex1 && !(d1 > c.goal_dist) && (s2 || !one_first);
-  const bool trig2 = t2 < c.thr && ex2 && !(d2 > c.goal_dist) && (s1 || one_first || k1.own == k2.own);
+  const bool trig1 = t1 < c.thr && ex1 && passes_goal_cut(P, c, d1, k1) && (s2 || !one_first);
+  const bool trig2 = t2 < c.thr && ex2 && passes_goal_cut(P, c, d2, k2) && (s1 || one_first || k1.own == k2.own);
   if (trig1) { f.key = k1; f.trig = k.v1; }
   if (trig2 && (!trig1 || key_less(P, k2, k1))) { f.key = k2; f.trig = k.v2; }
   return f;

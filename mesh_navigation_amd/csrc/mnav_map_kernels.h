@@ -219,7 +219,7 @@ __global__ void k_infl_ctl(const Plan* __restrict__ plans)
   const Plan& P = plans[0];
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   Ctl c0; memset(&c0, 0, sizeof(c0));
-  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f(); c0.arm_vertex = kNone;
   c0.thr = P.delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
   c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;
   P.ctl[1] = c0;

@@ -50,7 +50,7 @@ __global__ void k_seed(const Plan* __restrict__ plans)
     }
   }
   Ctl c0; memset(&c0, 0, sizeof(c0));
-  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f(); c0.arm_vertex = kNone;
   c0.thr = m0 + P.delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
   for (int k = 0; k < ns; ++k) if (!(P.seed_d[k] < c0.thr)) c0.thr = next_up(P.seed_d[k]);   // the first band holds every seed
   c0.band_new = 1; c0.width = P.delta; c0.wmin = inf_f(); c0.epoch = 1;

@@ -254,7 +254,7 @@ uint32_t sm_run(uint32_t planner, uint32_t V, uint32_t F, uint32_t E, const uint
   }
   c_init.changed = 1;
   Ctl& c0 = ctl[1];
-  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f(); c0.arm_vertex = kNone;
   c0.thr = m0 + delta; if (!(c0.thr > m0)) c0.thr = next_up(m0);
   for (int k = 0; k < ns; ++k) {                                   // the first band holds every seed (like k_seed)
     const float d = (planner == kPlannerCvp) ? seed_d[k] : 0.0f;
@@ -319,7 +319,7 @@ uint32_t sm_run_inflation(uint32_t V, uint32_t F, uint32_t E, const uint32_t* fa
   }
   c_init.changed = 1;
   Ctl& c0 = ctl[1];                                                 // like k_infl_ctl
-  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f();
+  c0.it = -1; c0.n = 0; c0.thr_fixed = -inf_f(); c0.goal_dist = inf_f(); c0.arm_vertex = kNone;
   c0.thr = delta; if (!(c0.thr > 0.0f)) c0.thr = next_up(0.0f);
   c0.band_new = 1; c0.width = delta; c0.wmin = inf_f(); c0.epoch = 1;
   const uint32_t code = drive(P, kPlannerCvp, order, ctl, cnt, tkey, blocked, stats_out, nullptr);

@@ -72,3 +72,47 @@ def test_wide_kernel_on_irregular_valence_and_adversarial_costs(gpu_ctx_factory)
         out = ctx2.plan_cvp(sps[k], int(sfs[k]), int(tfs[k]), goal_dist_offset=float("inf"))
         assert out.code == ref.code
         assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
+
+
+@pytest.mark.parametrize("kind", ["layered", "adversarial"])
+def test_negative_goal_dist_offset_in_cvp(gpu_ctx_factory, kind):
+    """`goal_dist_offset` is any double in the reference (cvp_mesh_planner.cpp:157, :769).  :754 is tested BEFORE the arming in
+    :765-769, so the arming pop and every pop before it expand whatever their value; below zero everything later is cut off unless
+    its value undercuts goal_dist.  Single plans (8-lane replay), a batch on the wide kernel and the forced other kernel each:
+    potential, predecessors, cutting faces and directions bit for bit, and the vector map where the reference has an entry."""
+    if kind == "layered":
+        base = terrain_case(224, 1)
+        costs, _ = layered_costs(base, "avg")
+        case = Case(base.mesh, costs, 1.0)
+    else:
+        m2 = meshgen.terrain(128, 0.1, 5)
+        case = Case(m2, np.random.default_rng(2).uniform(0.0, 1.1, m2.V).astype(np.float32), 1.0)
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    sps, sfs, tfs = _batch(Case(case.mesh, np.where(case.costs < 0.5, 0.0, 1.0).astype(np.float32)), 34, 7)
+    for off in (-0.05, -1.5, float("-inf")):
+        ks = [k for k in range(34) if sfs[k] < case.mesh.F]
+        ks = ks[:2] + ks[-1:] + [k for k in range(34) if sfs[k] >= case.mesh.F][:1]     # (+ a seed off the mesh: INVALID_START)
+        refs = {k: case.om.cvp(case.weights, case.costs, case.vn, sps[k], int(sfs[k]), int(tfs[k]), goal_dist_offset=off) for k in ks}
+        for k, ref in refs.items():
+            for wide in (0, 1):
+                ctx.set_option("cvp_wide", wide)
+                out = ctx.plan_cvp(sps[k], int(sfs[k]), int(tfs[k]), goal_dist_offset=off)
+                assert out.code == ref.code, (kind, off, k, wide)
+                if ref.code == 52:
+                    continue
+                assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)), (kind, off, k, wide)
+                assert np.array_equal(out.pred, ref.pred)
+                upd = ref.pred != np.arange(case.mesh.V)
+                assert np.array_equal(out.cutface[upd], ref.cutface[upd])
+                assert np.array_equal(out.direction[upd].view(np.uint32), ref.direction[upd].view(np.uint32))
+                has = ref.has_vec.astype(bool)
+                assert np.array_equal(out.vecmap[has].view(np.uint32), ref.vecmap[has].view(np.uint32))
+        ctx.set_option("cvp_wide", None)
+        b = ctx.plan_cvp_batch(sps, sfs, tfs, goal_dist_offset=off, want_fields=True)      # 34 plans: the wide kernel
+        for k, ref in refs.items():
+            assert b["codes"][k] == ref.code
+            if ref.code != 52:
+                assert np.array_equal(b["dist"][k].view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(b["pred"][k], ref.pred), (kind, off, k)
+    with pytest.raises(RuntimeError, match="goal_dist_offset"):
+        ctx.plan_cvp(sps[0], int(sfs[0]), int(tfs[0]), goal_dist_offset=float("nan"))

@@ -365,3 +365,64 @@ def test_zero_weight_edges_keep_distances_exact_and_predecessors_optimal():
             return c, v
         (c1, e1), (c2, e2) = cost_to_seed(pred), cost_to_seed(ref.pred)
         assert e1 == e2 == s and c1 == pytest.approx(c2, rel=1e-6)
+
+
+def _assert_cvp_fields_equal(mesh, ref, mod):
+    assert mod["code"] == ref.code
+    assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32))
+    assert np.array_equal(mod["pred"], ref.pred)
+    upd = ref.pred != np.arange(mesh.V)
+    assert np.array_equal(mod["cutface"][upd], ref.cutface[upd])
+    assert np.array_equal(mod["direction"][upd].view(np.uint32), ref.direction[upd].view(np.uint32))
+    assert mod["goal_dist"] == ref.stats["goal_dist"]
+
+
+@pytest.mark.parametrize("offset", [-0.01, -0.3, -2.0, -1e9])
+@pytest.mark.parametrize("delta,order", [(0.1, 0), (0.4, 2), (1.5, 3)])
+def test_cvp_negative_goal_dist_offset(offset, delta, order):
+    """cvp_mesh_planner.cpp:754 comes BEFORE :765-769 in an iteration: the arming pop itself expands, every pop before it met
+    goal_dist = +inf and expanded whatever its value, every later pop lies above goal_dist = (arming value + a negative
+    offset) unless its value undercuts it.  The gather rule decides that by POP ORDER against the arming vertex
+    (mnav_eval.h::passes_goal_cut), whatever the band width and the order of evaluation."""
+    case = Case(meshgen.terrain(56, 0.1, 14))
+    m = case.mesh
+    sp = m.xyz[m.vertex_at(0.2, 0.2)] + np.array([0.03, 0.02, 0], np.float32)
+    tp = m.xyz[m.vertex_at(0.8, 0.7)] + np.array([0.01, 0.04, 0], np.float32)
+    ref, mod = run_cvp(case, sp, tp, offset=offset, delta=delta, order=order)
+    _assert_cvp_fields_equal(m, ref, mod)
+    zero, _ = run_cvp(case, sp, tp, offset=0.0, delta=delta, order=order)
+    assert np.isfinite(ref.dist).sum() <= np.isfinite(zero.dist).sum()
+
+
+@pytest.mark.parametrize("kind", ["adversarial", "punched", "layered"])
+def test_cvp_negative_offsets_with_cascades(kind):
+    """the same where pops undercut the front (cost-inflated triangles, waves wrapping around holes): values below goal_dist
+    that pop after the arming vertex still expand (:754 is a test on the value), values above it that popped before it did too"""
+    if kind == "adversarial":
+        mesh = meshgen.terrain(72, 0.1, 13)
+        rng = np.random.default_rng(3)
+        costs = rng.uniform(0, 1.2, mesh.V).astype(np.float32)
+        case = Case(mesh, costs, 1.0)
+    elif kind == "punched":
+        case = Case(meshgen.punched(72, 0.1, 11, drop=0.15))
+        costs = case.costs
+    else:
+        base = Case(meshgen.terrain(72, 0.1, 3, amplitude=0.8))
+        costs, _ = layered_costs(base, "avg")
+        case = Case(base.mesh, costs, 1.0)
+    m = case.mesh
+    deg = np.bincount(m.edges.ravel(), minlength=m.V)
+    free = np.where((costs < 0.5) & (deg > 0))[0]
+    first_face = np.full(m.V, -1, np.int64)
+    fl = m.faces.ravel()
+    first_face[fl[::-1]] = np.arange(fl.size)[::-1] // 3
+    mean_w = float(case.weights[np.isfinite(case.weights)].mean())
+    rng = np.random.default_rng(29)
+    for k in range(6):
+        s, t = (int(x) for x in rng.choice(free, 2, replace=False))
+        sf, tf = int(first_face[s]), int(first_face[t])
+        sp = m.xyz[m.faces[sf]].astype(np.float64).mean(axis=0).astype(np.float32)
+        tp = m.xyz[m.faces[tf]].astype(np.float64).mean(axis=0).astype(np.float32)
+        off = (-0.02, -0.5, -3.0)[k % 3]
+        ref, mod = run_cvp(case, sp, tp, offset=off, delta=(4, 12, 30)[k % 3] * mean_w, order=(0, 3)[k % 2], max_steps=100000)
+        _assert_cvp_fields_equal(m, ref, mod)
