@@ -88,7 +88,7 @@ def compare_plans(case, rm, s, t, sp=None, tp=None, **kw):
     return rd, rc
 
 
-@pytest.mark.parametrize("offset", [0.0, 0.3, 2.5, float("inf")])
+@pytest.mark.parametrize("offset", [0.0, 0.3, 2.5, float("inf"), -0.2, -5.0])      # (any double: dijkstra :151, cvp :157)
 def test_c1_planners_bit_equal(offset):
     case = Case(meshgen.terrain(224, 0.1, 1))
     rm = R.RefMap(case.mesh.xyz, case.mesh.faces)
