@@ -34,7 +34,9 @@ namespace mesh_gpu_planners
 class CostChangeLog
 {
 public:
-  static std::shared_ptr<CostChangeLog> of(const mesh_map::MeshMap* map);   // the map's log (created on first use)
+  // the map's log (created on first use).  Logs live and die with THEIR map: a map allocated later at the same address starts with a
+  // fresh one, whatever a layer that was never destroyed (below) still holds
+  static std::shared_ptr<CostChangeLog> of(const std::shared_ptr<mesh_map::MeshMap>& map);
   void attach() { std::lock_guard<std::mutex> l(m_); ++observers_; }
   void detach() { std::lock_guard<std::mutex> l(m_); if (observers_) --observers_; }
   bool attached() { std::lock_guard<std::mutex> l(m_); return observers_ > 0; }
@@ -51,7 +53,10 @@ private:
 class CostObserverLayer : public mesh_map::AbstractLayer
 {
 public:
-  ~CostObserverLayer();                                               // (AbstractLayer has no virtual destructor: the layer detaches itself)
+  // AbstractLayer has no virtual destructor and pluginlib deletes layers through the base pointer: this destructor does NOT run
+  // then, and nothing relies on it -- a log is dropped with its map, and the planners probe the map's arrays on every plan
+  // (DeviceMap::syncCosts) instead of trusting attached() blindly
+  ~CostObserverLayer();
   bool readLayer() override { return true; }                           // nothing to read, nothing to compute
   bool writeLayer() override { return true; }
   float defaultValue() override { return 0.0f; }

@@ -45,7 +45,7 @@ public:
   mnav_ctx* ctx() const { return ctx_; }
   bool ok() const { return ctx_ != nullptr; }
   uint32_t numVertices() const { return V_; }
-  bool uploadMesh(mesh_map::MeshMap& map, std::string& err);
+  bool uploadMesh(const std::shared_ptr<mesh_map::MeshMap>& map_ptr, std::string& err);
   // true: the device copy is current.  With a CostObserverLayer in the map's layer graph: the vertices it filed since the
   // last call and their edges are updated (O(changed)); without one: one signing pass over the map's arrays per call, an
   // upload only when they changed; with setStaticCosts(true) not even that unless `force`

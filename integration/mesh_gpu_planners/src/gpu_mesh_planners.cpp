@@ -41,9 +41,11 @@ DeviceMap::~DeviceMap()
 }
 
 // The half-edge mesh as flat arrays, in the reference's own ids (handle indices), once per map.
-bool DeviceMap::uploadMesh(mesh_map::MeshMap& map, std::string& err)
+bool DeviceMap::uploadMesh(const std::shared_ptr<mesh_map::MeshMap>& map_ptr, std::string& err)
 {
   if (!ctx_) { err = "no usable GPU (mnav_create failed)"; return false; }
+  if (!map_ptr) { err = "no map"; return false; }
+  mesh_map::MeshMap& map = *map_ptr;
   const auto mesh = map.mesh();
   if (!mesh) { err = "the map holds no mesh"; return false; }
   V_ = (uint32_t)mesh->nextVertexIndex(); F_ = (uint32_t)mesh->nextFaceIndex(); E_ = (uint32_t)mesh->nextEdgeIndex();
@@ -81,7 +83,7 @@ bool DeviceMap::uploadMesh(mesh_map::MeshMap& map, std::string& err)
   mnav_set_resident_outputs(ctx_, 1);            // potential / predecessors / vector map stay on the device until asked for
   have_costs_ = false;
   if (log_ && log_id_ >= 0) log_->unsubscribe(log_id_);
-  log_ = CostChangeLog::of(&map);                // from now on every change an observer layer files is kept for this mirror
+  log_ = CostChangeLog::of(map_ptr);             // from now on every change an observer layer files is kept for this mirror
   log_id_ = log_->subscribe();
   return true;
 }
@@ -221,7 +223,7 @@ bool GpuDijkstraMeshPlanner::initialize(const std::string& plugin_name, const st
   dev_ = std::make_unique<DeviceMap>(device);
   dev_->setStaticCosts(static_costs);
   std::string err;
-  if (!dev_->uploadMesh(*mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
+  if (!dev_->uploadMesh(mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
     return false;
   }
@@ -368,7 +370,7 @@ bool GpuCVPMeshPlanner::initialize(const std::string& plugin_name, const std::sh
   dev_ = std::make_unique<DeviceMap>(device);
   dev_->setStaticCosts(static_costs);
   std::string err;
-  if (!dev_->uploadMesh(*mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
+  if (!dev_->uploadMesh(mesh_map_, err) || !dev_->syncCosts(*mesh_map_, err)) {
     RCLCPP_ERROR_STREAM(node_->get_logger(), name_ << ": " << err);
     return false;
   }

@@ -224,6 +224,14 @@ class RefMap:
             L.ref_param_string(self._h, ns + b"gpu_cost_observer.type", b"mesh_gpu_planners/CostObserverLayer")
             L.ref_param_string_array(self._h, ns + b"gpu_cost_observer.inputs", b"costs")
             L.ref_param_string(self._h, ns + b"default_layer", b"costs")
+        elif layers == "array+observer_misconfigured":
+            # the observer layer WITHOUT the default layer among its inputs: it would never hear of a change and must not attach
+            vc = np.zeros(self.V, np.float32) if vertex_costs is None else _f32(vertex_costs)
+            L.ref_set_array_layer(self._h, b"costs", self.V, _p(vc), None if lethal is None else _p(_u8(lethal)))
+            L.ref_param_string_array(self._h, ns + b"layers", b"costs,gpu_cost_observer")
+            L.ref_param_string(self._h, ns + b"costs.type", b"ref_harness/ArrayLayer")
+            L.ref_param_string(self._h, ns + b"gpu_cost_observer.type", b"mesh_gpu_planners/CostObserverLayer")
+            L.ref_param_string(self._h, ns + b"default_layer", b"costs")
         elif layers == "array+inflation":
             # a harness-served layer with lethal flags feeding the reference's InflationLayer (the default layer)
             vc = np.zeros(self.V, np.float32) if vertex_costs is None else _f32(vertex_costs)

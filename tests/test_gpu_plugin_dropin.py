@@ -257,3 +257,23 @@ def test_gpu_plugin_backstop_sees_what_the_change_signal_cannot(world):
         c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     assert c2 == cr2 and np.array_equal(p2, pr2) and k2 == kr2 and not np.array_equal(pr2, pr1)
     rm.plugin_release()
+
+
+def test_misconfigured_cost_observer_does_not_attach(world):
+    """An observer layer whose `inputs` do not contain the map's default layer is never told about a cost change
+    (layer_manager.cpp:229-261).  It must not report "attached": the plugin then keeps signing the map's arrays on every plan and
+    still plans like the reference planner after a change."""
+    m, _, robot, goal = world
+    rm = R.RefMap(m.xyz, m.faces, layers="array+observer_misconfigured", vertex_costs=np.zeros(m.V, np.float32), edge_cost_factor=1.0)
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_unobserved")
+    c0, p0, _, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    full0, inc0, sign0 = R.RefMap.gpu_plugin_cost_sync_counts()
+    N = m.N
+    band = (np.arange(N // 4, 3 * N // 4)[:, None] * N + np.arange(N // 2 - 2, N // 2 + 2)[None, :]).ravel().astype(np.uint32)
+    rm.update_array_layer(band, np.full(band.shape[0], 0.9, np.float32))
+    cr1, pr1, kr1 = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    c1, p1, k1, _ = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert c0 == c1 == cr1 == 0 and np.array_equal(p1, pr1) and k1 == kr1 and not np.array_equal(p1, p0)
+    full1, inc1, sign1 = R.RefMap.gpu_plugin_cost_sync_counts()
+    assert sign1 - sign0 >= 1 and inc1 == inc0                         # found by the signing pass, not through the (dead) log
+    rm.plugin_release()
