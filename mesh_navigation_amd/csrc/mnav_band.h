@@ -437,6 +437,25 @@ __global__ void k_flags_reset(const Plan* __restrict__ plans)
   if (threadIdx.x == 0) { Cnt z; memset(&z, 0, sizeof(z)); z.minkey = 0x7f800000u; plans[blockIdx.x].cnt[3] = z; }
 }
 
+// the vertices around each plan's seed face once more, with BOTH fire events of the faces that have a seed support
+// (mnav_eval.h: corner_fire_second, seed_ring_fix): predecessor / direction / cutting face of the last successful application
+__global__ __launch_bounds__(kWave) void k_cvp_seed_ring(const Plan* __restrict__ plans)
+{
+  const Plan& P = plans[blockIdx.x];
+  const Ctl a = P.ctl[0], b = P.ctl[1];
+  const Ctl cur = (a.it > b.it) ? a : b;
+  if (!cur.done || cur.overflow) return;
+  for (int q = 0; q < 3; ++q) {
+    const uint32_t s = P.seed[q];
+    if (s == kNone || s >= P.V) continue;
+    const uint32_t beg = P.crn_ptr[s], end = P.crn_ptr[s + 1];
+    for (uint32_t i = beg + (threadIdx.x >> 1); i < end; i += kWave / 2) {
+      const Corner k = P.crn[i];
+      seed_ring_fix(P, cur, (threadIdx.x & 1) ? k.v2 : k.v1);        // (a vertex met twice is written twice with the same values)
+    }
+  }
+}
+
 __global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans, int fix, uint32_t* __restrict__ any_bad)
 {
   const Plan& P = plans[blockIdx.y];

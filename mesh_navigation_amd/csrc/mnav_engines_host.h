@@ -105,6 +105,10 @@ int run_plans(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   }
   ctx->stats.launches = launches;
   if (cvp && rc == 0 && ctx->cvp_verify && verify_sweeps(ctx, n)) return -1;
+  if (cvp && rc == 0) {                                               // second fire events around the seed faces (k_cvp_seed_ring)
+    hipLaunchKernelGGL(k_cvp_seed_ring, dim3(n), dim3(kWave), 0, ctx->stream, ctx->d_plans);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipEventRecord(ctx->ev[3], ctx->stream));
   return rc;
 }

@@ -774,11 +774,40 @@ MNAV_HD Fire corner_fire(const Plan& P, const Ctl& c, const Corner& k)
   return corner_fire_pre(P, c, k, key_ref(P, k.v1), key_ref(P, k.v2), P.dist[k.v1], P.dist[k.v2]);
 }
 
+// The SECOND fire event of a face, where it has one.  A face is visited at the pop of a support whenever its other support
+// is fixed then (cvp :790-870).  A non-seed support is fixed by its own pop, so such a face fires once, at the later pop; a SEED is
+// fixed from the start (:726) but pops like everybody else -- a face with a seed support fires at the pop of its other support
+// AND, when that one comes first, again at the seed's own pop.  The second visit offers the very candidate of the first; in exact
+// arithmetic it could never lower anything, but :411 compares the float64 candidate with the float32 value that was stored --
+// usually a hair above it -- so the re-application "succeeds", leaves the value as it is and makes this face the vertex's cutting
+// face (and its support the predecessor) again where a tying face had taken them in between.  The replay of the step kernels uses
+// the first event only (corner_fire_pre); seed_ring_fix replays both for the few vertices around the seed face.
+MNAV_HD Fire corner_fire_second(const Plan& P, const Ctl& c, const Corner& k)
+{
+  Fire f; f.key = key_ref_of(key_inf(), inf_f(), 0); f.trig = kNone;
+  if (k.v1 == kNone || P.seed_mask) return f;
+  const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
+  if (!s1 && !s2) return f;
+  const KeyRef k1 = key_ref(P, k.v1), k2 = key_ref(P, k.v2);
+  const float t1 = key_time(k1.k), t2 = key_time(k2.k);
+  if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr)) || k1.own == k2.own) return f;
+  bool ex1 = true, ex2 = true;
+  if (s1) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v1) ex1 = P.seed_expands[q] != 0; }
+  if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
+  const bool one_first = key_less(P, k1, k2);
+  const bool trig1 = t1 < c.thr && ex1 && passes_goal_cut(P, c, P.dist[k.v1], k1) && (s2 || !one_first);
+  const bool trig2 = t2 < c.thr && ex2 && passes_goal_cut(P, c, P.dist[k.v2], k2) && (s1 || one_first);
+  if (!(trig1 && trig2)) return f;
+  if (one_first) { f.key = k2; f.trig = k.v2; } else { f.key = k1; f.trig = k.v1; }     // the later of the two pops
+  return f;
+}
+
 // CVP: replay of the incident-face updates of vertex v in the order their trigger vertices
 // pop.  A face is applied to v only while v is still free, i.e. while the trigger pops before v
 // itself would.  Faces fired by the same pop are applied in the order of the trigger's half-edge
 // circulator (cvp :778 loop over getFacesOfVertex(trigger)): Corner order flags, mnav_build.h.
-MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
+template <bool BOTH_EVENTS>
+MNAV_HD Eval eval_cvp_t(const Plan& P, const Ctl& c, uint32_t v)
 {
   Eval e; e.d = inf_f(); e.t = inf_f(); e.key = key_inf(); e.pred = v; e.dir = 0.0f; e.cut = kNone; e.keyd = inf_f();
   const uint32_t beg = P.crn_ptr[v], end = P.crn_ptr[v + 1];
@@ -795,12 +824,13 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
     if (pass_no == max_pass) { raise_flag(P, kFlagWalkLimit); break; }
     // next trigger pop strictly after the last one
     KeyRef m = last; uint32_t m_trig = kNone;
-    for (uint32_t i = beg; i < end; ++i) {
-      const Fire f = corner_fire(P, c, P.crn[i]);
-      if (f.trig == kNone || key_descends_from(P, f.trig, v)) continue;
-      if (!first && !key_less(P, last, f.key)) continue;
-      if (m_trig == kNone || key_less(P, f.key, m)) { m = f.key; m_trig = f.trig; }
-    }
+    for (uint32_t i = beg; i < end; ++i)
+      for (int ev = 0; ev < (BOTH_EVENTS ? 2 : 1); ++ev) {
+        const Fire f = ev == 0 ? corner_fire(P, c, P.crn[i]) : corner_fire_second(P, c, P.crn[i]);
+        if (f.trig == kNone || key_descends_from(P, f.trig, v)) continue;
+        if (!first && !key_less(P, last, f.key)) continue;
+        if (m_trig == kNone || key_less(P, f.key, m)) { m = f.key; m_trig = f.trig; }
+      }
     if (m_trig == kNone) break;
     if (queued && !key_less(P, m, key_ref_of(e.key, e.keyd, v))) break;   // v pops before this trigger
     bool any = false;
@@ -809,7 +839,8 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
       for (uint32_t i = beg; i < end; ++i) {
         const Corner k = P.crn[i];
         const Fire f = corner_fire(P, c, k);
-        if (f.trig != m_trig || corner_first_for(k, m_trig) != (pass == 0)) continue;
+        const bool fires = f.trig == m_trig || (BOTH_EVENTS && corner_fire_second(P, c, k).trig == m_trig);
+        if (!fires || corner_first_for(k, m_trig) != (pass == 0)) continue;
         if (infl) {
           const InflCand u = infl_candidate(P.dist[k.v1], P.dist[k.v2], k.a, k.b, k.c, P.infl_max);
           if (e.d == 0.0f || !u.ok || !(u.u3tmp < e.d)) continue;       // :252, :271, :298
@@ -832,6 +863,19 @@ MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v)
   if (!queued) { e.key = key_inf(); e.keyd = inf_f(); if (!infl) e.pred = v; }
   e.t = key_time(e.key);
   return e;
+}
+MNAV_HD Eval eval_cvp(const Plan& P, const Ctl& c, uint32_t v) { return eval_cvp_t<false>(P, c, v); }
+
+// After convergence and verification: the vertices around the seed face once more, with both fire events of the faces that
+// have a seed support (corner_fire_second).  Value and pop key are what they were -- the second event re-applies a candidate that
+// was applied before --; predecessor, direction and cutting face are the last successful application's, like in the
+// reference.  `v`: a support of one of the seeds' corners.  CVP planner only.
+MNAV_HD void seed_ring_fix(const Plan& P, const Ctl& c, uint32_t v)
+{
+  if (v == kNone || v >= P.V || is_seed(P, v) || P.blocked[v] || !(P.dist[v] < inf_f())) return;
+  const Eval e = eval_cvp_t<true>(P, c, v);
+  if (f2u(e.d) != f2u(P.dist[v]) || e.key != P.tkey[v]) return;
+  P.pred[v] = e.pred; P.dirn[v] = e.dir; P.cutf[v] = e.cut;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -165,6 +165,13 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
       ++verify_sweeps;
     }
   }
+  // model of k_cvp_seed_ring: the second fire events of the faces around the seed face (mnav_eval.h, corner_fire_second)
+  if (planner == kPlannerCvp && cur.done && !cur.overflow && verify_bad == 0)
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t sq = P.seed[q];
+      if (sq == kNone || sq >= V) continue;
+      for (uint32_t i = P.crn_ptr[sq]; i < P.crn_ptr[sq + 1]; ++i) { seed_ring_fix(P, cur, P.crn[i].v1); seed_ring_fix(P, cur, P.crn[i].v2); }
+    }
   if (stats_out) { stats_out[0] = (uint64_t)j; stats_out[1] = cur.bands; stats_out[2] = evals; stats_out[3] = cur.armed; stats_out[4] = cur.shrinks;
                    stats_out[5] = verify_bad; stats_out[6] = verify_flags; stats_out[7] = verify_sweeps | ((uint64_t)cur.cuts << 32); }
   if (goal_dist_out) *goal_dist_out = cur.goal_dist;

@@ -116,3 +116,32 @@ def test_negative_goal_dist_offset_in_cvp(gpu_ctx_factory, kind):
                 assert np.array_equal(b["dist"][k].view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(b["pred"][k], ref.pred), (kind, off, k)
     with pytest.raises(RuntimeError, match="goal_dist_offset"):
         ctx.plan_cvp(sps[0], int(sfs[0]), int(tfs[0]), goal_dist_offset=float("nan"))
+
+
+def test_faces_with_a_seed_support_fire_twice(gpu_ctx_factory):
+    """cvp :726 fixes the seeds from the start, but they pop like everybody else: a face with a seed support is visited twice, and the
+    second visit re-applies its candidate through :411's float64-against-float32 comparison (tests/test_schedule_model.py, same
+    name).  The cases the round-5 soak found, on both step kernels: cutting faces and directions around the seed face bit for bit."""
+    base = terrain_case(224, 1)
+    costs, _ = layered_costs(base, "avg")
+    case = Case(base.mesh, costs, 1.0)
+    m = case.mesh
+    ctx = gpu_ctx_factory()
+    case.upload(ctx)
+    offv = np.array([0.02, 0.015, 0.0], np.float32)
+    for s, t, off in ((9309, 9983, 0.0), (37731, 10822, 2.5), (9063, 1479, float("inf")), (4358, 48191, 2.5), (9758, 31675, -1.0)):
+        sp, tp = m.xyz[s] + offv, m.xyz[t] + offv
+        sf, _ = case.om.containing_face(sp)
+        tf, _ = case.om.containing_face(tp)
+        ref = case.om.cvp(case.weights, case.costs, case.vn, sp, int(sf), int(tf), goal_dist_offset=off)
+        upd = ref.pred != np.arange(m.V)
+        for wide in (0, 1):
+            ctx.set_option("cvp_wide", wide)
+            out = ctx.plan_cvp(sp, int(sf), int(tf), goal_dist_offset=off)
+            assert out.code == ref.code
+            assert np.array_equal(out.dist.view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(out.pred, ref.pred)
+            assert np.array_equal(out.cutface[upd], ref.cutface[upd]), (s, t, off, wide)
+            assert np.array_equal(out.direction[upd].view(np.uint32), ref.direction[upd].view(np.uint32))
+            has = ref.has_vec.astype(bool)
+            assert np.array_equal(out.vecmap[has].view(np.uint32), ref.vecmap[has].view(np.uint32))
+    ctx.set_option("cvp_wide", None)

@@ -426,3 +426,22 @@ def test_cvp_negative_offsets_with_cascades(kind):
         off = (-0.02, -0.5, -3.0)[k % 3]
         ref, mod = run_cvp(case, sp, tp, offset=off, delta=(4, 12, 30)[k % 3] * mean_w, order=(0, 3)[k % 2], max_steps=100000)
         _assert_cvp_fields_equal(m, ref, mod)
+
+
+def test_cvp_faces_with_a_seed_support_fire_twice():
+    """A seed vertex is fixed from the start (cvp :726) but pops like every other vertex, so a face with a seed support is visited at
+    the pop of its other support AND again at the seed's own pop.  The second visit offers the same candidate; :411 compares the
+    float64 candidate with the stored float32 value, the re-application "succeeds" and takes predecessor / cutting face back from a
+    tying face that had them in between.  Found by the round-5 soak on the fragmented layered mesh (0.2 % of random plans, one vertex
+    each); the step kernels replay the first event only, seed_ring_fix both for the seeds' ring (mnav_eval.h::corner_fire_second)."""
+    base = Case(meshgen.terrain(224, 0.1, 1))
+    costs, _ = layered_costs(base, "avg")
+    case = Case(base.mesh, costs, 1.0)
+    m = case.mesh
+    offv = np.array([0.02, 0.015, 0.0], np.float32)
+    for s, t, off, order in ((9309, 9983, 0.0, 0), (37731, 10822, 2.5, 2), (9063, 1479, np.inf, 3), (4358, 48191, 2.5, 0), (9758, 31675, -1.0, 1)):
+        ref, mod = run_cvp(case, m.xyz[s] + offv, m.xyz[t] + offv, offset=off, delta=0.3, order=order)
+        assert np.array_equal(mod["dist"].view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(mod["pred"], ref.pred)
+        upd = ref.pred != np.arange(m.V)
+        assert np.array_equal(mod["cutface"][upd], ref.cutface[upd]), (s, t, off)
+        assert np.array_equal(mod["direction"][upd].view(np.uint32), ref.direction[upd].view(np.uint32))

@@ -1,0 +1,151 @@
+"""Soak of the plan paths against the oracle on the GPU box (round 5): random goals, batch sizes and goal_dist_offsets (negative
+ones included) through every Dijkstra engine `auto` uses and both CVP step kernels.  Every device plan carries the library's
+own fixed-point check (a mismatch is INTERNAL_ERROR); a sample of each leg is compared with the oracle bit for bit.
+    python tools/gpu_soak.py [seconds per leg, default 40]  ->  one JSON line (profiles/r05_soak.json)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402  (HIP runtime order, see tests/conftest.py)
+
+torch.cuda.init()
+from mesh_navigation_amd import capi, meshgen  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.common import Case, layered_costs  # noqa: E402
+
+BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+OFFSETS = (0.3, 0.0, 2.5, float("inf"), -0.05, -1.0, float("-inf"))
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "20260925")))
+out = {"seed_budget_s": BUDGET, "legs": {}}
+
+
+def beq(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+def dijkstra_leg(name, case, ctx, batch_sizes, t_budget, oracle_every):
+    m = case.mesh
+    t0 = time.perf_counter()
+    plans = calls = checked = 0
+    bad = []
+    while time.perf_counter() - t0 < t_budget:
+        n = int(rng.choice(batch_sizes))
+        off = float(OFFSETS[int(rng.integers(len(OFFSETS)))])
+        seeds = rng.choice(m.V, n, replace=False).astype(np.uint32)
+        targets = np.full(n, int(rng.integers(m.V)), np.uint32) if rng.random() < 0.7 else rng.integers(0, m.V, n).astype(np.uint32)
+        fields = bool(rng.random() < 0.5) and n <= 512
+        if n == 1:
+            o = ctx.plan_dijkstra(int(seeds[0]), int(targets[0]), goal_dist_offset=off, want_fields=fields)
+            codes, paths = np.array([o.code]), [o.path]
+            dist = [o.dist] if fields else None
+            pred = [o.pred] if fields else None
+        else:
+            b = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=off, want_fields=fields, path_cap=65536)
+            codes, paths = b["codes"], b["paths"]
+            dist = b["dist"] if fields else None
+            pred = b["pred"] if fields else None
+        calls += 1
+        plans += n
+        if not np.isin(codes, (0, 54)).all():
+            bad.append(dict(leg=name, n=n, off=off, codes=sorted(set(int(c) for c in codes))))
+            continue
+        if calls % oracle_every == 0 or calls == 1:
+            for k in rng.choice(n, min(n, 2), replace=False):
+                ref = case.om.dijkstra(case.weights, case.costs, int(seeds[k]), int(targets[k]), goal_dist_offset=off)
+                ok = int(codes[k]) == ref.code and np.array_equal(paths[k], ref.path)
+                if fields:
+                    ok = ok and beq(dist[k], ref.dist) and np.array_equal(pred[k], ref.pred)
+                checked += 1
+                if not ok:
+                    bad.append(dict(leg=name, n=n, off=off, k=int(k), seed=int(seeds[k]), target=int(targets[k]), fields=fields))
+    out["legs"][name] = dict(calls=calls, plans=plans, compared_with_oracle=checked, mismatches=len(bad), seconds=round(time.perf_counter() - t0, 1))
+    return bad
+
+
+def cvp_leg(name, case, ctx, t_budget):
+    m = case.mesh
+    free = np.where(case.costs < 0.5)[0]
+    offv = np.array([0.02, 0.015, 0.0], np.float32)
+    t0 = time.perf_counter()
+    plans = checked = 0
+    bad = []
+    while time.perf_counter() - t0 < t_budget:
+        off = float(OFFSETS[int(rng.integers(len(OFFSETS)))])
+        s, t = (int(x) for x in rng.choice(free, 2, replace=False))
+        sp, tp = m.xyz[s] + offv, m.xyz[t] + offv
+        sf, _ = case.om.containing_face(sp)
+        tf, _ = case.om.containing_face(tp)
+        if sf < 0 or tf < 0 or sf >= m.F or tf >= m.F:
+            continue
+        ctx.set_option("cvp_wide", int(rng.integers(2)))
+        o = ctx.plan_cvp(sp, int(sf), int(tf), goal_dist_offset=off)
+        ref = case.om.cvp(case.weights, case.costs, case.vn, sp, int(sf), int(tf), goal_dist_offset=off)
+        plans += 1
+        checked += 1
+        upd = ref.pred != np.arange(m.V)
+        ok = o.code == ref.code and beq(o.dist, ref.dist) and np.array_equal(o.pred, ref.pred) and np.array_equal(o.cutface[upd], ref.cutface[upd]) \
+            and beq(o.direction[upd], ref.direction[upd])
+        if not ok:
+            bad.append(dict(leg=name, off=off, seed=s, target=t, code=int(o.code), ref_code=int(ref.code)))
+    ctx.set_option("cvp_wide", None)
+    out["legs"][name] = dict(plans=plans, compared_with_oracle=checked, mismatches=len(bad), seconds=round(time.perf_counter() - t0, 1))
+    return bad
+
+
+bad = []
+# ---- 1M terrain (C2): single plans and small batches on the asynchronous engine, large ones on the tile-batch engine
+case = Case(meshgen.terrain(1000, 0.1, 21))
+ctx = capi.MnavContext(0)
+case.upload(ctx)
+bad += dijkstra_leg("c2_async_1_to_96_plans", case, ctx, [1, 1, 1, 2, 8, 33, 96], BUDGET, 6)
+bad += dijkstra_leg("c2_tile_batch_97_to_3000_plans", case, ctx, [97, 128, 500, 1024, 3000], BUDGET, 2)
+ctx.close()
+# ---- 224 x 224 layered costs (C3 shape: cost-inflated triangles, cascades): CVP on both step kernels
+base = Case(meshgen.terrain(224, 0.1, 1))
+costs, _ = layered_costs(base, "avg")
+c3 = Case(base.mesh, costs, 1.0)
+ctx = capi.MnavContext(0)
+c3.upload(ctx)
+bad += cvp_leg("c3_layered_fragments_cvp_both_kernels", c3, ctx, BUDGET / 2)      # (threshold 0.3: components of <= 266 vertices)
+ctx.close()
+# ---- 160 x 160 terrain, random per-vertex costs up to 0.9 with edge_cost_factor 1 (one component, non-causal updates, cascades)
+m2 = meshgen.terrain(160, 0.1, 5)
+adv = Case(m2, np.random.default_rng(2).uniform(0.0, 0.9, m2.V).astype(np.float32), 1.0)
+ctx = capi.MnavContext(0)
+adv.upload(ctx)
+bad += cvp_leg("adversarial_costs_cvp_both_kernels", adv, ctx, BUDGET)
+ctx.close()
+# ---- 10M terrain (C4): single plans on the asynchronous engine
+if os.environ.get("SOAK_C4", "1") != "0":
+    mesh = meshgen.terrain(3163, 0.1, 4)
+    om = O.OracleMesh(mesh.xyz, mesh.faces)
+    w = meshgen.edge_lengths(mesh)
+    ctx = capi.MnavContext(0)
+    ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, None)
+    zeros = np.zeros(mesh.V, np.float32)
+    ctx.upload_costs(zeros, w)
+    t0 = time.perf_counter()
+    n = cmp = 0
+    b4 = []
+    while time.perf_counter() - t0 < BUDGET:
+        s, t = int(rng.integers(mesh.V)), int(rng.integers(mesh.V))
+        off = float(OFFSETS[int(rng.integers(len(OFFSETS)))])
+        o = ctx.plan_dijkstra(s, t, goal_dist_offset=off, want_fields=False)
+        n += 1
+        if o.code not in (0, 54):
+            b4.append(dict(leg="c4", seed=s, target=t, off=off, code=int(o.code)))
+        elif n % 12 == 1:
+            ref = om.dijkstra(w, zeros, s, t, goal_dist_offset=off)
+            cmp += 1
+            if o.code != ref.code or not np.array_equal(o.path, ref.path):
+                b4.append(dict(leg="c4", seed=s, target=t, off=off))
+    out["legs"]["c4_async_single_plans_10M"] = dict(plans=n, compared_with_oracle=cmp, mismatches=len(b4), seconds=round(time.perf_counter() - t0, 1))
+    bad += b4
+    ctx.close()
+out["mismatches"] = bad[:20]
+out["ok"] = not bad
+print(json.dumps(out))
