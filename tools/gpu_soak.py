@@ -27,7 +27,7 @@ def beq(a, b):
     return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
 
 
-def dijkstra_leg(name, case, ctx, batch_sizes, t_budget, oracle_every):
+def dijkstra_leg(name, case, ctx, batch_sizes, t_budget, oracle_every, limits=(1.0,)):
     m = case.mesh
     t0 = time.perf_counter()
     plans = calls = checked = 0
@@ -38,13 +38,14 @@ def dijkstra_leg(name, case, ctx, batch_sizes, t_budget, oracle_every):
         seeds = rng.choice(m.V, n, replace=False).astype(np.uint32)
         targets = np.full(n, int(rng.integers(m.V)), np.uint32) if rng.random() < 0.7 else rng.integers(0, m.V, n).astype(np.uint32)
         fields = bool(rng.random() < 0.5) and n <= 512
+        lim = float(rng.choice(limits))
         if n == 1:
-            o = ctx.plan_dijkstra(int(seeds[0]), int(targets[0]), goal_dist_offset=off, want_fields=fields)
+            o = ctx.plan_dijkstra(int(seeds[0]), int(targets[0]), goal_dist_offset=off, cost_limit=lim, want_fields=fields)
             codes, paths = np.array([o.code]), [o.path]
             dist = [o.dist] if fields else None
             pred = [o.pred] if fields else None
         else:
-            b = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=off, want_fields=fields, path_cap=65536)
+            b = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=off, cost_limit=lim, want_fields=fields, path_cap=65536)
             codes, paths = b["codes"], b["paths"]
             dist = b["dist"] if fields else None
             pred = b["pred"] if fields else None
@@ -55,13 +56,13 @@ def dijkstra_leg(name, case, ctx, batch_sizes, t_budget, oracle_every):
             continue
         if calls % oracle_every == 0 or calls == 1:
             for k in rng.choice(n, min(n, 2), replace=False):
-                ref = case.om.dijkstra(case.weights, case.costs, int(seeds[k]), int(targets[k]), goal_dist_offset=off)
+                ref = case.om.dijkstra(case.weights, case.costs, int(seeds[k]), int(targets[k]), goal_dist_offset=off, cost_limit=lim, invalid=case.invalid)
                 ok = int(codes[k]) == ref.code and np.array_equal(paths[k], ref.path)
                 if fields:
                     ok = ok and beq(dist[k], ref.dist) and np.array_equal(pred[k], ref.pred)
                 checked += 1
                 if not ok:
-                    bad.append(dict(leg=name, n=n, off=off, k=int(k), seed=int(seeds[k]), target=int(targets[k]), fields=fields))
+                    bad.append(dict(leg=name, n=n, off=off, lim=lim, k=int(k), seed=int(seeds[k]), target=int(targets[k]), fields=fields))
     out["legs"][name] = dict(calls=calls, plans=plans, compared_with_oracle=checked, mismatches=len(bad), seconds=round(time.perf_counter() - t0, 1))
     return bad
 
@@ -83,14 +84,35 @@ def cvp_leg(name, case, ctx, t_budget):
             continue
         ctx.set_option("cvp_wide", int(rng.integers(2)))
         o = ctx.plan_cvp(sp, int(sf), int(tf), goal_dist_offset=off)
-        ref = case.om.cvp(case.weights, case.costs, case.vn, sp, int(sf), int(tf), goal_dist_offset=off)
+        ref = case.om.cvp(case.weights, case.costs, case.vn, sp, int(sf), int(tf), goal_dist_offset=off, invalid=case.invalid)
         plans += 1
         checked += 1
         upd = ref.pred != np.arange(m.V)
+        has = ref.has_vec.astype(bool)
         ok = o.code == ref.code and beq(o.dist, ref.dist) and np.array_equal(o.pred, ref.pred) and np.array_equal(o.cutface[upd], ref.cutface[upd]) \
-            and beq(o.direction[upd], ref.direction[upd])
+            and beq(o.direction[upd], ref.direction[upd]) and beq(o.vecmap[has], ref.vecmap[has])
+        if ok and ref.code == 0 and plans % 3 == 0:                        # the walk along the resident field (cvp :920-951)
+            sw = float(rng.choice([0.4, 0.15, 0.05]))
+            rc, ppos, pface = case.om.cvp_backtrack(ref.vecmap, ref.has_vec, sp, int(sf), tp, int(tf), step_width=sw, cap=8192)
+            st, pos, face = ctx.backtrack_cvp(sp, int(sf), tp, int(tf), step_width=sw, cap=8192)
+            ok = (st == 1) == (rc == 0) and np.array_equal(face, pface) and beq(pos, ppos)
         if not ok:
             bad.append(dict(leg=name, off=off, seed=s, target=t, code=int(o.code), ref_code=int(ref.code)))
+        if plans % 40 == 0:                                                 # a batch on the wide kernel (plan groups on their own streams)
+            nb = int(rng.choice([33, 48, 80]))
+            vs = rng.choice(free, nb, replace=False)
+            sps = np.stack([m.xyz[v] + offv for v in vs]).astype(np.float32)
+            sfs = np.array([case.om.containing_face(q)[0] for q in sps], np.int64)
+            keep = (sfs >= 0) & (sfs < m.F)
+            sps, sfs = sps[keep], sfs[keep].astype(np.uint32)
+            ctx.set_option("cvp_wide", None)
+            b = ctx.plan_cvp_batch(sps, sfs, np.full(len(sfs), tf, np.uint32), goal_dist_offset=off, want_fields=True)
+            for k in rng.choice(len(sfs), 2, replace=False):
+                r2 = case.om.cvp(case.weights, case.costs, case.vn, sps[k], int(sfs[k]), int(tf), goal_dist_offset=off, invalid=case.invalid)
+                checked += 1
+                if int(b["codes"][k]) != r2.code or not beq(b["dist"][k], r2.dist) or not np.array_equal(b["pred"][k], r2.pred):
+                    bad.append(dict(leg=name + "/batch", off=off, n=int(len(sfs)), k=int(k), seed_face=int(sfs[k]), target_face=int(tf)))
+            plans += len(sfs)
     ctx.set_option("cvp_wide", None)
     out["legs"][name] = dict(plans=plans, compared_with_oracle=checked, mismatches=len(bad), seconds=round(time.perf_counter() - t0, 1))
     return bad
@@ -118,6 +140,15 @@ adv = Case(m2, np.random.default_rng(2).uniform(0.0, 0.9, m2.V).astype(np.float3
 ctx = capi.MnavContext(0)
 adv.upload(ctx)
 bad += cvp_leg("adversarial_costs_cvp_both_kernels", adv, ctx, BUDGET)
+ctx.close()
+# ---- 300 x 300 terrain with random costs, 2 % invalid vertices, cost limits that cut parts of the mesh off: every Dijkstra engine
+m3 = meshgen.terrain(300, 0.1, 9)
+r3 = np.random.default_rng(4)
+cm = Case(m3, r3.uniform(0.0, 1.0, m3.V).astype(np.float32), 0.7, (r3.uniform(size=m3.V) < 0.02).astype(np.uint8))
+ctx = capi.MnavContext(0)
+cm.upload(ctx)
+bad += dijkstra_leg("costs_invalid_limits_1_to_96_plans", cm, ctx, [1, 1, 5, 40, 96], BUDGET / 2, 3, limits=(1.0, 0.8, 0.55))
+bad += dijkstra_leg("costs_invalid_limits_97_to_700_plans", cm, ctx, [97, 300, 700], BUDGET / 2, 1, limits=(1.0, 0.8, 0.55))
 ctx.close()
 # ---- 10M terrain (C4): single plans on the asynchronous engine
 if os.environ.get("SOAK_C4", "1") != "0":
