@@ -23,7 +23,9 @@ def main():
     out = dict(grid=N, V=int(mesh.V))
     ref_paths = None
     variants = [("tiled", {}), ("async", {}), ("async_wg512", dict(async_wg_per_plan=512)), ("async_band2", dict(async_band_mult=2.0)),
-                ("async_band8", dict(async_band_mult=8.0)), ("async_band3", dict(async_band_mult=3.0)), ("async_band6", dict(async_band_mult=6.0))]
+                ("async_band8", dict(async_band_mult=8.0)), ("async_band3", dict(async_band_mult=3.0)), ("async_band6", dict(async_band_mult=6.0)),
+                ("async_cu5", dict(async_wg_per_cu=5)), ("async_cu3", dict(async_wg_per_cu=3)), ("async_cu2", dict(async_wg_per_cu=2)),
+                ("async_band1.5", dict(async_band_mult=1.5)), ("async_band1", dict(async_band_mult=1.0))]
     if len(sys.argv) > 3:
         variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
     for label, opts in variants:
