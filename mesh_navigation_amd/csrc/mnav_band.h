@@ -400,12 +400,23 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
     const uint32_t* list = P.list[cur.it & 1];
     const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
     const uint32_t ntot = cur.n + cur.wread;
+    if (cur.serial) {
+      // a band that the concurrent evaluation cannot settle (controller_core): ONE group of ONE wave, entry after entry, every
+      // store of an entry visible before the next one is read
+      if (blockIdx.x == 0)
+        for (uint32_t i = 0; i < ntot; ++i) {
+          const uint32_t v = i < cur.n ? list[i] : wprev[i - cur.n];
+          group_process<PLANNER, false>(S, P, cur, grp == 0, v, sub);
+          __threadfence();
+        }
+    } else {
     const uint32_t rounds = (ntot + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t i = g0 + r * ngroups;
       const bool active = i < ntot;
       const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
       group_process<PLANNER, false>(S, P, cur, active, v, sub);
+    }
     }
   }
   const float wmin = wave_min(S.lmin);

@@ -371,6 +371,7 @@ struct Ctl {
   uint32_t cuts;       // statistics: band cuts (kCutAfter)
   uint32_t epoch;      // id of the current waiting list (1 for the list the first steps append to, then step index of the
                        // epoch step + 2); Plan.wstamp (0 = never parked) dedups with it
+  uint32_t serial;     // 1: the steps of this band run on ONE 8-lane group, entry after entry (see controller_core)
   uint32_t arm_vertex; // CVP: the robot-face vertex whose pop armed goal_dist (kNone until then): pops up to and including its
                        // own met goal_dist = +inf at :754 and expand whatever their value (passes_goal_cut)
 };
@@ -673,11 +674,20 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
       if (thr > p.thr) thr = p.thr;
       q.thr = thr;
       q.repair = 2; q.band_new = 1; q.band_steps = 0; q.shrinks = p.shrinks + 1;
+    } else if (P.seed_mask != nullptr && q.band_steps >= kBandStepLimit) {
+      // The band is one key wide and STILL moving: vertices of exactly the same pop time (ties are common around isolated
+      // lethal vertices on a regular grid) that keep each other flipping.  Every sequential order settles such a band (the CPU
+      // model does, in list, reversed, random and Jacobi order); what does not is the device's concurrent in-place evaluation,
+      // where a vertex is read while its neighbour's evaluation is half stored.  The rest of the band runs entry after entry on
+      // one 8-lane group (k_step, cur.serial): no concurrency, no torn state.  (Found by the round-5 soak: 16 of 209 random
+      // sparse-lethal maps ran into the step cap here.)
+      q.serial = 1;
     }
     return q;                                                          // band still moving
   }
   q.thr_fixed = p.thr;
   q.band_steps = 0;
+  q.serial = 0;
   if (!p.repair) q.bands = p.bands + 1;
   if (!q.armed && !out_of_steps) {
     try_arm(P, q);

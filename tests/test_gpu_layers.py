@@ -141,3 +141,47 @@ def test_incremental_combination_equals_the_full_pass(gpu_ctx_factory):
         assert np.array_equal(bits(vc), bits(vc_full)) and np.array_equal(bits(w), bits(w_full))
         want = O.combine([a, b2], [1.0, 0.5], mode)
         assert np.array_equal(bits(vc), bits(want))
+
+
+def _sparse_lethal_case(i):
+    """the generator of tools/gpu_soak.py's inflation fuzz (round 5), configurations by index"""
+    rng = np.random.default_rng(5000 + i)
+    N = int(rng.choice([64, 128, 200])); seed = int(rng.integers(1000)); amp = float(rng.choice([0.3, 0.8]))
+    kind = int(rng.integers(3)); a = float(rng.choice([0.3, 0.5])); b = int(rng.choice([100, 400])); c = int(rng.choice([30, 300]))
+    use_inv = bool(rng.random() < 0.5); radius = float(rng.choice([0.25, 0.4, 0.9, 1.3]))
+    case = Case(meshgen.terrain(N, 0.1, seed, amplitude=amp))
+    m = case.mesh
+    lethal = np.zeros(m.V, np.uint8)
+    if kind == 0:
+        _, lethal = case.om.steepness(case.vn, a)
+    elif kind == 1:
+        lethal[m.edges[rng.choice(m.E, max(1, m.E // b), replace=False)].ravel()] = 1
+        lethal[rng.choice(m.V, max(1, m.V // 80), replace=False)] = 1
+    else:
+        lethal[rng.choice(m.V, max(1, m.V // c), replace=False)] = 1
+    inv = None
+    if use_inv:
+        inv = np.zeros(m.V, np.uint8)
+        inv[rng.choice(m.V, m.V // 40, replace=False)] = 1
+    return case, lethal, inv, radius
+
+
+@pytest.mark.parametrize("i", [129, 40, 16])
+def test_isolated_lethal_vertices_with_tied_pop_times_settle(gpu_ctx_factory, i):
+    """Isolated lethal vertices on the regular grid make vertices of EXACTLY the same pop time; such a band, one key wide, kept
+    flipping under the concurrent in-place evaluation until the step cap (16 of 209 random maps of the round-5 soak, all of this
+    kind: INTERNAL_ERROR).  The controller now runs the rest of such a band entry after entry on one 8-lane group (Ctl.serial):
+    distances and costs are the reference's bits again.  (Not all of them: 2 of the first 85 maps of that fuzz still end in
+    INTERNAL_ERROR -- configurations 67 and 84 --, where the sequential pass in list order cycles as well)"""
+    case, lethal, inv, radius = _sparse_lethal_case(i)
+    cfg = O.InflationCfg.defaults()
+    cfg.inflation_radius = radius
+    cost, dist, _ = case.om.inflation(lethal, case.edge_dist, cfg, invalid=inv)
+    ctx = gpu_ctx_factory()
+    upload(ctx, case)
+    ctx.layer_upload(0, np.zeros(case.mesh.V, np.float32), lethal)
+    st = ctx.layer_inflation(1, 0, inflation_radius=radius, invalid=inv)
+    c, _, d = ctx.layer_download(1, distances=True)
+    assert np.array_equal(bits(d), bits(dist)), int((bits(d) != bits(dist)).sum())
+    assert np.array_equal(bits(c), bits(cost))
+    assert st["steps"] < 5000

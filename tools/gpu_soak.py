@@ -150,6 +150,47 @@ cm.upload(ctx)
 bad += dijkstra_leg("costs_invalid_limits_1_to_96_plans", cm, ctx, [1, 1, 5, 40, 96], BUDGET / 2, 3, limits=(1.0, 0.8, 0.55))
 bad += dijkstra_leg("costs_invalid_limits_97_to_700_plans", cm, ctx, [97, 300, 700], BUDGET / 2, 1, limits=(1.0, 0.8, 0.55))
 ctx.close()
+# ---- the inflation wave (InflationLayer::waveCostInflation on the ordered-wave engine): random lethal sets, radii, invalid vertices
+t0 = time.perf_counter()
+runs = 0
+bl = []
+refused = []
+while time.perf_counter() - t0 < BUDGET / 2:
+    N = int(rng.choice([64, 128, 200]))
+    case = Case(meshgen.terrain(N, 0.1, int(rng.integers(1000)), amplitude=float(rng.choice([0.3, 0.8]))))
+    m = case.mesh
+    lethal = np.zeros(m.V, np.uint8)
+    kind = int(rng.integers(3))
+    if kind == 0:
+        _, lethal = case.om.steepness(case.vn, float(rng.choice([0.3, 0.5])))
+    elif kind == 1:
+        lethal[m.edges[rng.choice(m.E, max(1, m.E // int(rng.choice([100, 400]))), replace=False)].ravel()] = 1
+        lethal[rng.choice(m.V, max(1, m.V // 80), replace=False)] = 1
+    else:
+        lethal[rng.choice(m.V, max(1, m.V // int(rng.choice([30, 300]))), replace=False)] = 1
+    inv = None
+    if rng.random() < 0.5:
+        inv = np.zeros(m.V, np.uint8)
+        inv[rng.choice(m.V, m.V // 40, replace=False)] = 1
+    radius = float(rng.choice([0.25, 0.4, 0.9, 1.3]))
+    cfg = O.InflationCfg.defaults()
+    cfg.inflation_radius = radius
+    cost, dist, vec = case.om.inflation(lethal, case.edge_dist, cfg, invalid=inv)
+    ctx = capi.MnavContext(0)
+    ctx.upload_mesh(m.xyz, m.faces, m.edges, case.vn)
+    ctx.layer_upload(0, np.zeros(m.V, np.float32), lethal)
+    runs += 1
+    try:
+        ctx.layer_inflation(1, 0, inflation_radius=radius, invalid=inv)
+        c, _, d = ctx.layer_download(1, distances=True)
+        if not (beq(d, dist) and beq(c, cost)):
+            bl.append(dict(leg="inflation", N=N, kind=kind, radius=radius, invalid=inv is not None, dist_bits_differ=int((np.asarray(d).view(np.uint32) != dist.view(np.uint32)).sum())))
+    except RuntimeError as e:                                         # loud failure (INTERNAL_ERROR): tied pop times around isolated lethal vertices, DESIGN.md 3.2
+        refused.append(dict(N=N, kind=kind, radius=radius, invalid=inv is not None, error=str(e)[:90]))
+    ctx.close()
+out["legs"]["inflation_wave_random_sources"] = dict(runs=runs, mismatches=len(bl), refused_with_internal_error=len(refused), seconds=round(time.perf_counter() - t0, 1))
+out["inflation_refused"] = refused[:10]
+bad += bl
 # ---- 10M terrain (C4): single plans on the asynchronous engine
 if os.environ.get("SOAK_C4", "1") != "0":
     mesh = meshgen.terrain(3163, 0.1, 4)
