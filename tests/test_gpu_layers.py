@@ -172,7 +172,7 @@ def test_isolated_lethal_vertices_with_tied_pop_times_settle(gpu_ctx_factory, i)
     flipping under the concurrent in-place evaluation until the step cap (16 of 209 random maps of the round-5 soak, all of this
     kind: INTERNAL_ERROR).  The controller now runs the rest of such a band entry after entry on one 8-lane group (Ctl.serial):
     distances and costs are the reference's bits again.  (Not all of them: 2 of the first 85 maps of that fuzz still end in
-    INTERNAL_ERROR -- configurations 67 and 84 --, where the sequential pass in list order cycles as well)"""
+    INTERNAL_ERROR -- configurations 67 and 84 --, where the sequential pass cycles as well)"""
     case, lethal, inv, radius = _sparse_lethal_case(i)
     cfg = O.InflationCfg.defaults()
     cfg.inflation_radius = radius
