@@ -144,7 +144,7 @@ def test_incremental_combination_equals_the_full_pass(gpu_ctx_factory):
 
 
 def _sparse_lethal_case(i):
-    """the generator of tools/gpu_soak.py's inflation fuzz (round 5), configurations by index"""
+    """the generator of tools/gpu_infl_fuzz.py (round 5), configurations by index"""
     rng = np.random.default_rng(5000 + i)
     N = int(rng.choice([64, 128, 200])); seed = int(rng.integers(1000)); amp = float(rng.choice([0.3, 0.8]))
     kind = int(rng.integers(3)); a = float(rng.choice([0.3, 0.5])); b = int(rng.choice([100, 400])); c = int(rng.choice([30, 300]))
