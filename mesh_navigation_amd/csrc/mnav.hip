@@ -72,6 +72,7 @@ constexpr int kChunk = 96;  // step launches per graph replay; multiple of 6 (sl
 }  // namespace
 #include "mnav_tb.h"
 #include "mnav_tb_finalize.h"
+#include "mnav_tbv.h"
 #include "mnav_walk.h"
 
 // One back-tracking job: the plan's resident vector map and the two ends of the walk.
@@ -299,6 +300,7 @@ void apply_options(mnav_ctx* ctx)
   const Options& o = ctx->opt;
   ctx->use_graph = !opt_on(o.no_graph);
   if (opt_set(o.dijkstra_engine)) { const int e = (int)o.dijkstra_engine; ctx->dij_engine = (e == 0 || e == 1 || e == 5 || e == 6) ? e : 3; }
+  else ctx->dij_engine = 3;                                           // unset (NaN): the built-in default, auto
   ctx->max_steps = opt_u32(o.max_steps, ctx->max_steps_auto);
   ctx->max_wall_s = opt_set(o.max_wall_s) ? o.max_wall_s : 120.0;
   ctx->cvp_verify = !opt_set(o.cvp_verify) || o.cvp_verify != 0.0;
@@ -1266,6 +1268,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
   // instead of leaving a tail (results are mapped back through `map`).
   // engine: 0 = tiled rounds, 1 = band steps, 3 = auto, 5 = tile-batch (plan-vectorised, large batches), 6 = asynchronous tiles
   int engine = ctx->dij_engine;
+  const bool engine_auto = engine == 3;
   // paths only (nothing V-sized asked for, nothing kept resident): no finalize pass, predecessors along the path only
   ctx->lazy_paths = ctx->allow_lazy_paths && !dist_out && !pred_out && !want_vecmap && !ctx->resident_vecmap;
   {
@@ -1331,7 +1334,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
            : (engine == 6) ? run_dijkstra_async(ctx, m, in, offset)
            : (engine == 5) ? run_dijkstra_tb(ctx, m, in, offset)
                            : run_plans<kPlannerDijkstra>(ctx, m, in, offset, want_path);
-    if (engine == 6 && rc == 2) { engine = 0; rc = run_dijkstra_tiled(ctx, m, in, offset); }   // ticket ring exhausted: the rounds start over
+    // ticket ring exhausted: the rounds start over.  So they do when the in-kernel watchdog gave up (rc 3) on an engine that `auto`
+    // picked: the rounds have the whole max_wall_s (a serialising profiler, a mesh far beyond the tuned sizes)
+    if (engine == 6 && (rc == 2 || (rc == 3 && engine_auto))) { ctx->err.clear(); engine = 0; rc = run_dijkstra_tiled(ctx, m, in, offset); }
+    if (rc == 3) rc = -1;
     MTRACE("engine returned");
     if (rc != 0) (void)hipStreamSynchronize(ctx->stream);             // nothing of a failed / cancelled call stays in flight
     if (rc < 0) return MNAV_INTERNAL_ERROR;
@@ -1662,6 +1668,10 @@ int mnav_set_option(mnav_ctx* ctx, const char* name, double value)
   if (!ctx || !name) return -1;
   double* f = ctx->opt.find(name);
   if (!f) { ctx->err = std::string("unknown option: ") + name; return -1; }
+  if (!strcmp(name, "dijkstra_engine") && value == value) {           // the retired engines are refused like by mnav_set_dijkstra_engine
+    const int e = (int)value;
+    if (value != (double)e || e < 0 || e > 6 || e == 2 || e == 4) { ctx->err = "dijkstra_engine: 0, 1, 3 (auto), 5 or 6"; return -1; }
+  }
   *f = value;                                                         // NaN: back to the built-in default
   apply_options(ctx);
   drop_graphs(ctx);                                                   // (captured launch sequences may hold what the option decides)

@@ -295,8 +295,8 @@ int run_dijkstra_tiled(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   return rc;
 }
 
-// Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1, 1 (cancelled) or
-// 2 (the ticket ring ran out: nothing of the call is usable, run it on another engine).
+// Dijkstra through the asynchronous tile engine (mnav_async.h): ONE launch for the whole call.  Returns 0, -1, 1 (cancelled),
+// 2 (the ticket ring ran out: nothing of the call is usable, run it on another engine) or 3 (the in-kernel watchdog gave up).
 int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
   if (ensure_slots(ctx, n, false, false, ctx->want_vec)) return -1;
@@ -328,6 +328,7 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     T.seed = in[i].seed[0]; T.target = in[i].target[0]; T.offset = offset;
     T.max_rounds = 0x7FFFFFF0u;
     T.cancel = ctx->d_cancel;
+    T.pend1_is_state = 1u;
     // band of the plan in tile widths (<= 0: one band, every solve runs to its tile's fixed point); measured round 5, ms per call at
     // 1 / 8 / 47 / 64 plans on the 1M mesh: 2 widths 7.1 / 11.1 / 20.8 / 25.4, 3: 6.9 / 10.8 / 21.9 / 26.8, 4: 6.8 / 9.9 / 23.2 / 27.7, 6: 7.2 / 10.3 / 25.7 / 31.8, 8: 7.1 / 10.6 / 28.2 / 34.8
     T.band = (float)((opt_set(ctx->opt.async_band_mult) ? ctx->opt.async_band_mult : (n >= 32u ? 2.0 : 4.0)) * ctx->tile_band_auto);
@@ -384,7 +385,9 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
   uint32_t G = (uint32_t)std::min<uint64_t>((uint64_t)ncu * per_cu, (uint64_t)n * per_plan);
   if (G > M.ntiles * n) G = M.ntiles * n;
   if (G < 1) G = 1;
-  const double guard_s = opt_set(ctx->opt.async_max_s) && ctx->opt.async_max_s > 0.0 ? ctx->opt.async_max_s : std::min(ctx->max_wall_s, 10.0);   // in-kernel give-up (100 MHz wall clock)
+  // in-kernel give-up (100 MHz wall clock): async_max_s when set; a max_wall_s the caller set himself is honoured; 10 s otherwise
+  const double guard_s = opt_set(ctx->opt.async_max_s) && ctx->opt.async_max_s > 0.0 ? ctx->opt.async_max_s
+                       : opt_set(ctx->opt.max_wall_s) ? ctx->max_wall_s : std::min(ctx->max_wall_s, 10.0);
   const unsigned long long limit_ticks = (unsigned long long)(guard_s * 1.0e8);
   ctx->ms_chunks = 0.0;
   HIPCHK(hipEventRecord(ctx->evc[0], ctx->stream));
@@ -402,7 +405,7 @@ int run_dijkstra_async(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in,
     fprintf(stderr, "[mnav] async: %u plans, %u workgroups, %.3f ms, abort %u, tickets %u, polls %u, retired beyond the bound %u, plan switches %u\n", n, G, ctx->ms_chunks, h.abort, h.tickets, h.polls, h.dropped, h.switches);
   if (h.abort == 3u || ctx->cancel.load(std::memory_order_relaxed)) return 1;   // :350-354
   if (h.abort == 5u) return 2;                                         // out of ticket slots: the caller re-runs the call on the tile rounds
-  if (h.abort) { ctx->err = "asynchronous tile engine gave up (in-kernel wall-clock guard)"; return -1; }
+  if (h.abort) { ctx->err = "asynchronous tile engine gave up (in-kernel wall-clock guard)"; return 3; }   // (the caller turns 3 into a failure unless `auto` picked the engine)
   if (h.done_plans != n) { ctx->err = "asynchronous tile engine left plans unfinished"; return -1; }
   if (!ctx->lazy_paths) launch_finalize(ctx, n);
   HIPCHK(hipGetLastError());

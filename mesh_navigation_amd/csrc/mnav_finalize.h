@@ -81,7 +81,9 @@ __global__ __launch_bounds__(kTileBlock) void k_dij_finalize(const Plan* __restr
       MNAV_GLOBAL const float* g_tlast = as_global((const float*)T.tlast);
       MNAV_GLOBAL const uint32_t* g_p0 = as_global((const uint32_t*)T.pend[0]);
       MNAV_GLOBAL const uint32_t* g_p1 = as_global((const uint32_t*)T.pend[1]);
-      if (!(g_tlast[t] > -inf_f()) && g_p0[t] == kInfBits && g_p1[t] == kInfBits) continue;
+      // (after the asynchronous engine pend[1] is the tiles' state word, 0 when the plan has finished: every tile that was ever woken
+      //  was solved or dropped there, and both mark tlast)
+      if (!(g_tlast[t] > -inf_f()) && g_p0[t] == kInfBits && (T.pend1_is_state || g_p1[t] == kInfBits)) continue;
     }
     const uint32_t v0 = g_vptr[t], nv = g_vptr[t + 1] - v0;
     const uint32_t h0 = g_hptr[t], nh = g_hptr[t + 1] - h0;

@@ -154,7 +154,9 @@ static ShardDev shard_dev(const mnav_ctx* ctx)
 
 int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex, double goal_dist_offset, double cost_limit)
 {
-  if (ctx) ctx->shard.finalized = false;
+  // a goal tie set for THIS plan is consumed here on every exit path: an early return must not leave it for the next plan
+  uint32_t goal_tie1 = 0u;
+  if (ctx) { ctx->shard.finalized = false; goal_tie1 = ctx->shard.goal_tie1; ctx->shard.goal_tie1 = 0u; }
   if (check_ready(ctx)) return -1;
   if (!ctx->shard.ready) { ctx->err = "mnav_shard_setup has not been called"; return -1; }
   if (seed_vertex >= ctx->V || target_vertex >= ctx->V) { ctx->err = "vertex id out of range"; return -1; }
@@ -181,7 +183,7 @@ int mnav_shard_begin(mnav_ctx* ctx, uint32_t seed_vertex, uint32_t target_vertex
   P.row_ptr = ctx->d_row_ptr; P.nbr = ctx->d_nbr; P.crn_ptr = ctx->d_crn_ptr; P.crn = ctx->d_crn; P.blocked = ctx->d_blocked;
   P.dist = s.dist; P.pred = s.pred; P.dirn = s.dirn; P.cutf = s.cutf; P.stamp = s.stamp; P.dirty = s.dirty;
   P.list[0] = s.list0; P.list[1] = s.list1; P.wlist[0] = s.wlist0; P.wlist[1] = s.wlist1; P.wstamp = s.wstamp; P.cap = ctx->V; P.ctl = s.ctl; P.cnt = s.cnt;
-  P.offset = goal_dist_offset; P.goal_tie1 = ctx->shard.goal_tie1; ctx->shard.goal_tie1 = 0u; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
+  P.offset = goal_dist_offset; P.goal_tie1 = goal_tie1; P.max_steps = 0x7FFFFFF0u; P.walk_max = kKeyWalkMax; P.descend_max = kDescendWalkMax;
   for (int k = 0; k < 3; ++k) { P.seed[k] = kNone; P.target[k] = kNone; P.seed_expands[k] = 1; P.target_expands[k] = 1; }
   P.seed[0] = seed_vertex; P.target[0] = target_vertex; P.seed_face = kNone;
   TilePlan T; memset(&T, 0, sizeof(T));
@@ -365,6 +367,7 @@ int mnav_shard_finalize(mnav_ctx* ctx, float* dist_buf_dev, uint32_t* pred_buf_d
 int mnav_shard_set_goal_tie(mnav_ctx* ctx, uint32_t tie_id)
 {
   if (!ctx) return -1;
+  if (tie_id > ctx->V) { ctx->err = "mnav_shard_set_goal_tie: the tie id is a position among the part's ids (<= V)"; return -1; }
   ctx->shard.goal_tie1 = tie_id + 1u;                                 // taken (and cleared) by the next mnav_shard_begin
   return 0;
 }

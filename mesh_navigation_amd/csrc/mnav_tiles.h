@@ -43,6 +43,8 @@ struct TilePlan {
   uint32_t* parked;        // asynchronous engine (mnav_async.h): the two parked lists of the plan, 2 x kParkedLists x ntiles tile ids
   const uint8_t* owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
                            // neighbourhood is incomplete here (its value arrives through the exchange); null: every vertex is owned
+  uint32_t pend1_is_state; // asynchronous engine: pend[1] holds the tiles' state words (0 at the end), not wake-up values -- the
+                           // finalize pass then tells an untouched tile by tlast and pend[0] alone
 };
 
 constexpr int kTileBlock = 256;

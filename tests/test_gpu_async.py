@@ -137,6 +137,17 @@ def test_async_ring_overflow_falls_back_to_the_rounds_and_watchdog_reports(gpu_c
     ctx3.set_option("async_max_s", None)                               # and the context is usable afterwards
     refb = big.om.dijkstra(big.weights, big.costs, big.mesh.vertex_at(0.05, 0.05), big.mesh.vertex_at(0.95, 0.95))
     assert_dijkstra_equal(ctx3.plan_dijkstra(big.mesh.vertex_at(0.05, 0.05), big.mesh.vertex_at(0.95, 0.95)), refb)
+    # when `auto` picked the engine, a watchdog give-up is not the caller's problem: the call is re-run on the tile rounds
+    ctx3.set_option("dijkstra_engine", None)                           # NaN = the built-in default: auto (not "whatever was set last")
+    ctx3.set_option("async_max_s", 2e-5)
+    o = ctx3.plan_dijkstra(big.mesh.vertex_at(0.05, 0.05), big.mesh.vertex_at(0.95, 0.95))
+    assert o.stats["launches"] > 1
+    assert_dijkstra_equal(o, refb)
+    ctx3.set_option("async_max_s", None)
+    o = ctx3.plan_dijkstra(big.mesh.vertex_at(0.05, 0.05), big.mesh.vertex_at(0.95, 0.95))
+    assert o.stats["launches"] == 1                                     # auto again: the asynchronous engine, one launch
+    with pytest.raises(ValueError):                                     # the retired engines are refused by name and by option alike
+        ctx3.set_option("dijkstra_engine", 2)
 
 
 def test_cancel_stops_a_running_async_call(gpu_ctx_factory):

@@ -19,7 +19,7 @@ def main():
     mesh = meshgen.terrain(N, 0.1, 21 if N <= 1000 else 4)
     w = meshgen.edge_lengths(mesh)
     robot = mesh.vertex_at(0.9, 0.9)
-    goals = np.random.default_rng(5).choice(mesh.V, size=80, replace=False).astype(np.uint32)
+    goals = np.random.default_rng(5).choice(mesh.V, size=128, replace=False).astype(np.uint32)
     out = dict(grid=N, V=int(mesh.V))
     ref_paths = None
     variants = [("tiled", {}), ("async", {}), ("async_wg512", dict(async_wg_per_plan=512)), ("async_band2", dict(async_band_mult=2.0)),
@@ -36,7 +36,7 @@ def main():
         ctx.upload_costs(np.zeros(mesh.V, np.float32), w)
         ctx.set_dijkstra_engine("tiled" if label == "tiled" else "async")
         res = {}
-        for nb in (1, 8, 47, 64):
+        for nb in (1, 8, 47, 96):
             tg = np.full(nb, robot, np.uint32)
             ctx.plan_dijkstra_batch(goals[:nb], tg)
             ts, dev = [], []
