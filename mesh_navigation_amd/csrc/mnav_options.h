@@ -23,6 +23,7 @@
   X(tile_band) X(rounds_band_mult)                                                                                                       \
   X(tb_tile)             /* tile-batch engine: rows per tile, read when its streams are built */                                          \
   X(tb_no_prefill) X(tb_band_mult) X(tb_waves_per_cu)                                                                                    \
+  X(tb_kernel)           /* tile-batch solve: 0 = k_tb_solve_q (16 plans per quarter of a wave, distances in LDS), 1 = k_tbv_solve (64 plans per wave, distances in registers); default: by the expected plans per tile */ \
   X(async_wg_per_cu) X(async_wg_per_plan) X(async_max_s)                                                                                 \
   X(async_band_mult)     /* band of the asynchronous engine in tile widths of potential (default 4; <= 0: no bands) */                         \
   X(async_max_batch)     /* auto: batches of up to this many plans take the asynchronous engine */                                      \

@@ -63,6 +63,7 @@ struct Args {
   double offset; float band;
   uint8_t* pflag; uint32_t nblk;                                     // per (tile, block of 64 plans): 1 = some pend[tile][plan] of the block may be set
   uint32_t* pairs; uint32_t n_flag16;                                // the flagged pairs of the iteration (tile * nblk + block); 16-byte units of the flag matrix
+  uint32_t item_plans;                                               // plans per work item: 16 (a quarter of a wave, k_tb_solve_q) or 64 (a wave, k_tbv_solve)
 };
 
 __device__ __forceinline__ size_t slot_addr(const uint2 va, uint32_t NP, uint32_t p)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_items(tb::Args A)
 {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  constexpr uint32_t gran = kTbItemPlans;
+  const uint32_t gran = A.item_plans;
   uint32_t c = 0;
   if (t < A.ntiles) { c = A.bcnt[t]; if (c) A.bcnt[t] = 0u; }
   const uint32_t k = (c + gran - 1u) / gran;
@@ -790,6 +791,8 @@ struct TbState {
   std::vector<uint32_t> vert_tile;      // host copy: plans are ordered by the tile of their wave source
   uint32_t* d_verts = nullptr;          // tile order -> vertex id
   TbTile* d_tiles = nullptr; uint32_t* d_stream = nullptr; uint32_t* d_wsrc = nullptr; TbExp* d_exps = nullptr;
+  uint32_t *d_vstream = nullptr, *d_vwsrc = nullptr, *d_vtile = nullptr; size_t nvrec = 0;   // the sweep streams in the V layout (k_tbv_solve, mnav_tbv.h)
+  int kernel = 0;                       // solve kernel of the running batch: 0 = k_tb_solve_q (quarters, distances in LDS), 1 = k_tbv_solve (waves, distances in registers)
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // finalize tables (mnav_tb_finalize.h)
   uint16_t* d_fin_src = nullptr; uint32_t* d_fin_wsrc = nullptr; float* d_fin_w = nullptr; TbFinOvf* d_fin_ovf = nullptr; uint32_t* d_fin_ovf_wsrc = nullptr; float* d_fin_ovf_w = nullptr;

@@ -91,6 +91,10 @@ struct HostTb {
   std::vector<TbTile> tiles;
   std::vector<uint32_t> stream;       // chunks
   std::vector<uint32_t> wsrc;         // per stream dword: index into the gather CSR (Nbr) its weight comes from, kNone otherwise
+  // the sweep streams once more in the V layout (k_tbv_solve, mnav_tbv.h: the distances of a tile in registers, rows addressed
+  // through the VGPR index mode): chunks, their weight sources, and per tile {first chunk, chunks per order}
+  std::vector<uint32_t> vstream, vwsrc;
+  std::vector<uint32_t> vtile;        // 2 x ntiles
   std::vector<TbExp> exps;
   std::vector<uint32_t> verts;        // tile order -> vertex id
   std::vector<uint32_t> vert_tile, vert_local;   // V
@@ -162,6 +166,33 @@ inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k
 // ds_read_b128 per block against eight ds_read_b32 of data).  The ghost and export streams keep the plain layout (block j =
 // dwords 16 j .. 16 j + 15; they are parked in the LDS staging area).
 inline uint32_t tb_sweep_index(uint32_t j, uint32_t q) { return 4u * q + j; }
+
+// V layout of a sweep block (k_tbv_solve keeps a tile's distances in VGPRs and addresses row r as v[base + r] through the VGPR
+// index mode: the row indices are stored as ready-made values of M0 -- index in bits 7:0, the operands it applies to in bits 15:12):
+//   d0 = (0xA000 | target) | (0x2000 | source0) << 16      d1 = (0x2000 | source1) | (0x2000 | source2) << 16
+//   d2 = (0x2000 | source3) | (0x2000 | source4) << 16     d3 =  0x2000 | source5
+//   d8 .. d13 = the six weights (unused slot: source = target, weight +inf); chunks transposed like the Q sweep chunks
+// A vertex with more than six sources inside its tile continues in a second block of the same target (registers: the second
+// block sees what the first one wrote).  No forwarding rule, no separator blocks.
+constexpr uint32_t kTbvSources = 6;
+constexpr uint32_t kTbvSrc = 0x2000u, kTbvDst = 0xA000u;
+inline void tbv_set_source(uint32_t* blk, uint32_t k, uint32_t row)   // blk: the 16 dwords of a block, plain order
+{
+  static const uint32_t dw[6] = { 0, 1, 1, 2, 2, 3 }, sh[6] = { 16, 0, 16, 0, 16, 0 };
+  blk[dw[k]] = (blk[dw[k]] & ~(0xFFFFu << sh[k])) | ((kTbvSrc | row) << sh[k]);
+}
+inline void tbv_init_block(uint32_t* blk, uint32_t row)
+{
+  for (uint32_t q = 0; q < kTbBlock; ++q) blk[q] = 0u;
+  blk[0] = kTbvDst | row;
+  for (uint32_t k = 0; k < kTbvSources; ++k) { tbv_set_source(blk, k, row); blk[8 + k] = 0x7f800000u; }
+}
+inline uint32_t tbv_target(const uint32_t* blk) { return blk[0] & 0xFFu; }
+inline uint32_t tbv_source(const uint32_t* blk, uint32_t k)
+{
+  static const uint32_t dw[6] = { 0, 1, 1, 2, 2, 3 }, sh[6] = { 16, 0, 16, 0, 16, 0 };
+  return (blk[dw[k]] >> sh[k]) & 0xFFu;
+}
 
 inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
 {
@@ -284,6 +315,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     W.sweep_off = (uint32_t)(H.stream.size() / kTbChunk);
     static const float dirs[4][2] = { { 1, 1 }, { -1, 1 }, { -1, -1 }, { 1, -1 } };
     uint32_t order_chunks[4] = { 0, 0, 0, 0 };
+    std::vector<uint32_t> vs[4], vw[4];                               // the V layout of the four orders (plain block order until transposed below)
     for (int o = 0; o < 4; ++o) {
       order.resize(W.nv);
       for (uint32_t i = 0; i < W.nv; ++i) order[i] = (uint16_t)i;
@@ -291,6 +323,15 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
         const float* px = &xyz[3 * (size_t)H.verts[W.v0 + x]]; const float* py = &xyz[3 * (size_t)H.verts[W.v0 + y]];
         return dirs[o][0] * px[a0] + dirs[o][1] * px[a1] < dirs[o][0] * py[a0] + dirs[o][1] * py[a1];
       });
+      for (uint32_t i = 0; i < W.nv; ++i) {                          // V layout: blocks of up to six sources, nothing else
+        const uint32_t y = order[i], v = H.verts[W.v0 + y];
+        uint32_t k6 = kTbvSources; size_t at = 0;
+        for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
+          if (H.vert_tile[t.nbr_u[k]] != tl) continue;
+          if (k6 == kTbvSources) { at = vs[o].size(); vs[o].resize(at + kTbBlock); vw[o].resize(at + kTbBlock, kNone); tbv_init_block(&vs[o][at], y); k6 = 0; }
+          tbv_set_source(&vs[o][at], k6, H.vert_local[t.nbr_u[k]]); vw[o][at + 8 + k6] = k; ++k6;
+        }
+      }
       const size_t first = H.stream.size() / kTbChunk;
       for (uint32_t i = 0; i < W.nv; ++i) {
         const uint32_t y = order[i], v = H.verts[W.v0 + y];
@@ -361,6 +402,26 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
           H.stream[c * kTbChunk + tb_sweep_index(j, q)] = tmp[kTbBlock * j + q];
           H.wsrc[c * kTbChunk + tb_sweep_index(j, q)] = tmpw[kTbBlock * j + q];
         }
+    }
+    // the V layout of the same four orders: padded to the longest one with do-nothing blocks (row 0 from itself, weights +inf),
+    // order k at chunk vtile[2 tl] + k * vtile[2 tl + 1], chunks transposed like the Q chunks
+    {
+      size_t vblocks = 0;
+      for (int o = 0; o < 4; ++o) vblocks = std::max(vblocks, vs[o].size() / kTbBlock);
+      const uint32_t vchunks = (uint32_t)((vblocks + kTbBlocksPerChunk - 1) / kTbBlocksPerChunk);
+      H.vtile.push_back((uint32_t)(H.vstream.size() / kTbChunk)); H.vtile.push_back(vchunks);
+      for (int o = 0; o < 4; ++o) {
+        while (vs[o].size() < (size_t)vchunks * kTbChunk) { const size_t at = vs[o].size(); vs[o].resize(at + kTbBlock); vw[o].resize(at + kTbBlock, kNone); tbv_init_block(&vs[o][at], 0u); }
+        for (uint32_t c = 0; c < vchunks; ++c) {
+          const size_t at = H.vstream.size();
+          H.vstream.resize(at + kTbChunk); H.vwsrc.resize(at + kTbChunk);
+          for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j)
+            for (uint32_t q = 0; q < kTbBlock; ++q) {
+              H.vstream[at + tb_sweep_index(j, q)] = vs[o][(size_t)c * kTbChunk + kTbBlock * j + q];
+              H.vwsrc[at + tb_sweep_index(j, q)] = vw[o][(size_t)c * kTbChunk + kTbBlock * j + q];
+            }
+        }
+      }
     }
     // which of the four sweep orders runs WITH a wave that enters through ghost gv: the one whose direction has the largest
     // component along (tile centroid - ghost position).  The solve starts its sweeps with the order most lanes ask for.
@@ -439,6 +500,7 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     while (H.exps.size() % 4) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // groups of 4 records = one 64-byte scalar load
   }
   H.stream.resize(H.stream.size() + 4 * kTbChunk, 0u); H.wsrc.resize(H.wsrc.size() + 4 * kTbChunk, kNone);   // tail slack for the chunk prefetch
+  H.vstream.resize(H.vstream.size() + 4 * kTbChunk, 0u); H.vwsrc.resize(H.vwsrc.size() + 4 * kTbChunk, kNone);
   for (int k = 0; k < 48; ++k) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // tail slack: the quarter-wave solve reads the records in chunks of 16, two chunks ahead
   if (H.stream.size() / kTbChunk > 0xFFFFFFF0ull) throw std::invalid_argument("tile-batch engine: stream too large");
   return H;

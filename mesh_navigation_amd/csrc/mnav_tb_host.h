@@ -23,9 +23,11 @@ void tb_free(mnav_ctx* ctx)
   TbState& S = ctx->tb;
   tb_free_batch(ctx);
   for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile, (void*)S.d_verts,
+                   (void*)S.d_vstream, (void*)S.d_vwsrc, (void*)S.d_vtile,
                    (void*)S.d_fin_src, (void*)S.d_fin_wsrc, (void*)S.d_fin_ovf, (void*)S.d_fin_ovf_wsrc, (void*)S.d_ghost_gid })
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
   S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr; S.d_verts = nullptr;
+  S.d_vstream = nullptr; S.d_vwsrc = nullptr; S.d_vtile = nullptr;
   S.d_fin_src = nullptr; S.d_fin_wsrc = nullptr; S.d_fin_ovf = nullptr; S.d_fin_ovf_wsrc = nullptr; S.d_ghost_gid = nullptr;
   (void)hipFree(S.d_fin_w); S.d_fin_w = nullptr; (void)hipFree(S.d_fin_ovf_w); S.d_fin_ovf_w = nullptr; S.fin_w_valid = false;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
@@ -55,6 +57,9 @@ int tb_build(mnav_ctx* ctx)
   if (dev_upload(ctx, &S.d_stream, H.stream.data(), H.stream.size())) return -1;
   if (dev_upload(ctx, &S.d_wsrc, H.wsrc.data(), H.wsrc.size())) return -1;
   if (dev_upload(ctx, &S.d_exps, H.exps.data(), H.exps.size())) return -1;
+  if (dev_upload(ctx, &S.d_vstream, H.vstream.data(), H.vstream.size())) return -1;
+  if (dev_upload(ctx, &S.d_vwsrc, H.vwsrc.data(), H.vwsrc.size())) return -1;
+  if (dev_upload(ctx, &S.d_vtile, H.vtile.data(), H.vtile.size())) return -1;
   if (dev_upload(ctx, &S.d_vaddr, vaddr.data(), vaddr.size())) return -1;
   if (dev_upload(ctx, &S.d_vert_tile, H.vert_tile.data(), H.vert_tile.size())) return -1;
   if (dev_upload(ctx, &S.d_verts, H.verts.data(), H.verts.size())) return -1;
@@ -73,12 +78,13 @@ int tb_build(mnav_ctx* ctx)
   HIPCHK(hipMalloc((void**)&S.d_fin_w, 4 * std::max<size_t>(S.fin_n, 1)));
   HIPCHK(hipMalloc((void**)&S.d_fin_ovf_w, 4 * std::max<size_t>(S.fin_novf, 1)));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  S.nvrec = H.vstream.size();
   S.ntiles = H.ntiles; S.S = H.S; S.nrec = H.stream.size(); S.nexp = H.exps.size(); S.max_nh = H.max_nh;
   S.vert_tile = std::move(H.vert_tile);
   S.built = true; S.w_valid = false;
   if (opt_on(ctx->opt.verbose))
-    fprintf(stderr, "[mnav] tile-batch engine: T %u, %u tiles, %.2f slots per vertex, max ghosts %u, %.1f MB of streams\n", S.T, S.ntiles,
-            ctx->V ? (double)S.S / ctx->V : 0.0, S.max_nh, (4.0 * S.nrec + 16.0 * S.nexp) / 1e6);
+    fprintf(stderr, "[mnav] tile-batch engine: T %u, %u tiles, %.2f slots per vertex, max ghosts %u, %.1f MB of streams + %.1f MB of sweep streams in the V layout\n", S.T, S.ntiles,
+            ctx->V ? (double)S.S / ctx->V : 0.0, S.max_nh, (4.0 * S.nrec + 16.0 * S.nexp) / 1e6, 4.0 * S.nvrec / 1e6);
   return 0;
 }
 
@@ -87,6 +93,7 @@ int tb_weights(mnav_ctx* ctx)
   TbState& S = ctx->tb;
   if (S.w_valid) return 0;
   hipLaunchKernelGGL(k_tb_weights, dim3(4096), dim3(kBlock), 0, ctx->stream, S.nrec, S.d_wsrc, ctx->d_nbr, S.d_stream);
+  hipLaunchKernelGGL(k_tb_weights, dim3(4096), dim3(kBlock), 0, ctx->stream, S.nvrec, S.d_vwsrc, ctx->d_nbr, S.d_vstream);
   HIPCHK(hipGetLastError());
   S.w_valid = true; S.fin_w_valid = false;
   return 0;
@@ -152,7 +159,8 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     hipLaunchKernelGGL(k_tb_pairs, dim3((A.n_flag16 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_tb_scan, dim3(kTbScanWaves / (kBlock / 64)), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3((A.ntiles + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
-    if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
+    if (ctx->tb.kernel == 1) hipLaunchKernelGGL((k_tbv_solve<120>), dim3(waves), dim3(64), 0, ctx->stream, A, ctx->tb.d_vtile, ctx->tb.d_vstream, par);
+    else if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else hipLaunchKernelGGL((k_tb_solve_q<128>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
@@ -228,6 +236,12 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
   A.offset = offset;
+  // Solve kernel.  k_tbv_solve (distances in registers, mnav_tbv.h) takes whole waves per tile: it pays when a tile's bucket of
+  // ready plans fills most of a wave.  A plan's front crosses ~sqrt(tiles) tiles per iteration, so a tile sees about
+  // 0.85 n / sqrt(tiles) plans (measured: 63 at C2 = 7168 plans on 9 260 tiles, 11 at C4 = 4096 plans on 92 600 tiles).
+  S.kernel = (S.T == 120 && (double)n >= 40.0 * std::sqrt((double)std::max(S.ntiles, 1u))) ? 1 : 0;
+  if (opt_set(ctx->opt.tb_kernel)) S.kernel = (opt_u32(ctx->opt.tb_kernel, 0u) == 1u && S.T == 120) ? 1 : 0;
+  A.item_plans = S.kernel == 1 ? 64u : kTbItemPlans;
   {
     float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * S.band_mult;   // potential across one tile
     if (opt_set(ctx->opt.tb_band_mult)) band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * (float)ctx->opt.tb_band_mult;
@@ -268,6 +282,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
   uint32_t per_cu = (uint32_t)((160u * 1024u) / (S.T * 256u + kTbQStride * 4u));   // LDS: T x 256 bytes + staging per wave, 160 KB per CU
+  if (S.kernel == 1) per_cu = 8u;                                      // k_tbv_solve: 256 VGPRs per wave, two waves per SIMD, no LDS
   if (opt_set(ctx->opt.tb_waves_per_cu)) S.waves_per_cu = (int)ctx->opt.tb_waves_per_cu;
   if (S.waves_per_cu > 0) per_cu = (uint32_t)S.waves_per_cu;
   const uint32_t waves = per_cu * (uint32_t)ncu;

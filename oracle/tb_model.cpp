@@ -36,11 +36,13 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   std::vector<Nbr> nbr; std::vector<Corner> crn; std::vector<uint8_t> blocked;
   materialize_host(topo, edge_weights, vertex_costs, invalid, cost_limit, nbr, crn, blocked);
   const uint32_t rerun = (uint32_t)((jacobi >> 4) & 15);              // bits 4-7: every sweep re-runs its last chunk that many times (a quarter whose stream is shorter than its wave's)
+  const bool vlayout = (jacobi & 2) != 0;                            // bit 1: the sweeps read the V layout of the streams (k_tbv_solve, mnav_tbv.h)
   jacobi &= 1;
   HostTb H;
   try { H = build_tb(topo, xyz, T); }
   catch (const std::exception& ex) { fprintf(stderr, "tbm_run: %s\n", ex.what()); return 64; }
   for (size_t i = 0; i < H.stream.size(); ++i) if (H.wsrc[i] != kNone) H.stream[i] = f2u(nbr[H.wsrc[i]].w);   // k_tb_weights
+  for (size_t i = 0; i < H.vstream.size(); ++i) if (H.vwsrc[i] != kNone) H.vstream[i] = f2u(nbr[H.vwsrc[i]].w);
   const uint32_t NP = n, nt = H.ntiles;
   auto slot = [&](uint32_t t, uint32_t p, uint32_t i) { return (size_t)H.tiles[t].soff * NP + (size_t)p * H.tiles[t].sl + i; };
   std::vector<uint32_t> D((size_t)H.S * NP, kTbInfBits), Dsnap;
@@ -114,6 +116,35 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
         }
         // sweeps, all lanes in lockstep until a sweep changes nothing in any of them
         uint32_t sweep = 0;
+        if (vlayout) {
+          // the register-resident kernel: one wave per item, blocks of up to six sources, rows by index; a tile none of whose
+          // vertices has a source inside it has no blocks (one "sweep" that changes nothing)
+          const uint32_t voff = H.vtile[2 * t], vch = H.vtile[2 * t + 1];
+          for (;;) {
+            uint32_t chg = 0;
+            for (uint32_t c = 0; c < vch; ++c) {
+              const uint32_t* C = &H.vstream[((size_t)voff + (size_t)(sweep & 3u) * vch + c) * kTbChunk];
+              blocks_total += kTbBlocksPerChunk;
+              for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+                uint32_t blk[kTbBlock];
+                for (uint32_t q = 0; q < kTbBlock; ++q) blk[q] = C[tb_sweep_index(j, q)];
+                ++blocks_eval;
+                const uint32_t y = tbv_target(blk);
+                if (y >= T) return 62;
+                for (uint32_t l = 0; l < cnt_l; ++l) {
+                  uint32_t* lds = ldsv[l].data();
+                  const uint32_t acc0 = lds[y] & 0x7fffffffu;
+                  uint32_t acc = acc0;
+                  for (uint32_t k = 0; k < kTbvSources; ++k) { const uint32_t r = tbv_source(blk, k); if (r >= T) return 62; acc = std::min(acc, fabs_bits_add(lds[r], blk[8 + k])); }
+                  if (acc < acc0) { lds[y] = acc | kTbDirty; chg = 1; }
+                }
+              }
+            }
+            ++sweep;
+            if (!chg) break;
+            if (sweep >= 16u * T) return 60;
+          }
+        } else
         for (;;) {
           const uint32_t* B = &H.stream[((size_t)W.sweep_off + (size_t)(sweep & 3u) * W.sweep_chunks) * kTbChunk];
           uint32_t chg_cur = 0;

@@ -108,3 +108,34 @@ def test_a_quarter_that_reruns_its_last_chunk_changes_nothing():
         assert c["code"] == 0 and c["sweeps"] <= a["sweeps"]
         assert np.array_equal(a["dist"].view(np.uint32), c["dist"].view(np.uint32))
 
+
+
+def test_v_layout_streams_of_the_register_resident_kernel():
+    """k_tbv_solve (mnav_tbv.h) keeps a tile's distances in VGPRs and reads its sweeps from the V layout of the streams (blocks of
+    up to six sources, rows as ready-made register-index words, no forwarding rule): the model interprets that layout (jacobi bit
+    1) on the same schedule -- same potential bit for bit, never more sweeps than the Q layout with its reserved forwarding slot;
+    on the terrain, with costs / a cost limit / invalid vertices, on the punched mesh and on the valence-40 fan (continuation
+    blocks of one target)."""
+    case = terrain_case(224, 1)
+    rng = np.random.default_rng(3)
+    seeds = rng.choice(case.mesh.V, 6, replace=False)
+    targets = np.full(6, case.mesh.vertex_at(0.9, 0.9))
+    for jac in (2, 3):
+        rv = check(case, seeds, targets, tile=120, jacobi=jac)
+        rq = check(case, seeds, targets, tile=120, jacobi=jac & 1)
+        assert np.array_equal(rv["dist"].view(np.uint32), rq["dist"].view(np.uint32))
+        assert rv["max_sweeps"] <= 12 and rv["sweeps"] <= rq["sweeps"] * 1.05
+    mesh = meshgen.terrain(80, 0.1, 11)
+    rng = np.random.default_rng(5)
+    costs = rng.uniform(0.0, 1.4, mesh.V).astype(np.float32)
+    inv = (rng.uniform(size=mesh.V) < 0.05).astype(np.uint8)
+    case2 = Case(mesh, costs, edge_cost_factor=1.0, invalid=inv)
+    ok = np.flatnonzero((inv == 0) & (costs <= 0.8))
+    check(case2, rng.choice(ok, 5, replace=False), rng.choice(ok, 5, replace=False), cost_limit=0.8, tile=120, jacobi=3)
+    m = meshgen.punched(72, 0.1, 4, drop=0.15)
+    deg = np.bincount(m.edges.ravel(), minlength=m.V)
+    okp = np.flatnonzero(deg > 0)
+    check(Case(m), rng.choice(okp, 4, replace=False), rng.choice(okp, 4, replace=False), tile=120, jacobi=3)
+    f = meshgen.fan_field(spokes=40, rings=6, seed=1)
+    r = check(Case(f), [1, f.V - 1], [f.V - 2, 0], tile=120, jacobi=3)
+    assert r["max_sweeps"] <= 40

@@ -43,7 +43,7 @@ def main():
             L.mnav_debug_tb_timing(tt)
             tot = float(sum(tt)) or 1.0
             names = ["fetch", "load", "pre", "sweeps", "writeback", "post", "export", "-"]
-            print("phase cycles:", {n: "%.1f%%" % (100.0 * tt[i] / tot) for i, n in enumerate(names)}, "total Gcycles %.2f" % (tot / 1e9), file=sys.stderr)
+            print("engine", eng, "kernel", os.environ.get("MNAV_TB_KERNEL", "auto"), "phase cycles:", {n: "%.1f%%" % (100.0 * tt[i] / tot) for i, n in enumerate(names)}, "total Gcycles %.2f" % (tot / 1e9), file=sys.stderr)
         best = min(res, key=lambda x: x["wall_ms"])
         best["plans_per_s"] = B / best["wall_ms"] * 1e3
         best["gbps_prop"] = best["algo"] / best["prop_ms"] / 1e6

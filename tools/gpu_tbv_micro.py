@@ -16,7 +16,7 @@ T, INF = 120, np.uint32(0x7F800000)
 
 
 def make_stream(rng, nch):
-    """4 orders x nch chunks x 4 blocks in the V layout; returns (stream words, list of orders, each a list of (tgt, srcs[7], w[7]))"""
+    """4 orders x nch chunks x 4 blocks in the V layout; returns (stream words, list of orders, each a list of (tgt, srcs[6], w[6]))"""
     words = np.zeros(4 * nch * 64, np.uint32)
     orders = []
     for o in range(4):
@@ -26,12 +26,13 @@ def make_stream(rng, nch):
             for j in range(4):
                 b = c * 4 + j
                 tgt = int(perm[b % T])
-                n = int(rng.integers(3, 8))
-                srcs = [int(x) for x in rng.integers(0, T, n)] + [tgt] * (7 - n)
-                w = np.concatenate([rng.uniform(0.05, 0.3, n).astype(np.float32), np.full(7 - n, np.inf, np.float32)])
+                n = int(rng.integers(2, 7))
+                srcs = [int(x) for x in rng.integers(0, T, n)] + [tgt] * (6 - n)
+                w = np.concatenate([rng.uniform(0.05, 0.3, n).astype(np.float32), np.full(6 - n, np.inf, np.float32)])
                 d = np.zeros(16, np.uint32)
-                d[0] = tgt | (srcs[0] << 16); d[1] = srcs[1] | (srcs[2] << 16); d[2] = srcs[3] | (srcs[4] << 16); d[3] = srcs[5] | (srcs[6] << 16)
-                d[8:15] = w.view(np.uint32)
+                S = [0x2000 | x for x in srcs]
+                d[0] = (0xA000 | tgt) | (S[0] << 16); d[1] = S[1] | (S[2] << 16); d[2] = S[3] | (S[4] << 16); d[3] = S[5]
+                d[8:14] = w.view(np.uint32)
                 base = (o * nch + c) * 64
                 for q in range(16):
                     words[base + 4 * q + j] = d[q]
@@ -49,7 +50,7 @@ def emulate(img, orders, first, cap):
         changed = False
         for tgt, srcs, w in orders[o]:
             cand = np.full(64, np.inf, np.float32)
-            for k in range(7):
+            for k in range(6):
                 cand = np.minimum(cand, (f[srcs[k]] + w[k]).astype(np.float32))
             low = cand < f[tgt]
             if low.any():
