@@ -791,7 +791,7 @@ struct TbState {
   std::vector<uint32_t> vert_tile;      // host copy: plans are ordered by the tile of their wave source
   uint32_t* d_verts = nullptr;          // tile order -> vertex id
   TbTile* d_tiles = nullptr; uint32_t* d_stream = nullptr; uint32_t* d_wsrc = nullptr; TbExp* d_exps = nullptr;
-  uint32_t *d_vstream = nullptr, *d_vwsrc = nullptr, *d_vtile = nullptr; size_t nvrec = 0;   // the sweep streams in the V layout (k_tbv_solve, mnav_tbv.h)
+  uint32_t *d_vstream = nullptr, *d_vwsrc = nullptr, *d_vtile = nullptr, *d_vgroups = nullptr; TbvExp* d_vexps = nullptr; size_t nvrec = 0;   // the streams in the V layout (k_tbv_solve, mnav_tbv.h)
   int kernel = 0;                       // solve kernel of the running batch: 0 = k_tb_solve_q (quarters, distances in LDS), 1 = k_tbv_solve (waves, distances in registers)
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // finalize tables (mnav_tb_finalize.h)

@@ -82,6 +82,13 @@ constexpr uint32_t kTbFinSlots = 8;
 constexpr uint16_t kTbFinNone = 0xFFFFu;
 struct TbFinOvf { uint32_t y, src, wsrc, pad; };
 
+// Export RUN of the V layout: up to four boundary rows of a tile whose ghost copies in ONE neighbour's slices are adjacent slots
+// (the ghosts of a slice are sorted by owner tile and the owner's local index): rows = four window rows, one per byte (a run of
+// fewer repeats its first row), values to D[soff * NP + plan * sl + off .. + n - 1] -- one 16-byte store instead of four scattered
+// 4-byte ones (the kernel is bound by the NUMBER of store requests there: 64 per instruction, one per lane)
+struct TbvExp { uint32_t rows, soff, sl, off, n, pad[3]; };
+static_assert(sizeof(TbvExp) == 32, "read as two 16-byte loads");
+
 struct HostTb {
   std::vector<uint16_t> fin_src; std::vector<uint32_t> fin_wsrc; std::vector<TbFinOvf> fin_ovf;
   std::vector<uint32_t> ghost_gid;    // vertex ids of the tiles' ghosts, tile after tile in slice order (TbTile.goff)
@@ -94,7 +101,9 @@ struct HostTb {
   // the sweep streams once more in the V layout (k_tbv_solve, mnav_tbv.h: the distances of a tile in registers, rows addressed
   // through the VGPR index mode): chunks, their weight sources, and per tile {first chunk, chunks per order}
   std::vector<uint32_t> vstream, vwsrc;
-  std::vector<uint32_t> vtile;        // 2 x ntiles
+  std::vector<uint32_t> vtile;        // kTbvTileWords x ntiles: {pre first chunk, pre chunks, sweep first chunk, chunks per order, post first chunk, post chunks, first group, groups}
+  std::vector<TbvExp> vexps;          // export runs, tile after tile (vtile words 8, 9)
+  std::vector<uint32_t> vgroups;      // owner tiles of a tile's ghosts, one entry per run of ghosts with the same owner (= per wake-up), in slice order
   std::vector<TbExp> exps;
   std::vector<uint32_t> verts;        // tile order -> vertex id
   std::vector<uint32_t> vert_tile, vert_local;   // V
@@ -167,31 +176,62 @@ inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k
 // dwords 16 j .. 16 j + 15; they are parked in the LDS staging area).
 inline uint32_t tb_sweep_index(uint32_t j, uint32_t q) { return 4u * q + j; }
 
-// V layout of a sweep block (k_tbv_solve keeps a tile's distances in VGPRs and addresses row r as v[base + r] through the VGPR
-// index mode: the row indices are stored as ready-made values of M0 -- index in bits 7:0, the operands it applies to in bits 15:12):
-//   d0 = (0xA000 | target) | (0x2000 | source0) << 16      d1 = (0x2000 | source1) | (0x2000 | source2) << 16
-//   d2 = (0x2000 | source3) | (0x2000 | source4) << 16     d3 =  0x2000 | source5
-//   d8 .. d13 = the six weights (unused slot: source = target, weight +inf); chunks transposed like the Q sweep chunks
-// A vertex with more than six sources inside its tile continues in a second block of the same target (registers: the second
-// block sees what the first one wrote).  No forwarding rule, no separator blocks.
+// V layout of the streams (k_tbv_solve, mnav_tbv.h).  The kernel keeps a tile's distances in a window of VGPRs -- rows 0 ..
+// kTbvGhostRows - 1: the ghost slots of the slice, rows kTbvGhostRows + r: owned vertex r -- and addresses a row through the VGPR
+// index mode: row indices are stored as ready-made values of M0 (index in bits 7:0, the operands it applies to in bits 15:12).
+// One block format for the three phases:
+//   d0 = (mode | target) | (0x2000 | source0) << 16      d1 = (0x2000 | source1) | (0x2000 | source2) << 16
+//   d2 = (0x2000 | source3) | (0x2000 | source4) << 16   d3 = (0x2000 | source5) | flags << 16
+//   d8 .. d13 = the six weights (unused slot: source = target, weight +inf); chunks of 4 blocks, transposed like the Q sweep chunks
+//   sweep (four orders): target = an owned row (mode 0xA000: read and written), sources = its neighbours inside the tile
+//   pre  : target = an owned row with neighbours outside (0xA000), sources = those ghosts; flags bits 0-1 = the sweep order that
+//          runs with a wave entering at this row
+//   post : "target" = a ghost (0x2000: read only), sources = its owned neighbours; flags bit 0 = last block of this ghost,
+//          bit 1 = last ghost of its owner tile (one entry of vgroups per such run: the tile that is woken)
+// A vertex with more than six sources continues in a second block of the same target.  No forwarding rule, no separator blocks.
 constexpr uint32_t kTbvSources = 6;
+constexpr uint32_t kTbvGhostRows = 64;      // a tile with more ghosts than this keeps the engine on k_tb_solve_q
 constexpr uint32_t kTbvSrc = 0x2000u, kTbvDst = 0xA000u;
+constexpr uint32_t kTbvTileWords = 12;     // + {first export run, export runs, 0, 0}
+constexpr uint32_t kTbvGhostEnd = 1u, kTbvTileEnd = 2u;
 inline void tbv_set_source(uint32_t* blk, uint32_t k, uint32_t row)   // blk: the 16 dwords of a block, plain order
 {
   static const uint32_t dw[6] = { 0, 1, 1, 2, 2, 3 }, sh[6] = { 16, 0, 16, 0, 16, 0 };
   blk[dw[k]] = (blk[dw[k]] & ~(0xFFFFu << sh[k])) | ((kTbvSrc | row) << sh[k]);
 }
-inline void tbv_init_block(uint32_t* blk, uint32_t row)
+inline void tbv_init_block(uint32_t* blk, uint32_t row, uint32_t mode = kTbvDst)
 {
   for (uint32_t q = 0; q < kTbBlock; ++q) blk[q] = 0u;
-  blk[0] = kTbvDst | row;
+  blk[0] = mode | row;
   for (uint32_t k = 0; k < kTbvSources; ++k) { tbv_set_source(blk, k, row); blk[8 + k] = 0x7f800000u; }
 }
 inline uint32_t tbv_target(const uint32_t* blk) { return blk[0] & 0xFFu; }
+inline uint32_t tbv_flags(const uint32_t* blk) { return blk[3] >> 16; }
 inline uint32_t tbv_source(const uint32_t* blk, uint32_t k)
 {
   static const uint32_t dw[6] = { 0, 1, 1, 2, 2, 3 }, sh[6] = { 16, 0, 16, 0, 16, 0 };
   return (blk[dw[k]] >> sh[k]) & 0xFFu;
+}
+// blocks in plain order (16 dwords each) -> chunks appended to `stream` (padded with do-nothing blocks on row `pad_row`, transposed);
+// returns the first chunk, *chunks = their number (padded up to `min_chunks`)
+inline uint32_t tbv_append(std::vector<uint32_t>& stream, std::vector<uint32_t>& wsrc, std::vector<uint32_t>& blocks, std::vector<uint32_t>& bw,
+                           uint32_t pad_row, uint32_t pad_mode, uint32_t min_chunks, uint32_t* chunks)
+{
+  const uint32_t first = (uint32_t)(stream.size() / kTbChunk);
+  uint32_t n = (uint32_t)((blocks.size() / kTbBlock + kTbBlocksPerChunk - 1) / kTbBlocksPerChunk);
+  n = std::max(n, min_chunks);
+  while (blocks.size() < (size_t)n * kTbChunk) { const size_t at = blocks.size(); blocks.resize(at + kTbBlock); bw.resize(at + kTbBlock, 0xFFFFFFFFu); tbv_init_block(&blocks[at], pad_row, pad_mode); }
+  for (uint32_t c = 0; c < n; ++c) {
+    const size_t at = stream.size();
+    stream.resize(at + kTbChunk); wsrc.resize(at + kTbChunk);
+    for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j)
+      for (uint32_t q = 0; q < kTbBlock; ++q) {
+        stream[at + tb_sweep_index(j, q)] = blocks[(size_t)c * kTbChunk + kTbBlock * j + q];
+        wsrc[at + tb_sweep_index(j, q)] = bw[(size_t)c * kTbChunk + kTbBlock * j + q];
+      }
+  }
+  *chunks = n;
+  return first;
 }
 
 inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
@@ -328,8 +368,8 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
         uint32_t k6 = kTbvSources; size_t at = 0;
         for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
           if (H.vert_tile[t.nbr_u[k]] != tl) continue;
-          if (k6 == kTbvSources) { at = vs[o].size(); vs[o].resize(at + kTbBlock); vw[o].resize(at + kTbBlock, kNone); tbv_init_block(&vs[o][at], y); k6 = 0; }
-          tbv_set_source(&vs[o][at], k6, H.vert_local[t.nbr_u[k]]); vw[o][at + 8 + k6] = k; ++k6;
+          if (k6 == kTbvSources) { at = vs[o].size(); vs[o].resize(at + kTbBlock); vw[o].resize(at + kTbBlock, kNone); tbv_init_block(&vs[o][at], kTbvGhostRows + y); k6 = 0; }
+          tbv_set_source(&vs[o][at], k6, kTbvGhostRows + H.vert_local[t.nbr_u[k]]); vw[o][at + 8 + k6] = k; ++k6;
         }
       }
       const size_t first = H.stream.size() / kTbChunk;
@@ -403,24 +443,17 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
           H.wsrc[c * kTbChunk + tb_sweep_index(j, q)] = tmpw[kTbBlock * j + q];
         }
     }
-    // the V layout of the same four orders: padded to the longest one with do-nothing blocks (row 0 from itself, weights +inf),
-    // order k at chunk vtile[2 tl] + k * vtile[2 tl + 1], chunks transposed like the Q chunks
+    // the V layout of the same four orders: padded to the longest one with do-nothing blocks (the first owned row from itself,
+    // weights +inf); order k at chunk (sweep first chunk) + k * (chunks per order)
+    uint32_t v_sweep_off = 0, v_sweep_chunks = 0;
     {
       size_t vblocks = 0;
       for (int o = 0; o < 4; ++o) vblocks = std::max(vblocks, vs[o].size() / kTbBlock);
       const uint32_t vchunks = (uint32_t)((vblocks + kTbBlocksPerChunk - 1) / kTbBlocksPerChunk);
-      H.vtile.push_back((uint32_t)(H.vstream.size() / kTbChunk)); H.vtile.push_back(vchunks);
       for (int o = 0; o < 4; ++o) {
-        while (vs[o].size() < (size_t)vchunks * kTbChunk) { const size_t at = vs[o].size(); vs[o].resize(at + kTbBlock); vw[o].resize(at + kTbBlock, kNone); tbv_init_block(&vs[o][at], 0u); }
-        for (uint32_t c = 0; c < vchunks; ++c) {
-          const size_t at = H.vstream.size();
-          H.vstream.resize(at + kTbChunk); H.vwsrc.resize(at + kTbChunk);
-          for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j)
-            for (uint32_t q = 0; q < kTbBlock; ++q) {
-              H.vstream[at + tb_sweep_index(j, q)] = vs[o][(size_t)c * kTbChunk + kTbBlock * j + q];
-              H.vwsrc[at + tb_sweep_index(j, q)] = vw[o][(size_t)c * kTbChunk + kTbBlock * j + q];
-            }
-        }
+        uint32_t n = 0;
+        const uint32_t first = tbv_append(H.vstream, H.vwsrc, vs[o], vw[o], kTbvGhostRows, kTbvDst, vchunks, &n);
+        if (o == 0) { v_sweep_off = first; v_sweep_chunks = n; }
       }
     }
     // which of the four sweep orders runs WITH a wave that enters through ghost gv: the one whose direction has the largest
@@ -487,6 +520,42 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
     };
     emit_ghost_stream(false);
     emit_ghost_stream(true);
+    // --- the ghost phases in the V layout (pull form, the block format of the sweeps)
+    {
+      std::vector<uint32_t> pb, pw, qb, qw;
+      for (uint32_t y = 0; y < W.nv; ++y) {                            // pre: owned rows with neighbours outside the tile <- those ghosts (weight in row y)
+        const uint32_t v = H.verts[W.v0 + y];
+        uint32_t k6 = kTbvSources; size_t at = 0;
+        for (uint32_t k = t.row_ptr[v]; k < t.row_ptr[v + 1]; ++k) {
+          const uint32_t u = t.nbr_u[k];
+          if (H.vert_tile[u] == tl) continue;
+          if (k6 == kTbvSources) {
+            at = pb.size(); pb.resize(at + kTbBlock); pw.resize(at + kTbBlock, kNone);
+            tbv_init_block(&pb[at], kTbvGhostRows + y); pb[at + 3] |= ghost_order(v) << 16; k6 = 0;
+          }
+          tbv_set_source(&pb[at], k6, ghost_slot(tl, u)); pw[at + 8 + k6] = k; ++k6;
+        }
+      }
+      const uint32_t grp_off = (uint32_t)H.vgroups.size();
+      for (uint32_t h = 0; h < W.nh; ++h) {                            // post: ghost h <- its owned neighbours (weight in row gv)
+        const uint32_t gv = g[h], owner = H.vert_tile[gv];
+        const bool tile_end = (h + 1 == W.nh) || H.vert_tile[g[h + 1]] != owner;
+        uint32_t k6 = kTbvSources; size_t at = 0;
+        for (uint32_t k = t.row_ptr[gv]; k < t.row_ptr[gv + 1]; ++k) {
+          const uint32_t u = t.nbr_u[k];
+          if (H.vert_tile[u] != tl) continue;
+          if (k6 == kTbvSources) { at = qb.size(); qb.resize(at + kTbBlock); qw.resize(at + kTbBlock, kNone); tbv_init_block(&qb[at], h, kTbvSrc); k6 = 0; }
+          tbv_set_source(&qb[at], k6, kTbvGhostRows + H.vert_local[u]); qw[at + 8 + k6] = k; ++k6;
+        }
+        qb[at + 3] |= (kTbvGhostEnd | (tile_end ? kTbvTileEnd : 0u)) << 16;   // (a ghost has at least one neighbour in the tile: `at` is its last block)
+        if (tile_end) H.vgroups.push_back(owner);
+      }
+      uint32_t pre_chunks = 0, post_chunks = 0;
+      const uint32_t pre_off = tbv_append(H.vstream, H.vwsrc, pb, pw, kTbvGhostRows, kTbvDst, 0u, &pre_chunks);
+      const uint32_t post_off = tbv_append(H.vstream, H.vwsrc, qb, qw, 0u, kTbvSrc, 0u, &post_chunks);
+      const uint32_t words[kTbvTileWords] = { pre_off, pre_chunks, v_sweep_off, v_sweep_chunks, post_off, post_chunks, grp_off, (uint32_t)H.vgroups.size() - grp_off, 0u, 0u, 0u, 0u };
+      H.vtile.insert(H.vtile.end(), words, words + kTbvTileWords);
+    }
     // --- exports: owned boundary vertices -> ghost slots of the neighbouring tiles
     W.exp_off = (uint32_t)H.exps.size();
     for (uint32_t i = 0; i < W.nv; ++i) {
@@ -497,10 +566,28 @@ inline HostTb build_tb(const HostTopology& t, const float* xyz, uint32_t T)
       for (uint32_t t2 : ts) H.exps.push_back(TbExp{ i * kRow, H.tiles[t2].soff, H.tiles[t2].sl, T + ghost_slot(t2, v) });
     }
     W.exp_n = (uint32_t)H.exps.size() - W.exp_off;
+    {
+      // the same records as runs of adjacent ghost slots of one neighbour (V layout)
+      std::vector<TbExp> rs(H.exps.begin() + W.exp_off, H.exps.end());
+      std::sort(rs.begin(), rs.end(), [](const TbExp& a, const TbExp& b) { return a.soff != b.soff ? a.soff < b.soff : a.off < b.off; });
+      const uint32_t first = (uint32_t)H.vexps.size();
+      for (size_t i = 0; i < rs.size();) {
+        TbvExp r{}; r.soff = rs[i].soff; r.sl = rs[i].sl; r.off = rs[i].off;
+        const uint32_t row0 = kTbvGhostRows + rs[i].u / kRow;
+        r.rows = row0 * 0x01010101u;
+        uint32_t n = 1;
+        while (n < 4 && i + n < rs.size() && rs[i + n].soff == r.soff && rs[i + n].off == r.off + n) { r.rows = (r.rows & ~(0xFFu << (8 * n))) | ((kTbvGhostRows + rs[i + n].u / kRow) << (8 * n)); ++n; }
+        r.n = n;
+        H.vexps.push_back(r);
+        i += n;
+      }
+      H.vtile[(size_t)kTbvTileWords * tl + 8] = first; H.vtile[(size_t)kTbvTileWords * tl + 9] = (uint32_t)H.vexps.size() - first;
+    }
     while (H.exps.size() % 4) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // groups of 4 records = one 64-byte scalar load
   }
   H.stream.resize(H.stream.size() + 4 * kTbChunk, 0u); H.wsrc.resize(H.wsrc.size() + 4 * kTbChunk, kNone);   // tail slack for the chunk prefetch
   H.vstream.resize(H.vstream.size() + 4 * kTbChunk, 0u); H.vwsrc.resize(H.vwsrc.size() + 4 * kTbChunk, kNone);
+  for (int k = 0; k < 64; ++k) H.vexps.push_back(TbvExp{});          // tail slack: a wave fetches 64 runs at a time
   for (int k = 0; k < 48; ++k) H.exps.push_back(TbExp{ 0, 0, 0, 0 });   // tail slack: the quarter-wave solve reads the records in chunks of 16, two chunks ahead
   if (H.stream.size() / kTbChunk > 0xFFFFFFF0ull) throw std::invalid_argument("tile-batch engine: stream too large");
   return H;

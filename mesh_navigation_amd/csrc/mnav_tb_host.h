@@ -23,11 +23,11 @@ void tb_free(mnav_ctx* ctx)
   TbState& S = ctx->tb;
   tb_free_batch(ctx);
   for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile, (void*)S.d_verts,
-                   (void*)S.d_vstream, (void*)S.d_vwsrc, (void*)S.d_vtile,
+                   (void*)S.d_vstream, (void*)S.d_vwsrc, (void*)S.d_vtile, (void*)S.d_vgroups, (void*)S.d_vexps,
                    (void*)S.d_fin_src, (void*)S.d_fin_wsrc, (void*)S.d_fin_ovf, (void*)S.d_fin_ovf_wsrc, (void*)S.d_ghost_gid })
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
   S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr; S.d_verts = nullptr;
-  S.d_vstream = nullptr; S.d_vwsrc = nullptr; S.d_vtile = nullptr;
+  S.d_vstream = nullptr; S.d_vwsrc = nullptr; S.d_vtile = nullptr; S.d_vgroups = nullptr; S.d_vexps = nullptr;
   S.d_fin_src = nullptr; S.d_fin_wsrc = nullptr; S.d_fin_ovf = nullptr; S.d_fin_ovf_wsrc = nullptr; S.d_ghost_gid = nullptr;
   (void)hipFree(S.d_fin_w); S.d_fin_w = nullptr; (void)hipFree(S.d_fin_ovf_w); S.d_fin_ovf_w = nullptr; S.fin_w_valid = false;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
@@ -60,6 +60,9 @@ int tb_build(mnav_ctx* ctx)
   if (dev_upload(ctx, &S.d_vstream, H.vstream.data(), H.vstream.size())) return -1;
   if (dev_upload(ctx, &S.d_vwsrc, H.vwsrc.data(), H.vwsrc.size())) return -1;
   if (dev_upload(ctx, &S.d_vtile, H.vtile.data(), H.vtile.size())) return -1;
+  if (H.vgroups.empty()) H.vgroups.push_back(0u);
+  if (dev_upload(ctx, &S.d_vgroups, H.vgroups.data(), H.vgroups.size())) return -1;
+  if (dev_upload(ctx, &S.d_vexps, H.vexps.data(), H.vexps.size())) return -1;
   if (dev_upload(ctx, &S.d_vaddr, vaddr.data(), vaddr.size())) return -1;
   if (dev_upload(ctx, &S.d_vert_tile, H.vert_tile.data(), H.vert_tile.size())) return -1;
   if (dev_upload(ctx, &S.d_verts, H.verts.data(), H.verts.size())) return -1;
@@ -159,7 +162,7 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     hipLaunchKernelGGL(k_tb_pairs, dim3((A.n_flag16 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_tb_scan, dim3(kTbScanWaves / (kBlock / 64)), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3((A.ntiles + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
-    if (ctx->tb.kernel == 1) hipLaunchKernelGGL((k_tbv_solve<120>), dim3(waves), dim3(64), 0, ctx->stream, A, ctx->tb.d_vtile, ctx->tb.d_vstream, par);
+    if (ctx->tb.kernel == 1) hipLaunchKernelGGL((k_tbv_solve<120>), dim3(waves), dim3(64), 0, ctx->stream, A, ctx->tb.d_vtile, ctx->tb.d_vstream, ctx->tb.d_vgroups, ctx->tb.d_vexps, par);
     else if (ctx->tb.T == 64) hipLaunchKernelGGL((k_tb_solve_q<64>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 96) hipLaunchKernelGGL((k_tb_solve_q<96>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
@@ -239,8 +242,9 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   // Solve kernel.  k_tbv_solve (distances in registers, mnav_tbv.h) takes whole waves per tile: it pays when a tile's bucket of
   // ready plans fills most of a wave.  A plan's front crosses ~sqrt(tiles) tiles per iteration, so a tile sees about
   // 0.85 n / sqrt(tiles) plans (measured: 63 at C2 = 7168 plans on 9 260 tiles, 11 at C4 = 4096 plans on 92 600 tiles).
-  S.kernel = (S.T == 120 && (double)n >= 40.0 * std::sqrt((double)std::max(S.ntiles, 1u))) ? 1 : 0;
-  if (opt_set(ctx->opt.tb_kernel)) S.kernel = (opt_u32(ctx->opt.tb_kernel, 0u) == 1u && S.T == 120) ? 1 : 0;
+  const bool v_fits = S.T == 120 && S.max_nh <= kTbvGhostRows;        // (its register window holds 120 owned rows and 64 ghosts)
+  S.kernel = (v_fits && (double)n >= 40.0 * std::sqrt((double)std::max(S.ntiles, 1u))) ? 1 : 0;
+  if (opt_set(ctx->opt.tb_kernel)) S.kernel = (opt_u32(ctx->opt.tb_kernel, 0u) == 1u && v_fits) ? 1 : 0;
   A.item_plans = S.kernel == 1 ? 64u : kTbItemPlans;
   {
     float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * S.band_mult;   // potential across one tile

@@ -437,7 +437,7 @@ def tile_batch_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targe
                                _p(dist), _p(stats))
     return dict(code=code, dist=dist, iterations=int(stats[0]), activations=int(stats[1]), sweeps=int(stats[2]), wakes=int(stats[3]),
                 max_sweeps=int(stats[4]), tiles=int(stats[5]), slots_per_plan=int(stats[6]), items=int(stats[7]),
-                blocks_total=int(stats[8]), blocks_evaluated=int(stats[9]), stale_reads=int(stats[10]))
+                blocks_total=int(stats[8]), blocks_evaluated=int(stats[9]), stale_reads=int(stats[10]), max_ghosts=int(stats[11]))
 
 
 def async_tile_model(xyz, faces, edges, edge_weights, vertex_costs, seeds, targets, offset=0.3, cost_limit=1.0, tile=64, band=0.0,

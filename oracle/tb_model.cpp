@@ -98,6 +98,27 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
           const size_t sl = slot(t, p, 0), gs = sl + T;
           for (uint32_t r = 0; r < T; ++r) lds[r] = Din[sl + r];
           // pre
+          if (vlayout) {
+            const uint32_t* M = &H.vtile[(size_t)kTbvTileWords * t];
+            for (uint32_t c = 0; c < M[1]; ++c) {
+              const uint32_t* C = &H.vstream[((size_t)M[0] + c) * kTbChunk];
+              for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+                uint32_t blk[kTbBlock];
+                for (uint32_t q = 0; q < kTbBlock; ++q) blk[q] = C[tb_sweep_index(j, q)];
+                const uint32_t y = tbv_target(blk);
+                if (y < kTbvGhostRows || y - kTbvGhostRows >= T || (blk[0] & 0xF000u) != kTbvDst) return 63;
+                uint32_t m = kTbInfBits;
+                for (uint32_t k = 0; k < kTbvSources; ++k) {
+                  const uint32_t r = tbv_source(blk, k);
+                  const uint32_t val = r < kTbvGhostRows ? Din[gs + r] : (lds[r - kTbvGhostRows] & 0x7fffffffu);   // (an unused slot names the target itself, weight +inf)
+                  if (r < kTbvGhostRows && r >= W.nh) return 63;
+                  m = std::min(m, f2u(u2f(val) + u2f(blk[8 + k])));
+                }
+                uint32_t& tv = lds[y - kTbvGhostRows];
+                if (m < (tv & 0x7fffffffu)) tv = m | kTbDirty;
+              }
+            }
+          } else
           for (uint32_t c = 0; c < W.pre_chunks; ++c) {
             const uint32_t* cur = &H.stream[((size_t)W.pre_off + c) * kTbChunk];
             const uint32_t* G = &Din[gs + 4 * (size_t)cur[12]];
@@ -119,7 +140,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
         if (vlayout) {
           // the register-resident kernel: one wave per item, blocks of up to six sources, rows by index; a tile none of whose
           // vertices has a source inside it has no blocks (one "sweep" that changes nothing)
-          const uint32_t voff = H.vtile[2 * t], vch = H.vtile[2 * t + 1];
+          const uint32_t voff = H.vtile[(size_t)kTbvTileWords * t + 2], vch = H.vtile[(size_t)kTbvTileWords * t + 3];
           for (;;) {
             uint32_t chg = 0;
             for (uint32_t c = 0; c < vch; ++c) {
@@ -129,13 +150,13 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
                 uint32_t blk[kTbBlock];
                 for (uint32_t q = 0; q < kTbBlock; ++q) blk[q] = C[tb_sweep_index(j, q)];
                 ++blocks_eval;
-                const uint32_t y = tbv_target(blk);
+                const uint32_t y = tbv_target(blk) - kTbvGhostRows;
                 if (y >= T) return 62;
                 for (uint32_t l = 0; l < cnt_l; ++l) {
                   uint32_t* lds = ldsv[l].data();
                   const uint32_t acc0 = lds[y] & 0x7fffffffu;
                   uint32_t acc = acc0;
-                  for (uint32_t k = 0; k < kTbvSources; ++k) { const uint32_t r = tbv_source(blk, k); if (r >= T) return 62; acc = std::min(acc, fabs_bits_add(lds[r], blk[8 + k])); }
+                  for (uint32_t k = 0; k < kTbvSources; ++k) { const uint32_t r = tbv_source(blk, k) - kTbvGhostRows; if (r >= T) return 62; acc = std::min(acc, fabs_bits_add(lds[r], blk[8 + k])); }
                   if (acc < acc0) { lds[y] = acc | kTbDirty; chg = 1; }
                 }
               }
@@ -178,6 +199,38 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
           for (uint32_t r = 0; r < T; ++r) if (lds[r] & kTbDirty) D[sl + r] = lds[r] & 0x7fffffffu;
           // post
           uint32_t cnd = kTbInfBits, best = kTbInfBits;
+          if (vlayout) {
+            const uint32_t* M = &H.vtile[(size_t)kTbvTileWords * t];
+            uint32_t gi = 0;
+            for (uint32_t c = 0; c < M[5]; ++c) {
+              const uint32_t* C = &H.vstream[((size_t)M[4] + c) * kTbChunk];
+              for (uint32_t j = 0; j < kTbBlocksPerChunk; ++j) {
+                uint32_t blk[kTbBlock];
+                for (uint32_t q = 0; q < kTbBlock; ++q) blk[q] = C[tb_sweep_index(j, q)];
+                const uint32_t h = tbv_target(blk), fl = tbv_flags(blk);
+                if (h >= kTbvGhostRows || (blk[0] & 0xF000u) != kTbvSrc) return 63;
+                for (uint32_t k = 0; k < kTbvSources; ++k) {
+                  const uint32_t r = tbv_source(blk, k);
+                  if (r < kTbvGhostRows) { if (r != h || blk[8 + k] != kTbInfBits) return 63; continue; }   // unused slot
+                  cnd = std::min(cnd, fabs_bits_add(lds[r - kTbvGhostRows], blk[8 + k]));
+                }
+                if (fl & kTbvGhostEnd) { if (cnd < Din[gs + h]) best = std::min(best, cnd); cnd = kTbInfBits; }
+                if (fl & kTbvTileEnd) {
+                  if (gi >= M[7]) return 63;
+                  const uint32_t owner = H.vgroups[(size_t)M[6] + gi++];
+                  if (best != kTbInfBits) {
+                    const size_t pi = (size_t)owner * NP + p;
+                    const uint32_t old = pend[pi];
+                    if (best < old) { pend[pi] = best; marr[par ^ 1][p] = std::min(marr[par ^ 1][p], best); }
+                    if (old == kTbInfBits) cand[par ^ 1].push_back({ owner, p });
+                    ++wakes;
+                  }
+                  best = kTbInfBits;
+                }
+              }
+            }
+            if (gi != M[7]) return 63;
+          } else
           for (uint32_t c = 0; c < W.post_chunks; ++c) {
             const uint32_t* cur = &H.stream[((size_t)W.post_off + c) * kTbChunk];
             const uint32_t* G = &Din[gs + 4 * (size_t)cur[12]];
@@ -200,6 +253,22 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
             }
           }
           // export
+          if (vlayout) {
+            const uint32_t* M = &H.vtile[(size_t)kTbvTileWords * t];
+            uint32_t covered = 0;
+            for (uint32_t k = 0; k < M[9]; ++k) {
+              const TbvExp& e = H.vexps[(size_t)M[8] + k];
+              if (e.n < 1 || e.n > 4) return 63;
+              for (uint32_t q = 0; q < e.n; ++q) {
+                const uint32_t row = (e.rows >> (8 * q)) & 0xFFu;
+                if (row < kTbvGhostRows || row - kTbvGhostRows >= T) return 63;
+                const uint32_t v = lds[row - kTbvGhostRows];
+                if (v & kTbDirty) D[(size_t)e.soff * NP + (size_t)p * e.sl + e.off + q] = v & 0x7fffffffu;
+                ++covered;
+              }
+            }
+            if (covered != W.exp_n) return 63;
+          } else
           for (uint32_t k = 0; k < W.exp_n; ++k) {
             const TbExp& e = H.exps[W.exp_off + k];
             const uint32_t v = lds[e.u / 256u];
@@ -213,7 +282,7 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   }
   for (uint32_t p = 0; p < NP; ++p)
     for (uint32_t v = 0; v < V; ++v) dist_out[(size_t)p * V + v] = u2f(D[slot(H.vert_tile[v], p, H.vert_local[v])]);
-  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; stats_out[7] = items; stats_out[8] = blocks_total; stats_out[9] = blocks_eval; stats_out[10] = stale_reads; }
+  if (stats_out) { stats_out[0] = iters; stats_out[1] = acts; stats_out[2] = sweeps_tot; stats_out[3] = wakes; stats_out[4] = max_sweeps; stats_out[5] = nt; stats_out[6] = H.S; stats_out[7] = items; stats_out[8] = blocks_total; stats_out[9] = blocks_eval; stats_out[10] = stale_reads; stats_out[11] = H.max_nh; }
   return 0;
 }
 

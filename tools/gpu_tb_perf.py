@@ -42,7 +42,7 @@ def main():
             tt = (ctypes.c_ulonglong * 8)()
             L.mnav_debug_tb_timing(tt)
             tot = float(sum(tt)) or 1.0
-            names = ["fetch", "load", "pre", "sweeps", "writeback", "post", "export", "-"]
+            names = ["fetch", "load", "pre", "sweeps", "writeback", "post" if os.environ.get("MNAV_TB_KERNEL") != "1" else "wakeups", "export", "postpass"]
             print("engine", eng, "kernel", os.environ.get("MNAV_TB_KERNEL", "auto"), "phase cycles:", {n: "%.1f%%" % (100.0 * tt[i] / tot) for i, n in enumerate(names)}, "total Gcycles %.2f" % (tot / 1e9), file=sys.stderr)
         best = min(res, key=lambda x: x["wall_ms"])
         best["plans_per_s"] = B / best["wall_ms"] * 1e3

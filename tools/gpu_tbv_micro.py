@@ -30,8 +30,8 @@ def make_stream(rng, nch):
                 srcs = [int(x) for x in rng.integers(0, T, n)] + [tgt] * (6 - n)
                 w = np.concatenate([rng.uniform(0.05, 0.3, n).astype(np.float32), np.full(6 - n, np.inf, np.float32)])
                 d = np.zeros(16, np.uint32)
-                S = [0x2000 | x for x in srcs]
-                d[0] = (0xA000 | tgt) | (S[0] << 16); d[1] = S[1] | (S[2] << 16); d[2] = S[3] | (S[4] << 16); d[3] = S[5]
+                S = [0x2000 | (64 + x) for x in srcs]                          # window rows: 64 ghosts first, owned row r at 64 + r
+                d[0] = (0xA000 | (64 + tgt)) | (S[0] << 16); d[1] = S[1] | (S[2] << 16); d[2] = S[3] | (S[4] << 16); d[3] = S[5]
                 d[8:14] = w.view(np.uint32)
                 base = (o * nch + c) * 64
                 for q in range(16):
