@@ -149,6 +149,7 @@ def main() -> None:
             first = first_of(g, t, r)
     barrier()
     elapsed = time.perf_counter() - t0
+    headline_kernel = ctx.last_engine()                                 # which engine / kernel `auto` ran the batches on
     from mesh_navigation_amd import multi
     total_plans, elapsed = multi.aggregate_throughput(B * args.steps, elapsed, dist)   # sum of plans, MAX time over ranks
     ctx.set_resident_outputs(False)
@@ -200,7 +201,7 @@ def main() -> None:
         # incident edge, summed over the batch) divided by the average launch duration, measured live with HIP events that
         # the library records on ITS OWN stream around the engine's launches.  Batches of >= 256 plans run on the tile-batch
         # engine: ONE engine run per batch = a few hundred iterations of k_tb_plan / k_tb_scan / k_tb_items / k_tb_solve
-        # replayed from a hipGraph (k_tb_solve_q is > 85 % of it, profiles/r05_bench_kernel_stats.md); the events bracket the
+        # replayed from a hipGraph (the solve kernel is > 80 % of it, profiles/r06_bench_kernel_stats.md); the events bracket the
         # whole run, so `achieved` prices the scheduling kernels too.  HBM traffic per run from the PMC passes committed
         # under profiles/ (tools/prof_pmc.sh: FETCH_SIZE / WRITE_SIZE summed over the engine's kernels of one batch) -- only
         # quoted when it was measured on this very workload.
@@ -210,10 +211,10 @@ def main() -> None:
         traffic = None
         traffic_profiled = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_pmc_traffic.json")))
-            if pm.get("kernel") == "k_tb_solve_q" and B == pm.get("batch") and N == pm.get("grid"):
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_pmc_traffic.json")))
+            if pm.get("kernel", "") in headline_kernel and B == pm.get("batch") and N == pm.get("grid"):
                 traffic_profiled = {"bytes_per_launch": pm["traffic_bytes_per_launch"], "bytes_per_launch_high": pm.get("traffic_bytes_per_launch_high"),
-                                    "source": "profiles/r05_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"}
+                                    "source": "profiles/r06_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"}
         except (OSError, ValueError, KeyError):
             pass
         per_launch_bytes = algo / max(launches, 1)
@@ -242,8 +243,12 @@ def main() -> None:
             "ms_per_plan_in_batch": ms_step / B,
             "cvp_planner_same_mesh": cvp,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_profiled": traffic_profiled,
-                         "kernel": "k_tb_solve_q (tile-batch engine run: plan/scan/items/solve iterations)" if launches <= args.steps else "k_tile_round",
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         # HBM bytes per launch: the counters cannot be read inside a timed run; what is quoted is the figure of the
+                         # committed rocprofv3 --pmc passes over this very command, under a key that says so
+                         "traffic": ({"profiled": traffic_profiled["bytes_per_launch"], "profiled_high": traffic_profiled["bytes_per_launch_high"],
+                                      "source": traffic_profiled["source"]} if traffic_profiled else "not profiled (no PMC passes of this workload and kernel under profiles/)"),
+                         "kernel": headline_kernel + " -- the whole engine run: plan / pairs / scan / items / solve iterations",
                          "launches_per_step": launches / args.steps, "vector_map_ms_per_step": vec_ms / args.steps,
                          "algorithmic_bytes_per_step": algo / args.steps,
                          "avg_launch_us": per_launch_s * 1e6, "propagation_ms_per_step": prop_ms / args.steps,
@@ -289,7 +294,7 @@ def roofline_of(stats, kernel):
     launches = max(int(stats["launches"]), 1)
     per_s = stats["ms_step_kernels"] * 1e-3 / launches
     ach = (stats["algorithmic_bytes"] / launches) / per_s / 1e9 if per_s > 0 else 0.0
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": "not profiled",
             "kernel": kernel, "launches": launches, "avg_launch_us": per_s * 1e6,
             "algorithmic_bytes": int(stats["algorithmic_bytes"]), "propagation_ms": stats["ms_propagation"]}
 
@@ -320,7 +325,7 @@ def leg_paths_only(ctx, mesh, robot, rng, args):
             assert (r["codes"] == 0).all()
         st = ctx.stats()                                                # untimed: takes the settled-vertex count of the last batch
         out[f"batch_{B}"] = {"plans_per_s": B / float(np.median(ts)), "ms_per_step": float(np.median(ts)) * 1e3,
-                             "propagation_ms": st["ms_propagation"], "roofline": roofline_of(st, "k_tb_solve")}
+                             "propagation_ms": st["ms_propagation"], "roofline": roofline_of(st, ctx.last_engine())}
     out["workload"] = "C2 batches, vertex paths only (no finalize pass / vector map)"
     return out
 
@@ -532,13 +537,14 @@ def leg_c4(local_rank, args):
         rb = ctx.plan_dijkstra_batch(goals, tg, goal_dist_offset=args.offset, want_fields=False, path_cap=65536, want_stats=False)
         tb = time.perf_counter() - tb
         assert (rb["codes"] == 0).all()
+        batch_kernel = ctx.last_engine()
         sb = ctx.stats()                                                # untimed: the settled-vertex count (k_tb_count, instrumentation for the
                                                                         # algorithmic bytes) is taken here, after the clock -- it was 6 % of ms_per_batch
         out = {"workload": f"C4: delta-stepping SSSP, {N}x{N} terrain seed 4 = {mesh.V} vertices, uniform edge costs, goal_dist_offset {args.offset:g}, one GPU",
                "vertices": mesh.V, "edges": mesh.E, "mesh_generation_s": t_gen, "upload_and_tiling_s": t_up,
                "ms_per_makeplan_single": float(np.median(lat)), "ms_per_makeplan_single_p95": float(np.percentile(lat, 95)),
                "batch": B, "plans_per_s_batch": B / tb, "ms_per_batch": tb * 1e3,
-               "roofline": roofline_of(sb, "k_tb_solve_q (tile-batch engine run)" if sb["launches"] <= 1 else "k_tile_round"),
+               "roofline": roofline_of(sb, batch_kernel),
                "roofline_single_plan": roofline_of(st, "k_plan_async (asynchronous tile engine: one launch per plan)" if st["launches"] == 1 else "k_tile_round")}
         if not args.no_cpu:
             from oracle import oracle as O

@@ -337,6 +337,10 @@ const void* mnav_device_output(const mnav_ctx* ctx, uint32_t slot, int what);
 /* Algorithmic bytes of the last call per SURVEY.md §8(d): SSSP 24*V' + 24*E', CVP 32*V' + 68*F'
  * with V' = settled vertices and E'/F' their incident edges/faces scaled from the full mesh. */
 uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx);
+/* Which engine / kernel ran the last Dijkstra call (for reports and profiles): the engine of mnav_set_dijkstra_engine that `auto`
+ * resolved to (0, 1, 5, 6), + 16 when the tile-batch engine (5) solved its tiles with the register-resident kernel k_tbv_solve
+ * (64 plans per wave, distances in VGPRs) instead of k_tb_solve_q (16 plans per quarter of a wave, distances in LDS).  -1: none. */
+int mnav_last_engine(const mnav_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mnav_shard_finalize", "mnav_update_costs", "mnav_update_edge_weights", "mnav_download_costs", "mnav_set_resident_outputs", "mnav_download_output",
     "mnav_vector_at", "mnav_backtrack_cvp", "mnav_backtrack_cvp_batch", "mnav_layer_upload", "mnav_layer_steepness", "mnav_layer_inflation", "mnav_layer_download",
     "mnav_combine_layers", "mnav_layer_stats", "mnav_layer_download_vectors", "mnav_combine_layers_update",
-    "mnav_set_option", "mnav_get_option", "mnav_shard_set_goal_tie",
+    "mnav_set_option", "mnav_get_option", "mnav_shard_set_goal_tie", "mnav_last_engine",
 ]
 
 
@@ -173,6 +173,8 @@ def load(path: str | None = None):
     L.mnav_shard_finalize.argtypes = [vp, vp, vp]
     L.mnav_algorithmic_bytes.restype = C.c_uint64
     L.mnav_algorithmic_bytes.argtypes = [vp]
+    L.mnav_last_engine.restype = C.c_int
+    L.mnav_last_engine.argtypes = [vp]
     if path is None:
         _lib = L
     return L
@@ -493,6 +495,12 @@ class MnavContext:
         d = s.as_dict()
         d["algorithmic_bytes"] = int(self._L.mnav_algorithmic_bytes(self._h))
         return d
+
+    def last_engine(self) -> str:
+        """Engine / kernel of the last Dijkstra call, by name (mnav_last_engine)."""
+        e = int(self._L.mnav_last_engine(self._h))
+        return {0: "k_tile_round (tile rounds)", 1: "k_step (band steps)", 5: "k_tb_solve_q (tile-batch engine, quarters of a wave, distances in LDS)",
+                21: "k_tbv_solve (tile-batch engine, one wave per tile, distances in VGPRs)", 6: "k_plan_async (asynchronous tile engine)"}.get(e, "none")
 
     def timing(self) -> dict:
         """Event timings of the last call; never triggers the (lazy) settled-vertex count of a tile-batch call."""

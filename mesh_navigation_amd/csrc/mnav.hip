@@ -1877,6 +1877,12 @@ uint64_t mnav_algorithmic_bytes(const mnav_ctx* ctx)
   return ctx->algo_bytes;
 }
 
+int mnav_last_engine(const mnav_ctx* ctx)
+{
+  if (!ctx || ctx->last_planner != kPlannerDijkstra || ctx->last_n == 0) return -1;
+  return ctx->last_engine + ((ctx->last_engine == 5 && ctx->tb.kernel == 1) ? 16 : 0);
+}
+
 #ifdef MNAV_TILE_TIMING
 int mnav_debug_tile_timing(unsigned long long* out, unsigned int cap)
 {

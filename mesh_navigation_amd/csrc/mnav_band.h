@@ -382,6 +382,22 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
       park_agg(S, want, v);
       if (want) S.lmin = fminf(S.lmin, t);
     }
+  } else if (cur.repair == 4) {                                      // spec: process_reset -- no evaluation
+    const uint32_t nthreads = gridDim.x * kWave, tid = blockIdx.x * kWave + lane;
+    for (uint32_t base = 0; base < P.V; base += nthreads) {
+      const uint32_t v = base + tid;
+      bool want = false;
+      if (v < P.V && !is_seed(P, v)) {
+        const float t = (PLANNER == kPlannerCvp) ? key_time(P.tkey[v]) : P.dist[v];
+        want = !(t < cur.thr_fixed) && (t < inf_f() || P.dist[v] < inf_f());
+        if (want) {
+          P.dist[v] = inf_f(); P.pred[v] = v;
+          if constexpr (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
+          S.lchanged = true;
+        }
+      }
+      push_agg<true>(S, want, v);
+    }
   } else if (cur.repair == 1) {                                      // spec: process_repair
     const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {

@@ -642,7 +642,7 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
   q.n = c.n_next;
   if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
   const bool out_of_steps = (uint32_t)q.it >= P.max_steps;
-  if (p.repair == 3 && !out_of_steps) {                               // the band was cut: start it again under the lower bound
+  if ((p.repair == 3 || p.repair == 4) && !out_of_steps) {            // the band was cut (3) or reset (4): start it again
     q.band_new = 1; q.band_steps = 0;
     return q;
   }
@@ -681,7 +681,12 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
       // where a vertex is read while its neighbour's evaluation is half stored.  The rest of the band runs entry after entry on
       // one 8-lane group (k_step, cur.serial): no concurrency, no torn state.  (Found by the round-5 soak: 16 of 209 random
       // sparse-lethal maps ran into the step cap here.)
-      q.serial = 1;
+      // Round 6: that alone left 2-3 % of such maps cycling -- the sequential pass inherits whatever the concurrent phase left
+      // behind (a cascade of a hundred vertices below the popping value whose tree keeps re-hanging itself; reproduced on the CPU
+      // model: Jacobi order until the band is serial, configuration 84 of tools/gpu_infl_fuzz.py), and from THAT state list order
+      // cycles too, while from a clean state every sequential order settles.  So the serial band starts clean: one reset step
+      // (repair == 4, process_reset) makes every vertex that is not settled yet forget its state and look again.
+      if (!p.serial) { q.serial = 1; q.repair = 4; }
     }
     return q;                                                          // band still moving
   }
@@ -1176,6 +1181,24 @@ MNAV_HD void process_cut(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 
 // Work-list rebuild after a band shrink (step with ctl.repair == 2): every keyed vertex that is
 // not settled yet is re-evaluated under the narrower band and re-enters the list.
+// Band reset (one step with ctl.repair == 4, before a band runs serially): a vertex that is not settled yet -- pop time at or
+// beyond thr_fixed, or a value without a pop time -- goes back to the state k_init gave it and is evaluated again in the next
+// step; the settled part of the wave (everything an earlier band fixed) is what the band restarts from.
+template <uint32_t PLANNER, class Ops>
+MNAV_HD void process_reset(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
+{
+  if (is_seed(P, v)) return;
+  constexpr bool cvp = (PLANNER == kPlannerCvp);
+  float t = P.dist[v];
+  if constexpr (cvp) t = key_time(P.tkey[v]);
+  if (t < c.thr_fixed) return;                                       // settled by an earlier band
+  if (!(t < inf_f()) && !(P.dist[v] < inf_f())) return;              // never touched
+  P.dist[v] = inf_f(); P.pred[v] = v;
+  if constexpr (cvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
+  ops.push_dirty(v);
+  ops.note_changed();
+}
+
 template <uint32_t PLANNER, class Ops>
 MNAV_HD void process_rebuild(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 {

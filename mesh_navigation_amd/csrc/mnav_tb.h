@@ -172,38 +172,61 @@ __global__ __launch_bounds__(kBlock) void k_tb_pairs(tb::Args A)
 }
 
 constexpr uint32_t kTbScanWaves = 8192;                              // persistent waves of k_tb_scan (a row of the list after the other)
+// One listed row per wave and turn.  A row is a chain of dependent round trips (list entry -> the row of pending values and the
+// plans' thresholds -> the bucket's counter -> the bucket entries) and a wave walks a dozen of them per launch: the NEXT row's
+// pending values and thresholds are fetched before the current row is worked on, the list entry after that one too (round 6:
+// 107 -> ~60 us per launch at 7168 plans, where the pass had become a fifth of the engine run).
 __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kBlock / 64);
   const uint32_t n_pairs = A.ctl->n_pairs;
+  MNAV_GLOBAL const uint32_t* const pairs = as_global(A.pairs);
+  MNAV_GLOBAL const float* const g_thr = as_global(A.thr);
+  MNAV_GLOBAL const float* const g_bnd = as_global(A.bnd);
   uint32_t carried = 0;
-  for (uint32_t k = wave; k < n_pairs; k += nwaves) {
-    const uint32_t pr = A.pairs[k], t = pr / A.nblk, blk = pr - t * A.nblk;
-    if (t >= A.ntiles) continue;                                     // (padding bytes of the flag matrix are never set)
-    const uint32_t p = blk * 64u + (uint32_t)lane;
-    const bool live = p < A.NP;
-    MNAV_GLOBAL uint32_t* const pe = as_global(A.pend) + ((size_t)t * A.NP + (live ? p : 0u));
-    const uint32_t pb = live ? *pe : kTbInfBits;
-    bool ready = false, keep = false;
-    if (pb != kTbInfBits) {
-      const float pv = u2f(pb), thr = A.thr[p], bnd = A.bnd[p];
-      if (pv > bnd) *pe = kTbInfBits;
-      else if (pv < thr) { *pe = kTbInfBits; ready = true; }
-      else {
-        keep = true; ++carried;
-        MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
-        if (pb < *pm) atomicMin((uint32_t*)pm, pb);                    // plain look first (see k_tb_solve_q)
+  struct Row { uint32_t pr, t, p, pb; float thr, bnd; bool live; };
+  auto fetch = [&](uint32_t pr) {                                     // the loads of one row, all issued together
+    Row r; r.pr = pr;
+    r.t = pr / A.nblk;
+    const uint32_t blk = pr - r.t * A.nblk;
+    r.p = blk * 64u + (uint32_t)lane;
+    r.live = pr != kNone && r.t < A.ntiles && r.p < A.NP;              // (padding bytes of the flag matrix are never set)
+    r.pb = kTbInfBits; r.thr = 0.f; r.bnd = 0.f;
+    if (r.live) { r.pb = as_global(A.pend)[(size_t)r.t * A.NP + r.p]; r.thr = g_thr[r.p]; r.bnd = g_bnd[r.p]; }
+    return r;
+  };
+  uint32_t k = wave;
+  uint32_t pr_next = (k + nwaves < n_pairs) ? pairs[k + nwaves] : kNone;
+  Row cur = fetch(k < n_pairs ? pairs[k] : kNone);
+  for (; k < n_pairs; k += nwaves) {
+    const uint32_t pr_after = (k + 2u * nwaves < n_pairs) ? pairs[k + 2u * nwaves] : kNone;
+    const Row nxt = fetch(pr_next);                                   // in flight while `cur` is worked on
+    pr_next = pr_after;
+    if (cur.pr != kNone && cur.t < A.ntiles) {
+      const uint32_t t = cur.t, p = cur.p, pb = cur.pb;
+      MNAV_GLOBAL uint32_t* const pe = as_global(A.pend) + ((size_t)t * A.NP + (cur.live ? p : 0u));
+      bool ready = false, keep = false;
+      if (cur.live && pb != kTbInfBits) {
+        const float pv = u2f(pb);
+        if (pv > cur.bnd) *pe = kTbInfBits;
+        else if (pv < cur.thr) { *pe = kTbInfBits; ready = true; }
+        else {
+          keep = true; ++carried;
+          MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
+          if (pb < *pm) atomicMin((uint32_t*)pm, pb);                    // plain look first (see k_tb_solve_q)
+        }
+      }
+      if (!__any(keep) && lane == 0) A.pflag[cur.pr] = 0;
+      const unsigned long long m = __ballot(ready);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));
+        base = tb::rfl(base);
+        if (ready) A.bucket[(size_t)t * A.NP + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
       }
     }
-    if (!__any(keep) && lane == 0) A.pflag[pr] = 0;
-    const unsigned long long m = __ballot(ready);
-    if (m) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));
-      base = tb::rfl(base);
-      if (ready) A.bucket[(size_t)t * A.NP + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
-    }
+    cur = nxt;
   }
   carried = wave_sum(carried);
   if (lane == 0 && carried) atomicAdd(&A.ctl->n_cand[par ^ 1], carried);

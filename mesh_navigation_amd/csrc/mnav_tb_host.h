@@ -239,15 +239,20 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
   A.offset = offset;
-  // Solve kernel.  k_tbv_solve (distances in registers, mnav_tbv.h) takes whole waves per tile: it pays when a tile's bucket of
-  // ready plans fills most of a wave.  A plan's front crosses ~sqrt(tiles) tiles per iteration, so a tile sees about
-  // 0.85 n / sqrt(tiles) plans (measured: 63 at C2 = 7168 plans on 9 260 tiles, 11 at C4 = 4096 plans on 92 600 tiles).
+  // Solve kernel and band.  k_tbv_solve (distances in registers, mnav_tbv.h) takes whole waves per tile.  A plan's front crosses
+  // ~sqrt(tiles) tiles per iteration, so a tile sees about 0.85 n / sqrt(tiles) plans per iteration and band of 2 tile widths
+  // (measured: 63 at C2 = 7168 plans on 9 260 tiles, 11 at C4 = 4096 plans on 92 600 tiles); a wider band puts more plans on a
+  // tile per iteration at the price of more activations.  Measured round 6 (engine ms per batch, k_tb_solve_q band 2 /
+  // k_tbv_solve band 2 / band 4; density = n / sqrt(tiles)): 1M mesh 128 plans (density 1.3) 49 / 55 / 53, 512 (5.3) 64 / 72 / 67,
+  // 2048 (21) 100 / 86 / 83, 7168 (74) 194 / 124 / 133; 10M mesh 4096 plans (13.5) 1524 / 1292 / 1180 (band 6: 1176).
   const bool v_fits = S.T == 120 && S.max_nh <= kTbvGhostRows;        // (its register window holds 120 owned rows and 64 ghosts)
-  S.kernel = (v_fits && (double)n >= 40.0 * std::sqrt((double)std::max(S.ntiles, 1u))) ? 1 : 0;
+  const double density = (double)n / std::sqrt((double)std::max(S.ntiles, 1u));
+  S.kernel = (v_fits && density >= 8.0) ? 1 : 0;
   if (opt_set(ctx->opt.tb_kernel)) S.kernel = (opt_u32(ctx->opt.tb_kernel, 0u) == 1u && v_fits) ? 1 : 0;
   A.item_plans = S.kernel == 1 ? 64u : kTbItemPlans;
   {
-    float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * S.band_mult;   // potential across one tile
+    const float band_mult = (S.kernel == 1 && density < 40.0) ? 4.0f : S.band_mult;
+    float band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * band_mult;   // potential across one tile
     if (opt_set(ctx->opt.tb_band_mult)) band = (ctx->delta_auto / 3.0f) * std::sqrt((float)S.T) * (float)ctx->opt.tb_band_mult;
     if (ctx->tile_band_user > 0.f) band = ctx->tile_band_user;
     A.band = band;

@@ -84,6 +84,11 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
         if (planner == kPlannerCvp) process_cut<kPlannerCvp>(P, cur, v, ops);
         else process_cut<kPlannerDijkstra>(P, cur, v, ops);
       }
+    } else if (cur.repair == 4) {                                    // band reset before a serial band (controller_core)
+      for (uint32_t v = 0; v < V; ++v) {
+        if (planner == kPlannerCvp) process_reset<kPlannerCvp>(P, cur, v, ops);
+        else process_reset<kPlannerDijkstra>(P, cur, v, ops);
+      }
     } else if (cur.repair == 2) {
       for (uint32_t v = 0; v < V; ++v) {
         if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
@@ -103,7 +108,7 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
           rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
           std::swap(perm[i - 1], perm[rng % i]);
         }
-      if (order == 3 && !cur.serial) {
+      if ((order == 3 || order >= 4) && !cur.serial) {
         // snapshot of everything the rules read
         std::vector<float> sd(dist, dist + V), sdir; std::vector<uint32_t> sp(pred, pred + V), scut;
         std::vector<PopKey> sk(tkey); std::vector<float> skd; if (P.keyd) skd.assign(P.keyd, P.keyd + V);
@@ -111,9 +116,17 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
         Plan R = P;
         R.dist = sd.data(); R.pred = sp.data(); R.tkey = sk.data(); if (P.keyd) R.keyd = skd.data();
         if (planner == kPlannerCvp) { R.dirn = sdir.data(); R.cutf = scut.data(); }
+        // order >= 4: a seeded mixture -- every entry reads either the snapshot (a neighbour's evaluation has not landed yet) or
+        // the state in place (it has), in shuffled order: closer to the device's racy evaluation than pure Jacobi
+        if (order >= 4 && j == 0) rng ^= 0x9E3779B97F4A7C15ull * (uint64_t)order;
+        if (order >= 4)
+          for (uint32_t i = nent; i > 1; --i) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; std::swap(perm[i - 1], perm[rng % i]); }
         for (uint32_t i = 0; i < nent; ++i) {
-          if (planner == kPlannerCvp) process_entry_rw<kPlannerCvp>(R, P, cur, list[i], ops);
-          else process_entry_rw<kPlannerDijkstra>(R, P, cur, list[i], ops);
+          bool snap = true;
+          if (order >= 4) { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; snap = (rng >> 33) & 1u; }
+          const uint32_t vv = list[order >= 4 ? perm[i] : i];
+          if (planner == kPlannerCvp) process_entry_rw<kPlannerCvp>(snap ? R : P, P, cur, vv, ops);
+          else process_entry_rw<kPlannerDijkstra>(snap ? R : P, P, cur, vv, ops);
         }
       } else
       for (uint32_t i = 0; i < nent; ++i) {

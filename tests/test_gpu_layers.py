@@ -166,13 +166,14 @@ def _sparse_lethal_case(i):
     return case, lethal, inv, radius
 
 
-@pytest.mark.parametrize("i", [129, 40, 16])
+@pytest.mark.parametrize("i", [129, 40, 16, 62, 67, 84])
 def test_isolated_lethal_vertices_with_tied_pop_times_settle(gpu_ctx_factory, i):
     """Isolated lethal vertices on the regular grid make vertices of EXACTLY the same pop time; such a band, one key wide, kept
     flipping under the concurrent in-place evaluation until the step cap (16 of 209 random maps of the round-5 soak, all of this
-    kind: INTERNAL_ERROR).  The controller now runs the rest of such a band entry after entry on one 8-lane group (Ctl.serial):
-    distances and costs are the reference's bits again.  (Not all of them: 2 of the first 85 maps of that fuzz still end in
-    INTERNAL_ERROR -- configurations 67 and 84 --, where the sequential pass cycles as well)"""
+    kind: INTERNAL_ERROR).  The controller runs the rest of such a band entry after entry on one 8-lane group (Ctl.serial) -- since
+    round 6 from a CLEAN state (one reset step, mnav_eval.h process_reset): configurations 62, 67 and 84 of tools/gpu_infl_fuzz.py,
+    where the sequential pass inherited a cascade that kept re-hanging itself and cycled too, settle as well (reproduced and fixed
+    on the CPU model first: tests/test_inflation_model.py).  Distances and costs are the reference's bits."""
     case, lethal, inv, radius = _sparse_lethal_case(i)
     cfg = O.InflationCfg.defaults()
     cfg.inflation_radius = radius

@@ -146,3 +146,20 @@ def test_repulsive_vector_field_is_the_reference_restatement_bit_for_bit(kind):
                 assert ok.all(), (kind, s, trial, radius, int((~ok).sum()))
                 wave = int(np.isfinite(dist).sum()) > int(lethal.sum())     # scattered single lethal vertices start no wave
                 assert (r["has_vec"].sum() > 0) == wave
+
+
+def test_a_band_of_tied_pop_times_restarts_clean_before_it_runs_serially():
+    """Configuration 84 of tools/gpu_infl_fuzz.py (isolated lethal vertices + invalid vertices on the regular grid, radius 0.9): in
+    Jacobi order -- the model's stand-in for the device's concurrent evaluation -- a band one key wide keeps ~100 cascade members
+    below the popping value re-hanging each other; the controller turns the band serial after 64 steps, and until round 6 the
+    sequential pass CYCLED from the state it inherited (step cap -> INTERNAL_ERROR on the device, 2-3 % of such maps).  With the
+    reset step before the serial band (process_reset) the wave settles and is the reference's, bit for bit."""
+    from tests.test_gpu_layers import _sparse_lethal_case
+    case, lethal, inv, radius = _sparse_lethal_case(84)
+    cfg = O.InflationCfg.defaults()
+    cfg.inflation_radius = radius
+    _, dist, _ = case.om.inflation(lethal, case.edge_dist, cfg, invalid=inv)
+    m = case.mesh
+    r = O.schedule_model_inflation(m.faces, m.edges, case.edge_dist, lethal, radius, order=3, invalid=inv, max_steps=6000)
+    assert r["code"] == 0 and r["verify_bad"] == 0
+    assert np.array_equal(bits(r["dist"]), bits(dist))
