@@ -165,6 +165,7 @@ struct mnav_ctx {
   uint32_t *d_pack = nullptr, *h_pack = nullptr, *d_pack_meta = nullptr; size_t pack_words = 0, pack_meta_n = 0;   // packed paths (device, pinned host), offsets + lengths
   std::unordered_map<void*, size_t> alloc_bytes;                   // sizes of the dev_upload buffers (re-used when unchanged)
   Ctl* h_ctl = nullptr;       // pinned, 2 per plan
+  uint32_t infl_exact_bands = 0;   // bands of the last inflation wave that went through the exact band routine (k_exact_band)
   float* d_seed_pos = nullptr; uint32_t seed_pos_cap = 1;
   std::map<uint64_t, hipGraphExec_t> graphs;
   // tiled SSSP engine
@@ -1045,6 +1046,7 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
   if (G > 8192u) G = 8192u;
   const auto t_start = std::chrono::steady_clock::now();
   Ctl last{};
+  ctx->infl_exact_bands = 0;
   for (;;) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
       ctx->err = "inflation wave exceeded the wall-clock guard"; return -1;
@@ -1057,6 +1059,14 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
       fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u)\n", last.it,
               last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used);
     if (last.done) break;
+    if (last.exact_wanted) {
+      // a band that neither the concurrent steps nor a serial band from a clean state settle (tied pop times around isolated
+      // lethal vertices: 0.5 % of random such maps): its vertices are popped one at a time, the reference's own procedure
+      // (mnav_eval.h exact_*; the steps idle meanwhile and resume with a cut step)
+      hipLaunchKernelGGL(k_exact_band, dim3(1), dim3(kWave), 0, ctx->stream, ctx->d_plans, (uint32_t*)nullptr);
+      HIPCHK(hipGetLastError());
+      ++ctx->infl_exact_bands;
+    }
   }
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
   // verification: every vertex must be a fixed point of the replay rule on the converged state (k_cvp_verify)

@@ -359,6 +359,7 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
   __syncthreads();
   const Ctl cur = s_ctl;
   if (cur.done) return;
+  if (cur.repair == 5) return;                                       // idle: the host runs the exact band routine next (controller_core)
   if constexpr (PRECTL) { if (cur.repair <= 2 && P.seed_mask == nullptr) return; }   // k_step_wide's
   Cnt* cnt = &P.cnt[j % 3];
   StepCtx S{ &P, cnt, P.list[(cur.it + 1) & 1], (uint32_t)cur.it + 1u, inf_f(), 0u, false, P.wlist[cur.wsel & 1u], cur.wbase, cur.epoch, inf_f() };
@@ -449,6 +450,87 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
 
 template <uint32_t PLANNER>
 __global__ MNAV_STEP_BOUNDS void k_step(const Plan* __restrict__ plans, int j) { step_body<PLANNER, false>(plans, j, blockIdx.y); }
+
+// The exact band routine (mnav_eval.h: exact_*), run by the host between two chunks of steps when a plan's control block says
+// exact_wanted: ONE wave.  Lanes work side by side over the reset list, over the candidate list (minimum by key) and over the
+// corner neighbours of a popped vertex; an evaluation reads only final state and its own vertex, so the lanes of a round do not
+// depend on each other -- all evaluate, barrier, all store.  Lists: the plan's two work-list buffers (idle while the steps idle).
+__global__ __launch_bounds__(kWave) void k_exact_band(const Plan* __restrict__ plans, uint32_t* __restrict__ pops_out)
+{
+  const Plan& P = plans[blockIdx.x];
+  const int lane = threadIdx.x;
+  const Ctl a = P.ctl[0], b = P.ctl[1];
+  const int slot = (a.it > b.it) ? 0 : 1;
+  const Ctl cur = slot == 0 ? a : b;
+  if (!cur.exact_wanted || cur.done) return;
+  Ctl x = exact_ctl(cur);
+  uint32_t* const A = P.list[0];
+  uint32_t* const C = P.list[1];
+  __shared__ uint32_t s_nA, s_nC;
+  if (lane == 0) { s_nA = 0u; s_nC = 0u; }
+  __syncthreads();
+  const uint32_t tagA = kExactStamp - 2u, tagC = kExactStamp - 1u;
+  auto add = [&](uint32_t* L, uint32_t* n, uint32_t tag, uint32_t v) {
+    if (v == kNone || v >= P.V) return;
+    if (atomicExch(&P.stamp[v], tag) == tag) return;                  // listed already
+    const uint32_t at = atomicAdd(n, 1u);
+    if (at < P.cap) L[at] = v;
+  };
+  // 1. the band's vertices and their corner neighbours ...
+  for (uint32_t base = 0; base < P.V; base += kWave) {
+    const uint32_t v = base + (uint32_t)lane;
+    if (v >= P.V || is_seed(P, v)) continue;
+    const float t = key_time(P.tkey[v]);
+    if (!(t >= cur.thr_fixed && t < cur.thr)) continue;
+    add(A, &s_nA, tagA, v);
+    for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) { const Corner k = P.crn[i]; if (k.v1 == kNone) continue; add(A, &s_nA, tagA, k.v1); add(A, &s_nA, tagA, k.v2); }
+  }
+  __syncthreads();
+  const uint32_t nA = min(s_nA, P.cap);
+  // ... forget what was derived from provisional supports ...
+  for (uint32_t i = lane; i < nA; i += kWave) {
+    const uint32_t v = A[i];
+    if (is_seed(P, v) || P.blocked[v] || key_time(P.tkey[v]) < cur.thr_fixed) continue;
+    P.dist[v] = inf_f(); P.pred[v] = v; P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f();
+  }
+  __threadfence(); __syncthreads();
+  // ... and evaluate them on settled supports only
+  for (uint32_t base = 0; base < nA; base += kWave) {
+    const uint32_t i = base + (uint32_t)lane;
+    const uint32_t v = i < nA ? A[i] : kNone;
+    const ExactEval r = exact_eval(P, x, v);
+    __syncthreads();
+    if (exact_store(P, x, v, r)) add(C, &s_nC, tagC, v);
+    __threadfence(); __syncthreads();
+  }
+  // 2. one pop at a time
+  uint32_t pops = 0;
+  for (;;) {
+    const uint32_t nC = min(s_nC, P.cap);
+    uint32_t best = kNone;
+    for (uint32_t i = lane; i < nC; i += kWave) { const uint32_t u = C[i]; if (exact_better(P, x, u, best)) best = u; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)best, o);
+      if (other != kNone && (best == kNone || (other != best && key_less(P, key_ref(P, other), key_ref(P, best))))) best = other;
+    }
+    best = (uint32_t)__shfl((int)best, 0);
+    if (best == kNone) break;
+    x.bound_v = best; ++pops;
+    const uint32_t beg = P.crn_ptr[best], n2 = 2u * (P.crn_ptr[best + 1] - beg);
+    for (uint32_t base = 0; base < n2; base += kWave) {
+      const uint32_t i = base + (uint32_t)lane;
+      uint32_t w = kNone;
+      if (i < n2) { const Corner k = P.crn[beg + (i >> 1)]; if (k.v1 != kNone) w = (i & 1u) ? k.v2 : k.v1; }
+      const ExactEval r = exact_eval(P, x, w);
+      __syncthreads();
+      if (exact_store(P, x, w, r)) add(C, &s_nC, tagC, w);              // (a vertex met in two corners is stored twice with the same state)
+      __threadfence(); __syncthreads();
+    }
+  }
+  // 3. back to the band steps
+  if (lane == 0) { P.ctl[slot] = exact_done_ctl(cur); if (pops_out) atomicAdd(pops_out, pops); }
+}
 
 #include "mnav_cvp_wide.h"   // CVP batches: wide_round, k_cvp_ctl, k_step_wide, k_step_repair
 

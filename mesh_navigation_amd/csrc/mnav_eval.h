@@ -374,6 +374,11 @@ struct Ctl {
   uint32_t serial;     // 1: the steps of this band run on ONE 8-lane group, entry after entry (see controller_core)
   uint32_t arm_vertex; // CVP: the robot-face vertex whose pop armed goal_dist (kNone until then): pops up to and including its
                        // own met goal_dist = +inf at :754 and expand whatever their value (passes_goal_cut)
+  // the exact band (exact_band_* below): a band that does not settle is handed to a routine that pops its vertices one at a time
+  uint32_t exact_wanted; // 1: the steps idle (repair == 5) until the host has run the exact band routine on this plan
+  uint32_t force_cut;    // 1: the next step is a cut step at thr (rebuilds the waiting list), then the band starts again
+  uint32_t exact;        // inside the routine only: a support is fixed when it was settled by an earlier band or popped by the routine ...
+  uint32_t bound_v;      // ... i.e. when its key is not after the key of this vertex, the last one the routine popped (kNone: none yet)
 };
 
 struct Cnt {
@@ -642,6 +647,11 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
   q.n = c.n_next;
   if (c.n_next > P.cap) { q.overflow = 1; q.done = 1; q.n = 0; return q; }
   const bool out_of_steps = (uint32_t)q.it >= P.max_steps;
+  if (p.exact_wanted && !out_of_steps) { q.repair = 5; q.n = 0; return q; }   // idle until the exact band routine has run
+  if (p.force_cut && !out_of_steps) {                                 // the exact band routine has run: rebuild the waiting list, start the band again
+    q.force_cut = 0; q.repair = 3; q.band_steps = 0; q.n = 0;
+    return q;
+  }
   if ((p.repair == 3 || p.repair == 4) && !out_of_steps) {            // the band was cut (3) or reset (4): start it again
     q.band_new = 1; q.band_steps = 0;
     return q;
@@ -686,7 +696,13 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
       // model: Jacobi order until the band is serial, configuration 84 of tools/gpu_infl_fuzz.py), and from THAT state list order
       // cycles too, while from a clean state every sequential order settles.  So the serial band starts clean: one reset step
       // (repair == 4, process_reset) makes every vertex that is not settled yet forget its state and look again.
+      // ... which settled most of them (2-3 % -> 0.5 % of random sparse-lethal maps refused) but not all: a cascade whose members
+      // support each other with PROVISIONAL keys can keep re-hanging itself under every order of evaluation (reproduced on the CPU
+      // model with a seeded mixture of snapshot and in-place reads, orders >= 4).  What cannot cycle is the reference's own
+      // procedure -- one pop at a time, a vertex acting as a support only once its state is final --: after a serial band has had
+      // its kBandStepLimit steps too, the band is handed to exact_band_* (the steps idle until the host has run it).
       if (!p.serial) { q.serial = 1; q.repair = 4; }
+      else { q.exact_wanted = 1; q.repair = 5; q.n = 0; }
     }
     return q;                                                          // band still moving
   }
@@ -718,7 +734,7 @@ MNAV_HD Ctl controller(const Plan& P, const Ctl& p, const Cnt& c)
   const float wmin = fminf(p.wmin, u2f(c.minkey));
   Ctl q = controller_core(P, p, c, wmin, wtot);
   q.wsel = p.wsel; q.wread = 0; q.wbase = wtot; q.wmin = wmin; q.epoch = p.epoch;
-  if (!q.done && (q.band_new || q.repair)) {
+  if (!q.done && (q.band_new || (q.repair && q.repair != 5))) {
     q.wsel = p.wsel ^ 1u; q.wread = q.repair ? 0u : wtot; q.wbase = 0; q.wmin = inf_f(); q.epoch = (uint32_t)q.it + 2u;
   }
   return q;
@@ -757,6 +773,21 @@ MNAV_HD Eval eval_dijkstra(const Plan& P, const Ctl& c, uint32_t v)
 // earliest such pop; trig == kNone when the face cannot fire in this band.
 struct Fire { KeyRef key; uint32_t trig; };
 
+// Has the support with pop time t / key k popped as far as this evaluation is concerned?  In a band step: everything below the
+// band's upper bound (the in-band vertices support each other with their provisional keys, the iteration sorts it out).  In the
+// exact band routine: what an earlier band settled, and what the routine has popped so far.
+MNAV_HD_COLD bool popped_exact(const Plan& P, const Ctl& c, float t, KeyRef k)
+{
+  if (t < c.thr_fixed) return true;
+  if (c.bound_v == kNone || !(t < inf_f())) return false;
+  return !key_less(P, key_ref(P, c.bound_v), k);                     // not after the last pop
+}
+MNAV_HD bool popped(const Plan& P, const Ctl& c, float t, const KeyRef& k)
+{
+  if (!c.exact) return t < c.thr;
+  return popped_exact(P, c, t, k);
+}
+
 // (k1, k2: key_ref of the two supports, d1, d2: their potentials -- loaded by the caller, so that a kernel can have the loads of
 // many faces in flight before the first one is looked at)
 MNAV_HD Fire corner_fire_pre(const Plan& P, const Ctl& c, const Corner& k, const KeyRef& k1, const KeyRef& k2, float d1, float d2)
@@ -765,7 +796,8 @@ MNAV_HD Fire corner_fire_pre(const Plan& P, const Ctl& c, const Corner& k, const
   if (k.v1 == kNone) return f;
   const bool s1 = is_seed(P, k.v1), s2 = is_seed(P, k.v2);
   const float t1 = key_time(k1.k), t2 = key_time(k2.k);
-  if (!((s1 || t1 < c.thr) && (s2 || t2 < c.thr))) return f;         // both supports fixed by this band
+  const bool p1 = popped(P, c, t1, k1), p2 = popped(P, c, t2, k2);
+  if (!((s1 || p1) && (s2 || p2))) return f;                         // both supports fixed by this band
   bool ex1 = true, ex2 = true;
   if (P.seed_mask) {
     const uint8_t m1 = P.seed_mask[k.v1], m2 = P.seed_mask[k.v2];
@@ -776,8 +808,8 @@ MNAV_HD Fire corner_fire_pre(const Plan& P, const Ctl& c, const Corner& k, const
     if (s2) { for (int q = 0; q < 3; ++q) if (P.seed[q] == k.v2) ex2 = P.seed_expands[q] != 0; }
   }
   const bool one_first = key_less(P, k1, k2);                        // v1 pops before v2
-  const bool trig1 = t1 < c.thr && ex1 && passes_goal_cut(P, c, d1, k1) && (s2 || !one_first);
-  const bool trig2 = t2 < c.thr && ex2 && passes_goal_cut(P, c, d2, k2) && (s1 || one_first || k1.own == k2.own);
+  const bool trig1 = p1 && ex1 && passes_goal_cut(P, c, d1, k1) && (s2 || !one_first);
+  const bool trig2 = p2 && ex2 && passes_goal_cut(P, c, d2, k2) && (s1 || one_first || k1.own == k2.own);
   if (trig1) { f.key = k1; f.trig = k.v1; }
   if (trig2 && (!trig1 || key_less(P, k2, k1))) { f.key = k2; f.trig = k.v2; }
   return f;
@@ -1198,6 +1230,60 @@ MNAV_HD void process_reset(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
   ops.push_dirty(v);
   ops.note_changed();
 }
+
+// ---------------------------------------------------------------------------------------
+// The exact band (Ctl.exact_wanted): the reference's own procedure for ONE band -- pop the vertices of the band one at a time, in
+// key order; a vertex acts as a support only once it has popped, i.e. once its state is final.  No provisional state ever feeds
+// another, so there is nothing to iterate and nothing that can cycle: every pop fixes one vertex for good.  The routine
+//   1. resets the band: every vertex with a pop time in [thr_fixed, thr) and its corner neighbours that are not settled are
+//      evaluated again from SETTLED supports only (exact_entry with bound_v = kNone);
+//   2. repeats: the candidate with the smallest key pops (bound_v = that vertex), its corner neighbours are evaluated again;
+//      until no candidate with a pop time below thr is left;
+//   3. hands back to the band steps: force_cut (a cut step at thr rebuilds the waiting list from the vertices' stored keys), then
+//      the band starts again on a state that is a fixed point of the step rule -- it completes at once.
+// Candidates are kept in a plain list (a plan's idle work-list buffer), the minimum is found by scanning it: a band that needs
+// this is a few hundred vertices.  Host (CPU model) and device (k_exact_band: one workgroup, lanes over the list / the neighbours)
+// share the pieces below.  Inflation waves only (the CVP planner's bands have never needed it).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kExactStamp = 0xFFFFFFF1u;                        // Plan.stamp value of a vertex on the routine's candidate list
+MNAV_HD Ctl exact_ctl(const Ctl& c) { Ctl x = c; x.exact = 1u; x.bound_v = kNone; return x; }
+// evaluates v on final supports only and stores its state; true: v is a candidate now (keyed, not popped, pop time below thr)
+MNAV_HD bool exact_entry(const Plan& P, const Ctl& x, uint32_t v)
+{
+  if (v == kNone || v >= P.V || is_seed(P, v) || P.blocked[v]) return false;
+  if (popped_exact(P, x, key_time(P.tkey[v]), key_ref(P, v))) return false;   // final
+  const Eval e = eval_cvp(P, x, v);
+  P.dist[v] = e.d; P.pred[v] = e.pred; P.tkey[v] = e.key; P.dirn[v] = e.dir; P.cutf[v] = e.cut;
+  if (P.keyd) P.keyd[v] = e.keyd;
+  return e.t < x.thr;
+}
+// the same in two halves, for lanes that work side by side: all evaluate (reads only), barrier, all store
+struct ExactEval { Eval e; bool act; };
+MNAV_HD ExactEval exact_eval(const Plan& P, const Ctl& x, uint32_t v)
+{
+  ExactEval r; r.act = false;
+  if (v == kNone || v >= P.V || is_seed(P, v) || P.blocked[v]) return r;
+  if (popped_exact(P, x, key_time(P.tkey[v]), key_ref(P, v))) return r;
+  r.e = eval_cvp(P, x, v); r.act = true;
+  return r;
+}
+MNAV_HD bool exact_store(const Plan& P, const Ctl& x, uint32_t v, const ExactEval& r)
+{
+  if (!r.act) return false;
+  P.dist[v] = r.e.d; P.pred[v] = r.e.pred; P.tkey[v] = r.e.key; P.dirn[v] = r.e.dir; P.cutf[v] = r.e.cut;
+  if (P.keyd) P.keyd[v] = r.e.keyd;
+  return r.e.t < x.thr;
+}
+// is candidate u still one (its state may have moved since it was listed), and does it pop before the best so far?
+MNAV_HD bool exact_better(const Plan& P, const Ctl& x, uint32_t u, uint32_t best)
+{
+  const KeyRef ku = key_ref(P, u);
+  const float t = key_time(ku.k);
+  if (!(t < x.thr) || popped_exact(P, x, t, ku)) return false;
+  return best == kNone || key_less(P, ku, key_ref(P, best));
+}
+// the state the band steps resume from
+MNAV_HD Ctl exact_done_ctl(const Ctl& c) { Ctl q = c; q.exact = 0u; q.bound_v = kNone; q.exact_wanted = 0u; q.force_cut = 1u; q.serial = 0u; return q; }
 
 template <uint32_t PLANNER, class Ops>
 MNAV_HD void process_rebuild(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)

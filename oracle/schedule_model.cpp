@@ -71,6 +71,39 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
     if (sm_debug >= 0 && j >= sm_debug && j < sm_debug + 140)
       fprintf(stderr, "step %d n=%u thr=%.9g fixed=%.9g width=%.3g repair=%u band_new=%u band_steps=%u | prev changed=%u minkey=%.9g\n", j, cur.n, cur.thr, cur.thr_fixed, cur.width, cur.repair, cur.band_new, cur.band_steps, cprev.changed, u2f(cprev.minkey));
     if (cur.done) break;
+    if (cur.exact_wanted) {
+      // the exact band routine (mnav_eval.h), what the host runs between two chunks of steps on the device (k_exact_band)
+      Ctl x = exact_ctl(cur);
+      std::vector<uint32_t> A, C;
+      auto add = [&](std::vector<uint32_t>& L, uint32_t v) { if (v != kNone && P.stamp[v] != kExactStamp - 1u - (&L == &C ? 0u : 1u)) { P.stamp[v] = kExactStamp - 1u - (&L == &C ? 0u : 1u); L.push_back(v); } };
+      for (uint32_t v = 0; v < V; ++v) {                              // 1. the band's vertices and their corner neighbours, unless settled
+        const float t = key_time(tkey[v]);
+        if (is_seed(P, v) || !(t >= cur.thr_fixed && t < cur.thr)) continue;
+        add(A, v);
+        for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) { const Corner k = P.crn[i]; if (k.v1 == kNone) continue; add(A, k.v1); add(A, k.v2); }
+      }
+      for (uint32_t v : A) {                                          //    forget what was derived from provisional supports
+        if (is_seed(P, v) || blocked[v] || key_time(tkey[v]) < cur.thr_fixed) continue;
+        dist[v] = inf_f(); pred[v] = v; tkey[v] = key_inf(); dirn[v] = 0.0f; cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f();
+      }
+      for (uint32_t v : A) if (exact_entry(P, x, v)) add(C, v);
+      uint64_t pops = 0;
+      for (;;) {                                                      // 2. one pop at a time
+        uint32_t best = kNone;
+        for (uint32_t u : C) if (exact_better(P, x, u, best)) best = u;
+        if (best == kNone) break;
+        x.bound_v = best; ++pops;
+        for (uint32_t i = P.crn_ptr[best]; i < P.crn_ptr[best + 1]; ++i) {
+          const Corner k = P.crn[i];
+          if (k.v1 == kNone) continue;
+          if (exact_entry(P, x, k.v1)) add(C, k.v1);
+          if (exact_entry(P, x, k.v2)) add(C, k.v2);
+        }
+      }
+      if (getenv("SM_EXACT_DEBUG")) fprintf(stderr, "exact band at step %d: [%.9g, %.9g), %zu reset, %zu candidates, %llu pops\n", j, cur.thr_fixed, cur.thr, A.size(), C.size(), (unsigned long long)pops);
+      ctl[j & 1] = exact_done_ctl(cur);                               // 3. back to the band steps
+      continue;
+    }
     Cnt& cc = cnt[j % 3];
     HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1), P.wlist[cur.wsel], cur.wbase, cur.epoch };
     const uint32_t* list = P.list[j & 1];

@@ -163,3 +163,22 @@ def test_a_band_of_tied_pop_times_restarts_clean_before_it_runs_serially():
     r = O.schedule_model_inflation(m.faces, m.edges, case.edge_dist, lethal, radius, order=3, invalid=inv, max_steps=6000)
     assert r["code"] == 0 and r["verify_bad"] == 0
     assert np.array_equal(bits(r["dist"]), bits(dist))
+
+
+@pytest.mark.parametrize("i,order", [(62, 4), (476, 6)])
+def test_a_band_that_no_order_of_evaluation_settles_is_popped_one_vertex_at_a_time(i, order):
+    """Configurations 62 and 476 of tools/gpu_infl_fuzz.py refused on the device even with the clean serial band (8 of 1526 maps):
+    under a seeded mixture of snapshot and in-place reads (model orders >= 4: closer to the device's racy evaluation than pure
+    Jacobi) a band one key wide holds a cascade whose members support each other with provisional keys -- it re-hangs itself under
+    every order, the serial one included.  The controller then hands the band to the exact band routine (mnav_eval.h exact_*: the
+    reference's own procedure, one pop at a time, a vertex supports others only once its state is final), the steps resume from a
+    fixed point of their own rule.  The wave is the reference's bit for bit, and the verification sweep finds nothing."""
+    from tests.test_gpu_layers import _sparse_lethal_case
+    case, lethal, inv, radius = _sparse_lethal_case(i)
+    cfg = O.InflationCfg.defaults()
+    cfg.inflation_radius = radius
+    _, dist, _ = case.om.inflation(lethal, case.edge_dist, cfg, invalid=inv)
+    m = case.mesh
+    r = O.schedule_model_inflation(m.faces, m.edges, case.edge_dist, lethal, radius, order=order, invalid=inv, max_steps=20000)
+    assert r["code"] == 0 and r["verify_bad"] == 0 and r["verify_flags"] == 0
+    assert np.array_equal(bits(r["dist"]), bits(dist))
