@@ -290,8 +290,9 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
  * (2, one persistent workgroup per plan, was retired in round 5: -1),
  * 3 = automatic (default): 6 for calls of up to `async_max_batch` = 96 plans (a call whose ticket ring overflows is re-run on 0),
  *     5 beyond that (batches that also hold >= tiles/1000 plans), else 0,
- * 5 = tile-batch: one plan per lane, 16 plans per quarter of a wave, the tile's graph as record streams
- *     (highest throughput for large batches),
+ * 5 = tile-batch: one plan per lane, the tile's graph as record streams (highest throughput for large batches); its tiles are
+ *     solved by k_tbv_solve (one wave per tile, <= 64 plans, the distances in VGPRs) when a tile sees enough plans per iteration
+ *     (plans / sqrt(tiles) >= 8, option "tb_kernel" overrides), else by k_tb_solve_q (16 plans per quarter of a wave, LDS),
  * 6 = the LDS tiles without rounds: resident workgroups serve a ticket queue of woken tiles, solve and wake tiles
  *     asynchronously, one launch per call (single plans -- what MeshPlanner::makePlan runs -- and batches up to ~100 plans).
  * All give identical results (the label-correcting fixed point does not depend on the schedule). */

@@ -383,22 +383,6 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
       park_agg(S, want, v);
       if (want) S.lmin = fminf(S.lmin, t);
     }
-  } else if (cur.repair == 4) {                                      // spec: process_reset -- no evaluation
-    const uint32_t nthreads = gridDim.x * kWave, tid = blockIdx.x * kWave + lane;
-    for (uint32_t base = 0; base < P.V; base += nthreads) {
-      const uint32_t v = base + tid;
-      bool want = false;
-      if (v < P.V && !is_seed(P, v)) {
-        const float t = (PLANNER == kPlannerCvp) ? key_time(P.tkey[v]) : P.dist[v];
-        want = !(t < cur.thr_fixed) && (t < inf_f() || P.dist[v] < inf_f());
-        if (want) {
-          P.dist[v] = inf_f(); P.pred[v] = v;
-          if constexpr (PLANNER == kPlannerCvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
-          S.lchanged = true;
-        }
-      }
-      push_agg<true>(S, want, v);
-    }
   } else if (cur.repair == 1) {                                      // spec: process_repair
     const uint32_t rounds = (P.V + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {
@@ -417,23 +401,12 @@ __device__ __forceinline__ void step_body(const Plan* __restrict__ plans, int j,
     const uint32_t* list = P.list[cur.it & 1];
     const uint32_t* wprev = P.wlist[(cur.wsel ^ 1u) & 1u];
     const uint32_t ntot = cur.n + cur.wread;
-    if (cur.serial) {
-      // a band that the concurrent evaluation cannot settle (controller_core): ONE group of ONE wave, entry after entry, every
-      // store of an entry visible before the next one is read
-      if (blockIdx.x == 0)
-        for (uint32_t i = 0; i < ntot; ++i) {
-          const uint32_t v = i < cur.n ? list[i] : wprev[i - cur.n];
-          group_process<PLANNER, false>(S, P, cur, grp == 0, v, sub);
-          __threadfence();
-        }
-    } else {
     const uint32_t rounds = (ntot + ngroups - 1) / ngroups;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t i = g0 + r * ngroups;
       const bool active = i < ntot;
       const uint32_t v = active ? (i < cur.n ? list[i] : wprev[i - cur.n]) : 0u;
       group_process<PLANNER, false>(S, P, cur, active, v, sub);
-    }
     }
   }
   const float wmin = wave_min(S.lmin);

@@ -371,7 +371,7 @@ struct Ctl {
   uint32_t cuts;       // statistics: band cuts (kCutAfter)
   uint32_t epoch;      // id of the current waiting list (1 for the list the first steps append to, then step index of the
                        // epoch step + 2); Plan.wstamp (0 = never parked) dedups with it
-  uint32_t serial;     // 1: the steps of this band run on ONE 8-lane group, entry after entry (see controller_core)
+  uint32_t serial;     // (unused since round 6: the exact band routine replaced the serial band)
   uint32_t arm_vertex; // CVP: the robot-face vertex whose pop armed goal_dist (kNone until then): pops up to and including its
                        // own met goal_dist = +inf at :754 and expand whatever their value (passes_goal_cut)
   // the exact band (exact_band_* below): a band that does not settle is handed to a routine that pops its vertices one at a time
@@ -652,7 +652,7 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
     q.force_cut = 0; q.repair = 3; q.band_steps = 0; q.n = 0;
     return q;
   }
-  if ((p.repair == 3 || p.repair == 4) && !out_of_steps) {            // the band was cut (3) or reset (4): start it again
+  if (p.repair == 3 && !out_of_steps) {                               // the band was cut: start it again under the lower bound
     q.band_new = 1; q.band_steps = 0;
     return q;
   }
@@ -672,7 +672,11 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
         return q;
       }
     }
-    if (P.planner == kPlannerCvp && q.band_steps >= kBandStepLimit && p.thr > next_up(p.thr_fixed > 0.0f ? p.thr_fixed : 0.0f)) {
+    const bool wide = p.thr > next_up(p.thr_fixed > 0.0f ? p.thr_fixed : 0.0f);
+    // (inflation waves: after three shrinks in a row -- a sixty-fourth of the radius -- the band goes to the exact band routine
+    //  as it is; shrinking on, down to single keys, cost 66 steps per key on maps full of tied pop times: step cap)
+    const bool shrink = wide && (P.seed_mask == nullptr || p.width > P.delta * (1.0f / 64.0f));
+    if (P.planner == kPlannerCvp && q.band_steps >= kBandStepLimit && shrink) {
       // Not converging: on triangles that grossly violate the triangle inequality the in-band
       // vertices can support each other in a cycle.  Cut the band down from the bottom (at the
       // width of a single key the replay is exactly the sequential loop) and rebuild the work
@@ -685,30 +689,20 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
       q.thr = thr;
       q.repair = 2; q.band_new = 1; q.band_steps = 0; q.shrinks = p.shrinks + 1;
     } else if (P.seed_mask != nullptr && q.band_steps >= kBandStepLimit) {
-      // The band is one key wide and STILL moving: vertices of exactly the same pop time (ties are common around isolated
-      // lethal vertices on a regular grid) that keep each other flipping.  Every sequential order settles such a band (the CPU
-      // model does, in list, reversed, random and Jacobi order); what does not is the device's concurrent in-place evaluation,
-      // where a vertex is read while its neighbour's evaluation is half stored.  The rest of the band runs entry after entry on
-      // one 8-lane group (k_step, cur.serial): no concurrency, no torn state.  (Found by the round-5 soak: 16 of 209 random
-      // sparse-lethal maps ran into the step cap here.)
-      // Round 6: that alone left 2-3 % of such maps cycling -- the sequential pass inherits whatever the concurrent phase left
-      // behind (a cascade of a hundred vertices below the popping value whose tree keeps re-hanging itself; reproduced on the CPU
-      // model: Jacobi order until the band is serial, configuration 84 of tools/gpu_infl_fuzz.py), and from THAT state list order
-      // cycles too, while from a clean state every sequential order settles.  So the serial band starts clean: one reset step
-      // (repair == 4, process_reset) makes every vertex that is not settled yet forget its state and look again.
-      // ... which settled most of them (2-3 % -> 0.5 % of random sparse-lethal maps refused) but not all: a cascade whose members
-      // support each other with PROVISIONAL keys can keep re-hanging itself under every order of evaluation (reproduced on the CPU
-      // model with a seeded mixture of snapshot and in-place reads, orders >= 4).  What cannot cycle is the reference's own
-      // procedure -- one pop at a time, a vertex acting as a support only once its state is final --: after a serial band has had
-      // its kBandStepLimit steps too, the band is handed to exact_band_* (the steps idle until the host has run it).
-      if (!p.serial) { q.serial = 1; q.repair = 4; }
-      else { q.exact_wanted = 1; q.repair = 5; q.n = 0; }
+      // A narrow band that is STILL moving: vertices of exactly the same pop time (ties are common around isolated lethal
+      // vertices on a regular grid) and the cascades below them, whose members support each other with PROVISIONAL keys and keep
+      // re-hanging each other -- under the device's concurrent in-place evaluation, under a sequential pass that inherits its
+      // state, and (2-3 % -> 0.5 % of random sparse-lethal maps, round 6) even under a sequential pass from a clean state;
+      // reproduced on the CPU model with a seeded mixture of snapshot and in-place reads (orders >= 4).  What cannot cycle is the
+      // reference's own procedure -- one pop at a time, a vertex acting as a support only once its state is final --: the band is
+      // handed to exact_band_* (the steps idle until the host has run it).  (Rounds 5-6 first ran such a band entry after entry on
+      // one 8-lane group, `serial`, then the same from a reset state: gone, the routine covers both.)
+      q.exact_wanted = 1; q.repair = 5; q.n = 0;
     }
     return q;                                                          // band still moving
   }
   q.thr_fixed = p.thr;
   q.band_steps = 0;
-  q.serial = 0;
   if (!p.repair) q.bands = p.bands + 1;
   if (!q.armed && !out_of_steps) {
     try_arm(P, q);
@@ -718,7 +712,7 @@ MNAV_HD Ctl controller_core(const Plan& P, const Ctl& p, const Cnt& c, float m_w
   if (out_of_steps) { q.overflow = 2; q.done = 1; q.n = 0; return q; }   // did not converge: reported as an error
   if ((c.n_next == 0 && n_wait == 0) || !(m < inf_f())) { q.done = 1; q.n = 0; return q; }
   if (q.armed && m > q.goal_dist) { q.done = 1; q.n = 0; return q; }   // nothing left that may expand
-  q.width = fminf(P.delta, p.width * 2.0f);
+  q.width = fminf(P.delta, fmaxf(p.width * 2.0f, P.delta * (1.0f / 4096.0f)));   // (recovers from any shrink: a width that underflowed stayed 0)
   float thr = m + q.width;
   if (!(thr > m)) thr = next_up(m);
   q.thr = thr;
@@ -1213,24 +1207,6 @@ MNAV_HD void process_cut(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
 
 // Work-list rebuild after a band shrink (step with ctl.repair == 2): every keyed vertex that is
 // not settled yet is re-evaluated under the narrower band and re-enters the list.
-// Band reset (one step with ctl.repair == 4, before a band runs serially): a vertex that is not settled yet -- pop time at or
-// beyond thr_fixed, or a value without a pop time -- goes back to the state k_init gave it and is evaluated again in the next
-// step; the settled part of the wave (everything an earlier band fixed) is what the band restarts from.
-template <uint32_t PLANNER, class Ops>
-MNAV_HD void process_reset(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)
-{
-  if (is_seed(P, v)) return;
-  constexpr bool cvp = (PLANNER == kPlannerCvp);
-  float t = P.dist[v];
-  if constexpr (cvp) t = key_time(P.tkey[v]);
-  if (t < c.thr_fixed) return;                                       // settled by an earlier band
-  if (!(t < inf_f()) && !(P.dist[v] < inf_f())) return;              // never touched
-  P.dist[v] = inf_f(); P.pred[v] = v;
-  if constexpr (cvp) { P.tkey[v] = key_inf(); P.dirn[v] = 0.0f; P.cutf[v] = kNone; if (P.keyd) P.keyd[v] = inf_f(); }
-  ops.push_dirty(v);
-  ops.note_changed();
-}
-
 // ---------------------------------------------------------------------------------------
 // The exact band (Ctl.exact_wanted): the reference's own procedure for ONE band -- pop the vertices of the band one at a time, in
 // key order; a vertex acts as a support only once it has popped, i.e. once its state is final.  No provisional state ever feeds
@@ -1283,7 +1259,7 @@ MNAV_HD bool exact_better(const Plan& P, const Ctl& x, uint32_t u, uint32_t best
   return best == kNone || key_less(P, ku, key_ref(P, best));
 }
 // the state the band steps resume from
-MNAV_HD Ctl exact_done_ctl(const Ctl& c) { Ctl q = c; q.exact = 0u; q.bound_v = kNone; q.exact_wanted = 0u; q.force_cut = 1u; q.serial = 0u; return q; }
+MNAV_HD Ctl exact_done_ctl(const Ctl& c) { Ctl q = c; q.exact = 0u; q.bound_v = kNone; q.exact_wanted = 0u; q.force_cut = 1u; return q; }
 
 template <uint32_t PLANNER, class Ops>
 MNAV_HD void process_rebuild(const Plan& P, const Ctl& c, uint32_t v, Ops& ops)

@@ -117,11 +117,6 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
         if (planner == kPlannerCvp) process_cut<kPlannerCvp>(P, cur, v, ops);
         else process_cut<kPlannerDijkstra>(P, cur, v, ops);
       }
-    } else if (cur.repair == 4) {                                    // band reset before a serial band (controller_core)
-      for (uint32_t v = 0; v < V; ++v) {
-        if (planner == kPlannerCvp) process_reset<kPlannerCvp>(P, cur, v, ops);
-        else process_reset<kPlannerDijkstra>(P, cur, v, ops);
-      }
     } else if (cur.repair == 2) {
       for (uint32_t v = 0; v < V; ++v) {
         if (planner == kPlannerCvp) process_rebuild<kPlannerCvp>(P, cur, v, ops);
@@ -141,7 +136,7 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
           rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
           std::swap(perm[i - 1], perm[rng % i]);
         }
-      if ((order == 3 || order >= 4) && !cur.serial) {
+      if (order == 3 || order >= 4) {
         // snapshot of everything the rules read
         std::vector<float> sd(dist, dist + V), sdir; std::vector<uint32_t> sp(pred, pred + V), scut;
         std::vector<PopKey> sk(tkey); std::vector<float> skd; if (P.keyd) skd.assign(P.keyd, P.keyd + V);

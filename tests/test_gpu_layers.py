@@ -166,14 +166,15 @@ def _sparse_lethal_case(i):
     return case, lethal, inv, radius
 
 
-@pytest.mark.parametrize("i", [129, 40, 16, 62, 67, 84])
+@pytest.mark.parametrize("i", [129, 40, 16, 62, 67, 84, 745, 1211, 5438, 7515])
 def test_isolated_lethal_vertices_with_tied_pop_times_settle(gpu_ctx_factory, i):
-    """Isolated lethal vertices on the regular grid make vertices of EXACTLY the same pop time; such a band, one key wide, kept
-    flipping under the concurrent in-place evaluation until the step cap (16 of 209 random maps of the round-5 soak, all of this
-    kind: INTERNAL_ERROR).  The controller runs the rest of such a band entry after entry on one 8-lane group (Ctl.serial) -- since
-    round 6 from a CLEAN state (one reset step, mnav_eval.h process_reset): configurations 62, 67 and 84 of tools/gpu_infl_fuzz.py,
-    where the sequential pass inherited a cascade that kept re-hanging itself and cycled too, settle as well (reproduced and fixed
-    on the CPU model first: tests/test_inflation_model.py).  Distances and costs are the reference's bits."""
+    """Isolated lethal vertices on the regular grid make vertices of EXACTLY the same pop time, and cascades below them whose members
+    support each other with provisional keys: such a band kept flipping under the concurrent in-place evaluation until the step cap
+    (16 of 209 random maps of the round-5 soak: INTERNAL_ERROR; with a serial band 2-3 %, with a serial band from a reset state
+    0.5 % -- configurations 62, 67, 84 and 745, 1211, 5438 of tools/gpu_infl_fuzz.py are what each stage left).  Since round 6 a
+    narrow band that does not settle goes through the exact band routine (mnav_eval.h exact_*, k_exact_band: one pop at a time, the
+    reference's own procedure; reproduced and fixed on the CPU model first, tests/test_inflation_model.py).  Distances and costs are
+    the reference's bits."""
     case, lethal, inv, radius = _sparse_lethal_case(i)
     cfg = O.InflationCfg.defaults()
     cfg.inflation_radius = radius
@@ -185,4 +186,4 @@ def test_isolated_lethal_vertices_with_tied_pop_times_settle(gpu_ctx_factory, i)
     c, _, d = ctx.layer_download(1, distances=True)
     assert np.array_equal(bits(d), bits(dist)), int((bits(d) != bits(dist)).sum())
     assert np.array_equal(bits(c), bits(cost))
-    assert st["steps"] < 5000
+    assert st["steps"] < 20000                                         # (a band that goes through the exact band routine idles through the rest of its chunk of steps)
