@@ -726,8 +726,9 @@ def cpu_baseline(mesh, edge_w, costs, first, B, offset=0.3):
                     ref_ms.append((time.perf_counter() - t1) * 1e3)
                     ref_plans.append((code, plan))
                 plug, match = {}, True
-                for label, params in (("reference_side_effects", {}),
-                                      ("no_vsized_syncs_static_costs", dict(sync_vector_map=False, publish_potential=False, static_costs=True))):
+                for label, params in (("default", {}),
+                                      ("reference_side_effects", dict(reference_side_effects=True)),
+                                      ("static_costs", dict(static_costs=True))):
                     if not rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "bench_" + label, goal_dist_offset=float(offset), **params):
                         plug[label] = None
                         continue

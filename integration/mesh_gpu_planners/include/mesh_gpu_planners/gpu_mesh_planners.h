@@ -89,7 +89,7 @@ private:
   rclcpp::Node::SharedPtr node_;
   std::atomic_bool cancel_planning_{ false }, reload_costs_{ false };   // reload_costs_: parameter `<name>.reload_costs` was set (static_costs maps)
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0;
-           bool sync_vector_map = true; bool publish_potential = true; } config_;
+           bool sync_vector_map = false; bool publish_potential = false; } config_;
   // sync_vector_map: MeshMap::setVectorMap after every plan, like the reference (:208); publish_potential: the "Potential"
   // cost layer after every plan (:124).  Both cross PCIe with V-sized arrays; switched off, a plan costs the host O(path).
   std::unique_ptr<DeviceMap> dev_;
@@ -119,7 +119,7 @@ private:
   rclcpp::Node::SharedPtr node_;
   std::atomic_bool cancel_planning_{ false }, reload_costs_{ false };
   struct { bool publish_vector_field = false; bool publish_face_vectors = false; double goal_dist_offset = 0.3; double cost_limit = 1.0; double step_width = 0.4;
-           bool publish_potential = true; bool sync_vector_map = true; bool device_backtracking = false; int device_inflation_layer = -1; } config_;
+           bool publish_potential = false; bool sync_vector_map = false; bool device_backtracking = false; int device_inflation_layer = -1; } config_;
   // device_backtracking: the walk over the vector field (cvp :920-951) runs on the device (mnav_backtrack_cvp); with
   // sync_vector_map and publish_vector_field off as well, nothing V-sized crosses PCIe per plan.
   std::unique_ptr<DeviceMap> dev_;

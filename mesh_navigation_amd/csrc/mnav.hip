@@ -508,8 +508,28 @@ int verify_sweeps(mnav_ctx* ctx, uint32_t n)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&any, ctx->d_verify_any, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (any && n == 1 && opt_on(ctx->opt.trace)) {
+      Cnt f{};
+      (void)hipMemcpy(&f, ctx->slots[0].cnt + 3, sizeof(Cnt), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[mnav] verification sweep %d: %u vertices not at their fixed point\n", sweep, f.changed);
+    }
     if (!any) break;
     ++ctx->verify_sweeps_used;
+  }
+  if (ctx->verify_sweeps_used > (uint32_t)kVerifySweeps && n == 1) {
+    // the concurrent sweeps keep a tie cluster flipping: list what is off (fix == 2), repair it one vertex at a time, check again
+    uint32_t any = 0;
+    HIPCHK(hipMemsetAsync(ctx->d_verify_any, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_flags_reset, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
+    hipLaunchKernelGGL(k_cvp_verify, dim3(gv, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, 2, ctx->d_verify_any);
+    hipLaunchKernelGGL(k_verify_serial, dim3(n), dim3(kWave), 0, ctx->stream, ctx->d_plans, 200000u);
+    HIPCHK(hipMemsetAsync(ctx->d_verify_any, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_flags_reset, dim3(n), dim3(64), 0, ctx->stream, ctx->d_plans);
+    hipLaunchKernelGGL(k_cvp_verify, dim3(gv, n), dim3(kWave), 0, ctx->stream, ctx->d_plans, 0, ctx->d_verify_any);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&any, ctx->d_verify_any, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (opt_on(ctx->opt.trace)) fprintf(stderr, "[mnav] verification: serial repair, %s\n", any ? "still off" : "clean");
   }
   if (opt_on(ctx->opt.trace)) fprintf(stderr, "[mnav] verification: %u fixing sweep(s)\n", ctx->verify_sweeps_used);
   return 0;

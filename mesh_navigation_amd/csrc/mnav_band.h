@@ -538,6 +538,55 @@ __global__ __launch_bounds__(kWave) void k_cvp_seed_ring(const Plan* __restrict_
   }
 }
 
+// Serial repair, the last resort of the verification (verify_sweeps): the vertices a sweep flags (fix == 2: listed in the plan's
+// first work-list buffer, counted in cnt[3].n_wait) are evaluated again ONE AFTER THE OTHER by one 8-lane group; a vertex whose
+// state moves hands its corner neighbours on.  The concurrent fixing sweeps store while their neighbours read: a cluster of tied
+// pop times can keep flipping under them exactly like under the band steps (1 of 7 611 random sparse-lethal inflation maps,
+// configuration 7515 of tools/gpu_infl_fuzz.py: 4, 4, 1, 1, 9, 3, 7, 5 vertices off after sweeps 1..8); one at a time, every
+// evaluation sees its neighbours' stores (what the CPU model's verification does: it settles that map in two sweeps).
+__global__ __launch_bounds__(kWave) void k_verify_serial(const Plan* __restrict__ plans, uint32_t max_evals)
+{
+  const Plan& P = plans[blockIdx.x];
+  const int lane = threadIdx.x;
+  const Ctl a = P.ctl[0], b = P.ctl[1];
+  const Ctl cur = (a.it > b.it) ? a : b;
+  if (!cur.done || cur.overflow) return;
+  const int sub = lane & (kGroup - 1);
+  uint32_t* const L = P.list[0];
+  __shared__ uint32_t s_head, s_tail;
+  if (lane == 0) { s_head = 0u; s_tail = min(P.cnt[3].n_wait, P.cap); }
+  __syncthreads();
+  const uint32_t tag = kExactStamp - 3u;
+  if (lane == 0) for (uint32_t i = 0; i < s_tail; ++i) P.stamp[L[i]] = tag;
+  __threadfence(); __syncthreads();
+  for (uint32_t n = 0; n < max_evals; ++n) {
+    if (s_head >= s_tail) break;
+    const uint32_t v = L[s_head % P.cap];
+    __syncthreads();
+    bool moved = false;
+    if (lane < kGroup) {                                               // (one group: the others idle)
+      const Eval e = group_eval_cvp(P, cur, v, sub);
+      if (sub == 0) moved = !verify_entry(P, cur, v, e, true);
+    }
+    moved = __shfl((int)moved, 0) != 0;
+    if (lane == 0) {
+      ++s_head;
+      P.stamp[v] = 0u;                                                 // may be listed again
+      if (moved)
+        for (uint32_t i = P.crn_ptr[v]; i < P.crn_ptr[v + 1]; ++i) {
+          const Corner k = P.crn[i];
+          if (k.v1 == kNone) continue;
+          for (int q = 0; q < 2; ++q) {
+            const uint32_t w = q ? k.v2 : k.v1;
+            if (is_seed(P, w) || P.blocked[w] || P.stamp[w] == tag || s_tail - s_head >= P.cap) continue;
+            P.stamp[w] = tag; L[s_tail % P.cap] = w; ++s_tail;
+          }
+        }
+    }
+    __threadfence(); __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ plans, int fix, uint32_t* __restrict__ any_bad)
 {
   const Plan& P = plans[blockIdx.y];
@@ -554,7 +603,10 @@ __global__ __launch_bounds__(kWave) void k_cvp_verify(const Plan* __restrict__ p
     const bool act = v < P.V && !is_seed(P, v < P.V ? v : 0u) && !P.blocked[v < P.V ? v : 0u];
     if (!act) continue;                                               // whole 8-lane groups skip together
     const Eval e = group_eval_cvp(P, cur, v, sub);
-    if (sub == 0 && !verify_entry(P, cur, v, e, fix != 0)) ++bad;     // spec: mnav_eval.h (with fix: stores the re-evaluated state)
+    if (sub == 0 && !verify_entry(P, cur, v, e, fix == 1)) {          // spec: mnav_eval.h (fix 1: stores the re-evaluated state)
+      ++bad;
+      if (fix == 2) { const uint32_t at = atomicAdd(&P.cnt[3].n_wait, 1u); if (at < P.cap) P.list[0][at] = v; }   // listed for k_verify_serial
+    }
   }
   bad = wave_sum(bad);
   if (lane == 0 && bad) { atomicAdd(&P.cnt[3].changed, bad); atomicOr(any_bad, 1u); }

@@ -34,7 +34,7 @@ def test_gpu_dijkstra_plugin_equals_the_reference_planner_on_the_reference_map(w
     code_r, plan_r, cost_r = rm.dijkstra_make_plan(pose(robot), pose(goal))
     vm_r, has_r = rm.map_vector_map()                            # what the reference planner left in the MAP (setVectorMap, :208)
     assert has_r.any()
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra")
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra", reference_side_effects=True)
     code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal))
     assert code == code_r == 0
     vm, has = rm.map_vector_map()                                # ... and what the GPU plugin leaves there: the controller reads this
@@ -55,11 +55,30 @@ def test_gpu_dijkstra_plugin_equals_the_reference_planner_on_the_reference_map(w
     rm.plugin_release()
 
 
+def test_default_plugin_leaves_the_v_sized_fields_on_the_device(world):
+    """By default (`reference_side_effects` false) the plugin returns the reference's plan -- every pose bit for bit -- and does NOT
+    bring the vector field into the map or publish "Potential" after every plan (lvr2 maps of V entries: three quarters of a
+    makePlan at 1M vertices); the fields stay resident on the device (mnav_vector_at / mnav_download_output on demand)."""
+    m, rm, robot, goal = world
+    code_r, plan_r, cost_r = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    vm_r, has_r = rm.map_vector_map()                            # the reference planner's field is in the map now
+    goal2 = m.xyz[m.vertex_at(0.5, 0.9)]
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra_lazy")
+    c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal2))  # another wave: a synced field would differ from the reference's first
+    cr, pr, kr = rm.dijkstra_make_plan(pose(robot), pose(goal))
+    code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal))
+    assert code == code_r == 0 and np.array_equal(plan, plan_r) and cost == cost_r
+    vm, has = rm.map_vector_map()                                # untouched by the plugin: still what the reference planner left last
+    assert np.array_equal(has, has_r) and np.array_equal(vm.view(np.uint32), vm_r.view(np.uint32))
+    assert c2 == 0 and len(p2) > 20
+    rm.plugin_release()
+
+
 def test_gpu_cvp_plugin_equals_the_reference_planner_on_the_reference_map(world):
     m, rm, robot, goal = world
     gq = (0, 0, np.sin(0.3), np.cos(0.3))
     code_r, plan_r, cost_r, msg_r = rm.cvp_make_plan(pose(robot), pose(goal, gq), step_width=0.3)
-    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp", step_width=0.3)
+    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp", step_width=0.3, reference_side_effects=True)
     code, plan, cost, msg = rm.plugin_make_plan(pose(robot), pose(goal, gq))
     assert code == code_r == 0, (msg, msg_r)
     assert len(plan) == len(plan_r) and len(plan) > 10
@@ -70,7 +89,7 @@ def test_gpu_cvp_plugin_equals_the_reference_planner_on_the_reference_map(world)
     # the reference's default step width loses the surface on this 0.1 m terrain: same outcome, same message
     rm2 = R.RefMap(m.xyz, m.faces)
     cr, pr, kr, mr = rm2.cvp_make_plan(pose(robot), pose(goal))
-    assert rm2.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_default")
+    assert rm2.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_default", reference_side_effects=True)
     c, p, k, mm = rm2.plugin_make_plan(pose(robot), pose(goal))
     assert c == cr and mm == mr and len(p) == len(pr)
     rm.plugin_release(); rm2.plugin_release()
@@ -90,7 +109,7 @@ def test_gpu_plugins_publish_what_the_reference_publishes_and_follow_parameter_c
     path_r = rm.published_path()
     pot_r = rm.published_costs("Potential")
     assert code_r == 0 and path_r is not None and pot_r is not None and len(path_r) == len(plan_r)
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra_pub")
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dijkstra_pub", reference_side_effects=True)
     code, plan, cost, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     assert code == 0
     assert rm.published_count("~/path") == 1                     # the plugin's own publisher (it published last), first message
@@ -109,7 +128,7 @@ def test_gpu_plugins_publish_what_the_reference_publishes_and_follow_parameter_c
     assert code3 == 0 and np.array_equal(plan3, plan)
     rm.plugin_release()
     # CVP: path + potential published, step_width follows the parameter
-    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_pub", step_width=0.3)
+    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_pub", step_width=0.3, reference_side_effects=True)
     gq = (0, 0, np.sin(0.3), np.cos(0.3))
     c, p, k, msg = rm.plugin_make_plan(pose(robot), pose(goal, gq))
     assert c == 0, msg
@@ -140,14 +159,14 @@ def test_gpu_cvp_plugin_with_device_backtracking_equals_the_reference_planner(wo
         assert np.array_equal(plan, plan_r) and cost == cost_r
         rm.plugin_release()
         # the host walk on the downloaded field gives the same plan (the field itself is bit-identical now)
-        assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", name + "_host", step_width=sw)
+        assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", name + "_host", step_width=sw, reference_side_effects=True)
         code_h, plan_h, cost_h, _ = rm.plugin_make_plan(pose(robot), pose(goal, gq))
         assert code_h == 0 and np.array_equal(plan_h, plan_r) and cost_h == cost_r
         rm.plugin_release()
     # the walk that loses the surface (default step width on this 0.1 m terrain): same outcome and message from the device
     rm2 = R.RefMap(m.xyz, m.faces)
     cr, pr, kr, mr = rm2.cvp_make_plan(pose(robot), pose(goal))
-    assert rm2.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_dev_default", device_backtracking=True)
+    assert rm2.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_dev_default", device_backtracking=True, reference_side_effects=True)
     c, p, k, mm = rm2.plugin_make_plan(pose(robot), pose(goal))
     assert c == cr and mm == mr and len(p) == len(pr)
     rm2.plugin_release()
@@ -158,7 +177,7 @@ def test_gpu_plugin_follows_cost_changes_of_the_map(world):
     signature pass per plan (default), or -- `static_costs` -- only when `<name>.reload_costs` is set."""
     m, _, robot, goal = world
     rm = R.RefMap(m.xyz, m.faces, vertex_costs=np.zeros(m.V, np.float32), edge_cost_factor=1.0)
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_follow")
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_follow", reference_side_effects=True)
     c0, p0, k0, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     cr0, pr0, kr0 = rm.dijkstra_make_plan(pose(robot), pose(goal))
     assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
@@ -172,7 +191,7 @@ def test_gpu_plugin_follows_cost_changes_of_the_map(world):
     assert not np.array_equal(p1, p0) if len(p1) == len(p0) else True
     rm.plugin_release()
     # static_costs: the copy taken at initialize stays ...
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_static", static_costs=True)
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_static", static_costs=True, reference_side_effects=True)
     c2, p2, k2, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     assert c2 == 0 and np.array_equal(p2, pr1)
     rm.update_array_layer(band, np.zeros(band.shape[0], np.float32))       # the band is free again
@@ -193,7 +212,7 @@ def test_gpu_plugin_with_the_cost_observer_layer_updates_only_what_changed(world
     m, _, robot, goal = world
     rm = R.RefMap(m.xyz, m.faces, layers="array+observer", vertex_costs=np.zeros(m.V, np.float32), edge_cost_factor=1.0)
     full0, inc0, sign0 = R.RefMap.gpu_plugin_cost_sync_counts()
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_observed")
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_observed", reference_side_effects=True)
     c0, p0, k0, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     cr0, pr0, kr0 = rm.dijkstra_make_plan(pose(robot), pose(goal))
     assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
@@ -217,7 +236,7 @@ def test_gpu_plugin_with_the_cost_observer_layer_updates_only_what_changed(world
     assert c2 == cr2 == 0 and np.array_equal(p2, pr2) and k2 == kr2
     assert R.RefMap.gpu_plugin_cost_sync_counts() == (full2, inc2 + 1, sign2)
     # the CVP plugin on the same map has its own mirror and its own place in the log
-    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_observed")
+    assert rm.plugin_init("mesh_gpu_planners/GpuCVPMeshPlanner", "gpu_cvp_observed", reference_side_effects=True)
     cc, pc, kc, mc = rm.plugin_make_plan(pose(robot), pose(goal))
     crc, prc, krc, mrc = rm.cvp_make_plan(pose(robot), pose(goal))
     assert cc == crc and mc == mrc and len(pc) == len(prc) and (len(pc) == 0 or np.array_equal(pc, prc))
@@ -233,7 +252,7 @@ def test_gpu_plugin_backstop_sees_what_the_change_signal_cannot(world):
     rng = np.random.default_rng(4)
     costs = rng.uniform(0.0, 0.6, m.V).astype(np.float32)
     rm = R.RefMap(m.xyz, m.faces, layers="array+observer", vertex_costs=costs, edge_cost_factor=1.0)
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_backstop")
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_backstop", reference_side_effects=True)
     c0, p0, k0, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     cr0, pr0, kr0 = rm.dijkstra_make_plan(pose(robot), pose(goal))
     assert c0 == cr0 == 0 and np.array_equal(p0, pr0)
@@ -265,7 +284,7 @@ def test_misconfigured_cost_observer_does_not_attach(world):
     still plans like the reference planner after a change."""
     m, _, robot, goal = world
     rm = R.RefMap(m.xyz, m.faces, layers="array+observer_misconfigured", vertex_costs=np.zeros(m.V, np.float32), edge_cost_factor=1.0)
-    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_unobserved")
+    assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "gpu_dij_unobserved", reference_side_effects=True)
     c0, p0, _, _ = rm.plugin_make_plan(pose(robot), pose(goal))
     full0, inc0, sign0 = R.RefMap.gpu_plugin_cost_sync_counts()
     N = m.N

@@ -40,12 +40,12 @@ def main():
 
     if R.gpu_plugins_linked() and "--no-gpu" not in sys.argv:
         for label, params in () if "--cvp-only" in sys.argv else (("default", {}),
-                              ("no_sync", dict(sync_vector_map=False, publish_potential=False)),
-                              ("no_sync_static", dict(sync_vector_map=False, publish_potential=False, static_costs=True))):
+                              ("reference_side_effects", dict(reference_side_effects=True)),
+                              ("static_costs", dict(static_costs=True))):
             assert rm.plugin_init("mesh_gpu_planners/GpuDijkstraMeshPlanner", "t_dij_" + label, **params)
             rm.plugin_make_plan(pose(robot), pose(goals[0]))            # warm: tables, graphs
             out["gpu_dijkstra_ms_" + label], out["dijkstra_poses"] = timed(lambda g: rm.plugin_make_plan(pose(robot), pose(g)), 10)
-            if observer and label == "no_sync":
+            if observer and label == "default":
                 # a cost change between two plans: 2 000 vertices of the default layer, picked up as ONE incremental update
                 ids = rng.choice(m.V, 2000, replace=False).astype(np.uint32)
                 c0 = R.RefMap.gpu_plugin_cost_sync_counts()
