@@ -123,11 +123,21 @@ __global__ __launch_bounds__(64 * kFinWaves, MNAV_FIN_OCC) void k_tb_finalize(tb
     r[2] = i2 < W.sl ? s[i2] : kTbInfBits; r[3] = i3 < W.sl ? s[i3] : kTbInfBits;
   };
   uint32_t cur[4], nxt[4];
+#ifdef MNAV_FIN_PREFETCH2                                           // (A/B: the slice after the next one in flight too)
+  uint32_t nx2[4] = { kTbInfBits, kTbInfBits, kTbInfBits, kTbInfBits };
+#endif
   load_slice(p_beg, cur);
+#ifdef MNAV_FIN_PREFETCH2
+  if (p_beg + 1 < p_end) load_slice(p_beg + 1, nxt);
+#endif
   uint32_t bad = 0;
   for (uint32_t p = p_beg; p < p_end; ++p) {
     __syncthreads();                                                  // the tiles of the patch write plan p together
+#ifdef MNAV_FIN_PREFETCH2
+    if (p + 2 < p_end) load_slice(p + 2, nx2);
+#else
     if (p + 1 < p_end) load_slice(p + 1, nxt);
+#endif
     const Plan& P = F.plans[p];
     MNAV_GLOBAL float* const g_dist = as_global(P.dist);
     MNAV_GLOBAL uint32_t* const g_pred = as_global(P.pred);
@@ -244,6 +254,10 @@ __global__ __launch_bounds__(64 * kFinWaves, MNAV_FIN_OCC) void k_tb_finalize(tb
     if (lane == 0 && cnt && live) atomicAdd(&F.res[p].settled, (unsigned long long)cnt);
 #pragma unroll
     for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+#ifdef MNAV_FIN_PREFETCH2
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = nx2[q];
+#endif
   }
   bad = wave_sum(bad);
   if (lane == 0 && bad) atomicAdd(F.mismatch, bad);

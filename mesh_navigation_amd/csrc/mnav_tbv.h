@@ -191,7 +191,6 @@ __device__ __forceinline__ uint32_t tbv_sweeps(const uint32_t* sweep0, uint32_t 
   const Uni u = uni(sweep0, nch);
   first_order = tb::rfl(first_order); cap = tb::rfl(cap); force = tb::rfl(force);
   asm volatile(
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
       "v_mov_b32 v64, %[off]\n\t"
       "s_mov_b32 s72, %[stlo]\n\t"
       "s_mov_b32 s73, %[sthi]\n\t"
@@ -232,7 +231,6 @@ __device__ __forceinline__ void tbv_pre(const uint32_t* pre0, uint32_t nch, uint
 {
   const Uni u = uni(pre0, nch);
   asm volatile(
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
       "v_mov_b32 v64, %[off]\n\t"
       "v_mov_b32 v67, 0x7f800000\n\t"
       "v_mov_b32 v65, v67\n\t"
@@ -260,7 +258,6 @@ __device__ __forceinline__ void tbv_post(const uint32_t* post0, uint32_t nch, ui
 {
   const Uni u = uni(post0, nch);
   asm volatile(
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
       "v_mov_b32 v64, %[off]\n\t"
       "v_mov_b32 v67, 0x7f800000\n\t"
       "v_mov_b32 v65, v67\n\t"
@@ -311,12 +308,14 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
 #ifdef MNAV_TB_TIMING
   unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
 #endif
-  for (;;) {
-    uint32_t it = 0;
-    if (lane == 0) it = atomicAdd(&A.ctl->next_item, 1u);
-    it = tb::rfl(it);
-    if (it >= n_items) break;
-    const u32x2 item = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[it];
+  // The ticket of the NEXT item is taken while this item's slice is in flight, its item words while the passes run: two of the four
+  // dependent round trips between two items (ticket -> item words -> tile words / bucket entry -> slice) are off the chain.
+  uint32_t it = 0;
+  if (lane == 0) it = atomicAdd(&A.ctl->next_item, 1u);
+  it = tb::rfl(it);
+  u32x2 item = { 0u, 0u };
+  if (it < n_items) item = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[it];
+  while (it < n_items) {
     const uint32_t t = tb::rfl(item.x), start = tb::rfl(item.y & 0xFFFFu), count = tb::rfl(item.y >> 16);
     const tbv::cwords_t hw = ctiles + (size_t)t * 16u, vw = cvtile + (size_t)t * kTbvTileWords;
     const uint32_t soff = hw[tb::kTwSoff], slen = hw[tb::kTwSl], nh = hw[tb::kTwNh];
@@ -334,7 +333,12 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
       const uint32_t nq = (nh + 3u) >> 2;
       tbv::static_for<0, tbv::kGhostRows / 4>([&](auto q) { if ((uint32_t)decltype(q)::value < nq) tbv::ghost_load_quad<decltype(q)::value>((const void*)sl); });
     }
+    uint32_t it_n = 0;
+    if (lane == 0) it_n = atomicAdd(&A.ctl->next_item, 1u);           // (returns with the slice)
     tbv::img_loads_wait();
+    it_n = tb::rfl(it_n);
+    u32x2 item_n = { 0u, 0u };
+    if (it_n < n_items) item_n = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[it_n];   // in flight during the passes
     TB_STAMP(1);
     // ---- ghosts -> owned (the ghosts are constant during the activation); the order most lanes ask for starts the sweeps
     uint32_t first_order = 0;
@@ -434,6 +438,7 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
       }
     }
     TB_STAMP(6);
+    it = it_n; item = item_n;
   }
 #ifdef MNAV_TB_TIMING
   if (lane == 0) for (int k = 0; k < 8; ++k) if (tt[k]) atomicAdd(&g_tb_timing[k], tt[k]);

@@ -118,3 +118,36 @@ def test_c2_batch_equals_oracle_and_tile_rounds(gpu_ctx_factory):
         assert np.array_equal(b["paths"][k], p["paths"][k]), k
     assert st["settled"] == p["stats"]["settled"]                     # popped vertices, counted by both engines
     ctx.close()
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_both_solve_kernels_of_the_tile_batch_engine(gpu_ctx_factory, kernel):
+    """The engine solves its tiles with k_tb_solve_q (16 plans per quarter of a wave, distances in LDS) or with k_tbv_solve (one wave per
+    tile, <= 64 plans, distances and ghosts in a window of VGPRs addressed through the VGPR index mode, mnav_tbv.h) -- `auto` picks by
+    the plans a tile sees per iteration, option "tb_kernel" forces one.  Both against the oracle on the same batch: paths, popped
+    potential, the V-sized outputs through the finalize pass; costs, a cost limit, invalid vertices and unreachable targets in the
+    batch; and mnav_last_engine says which one ran."""
+    mesh = meshgen.terrain(160, 0.1, 6)
+    rng = np.random.default_rng(17)
+    costs = rng.uniform(0.0, 1.3, mesh.V).astype(np.float32)
+    inv = (rng.uniform(size=mesh.V) < 0.03).astype(np.uint8)
+    case = Case(mesh, costs, edge_cost_factor=1.0, invalid=inv)
+    ctx = gpu_ctx_factory()
+    ctx.set_option("tb_kernel", kernel)
+    case.upload(ctx)
+    ctx.set_dijkstra_engine("tile_batch")
+    ok = np.flatnonzero((inv == 0) & (costs <= 0.9))
+    n = 200
+    seeds = rng.choice(ok, n, replace=False).astype(np.uint32)
+    targets = rng.choice(ok, n, replace=False).astype(np.uint32)
+    targets[:120] = targets[0]
+    for offset in (0.3, 0.0):
+        b = ctx.plan_dijkstra_batch(seeds, targets, goal_dist_offset=offset, cost_limit=0.9, want_fields=False)
+        assert ("k_tbv_solve" in ctx.last_engine()) == (kernel == 1), ctx.last_engine()
+        check_against_oracle(case, ctx, b, seeds, targets, list(range(0, n, 17)), offset=offset, cost_limit=0.9)
+    bf = ctx.plan_dijkstra_batch(seeds[:100], targets[:100], goal_dist_offset=0.3, cost_limit=0.9, want_fields=True)
+    for k in (0, 33, 99):
+        ref = case.om.dijkstra(case.weights, case.costs, int(seeds[k]), int(targets[k]), goal_dist_offset=0.3, cost_limit=0.9, invalid=case.invalid)
+        assert bf["codes"][k] == ref.code
+        assert np.array_equal(bf["dist"][k].view(np.uint32), ref.dist.view(np.uint32)) and np.array_equal(bf["pred"][k], ref.pred)
+    ctx.close()
