@@ -819,7 +819,7 @@ struct TbState {
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // finalize tables (mnav_tb_finalize.h)
   uint16_t* d_fin_src = nullptr; uint32_t* d_fin_wsrc = nullptr; float* d_fin_w = nullptr; TbFinOvf* d_fin_ovf = nullptr; uint32_t* d_fin_ovf_wsrc = nullptr; float* d_fin_ovf_w = nullptr;
-  uint32_t* d_ghost_gid = nullptr; GoalCut* d_gcs = nullptr; size_t fin_n = 0, fin_novf = 0; bool fin_w_valid = false; uint32_t max_sl = 0;
+  uint32_t* d_ghost_gid = nullptr; uint32_t* d_fin_order = nullptr; struct FinRec* d_recs = nullptr; size_t fin_n = 0, fin_novf = 0; bool fin_w_valid = false; uint32_t max_sl = 0;
   // batch state, sized for cap_np plans
   uint32_t cap_np = 0;
   float* D = nullptr; uint32_t* pend = nullptr; uint8_t* pflag = nullptr; uint32_t* pairs = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;

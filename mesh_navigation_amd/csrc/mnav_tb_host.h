@@ -7,7 +7,7 @@ void tb_free_batch(mnav_ctx* ctx)
   TbState& S = ctx->tb;
   (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.pairs); S.pairs = nullptr; (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
   (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
-  (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target); (void)hipFree(S.d_gcs); S.d_gcs = nullptr;
+  (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target); (void)hipFree(S.d_recs); S.d_recs = nullptr;
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
   for (int k = 0; k < 2; ++k) { if (S.graph[k]) (void)hipGraphExecDestroy(S.graph[k]); S.graph[k] = nullptr; }
   if (S.fill_stream) (void)hipStreamSynchronize(S.fill_stream);
@@ -24,11 +24,11 @@ void tb_free(mnav_ctx* ctx)
   tb_free_batch(ctx);
   for (void* p : { (void*)S.d_tiles, (void*)S.d_stream, (void*)S.d_wsrc, (void*)S.d_exps, (void*)S.d_vaddr, (void*)S.d_vert_tile, (void*)S.d_verts,
                    (void*)S.d_vstream, (void*)S.d_vwsrc, (void*)S.d_vtile, (void*)S.d_vgroups, (void*)S.d_vexps,
-                   (void*)S.d_fin_src, (void*)S.d_fin_wsrc, (void*)S.d_fin_ovf, (void*)S.d_fin_ovf_wsrc, (void*)S.d_ghost_gid })
+                   (void*)S.d_fin_src, (void*)S.d_fin_wsrc, (void*)S.d_fin_ovf, (void*)S.d_fin_ovf_wsrc, (void*)S.d_ghost_gid, (void*)S.d_fin_order })
     if (p) { ctx->alloc_bytes.erase(p); (void)hipFree(p); }
   S.d_tiles = nullptr; S.d_stream = nullptr; S.d_wsrc = nullptr; S.d_exps = nullptr; S.d_vaddr = nullptr; S.d_vert_tile = nullptr; S.d_verts = nullptr;
   S.d_vstream = nullptr; S.d_vwsrc = nullptr; S.d_vtile = nullptr; S.d_vgroups = nullptr; S.d_vexps = nullptr;
-  S.d_fin_src = nullptr; S.d_fin_wsrc = nullptr; S.d_fin_ovf = nullptr; S.d_fin_ovf_wsrc = nullptr; S.d_ghost_gid = nullptr;
+  S.d_fin_src = nullptr; S.d_fin_wsrc = nullptr; S.d_fin_ovf = nullptr; S.d_fin_ovf_wsrc = nullptr; S.d_ghost_gid = nullptr; S.d_fin_order = nullptr;
   (void)hipFree(S.d_fin_w); S.d_fin_w = nullptr; (void)hipFree(S.d_fin_ovf_w); S.d_fin_ovf_w = nullptr; S.fin_w_valid = false;
   S.built = false; S.w_valid = false; S.vert_tile.clear();
   S.count_pending = false; ctx->tb_args_valid = false;
@@ -76,6 +76,19 @@ int tb_build(mnav_ctx* ctx)
     if (dev_upload(ctx, &S.d_fin_ovf_wsrc, ow.data(), ow.size())) return -1;
   }
   if (dev_upload(ctx, &S.d_ghost_gid, H.ghost_gid.data(), H.ghost_gid.size())) return -1;
+  {
+    // k_tb_finalize's workgroups take the tiles in the order of their smallest vertex id: the tiles of a workgroup -- and of the
+    // workgroups running next to it -- then write neighbouring pieces of the vertex-order output arrays (on a row-major grid: a
+    // strip of tiles side by side, whose 11-vertex runs join to whole cache lines in the L2)
+    std::vector<uint32_t> order(H.tiles.size()), key(H.tiles.size(), 0xFFFFFFFFu);
+    for (size_t t = 0; t < H.tiles.size(); ++t) {
+      order[t] = (uint32_t)t;
+      for (uint32_t i = 0; i < H.tiles[t].nv; ++i) key[t] = std::min(key[t], H.verts[H.tiles[t].v0 + i]);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    if (order.empty()) order.push_back(0u);
+    if (dev_upload(ctx, &S.d_fin_order, order.data(), order.size())) return -1;
+  }
   (void)hipFree(S.d_fin_w); S.d_fin_w = nullptr; (void)hipFree(S.d_fin_ovf_w); S.d_fin_ovf_w = nullptr;
   S.fin_n = H.fin_src.size(); S.fin_novf = H.fin_ovf.size(); S.fin_w_valid = false; S.max_sl = H.max_sl;
   HIPCHK(hipMalloc((void**)&S.d_fin_w, 4 * std::max<size_t>(S.fin_n, 1)));
@@ -138,7 +151,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   }
   HIPCHK(hipMalloc((void**)&S.thr, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.bnd, 4 * (size_t)np));
   HIPCHK(hipMalloc((void**)&S.seed, 4 * (size_t)np)); HIPCHK(hipMalloc((void**)&S.target, 4 * (size_t)np));
-  HIPCHK(hipMalloc((void**)&S.d_gcs, sizeof(GoalCut) * (size_t)np));
+  HIPCHK(hipMalloc((void**)&S.d_recs, sizeof(FinRec) * (size_t)np));
   S.cap_np = np;
   return 0;
 }
@@ -198,14 +211,14 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   // potential (with the reference's tentative values beyond goal_dist), predecessors and vector map of every plan, in vertex
   // order, straight from the blocked distances: one wave per (tile, 64 plans), eight tiles per workgroup, mnav_tb_finalize.h
   FinTb F{};
-  F.src = S.d_fin_src; F.w = S.d_fin_w; F.ovf = S.d_fin_ovf; F.ovf_w = S.d_fin_ovf_w; F.verts = S.d_verts; F.ghost_gid = S.d_ghost_gid;
+  F.src = S.d_fin_src; F.w = S.d_fin_w; F.ovf = S.d_fin_ovf; F.ovf_w = S.d_fin_ovf_w; F.verts = S.d_verts; F.ghost_gid = S.d_ghost_gid; F.order = S.d_fin_order;
   F.xyz = ctx->d_xyz; F.vecmaps = ctx->want_vec ? ctx->d_vecptrs : nullptr;
-  F.plans = ctx->d_plans; F.res = ctx->d_res; F.mismatch = ctx->d_mismatch; F.gcs = S.d_gcs;
+  F.plans = ctx->d_plans; F.res = ctx->d_res; F.mismatch = ctx->d_mismatch; F.recs = S.d_recs;
   const uint32_t groups = (S.ntiles + kFinWaves - 1u) / kFinWaves;    // a workgroup = kFinWaves consecutive tiles of the bisection order
   F.plans_per_wave = 64u; F.tiles_per_xcd = (groups + 7u) / 8u; F.max_sl = S.max_sl;
-  hipLaunchKernelGGL(k_tb_fin_plans, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A, ctx->d_plans, S.d_gcs);
+  hipLaunchKernelGGL(k_tb_fin_plans, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A, ctx->d_plans, F.vecmaps, S.d_recs);
   const uint32_t npg = (n + F.plans_per_wave - 1u) / F.plans_per_wave;
-  const size_t lds = 4 * 5 * (size_t)S.max_sl * kFinWaves;
+  const size_t lds = 4 * (size_t)fin_lds_words(S.max_sl, F.vecmaps != nullptr) * kFinWaves;
   const dim3 grid(8u * F.tiles_per_xcd * npg);
   if (S.T == 64) hipLaunchKernelGGL((k_tb_finalize<64>), grid, dim3(64 * kFinWaves), lds, ctx->stream, A, F);
   else if (S.T == 96) hipLaunchKernelGGL((k_tb_finalize<96>), grid, dim3(64 * kFinWaves), lds, ctx->stream, A, F);
