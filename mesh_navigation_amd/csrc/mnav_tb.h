@@ -172,60 +172,70 @@ __global__ __launch_bounds__(kBlock) void k_tb_pairs(tb::Args A)
 }
 
 constexpr uint32_t kTbScanWaves = 8192;                              // persistent waves of k_tb_scan (a row of the list after the other)
-// One listed row per wave and turn.  A row is a chain of dependent round trips (list entry -> the row of pending values and the
-// plans' thresholds -> the bucket's counter -> the bucket entries) and a wave walks a dozen of them per launch: the NEXT row's
-// pending values and thresholds are fetched before the current row is worked on, the list entry after that one too (round 6:
-// 107 -> ~60 us per launch at 7168 plans, where the pass had become a fifth of the engine run).
+// One listed row per wave and turn.  A row is a chain of dependent round trips -- list entry -> the row of pending values and the
+// plans' thresholds -> the bucket's counter -> the bucket entries.  What a turn issues, in this order: (B) the current row is
+// classified (its loads were issued a turn ago) and lane 0 asks the bucket's counter for slots; (A) the NEXT row's loads go out --
+// pending values, thresholds, bounds, the plans' carried minima, and the list entry after that one --, every one of them
+// unconditional at a clamped address; (C) the bucket entries are stored once the counter has answered.  The memory counter counts
+// in order, so (C) waits for the atomic with the loads of (A) still in flight (s_waitcnt vmcnt(5) in the ISA), and (B) of the next
+// turn finds them arrived.  Measured: no faster than the unpipelined loop (102 us per launch at 7168 plans either way) -- the pass
+// is not waiting for memory, it is issuing: ~200 000 listed rows per iteration x 130 instructions, 8 waves per SIMD, for 6-16 %
+// of the lanes holding a value.  (A list of the VALUES instead of the rows was tried too)
 __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
 {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kBlock / 64);
   const uint32_t n_pairs = A.ctl->n_pairs;
+  if (wave >= n_pairs) return;
   MNAV_GLOBAL const uint32_t* const pairs = as_global(A.pairs);
   MNAV_GLOBAL const float* const g_thr = as_global(A.thr);
   MNAV_GLOBAL const float* const g_bnd = as_global(A.bnd);
+  MNAV_GLOBAL uint32_t* const g_pend = as_global(A.pend);
+  MNAV_GLOBAL uint32_t* const g_min = as_global(A.marr[par ^ 1]);
   uint32_t carried = 0;
-  struct Row { uint32_t pr, t, p, pb; float thr, bnd; bool live; };
-  auto fetch = [&](uint32_t pr) {                                     // the loads of one row, all issued together
+  struct Row { uint32_t pr, t, p, pb, pm; float thr, bnd; bool live; };
+  auto fetch = [&](uint32_t pr, bool have) {                          // the loads of one row, all issued together and none of them under a branch
     Row r; r.pr = pr;
-    r.t = pr / A.nblk;
-    const uint32_t blk = pr - r.t * A.nblk;
-    r.p = blk * 64u + (uint32_t)lane;
-    r.live = pr != kNone && r.t < A.ntiles && r.p < A.NP;              // (padding bytes of the flag matrix are never set)
-    r.pb = kTbInfBits; r.thr = 0.f; r.bnd = 0.f;
-    if (r.live) { r.pb = as_global(A.pend)[(size_t)r.t * A.NP + r.p]; r.thr = g_thr[r.p]; r.bnd = g_bnd[r.p]; }
+    const uint32_t t = pr / A.nblk, p = (pr - t * A.nblk) * 64u + (uint32_t)lane;
+    r.live = have && t < A.ntiles && p < A.NP;                         // (padding bytes of the flag matrix are never set)
+    r.t = r.live ? t : 0u; r.p = r.live ? p : 0u;
+    r.pb = g_pend[(size_t)r.t * A.NP + r.p]; r.thr = g_thr[r.p]; r.bnd = g_bnd[r.p]; r.pm = g_min[r.p];
     return r;
   };
   uint32_t k = wave;
-  uint32_t pr_next = (k + nwaves < n_pairs) ? pairs[k + nwaves] : kNone;
-  Row cur = fetch(k < n_pairs ? pairs[k] : kNone);
+  const uint32_t last = n_pairs - 1u;
+  uint32_t pr_next = pairs[min(k + nwaves, last)];
+  Row cur = fetch(pairs[k], true);
   for (; k < n_pairs; k += nwaves) {
-    const uint32_t pr_after = (k + 2u * nwaves < n_pairs) ? pairs[k + 2u * nwaves] : kNone;
-    const Row nxt = fetch(pr_next);                                   // in flight while `cur` is worked on
-    pr_next = pr_after;
-    if (cur.pr != kNone && cur.t < A.ntiles) {
-      const uint32_t t = cur.t, p = cur.p, pb = cur.pb;
-      MNAV_GLOBAL uint32_t* const pe = as_global(A.pend) + ((size_t)t * A.NP + (cur.live ? p : 0u));
-      bool ready = false, keep = false;
-      if (cur.live && pb != kTbInfBits) {
-        const float pv = u2f(pb);
-        if (pv > cur.bnd) *pe = kTbInfBits;
-        else if (pv < cur.thr) { *pe = kTbInfBits; ready = true; }
-        else {
-          keep = true; ++carried;
-          MNAV_GLOBAL uint32_t* pm = as_global(A.marr[par ^ 1]) + p;
-          if (pb < *pm) atomicMin((uint32_t*)pm, pb);                    // plain look first (see k_tb_solve_q)
-        }
-      }
-      if (!__any(keep) && lane == 0) A.pflag[cur.pr] = 0;
-      const unsigned long long m = __ballot(ready);
-      if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));
-        base = tb::rfl(base);
-        if (ready) A.bucket[(size_t)t * A.NP + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
+    // ---- (B) the current row
+    asm volatile("" :: "v"(cur.pb), "v"(cur.thr), "v"(cur.bnd), "v"(cur.pm));   // (all four loads waited for HERE: a value only read under a
+                                                                       // branch stays "in flight" for the compiler on the other path, and it then
+                                                                       // makes room for the next loads by waiting for everything issued since)
+    const uint32_t t = cur.t, p = cur.p, pb = cur.pb;
+    MNAV_GLOBAL uint32_t* const pe = g_pend + ((size_t)t * A.NP + p);
+    bool ready = false, keep = false;
+    if (cur.live && pb != kTbInfBits) {
+      const float pv = u2f(pb);
+      if (pv > cur.bnd) *pe = kTbInfBits;
+      else if (pv < cur.thr) { *pe = kTbInfBits; ready = true; }
+      else {
+        keep = true; ++carried;
+        if (pb < cur.pm) atomicMin((uint32_t*)(g_min + p), pb);       // (cur.pm is a turn old: the minimum only falls, an older value only lets more through)
       }
     }
+    if (!__any(keep) && lane == 0) A.pflag[cur.pr] = 0;
+    const unsigned long long m = __ballot(ready);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&A.bcnt[t], (uint32_t)__popcll(m));   // (+0 when nothing is ready: the atomic is not worth a branch)
+    // ---- (A) the next row's loads, and the list entry after it
+    const bool have_next = k + nwaves < n_pairs;
+    const uint32_t pr_after = pairs[min(k + 2u * nwaves, last)];
+    const Row nxt = fetch(pr_next, have_next);
+    pr_next = pr_after;
+    __builtin_amdgcn_sched_barrier(0);                                 // (the scheduler would pull the read of `base`, and with it the wait, above the loads)
+    // ---- (C) the bucket entries
+    base = tb::rfl(base);
+    if (ready) A.bucket[(size_t)t * A.NP + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)p;
     cur = nxt;
   }
   carried = wave_sum(carried);
