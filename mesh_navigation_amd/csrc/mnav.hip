@@ -48,6 +48,8 @@ namespace {
 #define MNAV_GLOBAL __attribute__((address_space(1)))
 template <class T>
 __device__ __forceinline__ MNAV_GLOBAL T* as_global(T* p) { return (MNAV_GLOBAL T*)p; }
+template <class T>
+__device__ __forceinline__ MNAV_GLOBAL T* as_global(const GPtr<T>& p) { return (MNAV_GLOBAL T*)p.p; }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));   // one Nbr {u, w bits}
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte copy unit
 

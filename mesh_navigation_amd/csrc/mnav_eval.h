@@ -392,32 +392,52 @@ struct Cnt {
   uint32_t pad[2];
 };
 
+// A pointer field of a plan record.  In the device pass element access goes through the GLOBAL address space: a pointer loaded
+// from a record is otherwise a generic one and every access through it a flat_load, which counts on both memory counters and is
+// waited for with vmcnt(0) lgkmcnt(0) -- no two dependent-free loads ever overlap (k_step_wide had 323 of them).  Stored and
+// converted as a plain pointer (same layout in both passes, the host fills in device pointers; `P.dist + v`, atomics, null tests
+// see a T*); only p[i], *p and p-> are typed global.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MNAV_GP __attribute__((address_space(1)))
+#else
+#define MNAV_GP
+#endif
+template <class T> struct GPtr {
+  T* p;
+  GPtr() = default;
+  MNAV_HD GPtr(T* q) : p(q) {}
+  MNAV_HD operator T*() const { return p; }
+  template <class I> MNAV_HD T MNAV_GP& operator[](I i) const { return ((T MNAV_GP*)p)[i]; }
+  MNAV_HD T MNAV_GP& operator*() const { return *(T MNAV_GP*)p; }
+  MNAV_HD T MNAV_GP* operator->() const { return (T MNAV_GP*)p; }
+};
+
 // Constant per-plan parameters + state pointers.  All pointers address the plan's own slices.
 struct Plan {
   uint32_t planner;        // kPlannerDijkstra / kPlannerCvp
   uint32_t V;
   // shared read-only mesh data
-  const uint32_t* row_ptr; // V+1 (Dijkstra gather CSR)
-  const Nbr* nbr;          // 2E
-  const uint32_t* crn_ptr; // V+1 (CVP corners)
-  const Corner* crn;       // 3F
-  const uint8_t* blocked;  // V: CVP free-vertex gate (cost >= limit || invalid), cvp :760,802,825,848
+  GPtr<const uint32_t> row_ptr; // V+1 (Dijkstra gather CSR)
+  GPtr<const Nbr> nbr;          // 2E
+  GPtr<const uint32_t> crn_ptr; // V+1 (CVP corners)
+  GPtr<const Corner> crn;       // 3F
+  GPtr<const uint8_t> blocked;  // V: CVP free-vertex gate (cost >= limit || invalid), cvp :760,802,825,848
   // per-plan state
-  float* dist;             // V  potential
-  PopKey* tkey;            // V  pop key (CVP only)
-  uint32_t* pred;          // V
-  float* dirn;             // V  (CVP)
-  uint32_t* cutf;          // V  (CVP)
-  uint32_t* stamp;         // V  work-list dedup
-  uint32_t* dirty;         // V  step for which a neighbour asked for a re-evaluation
-  uint32_t* list[2];       // work lists, capacity `cap`: vertices to (re-)evaluate in the next step
-  uint32_t* wlist[2];      // waiting lists, capacity `cap`: keyed vertices beyond the band.  They are looked at again when
+  GPtr<float> dist;             // V  potential
+  GPtr<PopKey> tkey;            // V  pop key (CVP only)
+  GPtr<uint32_t> pred;          // V
+  GPtr<float> dirn;             // V  (CVP)
+  GPtr<uint32_t> cutf;          // V  (CVP)
+  GPtr<uint32_t> stamp;         // V  work-list dedup
+  GPtr<uint32_t> dirty;         // V  step for which a neighbour asked for a re-evaluation
+  GPtr<uint32_t> list[2];       // work lists, capacity `cap`: vertices to (re-)evaluate in the next step
+  GPtr<uint32_t> wlist[2];      // waiting lists, capacity `cap`: keyed vertices beyond the band.  They are looked at again when
                            // a neighbour moves (which puts them on the work list) or when the band advances (the epoch
                            // step of the next band processes the whole list), not in every step in between
-  uint32_t* wstamp;        // V  epoch in which the vertex was last appended to a waiting list
+  GPtr<uint32_t> wstamp;        // V  epoch in which the vertex was last appended to a waiting list
   uint32_t cap;
-  Ctl* ctl;                // [2]
-  Cnt* cnt;                // [4]: three rotating step counters + cnt[3] = sticky flags of the plan (kFlag*)
+  GPtr<Ctl> ctl;                // [2]
+  GPtr<Cnt> cnt;                // [4]: three rotating step counters + cnt[3] = sticky flags of the plan (kFlag*)
   // parameters
   float delta;             // band width
   double offset;           // goal_dist_offset
@@ -436,8 +456,8 @@ struct Plan {
   // seed_mask != nullptr.  seed_mask[v]: kInflSeed = lethal vertex (distance 0, fixed from the start :397-402),
   // kInflSeedMute = lethal and invalid (fixed, but its pop is skipped :417), kInflMute = invalid free vertex (is
   // updated, queued and popped like any other, but the pop is skipped before `fixed` is set :417-422: never a support).
-  const uint8_t* seed_mask;
-  float* keyd;             // V  value the vertex sits in the queue with (the last update that re-queued it, :311,:451)
+  GPtr<const uint8_t> seed_mask;
+  GPtr<float> keyd;             // V  value the vertex sits in the queue with (the last update that re-queued it, :311,:451)
   float infl_max;          // max_distance: an update only (re-)queues its vertex while both supports lie within (:311)
 };
 enum : uint8_t { kInflFree = 0, kInflSeed = 1, kInflSeedMute = 2, kInflMute = 3 };

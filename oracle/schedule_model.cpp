@@ -108,7 +108,7 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
     HostOps ops{ &P, &cc, P.list[(j + 1) & 1], (uint32_t)(j + 1), P.wlist[cur.wsel], cur.wbase, cur.epoch };
     const uint32_t* list = P.list[j & 1];
     std::vector<uint32_t> ent(list, list + cur.n);                   // work list, plus the previous band's waiting list in an epoch step
-    if (cur.wread) ent.insert(ent.end(), P.wlist[cur.wsel ^ 1u], P.wlist[cur.wsel ^ 1u] + cur.wread);
+    if (cur.wread) ent.insert(ent.end(), P.wlist[cur.wsel ^ 1u].p, P.wlist[cur.wsel ^ 1u].p + cur.wread);
     const uint32_t nent = (uint32_t)ent.size();
     list = ent.data();
     if (cur.repair == 3) {                                           // band cut: park what lies at or above the cut, keep the work list
@@ -139,7 +139,7 @@ static uint32_t drive(Plan& P, uint32_t planner, int order, Ctl* ctl, Cnt* cnt, 
       if (order == 3 || order >= 4) {
         // snapshot of everything the rules read
         std::vector<float> sd(dist, dist + V), sdir; std::vector<uint32_t> sp(pred, pred + V), scut;
-        std::vector<PopKey> sk(tkey); std::vector<float> skd; if (P.keyd) skd.assign(P.keyd, P.keyd + V);
+        std::vector<PopKey> sk(tkey); std::vector<float> skd; if (P.keyd) skd.assign(P.keyd.p, P.keyd.p + V);
         if (planner == kPlannerCvp) { sdir.assign(dirn, dirn + V); scut.assign(cutf, cutf + V); }
         Plan R = P;
         R.dist = sd.data(); R.pred = sp.data(); R.tkey = sk.data(); if (P.keyd) R.keyd = skd.data();
