@@ -81,7 +81,7 @@ __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: 
 // the per-plan words live in the slot's three TCnt records (48 bytes, unused by this engine otherwise)
 struct PlanWords { uint32_t work, acts, sweeps, epochs, thr, par, nparked[2], head, tail, done, pad; };
 static_assert(sizeof(PlanWords) == 3 * sizeof(TCnt), "PlanWords overlays TilePlan.cnt[3]");
-__device__ __forceinline__ PlanWords* words_of(const TilePlan& P) { return reinterpret_cast<PlanWords*>(P.cnt); }
+__device__ __forceinline__ PlanWords* words_of(const TilePlan& P) { return reinterpret_cast<PlanWords*>(P.cnt.p); }
 constexpr uint32_t kActive = 3u;
 constexpr uint32_t kParkedLists = 4u;    // capacity of a parked list in tiles-of-the-mesh (a tile can be parked, promoted, solved and parked again within a band)
 
@@ -225,24 +225,30 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
     aq::PlanWords* const W = aq::words_of(P);
     uint32_t* const pend = P.pend[0];
     uint32_t* const state = P.pend[1];
-    uint32_t* const dbits = reinterpret_cast<uint32_t*>(P.dist);
+    uint32_t* const dbits = reinterpret_cast<uint32_t*>(P.dist.p);
     if (tid == 0) {
+      // Everything the decision and the solve's header need goes out together -- ONE round trip, then the wake-up value is taken.
+      // (Until round 6: the exchange, the target's distance, thr, par and the seven header words one after the other, each waited
+      // for before the next was issued -- the header words through generic pointers, which the compiler keeps in order with the LDS
+      // stores between them: a dozen round trips per ticket on a path that is nothing but round trips.)
+      uint32_t* const tl = reinterpret_cast<uint32_t*>(P.tlast.p) + t;
+      const uint32_t dtb = aq::ld(dbits + P.target);
+      const uint32_t thr_b = aq::ld(&W->thr), par_b = aq::ld(&W->par);   // (constant while anybody holds a ticket of the plan)
+      const uint32_t tl_b = aq::ld(tl);                                  // (written by the tile's previous solver before it cleared the state)
+      const uint32_t h0w = P.vptr[t], h1w = P.vptr[t + 1], h2w = P.hptr[t], h3w = P.hptr[t + 1], h4w = P.eptr[t], h5w = P.eptr[t + 1], h6w = P.rptr[t];
       const uint32_t v = aq::xchg(pend + t, kInfBits);
-      const float dt = u2f(aq::ld(dbits + P.target));
-      const float bound = (float)((double)dt + fmax(P.offset, 0.0));  // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
+      const float bound = (float)((double)u2f(dtb) + fmax(P.offset, 0.0));   // >= the final goal_dist (dijkstra :296); negative offsets: goal_cut
       s_bound_bits = f2u(bound);
-      s_thr_bits = aq::ld(&W->thr); s_par = aq::ld(&W->par);           // (constant while anybody holds a ticket of the plan)
+      s_thr_bits = thr_b; s_par = par_b;
       uint32_t solve = 0u;
       if (v != kInfBits) {
         if (u2f(v) > bound) {                                         // can never propagate any more (k_tile_round does the same)
-          uint32_t* const tl = reinterpret_cast<uint32_t*>(P.tlast) + t;
-          if (!(u2f(aq::ld(tl)) > -inf_f())) aq::st(tl, f2u(-3.0e38f));   // the finalize pass still has to visit the tile
+          if (!(u2f(tl_b) > -inf_f())) aq::st(tl, f2u(-3.0e38f));         // the finalize pass still has to visit the tile
           ++my_dropped;
         } else {
           solve = 1u;
-          s_hdr[0] = P.vptr[t]; s_hdr[1] = P.vptr[t + 1]; s_hdr[2] = P.hptr[t]; s_hdr[3] = P.hptr[t + 1];
-          s_hdr[4] = P.eptr[t]; s_hdr[5] = P.eptr[t + 1]; s_hdr[6] = P.rptr[t];
-          s_hdr[7] = aq::ld(reinterpret_cast<uint32_t*>(P.tlast) + t);
+          s_hdr[0] = h0w; s_hdr[1] = h1w; s_hdr[2] = h2w; s_hdr[3] = h3w; s_hdr[4] = h4w; s_hdr[5] = h5w; s_hdr[6] = h6w;
+          s_hdr[7] = tl_b;
           s_nq[0] = 0; s_nq[1] = 0; s_nq[2] = 0;
         }
       }
@@ -266,20 +272,25 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       MNAV_GLOBAL const uint32_t* g_verts = as_global(P.verts);
       MNAV_GLOBAL const uint32_t* g_halo_verts = as_global(P.halo_verts);
       MNAV_GLOBAL const uint32_t* g_halo_tile = as_global(P.halo_tile);
+      // The ids, then the distances: every load unconditional at a clamped index, so that all of a level are in flight together
+      // (a load under `if (i < nv)` is waited for before the next branch: six ids and six distances were twelve round trips).
+      const uint32_t nvm = nv ? nv - 1u : 0u, nhm = nh ? nh - 1u : 0u;   // (an empty halo reads the slack behind the array: dev_upload)
       uint32_t gi[VPT];
 #pragma unroll
-      for (int k2 = 0; k2 < VPT; ++k2) { const uint32_t i = tid + k2 * kTileBlock; gi[k2] = (i < nv) ? g_verts[v0 + i] : 0u; }
+      for (int k2 = 0; k2 < VPT; ++k2) gi[k2] = g_verts[v0 + min((uint32_t)tid + k2 * kTileBlock, nvm)];
       uint32_t hi[2];
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) { const uint32_t i = tid + k2 * kTileBlock; hi[k2] = (i < nh) ? g_halo_verts[h0 + i] : 0u; }
+      for (int k2 = 0; k2 < 2; ++k2) hi[k2] = g_halo_verts[h0 + min((uint32_t)tid + k2 * kTileBlock, nhm)];
       stage_tile_graph(P, L, e0, ne, r0, nl, tid);
-      uint32_t orig[VPT];
+      uint32_t orig[VPT], hb[2];
+#pragma unroll
+      for (int k2 = 0; k2 < VPT; ++k2) orig[k2] = aq::ld(dbits + gi[k2]);
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) hb[k2] = aq::ld(dbits + (nh ? hi[k2] : gi[0]));
 #pragma unroll
       for (int k2 = 0; k2 < VPT; ++k2) {
         const uint32_t i = tid + k2 * kTileBlock;
-        orig[k2] = 0u;
         if (i < nv) {
-          orig[k2] = aq::ld(dbits + gi[k2]);
           const float d = u2f(orig[k2]);
           ldu[i] = orig[k2];
           if (d < thr && d <= bound && !(d < tl)) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)i;       // owned sources in [tlast, thr)
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
       for (int k2 = 0; k2 < 2; ++k2) {
         const uint32_t i = tid + k2 * kTileBlock;
         if (i < nh) {
-          const uint32_t b = aq::ld(dbits + hi[k2]); const float d = u2f(b);
+          const uint32_t b = hb[k2]; const float d = u2f(b);
           ldu[nv + i] = b; lh0[i] = b;
           if (d < thr && d <= bound) q0[atomicAdd(&s_nq[0], 1u)] = (uint16_t)(nv + i);
         }
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(kTileBlock) void k_plan_async(const TilePlan* __res
     // ---- retire the ticket: the tile is ours until state[t] is cleared; a wake-up that came in meanwhile is routed here
     if (tid == 0) {
       if (s_solve) {
-        aq::st(reinterpret_cast<uint32_t*>(P.tlast) + t, f2u(thr));
+        aq::st(reinterpret_cast<uint32_t*>(P.tlast.p) + t, f2u(thr));
         aq::add(&W->acts, 1u); aq::add(&W->sweeps, sweep);
         aq::drain();                                                   // the next solver of t reads tlast after its ticket arrived
       }

@@ -24,24 +24,27 @@ struct TCnt { uint32_t minpend; uint32_t acts; uint32_t sweeps; uint32_t pad; };
 
 struct TilePlan {
   uint32_t V, ntiles;
-  const uint32_t *vptr, *verts, *hptr, *halo_verts, *halo_tile, *eptr, *rptr;
-  const uint16_t* rowptr;
-  const uint16_t* col;     // per local edge: local target            } split arrays: 6 B per edge in LDS;
-  const float* tw;         // per local edge: push weight (+inf on padding) } tiles padded to 8 entries
-  float* dist;
-  uint32_t* pend[2];       // per-tile wake-up value (float bits), ping-pong by round parity
-  float* tlast;            // per-tile threshold of its last solve
-  TCtl* ctl;               // [2]
-  TCnt* cnt;               // [3]
+  // (GPtr, mnav_eval.h: element access typed global in the device pass -- a flat_load through a generic pointer may alias the LDS
+  // as far as the compiler knows, so it was kept in order with every LDS store around it: the seven words of a tile header were
+  // seven round trips)
+  GPtr<const uint32_t> vptr, verts, hptr, halo_verts, halo_tile, eptr, rptr;
+  GPtr<const uint16_t> rowptr;
+  GPtr<const uint16_t> col;     // per local edge: local target            } split arrays: 6 B per edge in LDS;
+  GPtr<const float> tw;         // per local edge: push weight (+inf on padding) } tiles padded to 8 entries
+  GPtr<float> dist;
+  GPtr<uint32_t> pend[2];       // per-tile wake-up value (float bits), ping-pong by round parity
+  GPtr<float> tlast;            // per-tile threshold of its last solve
+  GPtr<TCtl> ctl;               // [2]
+  GPtr<TCnt> cnt;               // [3]
   uint32_t seed, target;
   double offset;
   float band;
   uint32_t max_rounds;
   uint32_t max_nv, max_nh, max_ne;
-  const uint32_t* cancel;  // device word set by mnav_cancel (polled by k_plan_async), may be null
+  GPtr<const uint32_t> cancel;  // device word set by mnav_cancel (polled by k_plan_async), may be null
   uint32_t t_lo, t_hi;     // tiles this process owns (sharded single plan, mnav_shard_*); t_hi == 0: all tiles
-  uint32_t* parked;        // asynchronous engine (mnav_async.h): the two parked lists of the plan, 2 x kParkedLists x ntiles tile ids
-  const uint8_t* owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
+  GPtr<uint32_t> parked;        // asynchronous engine (mnav_async.h): the two parked lists of the plan, 2 x kParkedLists x ntiles tile ids
+  GPtr<const uint8_t> owned;    // partitioned mesh (mnav_shard_setup_partition): 1 = this process owns the vertex, 0 = halo copy whose
                            // neighbourhood is incomplete here (its value arrives through the exchange); null: every vertex is owned
   uint32_t pend1_is_state; // asynchronous engine: pend[1] holds the tiles' state words (0 at the end), not wake-up values -- the
                            // finalize pass then tells an untouched tile by tlast and pend[0] alone

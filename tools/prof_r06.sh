@@ -3,6 +3,7 @@
 #                                                            kernel trace, FETCH_SIZE / WRITE_SIZE passes, two SQ_* passes
 #                                         prof_r06.sh c2sq : SQ_* passes of the headline bench command (k_tb_solve_q at 1M)
 #                                         prof_r06.sh c2   : kernel trace + traffic passes of the headline bench command
+#                                         prof_r06.sh cvpsq: kernel trace + SQ_* passes of a batch of 128 CVP plans on the C3 configuration (tools/gpu_cvp_perf.py)
 # One counter group per pass, never combined with a trace domain other than --kernel-trace (MI355X_MICROARCH.md).
 # Outputs under gpurun_out/prof_r06/<what>/; tools/summarize_r06.py turns them into profiles/r06_*.
 cd /tmp && export TMPDIR=/tmp
@@ -13,11 +14,16 @@ rm -rf $OUT && mkdir -p $OUT
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"
 SQ2="SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY"
 SQ3="SQ_WAVES SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD"
+SQ4="SQ_WAIT_ANY SQ_IFETCH SQ_INSTS_VMEM_WR SQ_INSTS_SMEM"
 case $what in
   c4)   CMD="python $R/tools/gpu_c4_batch.py ${PROF_C4_BATCH:-4096}";;
   c2sq|c2) CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu --no-latency --no-configs";;
+  cvpsq) export PERF_BATCHES=128; CMD="python $R/tools/gpu_cvp_perf.py";;
 esac
-if [ $what != c2sq ]; then
+if [ $what = cvpsq ]; then
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+fi
+if [ $what != c2sq ] && [ $what != cvpsq ]; then
   TR="$CMD"; [ $what = c2 ] && TR="python $R/bench.py --steps 3 --warmup 1 --no-cpu --no-latency --no-configs"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $TR > $OUT/trace.log 2>&1
   grep '^{' $OUT/trace.log | tail -1 > $OUT/trace_line.json
@@ -27,7 +33,7 @@ if [ $what != c2sq ]; then
 fi
 if [ $what != c2 ]; then
   i=0
-  for grp in "$SQ1" "$SQ2" "$SQ3"; do
+  for grp in "$SQ1" "$SQ2" "$SQ3" "$SQ4"; do
     i=$((i+1))
     timeout 900 rocprofv3 --pmc $grp --output-format csv -d $OUT/sq_$i -o pmc -- $CMD > $OUT/sq_$i.log 2>&1
   done

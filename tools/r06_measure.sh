@@ -11,6 +11,7 @@ grep -h "inflation it" $O/bench_line.err | tail -3 | cut -c1-200
 bash tools/prof_r06.sh c2 > $O/prof_c2.log 2>&1
 bash tools/prof_r06.sh c2sq > $O/prof_c2sq.log 2>&1
 bash tools/prof_r06.sh c4 > $O/prof_c4.log 2>&1
+bash tools/prof_r06.sh cvpsq > $O/prof_cvpsq.log 2>&1
 timeout 900 python tools/gpu_soak.py 22 > $O/soak.json 2> $O/soak.err; tail -c 600 $O/soak.json; echo
 timeout 500 python tools/gpu_infl_fuzz.py 0 300 > $O/infl_fuzz.json 2> $O/infl_fuzz.err; tail -c 400 $O/infl_fuzz.json; echo
 PERF_BATCHES=128 timeout 300 python tools/gpu_cvp_perf.py > $O/cvp_perf.json 2> $O/cvp_perf.err; tail -2 $O/cvp_perf.json | cut -c1-400

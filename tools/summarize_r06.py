@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 what = sys.argv[1] if len(sys.argv) > 1 else "c4"
-tag = sys.argv[2] if len(sys.argv) > 2 else {"c4": "c4", "c2sq": "c2", "c2": "bench"}[what]
+tag = sys.argv[2] if len(sys.argv) > 2 else {"c4": "c4", "c2sq": "c2", "c2": "bench", "cvpsq": "cvp"}[what]
 G = os.path.join(ROOT, "gpurun_out", "prof_r06", what)
 P = os.path.join(ROOT, "profiles")
 ENGINE = ("k_tb_plan", "k_tb_pairs", "k_tb_scan", "k_tb_items", "k_tb_solve_q", "k_tbv_solve")
@@ -46,7 +46,7 @@ def sq_table(sq, kernels, wall_ns):
     """derived shader-core figures per kernel.  Units (checked against each other in these files): SQ_BUSY_CYCLES counts per shader
     engine (32 of them: busy / 32 = the kernel's cycles); SQ_WAVE_CYCLES, SQ_ACTIVE_INST_*, SQ_WAIT_INST_ANY count wave-quad-cycles
     (4 clocks: SQ_INSTS_VALU == SQ_ACTIVE_INST_VALU for a kernel of plain 4-cycle VALU instructions)."""
-    lines = ["| kernel | launches | cycles (BUSY/32) | waves resident per SIMD | VALU busy of SIMD time | LDS busy of CU time | wave time: issuing / waiting on a counter | VALU : LDS : SALU : VMEM-rd instructions | LDS bank-conflict share |",
+    lines = ["| kernel | launches | cycles (BUSY/32) | waves resident per SIMD | VALU busy of SIMD time | LDS busy of CU time | wave time: issuing / waiting on a counter / waiting for anything | VALU : LDS : SALU : VMEM-rd instructions | LDS bank-conflict share |",
              "|---|---|---|---|---|---|---|---|---|"]
     for k in kernels:
         c = sq.get(k)
@@ -60,7 +60,7 @@ def sq_table(sq, kernels, wall_ns):
         lds = g("SQ_ACTIVE_INST_LDS") / (quads * N_CU) if quads else 0
         wv = g("SQ_WAVE_CYCLES") or 1.0
         lines.append(f"| {k} | {c['SQ_BUSY_CYCLES'][1]} | {cyc:.4g} | {res:.2f} | {100*valu:.1f} % | {100*lds:.1f} % | "
-                     f"{100*g('SQ_ACTIVE_INST_ANY')/wv:.0f} % / {100*g('SQ_WAIT_INST_ANY')/wv:.0f} % | "
+                     f"{100*g('SQ_ACTIVE_INST_ANY')/wv:.0f} % / {100*g('SQ_WAIT_INST_ANY')/wv:.0f} % / {100*g('SQ_WAIT_ANY')/wv:.0f} % | "
                      f"{g('SQ_INSTS_VALU'):.3g} : {g('SQ_INSTS_LDS'):.3g} : {g('SQ_INSTS_SALU'):.3g} : {g('SQ_INSTS_VMEM_RD'):.3g} | "
                      f"{100*g('SQ_LDS_BANK_CONFLICT')/max(g('SQ_ACTIVE_INST_LDS'),1.0):.1f} % |")
     return "\n".join(lines)
@@ -68,7 +68,7 @@ def sq_table(sq, kernels, wall_ns):
 
 def merge_sq():
     sq = {}
-    for sub in ("sq_1", "sq_2", "sq_3"):
+    for sub in ("sq_1", "sq_2", "sq_3", "sq_4"):
         for k, v in counters(sub).items():
             sq.setdefault(k, {}).update(v)
     return sq
@@ -129,6 +129,33 @@ if what in ("c4", "c2"):
         if sq:
             f.write("\n## Shader-core counters (three separate passes)\n\n" + sq_table(sq, [k for k in sq if k.startswith(("k_tb_solve_q", "k_tbv_solve", "k_tb_scan", "k_tb_items", "k_tile_round"))], None) + "\n")
     print("engine ms per batch: rocprof", round(eng_ms, 1), "events", round(ev_ms, 1), "| traffic/algorithmic", round(traffic["ratio_traffic_to_algorithmic"], 3), "-", round(traffic["ratio_high"], 3))
+elif what == "cvpsq":
+    sq = merge_sq()
+    ks = [k for k in sq if k.startswith(("k_step_wide", "k_cvp_ctl", "k_step_repair", "k_step<", "k_cvp_verify"))]
+    rows = []
+    try:
+        for r in csv.DictReader(open(one("trace/**/*kernel_stats.csv"))):
+            rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
+    except SystemExit:
+        pass
+    line = [l for l in open(os.path.join(G, "trace.log")) if l.startswith("{")] if os.path.exists(os.path.join(G, "trace.log")) else []
+    with open(os.path.join(P, "r06_pmc_cvp.md"), "w") as f:
+        f.write("# profiles/r06_pmc_cvp.md — CVP batch of 128 plans on the C3 configuration: kernel trace and shader-core counters\n\n")
+        f.write("MI355X (gfx950). `tools/prof_r06.sh cvpsq`: `rocprofv3 --kernel-trace --stats` and four separate `rocprofv3 --pmc <group>` passes of "
+                "`PERF_BATCHES=128 python tools/gpu_cvp_perf.py` (1M-vertex terrain, Steepness + Inflation costs, 128 plans per batch); sums over all launches.\n\n")
+        if rows:
+            f.write("| kernel | calls | total ms | avg us |\n|---|---|---|---|\n")
+            for n, c, t, a in sorted(rows, key=lambda r: -r[2])[:10]:
+                f.write(f"| {n} | {c} | {t:.3f} | {a:.2f} |\n")
+            f.write("\n")
+        if line:
+            f.write("Line printed by the traced run:\n```json\n" + line[-1].strip()[:1500] + "\n```\n\n")
+        f.write(sq_table(sq, ks, None) + "\n\nRaw sums:\n\n```\n")
+        for k in ks:
+            for c, (v, n) in sorted(sq[k].items()):
+                f.write(f"{k:28s} {c:24s} {v:.6g}  ({n} launches)\n")
+        f.write("```\n")
+    print(open(os.path.join(P, "r06_pmc_cvp.md")).read()[:3000])
 else:
     sq = merge_sq()
     ks = [k for k in sq if k.startswith(("k_tb_solve_q", "k_tbv_solve", "k_dij_finalize", "k_tb_finalize", "k_tb_scan"))]
