@@ -402,11 +402,19 @@ def leg_c3(local_rank, args):
     try:
         ctx.upload_mesh(mesh.xyz, mesh.faces, mesh.edges, vnrm)
         def stack(threshold):
-            t0 = time.perf_counter()
-            ctx.layer_steepness(0, threshold)
-            infl = ctx.layer_inflation(1, 0)                            # InflationLayer defaults
-            ctx.combine_layers([0, 1], [1.0, 1.0], mode="avg", edge_cost_factor=1.0)
-            ms = (time.perf_counter() - t0) * 1e3
+            # three times in a row, every run reported, the MEDIAN quoted: the first call after a host-side phase (seconds of numpy /
+            # scipy with the GPU idle) runs the same 95-step graph up to 16x slower now and then -- same steps, same evaluations, the
+            # launch takes 0.07 ms as always and the wait 81 instead of 5 ms (tools/r06_infl_hunt.sh)
+            runs = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.layer_steepness(0, threshold)
+                infl_r = ctx.layer_inflation(1, 0)                      # InflationLayer defaults
+                ctx.combine_layers([0, 1], [1.0, 1.0], mode="avg", edge_cost_factor=1.0)
+                runs.append(((time.perf_counter() - t0) * 1e3, infl_r))
+            order = sorted(range(3), key=lambda k: runs[k][0])
+            ms, infl = runs[order[1]]
+            infl = dict(infl, ms_wave_of_each_run=[round(r[1]["ms_wave"], 3) for r in runs], stack_ms_of_each_run=[round(r[0], 3) for r in runs])
             vc, w = ctx.download_costs()
             _, lethal = ctx.layer_download(0)
             import scipy.sparse as sp

@@ -1073,13 +1073,17 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > ctx->max_wall_s) {
       ctx->err = "inflation wave exceeded the wall-clock guard"; return -1;
     }
+    const auto t_c0 = std::chrono::steady_clock::now();
     if (run_chunk<kPlannerCvp>(ctx, 1, G, false)) return -1;
+    const auto t_c1 = std::chrono::steady_clock::now();
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    const auto t_c2 = std::chrono::steady_clock::now();
     last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
     if (opt_on(ctx->opt.trace))
-      fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u)\n", last.it,
-              last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used);
+      fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u) host ms: since start %.3f, this chunk's launch %.3f, its wait %.3f\n", last.it,
+              last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used,
+              1e3 * std::chrono::duration<double>(t_c0 - t_start).count(), 1e3 * std::chrono::duration<double>(t_c1 - t_c0).count(), 1e3 * std::chrono::duration<double>(t_c2 - t_c1).count());
     if (last.done) break;
     if (last.exact_wanted) {
       // a band that neither the concurrent steps nor a serial band from a clean state settle (tied pop times around isolated
