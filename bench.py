@@ -30,6 +30,14 @@ import os
 import sys
 import time
 
+# The GPU boxes show 256 CPUs and give the container 16 of them (cgroup cpu.max = 1600000 100000): thread pools sized by the CPU
+# count (OpenBLAS / OpenMP behind numpy, scipy, torch) burn the quota within a period and the whole process -- the thread that
+# waits for the GPU included -- is frozen for the rest of it, up to 85 ms.  That is the "85 ms inflation wave" of the driver's
+# lines of rounds 3-5 (profiles/r06_infl_slow_mode.md: the device's own clock says 4.8 ms, the host waits 80; cpu.stat counts
+# two to four throttled periods per run).  Pools of 8 threads stay inside the quota.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -73,6 +81,7 @@ def main() -> None:
         return cpu_all_cores_child(args)
 
     import torch
+    torch.set_num_threads(8)                                            # (the container's CPU quota: see the top of this file)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -449,6 +449,8 @@ int launch_steps(mnav_ctx* ctx, uint32_t n, uint32_t G, int count, bool wide)
   return 0;
 }
 
+__global__ void k_stamp_to_host(unsigned long long* __restrict__ dst_host) { *dst_host = wall_clock64(); }   // (trace: the device's 100 MHz clock)
+
 template <uint32_t PLANNER>
 int run_chunk(mnav_ctx* ctx, uint32_t n, uint32_t G, bool wide)
 {
@@ -1074,16 +1076,23 @@ int mnav_layer_inflation(mnav_ctx* ctx, uint32_t layer, uint32_t input_layer, do
       ctx->err = "inflation wave exceeded the wall-clock guard"; return -1;
     }
     const auto t_c0 = std::chrono::steady_clock::now();
+    const bool tr = opt_on(ctx->opt.trace);
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ctx->h_res);   // (trace: two device clock stamps in the pinned result record, unused during a wave)
+    if (tr) { HIPCHK(hipEventRecord(ctx->ev[4], ctx->stream)); hipLaunchKernelGGL(k_stamp_to_host, dim3(1), dim3(1), 0, ctx->stream, stamps); }   // (trace: the chunk's time on the DEVICE, apart from the host's wait for it)
     if (run_chunk<kPlannerCvp>(ctx, 1, G, false)) return -1;
+    if (tr) HIPCHK(hipEventRecord(ctx->ev[5], ctx->stream));
     const auto t_c1 = std::chrono::steady_clock::now();
+    if (tr) hipLaunchKernelGGL(k_stamp_to_host, dim3(1), dim3(1), 0, ctx->stream, stamps + 1);
     HIPCHK(hipMemcpyAsync(ctx->h_ctl, ctx->d_ctl_pool, 2 * sizeof(Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const auto t_c2 = std::chrono::steady_clock::now();
+    float dev_ms = 0.f;
+    if (tr) (void)hipEventElapsedTime(&dev_ms, ctx->ev[4], ctx->ev[5]);
     last = ctx->h_ctl[0].it > ctx->h_ctl[1].it ? ctx->h_ctl[0] : ctx->h_ctl[1];
     if (opt_on(ctx->opt.trace))
-      fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u) host ms: since start %.3f, this chunk's launch %.3f, its wait %.3f\n", last.it,
+      fprintf(stderr, "[mnav] inflation it %d n %u thr %.6f fixed %.6f width %.4g bands %u band_steps %u shrinks %u cuts %u repair %u evals %u wread %u wbase %u done %u (verify sweeps of the previous wave %u) host ms: since start %.3f, this chunk's launch %.3f, its wait %.3f, the chunk on the device %.3f, by the device's own clock %.3f\n", last.it,
               last.n, last.thr, last.thr_fixed, last.width, last.bands, last.band_steps, last.shrinks, last.cuts, last.repair, last.evals, last.wread, last.wbase, last.done, ctx->verify_sweeps_used,
-              1e3 * std::chrono::duration<double>(t_c0 - t_start).count(), 1e3 * std::chrono::duration<double>(t_c1 - t_c0).count(), 1e3 * std::chrono::duration<double>(t_c2 - t_c1).count());
+              1e3 * std::chrono::duration<double>(t_c0 - t_start).count(), 1e3 * std::chrono::duration<double>(t_c1 - t_c0).count(), 1e3 * std::chrono::duration<double>(t_c2 - t_c1).count(), dev_ms, tr ? (double)(stamps[1] - stamps[0]) * 1e-5 : 0.0);
     if (last.done) break;
     if (last.exact_wanted) {
       // a band that neither the concurrent steps nor a serial band from a clean state settle (tied pop times around isolated
