@@ -288,7 +288,7 @@ int mnav_set_band_width(mnav_ctx* ctx, float delta);
 /* Schedule of the Dijkstra planner: 0 = LDS-tiled label-correcting rounds (one launch per round),
  * 1 = the distance-band gather steps that the CVP planner uses,
  * (2, one persistent workgroup per plan, was retired in round 5: -1),
- * 3 = automatic (default): 6 for calls of up to `async_max_batch` = 96 plans (a call whose ticket ring overflows is re-run on 0),
+ * 3 = automatic (default): 6 for calls of up to `async_max_batch` = 160 plans (a call whose ticket ring overflows is re-run on 0),
  *     5 beyond that (batches that also hold >= tiles/1000 plans), else 0,
  * 5 = tile-batch: one plan per lane, the tile's graph as record streams (highest throughput for large batches); its tiles are
  *     solved by k_tbv_solve (one wave per tile, <= 64 plans, the distances in VGPRs) when a tile sees enough plans per iteration

@@ -1332,7 +1332,10 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
       // tile-batch / asynchronous: 1 plan 10.1 / 20 / 6.8, 8 plans 28 / 29 / 9.7, 47 plans 55 / 38 / 22.9, 64 plans 65 / 46 / 27.5
       // (10M mesh: 8 plans 83 / - / 45, 47 plans 243 / - / 182, 64 plans 330 / 340 / 224); it grows linearly with the batch
       // where the tile-batch engine's iterations are shared by all plans: the engines cross at about a hundred plans.
-      engine = (m0 <= opt_u32(ctx->opt.async_max_batch, 96u)) ? 6 : fills ? 5 : 0;
+      // Round 6 (a ticket's round trips cut, mnav_async.h): ms per call, asynchronous / tile-batch, 1M mesh 96 plans 29 / 51,
+      // 128: 36 / 53, 192: 52 / 58, 256: 69 / 60; 10M mesh 96: 261 / 343, 128: 325 / 388, 192: 540 / 470
+      // (profiles/r06_async_crossover.json): the engines now cross at about 160 plans on both meshes.
+      engine = (m0 <= opt_u32(ctx->opt.async_max_batch, 160u)) ? 6 : fills ? 5 : 0;
     }
     if (engine == 5 && m0 > 65535u) engine = 0;                       // (plan ids are 16 bits in the tile-batch buckets)
     if (engine == 1 && offset < 0.0) engine = 0;                      // the band steps arm goal_dist inside the loop: tile rounds for a negative offset
