@@ -658,7 +658,9 @@ def cpu_all_cores_child(args):
     _OM = O.OracleMesh(mesh.xyz, mesh.faces)
     robot = mesh.vertex_at(0.9, 0.9)
     goals = np.random.default_rng(5).choice(mesh.V, size=args.batch, replace=False)
-    cores = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
+    quota = cpu_quota()                                                  # CPUs' worth of time the cgroup grants per period (None: no limit)
+    cores = max(1, min(visible, int(quota))) if quota else visible       # more workers than that are only frozen in turn
     per = 2
     jobs = [(edge_w, costs, [int(goals[(c * per + i) % args.batch]) for i in range(per)], robot, args.offset) for c in range(cores)]
     with mp.get_context("fork").Pool(cores) as pool:
@@ -666,8 +668,23 @@ def cpu_all_cores_child(args):
         ta = time.perf_counter()
         done = sum(pool.map(_oracle_worker, jobs, chunksize=1))
         ta = time.perf_counter() - ta
-    print(json.dumps({"value": done / ta, "unit": "plans/s", "cores": cores,
+    print(json.dumps({"value": done / ta, "unit": "plans/s", "cores": cores, "cpus_visible": visible, "cgroup_cpu_quota": quota,
                       "sample": f"{done} plans, {per} per forked worker, {ta:.2f} s wall"}), flush=True)
+
+
+def cpu_quota():
+    """CPUs' worth of time per period the container's cgroup grants (cgroup v2 cpu.max / v1 cfs quota); None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
 
 
 def _oracle_worker(job):
@@ -765,7 +782,7 @@ def cpu_baseline(mesh, edge_w, costs, first, B, offset=0.3):
         reference_code = {"error": repr(e)[:200]}
     return {"value": n / (t_sum * 1e-3), "unit": "plans/s", "cores": 1, "kind": "port", "reference_code": reference_code, "all_host_cores": all_cores,
             "sample": f"first {n} plans of the first batch, oracle Dijkstra single thread, {wall:.1f} s wall",
-            "ms_per_plan": t_sum / n, "host_cpu": model, "host_cores_available": os.cpu_count(),
+            "ms_per_plan": t_sum / n, "host_cpu": model, "host_cores_available": os.cpu_count(), "cgroup_cpu_quota": cpu_quota(),
             "gpu_paths_match_oracle": bool(ok)}
 
 
