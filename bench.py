@@ -35,8 +35,9 @@ import time
 # waits for the GPU included -- is frozen for the rest of it, up to 85 ms.  That is the "85 ms inflation wave" of the driver's
 # lines of rounds 3-5 (profiles/r06_infl_slow_mode.md: the device's own clock says 4.8 ms, the host waits 80; cpu.stat counts
 # two to four throttled periods per run).  Pools of 8 threads stay inside the quota.
+_POOL = "8" if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else "2"     # (one process per GPU: the ranks share the quota)
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
-    os.environ.setdefault(_v, "8")
+    os.environ.setdefault(_v, _POOL)
 
 import numpy as np
 
@@ -81,7 +82,7 @@ def main() -> None:
         return cpu_all_cores_child(args)
 
     import torch
-    torch.set_num_threads(8)                                            # (the container's CPU quota: see the top of this file)
+    torch.set_num_threads(int(_POOL))                                   # (the container's CPU quota: see the top of this file)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
