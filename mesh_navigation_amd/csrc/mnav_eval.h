@@ -460,6 +460,8 @@ struct Plan {
   GPtr<float> keyd;             // V  value the vertex sits in the queue with (the last update that re-queued it, :311,:451)
   float infl_max;          // max_distance: an update only (re-)queues its vertex while both supports lie within (:311)
 };
+static_assert(sizeof(GPtr<float>) == sizeof(float*) && alignof(GPtr<float>) == alignof(float*), "GPtr: a pointer, nothing else (the host fills plan records with memcpy)");
+static_assert(__is_trivially_copyable(Plan) && __is_trivially_copyable(GPtr<float>), "plan records travel by hipMemcpy");
 enum : uint8_t { kInflFree = 0, kInflSeed = 1, kInflSeedMute = 2, kInflMute = 3 };
 
 // Sticky per-plan flags (P.cnt[3].n_next).  kFlagWalkLimit: a walk over the cascade tree hit its bound and

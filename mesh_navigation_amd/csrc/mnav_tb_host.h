@@ -215,7 +215,10 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
   F.xyz = ctx->d_xyz; F.vecmaps = ctx->want_vec ? ctx->d_vecptrs : nullptr;
   F.plans = ctx->d_plans; F.res = ctx->d_res; F.mismatch = ctx->d_mismatch; F.recs = S.d_recs;
   const uint32_t groups = (S.ntiles + kFinWaves - 1u) / kFinWaves;    // a workgroup = kFinWaves consecutive tiles of the bisection order
-  F.plans_per_wave = 64u; F.tiles_per_xcd = (groups + 7u) / 8u; F.max_sl = S.max_sl;
+#ifndef MNAV_FIN_PPW
+#define MNAV_FIN_PPW 64u                  // plans a wave of k_tb_finalize walks; ms of the pass per 7168-plan batch at 32 / 64 / 128 / 256: 65.8 / 66.1 / 70.6 / 79.3
+#endif
+  F.plans_per_wave = MNAV_FIN_PPW; F.tiles_per_xcd = (groups + 7u) / 8u; F.max_sl = S.max_sl;
   hipLaunchKernelGGL(k_tb_fin_plans, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A, ctx->d_plans, F.vecmaps, S.d_recs);
   const uint32_t npg = (n + F.plans_per_wave - 1u) / F.plans_per_wave;
   const size_t lds = 4 * (size_t)fin_lds_words(S.max_sl, F.vecmaps != nullptr) * kFinWaves;
