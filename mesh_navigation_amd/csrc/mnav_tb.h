@@ -41,7 +41,7 @@ enum { kTwSoff = 0, kTwSl = 1, kTwNv = 2, kTwNh = 3, kTwSweepOff = 4, kTwSweepCh
 static_assert(offsetof(TbTile, exp_n) == 4 * kTwExpN && offsetof(TbTile, sweep_off) == 4 * kTwSweepOff, "TbTile layout");
 
 struct Ctl {
-  uint32_t n_cand[2];        // pending (tile, plan) pairs after / during an iteration, by iteration parity (0 at the end: converged)
+  uint32_t n_cand[2];        // 1: (tile, plan) pairs are pending after / during an iteration, by iteration parity (0 at the end: converged)
   uint32_t n_items, next_item;
   uint32_t err;              // 1: sweep cap hit
   uint32_t iters;
@@ -63,6 +63,7 @@ struct Args {
   double offset; float band;
   uint8_t* pflag; uint32_t nblk;                                     // per (tile, block of 64 plans): 1 = some pend[tile][plan] of the block may be set
   uint32_t* pairs; uint32_t n_flag16;                                // the flagged pairs of the iteration (tile * nblk + block); 16-byte units of the flag matrix
+  unsigned long long* wstat; uint32_t wstat_slots;                  // statistics per persistent wave {items, activations, sweeps, wakes}: k_tb_stats sums them
   uint32_t item_plans;                                               // plans per work item: 16 (a quarter of a wave, k_tb_solve_q) or 64 (a wave, k_tbv_solve)
 };
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_seed(tb::Args A)
   A.pend[(size_t)t * A.NP + p] = 0u;
   A.pflag[(size_t)t * A.nblk + (p >> 6)] = 1;
   A.marr[0][p] = 0u;
-  atomicAdd(&A.ctl->n_cand[0], 1u);
+  A.ctl->n_cand[0] = 1u;                                              // (a flag: see k_tb_scan)
 }
 
 // per plan and iteration: band threshold and goal bound
@@ -143,34 +144,53 @@ __global__ __launch_bounds__(kBlock) void k_tb_plan(tb::Args A, int par)
 // tiles, skipping rows by their flag): 92 600 tiles x 64 blocks of flags per iteration on the 10M mesh, 21 % of the engine run
 // (profiles/r05_c4_kernel_stats.md).  Now k_tb_pairs compacts the set flags into a list (the 5.9 MB flag matrix read as 16-byte
 // units: microseconds) and k_tb_scan gives one wave to each listed row.
+constexpr uint32_t kTbPairUnits = 4;                                 // 16-byte units of the flag matrix per thread of k_tb_pairs
+// (one atomic per WORKGROUP of 256 threads x 4 units = 16 384 flags: the list's counter is one address, and one atomic per wave of 64
+// units was 5 800 atomics in a row at the L2 on the 10M mesh -- 52 us for a pass that reads 6 MB)
 __global__ __launch_bounds__(kBlock) void k_tb_pairs(tb::Args A)
 {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  u32x4 f = { 0u, 0u, 0u, 0u };
-  if (i < A.n_flag16) f = ((MNAV_GLOBAL const u32x4*)as_global(A.pflag))[i];
-  const uint32_t w[4] = { f.x, f.y, f.z, f.w };
+  __shared__ uint32_t s_wave[kBlock / 64], s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * kTbPairUnits;
+  u32x4 f[kTbPairUnits];
   uint32_t c = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) c += ((w[k] >> (8 * b)) & 0xFFu) ? 1u : 0u;
-  uint32_t incl = c;                                                 // inclusive scan over the wave, one atomic per wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
-  const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
-  uint32_t base = 0;
-  if (lane == 63 && tot) base = atomicAdd(&A.ctl->n_pairs, tot);
-  base = (uint32_t)__shfl((int)base, 63) + incl - c;
-  if (c) {
+  for (uint32_t u = 0; u < kTbPairUnits; ++u) {
+    f[u] = u32x4{ 0u, 0u, 0u, 0u };
+    if (i0 + u < A.n_flag16) f[u] = ((MNAV_GLOBAL const u32x4*)as_global(A.pflag))[i0 + u];
+    const uint32_t w[4] = { f[u].x, f[u].y, f[u].z, f[u].w };
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if ((w[k] >> (8 * b)) & 0xFFu) A.pairs[base++] = 16u * i + 4u * k + b;
+      for (int b = 0; b < 4; ++b) c += ((w[k] >> (8 * b)) & 0xFFu) ? 1u : 0u;
+  }
+  uint32_t incl = c;                                                 // inclusive scan over the wave, then over the workgroup's waves
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { const uint32_t x = s_wave[w]; s_wave[w] = tot; tot += x; }
+    s_base = tot ? atomicAdd(&A.ctl->n_pairs, tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = s_base + s_wave[wave] + incl - c;
+  if (c) {
+#pragma unroll
+    for (uint32_t u = 0; u < kTbPairUnits; ++u) {
+      const uint32_t w[4] = { f[u].x, f[u].y, f[u].z, f[u].w };
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if ((w[k] >> (8 * b)) & 0xFFu) A.pairs[base++] = 16u * (i0 + u) + 4u * k + b;
+    }
   }
 }
 
+constexpr uint32_t kTbStatSlots = 16384;                             // >= the persistent waves of a solve launch (k_tb_stats)
 constexpr uint32_t kTbScanWaves = 8192;                              // persistent waves of k_tb_scan (a row of the list after the other)
 // One listed row per wave and turn.  A row is a chain of dependent round trips -- list entry -> the row of pending values and the
 // plans' thresholds -> the bucket's counter -> the bucket entries.  What a turn issues, in this order: (B) the current row is
@@ -239,7 +259,9 @@ __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
     cur = nxt;
   }
   carried = wave_sum(carried);
-  if (lane == 0 && carried) atomicAdd(&A.ctl->n_cand[par ^ 1], carried);
+  // "something is still pending" is all anybody asks of this word (the host's loop, the finalize pass): a plain store of 1, not
+  // a count -- 8192 waves adding to ONE address were 8192 atomics in a row at the L2 at the end of every launch
+  if (lane == 0 && carried) A.ctl->n_cand[par ^ 1] = 1u;
 }
 
 constexpr uint32_t kTbItemPlans = 16;     // plans per work item = lanes per quarter of a wave (k_tb_solve_q)
@@ -257,11 +279,45 @@ __global__ __launch_bounds__(kBlock) void k_tb_items(tb::Args A)
   uint32_t incl = k;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
-  const uint32_t tot = (uint32_t)__shfl((int)incl, 63);
-  uint32_t base = 0;
-  if (lane == 63 && tot) base = atomicAdd(&A.ctl->n_items, tot);
-  base = (uint32_t)__shfl((int)base, 63) + incl - k;
+  __shared__ uint32_t s_wave[kBlock / 64], s_base;                    // (one atomic per workgroup: see k_tb_pairs)
+  const int wave = threadIdx.x >> 6;
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { const uint32_t x = s_wave[w]; s_wave[w] = tot; tot += x; }
+    s_base = tot ? atomicAdd(&A.ctl->n_items, tot) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = s_base + s_wave[wave] + incl - k;
   for (uint32_t q = 0; q < k; ++q) A.items[base + q] = make_uint2(t, (q * gran) | (min(gran, c - q * gran) << 16));
+}
+
+// The statistics of the run: every persistent wave of the solve kernels keeps its own four counters (a slot per wave, plain
+// adds), one block sums them into the control record at the end of a chunk of iterations.  (Until round 6 every wave ended with four
+// atomicAdds on the control record: 8192 atomics on ONE cache line in a row at the L2, at the end of every launch.)
+__global__ __launch_bounds__(1024) void k_tb_stats(tb::Args A)
+{
+  __shared__ unsigned long long s_part[16][4];
+  unsigned long long acc[4] = { 0ull, 0ull, 0ull, 0ull };
+  for (uint32_t w = threadIdx.x; w < A.wstat_slots; w += 1024u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += A.wstat[4u * w + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+  if ((threadIdx.x & 63u) == 0u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_part[threadIdx.x >> 6][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t[4] = { 0ull, 0ull, 0ull, 0ull };
+    for (int w = 0; w < 16; ++w)
+      for (int k = 0; k < 4; ++k) t[k] += s_part[w][k];
+    A.ctl->items = t[0]; A.ctl->acts = t[1]; A.ctl->sweeps = t[2]; A.ctl->wakes = t[3];
+  }
 }
 
 // One block of a Gauss-Seidel sweep: the target row is relaxed from up to 7 source rows (dijkstra :331).  No branch: the row is
@@ -464,7 +520,7 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
   const uint32_t NP = A.NP;
   const uint32_t n_items = A.ctl->n_items;
   MNAV_GLOBAL const uint32_t* const stream = as_global(A.stream);
-  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0;
+  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0, my_first = 0;
   for (;;) {
     uint32_t it0 = 0;
     if (lane == 0) it0 = atomicAdd(&A.ctl->next_item, 4u);
@@ -644,8 +700,7 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
         }
         advance(0u, kTbInfBits, false);                                // drain the two stages in flight
         advance(0u, kTbInfBits, false);
-        n_first = wave_sum(n_first);
-        if (lane == 0 && n_first) atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
+        my_first |= n_first;                                           // (per lane; one store per wave at the end, mnav_tbv.h)
       }
       TB_STAMP(5);
       // ---- export the lowered boundary values to the ghost slots that mirror them.  The records {row, soff, sl, off} are read
@@ -674,9 +729,10 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
   if (lane == 0) for (int k = 0; k < 8; ++k) if (tt[k]) atomicAdd(&g_tb_timing[k], tt[k]);
 #endif
   my_wakes = wave_sum(my_wakes); my_acts = wave_sum(my_acts);
-  if (lane == 0 && my_items) {
-    atomicAdd(&A.ctl->items, (unsigned long long)my_items); atomicAdd(&A.ctl->acts, (unsigned long long)my_acts);
-    atomicAdd(&A.ctl->sweeps, (unsigned long long)my_sweeps); atomicAdd(&A.ctl->wakes, (unsigned long long)my_wakes);
+  if (__any(my_first != 0u) && lane == 0) A.ctl->n_cand[par ^ 1] = 1u;   // "pairs are pending" (k_tb_scan)
+  if (lane == 0 && my_items && blockIdx.x < A.wstat_slots) {         // (its own slot, a plain read-modify-write: see k_tb_stats)
+    unsigned long long* const ws = A.wstat + 4u * blockIdx.x;
+    ws[0] += (unsigned long long)my_items; ws[1] += (unsigned long long)my_acts; ws[2] += (unsigned long long)my_sweeps; ws[3] += (unsigned long long)my_wakes;
   }
 }
 
@@ -829,7 +885,7 @@ struct TbState {
   uint2* d_vaddr = nullptr; uint32_t* d_vert_tile = nullptr;
   // finalize tables (mnav_tb_finalize.h)
   uint16_t* d_fin_src = nullptr; uint32_t* d_fin_wsrc = nullptr; float* d_fin_w = nullptr; TbFinOvf* d_fin_ovf = nullptr; uint32_t* d_fin_ovf_wsrc = nullptr; float* d_fin_ovf_w = nullptr;
-  uint32_t* d_ghost_gid = nullptr; uint32_t* d_fin_order = nullptr; struct FinRec* d_recs = nullptr; size_t fin_n = 0, fin_novf = 0; bool fin_w_valid = false; uint32_t max_sl = 0;
+  uint32_t* d_ghost_gid = nullptr; uint32_t* d_fin_order = nullptr; unsigned long long* wstat = nullptr; struct FinRec* d_recs = nullptr; size_t fin_n = 0, fin_novf = 0; bool fin_w_valid = false; uint32_t max_sl = 0;
   // batch state, sized for cap_np plans
   uint32_t cap_np = 0;
   float* D = nullptr; uint32_t* pend = nullptr; uint8_t* pflag = nullptr; uint32_t* pairs = nullptr; uint16_t* bucket = nullptr; uint32_t* bcnt = nullptr; uint2* items = nullptr;

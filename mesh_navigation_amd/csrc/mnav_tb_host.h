@@ -5,7 +5,7 @@
 void tb_free_batch(mnav_ctx* ctx)
 {
   TbState& S = ctx->tb;
-  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.pairs); S.pairs = nullptr; (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl);
+  (void)hipFree(S.D); (void)hipFree(S.pend); (void)hipFree(S.pflag); (void)hipFree(S.pairs); S.pairs = nullptr; (void)hipFree(S.bucket); (void)hipFree(S.bcnt); (void)hipFree(S.items); (void)hipFree(S.ctl); (void)hipFree(S.wstat); S.wstat = nullptr;
   (void)hipFree(S.marr[0]); (void)hipFree(S.marr[1]);
   (void)hipFree(S.thr); (void)hipFree(S.bnd); (void)hipFree(S.seed); (void)hipFree(S.target); (void)hipFree(S.d_recs); S.d_recs = nullptr;
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
@@ -145,6 +145,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   HIPCHK(hipMalloc((void**)&S.bcnt, 4 * nt));
   HIPCHK(hipMalloc((void**)&S.items, 8 * (nt + pairs / kTbItemPlans + 64)));
   HIPCHK(hipMalloc((void**)&S.ctl, sizeof(tb::Ctl)));
+  if (!S.wstat) HIPCHK(hipMalloc((void**)&S.wstat, 32 * (size_t)kTbStatSlots));
   HIPCHK(hipHostMalloc((void**)&S.h_ctl, sizeof(tb::Ctl), hipHostMallocDefault));
   for (int k = 0; k < 2; ++k) {
     HIPCHK(hipMalloc((void**)&S.marr[k], 4 * (size_t)np));
@@ -172,7 +173,7 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
   for (int j = 0; j < count; ++j) {
     const int par = j & 1;
     hipLaunchKernelGGL(k_tb_plan, dim3(gp), dim3(kBlock), 0, ctx->stream, A, par);
-    hipLaunchKernelGGL(k_tb_pairs, dim3((A.n_flag16 + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_tb_pairs, dim3((A.n_flag16 + kBlock * kTbPairUnits - 1) / (kBlock * kTbPairUnits)), dim3(kBlock), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_tb_scan, dim3(kTbScanWaves / (kBlock / 64)), dim3(kBlock), 0, ctx->stream, A, par);
     hipLaunchKernelGGL(k_tb_items, dim3((A.ntiles + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
     if (ctx->tb.kernel == 1) hipLaunchKernelGGL((k_tbv_solve<120>), dim3(waves), dim3(64), 0, ctx->stream, A, ctx->tb.d_vtile, ctx->tb.d_vstream, ctx->tb.d_vgroups, ctx->tb.d_vexps, par);
@@ -181,6 +182,7 @@ int tb_launch_iterations(mnav_ctx* ctx, const tb::Args& A, int count, uint32_t w
     else if (ctx->tb.T == 120) hipLaunchKernelGGL((k_tb_solve_q<120>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
     else hipLaunchKernelGGL((k_tb_solve_q<128>), dim3(waves), dim3(64), 0, ctx->stream, A, par);
   }
+  hipLaunchKernelGGL(k_tb_stats, dim3(1), dim3(1024), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -250,7 +252,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   HIPCHK(hipMemsetAsync(ctx->d_mismatch, 0, 4, ctx->stream));
   tb::Args A{};
   A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.pflag = S.pflag; A.nblk = (n + 63u) / 64u; A.NP = n; A.ntiles = S.ntiles;
-  A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl;
+  A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl; A.wstat = S.wstat; A.wstat_slots = kTbStatSlots;
   A.pairs = S.pairs; A.n_flag16 = (uint32_t)(((size_t)S.ntiles * A.nblk + 15u) / 16u);
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
@@ -287,6 +289,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   if (tb_fill(ctx, S.marr[0], 4 * (size_t)n, kTbInfBits)) return -1;
   if (tb_fill(ctx, S.marr[1], 4 * (size_t)n, kTbInfBits)) return -1;
   HIPCHK(hipMemsetAsync(S.ctl, 0, sizeof(tb::Ctl), ctx->stream));
+  HIPCHK(hipMemsetAsync(S.wstat, 0, 32 * (size_t)kTbStatSlots, ctx->stream));
   HIPCHK(hipMemsetAsync(S.bcnt, 0, 4 * (size_t)(S.ntiles ? S.ntiles : 1), ctx->stream));
   hipLaunchKernelGGL(k_tb_seed, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());

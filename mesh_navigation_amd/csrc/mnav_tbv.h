@@ -304,7 +304,7 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
   const uint32_t n_items = tb::rfl(A.ctl->n_items);
   const uint32_t lane_off = 16u * ((uint32_t)lane & 15u);
   const tbv::cwords_t ctiles = tbv::cwords(A.tiles), cvtile = tbv::cwords(vtile), cgroups = tbv::cwords(vgroups);
-  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0;
+  uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0, my_first = 0;
 #ifdef MNAV_TB_TIMING
   unsigned long long tt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, t_last = __builtin_readcyclecounter();
 #endif
@@ -403,8 +403,8 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
           }
       }
       if (mbest != kTbInfBits) atomicMin((uint32_t*)(as_global(A.marr[par ^ 1]) + p), mbest);
-      n_first = wave_sum(n_first);
-      if (lane == 0 && n_first) atomicAdd(&A.ctl->n_cand[par ^ 1], n_first);
+      my_first |= n_first;                                             // (per lane; ONE store per wave at the end: a store per item on
+                                                                       // the one word every wave writes cost 57 ms of 100 -- the next pass waits for it)
     }
     TB_STAMP(5);
     // ---- write back and export.  A lane in which neither a ghost nor a sweep lowered a row has changed nothing: it stores
@@ -444,9 +444,10 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
   if (lane == 0) for (int k = 0; k < 8; ++k) if (tt[k]) atomicAdd(&g_tb_timing[k], tt[k]);
 #endif
   my_wakes = wave_sum(my_wakes); my_acts = wave_sum(my_acts);
-  if (lane == 0 && my_items) {
-    atomicAdd(&A.ctl->items, (unsigned long long)my_items); atomicAdd(&A.ctl->acts, (unsigned long long)my_acts);
-    atomicAdd(&A.ctl->sweeps, (unsigned long long)my_sweeps); atomicAdd(&A.ctl->wakes, (unsigned long long)my_wakes);
+  if (__any(my_first != 0u) && lane == 0) A.ctl->n_cand[par ^ 1] = 1u;   // "pairs are pending" (k_tb_scan)
+  if (lane == 0 && my_items && blockIdx.x < A.wstat_slots) {         // (its own slot, a plain read-modify-write: see k_tb_stats)
+    unsigned long long* const ws = A.wstat + 4u * blockIdx.x;
+    ws[0] += (unsigned long long)my_items; ws[1] += (unsigned long long)my_acts; ws[2] += (unsigned long long)my_sweeps; ws[3] += (unsigned long long)my_wakes;
   }
 }
 
