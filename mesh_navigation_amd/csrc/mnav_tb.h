@@ -63,6 +63,7 @@ struct Args {
   double offset; float band;
   uint8_t* pflag; uint32_t nblk;                                     // per (tile, block of 64 plans): 1 = some pend[tile][plan] of the block may be set
   uint32_t* pairs; uint32_t n_flag16;                                // the flagged pairs of the iteration (tile * nblk + block); 16-byte units of the flag matrix
+  uint32_t nblk_magic, nblk_shift;                                   // pair / nblk as one multiply-high and a shift (tb::div_magic; k_tb_scan divides once per listed row)
   unsigned long long* wstat; uint32_t wstat_slots;                  // statistics per persistent wave {items, activations, sweeps, wakes}: k_tb_stats sums them
   uint32_t item_plans;                                               // plans per work item: 16 (a quarter of a wave, k_tb_solve_q) or 64 (a wave, k_tbv_solve)
 };
@@ -78,6 +79,20 @@ typedef __attribute__((address_space(3))) u32x4* lds_u32x4_t;
 __device__ __forceinline__ u32x4 ldsr4(uint32_t off) { return *(lds_u32x4_t)(uintptr_t)off; }   // uniform address: broadcast
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// n / d for n < 2^31 as one multiply-high and a shift: s = floor(log2 d), M = ceil(2^(32+s) / d) -- M d - 2^(32+s) < d, so the
+// quotient is exact while n d <= 2^(32+s), which n < 2^31 guarantees.  Powers of two take s - 1 (M = 2^31); d == 1 has no such pair.
+inline void div_magic(uint32_t d, uint32_t* magic, uint32_t* shift)
+{
+  if (d <= 1u) { *magic = 0u; *shift = 0u; return; }
+  uint32_t s = 31u - (uint32_t)__builtin_clz(d);
+  if ((d & (d - 1u)) == 0u) s -= 1u;
+  *magic = (uint32_t)(((1ull << (32u + s)) + d - 1ull) / d); *shift = s;
+}
+__device__ __forceinline__ uint32_t div_by_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t shift)
+{
+  return d <= 1u ? n : (__umulhi(n, magic) >> shift);
+}
 
 }  // namespace tb
 
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_tb_scan(tb::Args A, int par)
   struct Row { uint32_t pr, t, p, pb, pm; float thr, bnd; bool live; };
   auto fetch = [&](uint32_t pr, bool have) {                          // the loads of one row, all issued together and none of them under a branch
     Row r; r.pr = pr;
-    const uint32_t t = pr / A.nblk, p = (pr - t * A.nblk) * 64u + (uint32_t)lane;
+    const uint32_t t = tb::div_by_magic(pr, A.nblk, A.nblk_magic, A.nblk_shift), p = (pr - t * A.nblk) * 64u + (uint32_t)lane;
     r.live = have && t < A.ntiles && p < A.NP;                         // (padding bytes of the flag matrix are never set)
     r.t = r.live ? t : 0u; r.p = r.live ? p : 0u;
     r.pb = g_pend[(size_t)r.t * A.NP + r.p]; r.thr = g_thr[r.p]; r.bnd = g_bnd[r.p]; r.pm = g_min[r.p];
@@ -521,10 +536,16 @@ __global__ __launch_bounds__(64) void k_tb_solve_q(tb::Args A, int par)
   const uint32_t n_items = A.ctl->n_items;
   MNAV_GLOBAL const uint32_t* const stream = as_global(A.stream);
   uint32_t my_items = 0, my_acts = 0, my_sweeps = 0, my_wakes = 0, my_first = 0;
+  // The first ticket of a wave is its own index (no atomic: a launch of 2048 waves began with 2048 atomics in a row on one word,
+  // 13 us of every iteration); the counter hands out the tickets behind the grid's.
+  bool first_ticket = true;
   for (;;) {
-    uint32_t it0 = 0;
-    if (lane == 0) it0 = atomicAdd(&A.ctl->next_item, 4u);
-    it0 = tb::rfl(it0);
+    uint32_t it0 = 4u * blockIdx.x;
+    if (!first_ticket) {
+      if (lane == 0) it0 = 4u * gridDim.x + atomicAdd(&A.ctl->next_item, 4u);
+      it0 = tb::rfl(it0);
+    }
+    first_ticket = false;
     if (it0 >= n_items) break;
     // a quarter beyond the last item shadows it and stores nothing
     const u32x2 item = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[min(it0 + q, n_items - 1u)];
@@ -898,7 +919,7 @@ struct TbState {
   hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
   // second distance buffer, filled with +inf on its own stream behind the previous call (the fill of 6 B x slots x plans is
   // otherwise 2 % of a batch); only when both fit comfortably
-  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr;
+  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr, fill_go = nullptr;
   tb::Ctl last{};                       // counters of the last batch
   bool count_pending = false;           // the settled-vertex count of the last (paths-only) batch has not been taken yet
 };

@@ -310,9 +310,8 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
 #endif
   // The ticket of the NEXT item is taken while this item's slice is in flight, its item words while the passes run: two of the four
   // dependent round trips between two items (ticket -> item words -> tile words / bucket entry -> slice) are off the chain.
-  uint32_t it = 0;
-  if (lane == 0) it = atomicAdd(&A.ctl->next_item, 1u);
-  it = tb::rfl(it);
+  // (the first ticket of a wave is its own index, the counter hands out the tickets behind the grid's: see k_tb_solve_q)
+  uint32_t it = blockIdx.x;
   u32x2 item = { 0u, 0u };
   if (it < n_items) item = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[it];
   while (it < n_items) {
@@ -336,7 +335,7 @@ void k_tbv_solve(tb::Args A, const uint32_t* __restrict__ vtile, const uint32_t*
     uint32_t it_n = 0;
     if (lane == 0) it_n = atomicAdd(&A.ctl->next_item, 1u);           // (returns with the slice)
     tbv::img_loads_wait();
-    it_n = tb::rfl(it_n);
+    it_n = gridDim.x + tb::rfl(it_n);
     u32x2 item_n = { 0u, 0u };
     if (it_n < n_items) item_n = ((MNAV_GLOBAL const u32x2*)as_global(A.items))[it_n];   // in flight during the passes
     TB_STAMP(1);

@@ -31,7 +31,7 @@ if [ $what != c2sq ] && [ $what != cvpsq ]; then
     timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- $CMD > $OUT/pmc_$c.log 2>&1
   done
 fi
-if [ $what != c2 ]; then
+if [ $what != c2 ] && [ -z "$PROF_SKIP_SQ" ]; then
   i=0
   for grp in "$SQ1" "$SQ2" "$SQ3" "$SQ4"; do
     i=$((i+1))

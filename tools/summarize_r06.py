@@ -17,7 +17,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "c4"
 tag = sys.argv[2] if len(sys.argv) > 2 else {"c4": "c4", "c2sq": "c2", "c2": "bench", "cvpsq": "cvp"}[what]
 G = os.path.join(ROOT, "gpurun_out", "prof_r06", what)
 P = os.path.join(ROOT, "profiles")
-ENGINE = ("k_tb_plan", "k_tb_pairs", "k_tb_scan", "k_tb_items", "k_tb_solve_q", "k_tbv_solve")
+ENGINE = ("k_tb_plan", "k_tb_pairs", "k_tb_scan", "k_tb_items", "k_tb_solve_q", "k_tbv_solve", "k_tb_stats")
 CLK_GHZ = 2.4          # MI355X peak engine clock (MI355X_MICROARCH.md); the SQ counters below are ratios, the clock only scales the "busy" lines
 N_CU, N_SIMD, N_SE = 256, 1024, 32
 
