@@ -80,18 +80,10 @@ __device__ __forceinline__ u32x4 ldsr4(uint32_t off) { return *(lds_u32x4_t)(uin
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// n / d for n < 2^31 as one multiply-high and a shift: s = floor(log2 d), M = ceil(2^(32+s) / d) -- M d - 2^(32+s) < d, so the
-// quotient is exact while n d <= 2^(32+s), which n < 2^31 guarantees.  Powers of two take s - 1 (M = 2^31); d == 1 has no such pair.
-inline void div_magic(uint32_t d, uint32_t* magic, uint32_t* shift)
-{
-  if (d <= 1u) { *magic = 0u; *shift = 0u; return; }
-  uint32_t s = 31u - (uint32_t)__builtin_clz(d);
-  if ((d & (d - 1u)) == 0u) s -= 1u;
-  *magic = (uint32_t)(((1ull << (32u + s)) + d - 1ull) / d); *shift = s;
-}
+// n / d for n < 2^31 as one multiply-high and a shift (mnav::tb_div_magic, mnav_tb_build.h, makes the pair on the host)
 __device__ __forceinline__ uint32_t div_by_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t shift)
 {
-  return d <= 1u ? n : (__umulhi(n, magic) >> shift);
+  return d <= 1u ? n : (__umulhi(n, magic) >> shift);                  // (= mnav::tb_div_by_magic, the host's copy the CPU test runs)
 }
 
 }  // namespace tb
@@ -919,7 +911,7 @@ struct TbState {
   hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
   // second distance buffer, filled with +inf on its own stream behind the previous call (the fill of 6 B x slots x plans is
   // otherwise 2 % of a batch); only when both fit comfortably
-  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr, fill_go = nullptr;
+  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr;
   tb::Ctl last{};                       // counters of the last batch
   bool count_pending = false;           // the settled-vertex count of the last (paths-only) batch has not been taken yet
 };

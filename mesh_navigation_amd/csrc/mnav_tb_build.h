@@ -174,6 +174,21 @@ inline void tb_bisect(std::vector<uint32_t>& ids, size_t lo, size_t hi, size_t k
 // the block descriptors never pass through the LDS (they were two thirds of the kernel's LDS traffic: four broadcast
 // ds_read_b128 per block against eight ds_read_b32 of data).  The ghost and export streams keep the plain layout (block j =
 // dwords 16 j .. 16 j + 15; they are parked in the LDS staging area).
+// n / d for n < 2^31 as one multiply-high and a shift (k_tb_scan divides a listed pair by the blocks per tile once per row):
+// s = floor(log2 d), M = ceil(2^(32+s) / d) -- M d - 2^(32+s) < d, so the quotient is exact while n d <= 2^(32+s), which n < 2^31
+// guarantees.  Powers of two take s - 1 (M = 2^31); d == 1 has no such pair and is tested for.
+inline void tb_div_magic(uint32_t d, uint32_t* magic, uint32_t* shift)
+{
+  if (d <= 1u) { *magic = 0u; *shift = 0u; return; }
+  uint32_t s = 31u - (uint32_t)__builtin_clz(d);
+  if ((d & (d - 1u)) == 0u) s -= 1u;
+  *magic = (uint32_t)(((1ull << (32u + s)) + d - 1ull) / d); *shift = s;
+}
+inline uint32_t tb_div_by_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t shift)
+{
+  return d <= 1u ? n : ((uint32_t)(((uint64_t)n * magic) >> 32) >> shift);
+}
+
 inline uint32_t tb_sweep_index(uint32_t j, uint32_t q) { return 4u * q + j; }
 
 // V layout of the streams (k_tbv_solve, mnav_tbv.h).  The kernel keeps a tile's distances in a window of VGPRs -- rows 0 ..

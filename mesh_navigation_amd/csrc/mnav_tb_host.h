@@ -136,7 +136,7 @@ int tb_ensure_batch(mnav_ctx* ctx, uint32_t np)
   HIPCHK(hipMalloc((void**)&S.D, 4 * (size_t)S.S * np + 64));
   if (8 * (size_t)S.S * np <= ((size_t)96 << 30) && !opt_on(ctx->opt.tb_no_prefill)) {
     if (hipMalloc((void**)&S.D2, 4 * (size_t)S.S * np + 64) != hipSuccess) { S.D2 = nullptr; (void)hipGetLastError(); }
-    if (S.D2 && !S.fill_stream) { HIPCHK(hipStreamCreateWithFlags(&S.fill_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&S.fill_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.fill_go, hipEventDisableTiming)); }
+    if (S.D2 && !S.fill_stream) { HIPCHK(hipStreamCreateWithFlags(&S.fill_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&S.fill_done, hipEventDisableTiming)); }
   }
   HIPCHK(hipMalloc((void**)&S.pend, 4 * pairs + 64));
   HIPCHK(hipMalloc((void**)&S.pflag, nt * (((size_t)np + 63) / 64) + 64));
@@ -254,7 +254,7 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   A.tiles = S.d_tiles; A.stream = S.d_stream; A.exps = S.d_exps; A.D = S.D; A.pend = S.pend; A.pflag = S.pflag; A.nblk = (n + 63u) / 64u; A.NP = n; A.ntiles = S.ntiles;
   A.bucket = S.bucket; A.bcnt = S.bcnt; A.items = S.items; A.ctl = S.ctl; A.wstat = S.wstat; A.wstat_slots = kTbStatSlots;
   A.pairs = S.pairs; A.n_flag16 = (uint32_t)(((size_t)S.ntiles * A.nblk + 15u) / 16u);
-  tb::div_magic(A.nblk, &A.nblk_magic, &A.nblk_shift);
+  tb_div_magic(A.nblk, &A.nblk_magic, &A.nblk_shift);
   if ((size_t)S.ntiles * A.nblk >= (1ull << 31)) { ctx->err = "tile-batch engine: flag matrix beyond 2^31 entries"; return -1; }
   A.marr[0] = S.marr[0]; A.marr[1] = S.marr[1];
   A.thr = S.thr; A.bnd = S.bnd; A.seed = S.seed; A.target = S.target; A.vaddr = S.d_vaddr; A.vert_tile = S.d_vert_tile;
@@ -302,17 +302,15 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     // engine run the fill would compete with the finalize pass's output writes and, in back-to-back batches, still be
     // running when the next call wants the buffer
     // ... with few workgroups: at full width the fill saturates the HBM write queues and the small kernels of the first
-    // iterations crawl behind it (k_tb_seed / k_tb_plan took 6-7 ms each); 192 workgroups move ~0.4 TB/s, done well within the run
-  }
-  static const int fill_mode = getenv("MNAV_TB_FILL_MODE") ? atoi(getenv("MNAV_TB_FILL_MODE")) : 0;   // A/B: +1 = 48 workgroups, +2 = behind the first chunk of iterations
-  auto launch_fill = [&]() -> int {
+    // iterations crawl behind it (k_tb_seed / k_tb_plan took 6-7 ms each).  Measured round 6 (tools/gpu_tb_modes.py, 7168 plans,
+    // 44 GB to clean): 192 workgroups move 3 TB/s (15 ms) and k_tb_plan / k_tb_seed still show 7 ms launches; 48 workgroups
+    // (60 ms, within the 95 ms run) take 4 ms off the batch; started behind the first 16 iterations instead, the fill slows the
+    // bulk of the run by 8 ms; no second buffer at all costs 4 ms per batch.
     const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
-    hipLaunchKernelGGL(k_tb_fill, dim3((fill_mode & 1) ? 48 : 192), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
+    hipLaunchKernelGGL(k_tb_fill, dim3(48), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
     HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
     S.d2_clean = true; S.d2_clean_np = n;
-    return 0;
-  };
-  if (S.D2 && !(fill_mode & 2) && launch_fill()) return -1;
+  }
 
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -348,11 +346,6 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
     if (ctx->use_graph) HIPCHK(hipGraphLaunch(S.graph[gi], ctx->stream));
     else if (tb_launch_iterations(ctx, A, chunk, waves)) return -1;
     iters += (uint32_t)chunk;
-    if (S.D2 && (fill_mode & 2) && !S.d2_clean) {
-      HIPCHK(hipEventRecord(S.fill_go, ctx->stream));
-      HIPCHK(hipStreamWaitEvent(S.fill_stream, S.fill_go, 0));
-      if (launch_fill()) return -1;
-    }
     HIPCHK(hipMemcpyAsync(S.h_ctl, S.ctl, sizeof(tb::Ctl), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (S.h_ctl->err) { ctx->err = "tile-batch engine: sweep cap hit"; return -1; }

@@ -286,4 +286,21 @@ uint32_t tbm_run(uint32_t V, uint32_t F, uint32_t E, const uint32_t* face_vtx, c
   return 0;
 }
 
+// the pair of mnav::tb_div_magic against the division it replaces: every n of [n_lo, n_hi) in steps of `stride`, and the values
+// around every multiple of d in that range when `edges` is set; returns the number of differences
+unsigned long long tbm_div_magic_check(uint32_t d, uint32_t n_lo, uint32_t n_hi, uint32_t stride, int edges)
+{
+  uint32_t M = 0, s = 0;
+  mnav::tb_div_magic(d, &M, &s);
+  unsigned long long bad = 0;
+  for (uint64_t n = n_lo; n < n_hi; n += stride) bad += mnav::tb_div_by_magic((uint32_t)n, d, M, s) != (uint32_t)n / d;
+  if (edges && d)
+    for (uint64_t m = (uint64_t)(n_lo / d) * d; m < n_hi; m += d)
+      for (int k = -1; k <= 1; ++k) {
+        const uint64_t n = m + (uint64_t)(int64_t)k;
+        if (n >= n_lo && n < n_hi) bad += mnav::tb_div_by_magic((uint32_t)n, d, M, s) != (uint32_t)n / d;
+      }
+  return bad;
+}
+
 }  // extern "C"

@@ -139,3 +139,18 @@ def test_v_layout_streams_of_the_register_resident_kernel():
     f = meshgen.fan_field(spokes=40, rings=6, seed=1)
     r = check(Case(f), [1, f.V - 1], [f.V - 2, 0], tile=120, jacobi=3)
     assert r["max_sweeps"] <= 40
+
+
+def test_pair_division_by_multiply_high():
+    """k_tb_scan splits a listed pair (tile * blocks + block) by one multiply-high and a shift (mnav::tb_div_magic): exact for
+    every numerator below 2^31 -- the host refuses a flag matrix beyond that -- and every number of blocks a batch can have."""
+    import ctypes as C
+    f = O.model_lib().tbm_div_magic_check
+    f.restype = C.c_ulonglong
+    f.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    for d in list(range(1, 1100)) + [4095, 4096, 4097, 65535, 65536]:
+        assert f(d, 0, 1 << 16, 1, 0) == 0, d
+        assert f(d, (1 << 31) - (1 << 16), 1 << 31, 1, 0) == 0, d
+        assert f(d, 0, 1 << 31, 104729, 0) == 0, d
+    for d in (2, 3, 7, 64, 112, 113, 127, 128, 1000, 1024):
+        assert f(d, (1 << 31) - (1 << 22), 1 << 31, 1 << 30, 1) == 0, d

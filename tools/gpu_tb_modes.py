@@ -8,7 +8,7 @@ import sys
 
 CHILD = r'''
 import sys, os, json, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from mesh_navigation_amd import capi, meshgen
 B = int(os.environ.get("B", "7168"))
 mesh = meshgen.terrain(1000, 0.1, 21)
