@@ -1494,6 +1494,7 @@ static uint32_t dijkstra_impl(mnav_ctx* ctx, uint32_t n, const uint32_t* seeds, 
     MTRACE("paths copied out");
     (void)hipEventRecord(ctx->ev[6], ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "sync failed"; return MNAV_INTERNAL_ERROR; }
+    if (engine == 5 && tb_clean_other(ctx)) return MNAV_INTERNAL_ERROR;   // (the next call's distance buffer, in the gap between the calls)
     finish_stats(ctx, m, false);
     MTRACE("stats done");
   }

@@ -911,7 +911,7 @@ struct TbState {
   hipGraphExec_t graph[2] = { nullptr, nullptr }; tb::Args graph_args[2]{};   // one per distance buffer
   // second distance buffer, filled with +inf on its own stream behind the previous call (the fill of 6 B x slots x plans is
   // otherwise 2 % of a batch); only when both fit comfortably
-  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr;
+  float* D2 = nullptr; bool d2_clean = false; uint32_t d2_clean_np = 0, d2_wanted_np = 0; hipStream_t fill_stream = nullptr; hipEvent_t fill_done = nullptr;
   tb::Ctl last{};                       // counters of the last batch
   bool count_pending = false;           // the settled-vertex count of the last (paths-only) batch has not been taken yet
 };

@@ -11,7 +11,7 @@ void tb_free_batch(mnav_ctx* ctx)
   if (S.h_ctl) (void)hipHostFree(S.h_ctl);
   for (int k = 0; k < 2; ++k) { if (S.graph[k]) (void)hipGraphExecDestroy(S.graph[k]); S.graph[k] = nullptr; }
   if (S.fill_stream) (void)hipStreamSynchronize(S.fill_stream);
-  (void)hipFree(S.D2); S.D2 = nullptr; S.d2_clean = false;
+  (void)hipFree(S.D2); S.D2 = nullptr; S.d2_clean = false; S.d2_wanted_np = 0u;
   S.D = nullptr; S.pend = nullptr; S.pflag = nullptr; S.bucket = nullptr; S.bcnt = nullptr; S.items = nullptr; S.ctl = nullptr; S.h_ctl = nullptr;
   S.marr[0] = S.marr[1] = nullptr; S.thr = S.bnd = nullptr; S.seed = S.target = nullptr;
   S.cap_np = 0;
@@ -234,6 +234,27 @@ int tb_fields(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double o
 }
 
 // Dijkstra batches through the tile-batch engine.  Returns 0, -1 (error) or 1 (cancelled).
+// The clean-up of the OTHER distance buffer for the next call, launched by the entry point when this call's last result has been
+// downloaded: on its own stream, with nothing of this call left on the device.  Round 6 measured where it must NOT run
+// (profiles/r06_fill_modes.txt, r06_fill_trace.txt): next to the call's own kernels.  Whatever kernel of the call's stream is in
+// flight when the fill starts does not finish before the fill does -- a 5 us memset took 6.9 ms next to a 7.5 ms fill -- and that
+// is the fill's DURATION, not its rate: 48 / 24 / 12 / 6 workgroups stretched the batch by 0 / 6 / 18 / 40 ms.  So it runs at
+// full width (44 GB in 7 ms at 7168 plans) in the gap the host leaves between two calls; a call that comes sooner waits for the
+// event, which costs what cleaning at its start would.
+int tb_clean_other(mnav_ctx* ctx)
+{
+  TbState& S = ctx->tb;
+  if (!S.D2 || !S.fill_stream || S.d2_wanted_np == 0u || S.d2_clean) return 0;
+  const uint32_t n = S.d2_wanted_np;
+  S.d2_wanted_np = 0u;
+  const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
+  const uint32_t g = (uint32_t)std::max<size_t>(std::min<size_t>((n16 + kBlock - 1) / kBlock, 256 * 32), 1);
+  hipLaunchKernelGGL(k_tb_fill, dim3(g), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
+  HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
+  S.d2_clean = true; S.d2_clean_np = n;
+  return 0;
+}
+
 int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, double offset)
 {
   TbState& S = ctx->tb;
@@ -296,21 +317,9 @@ int run_dijkstra_tb(mnav_ctx* ctx, uint32_t n, const std::vector<PlanIn>& in, do
   hipLaunchKernelGGL(k_tb_seed, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev[2], ctx->stream));
-  if (S.D2) {
-    // the other buffer (the previous call's distances: superseded the moment this call began) is cleaned for the NEXT call
-    // now, on its own stream, next to the solve -- which is latency bound and leaves the HBM write bandwidth idle; behind the
-    // engine run the fill would compete with the finalize pass's output writes and, in back-to-back batches, still be
-    // running when the next call wants the buffer
-    // ... with few workgroups: at full width the fill saturates the HBM write queues and the small kernels of the first
-    // iterations crawl behind it (k_tb_seed / k_tb_plan took 6-7 ms each).  Measured round 6 (tools/gpu_tb_modes.py, 7168 plans,
-    // 44 GB to clean): 192 workgroups move 3 TB/s (15 ms) and k_tb_plan / k_tb_seed still show 7 ms launches; 48 workgroups
-    // (60 ms, within the 95 ms run) take 4 ms off the batch; started behind the first 16 iterations instead, the fill slows the
-    // bulk of the run by 8 ms; no second buffer at all costs 4 ms per batch.
-    const size_t n16 = (4 * (size_t)S.S * n + 15) / 16;
-    hipLaunchKernelGGL(k_tb_fill, dim3(48), dim3(kBlock), 0, S.fill_stream, (u32x4*)S.D2, n16, kTbInfBits);
-    HIPCHK(hipEventRecord(S.fill_done, S.fill_stream));
-    S.d2_clean = true; S.d2_clean_np = n;
-  }
+  // (the other buffer -- the previous call's distances, superseded the moment this call began -- is cleaned for the NEXT call at the
+  // end of this one: tb_clean_other)
+  S.d2_wanted_np = S.D2 ? n : 0u;
 
   int ncu = 256;
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
