@@ -564,6 +564,13 @@ def leg_c4(local_rank, args):
                "batch": B, "plans_per_s_batch": B / tb, "ms_per_batch": tb * 1e3,
                "roofline": roofline_of(sb, batch_kernel),
                "roofline_single_plan": roofline_of(st, "k_plan_async (asynchronous tile engine: one launch per plan)" if st["launches"] == 1 else "k_tile_round")}
+        try:                                                            # HBM bytes of this leg by PMC: a committed profile of the same command, never this run
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r06_c4_final_pmc.json")))
+            if int(pm.get("batch", 0)) == B and int(pm.get("grid", 0)) == N and str(pm.get("kernel", "")) in str(batch_kernel):
+                out["roofline"]["traffic"] = {"profiled": pm["traffic_bytes_per_launch"], "profiled_high": pm.get("traffic_bytes_per_launch_high"),
+                                              "source": "profiles/r06_c4_final_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_c4_batch.py, not this run)"}
+        except (OSError, ValueError, KeyError):
+            pass
         if not args.no_cpu:
             from oracle import oracle as O
             om = O.OracleMesh(mesh.xyz, mesh.faces)
